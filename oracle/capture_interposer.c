@@ -1,0 +1,60 @@
+/*
+ * capture_interposer.c — sits between the unmodified reference EC3D.o and its solver.
+ * TEST INFRASTRUCTURE ONLY; used by oracle/make_goldens.py inside this container.
+ *
+ * EC3D.o calls the external F77 symbol sprsbcgstabwr_ (src/EC3D.f90:408).  In
+ * oracle/_ref/EC3D_capture the reference solver object has had that symbol renamed to
+ * ref_sprsbcgstabwr_ (objcopy, oracle/Makefile), and this file supplies sprsbcgstabwr_:
+ * it writes the call's inputs, forwards to the reference solver, then writes its outputs.
+ *
+ * One file per call: $EC3D_CAPTURE_DIR/call_%04d.bin
+ *   int64 n, nnz, itmax, iter_out; double tol, seconds;
+ *   int32 irow[n+1]; int32 jcol[nnz]; double valA[nnz]; double b[n]; double x_in[n]; double x_out[n]
+ * The matrix is written for call 0 only unless EC3D_CAPTURE_ALL_MATRICES is set (nnz = 0 otherwise).
+ */
+#define _POSIX_C_SOURCE 199309L
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+void ref_sprsbcgstabwr_(double *valA, int32_t *irow, int32_t *jcol, int32_t *n, double *b, double *x,
+                        double *tol, int32_t *itmax, int32_t *iter);
+
+static int ncall = 0;
+
+void sprsbcgstabwr_(double *valA, int32_t *irow, int32_t *jcol, int32_t *n, double *b, double *x,
+                    double *tol, int32_t *itmax, int32_t *iter)
+{
+    const char *dir = getenv("EC3D_CAPTURE_DIR");
+    const char *maxs = getenv("EC3D_CAPTURE_MAX_CALLS");
+    int maxcalls = maxs ? atoi(maxs) : 1 << 30;
+    int64_t nn = *n, nnz = irow[nn] - 1;
+    double *x_in = NULL;
+    if (dir) { x_in = malloc((size_t)nn * 8); memcpy(x_in, x, (size_t)nn * 8); }
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    ref_sprsbcgstabwr_(valA, irow, jcol, n, b, x, tol, itmax, iter);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    double sec = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+    fprintf(stderr, "[capture] call %d n=%lld nnz=%lld iter=%d t=%.4fs\n", ncall, (long long)nn,
+            (long long)nnz, *iter, sec);
+    if (dir) {
+        char path[4096];
+        snprintf(path, sizeof path, "%s/call_%04d.bin", dir, ncall);
+        FILE *f = fopen(path, "wb");
+        if (!f) { perror(path); exit(3); }
+        int with_matrix = (ncall == 0) || getenv("EC3D_CAPTURE_ALL_MATRICES");
+        int64_t h[4] = {nn, with_matrix ? nnz : 0, *itmax, *iter};
+        double d[2] = {*tol, sec};
+        fwrite(h, 8, 4, f); fwrite(d, 8, 2, f);
+        fwrite(irow, 4, (size_t)nn + 1, f);
+        if (with_matrix) { fwrite(jcol, 4, (size_t)nnz, f); fwrite(valA, 8, (size_t)nnz, f); }
+        fwrite(b, 8, (size_t)nn, f); fwrite(x_in, 8, (size_t)nn, f); fwrite(x, 8, (size_t)nn, f);
+        fclose(f);
+        free(x_in);
+    }
+    ++ncall;
+    if (ncall >= maxcalls) { fflush(NULL); _Exit(0); }
+}

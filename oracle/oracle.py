@@ -1,0 +1,238 @@
+"""ctypes binding of the CPU oracle.  TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this module; nothing under ``eddy_currents_3d_amd/`` does.  It is the checker, never the product.
+
+* ``liboracle.so``            — our C restatement (oracle/ec3d_oracle.c) of
+                                 /root/reference/src/solvers.f90:3-61 and src/EC3D.f90:465-1049.
+* ``_ref/libref_solver.so``   — the unmodified reference solver compiled with amdflang
+                                 (oracle/Makefile, target ``ref``); used to pin the restatement
+                                 and as the ``"reference"`` CPU baseline.  Run out of process
+                                 (``_ref/ref_solve``) because it keeps 48·n bytes on the stack.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import resource
+import subprocess
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF_DIR = os.path.join(HERE, "_ref")
+
+_f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+_i8p = np.ctypeslib.ndpointer(np.int8, flags="C_CONTIGUOUS")
+
+
+class GpuGeom(C.Structure):
+    """Reduction geometry of the HIP kernels (ec3d_get_reduction_geometry)."""
+    _fields_ = [("n_pad", C.c_int32), ("tile", C.c_int32), ("nblk", C.c_int32),
+                ("threads", C.c_int32), ("xcd_group", C.c_int32)]
+
+
+def build(with_ref: bool = True) -> None:
+    """Compile the checker (and oracle/_ref when /root/reference is present)."""
+    subprocess.run(["make", "-s", "-C", HERE, "all"], check=True)
+    if with_ref and os.path.isdir("/root/reference/src"):
+        subprocess.run(["make", "-s", "-C", HERE, "ref"], check=True)
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        path = os.path.join(HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build(with_ref=False)
+        L = C.CDLL(path)
+        L.oracle_spmv_csr.argtypes = [_f64p, _i32p, _i32p, C.c_int32, _f64p, _f64p]
+        L.oracle_spmv_csr.restype = None
+        L.oracle_dot.argtypes = [_f64p, _f64p, C.c_int64]
+        L.oracle_dot.restype = C.c_double
+        L.oracle_norm2.argtypes = [_f64p, C.c_int64]
+        L.oracle_norm2.restype = C.c_double
+        L.oracle_bicgstab_wr.argtypes = [_f64p, _i32p, _i32p, C.c_int32, _f64p, _f64p, C.c_double,
+                                         C.c_int32, C.POINTER(C.c_int32), C.c_void_p, C.c_void_p,
+                                         C.c_int32]
+        L.oracle_bicgstab_wr.restype = C.c_int
+        L.oracle_dot_gpuorder.argtypes = [C.POINTER(GpuGeom), _f64p, _f64p, C.c_int64]
+        L.oracle_dot_gpuorder.restype = C.c_double
+        L.oracle_bicgstab_wr_gpuorder.argtypes = [C.POINTER(GpuGeom), _f64p, _i32p, _i32p, C.c_int32,
+                                                  _f64p, _f64p, C.c_double, C.c_int32,
+                                                  C.POINTER(C.c_int32), C.c_void_p, C.c_void_p,
+                                                  C.c_int32]
+        L.oracle_bicgstab_wr_gpuorder.restype = C.c_int
+        L.oracle_gen_sparse_matrix.argtypes = [C.c_int32, C.c_int32, C.c_int32, _i8p, _i32p, _f64p,
+                                               C.c_int32, _f64p, _f64p, C.c_double, _i32p,
+                                               C.c_void_p, C.c_void_p, C.POINTER(C.c_int64),
+                                               C.POINTER(C.c_int32), C.c_void_p, _i32p]
+        L.oracle_gen_sparse_matrix.restype = C.c_int
+        L.oracle_poisson_csr.argtypes = [C.c_int32, C.c_int32, C.c_int32, _f64p, _f64p, _i32p,
+                                         C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+        L.oracle_poisson_csr.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+# --------------------------------------------------------------------------------------------
+def spmv_csr(valA, irow, jcol, v):
+    n = len(irow) - 1
+    y = np.empty(n)
+    lib().oracle_spmv_csr(valA, irow, jcol, n, np.ascontiguousarray(v, np.float64), y)
+    return y
+
+
+def dot(a, b):
+    return lib().oracle_dot(np.ascontiguousarray(a), np.ascontiguousarray(b), len(a))
+
+
+def norm2(a):
+    return lib().oracle_norm2(np.ascontiguousarray(a), len(a))
+
+
+def _hist(cap):
+    hs = np.full(cap, np.nan)
+    hr = np.full(cap, np.nan)
+    return hs, hr
+
+
+def bicgstab_wr(valA, irow, jcol, b, x0, tol, itmax, hist_cap=0):
+    """Restatement of src/solvers.f90:3-50.  Returns (x, iter, hist_s, hist_r)."""
+    n = len(irow) - 1
+    x = np.array(x0, dtype=np.float64, copy=True)
+    it = C.c_int32(0)
+    hs, hr = _hist(hist_cap)
+    lib().oracle_bicgstab_wr(valA, irow, jcol, n, np.ascontiguousarray(b, np.float64), x, tol, itmax,
+                             C.byref(it), hs.ctypes.data, hr.ctypes.data, hist_cap)
+    return x, it.value, hs, hr
+
+
+def bicgstab_wr_gpuorder(geom, valA, irow, jcol, b, x0, tol, itmax, hist_cap=0):
+    """Same algorithm with the HIP kernels' summation order.  geom: GpuGeom."""
+    n = len(irow) - 1
+    x = np.array(x0, dtype=np.float64, copy=True)
+    it = C.c_int32(0)
+    hs, hr = _hist(hist_cap)
+    lib().oracle_bicgstab_wr_gpuorder(C.byref(geom), valA, irow, jcol, n,
+                                      np.ascontiguousarray(b, np.float64), x, tol, itmax,
+                                      C.byref(it), hs.ctypes.data, hr.ctypes.data, hist_cap)
+    return x, it.value, hs, hr
+
+
+def dot_gpuorder(geom, a, b):
+    return lib().oracle_dot_gpuorder(C.byref(geom), np.ascontiguousarray(a), np.ascontiguousarray(b),
+                                     len(a))
+
+
+def poisson_csr(sdx, sdy, sdz, delta=(0.00333, 0.00333, 0.00333), bnd=-0.95):
+    """Config-2/4 operator: Ax block of a non-conducting box, 1-based CSR."""
+    n = sdx * sdy * sdz
+    BND = np.full(6, float(bnd)) if np.isscalar(bnd) else np.ascontiguousarray(bnd, np.float64)
+    d = np.ascontiguousarray(delta, np.float64)
+    irow = np.empty(n + 1, np.int32)
+    nnz = C.c_int64(0)
+    lib().oracle_poisson_csr(sdx, sdy, sdz, BND, d, irow, None, None, C.byref(nnz))
+    jcol = np.empty(nnz.value, np.int32)
+    valA = np.empty(nnz.value, np.float64)
+    lib().oracle_poisson_csr(sdx, sdy, sdz, BND, d, irow, jcol.ctypes.data, valA.ctypes.data,
+                             C.byref(nnz))
+    return valA, irow, jcol
+
+
+def bar_rhs(N):
+    """G5 / config-2 deterministic RHS: mu0*1e6 on the bar i,k in [N/2-2, N/2+3],
+    j in [N/4, 3N/4] (1-based, inclusive), mu0 = the reference's constant
+    (src/vxc2data.f90:402)."""
+    mu0 = 0.12566370964050292e-05
+    b = np.zeros((N, N, N))  # [k, j, i]
+    lo, hi = N // 2 - 2, N // 2 + 3
+    b[lo - 1:hi, N // 4 - 1:3 * N // 4, lo - 1:hi] = mu0 * 1e6
+    return b.reshape(-1)
+
+
+def gen_sparse_matrix(geoPHYS, geoPHYS_C, valPHYS, BND, delta, dt):
+    """Restatement of src/EC3D.f90:465-1049.  Arrays are [k, j, i] C-order == Fortran (i,j,k).
+    valPHYS: (nsub_glob, 5) array (row n-1 = domain n); BND: (3, 2) array BND[d, s].
+    Returns dict(valA, irow, jcol, n, ncells0, cel_bnd=[X, Y, Z, Ux, Uy, Uz])."""
+    sdz, sdy, sdx = geoPHYS.shape
+    g = np.ascontiguousarray(geoPHYS, np.int8).reshape(-1)
+    gc = np.ascontiguousarray(geoPHYS_C, np.int32).reshape(-1)
+    vp = np.asarray(valPHYS, np.float64)
+    nsub = vp.shape[0]
+    vpf = np.ascontiguousarray(vp.T).reshape(-1)          # column-major valPHYS(n, c)
+    bndf = np.ascontiguousarray(np.asarray(BND, np.float64).T).reshape(-1)  # BND(d, s)
+    d = np.ascontiguousarray(delta, np.float64)
+    ncell = sdx * sdy * sdz
+    nc0 = int(np.count_nonzero(gc))
+    n = 3 * ncell + nc0
+    irow = np.zeros(n + 1, np.int32)
+    nnz = C.c_int64(0)
+    c0 = C.c_int32(0)
+    nb = np.zeros(6, np.int32)
+    rc = lib().oracle_gen_sparse_matrix(sdx, sdy, sdz, g, gc, vpf, nsub, bndf, d, dt, irow, None, None,
+                                        C.byref(nnz), C.byref(c0), None, nb)
+    if rc:
+        raise RuntimeError(f"oracle_gen_sparse_matrix: reference would STOP (code {rc})")
+    jcol = np.empty(nnz.value, np.int32)
+    valA = np.empty(nnz.value, np.float64)
+    lists = [np.empty(max(int(k), 1), np.int32) for k in nb]
+    ptrs = (C.c_void_p * 6)(*[a.ctypes.data for a in lists])
+    nb2 = np.zeros(6, np.int32)
+    rc = lib().oracle_gen_sparse_matrix(sdx, sdy, sdz, g, gc, vpf, nsub, bndf, d, dt, irow,
+                                        jcol.ctypes.data, valA.ctypes.data, C.byref(nnz),
+                                        C.byref(c0), C.cast(ptrs, C.c_void_p), nb2)
+    if rc:
+        raise RuntimeError(f"oracle_gen_sparse_matrix: reference would STOP (code {rc})")
+    return dict(valA=valA, irow=irow, jcol=jcol, n=n, ncells0=c0.value,
+                cel_bnd=[a[:k] for a, k in zip(lists, nb2)])
+
+
+# --------------------------------------------------------------------------------------------
+# out-of-process solves (reference needs an unlimited stack: src/solvers.f90:11-12)
+def have_ref() -> bool:
+    return os.path.exists(os.path.join(REF_DIR, "ref_solve"))
+
+
+def _unlimit_stack():
+    try:
+        resource.setrlimit(resource.RLIMIT_STACK, (resource.RLIM_INFINITY, resource.RLIM_INFINITY))
+    except (ValueError, OSError):
+        soft, hard = resource.getrlimit(resource.RLIMIT_STACK)
+        resource.setrlimit(resource.RLIMIT_STACK, (hard, hard))
+
+
+def solve_process(kind, valA, irow, jcol, b, x0, tol, itmax, nrep=1, capture_stdout=False):
+    """Run ``kind`` in {"reference", "port"} as a child process on one core.
+    Returns (x, iter, seconds[, stdout])."""
+    exe = os.path.join(REF_DIR, "ref_solve") if kind == "reference" else os.path.join(HERE, "oracle_solve")
+    if not os.path.exists(exe):
+        if kind == "port":
+            build(with_ref=False)
+        else:
+            raise FileNotFoundError(exe)
+    n = len(irow) - 1
+    with tempfile.TemporaryDirectory(prefix="ec3d_oracle_") as td:
+        fin, fout = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
+        with open(fin, "wb") as f:
+            np.array([n, len(jcol), itmax, nrep], np.int64).tofile(f)
+            np.array([tol], np.float64).tofile(f)
+            np.ascontiguousarray(irow, np.int32).tofile(f)
+            np.ascontiguousarray(jcol, np.int32).tofile(f)
+            np.ascontiguousarray(valA, np.float64).tofile(f)
+            np.ascontiguousarray(b, np.float64).tofile(f)
+            np.ascontiguousarray(x0, np.float64).tofile(f)
+        p = subprocess.run([exe, fin, fout], preexec_fn=_unlimit_stack, check=True,
+                           stdout=subprocess.PIPE if capture_stdout else None)
+        with open(fout, "rb") as f:
+            it = int(np.fromfile(f, np.int32, 2)[0])
+            sec = float(np.fromfile(f, np.float64, 1)[0])
+            x = np.fromfile(f, np.float64, n)
+    if capture_stdout:
+        return x, it, sec, p.stdout.decode()
+    return x, it, sec
