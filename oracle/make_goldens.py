@@ -1,0 +1,313 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING THE UNMODIFIED REFERENCE in this container.
+
+TEST INFRASTRUCTURE ONLY.  Needs /root/reference and oracle/_ref (``make -C oracle ref``); the
+fixtures it writes are data (inputs + the reference's outputs) and are committed, so nothing here
+runs on the GPU box.
+
+How: oracle/_ref/EC3D_capture is the reference program (all five units compiled as they are with
+amdflang) linked against oracle/capture_interposer.c, which records every call of
+``sprsbcgstabwr_`` (src/EC3D.f90:408): CSR triple, b, x_in, x_out, iter.  Inputs are small ``.vxc``
+files written by this script in the ASCII_READABLE layer encoding (src/vxc2data.f90:297-312), so
+the reference's Python zlib helper (broken under numpy 2) is not involved.
+
+Environment shims only, no source edits: unlimited stack, a ``del`` no-op on PATH
+(src/vxc2data.f90:295), fresh output directory, input named ``in.vxc``.
+"""
+from __future__ import annotations
+
+import base64
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+import zlib
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+sys.path.insert(0, REPO)
+from oracle import oracle as O  # noqa: E402
+
+GOLD = os.path.join(REPO, "tests", "golden")
+EXE = os.path.join(HERE, "_ref", "EC3D_capture")
+LETTER = "123456789:;<=>?@ABCDEFGHIJKLMNOPQRSTUVWXYZ[\\]^_`abcdefghijklmnopqrstuvwxyz"
+
+
+def write_vxc(path, vox, names, lattice_dim, adj=(1, 1, 1)):
+    """vox: uint8 [sdz, sdy, sdx] material ids (0 = air); names: palette <Name> strings (id = idx+1)."""
+    sdz, sdy, sdx = vox.shape
+    with open(path, "w") as f:
+        f.write('<?xml version="1.0" encoding="ISO-8859-1"?>\n<VXC Version="0.94">\n  <Lattice>\n')
+        f.write(f"    <Lattice_Dim>{lattice_dim}</Lattice_Dim>\n")
+        f.write(f"    <X_Dim_Adj>{adj[0]}</X_Dim_Adj>\n    <Y_Dim_Adj>{adj[1]}</Y_Dim_Adj>\n"
+                f"    <Z_Dim_Adj>{adj[2]}</Z_Dim_Adj>\n  </Lattice>\n  <Palette>\n")
+        for i, nm in enumerate(names):
+            f.write(f'    <Material ID="{i + 1}">\n      <Name>{nm}</Name>\n    </Material>\n')
+        f.write('  </Palette>\n  <Structure Compression="ASCII_READABLE">\n')
+        f.write(f"    <X_Voxels>{sdx}</X_Voxels>\n    <Y_Voxels>{sdy}</Y_Voxels>\n"
+                f"    <Z_Voxels>{sdz}</Z_Voxels>\n    <Data>\n")
+        for k in range(sdz):
+            s = "".join("0" if v == 0 else LETTER[v - 1] for v in vox[k].reshape(-1))
+            f.write(f"      <Layer><![CDATA[{s}]]></Layer>\n")
+        f.write("    </Data>\n  </Structure>\n</VXC>\n")
+
+
+def read_shipped_vxc(path):
+    """Decode a shipped ZLIB .vxc into (vox[sdz,sdy,sdx], names, lattice_dim, adj)."""
+    txt = open(path, encoding="latin-1").read()
+    g = lambda tag: re.search(f"<{tag}>(.*?)</{tag}>", txt).group(1)
+    sdx, sdy, sdz = int(g("X_Voxels")), int(g("Y_Voxels")), int(g("Z_Voxels"))
+    names = re.findall(r"<Name>(.*?)</Name>", txt)
+    layers = re.findall(r"<Layer><!\[CDATA\[(.*?)\]\]></Layer>", txt)
+    vox = np.zeros((sdz, sdy, sdx), np.uint8)
+    for k, L in enumerate(layers):
+        vox[k] = np.frombuffer(zlib.decompress(base64.b64decode(L)), np.uint8).reshape(sdy, sdx)
+    return vox, names, g("Lattice_Dim"), (g("X_Dim_Adj"), g("Y_Dim_Adj"), g("Z_Dim_Adj"))
+
+
+def run_reference(vox, names, lattice_dim, adj=(1, 1, 1), max_calls=3, all_matrices=False):
+    """Run EC3D_capture on the given case; returns the list of captured calls (dicts)."""
+    td = tempfile.mkdtemp(prefix="ec3d_gold_")
+    try:
+        write_vxc(os.path.join(td, "in.vxc"), vox, names, lattice_dim, adj)
+        with open(os.path.join(td, "del"), "w") as f:
+            f.write("#!/bin/sh\nexit 0\n")
+        os.chmod(os.path.join(td, "del"), 0o755)
+        cap = os.path.join(td, "cap")
+        os.mkdir(cap)
+        env = dict(os.environ, PATH=td + ":" + os.environ["PATH"], EC3D_CAPTURE_DIR=cap,
+                   EC3D_CAPTURE_MAX_CALLS=str(max_calls))
+        if all_matrices:
+            env["EC3D_CAPTURE_ALL_MATRICES"] = "1"
+        p = subprocess.run([EXE], cwd=td, env=env, preexec_fn=O._unlimit_stack,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        log = p.stdout.decode(errors="replace") + p.stderr.decode(errors="replace")
+        calls = []
+        for fn in sorted(os.listdir(cap)):
+            with open(os.path.join(cap, fn), "rb") as f:
+                n, nnz, itmax, it = np.fromfile(f, np.int64, 4)
+                tol, sec = np.fromfile(f, np.float64, 2)
+                c = dict(n=int(n), itmax=int(itmax), iter=int(it), tol=float(tol), seconds=float(sec))
+                c["irow"] = np.fromfile(f, np.int32, n + 1)
+                if nnz:
+                    c["jcol"] = np.fromfile(f, np.int32, nnz)
+                    c["valA"] = np.fromfile(f, np.float64, nnz)
+                c["b"] = np.fromfile(f, np.float64, n)
+                c["x_in"] = np.fromfile(f, np.float64, n)
+                c["x_out"] = np.fromfile(f, np.float64, n)
+                calls.append(c)
+        if not calls:
+            raise RuntimeError("reference produced no solver call:\n" + log[-4000:])
+        return calls, log
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
+
+
+def parse_log(log):
+    """Pull (delta, dt) echoes out of the reference's stdout for cross-checking."""
+    out = {}
+    for key in ("deltaX", "deltaY", "deltaZ", "DT", "tolerance"):
+        m = re.search(key + r"=\s*([-+0-9.eE]+)", log)
+        if m:
+            out[key] = float(m.group(1))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+MU0 = 0.12566370964050292e-05  # src/vxc2data.f90:402
+
+
+def geometry_tables(vox, conductor_ids, nsub):
+    """Rebuild geoPHYS / geoPHYS_C the way src/vxc2data.f90:316-336, :604-636 does (air split
+    every 500000 cells, U ids = 3*Cells + scan-order index per conducting domain)."""
+    sdz, sdy, sdx = vox.shape
+    v = vox.reshape(-1).astype(np.int32).copy()
+    cells = v.size
+    air = np.flatnonzero(v == 0)
+    j = 0; k = 1                     # counter logic of :320-330
+    for idx in air:
+        j += 1
+        if j == 500000:
+            j = 0; k += 1
+        v[idx] = nsub + k
+    if j == 0:
+        k -= 1
+    nsub_air = k
+    geo = v.reshape(sdz, sdy, sdx).astype(np.int8)
+    geoC = np.zeros(cells, np.int32)
+    m = 0
+    for cid in conductor_ids:
+        idx = np.flatnonzero(v == cid)
+        geoC[idx] = 3 * cells + m + 1 + np.arange(idx.size)
+        m += idx.size
+    return geo, geoC.reshape(sdz, sdy, sdx), nsub_air
+
+
+def save(name, **arrs):
+    os.makedirs(GOLD, exist_ok=True)
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def pack_calls(calls):
+    d = dict(irow=calls[0]["irow"], jcol=calls[0]["jcol"], valA=calls[0]["valA"],
+             iters=np.array([c["iter"] for c in calls], np.int32),
+             tol=np.float64(calls[0]["tol"]), itmax=np.int32(calls[0]["itmax"]))
+    for s, c in enumerate(calls):
+        d[f"b{s}"] = c["b"]; d[f"xin{s}"] = c["x_in"]; d[f"xout{s}"] = c["x_out"]
+    return d
+
+
+def coil_names(extra=""):
+    return [f"axp D=1 SRCx=Fp{extra}", f"axm D=1 SRCx=Fm{extra}", f"ayp D=1 SRCy=Fp{extra}",
+            f"aym D=1 SRCy=Fm{extra}"]
+
+
+def put_coil(vox, ids, k0, k1, j0, j1, i0, i1, w=1):
+    """Rectangular loop in planes k0..k1 (0-based, exclusive ends): +x side, -x side, +y, -y."""
+    axp, axm, ayp, aym = ids
+    vox[k0:k1, j0:j0 + w, i0 + w:i1 - w] = axp
+    vox[k0:k1, j1 - w:j1, i0 + w:i1 - w] = axm
+    vox[k0:k1, j0:j1, i1 - w:i1] = ayp
+    vox[k0:k1, j0:j1, i0:i0 + w] = aym
+
+
+def case_g1():
+    """G1: tiny non-conducting box 8x7x6 with one coil, 3 steps."""
+    vox = np.zeros((6, 7, 8), np.uint8)
+    put_coil(vox, (1, 2, 3, 4), 2, 4, 1, 6, 1, 7)
+    names = coil_names() + ["param tran stop=3m step=1m", "p2 solver tol=1u itmax=10000 dir=g1",
+                            "f1 func Fp=a*cos(p2*f*t) a='100/(dx*dz)' p2='2*pi' f=50 t=t",
+                            "f2 func Fm=a*cos(p2*f*t) a='-100/(dx*dz)' p2='2*pi' f=50 t=t"]
+    calls, log = run_reference(vox, names, "0.005", max_calls=3)
+    geo, geoC, _ = geometry_tables(vox, [], 4)
+    save("g1_nonconducting_8x7x6", vox=vox, geoPHYS=geo, geoPHYS_C=geoC, delta=np.full(3, 0.005),
+         dt=np.float64(1e-3), BND=np.full((3, 2), -0.95), valPHYS=np.zeros((int(geo.max()), 5)),
+         **pack_calls(calls))
+    return calls
+
+
+def conductor_block(shape, k0, j0, i0, dk, dj, di, hole=True):
+    vox = np.zeros(shape, np.uint8)
+    vox[k0:k0 + dk, j0:j0 + dj, i0:i0 + di] = 1
+    if hole:  # through-hole along z, 2x1 cells, walls 3 thick
+        vox[k0:k0 + dk, j0 + 3:j0 + dj - 3, i0 + 3:i0 + di - 3] = 0
+    return vox
+
+
+def case_g2(vel=False, itmax_case=False):
+    """G2 (tol 5e-3 like the shipped inputs; g2i: tol 1e-9 with itmax=25 so the itmax exit of
+    src/solvers.f90:25-28 is taken after 26 iterations): conducting 8x7x6 block with a through-hole in a 16x15x14 box + coil above it; every
+    corner/edge/face/interior U-row branch and both one-sided A-U stencils occur.  With vel=True
+    the conductor also moves (VEX/VEY/VEZ terms of src/EC3D.f90:657-662)."""
+    vox = conductor_block((14, 15, 16), 3, 4, 4, 6, 7, 8)
+    put_coil(vox, (2, 3, 4, 5), 10, 12, 3, 12, 3, 13)
+    cname = "plast D=1 C='mu0*35.26e6'" + (" Vex=1.5 Vey=-0.7 Vez=0.3" if vel else "")
+    names = [cname] + coil_names() + [
+        "param tran stop=3m step=1m",
+        "p2 solver tol=1n itmax=25 dir=g2" if itmax_case else "p2 solver tol=5m itmax=10000 dir=g2",
+        "f1 func Fp=a*cos(p2*f*t) a='183/(dx*2*dz)' p2='2*pi' f=50 t=t",
+        "f2 func Fm=a*cos(p2*f*t) a='-183/(dx*2*dz)' p2='2*pi' f=50 t=t"]
+    calls, log = run_reference(vox, names, "0.004", adj=("1", "1.25", "0.75"), max_calls=3)
+    geo, geoC, _ = geometry_tables(vox, [1], 5)
+    nsubg = int(geo.max())
+    valPHYS = np.zeros((nsubg, 5)); valPHYS[:, 0] = 1.0
+    valPHYS[0, 1] = MU0 * 35.26e6
+    if vel:
+        valPHYS[0, 2:5] = (1.5, -0.7, 0.3)
+    delta = np.array([0.004, 0.004 * 1.25, 0.004 * 0.75])
+    stem = "g2i_itmax_exit_16x15x14" if itmax_case else (
+        "g2v_conducting_moving_16x15x14" if vel else "g2_conducting_hole_16x15x14")
+    save(stem, vox=vox,
+         geoPHYS=geo, geoPHYS_C=geoC, delta=delta, dt=np.float64(1e-3), BND=np.full((3, 2), -0.95),
+         valPHYS=valPHYS, **pack_calls(calls))
+    return calls
+
+
+def case_g3():
+    """G3: moving coil (constant Vsx and a FUNC velocity Vsy) over a conducting plate: b per step."""
+    vox = conductor_block((12, 16, 18), 2, 3, 3, 3, 10, 12, hole=False)
+    put_coil(vox, (2, 3, 4, 5), 7, 9, 4, 10, 4, 10)
+    mv = " Vsx=2.0 Vsy=Vmy"
+    names = ["plast D=1 C='mu0*35.26e6'"] + coil_names(mv) + [
+        "param tran stop=4m step=1m", "p2 solver tol=1m itmax=10000 dir=g3",
+        "f1 func Fp=a*cos(p2*f*t) a='183/(dx*2*dz)' p2='2*pi' f=50 t=t",
+        "f2 func Fm=a*cos(p2*f*t) a='-183/(dx*2*dz)' p2='2*pi' f=50 t=t",
+        "m2 func Vmy=a*p2*f*cos(p2*f*t) a='-dY*3' p2='2*pi' f=100 t=t"]
+    calls, log = run_reference(vox, names, "0.004", max_calls=4)
+    geo, geoC, _ = geometry_tables(vox, [1], 5)
+    nsubg = int(geo.max())
+    valPHYS = np.zeros((nsubg, 5)); valPHYS[:, 0] = 1.0
+    valPHYS[0, 1] = MU0 * 35.26e6
+    save("g3_moving_coil_18x16x12", vox=vox, geoPHYS=geo, geoPHYS_C=geoC, delta=np.full(3, 0.004),
+         dt=np.float64(1e-3), BND=np.full((3, 2), -0.95), valPHYS=valPHYS, **pack_calls(calls))
+    return calls
+
+
+def case_g4():
+    """G4: the three shipped inputs, re-encoded ASCII_READABLE.  Too large to commit whole:
+    keep the voxel grid + palette (inputs), n/nnz/row-length histogram, per-step iter, norms and
+    200 probe values of x."""
+    for stem, steps in (("compare_to_Elmer", 3), ("ec_src_move_hole", 3), ("LIM", 3)):
+        vox, names, ld, adj = read_shipped_vxc(f"/root/reference/src/{stem}.vxc")
+        calls, log = run_reference(vox, names, ld, adj, max_calls=steps)
+        n = calls[0]["n"]
+        rl = np.diff(calls[0]["irow"])
+        hist = np.bincount(rl, minlength=14)
+        rng = np.random.Generator(np.random.PCG64(2024))
+        probes = np.sort(rng.choice(n, 200, replace=False)).astype(np.int64)
+        d = dict(vox=vox, names=np.array(names), lattice_dim=np.array(ld), adj=np.array(adj),
+                 n=np.int64(n), nnz=np.int64(len(calls[0]["jcol"])), rowlen_hist=hist,
+                 iters=np.array([c["iter"] for c in calls], np.int32), tol=np.float64(calls[0]["tol"]),
+                 bnorm=np.array([np.linalg.norm(c["b"]) for c in calls]),
+                 xnorm=np.array([np.linalg.norm(c["x_out"]) for c in calls]),
+                 probes=probes, xprobe=np.stack([c["x_out"][probes] for c in calls]),
+                 bprobe=np.stack([c["b"][probes] for c in calls]),
+                 seconds=np.array([c["seconds"] for c in calls]))
+        print(stem, "iters", d["iters"], "bnorm", d["bnorm"], "xnorm", d["xnorm"])
+        save("g4_" + stem, **d)
+
+
+def case_g5():
+    """G5: reference solver alone on synthetic cubes (config-2 operator, bar RHS, tol 1e-8):
+    iteration count, ||x||, probes, and the first 24 iterates' norms obtained from the UNMODIFIED
+    solver by calling it with itmax = k-1 (it then returns after exactly k iterations and prints
+    norm2(R): src/solvers.f90:25-28)."""
+    for N in (16, 32, 64):
+        valA, irow, jcol = O.poisson_csr(N, N, N)
+        b = O.bar_rhs(N)
+        x0 = np.zeros(N ** 3)
+        x, it, sec = O.solve_process("reference", valA, irow, jcol, b, x0, 1e-8, 100000)
+        K = 24
+        rnorm = np.zeros(K); xk_norm = np.zeros(K)
+        xk_probe = np.zeros((K, 16))
+        rng = np.random.Generator(np.random.PCG64(7))
+        probes = np.sort(rng.choice(N ** 3, 16, replace=False))
+        for k in range(1, K + 1):
+            xk, itk, _, out = O.solve_process("reference", valA, irow, jcol, b, x0, 1e-300, k - 1,
+                                              capture_stdout=True)
+            assert itk == k, (itk, k)
+            rnorm[k - 1] = float(out.split()[-1])
+            xk_norm[k - 1] = np.linalg.norm(xk)
+            xk_probe[k - 1] = xk[probes]
+        print(f"G5 N={N}: iter={it} ||x||={np.linalg.norm(x):.10e} t={sec:.3f}s rnorm[:3]={rnorm[:3]}")
+        save(f"g5_cube{N}", N=np.int32(N), iter=np.int32(it), xnorm=np.linalg.norm(x),
+             rnorm_first=rnorm, xk_norm=xk_norm, probes=probes, xk_probe=xk_probe,
+             x=x if N <= 32 else x[::max(1, N ** 3 // 4096)], seconds=np.float64(sec))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "g2v", "g2i", "g3", "g4", "g5"]
+    O.build()
+    if "g1" in which: case_g1()
+    if "g2" in which: case_g2(False)
+    if "g2v" in which: case_g2(True)
+    if "g2i" in which: case_g2(False, itmax_case=True)
+    if "g3" in which: case_g3()
+    if "g4" in which: case_g4()
+    if "g5" in which: case_g5()

@@ -1,0 +1,27 @@
+import os
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU checker (oracle/): C restatement of the reference, compiled on first use."""
+    from oracle import oracle as O
+    O.build(with_ref=False)
+    return O
+
+
+def load_golden(name):
+    import numpy as np
+    return np.load(os.path.join(GOLDEN, name + ".npz"))

@@ -1,0 +1,120 @@
+"""Pin the oracle (oracle/ec3d_oracle.c) against fixtures captured from the UNMODIFIED reference
+(tests/golden/*.npz, written by oracle/make_goldens.py with oracle/_ref/EC3D_capture).
+CPU only.  Bar: bit-identical iteration counts, solutions and CSR arrays."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+CAPTURED = ["g1_nonconducting_8x7x6", "g2_conducting_hole_16x15x14",
+            "g2v_conducting_moving_16x15x14", "g2i_itmax_exit_16x15x14", "g3_moving_coil_18x16x12"]
+
+
+@pytest.mark.parametrize("name", CAPTURED)
+def test_solver_restatement_bitwise(oracle, name):
+    """src/solvers.f90:3-50 vs oracle_bicgstab_wr on every captured call (warm starts included)."""
+    g = load_golden(name)
+    for s, it_ref in enumerate(g["iters"]):
+        x, it, _, _ = oracle.bicgstab_wr(g["valA"], g["irow"], g["jcol"], g[f"b{s}"], g[f"xin{s}"],
+                                         float(g["tol"]), int(g["itmax"]))
+        assert it == int(it_ref)
+        assert np.array_equal(x, g[f"xout{s}"])
+
+
+def test_itmax_exit_runs_itmax_plus_one(oracle):
+    """src/solvers.f90:25-29: the test precedes the increment, so itmax=25 gives 26 iterations."""
+    g = load_golden("g2i_itmax_exit_16x15x14")
+    assert int(g["itmax"]) == 25 and all(int(i) == 26 for i in g["iters"])
+
+
+@pytest.mark.parametrize("name", CAPTURED)
+def test_assembly_restatement_bitwise(oracle, name):
+    """src/EC3D.f90:465-1049 vs oracle_gen_sparse_matrix: irow, jcol, valA identical."""
+    g = load_golden(name)
+    m = oracle.gen_sparse_matrix(g["geoPHYS"], g["geoPHYS_C"], g["valPHYS"], g["BND"], g["delta"],
+                                 float(g["dt"]))
+    assert np.array_equal(m["irow"], g["irow"])
+    assert np.array_equal(m["jcol"], g["jcol"])
+    assert np.array_equal(m["valA"], g["valA"])
+
+
+def test_assembly_covers_every_u_branch(oracle):
+    """The G2 block with a through-hole exercises corner/edge/face/interior U rows (7 or 13
+    entries) and both one-sided A-U stencils (rows of 10)."""
+    g = load_golden("g2_conducting_hole_16x15x14")
+    hist = np.bincount(np.diff(g["irow"]), minlength=14)
+    assert hist[13] > 0 and hist[10] > 0 and hist[9] > 0 and hist[7] > 0
+    m = oracle.gen_sparse_matrix(g["geoPHYS"], g["geoPHYS_C"], g["valPHYS"], g["BND"], g["delta"],
+                                 float(g["dt"]))
+    assert all(len(c) > 0 for c in m["cel_bnd"])
+
+
+def test_rhs_zeroed_at_onesided_cells(oracle):
+    """src/EC3D.f90:396-402 zeroes Jaf at cel_bnd*: the captured b must be 0 exactly there."""
+    g = load_golden("g2_conducting_hole_16x15x14")
+    m = oracle.gen_sparse_matrix(g["geoPHYS"], g["geoPHYS_C"], g["valPHYS"], g["BND"], g["delta"],
+                                 float(g["dt"]))
+    for lst in m["cel_bnd"]:
+        assert np.all(g["b1"][lst - 1] == 0.0)
+
+
+@pytest.mark.parametrize("N", [16, 32])
+def test_cube_iterations_and_norm(oracle, N):
+    """G5: reference solver alone on the config-2 operator: iter and ||x||."""
+    g = load_golden(f"g5_cube{N}")
+    valA, irow, jcol = oracle.poisson_csr(N, N, N)
+    x, it, hs, hr = oracle.bicgstab_wr(valA, irow, jcol, oracle.bar_rhs(N), np.zeros(N ** 3), 1e-8,
+                                       100000, hist_cap=24)
+    assert it == int(g["iter"])
+    assert np.linalg.norm(x) == pytest.approx(float(g["xnorm"]), rel=1e-14)
+    if N <= 32:
+        assert np.array_equal(x, g["x"])
+    # residual history of the unmodified solver (itmax trick, src/solvers.f90:25-28)
+    assert np.allclose(hr, g["rnorm_first"], rtol=1e-13, atol=0)
+
+
+def test_cube_iterates_match_reference(oracle):
+    """x after exactly k iterations (k = 1..24) equals the reference's, via the itmax exit."""
+    g = load_golden("g5_cube16")
+    N = 16
+    valA, irow, jcol = oracle.poisson_csr(N, N, N)
+    b = oracle.bar_rhs(N)
+    for k in (1, 2, 7, 24):
+        x, it, _, _ = oracle.bicgstab_wr(valA, irow, jcol, b, np.zeros(N ** 3), 1e-300, k - 1)
+        assert it == k
+        assert np.array_equal(x[g["probes"]], g["xk_probe"][k - 1])
+        assert np.linalg.norm(x) == pytest.approx(float(g["xk_norm"][k - 1]), rel=1e-14)
+
+
+def test_known_survey_numbers():
+    """SURVEY §8c [measured] values for the shipped input and cubes are what our captures show."""
+    g = load_golden("g4_compare_to_Elmer")
+    assert list(g["iters"]) == [173, 160, 80]
+    assert int(g["n"]) == 792288 and int(g["nnz"]) == 5892072
+    assert np.allclose(g["bnorm"], [50.79818, 58.99444, 65.39831], rtol=1e-6)
+    assert np.allclose(g["xnorm"], [1.219872e-2, 1.223487e-2, 1.100793e-2], rtol=1e-6)
+    assert list(g["rowlen_hist"][[4, 5, 6, 7, 9, 10, 13]]) == [24, 2664, 86400, 546704, 112320, 17280, 26896]
+    assert int(load_golden("g5_cube32")["iter"]) == 270 and int(load_golden("g5_cube64")["iter"]) == 603
+
+
+def test_norm2_and_dot_semantics(oracle):
+    rng = np.random.Generator(np.random.PCG64(1))
+    a = rng.standard_normal(1000) * 10.0 ** rng.integers(-3, 3, 1000)
+    assert oracle.norm2(a) == pytest.approx(np.linalg.norm(a), rel=1e-14)
+    assert oracle.norm2(np.zeros(5)) == 0.0
+    s = 0.0
+    for u, v in zip(a, a[::-1]):
+        s = s + u * v
+    assert oracle.dot(a, a[::-1].copy()) == s
+
+
+def test_gpu_order_dot_is_a_permutation_of_the_sum(oracle):
+    """The GPU-order twin only re-associates: same value to ~1e-15, and deterministic."""
+    rng = np.random.Generator(np.random.PCG64(2))
+    n = 5000
+    a, b = rng.standard_normal(n), rng.standard_normal(n)
+    for nblk, xg in ((3, 0), (16, 2), (64, 8)):
+        geom = oracle.GpuGeom(n_pad=5120, tile=512, nblk=nblk, threads=256, xcd_group=xg)
+        d = oracle.dot_gpuorder(geom, a, b)
+        assert d == oracle.dot_gpuorder(geom, a, b)
+        assert d == pytest.approx(float(np.dot(a, b)), rel=1e-12)
