@@ -1,0 +1,417 @@
+// ec3d_assemble.hip — matrix assembly on the device, straight into DIA bands + sliced-ELL tail.
+//
+// Replaces gen_sparse_matrix (src/EC3D.f90:465-1049): one thread per cell instead of a serial
+// triple loop with one heap node per nonzero and a bubble sort per row.  The reference's CSR is
+// never materialised; ec3d_export_csr() can rebuild it for parity checks.
+//
+// Row layout produced (unknowns [Ax | Ay | Az | U], src/EC3D.f90:101-106):
+//   * A rows: 7 bands at offsets (-kdz, -sdx, -1, 0, +1, +sdx, +kdz) = the reference's ascending
+//     column order; the 2-3 U couplings of a conducting cell (columns > 3*nCells, i.e. after every
+//     band column) go to the row's tail, sorted ascending (full_sort, :715/:729/:744);
+//   * U rows (7 or 13 entries, :766-959): entirely in the tail, sorted ascending (:942);
+//   * U row index = scan-order count (:521, :955); U column ids are geoPHYS_C's (:767).
+#include "ec3d_internal.hpp"
+
+#include <algorithm>
+#include <cstring>
+
+namespace {
+
+struct GridPar {
+    int sdx, sdy, sdz;
+    int64_t kdz, nCells, n_pad;
+    double s[3];     // 1/delta^2          :496-498
+    double ds[3];    // 0.5/delta          :499-501
+    double delta[3];
+    double bnd[6];   // BND(d,s) column-major: [s*3+d]
+    double dt;
+    int nsub_glob;
+    int64_t ncells0;
+};
+
+// The A row shared by Ax/Ay/Az for a cell, as 7 band coefficients in offset order
+// (-z,-y,-x,diag,+x,+y,+z).  Box-boundary cell: src/EC3D.f90:528-646 (per axis: low edge keeps
+// only the + neighbour with BND(d,2)*s_d, high edge only the - neighbour with BND(d,1)*s_d, and
+// the diagonal gets s_d instead of 2 s_d); interior: :649-654.
+__device__ __forceinline__ void a_row_bands(const GridPar &g, int i, int j, int k, double (&c)[7], bool &on_box)
+{
+    const int idx[3] = {i, j, k}, sd[3] = {g.sdx, g.sdy, g.sdz};
+    double m[3], p[3], dg[3];
+    on_box = false;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        if (idx[d] == 1) {
+            m[d] = 0.0; p[d] = g.bnd[3 + d] * g.s[d]; dg[d] = 1.0; on_box = true;
+        } else if (idx[d] == sd[d]) {
+            m[d] = g.bnd[d] * g.s[d]; p[d] = 0.0; dg[d] = 1.0; on_box = true;
+        } else {
+            m[d] = -g.s[d]; p[d] = -g.s[d]; dg[d] = 2.0;
+        }
+    }
+    c[0] = m[2]; c[1] = m[1]; c[2] = m[0];
+    c[4] = p[0]; c[5] = p[1]; c[6] = p[2];
+    // literals like (2.d0*sx + sy + sz) associate left to right; 2.d0*(sx+sy+sz) for the interior
+    c[3] = on_box ? (dg[0] * g.s[0] + dg[1] * g.s[1]) + dg[2] * g.s[2] : 2.0 * ((g.s[0] + g.s[1]) + g.s[2]);
+}
+
+__device__ __forceinline__ void sort_small(int32_t *col, double *val, int L)
+{
+    for (int a = 1; a < L; ++a) {
+        int32_t cc = col[a];
+        double vv = val[a];
+        int q = a - 1;
+        while (q >= 0 && col[q] > cc) { col[q + 1] = col[q]; val[q + 1] = val[q]; --q; }
+        col[q + 1] = cc;
+        val[q + 1] = vv;
+    }
+}
+
+__device__ __forceinline__ void put_tail(const int64_t *chunk_ptr, int32_t *tcol, double *tval, int64_t t,
+                                         const int32_t *col, const double *val, int L)
+{
+    const int64_t base = chunk_ptr[t >> 6] + (t & 63);
+    for (int q = 0; q < L; ++q) {
+        tcol[base + (int64_t)q * EC3D_CHUNK] = col[q] - 1; // 0-based
+        tval[base + (int64_t)q * EC3D_CHUNK] = val[q];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_assemble_poisson(GridPar g, double *bands)
+{
+    const int64_t nn0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (nn0 >= g.nCells) return;
+    const int i = (int)(nn0 % g.sdx) + 1, j = (int)((nn0 / g.sdx) % g.sdy) + 1, k = (int)(nn0 / g.kdz) + 1;
+    double c[7];
+    bool on_box;
+    a_row_bands(g, i, j, k, c, on_box);
+#pragma unroll
+    for (int b = 0; b < 7; ++b) bands[(size_t)b * g.n_pad + nn0] = c[b];
+}
+
+// flags per cell: bit0-2 one-sided A-U stencil along x,y,z (cel_bndX/Y/Z, :758-760),
+//                 bit3-5 U row with a missing neighbour along x,y,z (cel_bndUx/y/z, :938-940)
+__global__ __launch_bounds__(256) void k_assemble_av(GridPar g, const int8_t *__restrict__ geo,
+                                                     const int32_t *__restrict__ geoC,
+                                                     const int32_t *__restrict__ uidx,
+                                                     const double *__restrict__ valPHYS, double *bands,
+                                                     int32_t *tail_id, uint8_t *tile_flag, const int64_t *chunk_ptr,
+                                                     int32_t *tcol, double *tval, uint8_t *flags, int *err,
+                                                     unsigned long long *nnz)
+{
+    const int64_t nn0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (nn0 >= g.nCells) return;
+    const int i = (int)(nn0 % g.sdx) + 1, j = (int)((nn0 / g.sdx) % g.sdy) + 1, k = (int)(nn0 / g.kdz) + 1;
+    const int32_t nn = (int32_t)nn0 + 1; // the reference's 1-based cell id
+    const int32_t nC = (int32_t)g.nCells;
+    double c[7];
+    bool on_box;
+    a_row_bands(g, i, j, k, c, on_box);
+    unsigned long long cnt = 0;
+    for (int b = 0; b < 7; ++b) cnt += 3ull * (c[b] != 0.0 || b == 3);
+    const int32_t u0 = geoC[nn0];
+    const int ndom = geo[nn0];
+    uint8_t fl = 0;
+    if (u0 != 0 && on_box) { atomicMax(err, 3); return; }
+    if (u0 != 0) {
+        const double C = valPHYS[1 * (int64_t)g.nsub_glob + ndom - 1];
+        // :657-663 conductor velocity (advection) and inertia terms, identical for Ax/Ay/Az
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const double h = valPHYS[(2 + d) * (int64_t)g.nsub_glob + ndom - 1] / (2.0 * g.delta[d]);
+            c[2 - d] = c[2 - d] - h;
+            c[4 + d] = c[4 + d] + h;
+        }
+        c[3] = c[3] + 2.0 * C / g.dt;
+        const int64_t m = uidx[nn0];
+        const int64_t step[3] = {1, g.sdx, g.kdz};
+        const int pos[3] = {i, j, k}, sd[3] = {g.sdx, g.sdy, g.sdz};
+        int32_t nb6[6]; // U ids of the -x,+x,-y,+y,-z,+z neighbours
+        for (int d = 0; d < 3; ++d) {
+            nb6[2 * d] = geoC[nn0 - step[d]];
+            nb6[2 * d + 1] = geoC[nn0 + step[d]];
+        }
+        // ---- A rows: U couplings :667-710 --------------------------------------------------
+        for (int d = 0; d < 3; ++d) {
+            int32_t col[3];
+            double val[3];
+            int L;
+            const int32_t um = nb6[2 * d], up = nb6[2 * d + 1];
+            if (up == 0) {
+                if (pos[d] - 2 < 1) { atomicMax(err, 3); return; }
+                col[0] = u0; val[0] = -3.0 * C * g.ds[d];
+                col[1] = um; val[1] = +4.0 * C * g.ds[d];
+                col[2] = geoC[nn0 - 2 * step[d]]; val[2] = -1.0 * C * g.ds[d];
+                L = 3; fl |= (uint8_t)(1u << d);
+            } else if (um == 0) {
+                if (pos[d] + 2 > sd[d]) { atomicMax(err, 3); return; }
+                col[0] = u0; val[0] = +3.0 * C * g.ds[d];
+                col[1] = up; val[1] = -4.0 * C * g.ds[d];
+                col[2] = geoC[nn0 + 2 * step[d]]; val[2] = +1.0 * C * g.ds[d];
+                L = 3; fl |= (uint8_t)(1u << d);
+            } else {
+                col[0] = up; val[0] = -C * g.ds[d];
+                col[1] = um; val[1] = +C * g.ds[d];
+                L = 2;
+            }
+            for (int q = 0; q < L; ++q)
+                if (col[q] <= 0) { atomicMax(err, 1); return; } // :717-720
+            sort_small(col, val, L);
+            const int64_t t = (int64_t)d * g.ncells0 + m;
+            put_tail(chunk_ptr, tcol, tval, t, col, val, L);
+            const int64_t row = (int64_t)d * g.nCells + nn0;
+            tail_id[row] = (int32_t)t;
+            tile_flag[row / EC3D_TILE] = 1;
+            cnt += (unsigned long long)L;
+        }
+        // ---- U row :766-959 ----------------------------------------------------------------
+        {
+            int32_t col[13];
+            double val[13];
+            int L = 0;
+            const double sdiag = 2.0 * ((g.s[0] + g.s[1]) + g.s[2]);
+            const bool miss_m[3] = {nb6[0] == 0, nb6[2] == 0, nb6[4] == 0};
+            const bool miss_p[3] = {nb6[1] == 0, nb6[3] == 0, nb6[5] == 0};
+            const int nmiss = (miss_m[0] || miss_p[0]) + (miss_m[1] || miss_p[1]) + (miss_m[2] || miss_p[2]);
+            if ((miss_m[0] && miss_p[0]) || (miss_m[1] && miss_p[1]) || (miss_m[2] && miss_p[2])) {
+                atomicMax(err, 1); // the reference reaches a zero column here and STOPs (:945-948)
+                return;
+            }
+            const int32_t own[3] = {nn, nC + nn, 2 * nC + nn};
+            if (nmiss == 0) { // interior :917-922
+                const double h = 0.5 / g.dt;
+                for (int d = 0; d < 3; ++d) {
+                    col[L] = nb6[2 * d]; val[L++] = -g.s[d];
+                    col[L] = nb6[2 * d + 1]; val[L++] = -g.s[d];
+                }
+                col[L] = u0; val[L++] = sdiag;
+                for (int d = 0; d < 3; ++d) {
+                    col[L] = d * nC + nn + (int32_t)step[d]; val[L++] = h * (-1.0 / g.delta[d]);
+                    col[L] = d * nC + nn - (int32_t)step[d]; val[L++] = h * (1.0 / g.delta[d]);
+                }
+            } else { // corners :773-812, edges :815-878, faces :881-916 (Neumann mirror)
+                // the corner "not i-1 j+1 k+1" carries a = +, b = - in the reference (:803-804)
+                const bool quirk = miss_m[0] && miss_p[1] && miss_p[2];
+                for (int d = 0; d < 3; ++d) {
+                    if (miss_m[d]) {
+                        col[L] = nb6[2 * d + 1]; val[L++] = -2.0 * g.s[d];
+                    } else if (miss_p[d]) {
+                        col[L] = nb6[2 * d]; val[L++] = -2.0 * g.s[d];
+                    } else {
+                        col[L] = nb6[2 * d]; val[L++] = -g.s[d];
+                        col[L] = nb6[2 * d + 1]; val[L++] = -g.s[d];
+                    }
+                }
+                col[L] = u0; val[L++] = sdiag;
+                for (int d = 0; d < 3; ++d) {
+                    if (!(miss_m[d] || miss_p[d])) continue;
+                    double a = 2.0 / (g.dt * g.delta[d]);
+                    bool neg = miss_m[d];
+                    if (quirk && d < 2) neg = !neg;
+                    col[L] = own[d]; val[L++] = neg ? -a : a;
+                    fl |= (uint8_t)(8u << d);
+                }
+            }
+            for (int q = 0; q < L; ++q)
+                if (col[q] <= 0) { atomicMax(err, 1); return; }
+            for (int q1 = 0; q1 < L - 1; ++q1) // :924-936
+                for (int q2 = q1 + 1; q2 < L; ++q2)
+                    if (col[q1] == col[q2]) { atomicMax(err, 2); return; }
+            sort_small(col, val, L);
+            const int64_t t = 3 * g.ncells0 + m;
+            put_tail(chunk_ptr, tcol, tval, t, col, val, L);
+            const int64_t row = 3 * g.nCells + m;
+            tail_id[row] = (int32_t)t;
+            tile_flag[row / EC3D_TILE] = 1;
+            cnt += (unsigned long long)L;
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < 7; ++b) {
+        bands[(size_t)b * g.n_pad + nn0] = c[b];
+        bands[(size_t)b * g.n_pad + g.nCells + nn0] = c[b];
+        bands[(size_t)b * g.n_pad + 2 * g.nCells + nn0] = c[b];
+    }
+    if (flags) flags[nn0] = fl;
+    atomicAdd(nnz, cnt);
+}
+
+int fill_gridpar(GridPar &g, int32_t sdx, int32_t sdy, int32_t sdz, const double *BND, const double *delta, double dt)
+{
+    if (sdx < 3 || sdy < 3 || sdz < 3) {
+        ec3d_set_error("ec3d_assemble: grid must be at least 3 cells along every axis");
+        return 2;
+    }
+    g.sdx = sdx; g.sdy = sdy; g.sdz = sdz;
+    g.kdz = (int64_t)sdx * sdy;
+    g.nCells = g.kdz * sdz;
+    for (int d = 0; d < 3; ++d) {
+        g.delta[d] = delta[d];
+        g.s[d] = 1.0 / (delta[d] * delta[d]);
+        g.ds[d] = 0.5 / delta[d];
+    }
+    for (int q = 0; q < 6; ++q) g.bnd[q] = BND[q];
+    g.dt = dt;
+    return 0;
+}
+
+void set_offsets(DevMatrix &A, const GridPar &g)
+{
+    A.nb = 7;
+    const int64_t off[7] = {-g.kdz, -(int64_t)g.sdx, -1, 0, 1, g.sdx, g.kdz};
+    for (int b = 0; b < 7; ++b) A.off[b] = off[b];
+}
+
+} // namespace
+
+static int64_t round_up64(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+int ec3d_assemble_poisson_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t sdz, const double *BND,
+                                 const double *delta)
+{
+    GridPar g;
+    memset(&g, 0, sizeof g);
+    int rc = fill_gridpar(g, sdx, sdy, sdz, BND, delta, 1.0);
+    if (rc) return rc;
+    if (g.nCells > (int64_t)INT32_MAX - EC3D_TILE) {
+        ec3d_set_error("ec3d_assemble_poisson: more than 2^31 unknowns");
+        return 2;
+    }
+    ec3d_free_matrix(c);
+    DevMatrix &A = c->A;
+    A.n = g.nCells;
+    A.n_pad = g.n_pad = round_up64(A.n, EC3D_TILE);
+    set_offsets(A, g);
+    const size_t bb = (size_t)7 * A.n_pad * sizeof(double);
+    EC3D_HIP(hipMalloc(&A.bands, bb));
+    EC3D_HIP(hipMemsetAsync(A.bands, 0, bb, c->stream));
+    // unused tail arrays still need valid pointers
+    EC3D_HIP(hipMalloc(&A.tail_id, 8));
+    EC3D_HIP(hipMalloc(&A.tile_flag, 8));
+    EC3D_HIP(hipMalloc(&A.chunk_ptr, 8));
+    EC3D_HIP(hipMalloc(&A.tcol, 8));
+    EC3D_HIP(hipMalloc(&A.tval, 8));
+    A.bytes = (int64_t)bb;
+    const int64_t nblk = (g.nCells + 255) / 256;
+    k_assemble_poisson<<<(unsigned)nblk, 256, 0, c->stream>>>(g, A.bands);
+    EC3D_HIP(hipGetLastError());
+    EC3D_HIP(hipStreamSynchronize(c->stream));
+    // nnz = 7 n - 2 (sdx sdy + sdy sdz + sdx sdz)   (one neighbour dropped per boundary face cell)
+    A.nnz = 7 * g.nCells - 2 * ((int64_t)sdx * sdy + (int64_t)sdy * sdz + (int64_t)sdx * sdz);
+    c->have_matrix = true;
+    c->sdx = sdx; c->sdy = sdy; c->sdz = sdz;
+    return ec3d_prepare_vectors(c);
+}
+
+int ec3d_assemble_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t sdz, const int8_t *geoPHYS,
+                         const int32_t *geoPHYS_C, const double *valPHYS, int32_t nsub_glob,
+                         const double *BND, const double *delta, double dt)
+{
+    GridPar g;
+    memset(&g, 0, sizeof g);
+    int rc = fill_gridpar(g, sdx, sdy, sdz, BND, delta, dt);
+    if (rc) return rc;
+    g.nsub_glob = nsub_glob;
+    // scan-order index of the conducting cells = U row order (src/EC3D.f90:519-522, :955)
+    std::vector<int32_t> uidx((size_t)g.nCells, -1);
+    int64_t nc0 = 0;
+    for (int64_t q = 0; q < g.nCells; ++q)
+        if (geoPHYS_C[q] != 0) {
+            if (geoPHYS[q] < 1 || geoPHYS[q] > nsub_glob) {
+                ec3d_set_error("ec3d_assemble: geoPHYS domain id out of range");
+                return 2;
+            }
+            uidx[(size_t)q] = (int32_t)nc0++;
+        }
+    g.ncells0 = nc0;
+    const int64_t n = 3 * g.nCells + nc0;
+    if (n > (int64_t)INT32_MAX - EC3D_TILE) {
+        ec3d_set_error("ec3d_assemble: more than 2^31 unknowns");
+        return 2;
+    }
+    ec3d_free_matrix(c);
+    DevMatrix &A = c->A;
+    A.n = n;
+    A.n_pad = g.n_pad = round_up64(n, EC3D_TILE);
+    set_offsets(A, g);
+    // sliced-ELL geometry: slices made only of A-row tails are 3 wide, the rest 13
+    A.ntail = 4 * nc0;
+    A.nchunk = (A.ntail + EC3D_CHUNK - 1) / EC3D_CHUNK;
+    std::vector<int64_t> cp((size_t)A.nchunk + 1, 0);
+    for (int64_t q = 0; q < A.nchunk; ++q) {
+        const int64_t w = (q * EC3D_CHUNK + EC3D_CHUNK - 1 < 3 * nc0) ? 3 : 13;
+        cp[(size_t)q + 1] = cp[(size_t)q] + w * EC3D_CHUNK;
+    }
+    A.tail_entries = cp.back();
+    const size_t bb = (size_t)7 * A.n_pad * sizeof(double);
+    const size_t te = (size_t)std::max<int64_t>(A.tail_entries, 1);
+    EC3D_HIP(hipMalloc(&A.bands, bb));
+    EC3D_HIP(hipMemsetAsync(A.bands, 0, bb, c->stream));
+    EC3D_HIP(hipMalloc(&A.tail_id, (size_t)A.n_pad * 4));
+    EC3D_HIP(hipMemsetAsync(A.tail_id, 0xFF, (size_t)A.n_pad * 4, c->stream));
+    EC3D_HIP(hipMalloc(&A.tile_flag, (size_t)(A.n_pad / EC3D_TILE)));
+    EC3D_HIP(hipMemsetAsync(A.tile_flag, 0, (size_t)(A.n_pad / EC3D_TILE), c->stream));
+    EC3D_HIP(hipMalloc(&A.chunk_ptr, cp.size() * 8));
+    EC3D_HIP(hipMemcpyAsync(A.chunk_ptr, cp.data(), cp.size() * 8, hipMemcpyHostToDevice, c->stream));
+    EC3D_HIP(hipMalloc(&A.tcol, te * 4));
+    EC3D_HIP(hipMemsetAsync(A.tcol, 0, te * 4, c->stream));
+    EC3D_HIP(hipMalloc(&A.tval, te * 8));
+    EC3D_HIP(hipMemsetAsync(A.tval, 0, te * 8, c->stream));
+    A.bytes = (int64_t)(bb + (size_t)A.n_pad * 4 + A.n_pad / EC3D_TILE + cp.size() * 8 + te * 12);
+
+    // inputs
+    int8_t *d_geo = nullptr;
+    int32_t *d_geoC = nullptr, *d_uidx = nullptr;
+    double *d_val = nullptr;
+    uint8_t *d_flags = nullptr;
+    int *d_err = nullptr;
+    unsigned long long *d_nnz = nullptr;
+    EC3D_HIP(hipMalloc(&d_geo, (size_t)g.nCells));
+    EC3D_HIP(hipMalloc(&d_geoC, (size_t)g.nCells * 4));
+    EC3D_HIP(hipMalloc(&d_uidx, (size_t)g.nCells * 4));
+    EC3D_HIP(hipMalloc(&d_val, (size_t)nsub_glob * 5 * 8));
+    EC3D_HIP(hipMalloc(&d_flags, (size_t)g.nCells));
+    EC3D_HIP(hipMalloc(&d_err, sizeof(int)));
+    EC3D_HIP(hipMalloc(&d_nnz, sizeof(unsigned long long)));
+    EC3D_HIP(hipMemcpyAsync(d_geo, geoPHYS, (size_t)g.nCells, hipMemcpyHostToDevice, c->stream));
+    EC3D_HIP(hipMemcpyAsync(d_geoC, geoPHYS_C, (size_t)g.nCells * 4, hipMemcpyHostToDevice, c->stream));
+    EC3D_HIP(hipMemcpyAsync(d_uidx, uidx.data(), (size_t)g.nCells * 4, hipMemcpyHostToDevice, c->stream));
+    EC3D_HIP(hipMemcpyAsync(d_val, valPHYS, (size_t)nsub_glob * 5 * 8, hipMemcpyHostToDevice, c->stream));
+    EC3D_HIP(hipMemsetAsync(d_err, 0, sizeof(int), c->stream));
+    EC3D_HIP(hipMemsetAsync(d_nnz, 0, sizeof(unsigned long long), c->stream));
+    const int64_t nblk = (g.nCells + 255) / 256;
+    k_assemble_av<<<(unsigned)nblk, 256, 0, c->stream>>>(g, d_geo, d_geoC, d_uidx, d_val, A.bands, A.tail_id,
+                                                         A.tile_flag, A.chunk_ptr, A.tcol, A.tval, d_flags, d_err,
+                                                         d_nnz);
+    EC3D_HIP(hipGetLastError());
+    int err = 0;
+    unsigned long long nnz = 0;
+    std::vector<uint8_t> flags((size_t)g.nCells);
+    EC3D_HIP(hipMemcpyAsync(&err, d_err, sizeof err, hipMemcpyDeviceToHost, c->stream));
+    EC3D_HIP(hipMemcpyAsync(&nnz, d_nnz, sizeof nnz, hipMemcpyDeviceToHost, c->stream));
+    EC3D_HIP(hipMemcpyAsync(flags.data(), d_flags, flags.size(), hipMemcpyDeviceToHost, c->stream));
+    EC3D_HIP(hipStreamSynchronize(c->stream));
+    (void)hipFree(d_geo); (void)hipFree(d_geoC); (void)hipFree(d_uidx); (void)hipFree(d_val);
+    (void)hipFree(d_flags); (void)hipFree(d_err); (void)hipFree(d_nnz);
+    if (err) {
+        ec3d_free_matrix(c);
+        ec3d_set_error(err == 3 ? "ec3d_assemble: conductor touches the box boundary or is thinner than 3 cells "
+                                  "(the reference indexes out of range here)"
+                      : err == 2 ? "ec3d_assemble: node Fi double (src/EC3D.f90:924-936)"
+                                 : "ec3d_assemble: non-positive column (src/EC3D.f90:717-720, :945-948)");
+        return err;
+    }
+    A.nnz = (int64_t)nnz;
+    // cel_bnd* lists in scan order (src/EC3D.f90:758-760, :938-940)
+    for (auto &l : c->cel_bnd) l.clear();
+    for (int64_t q = 0; q < g.nCells; ++q) {
+        const uint8_t f = flags[(size_t)q];
+        if (!f) continue;
+        for (int d = 0; d < 3; ++d) {
+            if (f & (1u << d)) c->cel_bnd[d].push_back((int32_t)(d * g.nCells + q + 1));
+            if (f & (8u << d)) c->cel_bnd[3 + d].push_back(geoPHYS_C[q]);
+        }
+    }
+    c->have_matrix = true;
+    c->sdx = sdx; c->sdy = sdy; c->sdz = sdz;
+    return ec3d_prepare_vectors(c);
+}

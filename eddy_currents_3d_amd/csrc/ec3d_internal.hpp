@@ -1,0 +1,148 @@
+// ec3d_internal.hpp — shared declarations of libec3d_hip.so (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <climits>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#define EC3D_THREADS 256
+#define EC3D_TILE 512 /* rows per tile: every thread owns 2 consecutive rows (one 16-B access) */
+#define EC3D_MAXB 16  /* DIA bands */
+#define EC3D_CHUNK 64 /* sliced-ELL slice height = one wavefront */
+
+// ---------------------------------------------------------------------------------------------
+// Device format.  Rows [0, n_pad).  Row r of A is
+//     sum_b band[b][r] * x[r + off[b]]   (bands in ascending offset order)
+//   + sum_j tval[...] * x[tcol[...]]     (tail entries of row r, in stored order)
+// which is the reference's ascending-column summation order (src/solvers.f90:59 after full_sort,
+// src/EC3D.f90:715) whenever every tail column of a row exceeds its band columns; rows that
+// violate that are stored entirely in the tail (their band coefficients are zero).
+struct MatView {
+    const double *band[EC3D_MAXB];
+    int64_t off[EC3D_MAXB];
+    int nb;
+    int has_tail;
+    const int32_t *tail_id;   // [n_pad]  -1 or index of the row's tail slot
+    const uint8_t *tile_flag; // [ntiles] 1 when any row of the tile has a tail
+    const int64_t *chunk_ptr; // [nchunk+1] entry offsets of the 64-row slices
+    const int32_t *tcol;      // 0-based column
+    const double *tval;
+};
+
+// blockIdx -> tile map (XCD aware when S > 0): see ec3d_tile_of() in ec3d_kernels.hip
+struct Sweep {
+    int64_t ntiles;
+    int nblk;
+    int S;
+};
+
+struct SolverState {
+    double rr0[2]; // R·R0 entering iteration it is rr0[it & 1]
+    double alpha, omega;
+    double bnorm, tol;
+    int stop_iter; // INT_MAX while running; iteration at which an exit was taken
+    int stop_kind; // 1: ‖S‖ exit (solvers.f90:34-38), 2: ‖R‖ exit (:43), 0: none / ‖b‖ = 0
+};
+
+// host-side image of the format (CSR conversion / export)
+struct HostMatrix {
+    int64_t n = 0, n_pad = 0, nnz = 0;
+    int nb = 0;
+    int64_t off[EC3D_MAXB] = {0};
+    std::vector<double> bands;      // nb * n_pad
+    std::vector<int32_t> tail_id;   // n_pad
+    std::vector<uint8_t> tile_flag; // n_pad / EC3D_TILE
+    int64_t ntail = 0;
+    std::vector<int64_t> chunk_ptr;
+    std::vector<int32_t> tcol;
+    std::vector<double> tval;
+};
+
+struct DevMatrix {
+    int64_t n = 0, n_pad = 0, nnz = 0;
+    int nb = 0;
+    int64_t off[EC3D_MAXB] = {0};
+    double *bands = nullptr;
+    int32_t *tail_id = nullptr;
+    uint8_t *tile_flag = nullptr;
+    int64_t ntail = 0, nchunk = 0, tail_entries = 0;
+    int64_t *chunk_ptr = nullptr;
+    int32_t *tcol = nullptr;
+    double *tval = nullptr;
+    int64_t bytes = 0;
+    MatView view() const;
+};
+
+struct ec3d_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    DevMatrix A;
+    bool have_matrix = false;
+    int64_t ghost = 0;     // zero halo (doubles) on both sides of every vector
+    double *vec_base = nullptr;
+    double *vec[8] = {nullptr};
+    Sweep sweep{0, 0, 0};
+    int nblk_request = 0;
+    double *partials = nullptr; // 8 * nblk doubles
+    SolverState *state = nullptr;
+    SolverState *state_pinned = nullptr; // 2 slots
+    double *hist = nullptr;
+    int64_t hist_cap = 0;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    // assembly by-products (1-based ids, reference order)
+    std::vector<int32_t> cel_bnd[6];
+    // grid of the last native assembly (0 when the matrix came from CSR)
+    int32_t sdx = 0, sdy = 0, sdz = 0;
+};
+
+// partial-sum slots inside ctx->partials (each nblk doubles)
+enum { P_BB = 0, P_RR_INIT = 1, P_D1 = 2, P_SS = 3, P_D2 = 4, P_D3 = 5, P_RR = 6, P_RR0N = 7, P_NSLOT = 8 };
+
+void ec3d_set_error(const std::string &msg);
+#define EC3D_HIP(call)                                                                         \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            ec3d_set_error(std::string(#call) + ": " + hipGetErrorString(e_));                 \
+            return 100;                                                                        \
+        }                                                                                      \
+    } while (0)
+
+// ec3d_format.cpp
+int ec3d_csr_to_host_matrix(int64_t n, const double *valA, const int32_t *irow, const int32_t *jcol,
+                            HostMatrix &M);
+void ec3d_host_matrix_to_csr(const HostMatrix &M, std::vector<int32_t> &irow, std::vector<int32_t> &jcol,
+                             std::vector<double> &valA);
+
+// ec3d_solver.hip
+int ec3d_upload_matrix(ec3d_ctx *c, const HostMatrix &M);
+int ec3d_download_matrix(ec3d_ctx *c, HostMatrix &M);
+void ec3d_free_matrix(ec3d_ctx *c);
+int ec3d_prepare_vectors(ec3d_ctx *c);
+
+// ec3d_kernels.hip — launchers (all asynchronous on `s`)
+void ec3d_launch_spmv(const MatView &A, const Sweep &sw, const double *x, double *y, hipStream_t s);
+void ec3d_launch_residual(const MatView &A, const Sweep &sw, const double *x, const double *b, double *r,
+                          double *r0, double *p, double *part, hipStream_t s);
+void ec3d_launch_setup(SolverState *st, const double *part, int nblk, double tol, hipStream_t s);
+void ec3d_launch_k1(const MatView &A, const Sweep &sw, const SolverState *st, int it, const double *p,
+                    const double *r0, double *ap, double *part, hipStream_t s);
+void ec3d_launch_k2(const Sweep &sw, SolverState *st, int it, const double *r, const double *ap, double *sv,
+                    double *part, hipStream_t s);
+void ec3d_launch_k3(const MatView &A, const Sweep &sw, SolverState *st, int it, const double *sv,
+                    const double *p, double *x, double *as, double *part, double *hist, int64_t hist_cap,
+                    hipStream_t s);
+void ec3d_launch_k4(const Sweep &sw, SolverState *st, int it, const double *p, const double *sv,
+                    const double *as, const double *r0, double *x, double *r, double *part, hipStream_t s);
+void ec3d_launch_k5(const Sweep &sw, SolverState *st, int it, double *r, const double *ap, double *p,
+                    double *r0, double *part, double *hist, int64_t hist_cap, hipStream_t s);
+
+// ec3d_assemble.hip
+int ec3d_assemble_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t sdz, const int8_t *geoPHYS,
+                         const int32_t *geoPHYS_C, const double *valPHYS, int32_t nsub_glob,
+                         const double *BND, const double *delta, double dt);
+int ec3d_assemble_poisson_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t sdz, const double *BND,
+                                 const double *delta);

@@ -1,0 +1,421 @@
+// ec3d_kernels.hip — gfx950 kernels of the BiCGSTAB-with-restart hot path.
+//
+// Reference arithmetic restated (src/solvers.f90:3-61, see the per-kernel notes) with these
+// MI355X-first choices:
+//   * matrix = DIA bands (SoA, one fp64 stream per band) + sliced-ELL tail; no column indices
+//     on the band part, every stream is read with 16-byte accesses, one tile = 512 rows;
+//   * one iteration = 5 launches (K1..K5); every vector op is fused into the kernel that
+//     produces its operand, every dot product into the kernel that produces its vector;
+//   * reductions are deterministic: per-thread sequential over its tiles, 64-lane shuffle tree,
+//     4 wave sums left to right, one partial per workgroup; the NEXT kernel's workgroups each
+//     re-reduce the partials in the same order (a few KB from L2), so there is no atomics, no
+//     inter-workgroup handshake and no host round trip; scalars (alpha, omega, beta, rr0) live
+//     in a device-resident SolverState;
+//   * convergence is decided on the device: an exit writes stop_iter, later launches become
+//     no-ops, the host polls asynchronously (ec3d_solver.hip);
+//   * blockIdx -> tile map is XCD aware: the 8 XCD labels (blockIdx % 8) sweep disjoint
+//     contiguous groups of S tiles of one moving window, so x[r ± sdx] re-reads hit the L2 of
+//     the XCD that fetched them and the window's planes stay in the Infinity Cache.
+// Built with -ffp-contract=off: products and sums are rounded separately, exactly as the
+// reference's x86-64 object code does; the oracle's "GPU order" twin reproduces every bit.
+#include "ec3d_internal.hpp"
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+typedef int i2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int64_t ec3d_tile_of(const Sweep &sw, int b, int64_t i)
+{
+    if (sw.S > 0) {
+        int64_t c = b & 7, s = b >> 3;
+        return (i * 8 + c) * sw.S + s;
+    }
+    return i * (int64_t)sw.nblk + b;
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = v + __shfl_down(v, off, 64);
+    return v; // lane 0
+}
+
+// sums NV values over the workgroup; result valid in every thread.  lds: NV*4 doubles.
+template <int NV>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double *lds)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        double t = wave_sum(v[k]);
+        if (lane == 0) lds[k * 4 + w] = t;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = ((lds[k * 4 + 0] + lds[k * 4 + 1]) + lds[k * 4 + 2]) + lds[k * 4 + 3];
+    __syncthreads();
+}
+
+// every workgroup re-reduces the previous kernel's per-workgroup partials, same order everywhere
+template <int NV>
+__device__ __forceinline__ void reduce_partials(const double *const (&part)[NV], int nblk, double (&out)[NV],
+                                                double *lds)
+{
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        double a = 0.0;
+        for (int i = threadIdx.x; i < nblk; i += EC3D_THREADS) a = a + part[k][i];
+        out[k] = a;
+    }
+    block_sum<NV>(out, lds);
+}
+
+__device__ __forceinline__ double tail_add(const MatView &A, const double *__restrict__ x, int t, double s)
+{
+    const int64_t base = A.chunk_ptr[t >> 6], end = A.chunk_ptr[(t >> 6) + 1];
+    const int lane = t & 63;
+    for (int64_t e = base + lane; e < end; e += EC3D_CHUNK) s = s + A.tval[e] * x[A.tcol[e]];
+    return s;
+}
+
+// rows r, r+1 of A*x (src/solvers.f90:58-59): bands in ascending column order, then the tail
+template <int NB>
+__device__ __forceinline__ void spmv_pair(const MatView &A, const double *__restrict__ x, int64_t r,
+                                          int64_t tile, double &s0, double &s1)
+{
+    if (NB > 0) {
+        d2 c[NB > 0 ? NB : 1], xv[NB > 0 ? NB : 1];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) c[b] = *reinterpret_cast<const d2 *>(A.band[b] + r);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) xv[b] = *reinterpret_cast<const d2u *>(x + r + A.off[b]);
+        s0 = c[0].x * xv[0].x;
+        s1 = c[0].y * xv[0].y;
+#pragma unroll
+        for (int b = 1; b < NB; ++b) {
+            s0 = s0 + c[b].x * xv[b].x;
+            s1 = s1 + c[b].y * xv[b].y;
+        }
+    } else {
+        s0 = 0.0;
+        s1 = 0.0;
+        for (int b = 0; b < A.nb; ++b) {
+            d2 c = *reinterpret_cast<const d2 *>(A.band[b] + r);
+            d2u xv = *reinterpret_cast<const d2u *>(x + r + A.off[b]);
+            s0 = s0 + c.x * xv.x;
+            s1 = s1 + c.y * xv.y;
+        }
+    }
+    if (A.has_tail && A.tile_flag[tile]) {
+        i2 t = *reinterpret_cast<const i2 *>(A.tail_id + r);
+        if (t.x >= 0) s0 = tail_add(A, x, t.x, s0);
+        if (t.y >= 0) s1 = tail_add(A, x, t.y, s1);
+    }
+}
+
+#define EC3D_SWEEP_BEGIN                                                                       \
+    for (int64_t it_ = 0;; ++it_) {                                                            \
+        const int64_t tile = ec3d_tile_of(sw, blockIdx.x, it_);                                \
+        if (tile >= sw.ntiles) break;                                                          \
+        const int64_t r = tile * EC3D_TILE + 2 * (int64_t)threadIdx.x;
+#define EC3D_SWEEP_END }
+
+// ---------------------------------------------------------------------------------------------
+// plain y = A x  (src/solvers.f90:54-61).  72 B/row with 7 bands.
+template <int NB>
+__global__ __launch_bounds__(EC3D_THREADS) void k_spmv(MatView A, Sweep sw, const double *__restrict__ x,
+                                                       double *__restrict__ y)
+{
+    EC3D_SWEEP_BEGIN
+    double s0, s1;
+    spmv_pair<NB>(A, x, r, tile, s0, s1);
+    *reinterpret_cast<d2 *>(y + r) = d2{s0, s1};
+    EC3D_SWEEP_END
+}
+
+// setup: R = B - A X ; R0 = R ; P = R ; partials of B·B and R·R   (src/solvers.f90:14-21)
+template <int NB>
+__global__ __launch_bounds__(EC3D_THREADS) void k_residual(MatView A, Sweep sw, const double *__restrict__ x,
+                                                           const double *__restrict__ b, double *__restrict__ rv,
+                                                           double *__restrict__ r0, double *__restrict__ p,
+                                                           double *__restrict__ part)
+{
+    __shared__ double lds[8];
+    double acc[2] = {0.0, 0.0};
+    EC3D_SWEEP_BEGIN
+    double s0, s1;
+    spmv_pair<NB>(A, x, r, tile, s0, s1);
+    d2 bv = *reinterpret_cast<const d2 *>(b + r);
+    d2 res = d2{bv.x - s0, bv.y - s1};
+    *reinterpret_cast<d2 *>(rv + r) = res;
+    *reinterpret_cast<d2 *>(r0 + r) = res;
+    *reinterpret_cast<d2 *>(p + r) = res;
+    acc[0] = acc[0] + bv.x * bv.x;
+    acc[0] = acc[0] + bv.y * bv.y;
+    acc[1] = acc[1] + res.x * res.x;
+    acc[1] = acc[1] + res.y * res.y;
+    EC3D_SWEEP_END
+    block_sum<2>(acc, lds);
+    if (threadIdx.x == 0) {
+        part[P_BB * sw.nblk + blockIdx.x] = acc[0];
+        part[P_RR_INIT * sw.nblk + blockIdx.x] = acc[1];
+    }
+}
+
+// Bnorm, rr0, "‖b‖ = 0 -> return" (src/solvers.f90:21-23); one workgroup
+__global__ __launch_bounds__(EC3D_THREADS) void k_setup(SolverState *st, const double *part, int nblk, double tol)
+{
+    __shared__ double lds[8];
+    const double *const pp[2] = {part + P_BB * nblk, part + P_RR_INIT * nblk};
+    double v[2];
+    reduce_partials<2>(pp, nblk, v, lds);
+    if (threadIdx.x == 0) {
+        const double bnorm = sqrt(v[0]);
+        st->bnorm = bnorm;
+        st->tol = tol;
+        st->rr0[1] = v[1]; // iteration 1 reads rr0[1 & 1]
+        st->rr0[0] = 0.0;
+        st->alpha = 0.0;
+        st->omega = 0.0;
+        st->stop_kind = 0;
+        st->stop_iter = (bnorm == 0.0) ? 0 : INT_MAX;
+    }
+}
+
+// K1: AP = A P ; partial AP·R0    (src/solvers.f90:30, :32 denominator).  80 B/row.
+template <int NB>
+__global__ __launch_bounds__(EC3D_THREADS) void k1_spmv_dot(MatView A, Sweep sw, const SolverState *st, int it,
+                                                            const double *__restrict__ p,
+                                                            const double *__restrict__ r0,
+                                                            double *__restrict__ ap, double *__restrict__ part)
+{
+    __shared__ double lds[4];
+    if (st->stop_iter < it) return;
+    double acc[1] = {0.0};
+    EC3D_SWEEP_BEGIN
+    double s0, s1;
+    spmv_pair<NB>(A, p, r, tile, s0, s1);
+    d2 q = *reinterpret_cast<const d2 *>(r0 + r);
+    *reinterpret_cast<d2 *>(ap + r) = d2{s0, s1};
+    acc[0] = acc[0] + s0 * q.x;
+    acc[0] = acc[0] + s1 * q.y;
+    EC3D_SWEEP_END
+    block_sum<1>(acc, lds);
+    if (threadIdx.x == 0) part[P_D1 * sw.nblk + blockIdx.x] = acc[0];
+}
+
+// K2: alpha = rr0 / (AP·R0) ; S = R - alpha*AP ; partial S·S   (src/solvers.f90:31-34).  24 B/row.
+__global__ __launch_bounds__(EC3D_THREADS) void k2_s_update(Sweep sw, SolverState *st, int it,
+                                                            const double *__restrict__ rv,
+                                                            const double *__restrict__ ap, double *__restrict__ sv,
+                                                            double *__restrict__ part)
+{
+    __shared__ double lds[4];
+    if (st->stop_iter < it) return;
+    const double *const pp[1] = {part + P_D1 * sw.nblk};
+    double d[1];
+    reduce_partials<1>(pp, sw.nblk, d, lds);
+    const double alpha = st->rr0[it & 1] / d[0];
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->alpha = alpha;
+    double acc[1] = {0.0};
+    EC3D_SWEEP_BEGIN
+    d2 a = *reinterpret_cast<const d2 *>(ap + r);
+    d2 q = *reinterpret_cast<const d2 *>(rv + r);
+    d2 s = d2{q.x - alpha * a.x, q.y - alpha * a.y};
+    *reinterpret_cast<d2 *>(sv + r) = s;
+    acc[0] = acc[0] + s.x * s.x;
+    acc[0] = acc[0] + s.y * s.y;
+    EC3D_SWEEP_END
+    block_sum<1>(acc, lds);
+    if (threadIdx.x == 0) part[P_SS * sw.nblk + blockIdx.x] = acc[0];
+}
+
+// K3: if ‖S‖/Bnorm < tol: X += alpha*P, exit (src/solvers.f90:34-38)
+//     else AS = A S ; partials AS·S and AS·AS (:39-40).  72 B/row.
+template <int NB>
+__global__ __launch_bounds__(EC3D_THREADS) void k3_spmv_dots(MatView A, Sweep sw, SolverState *st, int it,
+                                                             const double *__restrict__ sv,
+                                                             const double *__restrict__ p, double *__restrict__ x,
+                                                             double *__restrict__ as, double *__restrict__ part,
+                                                             double *hist, int64_t hist_cap)
+{
+    __shared__ double lds[8];
+    if (st->stop_iter < it) return;
+    const double *const pp[1] = {part + P_SS * sw.nblk};
+    double ss[1];
+    reduce_partials<1>(pp, sw.nblk, ss, lds);
+    const double snorm = sqrt(ss[0]);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && hist && it <= hist_cap) hist[2 * (int64_t)(it - 1)] = snorm;
+    if (snorm / st->bnorm < st->tol) {
+        const double alpha = st->alpha;
+        EC3D_SWEEP_BEGIN
+        d2 xv = *reinterpret_cast<const d2 *>(x + r);
+        d2 pv = *reinterpret_cast<const d2 *>(p + r);
+        *reinterpret_cast<d2 *>(x + r) = d2{xv.x + alpha * pv.x, xv.y + alpha * pv.y};
+        EC3D_SWEEP_END
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            st->stop_kind = 1;
+            st->stop_iter = it; // K4/K5 of this iteration test stop_iter <= it
+        }
+        return;
+    }
+    double acc[2] = {0.0, 0.0};
+    EC3D_SWEEP_BEGIN
+    double s0, s1;
+    spmv_pair<NB>(A, sv, r, tile, s0, s1);
+    d2 q = *reinterpret_cast<const d2 *>(sv + r);
+    *reinterpret_cast<d2 *>(as + r) = d2{s0, s1};
+    acc[0] = acc[0] + s0 * q.x;
+    acc[0] = acc[0] + s1 * q.y;
+    acc[1] = acc[1] + s0 * s0;
+    acc[1] = acc[1] + s1 * s1;
+    EC3D_SWEEP_END
+    block_sum<2>(acc, lds);
+    if (threadIdx.x == 0) {
+        part[P_D2 * sw.nblk + blockIdx.x] = acc[0];
+        part[P_D3 * sw.nblk + blockIdx.x] = acc[1];
+    }
+}
+
+// K4: omega = (AS·S)/(AS·AS) ; X = X + alpha*P + omega*S ; R = S - omega*AS ;
+//     partials R·R and R·R0   (src/solvers.f90:40-44).  56 B/row.
+__global__ __launch_bounds__(EC3D_THREADS) void k4_x_r_update(Sweep sw, SolverState *st, int it,
+                                                              const double *__restrict__ p,
+                                                              const double *__restrict__ sv,
+                                                              const double *__restrict__ as,
+                                                              const double *__restrict__ r0, double *__restrict__ x,
+                                                              double *__restrict__ rv, double *__restrict__ part)
+{
+    __shared__ double lds[8];
+    if (st->stop_iter <= it) return;
+    const double *const pp[2] = {part + P_D2 * sw.nblk, part + P_D3 * sw.nblk};
+    double d[2];
+    reduce_partials<2>(pp, sw.nblk, d, lds);
+    const double omega = d[0] / d[1];
+    const double alpha = st->alpha;
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->omega = omega;
+    double acc[2] = {0.0, 0.0};
+    EC3D_SWEEP_BEGIN
+    d2 xv = *reinterpret_cast<const d2 *>(x + r);
+    d2 pv = *reinterpret_cast<const d2 *>(p + r);
+    d2 s = *reinterpret_cast<const d2 *>(sv + r);
+    d2 a = *reinterpret_cast<const d2 *>(as + r);
+    d2 q = *reinterpret_cast<const d2 *>(r0 + r);
+    d2 xn = d2{(xv.x + alpha * pv.x) + omega * s.x, (xv.y + alpha * pv.y) + omega * s.y};
+    d2 rn = d2{s.x - omega * a.x, s.y - omega * a.y};
+    *reinterpret_cast<d2 *>(x + r) = xn;
+    *reinterpret_cast<d2 *>(rv + r) = rn;
+    acc[0] = acc[0] + rn.x * rn.x;
+    acc[0] = acc[0] + rn.y * rn.y;
+    acc[1] = acc[1] + rn.x * q.x;
+    acc[1] = acc[1] + rn.y * q.y;
+    EC3D_SWEEP_END
+    block_sum<2>(acc, lds);
+    if (threadIdx.x == 0) {
+        part[P_RR * sw.nblk + blockIdx.x] = acc[0];
+        part[P_RR0N * sw.nblk + blockIdx.x] = acc[1];
+    }
+}
+
+// K5: if ‖R‖/Bnorm < tol exit (src/solvers.f90:43) ; beta = (alpha/omega)*rr0_new/rr0 (:45) ;
+//     P = R + beta*(P - omega*AP) (:46) ; restart R0 = R, P = R when |rr0_new|/Bnorm < tol (:47-49).
+//     32 B/row (+16 on a restart).
+__global__ __launch_bounds__(EC3D_THREADS) void k5_p_update(Sweep sw, SolverState *st, int it,
+                                                            const double *__restrict__ rv,
+                                                            const double *__restrict__ ap, double *__restrict__ p,
+                                                            double *__restrict__ r0, const double *__restrict__ part,
+                                                            double *hist, int64_t hist_cap)
+{
+    __shared__ double lds[8];
+    if (st->stop_iter <= it) return;
+    const double *const pp[2] = {part + P_RR * sw.nblk, part + P_RR0N * sw.nblk};
+    double d[2];
+    reduce_partials<2>(pp, sw.nblk, d, lds);
+    const double rnorm = sqrt(d[0]);
+    const double bnorm = st->bnorm, tol = st->tol;
+    const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+    if (lead && hist && it <= hist_cap) hist[2 * (int64_t)(it - 1) + 1] = rnorm;
+    if (rnorm / bnorm < tol) {
+        if (lead) {
+            st->stop_kind = 2;
+            st->stop_iter = it;
+        }
+        return;
+    }
+    const double rr0_new = d[1];
+    const double alpha = st->alpha, omega = st->omega;
+    const double beta = (alpha / omega) * rr0_new / st->rr0[it & 1];
+    const bool restart = fabs(rr0_new) / bnorm < tol;
+    // next iteration's R·R0: after a restart R0 == R, so it is R·R in the same summation order
+    if (lead) st->rr0[(it + 1) & 1] = restart ? d[0] : rr0_new;
+    EC3D_SWEEP_BEGIN
+    d2 q = *reinterpret_cast<const d2 *>(rv + r);
+    if (restart) {
+        *reinterpret_cast<d2 *>(r0 + r) = q;
+        *reinterpret_cast<d2 *>(p + r) = q;
+    } else {
+        d2 pv = *reinterpret_cast<const d2 *>(p + r);
+        d2 a = *reinterpret_cast<const d2 *>(ap + r);
+        *reinterpret_cast<d2 *>(p + r) = d2{q.x + beta * (pv.x - omega * a.x), q.y + beta * (pv.y - omega * a.y)};
+    }
+    EC3D_SWEEP_END
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+#define EC3D_DISPATCH_NB(NBV, CALL7, CALLG)                                                    \
+    do {                                                                                       \
+        if ((NBV) == 7) { CALL7; } else { CALLG; }                                             \
+    } while (0)
+
+void ec3d_launch_spmv(const MatView &A, const Sweep &sw, const double *x, double *y, hipStream_t s)
+{
+    EC3D_DISPATCH_NB(A.nb, (k_spmv<7><<<sw.nblk, EC3D_THREADS, 0, s>>>(A, sw, x, y)),
+                     (k_spmv<0><<<sw.nblk, EC3D_THREADS, 0, s>>>(A, sw, x, y)));
+}
+
+void ec3d_launch_residual(const MatView &A, const Sweep &sw, const double *x, const double *b, double *r,
+                          double *r0, double *p, double *part, hipStream_t s)
+{
+    EC3D_DISPATCH_NB(A.nb, (k_residual<7><<<sw.nblk, EC3D_THREADS, 0, s>>>(A, sw, x, b, r, r0, p, part)),
+                     (k_residual<0><<<sw.nblk, EC3D_THREADS, 0, s>>>(A, sw, x, b, r, r0, p, part)));
+}
+
+void ec3d_launch_setup(SolverState *st, const double *part, int nblk, double tol, hipStream_t s)
+{
+    k_setup<<<1, EC3D_THREADS, 0, s>>>(st, part, nblk, tol);
+}
+
+void ec3d_launch_k1(const MatView &A, const Sweep &sw, const SolverState *st, int it, const double *p,
+                    const double *r0, double *ap, double *part, hipStream_t s)
+{
+    EC3D_DISPATCH_NB(A.nb, (k1_spmv_dot<7><<<sw.nblk, EC3D_THREADS, 0, s>>>(A, sw, st, it, p, r0, ap, part)),
+                     (k1_spmv_dot<0><<<sw.nblk, EC3D_THREADS, 0, s>>>(A, sw, st, it, p, r0, ap, part)));
+}
+
+void ec3d_launch_k2(const Sweep &sw, SolverState *st, int it, const double *r, const double *ap, double *sv,
+                    double *part, hipStream_t s)
+{
+    k2_s_update<<<sw.nblk, EC3D_THREADS, 0, s>>>(sw, st, it, r, ap, sv, part);
+}
+
+void ec3d_launch_k3(const MatView &A, const Sweep &sw, SolverState *st, int it, const double *sv,
+                    const double *p, double *x, double *as, double *part, double *hist, int64_t hist_cap,
+                    hipStream_t s)
+{
+    EC3D_DISPATCH_NB(
+        A.nb, (k3_spmv_dots<7><<<sw.nblk, EC3D_THREADS, 0, s>>>(A, sw, st, it, sv, p, x, as, part, hist, hist_cap)),
+        (k3_spmv_dots<0><<<sw.nblk, EC3D_THREADS, 0, s>>>(A, sw, st, it, sv, p, x, as, part, hist, hist_cap)));
+}
+
+void ec3d_launch_k4(const Sweep &sw, SolverState *st, int it, const double *p, const double *sv,
+                    const double *as, const double *r0, double *x, double *r, double *part, hipStream_t s)
+{
+    k4_x_r_update<<<sw.nblk, EC3D_THREADS, 0, s>>>(sw, st, it, p, sv, as, r0, x, r, part);
+}
+
+void ec3d_launch_k5(const Sweep &sw, SolverState *st, int it, double *r, const double *ap, double *p,
+                    double *r0, double *part, double *hist, int64_t hist_cap, hipStream_t s)
+{
+    k5_p_update<<<sw.nblk, EC3D_THREADS, 0, s>>>(sw, st, it, r, ap, p, r0, part, hist, hist_cap);
+}

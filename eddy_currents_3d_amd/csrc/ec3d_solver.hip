@@ -1,0 +1,601 @@
+// ec3d_solver.hip — context, device memory, the solve loop and the C ABI (include/ec3d_hip.h).
+//
+// Host side of src/solvers.f90:3-50.  The loop body is five asynchronous launches per iteration
+// (ec3d_kernels.hip); all scalars and the convergence decision stay on the device.  The host runs
+// ahead by up to two chunks of iterations and learns about an exit from an asynchronous copy of the
+// SolverState; launches issued past the exit are no-ops, so the result is exactly the reference's.
+#include "../../include/ec3d_hip.h"
+#include "ec3d_internal.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+static thread_local std::string g_err;
+void ec3d_set_error(const std::string &msg) { g_err = msg; }
+extern "C" const char *ec3d_last_error(void) { return g_err.c_str(); }
+
+static int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+MatView DevMatrix::view() const
+{
+    MatView v;
+    memset(&v, 0, sizeof v);
+    v.nb = nb;
+    for (int b = 0; b < nb; ++b) {
+        v.band[b] = bands + (size_t)b * n_pad;
+        v.off[b] = off[b];
+    }
+    v.has_tail = ntail > 0;
+    v.tail_id = tail_id;
+    v.tile_flag = tile_flag;
+    v.chunk_ptr = chunk_ptr;
+    v.tcol = tcol;
+    v.tval = tval;
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" int ec3d_create(ec3d_handle *h, int device)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        ec3d_set_error("ec3d_create: no HIP device available (this library has no CPU path)");
+        return 101;
+    }
+    if (device < 0 || device >= ndev) {
+        ec3d_set_error("ec3d_create: device ordinal out of range");
+        return 102;
+    }
+    EC3D_HIP(hipSetDevice(device));
+    ec3d_ctx *c = new ec3d_ctx();
+    c->device = device;
+    EC3D_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    EC3D_HIP(hipMalloc(&c->state, sizeof(SolverState)));
+    EC3D_HIP(hipHostMalloc(&c->state_pinned, 2 * sizeof(SolverState), hipHostMallocDefault));
+    for (int i = 0; i < 2; ++i) EC3D_HIP(hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming));
+    EC3D_HIP(hipEventCreate(&c->t0));
+    EC3D_HIP(hipEventCreate(&c->t1));
+    if (const char *e = getenv("EC3D_NBLK")) c->nblk_request = atoi(e);
+    *h = c;
+    return 0;
+}
+
+static void free_vectors(ec3d_ctx *c)
+{
+    if (c->vec_base) (void)hipFree(c->vec_base);
+    if (c->partials) (void)hipFree(c->partials);
+    c->vec_base = nullptr;
+    c->partials = nullptr;
+    for (auto &v : c->vec) v = nullptr;
+}
+
+void ec3d_free_matrix(ec3d_ctx *c)
+{
+    DevMatrix &A = c->A;
+    if (A.bands) (void)hipFree(A.bands);
+    if (A.tail_id) (void)hipFree(A.tail_id);
+    if (A.tile_flag) (void)hipFree(A.tile_flag);
+    if (A.chunk_ptr) (void)hipFree(A.chunk_ptr);
+    if (A.tcol) (void)hipFree(A.tcol);
+    if (A.tval) (void)hipFree(A.tval);
+    A = DevMatrix();
+    c->have_matrix = false;
+    free_vectors(c);
+    for (auto &l : c->cel_bnd) l.clear();
+    c->sdx = c->sdy = c->sdz = 0;
+}
+
+extern "C" int ec3d_destroy(ec3d_handle c)
+{
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    ec3d_free_matrix(c);
+    if (c->hist) (void)hipFree(c->hist);
+    if (c->state) (void)hipFree(c->state);
+    if (c->state_pinned) (void)hipHostFree(c->state_pinned);
+    for (int i = 0; i < 2; ++i)
+        if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->t0) (void)hipEventDestroy(c->t0);
+    if (c->t1) (void)hipEventDestroy(c->t1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+static void choose_sweep(ec3d_ctx *c)
+{
+    Sweep &sw = c->sweep;
+    sw.ntiles = c->A.n_pad / EC3D_TILE;
+    int want = c->nblk_request > 0 ? c->nblk_request : 2048; // 256 CUs x 8 workgroups
+    int64_t nblk = std::min<int64_t>(sw.ntiles, want);
+    if (nblk >= 8) {
+        nblk -= nblk % 8;
+        sw.S = (int)(nblk / 8);
+    } else {
+        sw.S = 0;
+    }
+    sw.nblk = (int)nblk;
+}
+
+// vectors: [ghost | n_pad | ghost] doubles each, zero filled; kernels only ever write [0, n_pad)
+int ec3d_prepare_vectors(ec3d_ctx *c)
+{
+    free_vectors(c);
+    int64_t maxoff = 0;
+    for (int b = 0; b < c->A.nb; ++b) maxoff = std::max<int64_t>(maxoff, std::llabs(c->A.off[b]));
+    c->ghost = round_up(maxoff + 2, 64);
+    const int64_t len = c->ghost + c->A.n_pad + c->ghost;
+    EC3D_HIP(hipMalloc(&c->vec_base, (size_t)len * EC3D_NVEC * sizeof(double)));
+    EC3D_HIP(hipMemsetAsync(c->vec_base, 0, (size_t)len * EC3D_NVEC * sizeof(double), c->stream));
+    for (int v = 0; v < EC3D_NVEC; ++v) c->vec[v] = c->vec_base + (size_t)v * len + c->ghost;
+    choose_sweep(c);
+    EC3D_HIP(hipMalloc(&c->partials, (size_t)P_NSLOT * c->sweep.nblk * sizeof(double)));
+    EC3D_HIP(hipMemsetAsync(c->partials, 0, (size_t)P_NSLOT * c->sweep.nblk * sizeof(double), c->stream));
+    EC3D_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int ec3d_set_workgroups(ec3d_handle c, int32_t nblk)
+{
+    c->nblk_request = nblk;
+    if (c->have_matrix) {
+        EC3D_HIP(hipSetDevice(c->device));
+        // partial buffer depends on nblk; vectors are kept
+        choose_sweep(c);
+        if (c->partials) (void)hipFree(c->partials);
+        EC3D_HIP(hipMalloc(&c->partials, (size_t)P_NSLOT * c->sweep.nblk * sizeof(double)));
+        EC3D_HIP(hipMemset(c->partials, 0, (size_t)P_NSLOT * c->sweep.nblk * sizeof(double)));
+    }
+    return 0;
+}
+
+template <class T>
+static int up(T *&dst, const std::vector<T> &src, int64_t &bytes, hipStream_t s)
+{
+    const size_t nb = std::max<size_t>(src.size(), 1) * sizeof(T);
+    EC3D_HIP(hipMalloc(&dst, nb));
+    if (!src.empty()) EC3D_HIP(hipMemcpyAsync(dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, s));
+    bytes += (int64_t)nb;
+    return 0;
+}
+
+int ec3d_upload_matrix(ec3d_ctx *c, const HostMatrix &M)
+{
+    EC3D_HIP(hipSetDevice(c->device));
+    ec3d_free_matrix(c);
+    DevMatrix &A = c->A;
+    A.n = M.n;
+    A.n_pad = M.n_pad;
+    A.nnz = M.nnz;
+    A.nb = M.nb;
+    for (int b = 0; b < M.nb; ++b) A.off[b] = M.off[b];
+    A.ntail = M.ntail;
+    A.nchunk = (int64_t)M.chunk_ptr.size() - 1;
+    A.tail_entries = M.chunk_ptr.empty() ? 0 : M.chunk_ptr.back();
+    int rc = 0;
+    if ((rc = up(A.bands, M.bands, A.bytes, c->stream))) return rc;
+    if ((rc = up(A.tail_id, M.tail_id, A.bytes, c->stream))) return rc;
+    if ((rc = up(A.tile_flag, M.tile_flag, A.bytes, c->stream))) return rc;
+    if ((rc = up(A.chunk_ptr, M.chunk_ptr, A.bytes, c->stream))) return rc;
+    if ((rc = up(A.tcol, M.tcol, A.bytes, c->stream))) return rc;
+    if ((rc = up(A.tval, M.tval, A.bytes, c->stream))) return rc;
+    EC3D_HIP(hipStreamSynchronize(c->stream));
+    c->have_matrix = true;
+    return ec3d_prepare_vectors(c);
+}
+
+template <class T>
+static int down(std::vector<T> &dst, const T *src, size_t cnt)
+{
+    dst.resize(cnt);
+    if (cnt) EC3D_HIP(hipMemcpy(dst.data(), src, cnt * sizeof(T), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int ec3d_download_matrix(ec3d_ctx *c, HostMatrix &M)
+{
+    EC3D_HIP(hipSetDevice(c->device));
+    EC3D_HIP(hipStreamSynchronize(c->stream));
+    const DevMatrix &A = c->A;
+    M = HostMatrix();
+    M.n = A.n;
+    M.n_pad = A.n_pad;
+    M.nnz = A.nnz;
+    M.nb = A.nb;
+    for (int b = 0; b < A.nb; ++b) M.off[b] = A.off[b];
+    M.ntail = A.ntail;
+    int rc = 0;
+    if ((rc = down(M.bands, A.bands, (size_t)A.nb * A.n_pad))) return rc;
+    if ((rc = down(M.tail_id, A.tail_id, (size_t)A.n_pad))) return rc;
+    if ((rc = down(M.tile_flag, A.tile_flag, (size_t)(A.n_pad / EC3D_TILE)))) return rc;
+    if ((rc = down(M.chunk_ptr, A.chunk_ptr, (size_t)A.nchunk + 1))) return rc;
+    if ((rc = down(M.tcol, A.tcol, (size_t)A.tail_entries))) return rc;
+    if ((rc = down(M.tval, A.tval, (size_t)A.tail_entries))) return rc;
+    return 0;
+}
+
+static int need_matrix(ec3d_ctx *c, const char *who)
+{
+    if (!c || !c->have_matrix) {
+        ec3d_set_error(std::string(who) + ": no matrix (call ec3d_set_matrix_csr / ec3d_assemble first)");
+        return 3;
+    }
+    EC3D_HIP(hipSetDevice(c->device));
+    return 0;
+}
+
+extern "C" int ec3d_set_matrix_csr(ec3d_handle c, int32_t n, const double *valA, const int32_t *irow,
+                                   const int32_t *jcol)
+{
+    HostMatrix M;
+    int rc = ec3d_csr_to_host_matrix(n, valA, irow, jcol, M);
+    if (rc) return rc;
+    return ec3d_upload_matrix(c, M);
+}
+
+extern "C" int ec3d_assemble(ec3d_handle c, int32_t sdx, int32_t sdy, int32_t sdz, const int8_t *geoPHYS,
+                             const int32_t *geoPHYS_C, const double *valPHYS, int32_t nsub_glob,
+                             const double *BND, const double *delta, double dt)
+{
+    EC3D_HIP(hipSetDevice(c->device));
+    return ec3d_assemble_device(c, sdx, sdy, sdz, geoPHYS, geoPHYS_C, valPHYS, nsub_glob, BND, delta, dt);
+}
+
+extern "C" int ec3d_assemble_poisson(ec3d_handle c, int32_t sdx, int32_t sdy, int32_t sdz, const double *BND,
+                                     const double *delta)
+{
+    EC3D_HIP(hipSetDevice(c->device));
+    return ec3d_assemble_poisson_device(c, sdx, sdy, sdz, BND, delta);
+}
+
+extern "C" int ec3d_export_csr(ec3d_handle c, int32_t *n, int64_t *nnz, int32_t *irow, int32_t *jcol,
+                               double *valA)
+{
+    int rc = need_matrix(c, "ec3d_export_csr");
+    if (rc) return rc;
+    HostMatrix M;
+    if ((rc = ec3d_download_matrix(c, M))) return rc;
+    std::vector<int32_t> ir, jc;
+    std::vector<double> va;
+    ec3d_host_matrix_to_csr(M, ir, jc, va);
+    *n = (int32_t)M.n;
+    *nnz = (int64_t)jc.size();
+    if (irow) memcpy(irow, ir.data(), ir.size() * sizeof(int32_t));
+    if (jcol) memcpy(jcol, jc.data(), jc.size() * sizeof(int32_t));
+    if (valA) memcpy(valA, va.data(), va.size() * sizeof(double));
+    return 0;
+}
+
+extern "C" int ec3d_get_cel_bnd(ec3d_handle c, int which, int32_t *count, int32_t *list)
+{
+    if (which < 0 || which > 5) return 2;
+    *count = (int32_t)c->cel_bnd[which].size();
+    if (list) memcpy(list, c->cel_bnd[which].data(), c->cel_bnd[which].size() * sizeof(int32_t));
+    return 0;
+}
+
+extern "C" int ec3d_get_reduction_geometry(ec3d_handle c, ec3d_geom *g)
+{
+    int rc = need_matrix(c, "ec3d_get_reduction_geometry");
+    if (rc) return rc;
+    g->n_pad = (int32_t)c->A.n_pad;
+    g->tile = EC3D_TILE;
+    g->nblk = c->sweep.nblk;
+    g->threads = EC3D_THREADS;
+    g->xcd_group = c->sweep.S;
+    return 0;
+}
+
+extern "C" int ec3d_get_matrix_info(ec3d_handle c, ec3d_matrix_info *info)
+{
+    int rc = need_matrix(c, "ec3d_get_matrix_info");
+    if (rc) return rc;
+    memset(info, 0, sizeof *info);
+    info->n = c->A.n;
+    info->n_pad = c->A.n_pad;
+    info->nnz = c->A.nnz;
+    info->nbands = c->A.nb;
+    for (int b = 0; b < c->A.nb; ++b) info->band_offset[b] = (int32_t)c->A.off[b];
+    info->tail_rows = c->A.ntail;
+    info->tail_entries_padded = c->A.tail_entries;
+    info->device_bytes = c->A.bytes + (c->ghost * 2 + c->A.n_pad) * (int64_t)EC3D_NVEC * 8;
+    return 0;
+}
+
+extern "C" int ec3d_upload(ec3d_handle c, int which, const double *host)
+{
+    int rc = need_matrix(c, "ec3d_upload");
+    if (rc) return rc;
+    if (which < 0 || which >= EC3D_NVEC) return 2;
+    EC3D_HIP(hipMemcpyAsync(c->vec[which], host, (size_t)c->A.n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    EC3D_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int ec3d_download(ec3d_handle c, int which, double *host)
+{
+    int rc = need_matrix(c, "ec3d_download");
+    if (rc) return rc;
+    if (which < 0 || which >= EC3D_NVEC) return 2;
+    EC3D_HIP(hipMemcpyAsync(host, c->vec[which], (size_t)c->A.n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    EC3D_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int ec3d_device_vector(ec3d_handle c, int which, double **device_ptr, int64_t *n)
+{
+    int rc = need_matrix(c, "ec3d_device_vector");
+    if (rc) return rc;
+    if (which < 0 || which >= EC3D_NVEC) return 2;
+    *device_ptr = c->vec[which];
+    *n = c->A.n;
+    return 0;
+}
+
+extern "C" int ec3d_device_synchronize(ec3d_handle c)
+{
+    EC3D_HIP(hipSetDevice(c->device));
+    EC3D_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int ec3d_spmv(ec3d_handle c, const double *x, double *y)
+{
+    int rc = need_matrix(c, "ec3d_spmv");
+    if (rc) return rc;
+    // P and AP serve as scratch
+    EC3D_HIP(hipMemcpyAsync(c->vec[EC3D_VEC_P], x, (size_t)c->A.n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    ec3d_launch_spmv(c->A.view(), c->sweep, c->vec[EC3D_VEC_P], c->vec[EC3D_VEC_AP], c->stream);
+    EC3D_HIP(hipGetLastError());
+    EC3D_HIP(hipMemcpyAsync(y, c->vec[EC3D_VEC_AP], (size_t)c->A.n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    EC3D_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+static void launch_iteration(ec3d_ctx *c, const MatView &A, int it)
+{
+    double **v = c->vec;
+    const Sweep &sw = c->sweep;
+    hipStream_t s = c->stream;
+    ec3d_launch_k1(A, sw, c->state, it, v[EC3D_VEC_P], v[EC3D_VEC_R0], v[EC3D_VEC_AP], c->partials, s);
+    ec3d_launch_k2(sw, c->state, it, v[EC3D_VEC_R], v[EC3D_VEC_AP], v[EC3D_VEC_S], c->partials, s);
+    ec3d_launch_k3(A, sw, c->state, it, v[EC3D_VEC_S], v[EC3D_VEC_P], v[EC3D_VEC_X], v[EC3D_VEC_AS], c->partials,
+                   c->hist, c->hist_cap, s);
+    ec3d_launch_k4(sw, c->state, it, v[EC3D_VEC_P], v[EC3D_VEC_S], v[EC3D_VEC_AS], v[EC3D_VEC_R0], v[EC3D_VEC_X],
+                   v[EC3D_VEC_R], c->partials, s);
+    ec3d_launch_k5(sw, c->state, it, v[EC3D_VEC_R], v[EC3D_VEC_AP], v[EC3D_VEC_P], v[EC3D_VEC_R0], c->partials,
+                   c->hist, c->hist_cap, s);
+}
+
+static int launch_setup(ec3d_ctx *c, const MatView &A, double tol)
+{
+    double **v = c->vec;
+    ec3d_launch_residual(A, c->sweep, v[EC3D_VEC_X], v[EC3D_VEC_B], v[EC3D_VEC_R], v[EC3D_VEC_R0], v[EC3D_VEC_P],
+                         c->partials, c->stream);
+    ec3d_launch_setup(c->state, c->partials, c->sweep.nblk, tol, c->stream);
+    EC3D_HIP(hipGetLastError());
+    return 0;
+}
+
+static int ensure_hist(ec3d_ctx *c, int64_t cap)
+{
+    if (cap <= 0) {
+        c->hist_cap = 0;
+        return 0;
+    }
+    if (c->hist) (void)hipFree(c->hist);
+    c->hist = nullptr;
+    EC3D_HIP(hipMalloc(&c->hist, (size_t)cap * 2 * sizeof(double)));
+    EC3D_HIP(hipMemsetAsync(c->hist, 0xFF, (size_t)cap * 2 * sizeof(double), c->stream)); // NaN = "not reached"
+    c->hist_cap = cap;
+    return 0;
+}
+
+static int solve_core(ec3d_ctx *c, double tol, int32_t itmax, int32_t *iter, double *hist_host, int32_t hist_cap,
+                      bool print_on_itmax)
+{
+    const MatView A = c->A.view();
+    const int64_t total = std::max<int64_t>(0, (int64_t)itmax + 1); // src/solvers.f90:25-29
+    int rc = ensure_hist(c, hist_host ? std::min<int64_t>(hist_cap, total) : 0);
+    if (rc) return rc;
+    if ((rc = launch_setup(c, A, tol))) return rc;
+
+    // iterations per poll: about 0.4 ms of device work, so an exit is noticed within ~1 ms
+    const double est_us = (double)c->A.n_pad * 264.0 / 4.0e6 + 12.0;
+    const int chunk = (int)std::min<double>(32.0, std::max<double>(1.0, 400.0 / est_us));
+    int64_t launched = 0;
+    int ci = 0;
+    bool stopped = false;
+    while (launched < total && !stopped) {
+        const int64_t m = std::min<int64_t>(chunk, total - launched);
+        for (int64_t i = 0; i < m; ++i) launch_iteration(c, A, (int)(++launched));
+        EC3D_HIP(hipGetLastError());
+        EC3D_HIP(hipMemcpyAsync(&c->state_pinned[ci & 1], c->state, sizeof(SolverState), hipMemcpyDeviceToHost,
+                                c->stream));
+        EC3D_HIP(hipEventRecord(c->ev[ci & 1], c->stream));
+        if (ci > 0) {
+            EC3D_HIP(hipEventSynchronize(c->ev[(ci - 1) & 1]));
+            if (c->state_pinned[(ci - 1) & 1].stop_iter != INT_MAX) stopped = true;
+        }
+        ++ci;
+    }
+    EC3D_HIP(hipStreamSynchronize(c->stream));
+    SolverState fin;
+    EC3D_HIP(hipMemcpy(&fin, c->state, sizeof fin, hipMemcpyDeviceToHost));
+    if (fin.stop_iter != INT_MAX) {
+        *iter = fin.stop_iter;
+    } else {
+        *iter = (int32_t)total; // itmax exit: the reference prints norm2(R) and returns (:25-28)
+        if (print_on_itmax) {
+            // ‖R‖ = sqrt(sum of the last K4 partials), summed here in workgroup order
+            std::vector<double> part((size_t)c->sweep.nblk);
+            EC3D_HIP(hipMemcpy(part.data(), c->partials + (size_t)P_RR * c->sweep.nblk,
+                               part.size() * sizeof(double), hipMemcpyDeviceToHost));
+            double s = 0.0;
+            for (double p : part) s += p;
+            if (total == 0) {
+                EC3D_HIP(hipMemcpy(part.data(), c->partials + (size_t)P_RR_INIT * c->sweep.nblk,
+                                   part.size() * sizeof(double), hipMemcpyDeviceToHost));
+                s = 0.0;
+                for (double p : part) s += p;
+            }
+            printf(" %.17g\n", std::sqrt(s));
+            fflush(stdout);
+        }
+    }
+    if (hist_host && c->hist_cap > 0)
+        EC3D_HIP(hipMemcpy(hist_host, c->hist, (size_t)c->hist_cap * 2 * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int ec3d_solve_resident(ec3d_handle c, double tolerance, int32_t itmax, int32_t *iter,
+                                   double *resid_hist, int32_t hist_cap)
+{
+    int rc = need_matrix(c, "ec3d_solve_resident");
+    if (rc) return rc;
+    return solve_core(c, tolerance, itmax, iter, resid_hist, hist_cap, true);
+}
+
+extern "C" int ec3d_solve(ec3d_handle c, const double *b, double *x, double tolerance, int32_t itmax,
+                          int32_t *iter, double *resid_hist, int32_t hist_cap)
+{
+    int rc = need_matrix(c, "ec3d_solve");
+    if (rc) return rc;
+    const size_t nb = (size_t)c->A.n * sizeof(double);
+    EC3D_HIP(hipMemcpyAsync(c->vec[EC3D_VEC_B], b, nb, hipMemcpyHostToDevice, c->stream));
+    EC3D_HIP(hipMemcpyAsync(c->vec[EC3D_VEC_X], x, nb, hipMemcpyHostToDevice, c->stream));
+    if ((rc = solve_core(c, tolerance, itmax, iter, resid_hist, hist_cap, true))) return rc;
+    EC3D_HIP(hipMemcpyAsync(x, c->vec[EC3D_VEC_X], nb, hipMemcpyDeviceToHost, c->stream));
+    EC3D_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// measurement
+extern "C" int ec3d_time_iterations(ec3d_handle c, int32_t iters, double *ms_total)
+{
+    int rc = need_matrix(c, "ec3d_time_iterations");
+    if (rc) return rc;
+    const MatView A = c->A.view();
+    c->hist_cap = 0;
+    if ((rc = launch_setup(c, A, -1.0))) return rc; // tol < 0: no exit, no restart
+    EC3D_HIP(hipEventRecord(c->t0, c->stream));
+    for (int it = 1; it <= iters; ++it) launch_iteration(c, A, it);
+    EC3D_HIP(hipEventRecord(c->t1, c->stream));
+    EC3D_HIP(hipGetLastError());
+    EC3D_HIP(hipEventSynchronize(c->t1));
+    float ms = 0.f;
+    EC3D_HIP(hipEventElapsedTime(&ms, c->t0, c->t1));
+    *ms_total = ms;
+    return 0;
+}
+
+extern "C" int ec3d_time_kernel(ec3d_handle c, int kernel, int32_t reps, double *ms_per_launch)
+{
+    int rc = need_matrix(c, "ec3d_time_kernel");
+    if (rc) return rc;
+    const MatView A = c->A.view();
+    double **v = c->vec;
+    const Sweep &sw = c->sweep;
+    hipStream_t s = c->stream;
+    c->hist_cap = 0;
+    if ((rc = launch_setup(c, A, -1.0))) return rc;
+    launch_iteration(c, A, 1); // populate every partial slot and the scalars
+    auto one = [&]() {
+        switch (kernel) {
+        case EC3D_K_SPMV: ec3d_launch_spmv(A, sw, v[EC3D_VEC_P], v[EC3D_VEC_AP], s); break;
+        case EC3D_K1: ec3d_launch_k1(A, sw, c->state, 2, v[EC3D_VEC_P], v[EC3D_VEC_R0], v[EC3D_VEC_AP], c->partials, s); break;
+        case EC3D_K2: ec3d_launch_k2(sw, c->state, 2, v[EC3D_VEC_R], v[EC3D_VEC_AP], v[EC3D_VEC_S], c->partials, s); break;
+        case EC3D_K3:
+            ec3d_launch_k3(A, sw, c->state, 2, v[EC3D_VEC_S], v[EC3D_VEC_P], v[EC3D_VEC_X], v[EC3D_VEC_AS], c->partials,
+                           nullptr, 0, s);
+            break;
+        case EC3D_K4:
+            ec3d_launch_k4(sw, c->state, 2, v[EC3D_VEC_P], v[EC3D_VEC_S], v[EC3D_VEC_AS], v[EC3D_VEC_R0], v[EC3D_VEC_X],
+                           v[EC3D_VEC_R], c->partials, s);
+            break;
+        default:
+            ec3d_launch_k5(sw, c->state, 2, v[EC3D_VEC_R], v[EC3D_VEC_AP], v[EC3D_VEC_P], v[EC3D_VEC_R0], c->partials,
+                           nullptr, 0, s);
+        }
+    };
+    one(); // warm
+    EC3D_HIP(hipEventRecord(c->t0, s));
+    for (int i = 0; i < reps; ++i) one();
+    EC3D_HIP(hipEventRecord(c->t1, s));
+    EC3D_HIP(hipGetLastError());
+    EC3D_HIP(hipEventSynchronize(c->t1));
+    float ms = 0.f;
+    EC3D_HIP(hipEventElapsedTime(&ms, c->t0, c->t1));
+    *ms_per_launch = (double)ms / std::max(1, reps);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// drop-in for src/solvers.f90:3 (called from src/EC3D.f90:408)
+namespace {
+struct DropIn {
+    ec3d_ctx *ctx = nullptr;
+    const void *valA = nullptr, *irow = nullptr, *jcol = nullptr;
+    int64_t n = 0, nnz = 0;
+    uint64_t sig = 0;
+    std::mutex mu;
+} g_drop;
+
+uint64_t sample_signature(const double *valA, const int32_t *jcol, int64_t nnz)
+{
+    // cheap change detector for callers that rebuild the matrix in place without telling us
+    uint64_t h = 1469598103934665603ull;
+    const int64_t step = std::max<int64_t>(1, nnz / 4096);
+    for (int64_t p = 0; p < nnz; p += step) {
+        uint64_t bits;
+        memcpy(&bits, &valA[p], 8);
+        h = (h ^ bits) * 1099511628211ull;
+        h = (h ^ (uint64_t)jcol[p]) * 1099511628211ull;
+    }
+    return h;
+}
+
+[[noreturn]] void die(const char *what)
+{
+    fprintf(stderr, "libec3d_hip: %s: %s\n", what, ec3d_last_error());
+    abort();
+}
+} // namespace
+
+extern "C" void ec3d_invalidate(void)
+{
+    std::lock_guard<std::mutex> lk(g_drop.mu);
+    if (g_drop.ctx) ec3d_free_matrix(g_drop.ctx);
+    g_drop.valA = nullptr;
+}
+
+extern "C" void sprsbcgstabwr_(double *valA, int32_t *irow, int32_t *jcol, int32_t *n, double *b, double *x,
+                               double *tolerance, int32_t *itmax, int32_t *iter)
+{
+    std::lock_guard<std::mutex> lk(g_drop.mu);
+    if (!g_drop.ctx) {
+        int dev = 0;
+        if (const char *e = getenv("EC3D_DEVICE")) dev = atoi(e);
+        if (ec3d_create(&g_drop.ctx, dev)) die("ec3d_create");
+    }
+    const int64_t nn = *n, nnz = (int64_t)irow[nn] - 1;
+    const uint64_t sig = sample_signature(valA, jcol, nnz);
+    if (!(g_drop.ctx->have_matrix && g_drop.valA == valA && g_drop.irow == irow && g_drop.jcol == jcol &&
+          g_drop.n == nn && g_drop.nnz == nnz && g_drop.sig == sig)) {
+        if (ec3d_set_matrix_csr(g_drop.ctx, *n, valA, irow, jcol)) die("ec3d_set_matrix_csr");
+        g_drop.valA = valA;
+        g_drop.irow = irow;
+        g_drop.jcol = jcol;
+        g_drop.n = nn;
+        g_drop.nnz = nnz;
+        g_drop.sig = sig;
+    }
+    if (ec3d_solve(g_drop.ctx, b, x, *tolerance, *itmax, iter, nullptr, 0)) die("ec3d_solve");
+}

@@ -1,0 +1,257 @@
+"""ctypes host over the C ABI of libec3d_hip.so (include/ec3d_hip.h).
+
+Mirrors the reference's interface for the hot path:
+
+* :func:`sprsBCGstabWR` — same name, argument order and meaning as
+  ``SUBROUTINE sprsBCGstabWR (valA, irow, jcol, n, b, x, tolerance, itmax, iter)``
+  (/root/reference/src/solvers.f90:3): 1-based CSR, ``x`` is updated in place (warm start),
+  ``iter`` is returned.
+* :class:`EC3DSolver` — the native handle API (assembly on the device, resident vectors,
+  residual history, timing hooks).
+
+No fallback: if the shared library or a HIP device is missing this raises :class:`EC3DError`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIBPATH = os.path.join(PKG, "libec3d_hip.so")
+
+
+class EC3DError(RuntimeError):
+    pass
+
+
+class Geom(C.Structure):
+    _fields_ = [("n_pad", C.c_int32), ("tile", C.c_int32), ("nblk", C.c_int32),
+                ("threads", C.c_int32), ("xcd_group", C.c_int32)]
+
+
+class MatrixInfo(C.Structure):
+    _fields_ = [("n", C.c_int64), ("n_pad", C.c_int64), ("nnz", C.c_int64), ("nbands", C.c_int32),
+                ("band_offset", C.c_int32 * 16), ("tail_rows", C.c_int64),
+                ("tail_entries_padded", C.c_int64), ("device_bytes", C.c_int64)]
+
+
+VEC = dict(X=0, B=1, R=2, R0=3, P=4, AP=5, S=6, AS=7)
+KERNEL = dict(spmv=0, k1=1, k2=2, k3=3, k4=4, k5=5)
+# algorithmic bytes per row of each kernel with 7 bands
+KERNEL_BYTES_PER_ROW = dict(spmv=72, k1=80, k2=24, k3=72, k4=56, k5=32)
+
+EXPORTS = ["sprsbcgstabwr_", "ec3d_invalidate", "ec3d_create", "ec3d_destroy", "ec3d_last_error",
+           "ec3d_set_matrix_csr", "ec3d_assemble", "ec3d_assemble_poisson", "ec3d_solve",
+           "ec3d_upload", "ec3d_download", "ec3d_device_vector", "ec3d_solve_resident", "ec3d_spmv",
+           "ec3d_export_csr", "ec3d_get_cel_bnd", "ec3d_get_reduction_geometry",
+           "ec3d_set_workgroups", "ec3d_get_matrix_info", "ec3d_time_kernel", "ec3d_time_iterations",
+           "ec3d_device_synchronize"]
+
+_f64 = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+_i32 = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+_i8 = np.ctypeslib.ndpointer(np.int8, flags="C_CONTIGUOUS")
+_lib = None
+
+
+def load_library(path: str | None = None) -> C.CDLL:
+    """dlopen libec3d_hip.so and declare every prototype of include/ec3d_hip.h."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIBPATH
+    if not os.path.exists(p):
+        raise EC3DError(f"{p} not built: run `python -m eddy_currents_3d_amd.build` "
+                        "(there is no CPU fallback)")
+    L = C.CDLL(p)
+    hp = C.c_void_p
+    L.ec3d_last_error.restype = C.c_char_p
+    L.ec3d_create.argtypes = [C.POINTER(hp), C.c_int]
+    L.ec3d_destroy.argtypes = [hp]
+    L.ec3d_set_matrix_csr.argtypes = [hp, C.c_int32, _f64, _i32, _i32]
+    L.ec3d_assemble.argtypes = [hp, C.c_int32, C.c_int32, C.c_int32, _i8, _i32, _f64, C.c_int32, _f64,
+                                _f64, C.c_double]
+    L.ec3d_assemble_poisson.argtypes = [hp, C.c_int32, C.c_int32, C.c_int32, _f64, _f64]
+    L.ec3d_solve.argtypes = [hp, _f64, _f64, C.c_double, C.c_int32, C.POINTER(C.c_int32), hp, C.c_int32]
+    L.ec3d_upload.argtypes = [hp, C.c_int, _f64]
+    L.ec3d_download.argtypes = [hp, C.c_int, _f64]
+    L.ec3d_device_vector.argtypes = [hp, C.c_int, C.POINTER(hp), C.POINTER(C.c_int64)]
+    L.ec3d_solve_resident.argtypes = [hp, C.c_double, C.c_int32, C.POINTER(C.c_int32), hp, C.c_int32]
+    L.ec3d_spmv.argtypes = [hp, _f64, _f64]
+    L.ec3d_export_csr.argtypes = [hp, C.POINTER(C.c_int32), C.POINTER(C.c_int64), hp, hp, hp]
+    L.ec3d_get_cel_bnd.argtypes = [hp, C.c_int, C.POINTER(C.c_int32), hp]
+    L.ec3d_get_reduction_geometry.argtypes = [hp, C.POINTER(Geom)]
+    L.ec3d_set_workgroups.argtypes = [hp, C.c_int32]
+    L.ec3d_get_matrix_info.argtypes = [hp, C.POINTER(MatrixInfo)]
+    L.ec3d_time_kernel.argtypes = [hp, C.c_int, C.c_int32, C.POINTER(C.c_double)]
+    L.ec3d_time_iterations.argtypes = [hp, C.c_int32, C.POINTER(C.c_double)]
+    L.ec3d_device_synchronize.argtypes = [hp]
+    L.sprsbcgstabwr_.argtypes = [_f64, _i32, _i32, C.POINTER(C.c_int32), _f64, _f64,
+                                 C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.sprsbcgstabwr_.restype = None
+    L.ec3d_invalidate.restype = None
+    if path is None:
+        _lib = L
+    return L
+
+
+def _chk(L, rc, what):
+    if rc != 0:
+        raise EC3DError(f"{what} failed ({rc}): {L.ec3d_last_error().decode()}")
+
+
+def sprsBCGstabWR(valA, irow, jcol, n, b, x, tolerance, itmax):
+    """Drop-in for the reference solver (src/solvers.f90:3, called at src/EC3D.f90:408).
+
+    ``valA`` f64[nnz], ``irow`` i32[n+1] and ``jcol`` i32[nnz] are the reference's 1-based CSR;
+    ``x`` (f64[n], C-contiguous) is the warm start and receives the solution in place.
+    Returns ``iter``.  Goes through the exported F77 symbol ``sprsbcgstabwr_`` itself."""
+    L = load_library()
+    if not (isinstance(x, np.ndarray) and x.dtype == np.float64 and x.flags.c_contiguous):
+        raise TypeError("x must be a C-contiguous float64 ndarray (updated in place)")
+    it = C.c_int32(0)
+    L.sprsbcgstabwr_(np.ascontiguousarray(valA, np.float64), np.ascontiguousarray(irow, np.int32),
+                     np.ascontiguousarray(jcol, np.int32), C.byref(C.c_int32(int(n))),
+                     np.ascontiguousarray(b, np.float64), x, C.byref(C.c_double(float(tolerance))),
+                     C.byref(C.c_int32(int(itmax))), C.byref(it))
+    return it.value
+
+
+class EC3DSolver:
+    """Handle API of include/ec3d_hip.h (one HIP device, one stream)."""
+
+    def __init__(self, device: int = 0, nblk: int | None = None):
+        self.L = load_library()
+        self.h = C.c_void_p()
+        _chk(self.L, self.L.ec3d_create(C.byref(self.h), device), "ec3d_create")
+        if nblk:
+            self.set_workgroups(nblk)
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.L.ec3d_destroy(self.h)
+            self.h = C.c_void_p()
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- matrix ---------------------------------------------------------------------------
+    def set_matrix_csr(self, valA, irow, jcol):
+        irow = np.ascontiguousarray(irow, np.int32)
+        _chk(self.L, self.L.ec3d_set_matrix_csr(self.h, len(irow) - 1, np.ascontiguousarray(valA, np.float64),
+                                                irow, np.ascontiguousarray(jcol, np.int32)),
+             "ec3d_set_matrix_csr")
+
+    def assemble(self, geoPHYS, geoPHYS_C, valPHYS, BND, delta, dt):
+        """geoPHYS/geoPHYS_C: [sdz, sdy, sdx] (C order == Fortran (i,j,k)); valPHYS (nsub_glob, 5);
+        BND (3, 2).  Replaces gen_sparse_matrix (src/EC3D.f90:465-1049)."""
+        sdz, sdy, sdx = geoPHYS.shape
+        vp = np.asarray(valPHYS, np.float64)
+        _chk(self.L, self.L.ec3d_assemble(
+            self.h, sdx, sdy, sdz, np.ascontiguousarray(geoPHYS, np.int8).reshape(-1),
+            np.ascontiguousarray(geoPHYS_C, np.int32).reshape(-1),
+            np.ascontiguousarray(vp.T).reshape(-1), vp.shape[0],
+            np.ascontiguousarray(np.asarray(BND, np.float64).T).reshape(-1),
+            np.ascontiguousarray(delta, np.float64), float(dt)), "ec3d_assemble")
+
+    def assemble_poisson(self, sdx, sdy, sdz, delta=(0.00333, 0.00333, 0.00333), bnd=-0.95):
+        BND = np.full(6, float(bnd)) if np.isscalar(bnd) else np.ascontiguousarray(
+            np.asarray(bnd, np.float64).T).reshape(-1)
+        _chk(self.L, self.L.ec3d_assemble_poisson(self.h, sdx, sdy, sdz, BND,
+                                                  np.ascontiguousarray(delta, np.float64)),
+             "ec3d_assemble_poisson")
+
+    def export_csr(self):
+        n, nnz = C.c_int32(0), C.c_int64(0)
+        _chk(self.L, self.L.ec3d_export_csr(self.h, C.byref(n), C.byref(nnz), None, None, None), "ec3d_export_csr")
+        irow = np.empty(n.value + 1, np.int32)
+        jcol = np.empty(nnz.value, np.int32)
+        valA = np.empty(nnz.value, np.float64)
+        _chk(self.L, self.L.ec3d_export_csr(self.h, C.byref(n), C.byref(nnz), irow.ctypes.data,
+                                            jcol.ctypes.data, valA.ctypes.data), "ec3d_export_csr")
+        return valA, irow, jcol
+
+    def cel_bnd(self):
+        out = []
+        for w in range(6):
+            k = C.c_int32(0)
+            _chk(self.L, self.L.ec3d_get_cel_bnd(self.h, w, C.byref(k), None), "ec3d_get_cel_bnd")
+            a = np.empty(max(k.value, 1), np.int32)
+            _chk(self.L, self.L.ec3d_get_cel_bnd(self.h, w, C.byref(k), a.ctypes.data), "ec3d_get_cel_bnd")
+            out.append(a[:k.value])
+        return out
+
+    @property
+    def info(self) -> MatrixInfo:
+        mi = MatrixInfo()
+        _chk(self.L, self.L.ec3d_get_matrix_info(self.h, C.byref(mi)), "ec3d_get_matrix_info")
+        return mi
+
+    @property
+    def n(self) -> int:
+        return int(self.info.n)
+
+    def geometry(self) -> Geom:
+        g = Geom()
+        _chk(self.L, self.L.ec3d_get_reduction_geometry(self.h, C.byref(g)), "ec3d_get_reduction_geometry")
+        return g
+
+    def set_workgroups(self, nblk: int):
+        _chk(self.L, self.L.ec3d_set_workgroups(self.h, int(nblk)), "ec3d_set_workgroups")
+
+    # ---- solve ----------------------------------------------------------------------------
+    def solve(self, b, x0, tolerance, itmax, hist_cap: int = 0):
+        """One reference solve (src/solvers.f90:3-50).  Returns (x, iter, hist[hist_cap, 2])."""
+        x = np.array(x0, dtype=np.float64, copy=True)
+        it = C.c_int32(0)
+        hist = np.full((max(hist_cap, 1), 2), np.nan)
+        _chk(self.L, self.L.ec3d_solve(self.h, np.ascontiguousarray(b, np.float64), x, float(tolerance),
+                                       int(itmax), C.byref(it), hist.ctypes.data if hist_cap else None,
+                                       hist_cap), "ec3d_solve")
+        return x, it.value, hist[:hist_cap]
+
+    def upload(self, which: str, a):
+        _chk(self.L, self.L.ec3d_upload(self.h, VEC[which], np.ascontiguousarray(a, np.float64)), "ec3d_upload")
+
+    def download(self, which: str):
+        a = np.empty(self.n)
+        _chk(self.L, self.L.ec3d_download(self.h, VEC[which], a), "ec3d_download")
+        return a
+
+    def device_vector(self, which: str):
+        p, n = C.c_void_p(), C.c_int64(0)
+        _chk(self.L, self.L.ec3d_device_vector(self.h, VEC[which], C.byref(p), C.byref(n)), "ec3d_device_vector")
+        return p.value, n.value
+
+    def solve_resident(self, tolerance, itmax, hist_cap: int = 0):
+        it = C.c_int32(0)
+        hist = np.full((max(hist_cap, 1), 2), np.nan)
+        _chk(self.L, self.L.ec3d_solve_resident(self.h, float(tolerance), int(itmax), C.byref(it),
+                                                hist.ctypes.data if hist_cap else None, hist_cap),
+             "ec3d_solve_resident")
+        return it.value, hist[:hist_cap]
+
+    def spmv(self, x):
+        y = np.empty(self.n)
+        _chk(self.L, self.L.ec3d_spmv(self.h, np.ascontiguousarray(x, np.float64), y), "ec3d_spmv")
+        return y
+
+    # ---- measurement ----------------------------------------------------------------------
+    def time_kernel(self, name: str, reps: int = 20) -> float:
+        ms = C.c_double(0)
+        _chk(self.L, self.L.ec3d_time_kernel(self.h, KERNEL[name], reps, C.byref(ms)), "ec3d_time_kernel")
+        return ms.value
+
+    def time_iterations(self, iters: int) -> float:
+        ms = C.c_double(0)
+        _chk(self.L, self.L.ec3d_time_iterations(self.h, iters, C.byref(ms)), "ec3d_time_iterations")
+        return ms.value
+
+    def synchronize(self):
+        _chk(self.L, self.L.ec3d_device_synchronize(self.h), "ec3d_device_synchronize")

@@ -1,0 +1,138 @@
+/*
+ * ec3d_hip.h — C ABI of libec3d_hip.so, the MI355X (gfx950) solver for the A–V eddy-current
+ * system of JNSresearcher/eddy_currents_3d.
+ *
+ * Scope: the BiCGSTAB-with-restart solve the reference time loop runs every step
+ * (src/EC3D.f90:408 -> src/solvers.f90:3-63) and the one-time assembly of its matrix
+ * (src/EC3D.f90:465-1049).  Everything is fp64; no CPU fallback exists: every entry point
+ * fails (status != 0 / abort in the F77 symbol) when no HIP device is usable.
+ *
+ * Plain C types only; all arrays are caller-owned host memory unless a name says "device".
+ * Fortran-side binding: see INTEGRATION.md (one `interface ... bind(C)` block) — arrays are
+ * column-major with i fastest, which is the same linear order as nn = i + (j-1)*sdx + (k-1)*sdx*sdy
+ * (src/EC3D.f90:506-510).
+ */
+#ifndef EC3D_HIP_H
+#define EC3D_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------
+ * 1. Drop-in for the reference solver symbol
+ *    replaces: SUBROUTINE sprsBCGstabWR (valA, irow, jcol, n, b, x, tolerance, itmax, iter)
+ *              src/solvers.f90:3 (external procedure, F77 ABI: lower case + '_', all by reference)
+ *    called from src/EC3D.f90:408.  Same observable behaviour: x in/out (warm start), iter out,
+ *    ‖b‖ = 0 -> iter = 0 and x untouched (:23), itmax exit after itmax+1 iterations with ‖R‖
+ *    printed (:25-28), restart rule (:47-49).  irow/jcol are 1-based (:58-59).
+ *    The device copy of the matrix is cached across calls (the reference assembles once,
+ *    src/EC3D.f90:115); ec3d_invalidate() drops the cache for callers that rebuild in place.
+ *    HIP failures abort with a message (the reference interface has no status channel).
+ * ---------------------------------------------------------------------------------------- */
+void sprsbcgstabwr_(double *valA, int32_t *irow, int32_t *jcol, int32_t *n, double *b, double *x,
+                    double *tolerance, int32_t *itmax, int32_t *iter);
+void ec3d_invalidate(void);
+
+/* ------------------------------------------------------------------------------------------
+ * 2. Native handle API (what a Fortran host binds through iso_c_binding)
+ *    Every function returns 0 on success, non-zero on failure; ec3d_last_error() has the text.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct ec3d_ctx *ec3d_handle;
+
+int ec3d_create(ec3d_handle *h, int device);
+int ec3d_destroy(ec3d_handle h);
+const char *ec3d_last_error(void);
+
+/* Matrix from the reference's CSR triple (src/EC3D.f90:36-38 irow/jcol/valA, 1-based).
+ * Converted once on the host to the device format: DIA bands + sliced-ELL tail. */
+int ec3d_set_matrix_csr(ec3d_handle h, int32_t n, const double *valA, const int32_t *irow,
+                        const int32_t *jcol);
+
+/* Assembly on the device, replaces gen_sparse_matrix (src/EC3D.f90:465-1049).
+ *   geoPHYS   int8  [sdx*sdy*sdz]   src/m_vxc2data.f90:43   domain id per cell
+ *   geoPHYS_C int32 [sdx*sdy*sdz]   src/m_vxc2data.f90:44   0 or U column id 3*nCells+m
+ *   valPHYS   f64   (nsub_glob,5)   src/m_vxc2data.f90:52   column-major
+ *   BND       f64   (3,2)           src/EC3D.f90:77         column-major
+ *   delta     f64   [3], dt                                  src/EC3D.f90:60-61
+ * Unknown layout [Ax | Ay | Az | U], n = 3*nCells + Ncells0 (src/EC3D.f90:101-106).
+ * Returns 3 where the reference would index out of range (conductor on the box boundary or
+ * thinner than 3 cells), 1/2 for its two STOPs (:717-720, :924-936). */
+int ec3d_assemble(ec3d_handle h, int32_t sdx, int32_t sdy, int32_t sdz, const int8_t *geoPHYS,
+                  const int32_t *geoPHYS_C, const double *valPHYS, int32_t nsub_glob,
+                  const double *BND, const double *delta, double dt);
+
+/* The non-conducting Ax block alone (src/EC3D.f90:528-654): the synthetic-cube operator of
+ * BASELINE.json configs 2 and 4; n = sdx*sdy*sdz. */
+int ec3d_assemble_poisson(ec3d_handle h, int32_t sdx, int32_t sdy, int32_t sdz, const double *BND,
+                          const double *delta);
+
+/* One solve, host vectors (H2D of b and x, D2H of x).  resid_hist (may be NULL) receives
+ * 2 doubles per iteration: ‖S‖₂ (src/solvers.f90:34) and ‖R‖₂ (:43), hist_cap = iterations. */
+int ec3d_solve(ec3d_handle h, const double *b, double *x, double tolerance, int32_t itmax,
+               int32_t *iter, double *resid_hist, int32_t hist_cap);
+
+/* Same with b and x already resident in HBM: the library-owned device vectors are filled
+ * with ec3d_upload / read with ec3d_download (or written by the caller's own kernels through
+ * ec3d_device_vector).  No host<->device vector traffic inside the call. */
+enum { EC3D_VEC_X = 0, EC3D_VEC_B = 1, EC3D_VEC_R = 2, EC3D_VEC_R0 = 3, EC3D_VEC_P = 4,
+       EC3D_VEC_AP = 5, EC3D_VEC_S = 6, EC3D_VEC_AS = 7, EC3D_NVEC = 8 };
+int ec3d_upload(ec3d_handle h, int which, const double *host);
+int ec3d_download(ec3d_handle h, int which, double *host);
+int ec3d_device_vector(ec3d_handle h, int which, double **device_ptr, int64_t *n);
+int ec3d_solve_resident(ec3d_handle h, double tolerance, int32_t itmax, int32_t *iter,
+                        double *resid_hist, int32_t hist_cap);
+
+/* y = A*x through the device format (src/solvers.f90:54-61), host vectors.  Parity probe. */
+int ec3d_spmv(ec3d_handle h, const double *x, double *y);
+
+/* Read the device matrix back as the reference's 1-based CSR (two-pass: jcol == NULL -> sizes). */
+int ec3d_export_csr(ec3d_handle h, int32_t *n, int64_t *nnz, int32_t *irow, int32_t *jcol,
+                    double *valA);
+
+/* Index lists the reference builds during assembly (src/EC3D.f90:758-760, :938-940), 1-based:
+ * which = 0..5 -> cel_bndX, Y, Z, Ux, Uy, Uz.  list == NULL -> count only. */
+int ec3d_get_cel_bnd(ec3d_handle h, int which, int32_t *count, int32_t *list);
+
+/* ------------------------------------------------------------------------------------------
+ * 3. Introspection / measurement
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t n_pad;     /* rows swept by every kernel (n rounded up to the tile)         */
+    int32_t tile;      /* rows per tile = 2 * threads                                   */
+    int32_t nblk;      /* workgroups per launch                                         */
+    int32_t threads;   /* 256                                                           */
+    int32_t xcd_group; /* S in the XCD-aware blockIdx -> tile map (0: plain grid stride) */
+} ec3d_geom;
+int ec3d_get_reduction_geometry(ec3d_handle h, ec3d_geom *g);
+int ec3d_set_workgroups(ec3d_handle h, int32_t nblk); /* 0 = default; multiple of 8 enables the XCD map */
+
+typedef struct {
+    int64_t n, n_pad, nnz;
+    int32_t nbands;
+    int32_t band_offset[16];
+    int64_t tail_rows, tail_entries_padded; /* sliced-ELL tail */
+    int64_t device_bytes;
+} ec3d_matrix_info;
+int ec3d_get_matrix_info(ec3d_handle h, ec3d_matrix_info *info);
+
+/* Time `reps` back-to-back launches of one kernel with hipEvents on the library's stream and
+ * return the average per launch in milliseconds.  kernel: */
+enum { EC3D_K_SPMV = 0,   /* y = A p                        72 B/row             */
+       EC3D_K1 = 1,       /* AP = A P, AP·R0                80 B/row                          */
+       EC3D_K2 = 2,       /* S = R - a AP, S·S              24 B/row                          */
+       EC3D_K3 = 3,       /* AS = A S, AS·S, AS·AS          72 B/row                          */
+       EC3D_K4 = 4,       /* X, R updates, R·R, R·R0        56 B/row                          */
+       EC3D_K5 = 5 };     /* P update                       32 B/row                          */
+int ec3d_time_kernel(ec3d_handle h, int kernel, int32_t reps, double *ms_per_launch);
+
+/* Run exactly `iters` BiCGSTAB iterations on the resident b/x (convergence exits disabled),
+ * timed with hipEvents on the library's stream; the bench "step". */
+int ec3d_time_iterations(ec3d_handle h, int32_t iters, double *ms_total);
+
+int ec3d_device_synchronize(ec3d_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,62 @@
+"""CPU-only: the C-ABI library builds, loads, exports every symbol include/ec3d_hip.h declares,
+and refuses to work without a HIP device (no CPU fallback)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import REPO
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from eddy_currents_3d_amd import build
+    build.build()
+    import eddy_currents_3d_amd as E
+    return E.load_library()
+
+
+def declared_symbols():
+    txt = open(os.path.join(REPO, "include", "ec3d_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(ec3d_[a-z_0-9]+|sprsbcgstabwr_)\s*\(", txt)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    from eddy_currents_3d_amd.solver import EXPORTS, LIBPATH
+    decl = declared_symbols()
+    assert "sprsbcgstabwr_" in decl and len(decl) >= 20
+    nm = subprocess.run(["nm", "-D", "--defined-only", LIBPATH], check=True, capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (\w+)", nm))
+    missing = [s for s in decl if s not in exported]
+    assert not missing, missing
+    assert sorted(EXPORTS) == decl  # the Python host binds exactly the header
+
+
+def test_no_oracle_or_cpu_fallback_in_product():
+    """The product must not import, link or execute anything under oracle/."""
+    pkg = os.path.join(REPO, "eddy_currents_3d_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h", ".f90")):
+                src = open(os.path.join(root, f), errors="replace").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert "liboracle" not in src and "ec3d_oracle" not in src, f
+    from eddy_currents_3d_amd.solver import LIBPATH
+    ldd = subprocess.run(["ldd", LIBPATH], capture_output=True, text=True).stdout
+    assert "oracle" not in ldd and "ref_solver" not in ldd
+
+
+def test_fails_loudly_without_a_device(lib):
+    import ctypes as C
+    import eddy_currents_3d_amd as E
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = os.path.exists("/dev/kfd")
+    if has_gpu:
+        pytest.skip("a GPU is present")
+    with pytest.raises(E.EC3DError, match="no HIP device"):
+        E.EC3DSolver()
