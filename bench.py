@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py — DOF·iters/s of the BiCGSTAB-with-restart hot path on MI355X (fp64).
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W     -> one JSON line on rank 0.
+  * a "step" is one BiCGSTAB iteration = one pass of src/solvers.f90:24-50 (2 SpMV, 5 dots, 2 norms,
+    4 vector updates) over the whole grid, convergence exits disabled so exactly K run;
+  * workload: synthetic N^3 7-point operator of BASELINE.json configs 2/4 (src/EC3D.f90:528-654 rule,
+    delta = 0.00333, BND = -0.95), default 512^3 = the grid the metric's roofline and strong-scaling
+    targets are quoted on; it fits one GPU (16 GB), so every N runs the SAME grid: scaling "strong".
+    RHS = the deterministic bar source of SURVEY §8c, x0 = 0; operator, b and x are resident in HBM
+    before the timed region starts (assembly is on the device, nothing crosses PCIe in the loop);
+  * N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), z-slab decomposition, halo
+    planes by send/recv and the dot products by all_gather (eddy_currents_3d_amd/dist.py);
+  * roofline: the dominant kernel K1 (AP = A·P fused with AP·R0), algorithmic 80 B/row,
+    duration measured live with hipEvents on the library's stream inside an extra instrumented pass
+    of the same K iterations; peak 8.0 TB/s (MI355X_MICROARCH.md);
+  * cpu_baseline (rank 0, N = 1 only): the unmodified reference solver (oracle/_ref/ref_solve,
+    src/solvers.f90 compiled with amdflang; "port" = our C restatement when that binary is absent)
+    on one host core, fixed iteration count on a bounded cube.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+ITER_BYTES_PER_DOF = 264       # K1 80 + K2 24 + K3 72 + K4 56 + K5 32
+K1_BYTES_PER_ROW = 80
+
+
+def bar_rhs(N, k0=0, k1=None):
+    """mu0*1e6 on the bar i,k in [N/2-2, N/2+3], j in [N/4, 3N/4] (1-based);
+    planes k0..k1-1 (0-based) only."""
+    import numpy as np
+    k1 = N if k1 is None else k1
+    mu0 = 0.12566370964050292e-05
+    b = np.zeros((k1 - k0, N, N))
+    lo, hi = N // 2 - 2, N // 2 + 3
+    ka, kb = max(lo - 1, k0), min(hi, k1)
+    if kb > ka:
+        b[ka - k0:kb - k0, N // 4 - 1:3 * N // 4, lo - 1:hi] = mu0 * 1e6
+    return b.reshape(-1)
+
+
+def cpu_baseline(budget_s=20.0):
+    """Reference solver on one host core, bounded sample (never the thing measured as product)."""
+    import numpy as np
+    from oracle import oracle as O
+    kind = "reference" if O.have_ref() else "port"
+    N = 192
+    valA, irow, jcol = O.poisson_csr(N, N, N)
+    b = bar_rhs(N)
+    n = N ** 3
+    # calibrate on 2 iterations, then spend the budget
+    x, it, sec = O.solve_process(kind, valA, irow, jcol, b, np.zeros(n), 1e-300, 1)
+    per_iter = sec / max(it, 1)
+    iters = int(max(4, min(200, budget_s / max(per_iter, 1e-3))))
+    x, it, sec = O.solve_process(kind, valA, irow, jcol, b, np.zeros(n), 1e-300, iters - 1)
+    return {"value": n * it / sec, "unit": "DOF*iters/s", "cores": 1, "kind": kind,
+            "sample": f"{N}^3 cube of the same operator/RHS (n={n}), {it} iterations of "
+                      f"{'src/solvers.f90 (amdflang -O2)' if kind == 'reference' else 'oracle/ec3d_oracle.c'}"
+                      f" in {sec:.1f} s, 1 thread, host cores available: {os.cpu_count()}"}
+
+
+def latest_traffic():
+    """HBM bytes per K1 launch from the committed PMC profile (profiles/*pmc*.json), or None."""
+    pdir = os.path.join(REPO, "profiles")
+    try:
+        cands = sorted(f for f in os.listdir(pdir) if f.endswith(".json") and "pmc" in f)
+        if not cands:
+            return None
+        with open(os.path.join(pdir, cands[-1])) as f:
+            return json.load(f)
+    except OSError:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--grid", type=int, default=512, help="cube edge N (512 = headline, 256 = config 2)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    args = ap.parse_args()
+
+    import torch  # first: the library then shares torch's HIP runtime
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run "
+                             "(--nproc-per-node N)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import numpy as np
+    import eddy_currents_3d_amd as E
+
+    N, K, W = args.grid, args.steps, args.warmup
+    n_global = N ** 3
+    kernel_ms = None
+    if world == 1:
+        s = E.EC3DSolver(device=local_rank)
+        s.assemble_poisson(N, N, N)
+        s.upload("B", bar_rhs(N))
+        s.upload("X", np.zeros(n_global))
+        s.iterate_begin()
+        s.iterate(1, W)
+        s.synchronize()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        s.iterate(W + 1, K)
+        s.synchronize()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        elapsed = t1 - t0
+        # instrumented pass of the same K iterations: hipEvents around every launch, library stream
+        kernel_ms = s.iterate(W + K + 1, K, per_kernel=True)
+        geom = s.geometry()
+        info = s.info
+        parallelism = "single GPU"
+    else:
+        from eddy_currents_3d_amd.dist import SlabSolver
+        s = SlabSolver.poisson_cube(N, rank, world, device=local_rank)
+        s.set_rhs(bar_rhs(N, s.k0, s.k1), np.zeros(s.n_local))
+        s.iterate_begin()
+        s.iterate(1, W)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        s.iterate(W + 1, K)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        el = torch.tensor([t1 - t0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        elapsed = float(el.item())
+        kernel_ms = s.iterate(W + K + 1, min(K, 20), per_kernel=True)
+        geom = s.local.geometry()
+        info = s.local.info
+        parallelism = f"z-slab x{world} (halo send/recv + all_gather of dot products, RCCL)"
+
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / K
+        value = n_global * K / elapsed
+        rows_per_launch = int(info.n)
+        k1_ms = kernel_ms["k1"]
+        achieved = K1_BYTES_PER_ROW * rows_per_launch / (k1_ms * 1e-3) / 1e9
+        tr = latest_traffic()
+        traffic = None
+        if tr and tr.get("grid") == N and tr.get("n_gpus", 1) == world:
+            traffic = tr.get("k1_hbm_bytes_per_launch")
+        out = {
+            "metric": "DOF*iters/s (fp64 BiCGSTAB-with-restart, 7-pt A-V operator)",
+            "value": value, "unit": "DOF*iters/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"synthetic {N}^3 7-pt operator (BASELINE config "
+                                   f"{'4' if N == 512 else '2'} grid), bar RHS, x0=0, exits disabled",
+                       "n": n_global, "grid": [N, N, N], "parallelism": parallelism,
+                       "workgroups": int(geom.nblk), "bytes_per_dof_iter": ITER_BYTES_PER_DOF},
+            "iter_hbm_frac": ITER_BYTES_PER_DOF * value / 1e9 / world / PEAK_HBM_GBS,
+            "kernel_ms": kernel_ms,
+            "roofline": {"bound": "hbm", "kernel": "k1_spmv_dot<7> (AP = A*P fused with AP.R0)",
+                         "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": achieved / PEAK_HBM_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": K1_BYTES_PER_ROW * rows_per_launch,
+                         "avg_launch_ms": k1_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.cpu_budget)
+            except Exception as e:  # the baseline is reporting only; never fail the GPU number on it
+                out["cpu_baseline"] = {"value": None, "unit": "DOF*iters/s", "cores": 1, "kind": "port",
+                                       "sample": f"failed: {e!r}"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -211,6 +211,12 @@ int ec3d_download_matrix(ec3d_ctx *c, HostMatrix &M)
     M.ntail = A.ntail;
     int rc = 0;
     if ((rc = down(M.bands, A.bands, (size_t)A.nb * A.n_pad))) return rc;
+    if (A.ntail == 0) { // band-only matrix (ec3d_assemble_poisson): no tail arrays on the device
+        M.tail_id.assign((size_t)A.n_pad, -1);
+        M.tile_flag.assign((size_t)(A.n_pad / EC3D_TILE), 0);
+        M.chunk_ptr.assign(1, 0);
+        return 0;
+    }
     if ((rc = down(M.tail_id, A.tail_id, (size_t)A.n_pad))) return rc;
     if ((rc = down(M.tile_flag, A.tile_flag, (size_t)(A.n_pad / EC3D_TILE)))) return rc;
     if ((rc = down(M.chunk_ptr, A.chunk_ptr, (size_t)A.nchunk + 1))) return rc;
@@ -493,6 +499,62 @@ extern "C" int ec3d_time_iterations(ec3d_handle c, int32_t iters, double *ms_tot
     float ms = 0.f;
     EC3D_HIP(hipEventElapsedTime(&ms, c->t0, c->t1));
     *ms_total = ms;
+    return 0;
+}
+
+// Bench "steps": exits disabled (tol < 0), launches only, no host synchronisation.
+extern "C" int ec3d_iterate_begin(ec3d_handle c)
+{
+    int rc = need_matrix(c, "ec3d_iterate_begin");
+    if (rc) return rc;
+    c->hist_cap = 0;
+    return launch_setup(c, c->A.view(), -1.0);
+}
+
+extern "C" int ec3d_iterate(ec3d_handle c, int32_t first_iter, int32_t count, double *kernel_ms)
+{
+    int rc = need_matrix(c, "ec3d_iterate");
+    if (rc) return rc;
+    const MatView A = c->A.view();
+    if (!kernel_ms) {
+        for (int it = first_iter; it < first_iter + count; ++it) launch_iteration(c, A, it);
+        EC3D_HIP(hipGetLastError());
+        return 0;
+    }
+    // per-kernel durations: an event at every kernel boundary of every iteration, on our stream
+    std::vector<hipEvent_t> ev((size_t)count * 6);
+    for (auto &e : ev) EC3D_HIP(hipEventCreate(&e));
+    double **v = c->vec;
+    const Sweep &sw = c->sweep;
+    hipStream_t s = c->stream;
+    for (int i = 0; i < count; ++i) {
+        const int it = first_iter + i;
+        hipEvent_t *e = &ev[(size_t)i * 6];
+        EC3D_HIP(hipEventRecord(e[0], s));
+        ec3d_launch_k1(A, sw, c->state, it, v[EC3D_VEC_P], v[EC3D_VEC_R0], v[EC3D_VEC_AP], c->partials, s);
+        EC3D_HIP(hipEventRecord(e[1], s));
+        ec3d_launch_k2(sw, c->state, it, v[EC3D_VEC_R], v[EC3D_VEC_AP], v[EC3D_VEC_S], c->partials, s);
+        EC3D_HIP(hipEventRecord(e[2], s));
+        ec3d_launch_k3(A, sw, c->state, it, v[EC3D_VEC_S], v[EC3D_VEC_P], v[EC3D_VEC_X], v[EC3D_VEC_AS], c->partials,
+                       nullptr, 0, s);
+        EC3D_HIP(hipEventRecord(e[3], s));
+        ec3d_launch_k4(sw, c->state, it, v[EC3D_VEC_P], v[EC3D_VEC_S], v[EC3D_VEC_AS], v[EC3D_VEC_R0], v[EC3D_VEC_X],
+                       v[EC3D_VEC_R], c->partials, s);
+        EC3D_HIP(hipEventRecord(e[4], s));
+        ec3d_launch_k5(sw, c->state, it, v[EC3D_VEC_R], v[EC3D_VEC_AP], v[EC3D_VEC_P], v[EC3D_VEC_R0], c->partials,
+                       nullptr, 0, s);
+        EC3D_HIP(hipEventRecord(e[5], s));
+    }
+    EC3D_HIP(hipGetLastError());
+    EC3D_HIP(hipStreamSynchronize(s));
+    for (int k = 0; k < 5; ++k) kernel_ms[k] = 0.0;
+    for (int i = 0; i < count; ++i)
+        for (int k = 0; k < 5; ++k) {
+            float ms = 0.f;
+            EC3D_HIP(hipEventElapsedTime(&ms, ev[(size_t)i * 6 + k], ev[(size_t)i * 6 + k + 1]));
+            kernel_ms[k] += (double)ms / count;
+        }
+    for (auto &e : ev) (void)hipEventDestroy(e);
     return 0;
 }
 

@@ -47,6 +47,7 @@ EXPORTS = ["sprsbcgstabwr_", "ec3d_invalidate", "ec3d_create", "ec3d_destroy", "
            "ec3d_upload", "ec3d_download", "ec3d_device_vector", "ec3d_solve_resident", "ec3d_spmv",
            "ec3d_export_csr", "ec3d_get_cel_bnd", "ec3d_get_reduction_geometry",
            "ec3d_set_workgroups", "ec3d_get_matrix_info", "ec3d_time_kernel", "ec3d_time_iterations",
+           "ec3d_iterate_begin", "ec3d_iterate",
            "ec3d_device_synchronize"]
 
 _f64 = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
@@ -87,6 +88,8 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.ec3d_time_kernel.argtypes = [hp, C.c_int, C.c_int32, C.POINTER(C.c_double)]
     L.ec3d_time_iterations.argtypes = [hp, C.c_int32, C.POINTER(C.c_double)]
     L.ec3d_device_synchronize.argtypes = [hp]
+    L.ec3d_iterate_begin.argtypes = [hp]
+    L.ec3d_iterate.argtypes = [hp, C.c_int32, C.c_int32, hp]
     L.sprsbcgstabwr_.argtypes = [_f64, _i32, _i32, C.POINTER(C.c_int32), _f64, _f64,
                                  C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.sprsbcgstabwr_.restype = None
@@ -252,6 +255,19 @@ class EC3DSolver:
         ms = C.c_double(0)
         _chk(self.L, self.L.ec3d_time_iterations(self.h, iters, C.byref(ms)), "ec3d_time_iterations")
         return ms.value
+
+    def iterate_begin(self):
+        _chk(self.L, self.L.ec3d_iterate_begin(self.h), "ec3d_iterate_begin")
+
+    def iterate(self, first_iter: int, count: int, per_kernel: bool = False):
+        """Enqueue `count` iterations (exits disabled).  per_kernel=True: synchronises and returns
+        the average duration of K1..K5 in ms (hipEvents on the library's stream)."""
+        if not per_kernel:
+            _chk(self.L, self.L.ec3d_iterate(self.h, first_iter, count, None), "ec3d_iterate")
+            return None
+        ms = np.zeros(5)
+        _chk(self.L, self.L.ec3d_iterate(self.h, first_iter, count, ms.ctypes.data), "ec3d_iterate")
+        return dict(zip(("k1", "k2", "k3", "k4", "k5"), ms.tolist()))
 
     def synchronize(self):
         _chk(self.L, self.L.ec3d_device_synchronize(self.h), "ec3d_device_synchronize")

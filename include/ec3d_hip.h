@@ -130,6 +130,14 @@ int ec3d_time_kernel(ec3d_handle h, int kernel, int32_t reps, double *ms_per_lau
  * timed with hipEvents on the library's stream; the bench "step". */
 int ec3d_time_iterations(ec3d_handle h, int32_t iters, double *ms_total);
 
+/* The same as asynchronous launches for a caller that does its own timing (bench.py):
+ * ec3d_iterate_begin sets up R, R0, P from the resident b/x with exits disabled; ec3d_iterate
+ * enqueues iterations first_iter .. first_iter+count-1 and returns without synchronising.
+ * With kernel_ms != NULL (5 doubles, K1..K5) it brackets every launch with hipEvents on the
+ * library's stream, synchronises, and returns each kernel's average duration in ms. */
+int ec3d_iterate_begin(ec3d_handle h);
+int ec3d_iterate(ec3d_handle h, int32_t first_iter, int32_t count, double *kernel_ms);
+
 int ec3d_device_synchronize(ec3d_handle h);
 
 #ifdef __cplusplus
