@@ -18,7 +18,9 @@
 namespace {
 
 struct GridPar {
-    int sdx, sdy, sdz;
+    int sdx, sdy, sdz; // global grid
+    int k0;            // first plane held (z-slab; 0 otherwise)
+    int zero_cls;      // dictionary class whose coefficients are all 0 (U rows, padding)
     int64_t kdz, nCells, n_pad;
     double s[3];     // 1/delta^2          :496-498
     double ds[3];    // 0.5/delta          :499-501
@@ -54,6 +56,50 @@ __device__ __forceinline__ void a_row_bands(const GridPar &g, int i, int j, int 
     c[3] = on_box ? (dg[0] * g.s[0] + dg[1] * g.s[1]) + dg[2] * g.s[2] : 2.0 * ((g.s[0] + g.s[1]) + g.s[2]);
 }
 
+// dictionary class of the A row of a cell: 0..26 = position type tx + 3 ty + 9 tz (t = 0 low edge,
+// 1 inside, 2 high edge; 13 = interior, non-conducting), 27 + (domain - 1) = interior conducting cell
+__device__ __forceinline__ int a_row_class(const GridPar &g, int i, int j, int k, int cond_dom)
+{
+    const int tx = i == 1 ? 0 : (i == g.sdx ? 2 : 1), ty = j == 1 ? 0 : (j == g.sdy ? 2 : 1),
+              tz = k == 1 ? 0 : (k == g.sdz ? 2 : 1);
+    const int bt = tx + 3 * ty + 9 * tz;
+    return (bt == 13 && cond_dom > 0) ? 27 + cond_dom - 1 : bt;
+}
+
+// :657-663 conductor velocity (advection) and inertia terms, identical for Ax/Ay/Az
+__device__ __forceinline__ void conductor_terms(const GridPar &g, const double *__restrict__ valPHYS, int ndom,
+                                                double (&c)[7])
+{
+    const double C = valPHYS[1 * (int64_t)g.nsub_glob + ndom - 1];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const double h = valPHYS[(2 + d) * (int64_t)g.nsub_glob + ndom - 1] / (2.0 * g.delta[d]);
+        c[2 - d] = c[2 - d] - h;
+        c[4 + d] = c[4 + d] + h;
+    }
+    c[3] = c[3] + 2.0 * C / g.dt;
+}
+
+// one thread per class: evaluates the very same device functions on a representative cell
+__global__ void k_build_table(GridPar g, const double *__restrict__ valPHYS, double *table, int ncls)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= ncls) return;
+    double c[7] = {0, 0, 0, 0, 0, 0, 0};
+    if (q < 27) {
+        const int t[3] = {q % 3, (q / 3) % 3, q / 9}, sd[3] = {g.sdx, g.sdy, g.sdz};
+        int p[3];
+        for (int d = 0; d < 3; ++d) p[d] = t[d] == 0 ? 1 : (t[d] == 2 ? sd[d] : 2);
+        bool on_box;
+        a_row_bands(g, p[0], p[1], p[2], c, on_box);
+    } else if (q != g.zero_cls) {
+        bool on_box;
+        a_row_bands(g, 2, 2, 2, c, on_box);
+        conductor_terms(g, valPHYS, q - 27 + 1, c);
+    }
+    for (int b = 0; b < 7; ++b) table[q * 7 + b] = c[b];
+}
+
 __device__ __forceinline__ void sort_small(int32_t *col, double *val, int L)
 {
     for (int a = 1; a < L; ++a) {
@@ -76,11 +122,16 @@ __device__ __forceinline__ void put_tail(const int64_t *chunk_ptr, int32_t *tcol
     }
 }
 
-__global__ __launch_bounds__(256) void k_assemble_poisson(GridPar g, double *bands)
+// nCells here = cells of the slab held (planes k0 .. k0 + nCells/kdz - 1 of the global grid)
+__global__ __launch_bounds__(256) void k_assemble_poisson(GridPar g, double *bands, uint8_t *cls)
 {
     const int64_t nn0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (nn0 >= g.nCells) return;
-    const int i = (int)(nn0 % g.sdx) + 1, j = (int)((nn0 / g.sdx) % g.sdy) + 1, k = (int)(nn0 / g.kdz) + 1;
+    const int i = (int)(nn0 % g.sdx) + 1, j = (int)((nn0 / g.sdx) % g.sdy) + 1, k = g.k0 + (int)(nn0 / g.kdz) + 1;
+    if (cls) {
+        cls[nn0] = (uint8_t)a_row_class(g, i, j, k, 0);
+        return;
+    }
     double c[7];
     bool on_box;
     a_row_bands(g, i, j, k, c, on_box);
@@ -94,7 +145,7 @@ __global__ __launch_bounds__(256) void k_assemble_av(GridPar g, const int8_t *__
                                                      const int32_t *__restrict__ geoC,
                                                      const int32_t *__restrict__ uidx,
                                                      const double *__restrict__ valPHYS, double *bands,
-                                                     int32_t *tail_id, uint8_t *tile_flag, const int64_t *chunk_ptr,
+                                                     uint8_t *cls, int32_t *tail_id, uint8_t *tile_flag, const int64_t *chunk_ptr,
                                                      int32_t *tcol, double *tval, uint8_t *flags, int *err,
                                                      unsigned long long *nnz)
 {
@@ -114,14 +165,7 @@ __global__ __launch_bounds__(256) void k_assemble_av(GridPar g, const int8_t *__
     if (u0 != 0 && on_box) { atomicMax(err, 3); return; }
     if (u0 != 0) {
         const double C = valPHYS[1 * (int64_t)g.nsub_glob + ndom - 1];
-        // :657-663 conductor velocity (advection) and inertia terms, identical for Ax/Ay/Az
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const double h = valPHYS[(2 + d) * (int64_t)g.nsub_glob + ndom - 1] / (2.0 * g.delta[d]);
-            c[2 - d] = c[2 - d] - h;
-            c[4 + d] = c[4 + d] + h;
-        }
-        c[3] = c[3] + 2.0 * C / g.dt;
+        conductor_terms(g, valPHYS, ndom, c);
         const int64_t m = uidx[nn0];
         const int64_t step[3] = {1, g.sdx, g.kdz};
         const int pos[3] = {i, j, k}, sd[3] = {g.sdx, g.sdy, g.sdz};
@@ -225,11 +269,18 @@ __global__ __launch_bounds__(256) void k_assemble_av(GridPar g, const int8_t *__
             cnt += (unsigned long long)L;
         }
     }
+    if (cls) {
+        const uint8_t q = (uint8_t)a_row_class(g, i, j, k, u0 != 0 ? ndom : 0);
+        cls[nn0] = q;
+        cls[g.nCells + nn0] = q;
+        cls[2 * g.nCells + nn0] = q;
+    } else {
 #pragma unroll
-    for (int b = 0; b < 7; ++b) {
-        bands[(size_t)b * g.n_pad + nn0] = c[b];
-        bands[(size_t)b * g.n_pad + g.nCells + nn0] = c[b];
-        bands[(size_t)b * g.n_pad + 2 * g.nCells + nn0] = c[b];
+        for (int b = 0; b < 7; ++b) {
+            bands[(size_t)b * g.n_pad + nn0] = c[b];
+            bands[(size_t)b * g.n_pad + g.nCells + nn0] = c[b];
+            bands[(size_t)b * g.n_pad + 2 * g.nCells + nn0] = c[b];
+        }
     }
     if (flags) flags[nn0] = fl;
     atomicAdd(nnz, cnt);
@@ -265,13 +316,32 @@ void set_offsets(DevMatrix &A, const GridPar &g)
 
 static int64_t round_up64(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
-int ec3d_assemble_poisson_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t sdz, const double *BND,
-                                 const double *delta)
+// dictionary for natively assembled operators: 27 position classes, one per domain, one all-zero
+static int build_device_table(ec3d_ctx *c, GridPar &g, const double *d_valPHYS, int nsub_glob)
+{
+    DevMatrix &A = c->A;
+    const int ncls = 27 + nsub_glob + 1;
+    if (ncls > 256) return 0;
+    g.zero_cls = ncls - 1;
+    A.ncls = ncls;
+    EC3D_HIP(hipMalloc(&A.table, (size_t)ncls * 7 * sizeof(double)));
+    k_build_table<<<(ncls + 63) / 64, 64, 0, c->stream>>>(g, d_valPHYS, A.table, ncls);
+    EC3D_HIP(hipGetLastError());
+    EC3D_HIP(hipMalloc(&A.cls, (size_t)A.n_pad));
+    EC3D_HIP(hipMemsetAsync(A.cls, g.zero_cls, (size_t)A.n_pad, c->stream));
+    A.bytes += (int64_t)A.n_pad + ncls * 56;
+    return ncls;
+}
+
+int ec3d_assemble_poisson_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t sdz, int32_t k0, int32_t k1,
+                                 const double *BND, const double *delta)
 {
     GridPar g;
     memset(&g, 0, sizeof g);
     int rc = fill_gridpar(g, sdx, sdy, sdz, BND, delta, 1.0);
     if (rc) return rc;
+    g.k0 = k0;
+    g.nCells = g.kdz * (k1 - k0); // cells held by this handle
     if (g.nCells > (int64_t)INT32_MAX - EC3D_TILE) {
         ec3d_set_error("ec3d_assemble_poisson: more than 2^31 unknowns");
         return 2;
@@ -281,24 +351,32 @@ int ec3d_assemble_poisson_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t 
     A.n = g.nCells;
     A.n_pad = g.n_pad = round_up64(A.n, EC3D_TILE);
     set_offsets(A, g);
-    const size_t bb = (size_t)7 * A.n_pad * sizeof(double);
-    EC3D_HIP(hipMalloc(&A.bands, bb));
-    EC3D_HIP(hipMemsetAsync(A.bands, 0, bb, c->stream));
     // unused tail arrays still need valid pointers
     EC3D_HIP(hipMalloc(&A.tail_id, 8));
     EC3D_HIP(hipMalloc(&A.tile_flag, 8));
     EC3D_HIP(hipMalloc(&A.chunk_ptr, 8));
     EC3D_HIP(hipMalloc(&A.tcol, 8));
     EC3D_HIP(hipMalloc(&A.tval, 8));
-    A.bytes = (int64_t)bb;
     const int64_t nblk = (g.nCells + 255) / 256;
-    k_assemble_poisson<<<(unsigned)nblk, 256, 0, c->stream>>>(g, A.bands);
+    if (c->use_dict) {
+        if (build_device_table(c, g, nullptr, 0) <= 0) return 100;
+        k_assemble_poisson<<<(unsigned)nblk, 256, 0, c->stream>>>(g, nullptr, A.cls);
+    } else {
+        const size_t bb = (size_t)7 * A.n_pad * sizeof(double);
+        EC3D_HIP(hipMalloc(&A.bands, bb));
+        EC3D_HIP(hipMemsetAsync(A.bands, 0, bb, c->stream));
+        A.bytes = (int64_t)bb;
+        k_assemble_poisson<<<(unsigned)nblk, 256, 0, c->stream>>>(g, A.bands, nullptr);
+    }
     EC3D_HIP(hipGetLastError());
     EC3D_HIP(hipStreamSynchronize(c->stream));
-    // nnz = 7 n - 2 (sdx sdy + sdy sdz + sdx sdz)   (one neighbour dropped per boundary face cell)
-    A.nnz = 7 * g.nCells - 2 * ((int64_t)sdx * sdy + (int64_t)sdy * sdz + (int64_t)sdx * sdz);
+    // one neighbour is dropped per cell on each GLOBAL box face
+    const int64_t planes = k1 - k0;
+    A.nnz = 7 * g.nCells - 2 * ((int64_t)sdy * planes + (int64_t)sdx * planes) -
+            ((k0 == 0) + (k1 == sdz)) * (int64_t)sdx * sdy;
     c->have_matrix = true;
     c->sdx = sdx; c->sdy = sdy; c->sdz = sdz;
+    c->halo = (k0 == 0 && k1 == sdz) ? 0 : g.kdz;
     return ec3d_prepare_vectors(c);
 }
 
@@ -342,10 +420,12 @@ int ec3d_assemble_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t sdz, con
         cp[(size_t)q + 1] = cp[(size_t)q] + w * EC3D_CHUNK;
     }
     A.tail_entries = cp.back();
-    const size_t bb = (size_t)7 * A.n_pad * sizeof(double);
+    const size_t bb = c->use_dict && nsub_glob + 28 <= 256 ? 0 : (size_t)7 * A.n_pad * sizeof(double);
     const size_t te = (size_t)std::max<int64_t>(A.tail_entries, 1);
-    EC3D_HIP(hipMalloc(&A.bands, bb));
-    EC3D_HIP(hipMemsetAsync(A.bands, 0, bb, c->stream));
+    if (bb) {
+        EC3D_HIP(hipMalloc(&A.bands, bb));
+        EC3D_HIP(hipMemsetAsync(A.bands, 0, bb, c->stream));
+    }
     EC3D_HIP(hipMalloc(&A.tail_id, (size_t)A.n_pad * 4));
     EC3D_HIP(hipMemsetAsync(A.tail_id, 0xFF, (size_t)A.n_pad * 4, c->stream));
     EC3D_HIP(hipMalloc(&A.tile_flag, (size_t)(A.n_pad / EC3D_TILE)));
@@ -378,8 +458,9 @@ int ec3d_assemble_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t sdz, con
     EC3D_HIP(hipMemcpyAsync(d_val, valPHYS, (size_t)nsub_glob * 5 * 8, hipMemcpyHostToDevice, c->stream));
     EC3D_HIP(hipMemsetAsync(d_err, 0, sizeof(int), c->stream));
     EC3D_HIP(hipMemsetAsync(d_nnz, 0, sizeof(unsigned long long), c->stream));
+    if (!bb && build_device_table(c, g, d_val, nsub_glob) <= 0) return 100;
     const int64_t nblk = (g.nCells + 255) / 256;
-    k_assemble_av<<<(unsigned)nblk, 256, 0, c->stream>>>(g, d_geo, d_geoC, d_uidx, d_val, A.bands, A.tail_id,
+    k_assemble_av<<<(unsigned)nblk, 256, 0, c->stream>>>(g, d_geo, d_geoC, d_uidx, d_val, A.bands, A.cls, A.tail_id,
                                                          A.tile_flag, A.chunk_ptr, A.tcol, A.tval, d_flags, d_err,
                                                          d_nnz);
     EC3D_HIP(hipGetLastError());

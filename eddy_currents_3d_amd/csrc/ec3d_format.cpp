@@ -9,6 +9,7 @@
 #include "ec3d_internal.hpp"
 
 #include <algorithm>
+#include <cstring>
 #include <unordered_map>
 
 static int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
@@ -108,6 +109,57 @@ int ec3d_csr_to_host_matrix(int64_t n, const double *valA, const int32_t *irow, 
         }
     }
     return 0;
+}
+
+// Dictionary form of the bands: rows whose nb coefficients are bitwise equal share a class.
+// Returns the number of classes, or 0 (and leaves M untouched) when more than 256 are needed.
+int ec3d_build_dictionary_host(HostMatrix &M)
+{
+    if (M.nb != 7) return 0; // the specialised kernels cover the 7-band operator
+    struct Key {
+        uint64_t w[EC3D_MAXB];
+        int nb;
+        bool operator==(const Key &o) const { return memcmp(w, o.w, sizeof(uint64_t) * nb) == 0; }
+    };
+    struct Hash {
+        size_t operator()(const Key &k) const
+        {
+            uint64_t h = 1469598103934665603ull;
+            for (int b = 0; b < k.nb; ++b) h = (h ^ k.w[b]) * 1099511628211ull;
+            return (size_t)h;
+        }
+    };
+    std::unordered_map<Key, int, Hash> dict;
+    std::vector<uint8_t> cls((size_t)M.n_pad, 0);
+    std::vector<double> table;
+    Key last{};
+    int last_id = -1;
+    for (int64_t r = 0; r < M.n_pad; ++r) {
+        Key k{};
+        k.nb = M.nb;
+        for (int b = 0; b < M.nb; ++b) memcpy(&k.w[b], &M.bands[(size_t)b * M.n_pad + r], 8);
+        int id;
+        if (last_id >= 0 && k == last) {
+            id = last_id;
+        } else {
+            auto it = dict.find(k);
+            if (it == dict.end()) {
+                if (dict.size() == 256) return 0;
+                id = (int)dict.size();
+                dict.emplace(k, id);
+                for (int b = 0; b < M.nb; ++b) table.push_back(M.bands[(size_t)b * M.n_pad + r]);
+            } else {
+                id = it->second;
+            }
+            last = k;
+            last_id = id;
+        }
+        cls[(size_t)r] = (uint8_t)id;
+    }
+    M.cls.swap(cls);
+    M.table.swap(table);
+    M.ncls = (int)dict.size();
+    return M.ncls;
 }
 
 // inverse, for parity checks of the device assembly.  Band slots holding exactly 0.0 and tail

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "../../include/ec3d_hip.h"
+
 #include <climits>
 #include <cstdint>
 #include <string>
@@ -29,11 +31,25 @@ struct MatView {
     const int64_t *chunk_ptr; // [nchunk+1] entry offsets of the 64-row slices
     const int32_t *tcol;      // 0-based column
     const double *tval;
+    // dictionary form of the bands (ncls > 0): band[b][r] == table[cls[r] * nb + b]
+    const uint8_t *cls; // [n_pad]
+    const double *table;
+    int ncls;
+};
+
+// where a kernel finds the partial sums it has to finish: value i of slot s is
+// base[s * slot_mul + i * stride], i < count.  Single GPU: the producer's per-workgroup partials
+// (count = nblk, stride = 1, slot_mul = nblk).  Multi rank: the all-gathered per-rank sums
+// (count = nranks, stride = P_NSLOT, slot_mul = 1).
+struct RedSrc {
+    const double *base;
+    int count, stride, slot_mul;
 };
 
 // blockIdx -> tile map (XCD aware when S > 0): see ec3d_tile_of() in ec3d_kernels.hip
 struct Sweep {
     int64_t ntiles;
+    int64_t n; // rows owned; rows in [n, ntiles*EC3D_TILE) are padding
     int nblk;
     int S;
 };
@@ -58,6 +74,10 @@ struct HostMatrix {
     std::vector<int64_t> chunk_ptr;
     std::vector<int32_t> tcol;
     std::vector<double> tval;
+    // dictionary form (ncls > 0): `bands` may then be empty
+    std::vector<uint8_t> cls;
+    std::vector<double> table;
+    int ncls = 0;
 };
 
 struct DevMatrix {
@@ -71,19 +91,30 @@ struct DevMatrix {
     int64_t *chunk_ptr = nullptr;
     int32_t *tcol = nullptr;
     double *tval = nullptr;
+    uint8_t *cls = nullptr; // dictionary form (ncls > 0): bands == nullptr
+    double *table = nullptr;
+    int ncls = 0;
     int64_t bytes = 0;
     MatView view() const;
 };
 
 struct ec3d_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;         // the stream every launch goes to
+    hipStream_t own_stream_obj = nullptr; // created by ec3d_create; `stream` may point elsewhere
     DevMatrix A;
     bool have_matrix = false;
     int64_t ghost = 0;     // zero halo (doubles) on both sides of every vector
     double *vec_base = nullptr;
     double *vec[8] = {nullptr};
-    Sweep sweep{0, 0, 0};
+    Sweep sweep{0, 0, 0, 0};
+    bool own_vectors = true;
+    bool dist = false;
+    // multi-rank (z-slab) mode: reductions come from the all-gathered per-rank sums
+    int nranks = 1;
+    double *lsum = nullptr, *gsum = nullptr; // caller-owned device buffers (P_NSLOT, nranks*P_NSLOT)
+    int64_t halo = 0;                        // doubles per halo plane (kdz), 0 when not a slab
+    bool use_dict = true;
     int nblk_request = 0;
     double *partials = nullptr; // 8 * nblk doubles
     SolverState *state = nullptr;
@@ -127,22 +158,25 @@ int ec3d_prepare_vectors(ec3d_ctx *c);
 void ec3d_launch_spmv(const MatView &A, const Sweep &sw, const double *x, double *y, hipStream_t s);
 void ec3d_launch_residual(const MatView &A, const Sweep &sw, const double *x, const double *b, double *r,
                           double *r0, double *p, double *part, hipStream_t s);
-void ec3d_launch_setup(SolverState *st, const double *part, int nblk, double tol, hipStream_t s);
+void ec3d_launch_finalize(const double *part, int nblk, double *lsum, unsigned mask, hipStream_t s);
+void ec3d_launch_setup(SolverState *st, const RedSrc &src, double tol, hipStream_t s);
 void ec3d_launch_k1(const MatView &A, const Sweep &sw, const SolverState *st, int it, const double *p,
                     const double *r0, double *ap, double *part, hipStream_t s);
-void ec3d_launch_k2(const Sweep &sw, SolverState *st, int it, const double *r, const double *ap, double *sv,
-                    double *part, hipStream_t s);
-void ec3d_launch_k3(const MatView &A, const Sweep &sw, SolverState *st, int it, const double *sv,
+void ec3d_launch_k2(const Sweep &sw, const RedSrc &src, SolverState *st, int it, const double *r, const double *ap,
+                    double *sv, double *part, hipStream_t s);
+void ec3d_launch_k3(const MatView &A, const Sweep &sw, const RedSrc &src, SolverState *st, int it, const double *sv,
                     const double *p, double *x, double *as, double *part, double *hist, int64_t hist_cap,
                     hipStream_t s);
-void ec3d_launch_k4(const Sweep &sw, SolverState *st, int it, const double *p, const double *sv,
+void ec3d_launch_k4(const Sweep &sw, const RedSrc &src, SolverState *st, int it, const double *p, const double *sv,
                     const double *as, const double *r0, double *x, double *r, double *part, hipStream_t s);
-void ec3d_launch_k5(const Sweep &sw, SolverState *st, int it, double *r, const double *ap, double *p,
-                    double *r0, double *part, double *hist, int64_t hist_cap, hipStream_t s);
+void ec3d_launch_k5(const Sweep &sw, const RedSrc &src, SolverState *st, int it, const double *r, const double *ap,
+                    double *p, double *r0, double *hist, int64_t hist_cap, hipStream_t s);
 
 // ec3d_assemble.hip
 int ec3d_assemble_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t sdz, const int8_t *geoPHYS,
                          const int32_t *geoPHYS_C, const double *valPHYS, int32_t nsub_glob,
                          const double *BND, const double *delta, double dt);
-int ec3d_assemble_poisson_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t sdz, const double *BND,
-                                 const double *delta);
+int ec3d_assemble_poisson_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t sdz, int32_t k0, int32_t k1,
+                                 const double *BND, const double *delta);
+// ec3d_format.cpp / ec3d_solver.hip: dictionary compression of the bands
+int ec3d_build_dictionary_host(HostMatrix &M);

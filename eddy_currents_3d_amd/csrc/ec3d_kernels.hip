@@ -56,19 +56,39 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double *lds)
     __syncthreads();
 }
 
-// every workgroup re-reduces the previous kernel's per-workgroup partials, same order everywhere
+// every workgroup re-reduces the producer's partial sums, same order everywhere.  Single GPU:
+// the previous kernel's per-workgroup partials; multi rank: the all-gathered per-rank sums.
 template <int NV>
-__device__ __forceinline__ void reduce_partials(const double *const (&part)[NV], int nblk, double (&out)[NV],
+__device__ __forceinline__ void reduce_partials(const RedSrc &src, const int (&slot)[NV], double (&out)[NV],
                                                 double *lds)
 {
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
+        const double *p = src.base + (int64_t)slot[k] * src.slot_mul;
         double a = 0.0;
-        for (int i = threadIdx.x; i < nblk; i += EC3D_THREADS) a = a + part[k][i];
+        for (int i = threadIdx.x; i < src.count; i += EC3D_THREADS) a = a + p[(int64_t)i * src.stride];
         out[k] = a;
     }
     block_sum<NV>(out, lds);
 }
+
+// rows >= n (padding up to the tile; in a z-slab they overlap the upper halo plane) are never
+// stored and contribute +0 to every dot product
+__device__ __forceinline__ void store2(double *__restrict__ v, int64_t r, int64_t n, double a, double b)
+{
+    if (r + 1 < n) {
+        *reinterpret_cast<d2 *>(v + r) = d2{a, b};
+    } else if (r < n) {
+        v[r] = a;
+    }
+}
+#define EC3D_MASK2(r, n, a, b)                                                                 \
+    do {                                                                                       \
+        if ((r) + 1 >= (n)) {                                                                  \
+            (b) = 0.0;                                                                         \
+            if ((r) >= (n)) (a) = 0.0;                                                         \
+        }                                                                                      \
+    } while (0)
 
 __device__ __forceinline__ double tail_add(const MatView &A, const double *__restrict__ x, int t, double s)
 {
@@ -78,23 +98,54 @@ __device__ __forceinline__ double tail_add(const MatView &A, const double *__res
     return s;
 }
 
-// rows r, r+1 of A*x (src/solvers.f90:58-59): bands in ascending column order, then the tail
-template <int NB>
-__device__ __forceinline__ void spmv_pair(const MatView &A, const double *__restrict__ x, int64_t r,
-                                          int64_t tile, double &s0, double &s1)
+// Matrix formats the row kernel is specialised for (template parameter FMT):
+//   FMT_GENERIC  any number of bands, one fp64 stream per band
+//   FMT_DIA7     7 bands, unrolled (72 B/row: 56 coefficients + x + y)
+//   FMT_DICT7    7 bands whose coefficient 7-tuples take <= 256 distinct values ("stencil classes"):
+//                one class byte per row + a table staged in LDS (17 B/row: 1 + x + y).  The values
+//                multiplied are the same doubles, so results are bit-identical to FMT_DIA7.
+enum { FMT_GENERIC = 0, FMT_DIA7 = 7, FMT_DICT7 = 107 };
+#define EC3D_TBL_DOUBLES (256 * 7)
+
+template <int FMT>
+__device__ __forceinline__ void stage_table(const MatView &A, double *tbl)
 {
-    if (NB > 0) {
-        d2 c[NB > 0 ? NB : 1], xv[NB > 0 ? NB : 1];
+    if (FMT == FMT_DICT7) {
+        for (int i = threadIdx.x; i < A.ncls * 7; i += EC3D_THREADS) tbl[i] = A.table[i];
+        __syncthreads();
+    }
+}
+
+// rows r, r+1 of A*x (src/solvers.f90:58-59): bands in ascending column order, then the tail
+template <int FMT>
+__device__ __forceinline__ void spmv_pair(const MatView &A, const double *tbl, const double *__restrict__ x,
+                                          int64_t r, int64_t tile, double &s0, double &s1)
+{
+    if (FMT == FMT_DIA7) {
+        d2 c[7], xv[7];
 #pragma unroll
-        for (int b = 0; b < NB; ++b) c[b] = *reinterpret_cast<const d2 *>(A.band[b] + r);
+        for (int b = 0; b < 7; ++b) c[b] = *reinterpret_cast<const d2 *>(A.band[b] + r);
 #pragma unroll
-        for (int b = 0; b < NB; ++b) xv[b] = *reinterpret_cast<const d2u *>(x + r + A.off[b]);
+        for (int b = 0; b < 7; ++b) xv[b] = *reinterpret_cast<const d2u *>(x + r + A.off[b]);
         s0 = c[0].x * xv[0].x;
         s1 = c[0].y * xv[0].y;
 #pragma unroll
-        for (int b = 1; b < NB; ++b) {
+        for (int b = 1; b < 7; ++b) {
             s0 = s0 + c[b].x * xv[b].x;
             s1 = s1 + c[b].y * xv[b].y;
+        }
+    } else if (FMT == FMT_DICT7) {
+        d2u xv[7];
+        const unsigned short cc = *reinterpret_cast<const unsigned short *>(A.cls + r);
+#pragma unroll
+        for (int b = 0; b < 7; ++b) xv[b] = *reinterpret_cast<const d2u *>(x + r + A.off[b]);
+        const double *t0 = tbl + (cc & 0xFF) * 7, *t1 = tbl + (cc >> 8) * 7;
+        s0 = t0[0] * xv[0].x;
+        s1 = t1[0] * xv[0].y;
+#pragma unroll
+        for (int b = 1; b < 7; ++b) {
+            s0 = s0 + t0[b] * xv[b].x;
+            s1 = s1 + t1[b] * xv[b].y;
         }
     } else {
         s0 = 0.0;
@@ -119,41 +170,48 @@ __device__ __forceinline__ void spmv_pair(const MatView &A, const double *__rest
         if (tile >= sw.ntiles) break;                                                          \
         const int64_t r = tile * EC3D_TILE + 2 * (int64_t)threadIdx.x;
 #define EC3D_SWEEP_END }
+#define EC3D_TBL_DECL __shared__ double tbl[FMT == FMT_DICT7 ? EC3D_TBL_DOUBLES : 1]
 
 // ---------------------------------------------------------------------------------------------
-// plain y = A x  (src/solvers.f90:54-61).  72 B/row with 7 bands.
-template <int NB>
+// plain y = A x  (src/solvers.f90:54-61)
+template <int FMT>
 __global__ __launch_bounds__(EC3D_THREADS) void k_spmv(MatView A, Sweep sw, const double *__restrict__ x,
                                                        double *__restrict__ y)
 {
+    EC3D_TBL_DECL;
+    stage_table<FMT>(A, tbl);
     EC3D_SWEEP_BEGIN
     double s0, s1;
-    spmv_pair<NB>(A, x, r, tile, s0, s1);
-    *reinterpret_cast<d2 *>(y + r) = d2{s0, s1};
+    spmv_pair<FMT>(A, tbl, x, r, tile, s0, s1);
+    store2(y, r, sw.n, s0, s1);
     EC3D_SWEEP_END
 }
 
 // setup: R = B - A X ; R0 = R ; P = R ; partials of B·B and R·R   (src/solvers.f90:14-21)
-template <int NB>
+template <int FMT>
 __global__ __launch_bounds__(EC3D_THREADS) void k_residual(MatView A, Sweep sw, const double *__restrict__ x,
                                                            const double *__restrict__ b, double *__restrict__ rv,
                                                            double *__restrict__ r0, double *__restrict__ p,
                                                            double *__restrict__ part)
 {
     __shared__ double lds[8];
+    EC3D_TBL_DECL;
+    stage_table<FMT>(A, tbl);
     double acc[2] = {0.0, 0.0};
     EC3D_SWEEP_BEGIN
     double s0, s1;
-    spmv_pair<NB>(A, x, r, tile, s0, s1);
+    spmv_pair<FMT>(A, tbl, x, r, tile, s0, s1);
     d2 bv = *reinterpret_cast<const d2 *>(b + r);
-    d2 res = d2{bv.x - s0, bv.y - s1};
-    *reinterpret_cast<d2 *>(rv + r) = res;
-    *reinterpret_cast<d2 *>(r0 + r) = res;
-    *reinterpret_cast<d2 *>(p + r) = res;
-    acc[0] = acc[0] + bv.x * bv.x;
-    acc[0] = acc[0] + bv.y * bv.y;
-    acc[1] = acc[1] + res.x * res.x;
-    acc[1] = acc[1] + res.y * res.y;
+    double e0 = bv.x - s0, e1 = bv.y - s1, b0 = bv.x, b1 = bv.y;
+    store2(rv, r, sw.n, e0, e1);
+    store2(r0, r, sw.n, e0, e1);
+    store2(p, r, sw.n, e0, e1);
+    EC3D_MASK2(r, sw.n, e0, e1);
+    EC3D_MASK2(r, sw.n, b0, b1);
+    acc[0] = acc[0] + b0 * b0;
+    acc[0] = acc[0] + b1 * b1;
+    acc[1] = acc[1] + e0 * e0;
+    acc[1] = acc[1] + e1 * e1;
     EC3D_SWEEP_END
     block_sum<2>(acc, lds);
     if (threadIdx.x == 0) {
@@ -162,13 +220,28 @@ __global__ __launch_bounds__(EC3D_THREADS) void k_residual(MatView A, Sweep sw, 
     }
 }
 
+// multi-rank only: collapse this rank's per-workgroup partials of the slots in `mask` into lsum[slot]
+// (same tree as reduce_partials), ready for the all_gather
+__global__ __launch_bounds__(EC3D_THREADS) void k_finalize(const double *part, int nblk, double *lsum, unsigned mask)
+{
+    __shared__ double lds[4];
+    const RedSrc src{part, nblk, 1, nblk};
+    for (int sl = 0; sl < P_NSLOT; ++sl) {
+        if (!(mask & (1u << sl))) continue;
+        const int slot[1] = {sl};
+        double v[1];
+        reduce_partials<1>(src, slot, v, lds);
+        if (threadIdx.x == 0) lsum[sl] = v[0];
+    }
+}
+
 // Bnorm, rr0, "‖b‖ = 0 -> return" (src/solvers.f90:21-23); one workgroup
-__global__ __launch_bounds__(EC3D_THREADS) void k_setup(SolverState *st, const double *part, int nblk, double tol)
+__global__ __launch_bounds__(EC3D_THREADS) void k_setup(SolverState *st, RedSrc src, double tol)
 {
     __shared__ double lds[8];
-    const double *const pp[2] = {part + P_BB * nblk, part + P_RR_INIT * nblk};
+    const int slot[2] = {P_BB, P_RR_INIT};
     double v[2];
-    reduce_partials<2>(pp, nblk, v, lds);
+    reduce_partials<2>(src, slot, v, lds);
     if (threadIdx.x == 0) {
         const double bnorm = sqrt(v[0]);
         st->bnorm = bnorm;
@@ -182,21 +255,24 @@ __global__ __launch_bounds__(EC3D_THREADS) void k_setup(SolverState *st, const d
     }
 }
 
-// K1: AP = A P ; partial AP·R0    (src/solvers.f90:30, :32 denominator).  80 B/row.
-template <int NB>
+// K1: AP = A P ; partial AP·R0    (src/solvers.f90:30, :32 denominator)
+template <int FMT>
 __global__ __launch_bounds__(EC3D_THREADS) void k1_spmv_dot(MatView A, Sweep sw, const SolverState *st, int it,
                                                             const double *__restrict__ p,
                                                             const double *__restrict__ r0,
                                                             double *__restrict__ ap, double *__restrict__ part)
 {
     __shared__ double lds[4];
+    EC3D_TBL_DECL;
     if (st->stop_iter < it) return;
+    stage_table<FMT>(A, tbl);
     double acc[1] = {0.0};
     EC3D_SWEEP_BEGIN
     double s0, s1;
-    spmv_pair<NB>(A, p, r, tile, s0, s1);
+    spmv_pair<FMT>(A, tbl, p, r, tile, s0, s1);
     d2 q = *reinterpret_cast<const d2 *>(r0 + r);
-    *reinterpret_cast<d2 *>(ap + r) = d2{s0, s1};
+    store2(ap, r, sw.n, s0, s1);
+    EC3D_MASK2(r, sw.n, s0, s1);
     acc[0] = acc[0] + s0 * q.x;
     acc[0] = acc[0] + s1 * q.y;
     EC3D_SWEEP_END
@@ -204,46 +280,48 @@ __global__ __launch_bounds__(EC3D_THREADS) void k1_spmv_dot(MatView A, Sweep sw,
     if (threadIdx.x == 0) part[P_D1 * sw.nblk + blockIdx.x] = acc[0];
 }
 
-// K2: alpha = rr0 / (AP·R0) ; S = R - alpha*AP ; partial S·S   (src/solvers.f90:31-34).  24 B/row.
-__global__ __launch_bounds__(EC3D_THREADS) void k2_s_update(Sweep sw, SolverState *st, int it,
+// K2: alpha = rr0 / (AP·R0) ; S = R - alpha*AP ; partial S·S   (src/solvers.f90:31-34)
+__global__ __launch_bounds__(EC3D_THREADS) void k2_s_update(Sweep sw, RedSrc src, SolverState *st, int it,
                                                             const double *__restrict__ rv,
                                                             const double *__restrict__ ap, double *__restrict__ sv,
                                                             double *__restrict__ part)
 {
     __shared__ double lds[4];
     if (st->stop_iter < it) return;
-    const double *const pp[1] = {part + P_D1 * sw.nblk};
+    const int slot[1] = {P_D1};
     double d[1];
-    reduce_partials<1>(pp, sw.nblk, d, lds);
+    reduce_partials<1>(src, slot, d, lds);
     const double alpha = st->rr0[it & 1] / d[0];
     if (blockIdx.x == 0 && threadIdx.x == 0) st->alpha = alpha;
     double acc[1] = {0.0};
     EC3D_SWEEP_BEGIN
     d2 a = *reinterpret_cast<const d2 *>(ap + r);
     d2 q = *reinterpret_cast<const d2 *>(rv + r);
-    d2 s = d2{q.x - alpha * a.x, q.y - alpha * a.y};
-    *reinterpret_cast<d2 *>(sv + r) = s;
-    acc[0] = acc[0] + s.x * s.x;
-    acc[0] = acc[0] + s.y * s.y;
+    double s0 = q.x - alpha * a.x, s1 = q.y - alpha * a.y;
+    store2(sv, r, sw.n, s0, s1);
+    EC3D_MASK2(r, sw.n, s0, s1);
+    acc[0] = acc[0] + s0 * s0;
+    acc[0] = acc[0] + s1 * s1;
     EC3D_SWEEP_END
     block_sum<1>(acc, lds);
     if (threadIdx.x == 0) part[P_SS * sw.nblk + blockIdx.x] = acc[0];
 }
 
 // K3: if ‖S‖/Bnorm < tol: X += alpha*P, exit (src/solvers.f90:34-38)
-//     else AS = A S ; partials AS·S and AS·AS (:39-40).  72 B/row.
-template <int NB>
-__global__ __launch_bounds__(EC3D_THREADS) void k3_spmv_dots(MatView A, Sweep sw, SolverState *st, int it,
-                                                             const double *__restrict__ sv,
+//     else AS = A S ; partials AS·S and AS·AS (:39-40)
+template <int FMT>
+__global__ __launch_bounds__(EC3D_THREADS) void k3_spmv_dots(MatView A, Sweep sw, RedSrc src, SolverState *st,
+                                                             int it, const double *__restrict__ sv,
                                                              const double *__restrict__ p, double *__restrict__ x,
                                                              double *__restrict__ as, double *__restrict__ part,
                                                              double *hist, int64_t hist_cap)
 {
     __shared__ double lds[8];
+    EC3D_TBL_DECL;
     if (st->stop_iter < it) return;
-    const double *const pp[1] = {part + P_SS * sw.nblk};
+    const int slot[1] = {P_SS};
     double ss[1];
-    reduce_partials<1>(pp, sw.nblk, ss, lds);
+    reduce_partials<1>(src, slot, ss, lds);
     const double snorm = sqrt(ss[0]);
     if (blockIdx.x == 0 && threadIdx.x == 0 && hist && it <= hist_cap) hist[2 * (int64_t)(it - 1)] = snorm;
     if (snorm / st->bnorm < st->tol) {
@@ -251,7 +329,7 @@ __global__ __launch_bounds__(EC3D_THREADS) void k3_spmv_dots(MatView A, Sweep sw
         EC3D_SWEEP_BEGIN
         d2 xv = *reinterpret_cast<const d2 *>(x + r);
         d2 pv = *reinterpret_cast<const d2 *>(p + r);
-        *reinterpret_cast<d2 *>(x + r) = d2{xv.x + alpha * pv.x, xv.y + alpha * pv.y};
+        store2(x, r, sw.n, xv.x + alpha * pv.x, xv.y + alpha * pv.y);
         EC3D_SWEEP_END
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             st->stop_kind = 1;
@@ -259,12 +337,14 @@ __global__ __launch_bounds__(EC3D_THREADS) void k3_spmv_dots(MatView A, Sweep sw
         }
         return;
     }
+    stage_table<FMT>(A, tbl);
     double acc[2] = {0.0, 0.0};
     EC3D_SWEEP_BEGIN
     double s0, s1;
-    spmv_pair<NB>(A, sv, r, tile, s0, s1);
+    spmv_pair<FMT>(A, tbl, sv, r, tile, s0, s1);
     d2 q = *reinterpret_cast<const d2 *>(sv + r);
-    *reinterpret_cast<d2 *>(as + r) = d2{s0, s1};
+    store2(as, r, sw.n, s0, s1);
+    EC3D_MASK2(r, sw.n, s0, s1);
     acc[0] = acc[0] + s0 * q.x;
     acc[0] = acc[0] + s1 * q.y;
     acc[1] = acc[1] + s0 * s0;
@@ -278,8 +358,8 @@ __global__ __launch_bounds__(EC3D_THREADS) void k3_spmv_dots(MatView A, Sweep sw
 }
 
 // K4: omega = (AS·S)/(AS·AS) ; X = X + alpha*P + omega*S ; R = S - omega*AS ;
-//     partials R·R and R·R0   (src/solvers.f90:40-44).  56 B/row.
-__global__ __launch_bounds__(EC3D_THREADS) void k4_x_r_update(Sweep sw, SolverState *st, int it,
+//     partials R·R and R·R0   (src/solvers.f90:40-44)
+__global__ __launch_bounds__(EC3D_THREADS) void k4_x_r_update(Sweep sw, RedSrc src, SolverState *st, int it,
                                                               const double *__restrict__ p,
                                                               const double *__restrict__ sv,
                                                               const double *__restrict__ as,
@@ -288,9 +368,9 @@ __global__ __launch_bounds__(EC3D_THREADS) void k4_x_r_update(Sweep sw, SolverSt
 {
     __shared__ double lds[8];
     if (st->stop_iter <= it) return;
-    const double *const pp[2] = {part + P_D2 * sw.nblk, part + P_D3 * sw.nblk};
+    const int slot[2] = {P_D2, P_D3};
     double d[2];
-    reduce_partials<2>(pp, sw.nblk, d, lds);
+    reduce_partials<2>(src, slot, d, lds);
     const double omega = d[0] / d[1];
     const double alpha = st->alpha;
     if (blockIdx.x == 0 && threadIdx.x == 0) st->omega = omega;
@@ -301,14 +381,14 @@ __global__ __launch_bounds__(EC3D_THREADS) void k4_x_r_update(Sweep sw, SolverSt
     d2 s = *reinterpret_cast<const d2 *>(sv + r);
     d2 a = *reinterpret_cast<const d2 *>(as + r);
     d2 q = *reinterpret_cast<const d2 *>(r0 + r);
-    d2 xn = d2{(xv.x + alpha * pv.x) + omega * s.x, (xv.y + alpha * pv.y) + omega * s.y};
-    d2 rn = d2{s.x - omega * a.x, s.y - omega * a.y};
-    *reinterpret_cast<d2 *>(x + r) = xn;
-    *reinterpret_cast<d2 *>(rv + r) = rn;
-    acc[0] = acc[0] + rn.x * rn.x;
-    acc[0] = acc[0] + rn.y * rn.y;
-    acc[1] = acc[1] + rn.x * q.x;
-    acc[1] = acc[1] + rn.y * q.y;
+    store2(x, r, sw.n, (xv.x + alpha * pv.x) + omega * s.x, (xv.y + alpha * pv.y) + omega * s.y);
+    double e0 = s.x - omega * a.x, e1 = s.y - omega * a.y;
+    store2(rv, r, sw.n, e0, e1);
+    EC3D_MASK2(r, sw.n, e0, e1);
+    acc[0] = acc[0] + e0 * e0;
+    acc[0] = acc[0] + e1 * e1;
+    acc[1] = acc[1] + e0 * q.x;
+    acc[1] = acc[1] + e1 * q.y;
     EC3D_SWEEP_END
     block_sum<2>(acc, lds);
     if (threadIdx.x == 0) {
@@ -318,19 +398,17 @@ __global__ __launch_bounds__(EC3D_THREADS) void k4_x_r_update(Sweep sw, SolverSt
 }
 
 // K5: if ‖R‖/Bnorm < tol exit (src/solvers.f90:43) ; beta = (alpha/omega)*rr0_new/rr0 (:45) ;
-//     P = R + beta*(P - omega*AP) (:46) ; restart R0 = R, P = R when |rr0_new|/Bnorm < tol (:47-49).
-//     32 B/row (+16 on a restart).
-__global__ __launch_bounds__(EC3D_THREADS) void k5_p_update(Sweep sw, SolverState *st, int it,
+//     P = R + beta*(P - omega*AP) (:46) ; restart R0 = R, P = R when |rr0_new|/Bnorm < tol (:47-49)
+__global__ __launch_bounds__(EC3D_THREADS) void k5_p_update(Sweep sw, RedSrc src, SolverState *st, int it,
                                                             const double *__restrict__ rv,
                                                             const double *__restrict__ ap, double *__restrict__ p,
-                                                            double *__restrict__ r0, const double *__restrict__ part,
-                                                            double *hist, int64_t hist_cap)
+                                                            double *__restrict__ r0, double *hist, int64_t hist_cap)
 {
     __shared__ double lds[8];
     if (st->stop_iter <= it) return;
-    const double *const pp[2] = {part + P_RR * sw.nblk, part + P_RR0N * sw.nblk};
+    const int slot[2] = {P_RR, P_RR0N};
     double d[2];
-    reduce_partials<2>(pp, sw.nblk, d, lds);
+    reduce_partials<2>(src, slot, d, lds);
     const double rnorm = sqrt(d[0]);
     const double bnorm = st->bnorm, tol = st->tol;
     const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
@@ -351,71 +429,81 @@ __global__ __launch_bounds__(EC3D_THREADS) void k5_p_update(Sweep sw, SolverStat
     EC3D_SWEEP_BEGIN
     d2 q = *reinterpret_cast<const d2 *>(rv + r);
     if (restart) {
-        *reinterpret_cast<d2 *>(r0 + r) = q;
-        *reinterpret_cast<d2 *>(p + r) = q;
+        store2(r0, r, sw.n, q.x, q.y);
+        store2(p, r, sw.n, q.x, q.y);
     } else {
         d2 pv = *reinterpret_cast<const d2 *>(p + r);
         d2 a = *reinterpret_cast<const d2 *>(ap + r);
-        *reinterpret_cast<d2 *>(p + r) = d2{q.x + beta * (pv.x - omega * a.x), q.y + beta * (pv.y - omega * a.y)};
+        store2(p, r, sw.n, q.x + beta * (pv.x - omega * a.x), q.y + beta * (pv.y - omega * a.y));
     }
     EC3D_SWEEP_END
 }
 
 // ---------------------------------------------------------------------------------------------
 // launchers
-#define EC3D_DISPATCH_NB(NBV, CALL7, CALLG)                                                    \
+static inline int fmt_of(const MatView &A)
+{
+    if (A.nb == 7 && A.ncls > 0) return FMT_DICT7;
+    if (A.nb == 7) return FMT_DIA7;
+    return FMT_GENERIC;
+}
+#define EC3D_DISPATCH(A, KERNEL, ...)                                                          \
     do {                                                                                       \
-        if ((NBV) == 7) { CALL7; } else { CALLG; }                                             \
+        switch (fmt_of(A)) {                                                                   \
+        case FMT_DICT7: KERNEL<FMT_DICT7><<<sw.nblk, EC3D_THREADS, 0, s>>>(__VA_ARGS__); break; \
+        case FMT_DIA7: KERNEL<FMT_DIA7><<<sw.nblk, EC3D_THREADS, 0, s>>>(__VA_ARGS__); break;   \
+        default: KERNEL<FMT_GENERIC><<<sw.nblk, EC3D_THREADS, 0, s>>>(__VA_ARGS__);            \
+        }                                                                                      \
     } while (0)
 
 void ec3d_launch_spmv(const MatView &A, const Sweep &sw, const double *x, double *y, hipStream_t s)
 {
-    EC3D_DISPATCH_NB(A.nb, (k_spmv<7><<<sw.nblk, EC3D_THREADS, 0, s>>>(A, sw, x, y)),
-                     (k_spmv<0><<<sw.nblk, EC3D_THREADS, 0, s>>>(A, sw, x, y)));
+    EC3D_DISPATCH(A, k_spmv, A, sw, x, y);
 }
 
 void ec3d_launch_residual(const MatView &A, const Sweep &sw, const double *x, const double *b, double *r,
                           double *r0, double *p, double *part, hipStream_t s)
 {
-    EC3D_DISPATCH_NB(A.nb, (k_residual<7><<<sw.nblk, EC3D_THREADS, 0, s>>>(A, sw, x, b, r, r0, p, part)),
-                     (k_residual<0><<<sw.nblk, EC3D_THREADS, 0, s>>>(A, sw, x, b, r, r0, p, part)));
+    EC3D_DISPATCH(A, k_residual, A, sw, x, b, r, r0, p, part);
 }
 
-void ec3d_launch_setup(SolverState *st, const double *part, int nblk, double tol, hipStream_t s)
+void ec3d_launch_finalize(const double *part, int nblk, double *lsum, unsigned mask, hipStream_t s)
 {
-    k_setup<<<1, EC3D_THREADS, 0, s>>>(st, part, nblk, tol);
+    k_finalize<<<1, EC3D_THREADS, 0, s>>>(part, nblk, lsum, mask);
+}
+
+void ec3d_launch_setup(SolverState *st, const RedSrc &src, double tol, hipStream_t s)
+{
+    k_setup<<<1, EC3D_THREADS, 0, s>>>(st, src, tol);
 }
 
 void ec3d_launch_k1(const MatView &A, const Sweep &sw, const SolverState *st, int it, const double *p,
                     const double *r0, double *ap, double *part, hipStream_t s)
 {
-    EC3D_DISPATCH_NB(A.nb, (k1_spmv_dot<7><<<sw.nblk, EC3D_THREADS, 0, s>>>(A, sw, st, it, p, r0, ap, part)),
-                     (k1_spmv_dot<0><<<sw.nblk, EC3D_THREADS, 0, s>>>(A, sw, st, it, p, r0, ap, part)));
+    EC3D_DISPATCH(A, k1_spmv_dot, A, sw, st, it, p, r0, ap, part);
 }
 
-void ec3d_launch_k2(const Sweep &sw, SolverState *st, int it, const double *r, const double *ap, double *sv,
-                    double *part, hipStream_t s)
+void ec3d_launch_k2(const Sweep &sw, const RedSrc &src, SolverState *st, int it, const double *r, const double *ap,
+                    double *sv, double *part, hipStream_t s)
 {
-    k2_s_update<<<sw.nblk, EC3D_THREADS, 0, s>>>(sw, st, it, r, ap, sv, part);
+    k2_s_update<<<sw.nblk, EC3D_THREADS, 0, s>>>(sw, src, st, it, r, ap, sv, part);
 }
 
-void ec3d_launch_k3(const MatView &A, const Sweep &sw, SolverState *st, int it, const double *sv,
+void ec3d_launch_k3(const MatView &A, const Sweep &sw, const RedSrc &src, SolverState *st, int it, const double *sv,
                     const double *p, double *x, double *as, double *part, double *hist, int64_t hist_cap,
                     hipStream_t s)
 {
-    EC3D_DISPATCH_NB(
-        A.nb, (k3_spmv_dots<7><<<sw.nblk, EC3D_THREADS, 0, s>>>(A, sw, st, it, sv, p, x, as, part, hist, hist_cap)),
-        (k3_spmv_dots<0><<<sw.nblk, EC3D_THREADS, 0, s>>>(A, sw, st, it, sv, p, x, as, part, hist, hist_cap)));
+    EC3D_DISPATCH(A, k3_spmv_dots, A, sw, src, st, it, sv, p, x, as, part, hist, hist_cap);
 }
 
-void ec3d_launch_k4(const Sweep &sw, SolverState *st, int it, const double *p, const double *sv,
+void ec3d_launch_k4(const Sweep &sw, const RedSrc &src, SolverState *st, int it, const double *p, const double *sv,
                     const double *as, const double *r0, double *x, double *r, double *part, hipStream_t s)
 {
-    k4_x_r_update<<<sw.nblk, EC3D_THREADS, 0, s>>>(sw, st, it, p, sv, as, r0, x, r, part);
+    k4_x_r_update<<<sw.nblk, EC3D_THREADS, 0, s>>>(sw, src, st, it, p, sv, as, r0, x, r, part);
 }
 
-void ec3d_launch_k5(const Sweep &sw, SolverState *st, int it, double *r, const double *ap, double *p,
-                    double *r0, double *part, double *hist, int64_t hist_cap, hipStream_t s)
+void ec3d_launch_k5(const Sweep &sw, const RedSrc &src, SolverState *st, int it, const double *r, const double *ap,
+                    double *p, double *r0, double *hist, int64_t hist_cap, hipStream_t s)
 {
-    k5_p_update<<<sw.nblk, EC3D_THREADS, 0, s>>>(sw, st, it, r, ap, p, r0, part, hist, hist_cap);
+    k5_p_update<<<sw.nblk, EC3D_THREADS, 0, s>>>(sw, src, st, it, r, ap, p, r0, hist, hist_cap);
 }

@@ -26,9 +26,12 @@ MatView DevMatrix::view() const
     memset(&v, 0, sizeof v);
     v.nb = nb;
     for (int b = 0; b < nb; ++b) {
-        v.band[b] = bands + (size_t)b * n_pad;
+        v.band[b] = bands ? bands + (size_t)b * n_pad : nullptr;
         v.off[b] = off[b];
     }
+    v.cls = cls;
+    v.table = table;
+    v.ncls = ncls;
     v.has_tail = ntail > 0;
     v.tail_id = tail_id;
     v.tile_flag = tile_flag;
@@ -53,20 +56,23 @@ extern "C" int ec3d_create(ec3d_handle *h, int device)
     EC3D_HIP(hipSetDevice(device));
     ec3d_ctx *c = new ec3d_ctx();
     c->device = device;
-    EC3D_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    EC3D_HIP(hipStreamCreateWithFlags(&c->own_stream_obj, hipStreamNonBlocking));
+    c->stream = c->own_stream_obj;
     EC3D_HIP(hipMalloc(&c->state, sizeof(SolverState)));
     EC3D_HIP(hipHostMalloc(&c->state_pinned, 2 * sizeof(SolverState), hipHostMallocDefault));
     for (int i = 0; i < 2; ++i) EC3D_HIP(hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming));
     EC3D_HIP(hipEventCreate(&c->t0));
     EC3D_HIP(hipEventCreate(&c->t1));
     if (const char *e = getenv("EC3D_NBLK")) c->nblk_request = atoi(e);
+    if (const char *e = getenv("EC3D_DICT")) c->use_dict = atoi(e) != 0;
     *h = c;
     return 0;
 }
 
 static void free_vectors(ec3d_ctx *c)
 {
-    if (c->vec_base) (void)hipFree(c->vec_base);
+    if (c->vec_base && c->own_vectors) (void)hipFree(c->vec_base);
+    c->own_vectors = true;
     if (c->partials) (void)hipFree(c->partials);
     c->vec_base = nullptr;
     c->partials = nullptr;
@@ -82,7 +88,10 @@ void ec3d_free_matrix(ec3d_ctx *c)
     if (A.chunk_ptr) (void)hipFree(A.chunk_ptr);
     if (A.tcol) (void)hipFree(A.tcol);
     if (A.tval) (void)hipFree(A.tval);
+    if (A.cls) (void)hipFree(A.cls);
+    if (A.table) (void)hipFree(A.table);
     A = DevMatrix();
+    c->halo = 0;
     c->have_matrix = false;
     free_vectors(c);
     for (auto &l : c->cel_bnd) l.clear();
@@ -102,7 +111,7 @@ extern "C" int ec3d_destroy(ec3d_handle c)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->t0) (void)hipEventDestroy(c->t0);
     if (c->t1) (void)hipEventDestroy(c->t1);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->own_stream_obj) (void)hipStreamDestroy(c->own_stream_obj);
     delete c;
     return 0;
 }
@@ -111,6 +120,7 @@ static void choose_sweep(ec3d_ctx *c)
 {
     Sweep &sw = c->sweep;
     sw.ntiles = c->A.n_pad / EC3D_TILE;
+    sw.n = c->A.n;
     int want = c->nblk_request > 0 ? c->nblk_request : 2048; // 256 CUs x 8 workgroups
     int64_t nblk = std::min<int64_t>(sw.ntiles, want);
     if (nblk >= 8) {
@@ -178,7 +188,13 @@ int ec3d_upload_matrix(ec3d_ctx *c, const HostMatrix &M)
     A.nchunk = (int64_t)M.chunk_ptr.size() - 1;
     A.tail_entries = M.chunk_ptr.empty() ? 0 : M.chunk_ptr.back();
     int rc = 0;
-    if ((rc = up(A.bands, M.bands, A.bytes, c->stream))) return rc;
+    if (M.ncls > 0) { // dictionary form: the bands themselves never go to the device
+        A.ncls = M.ncls;
+        if ((rc = up(A.cls, M.cls, A.bytes, c->stream))) return rc;
+        if ((rc = up(A.table, M.table, A.bytes, c->stream))) return rc;
+    } else if ((rc = up(A.bands, M.bands, A.bytes, c->stream))) {
+        return rc;
+    }
     if ((rc = up(A.tail_id, M.tail_id, A.bytes, c->stream))) return rc;
     if ((rc = up(A.tile_flag, M.tile_flag, A.bytes, c->stream))) return rc;
     if ((rc = up(A.chunk_ptr, M.chunk_ptr, A.bytes, c->stream))) return rc;
@@ -210,7 +226,17 @@ int ec3d_download_matrix(ec3d_ctx *c, HostMatrix &M)
     for (int b = 0; b < A.nb; ++b) M.off[b] = A.off[b];
     M.ntail = A.ntail;
     int rc = 0;
-    if ((rc = down(M.bands, A.bands, (size_t)A.nb * A.n_pad))) return rc;
+    if (A.ncls > 0) { // expand the dictionary: band[b][r] = table[cls[r]*nb + b]
+        if ((rc = down(M.cls, A.cls, (size_t)A.n_pad))) return rc;
+        if ((rc = down(M.table, A.table, (size_t)A.ncls * A.nb))) return rc;
+        M.ncls = A.ncls;
+        M.bands.assign((size_t)A.nb * A.n_pad, 0.0);
+        for (int64_t r = 0; r < A.n_pad; ++r)
+            for (int b = 0; b < A.nb; ++b)
+                M.bands[(size_t)b * A.n_pad + r] = M.table[(size_t)M.cls[(size_t)r] * A.nb + b];
+    } else if ((rc = down(M.bands, A.bands, (size_t)A.nb * A.n_pad))) {
+        return rc;
+    }
     if (A.ntail == 0) { // band-only matrix (ec3d_assemble_poisson): no tail arrays on the device
         M.tail_id.assign((size_t)A.n_pad, -1);
         M.tile_flag.assign((size_t)(A.n_pad / EC3D_TILE), 0);
@@ -241,6 +267,7 @@ extern "C" int ec3d_set_matrix_csr(ec3d_handle c, int32_t n, const double *valA,
     HostMatrix M;
     int rc = ec3d_csr_to_host_matrix(n, valA, irow, jcol, M);
     if (rc) return rc;
+    if (c->use_dict) ec3d_build_dictionary_host(M);
     return ec3d_upload_matrix(c, M);
 }
 
@@ -256,7 +283,32 @@ extern "C" int ec3d_assemble_poisson(ec3d_handle c, int32_t sdx, int32_t sdy, in
                                      const double *delta)
 {
     EC3D_HIP(hipSetDevice(c->device));
-    return ec3d_assemble_poisson_device(c, sdx, sdy, sdz, BND, delta);
+    return ec3d_assemble_poisson_device(c, sdx, sdy, sdz, 0, sdz, BND, delta);
+}
+
+extern "C" int ec3d_assemble_poisson_slab(ec3d_handle c, int32_t sdx, int32_t sdy, int32_t sdz, int32_t k0,
+                                          int32_t k1, const double *BND, const double *delta)
+{
+    EC3D_HIP(hipSetDevice(c->device));
+    if (k0 < 0 || k1 > sdz || k1 <= k0) {
+        ec3d_set_error("ec3d_assemble_poisson_slab: need 0 <= k0 < k1 <= sdz");
+        return 2;
+    }
+    return ec3d_assemble_poisson_device(c, sdx, sdy, sdz, k0, k1, BND, delta);
+}
+
+extern "C" int ec3d_set_format(ec3d_handle c, int dictionary)
+{
+    c->use_dict = dictionary != 0;
+    return 0;
+}
+
+extern "C" int ec3d_set_stream(ec3d_handle c, void *stream)
+{
+    EC3D_HIP(hipSetDevice(c->device));
+    EC3D_HIP(hipStreamSynchronize(c->stream));
+    c->stream = stream ? (hipStream_t)stream : c->own_stream_obj;
+    return 0;
 }
 
 extern "C" int ec3d_export_csr(ec3d_handle c, int32_t *n, int64_t *nnz, int32_t *irow, int32_t *jcol,
@@ -309,6 +361,7 @@ extern "C" int ec3d_get_matrix_info(ec3d_handle c, ec3d_matrix_info *info)
     for (int b = 0; b < c->A.nb; ++b) info->band_offset[b] = (int32_t)c->A.off[b];
     info->tail_rows = c->A.ntail;
     info->tail_entries_padded = c->A.tail_entries;
+    info->dict_classes = c->A.ncls;
     info->device_bytes = c->A.bytes + (c->ghost * 2 + c->A.n_pad) * (int64_t)EC3D_NVEC * 8;
     return 0;
 }
@@ -364,28 +417,49 @@ extern "C" int ec3d_spmv(ec3d_handle c, const double *x, double *y)
 }
 
 // ---------------------------------------------------------------------------------------------
-static void launch_iteration(ec3d_ctx *c, const MatView &A, int it)
+static RedSrc local_src(const ec3d_ctx *c) { return RedSrc{c->partials, c->sweep.nblk, 1, c->sweep.nblk}; }
+static RedSrc dist_src(const ec3d_ctx *c) { return RedSrc{c->gsum, c->nranks, P_NSLOT, 1}; }
+
+// the five launches of one iteration; `k` selects one of them (1..5) or all (0)
+static void launch_stage(ec3d_ctx *c, const MatView &A, const RedSrc &src, int it, int k)
 {
     double **v = c->vec;
     const Sweep &sw = c->sweep;
     hipStream_t s = c->stream;
-    ec3d_launch_k1(A, sw, c->state, it, v[EC3D_VEC_P], v[EC3D_VEC_R0], v[EC3D_VEC_AP], c->partials, s);
-    ec3d_launch_k2(sw, c->state, it, v[EC3D_VEC_R], v[EC3D_VEC_AP], v[EC3D_VEC_S], c->partials, s);
-    ec3d_launch_k3(A, sw, c->state, it, v[EC3D_VEC_S], v[EC3D_VEC_P], v[EC3D_VEC_X], v[EC3D_VEC_AS], c->partials,
-                   c->hist, c->hist_cap, s);
-    ec3d_launch_k4(sw, c->state, it, v[EC3D_VEC_P], v[EC3D_VEC_S], v[EC3D_VEC_AS], v[EC3D_VEC_R0], v[EC3D_VEC_X],
-                   v[EC3D_VEC_R], c->partials, s);
-    ec3d_launch_k5(sw, c->state, it, v[EC3D_VEC_R], v[EC3D_VEC_AP], v[EC3D_VEC_P], v[EC3D_VEC_R0], c->partials,
-                   c->hist, c->hist_cap, s);
+    if (k == 0 || k == 1)
+        ec3d_launch_k1(A, sw, c->state, it, v[EC3D_VEC_P], v[EC3D_VEC_R0], v[EC3D_VEC_AP], c->partials, s);
+    if (k == 0 || k == 2)
+        ec3d_launch_k2(sw, src, c->state, it, v[EC3D_VEC_R], v[EC3D_VEC_AP], v[EC3D_VEC_S], c->partials, s);
+    if (k == 0 || k == 3)
+        ec3d_launch_k3(A, sw, src, c->state, it, v[EC3D_VEC_S], v[EC3D_VEC_P], v[EC3D_VEC_X], v[EC3D_VEC_AS],
+                       c->partials, c->hist, c->hist_cap, s);
+    if (k == 0 || k == 4)
+        ec3d_launch_k4(sw, src, c->state, it, v[EC3D_VEC_P], v[EC3D_VEC_S], v[EC3D_VEC_AS], v[EC3D_VEC_R0],
+                       v[EC3D_VEC_X], v[EC3D_VEC_R], c->partials, s);
+    if (k == 0 || k == 5)
+        ec3d_launch_k5(sw, src, c->state, it, v[EC3D_VEC_R], v[EC3D_VEC_AP], v[EC3D_VEC_P], v[EC3D_VEC_R0], c->hist,
+                       c->hist_cap, s);
 }
+
+static void launch_iteration(ec3d_ctx *c, const MatView &A, int it) { launch_stage(c, A, local_src(c), it, 0); }
 
 static int launch_setup(ec3d_ctx *c, const MatView &A, double tol)
 {
     double **v = c->vec;
     ec3d_launch_residual(A, c->sweep, v[EC3D_VEC_X], v[EC3D_VEC_B], v[EC3D_VEC_R], v[EC3D_VEC_R0], v[EC3D_VEC_P],
                          c->partials, c->stream);
-    ec3d_launch_setup(c->state, c->partials, c->sweep.nblk, tol, c->stream);
+    ec3d_launch_setup(c->state, local_src(c), tol, c->stream);
     EC3D_HIP(hipGetLastError());
+    return 0;
+}
+
+static int single_rank_only(ec3d_ctx *c, const char *who)
+{
+    if (c->halo > 0 || c->nranks > 1) {
+        ec3d_set_error(std::string(who) + ": this handle holds one z-slab of a multi-rank problem; drive it "
+                                          "with ec3d_dist_step (eddy_currents_3d_amd/dist.py)");
+        return 4;
+    }
     return 0;
 }
 
@@ -465,6 +539,7 @@ extern "C" int ec3d_solve_resident(ec3d_handle c, double tolerance, int32_t itma
 {
     int rc = need_matrix(c, "ec3d_solve_resident");
     if (rc) return rc;
+    if ((rc = single_rank_only(c, "ec3d_solve_resident"))) return rc;
     return solve_core(c, tolerance, itmax, iter, resid_hist, hist_cap, true);
 }
 
@@ -473,6 +548,7 @@ extern "C" int ec3d_solve(ec3d_handle c, const double *b, double *x, double tole
 {
     int rc = need_matrix(c, "ec3d_solve");
     if (rc) return rc;
+    if ((rc = single_rank_only(c, "ec3d_solve"))) return rc;
     const size_t nb = (size_t)c->A.n * sizeof(double);
     EC3D_HIP(hipMemcpyAsync(c->vec[EC3D_VEC_B], b, nb, hipMemcpyHostToDevice, c->stream));
     EC3D_HIP(hipMemcpyAsync(c->vec[EC3D_VEC_X], x, nb, hipMemcpyHostToDevice, c->stream));
@@ -507,6 +583,7 @@ extern "C" int ec3d_iterate_begin(ec3d_handle c)
 {
     int rc = need_matrix(c, "ec3d_iterate_begin");
     if (rc) return rc;
+    if ((rc = single_rank_only(c, "ec3d_iterate_begin"))) return rc;
     c->hist_cap = 0;
     return launch_setup(c, c->A.view(), -1.0);
 }
@@ -524,26 +601,16 @@ extern "C" int ec3d_iterate(ec3d_handle c, int32_t first_iter, int32_t count, do
     // per-kernel durations: an event at every kernel boundary of every iteration, on our stream
     std::vector<hipEvent_t> ev((size_t)count * 6);
     for (auto &e : ev) EC3D_HIP(hipEventCreate(&e));
-    double **v = c->vec;
-    const Sweep &sw = c->sweep;
     hipStream_t s = c->stream;
+    const RedSrc src = local_src(c);
     for (int i = 0; i < count; ++i) {
         const int it = first_iter + i;
         hipEvent_t *e = &ev[(size_t)i * 6];
         EC3D_HIP(hipEventRecord(e[0], s));
-        ec3d_launch_k1(A, sw, c->state, it, v[EC3D_VEC_P], v[EC3D_VEC_R0], v[EC3D_VEC_AP], c->partials, s);
-        EC3D_HIP(hipEventRecord(e[1], s));
-        ec3d_launch_k2(sw, c->state, it, v[EC3D_VEC_R], v[EC3D_VEC_AP], v[EC3D_VEC_S], c->partials, s);
-        EC3D_HIP(hipEventRecord(e[2], s));
-        ec3d_launch_k3(A, sw, c->state, it, v[EC3D_VEC_S], v[EC3D_VEC_P], v[EC3D_VEC_X], v[EC3D_VEC_AS], c->partials,
-                       nullptr, 0, s);
-        EC3D_HIP(hipEventRecord(e[3], s));
-        ec3d_launch_k4(sw, c->state, it, v[EC3D_VEC_P], v[EC3D_VEC_S], v[EC3D_VEC_AS], v[EC3D_VEC_R0], v[EC3D_VEC_X],
-                       v[EC3D_VEC_R], c->partials, s);
-        EC3D_HIP(hipEventRecord(e[4], s));
-        ec3d_launch_k5(sw, c->state, it, v[EC3D_VEC_R], v[EC3D_VEC_AP], v[EC3D_VEC_P], v[EC3D_VEC_R0], c->partials,
-                       nullptr, 0, s);
-        EC3D_HIP(hipEventRecord(e[5], s));
+        for (int k = 1; k <= 5; ++k) {
+            launch_stage(c, A, src, it, k);
+            EC3D_HIP(hipEventRecord(e[k], s));
+        }
     }
     EC3D_HIP(hipGetLastError());
     EC3D_HIP(hipStreamSynchronize(s));
@@ -569,23 +636,12 @@ extern "C" int ec3d_time_kernel(ec3d_handle c, int kernel, int32_t reps, double 
     c->hist_cap = 0;
     if ((rc = launch_setup(c, A, -1.0))) return rc;
     launch_iteration(c, A, 1); // populate every partial slot and the scalars
+    const RedSrc src = local_src(c);
     auto one = [&]() {
-        switch (kernel) {
-        case EC3D_K_SPMV: ec3d_launch_spmv(A, sw, v[EC3D_VEC_P], v[EC3D_VEC_AP], s); break;
-        case EC3D_K1: ec3d_launch_k1(A, sw, c->state, 2, v[EC3D_VEC_P], v[EC3D_VEC_R0], v[EC3D_VEC_AP], c->partials, s); break;
-        case EC3D_K2: ec3d_launch_k2(sw, c->state, 2, v[EC3D_VEC_R], v[EC3D_VEC_AP], v[EC3D_VEC_S], c->partials, s); break;
-        case EC3D_K3:
-            ec3d_launch_k3(A, sw, c->state, 2, v[EC3D_VEC_S], v[EC3D_VEC_P], v[EC3D_VEC_X], v[EC3D_VEC_AS], c->partials,
-                           nullptr, 0, s);
-            break;
-        case EC3D_K4:
-            ec3d_launch_k4(sw, c->state, 2, v[EC3D_VEC_P], v[EC3D_VEC_S], v[EC3D_VEC_AS], v[EC3D_VEC_R0], v[EC3D_VEC_X],
-                           v[EC3D_VEC_R], c->partials, s);
-            break;
-        default:
-            ec3d_launch_k5(sw, c->state, 2, v[EC3D_VEC_R], v[EC3D_VEC_AP], v[EC3D_VEC_P], v[EC3D_VEC_R0], c->partials,
-                           nullptr, 0, s);
-        }
+        if (kernel == EC3D_K_SPMV)
+            ec3d_launch_spmv(A, sw, v[EC3D_VEC_P], v[EC3D_VEC_AP], s);
+        else
+            launch_stage(c, A, src, 2, kernel);
     };
     one(); // warm
     EC3D_HIP(hipEventRecord(c->t0, s));
@@ -596,6 +652,92 @@ extern "C" int ec3d_time_kernel(ec3d_handle c, int kernel, int32_t reps, double 
     float ms = 0.f;
     EC3D_HIP(hipEventElapsedTime(&ms, c->t0, c->t1));
     *ms_per_launch = (double)ms / std::max(1, reps);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// multi-rank (z-slab) building blocks: one process per GPU drives these from
+// eddy_currents_3d_amd/dist.py with torch.distributed (RCCL) between the stages
+extern "C" int ec3d_vector_layout(ec3d_handle c, int64_t *ghost, int64_t *n, int64_t *n_pad, int64_t *halo)
+{
+    int rc = need_matrix(c, "ec3d_vector_layout");
+    if (rc) return rc;
+    *ghost = c->ghost;
+    *n = c->A.n;
+    *n_pad = c->A.n_pad;
+    *halo = c->halo;
+    return 0;
+}
+
+// Use caller-owned device memory for the 8 work vectors: EC3D_NVEC * (ghost + n_pad + ghost) doubles,
+// zero filled by the caller.  Vector v's element 0 is at base[v*len + ghost].
+extern "C" int ec3d_adopt_vectors(ec3d_handle c, double *base)
+{
+    int rc = need_matrix(c, "ec3d_adopt_vectors");
+    if (rc) return rc;
+    EC3D_HIP(hipStreamSynchronize(c->stream));
+    if (c->vec_base && c->own_vectors) (void)hipFree(c->vec_base);
+    const int64_t len = c->ghost + c->A.n_pad + c->ghost;
+    c->vec_base = base;
+    c->own_vectors = false;
+    for (int v = 0; v < EC3D_NVEC; ++v) c->vec[v] = base + (size_t)v * len + c->ghost;
+    return 0;
+}
+
+extern "C" int ec3d_dist_configure(ec3d_handle c, int32_t nranks, double *lsum_device, double *gsum_device)
+{
+    if (nranks < 1 || !lsum_device || !gsum_device) {
+        ec3d_set_error("ec3d_dist_configure: need nranks >= 1 and two device buffers");
+        return 2;
+    }
+    c->nranks = nranks;
+    c->lsum = lsum_device;
+    c->gsum = gsum_device;
+    c->dist = true;
+    return 0;
+}
+
+extern "C" int ec3d_dist_step(ec3d_handle c, int32_t stage, int32_t it, double tolerance)
+{
+    int rc = need_matrix(c, "ec3d_dist_step");
+    if (rc) return rc;
+    if (!c->dist) {
+        ec3d_set_error("ec3d_dist_step: call ec3d_dist_configure first");
+        return 3;
+    }
+    const MatView A = c->A.view();
+    const RedSrc src = dist_src(c);
+    double **v = c->vec;
+    auto fin = [&](unsigned mask) { ec3d_launch_finalize(c->partials, c->sweep.nblk, c->lsum, mask, c->stream); };
+    switch (stage) {
+    case EC3D_STAGE_RESID:
+        c->hist_cap = 0;
+        ec3d_launch_residual(A, c->sweep, v[EC3D_VEC_X], v[EC3D_VEC_B], v[EC3D_VEC_R], v[EC3D_VEC_R0], v[EC3D_VEC_P],
+                             c->partials, c->stream);
+        fin(1u << P_BB | 1u << P_RR_INIT);
+        break;
+    case EC3D_STAGE_SETUP: ec3d_launch_setup(c->state, src, tolerance, c->stream); break;
+    case EC3D_STAGE_K1: launch_stage(c, A, src, it, 1); fin(1u << P_D1); break;
+    case EC3D_STAGE_K2: launch_stage(c, A, src, it, 2); fin(1u << P_SS); break;
+    case EC3D_STAGE_K3: launch_stage(c, A, src, it, 3); fin(1u << P_D2 | 1u << P_D3); break;
+    case EC3D_STAGE_K4: launch_stage(c, A, src, it, 4); fin(1u << P_RR | 1u << P_RR0N); break;
+    case EC3D_STAGE_K5: launch_stage(c, A, src, it, 5); break;
+    default: ec3d_set_error("ec3d_dist_step: unknown stage"); return 2;
+    }
+    EC3D_HIP(hipGetLastError());
+    return 0;
+}
+
+// synchronous read of the device-resident solver state (stream is drained first)
+extern "C" int ec3d_read_state(ec3d_handle c, int32_t *stop_iter, int32_t *stop_kind, double *bnorm)
+{
+    EC3D_HIP(hipSetDevice(c->device));
+    EC3D_HIP(hipStreamSynchronize(c->stream));
+    SolverState st;
+    EC3D_HIP(hipMemcpy(&st, c->state, sizeof st, hipMemcpyDeviceToHost));
+    if (stop_iter) *stop_iter = st.stop_iter == INT_MAX ? -1 : st.stop_iter;
+    if (stop_kind) *stop_kind = st.stop_kind;
+    if (bnorm) *bnorm = st.bnorm;
     return 0;
 }
 

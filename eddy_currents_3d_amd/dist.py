@@ -1,0 +1,271 @@
+"""z-slab multi-GPU BiCGSTAB-with-restart: one process per GPU, torch.distributed (nccl = RCCL over
+xGMI on the GPU box, gloo in the CPU tests) between the stages of an iteration.
+
+The reference is serial; this is new design.  Rank g of G owns the z-planes
+[k0, k1) of the structured grid, i.e. one contiguous index range (k is the slowest index,
+/root/reference/src/EC3D.f90:506-510).  Per iteration (src/solvers.f90:24-50):
+
+    halo(P) -> K1 -> gather -> K2 -> gather -> halo(S) -> K3 -> gather -> K4 -> gather -> K5
+
+* halo(v): the first/last owned plane of v goes to the z-neighbours' ghost planes (send/recv pairs,
+  nearest neighbours only; the planes are contiguous, so tensors are sent in place, no packing);
+* gather: all_gather of the 8 per-rank partial sums (64 B).  Every rank then adds the G values in
+  the same fixed order inside the next kernel, so all ranks take bit-identical decisions
+  (alpha, omega, beta, exits, restart) without any further synchronisation;
+* all scalars stay on the device; the host only polls the stop flag every few iterations.
+
+The orchestration below is backend-agnostic: `ops` supplies the per-stage local compute.  The
+product ops (:class:`HipSlabOps`) drive libec3d_hip.so through the C ABI and raise when it is
+missing; the CPU tests inject a numpy stand-in to exercise exactly this file over gloo.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+RESID, SETUP, K1, K2, K3, K4, K5 = range(7)
+NSLOT = 8
+# the communication/compute schedule, shared by every driver below
+BEGIN_PLAN = (("halo", "X"), ("step", RESID), ("gather",), ("step", SETUP))
+ITER_PLAN = (("halo", "P"), ("step", K1), ("gather",), ("step", K2), ("gather",), ("halo", "S"),
+             ("step", K3), ("gather",), ("step", K4), ("gather",), ("step", K5))
+
+
+def slab_bounds(sdz: int, rank: int, world: int):
+    """Planes [k0, k1) of rank `rank`: as even as possible, lower ranks take the remainder."""
+    base, rem = divmod(sdz, world)
+    k0 = rank * base + min(rank, rem)
+    return k0, k0 + base + (1 if rank < rem else 0)
+
+
+class HipSlabOps:
+    """One z-slab on one MI355X through the C ABI (include/ec3d_hip.h §2b)."""
+
+    VEC = dict(X=0, B=1, R=2, R0=3, P=4, AP=5, S=6, AS=7)
+
+    def __init__(self, sdx, sdy, sdz, k0, k1, world, device=0, delta=(0.00333,) * 3, bnd=-0.95,
+                 dictionary=None):
+        import torch
+        from .solver import EC3DSolver
+        self.torch = torch
+        self.device = torch.device("cuda", device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.local = EC3DSolver(device=device, dictionary=dictionary)
+        self.local.set_stream(self.stream.cuda_stream)
+        self.local.assemble_poisson(sdx, sdy, sdz, delta, bnd, slab=(k0, k1))
+        lay = self.local.vector_layout()
+        self.n, self.ghost, self.kdz = lay["n"], lay["ghost"], sdx * sdy
+        self.len = 2 * lay["ghost"] + lay["n_pad"]
+        with torch.cuda.stream(self.stream):
+            self.store = torch.zeros(8 * self.len, dtype=torch.float64, device=self.device)
+            self.lsum = torch.zeros(NSLOT, dtype=torch.float64, device=self.device)
+            self.gsum = torch.zeros(world * NSLOT, dtype=torch.float64, device=self.device)
+        self.stream.synchronize()
+        self.local.adopt_vectors(self.store.data_ptr())
+        self.local.dist_configure(world, self.lsum.data_ptr(), self.gsum.data_ptr())
+
+    def context(self):
+        return self.torch.cuda.stream(self.stream)
+
+    def _base(self, name):
+        return self.VEC[name] * self.len + self.ghost
+
+    def owned(self, name):
+        b = self._base(name)
+        return self.store[b:b + self.n]
+
+    def halo_views(self, name):
+        b, n, p = self._base(name), self.n, self.kdz
+        return (self.store[b:b + p], self.store[b - p:b],          # lo: send first plane, recv ghost
+                self.store[b + n - p:b + n], self.store[b + n:b + n + p])  # hi
+
+    def set_vector(self, name, host_array):
+        with self.context():
+            self.owned(name).copy_(self.torch.from_numpy(np.ascontiguousarray(host_array, np.float64)))
+
+    def get_vector(self, name):
+        with self.context():
+            return self.owned(name).cpu().numpy()
+
+    def step(self, stage, it=0, tol=0.0):
+        self.local.dist_step(stage, it, tol)
+
+    def read_state(self):
+        return self.local.read_state()
+
+    def timed(self, fn):
+        """Run fn() on the stream between two events; returns a closure giving ms after a sync."""
+        e0, e1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+        e0.record(self.stream)
+        fn()
+        e1.record(self.stream)
+        return lambda: e0.elapsed_time(e1)
+
+    def synchronize(self):
+        self.stream.synchronize()
+
+
+class SlabSolver:
+    """Backend-agnostic distributed loop (see module docstring)."""
+
+    def __init__(self, ops, rank: int, world: int, k0: int, k1: int):
+        self.ops, self.rank, self.world, self.k0, self.k1 = ops, rank, world, k0, k1
+        self.n_local = ops.n
+        if world > 1:
+            import torch.distributed as dist
+            self.dist = dist
+        else:
+            self.dist = None
+
+    @classmethod
+    def poisson_cube(cls, N, rank, world, device=0, dictionary=None):
+        k0, k1 = slab_bounds(N, rank, world)
+        return cls(HipSlabOps(N, N, N, k0, k1, world, device=device, dictionary=dictionary), rank, world, k0, k1)
+
+    @property
+    def local(self):
+        return self.ops.local
+
+    # ---- communication -----------------------------------------------------------------------
+    def exchange(self, name):
+        """Nearest-neighbour halo planes of vector `name` (no-op for a single rank)."""
+        if self.world == 1:
+            return
+        d = self.dist
+        lo_send, lo_recv, hi_send, hi_recv = self.ops.halo_views(name)
+        p2p = []
+        if self.rank > 0:
+            p2p += [d.P2POp(d.isend, lo_send, self.rank - 1), d.P2POp(d.irecv, lo_recv, self.rank - 1)]
+        if self.rank < self.world - 1:
+            p2p += [d.P2POp(d.isend, hi_send, self.rank + 1), d.P2POp(d.irecv, hi_recv, self.rank + 1)]
+        for req in d.batch_isend_irecv(p2p):
+            req.wait()
+
+    def gather(self):
+        """gsum[g*8 + slot] <- rank g's lsum[slot]; summed in rank order inside the next kernel."""
+        if self.world == 1:
+            self.ops.gsum.copy_(self.ops.lsum)
+        else:
+            self.dist.all_gather_into_tensor(self.ops.gsum, self.ops.lsum)
+
+    # ---- algorithm ---------------------------------------------------------------------------
+    def set_rhs(self, b_local, x_local):
+        self.ops.set_vector("B", b_local)
+        self.ops.set_vector("X", x_local)
+
+    def begin(self, tol):
+        """R = B - A X, R0 = P = R, Bnorm, rr0 (src/solvers.f90:14-23)."""
+        with self.ops.context():
+            self._run(BEGIN_PLAN, 0, tol, None)
+
+    def _run(self, plan, it, tol, timers):
+        ops = self.ops
+        for op in plan:
+            if op[0] == "halo":
+                self.exchange(op[1])
+            elif op[0] == "gather":
+                self.gather()
+            elif timers is None:
+                ops.step(op[1], it, tol)
+            else:
+                timers.setdefault(op[1], []).append(ops.timed(lambda st=op[1]: ops.step(st, it, tol)))
+
+    def iteration(self, it, timers=None):
+        self._run(ITER_PLAN, it, 0.0, timers)
+
+    def solve(self, tol, itmax, poll=8):
+        """One reference solve on the resident slab of b/x.  Returns iter (identical on all ranks)."""
+        total = max(0, itmax + 1)                      # src/solvers.f90:25-29
+        self.begin(tol)
+        it = 0
+        with self.ops.context():
+            while it < total:
+                for _ in range(min(poll, total - it)):
+                    it += 1
+                    self.iteration(it)
+                stop_iter, _, _ = self.ops.read_state()
+                if stop_iter >= 0:
+                    return stop_iter
+        stop_iter, _, _ = self.ops.read_state()
+        return stop_iter if stop_iter >= 0 else total
+
+    # ---- bench "steps": exits disabled ---------------------------------------------------------
+    def iterate_begin(self):
+        self.begin(-1.0)
+        self.ops.synchronize()
+
+    def iterate(self, first_iter, count, per_kernel=False):
+        timers = {} if per_kernel else None
+        with self.ops.context():
+            for it in range(first_iter, first_iter + count):
+                self.iteration(it, timers)
+        if not per_kernel:
+            return None
+        self.ops.synchronize()
+        names = {K1: "k1", K2: "k2", K3: "k3", K4: "k4", K5: "k5"}
+        return {names[st]: float(np.mean([t() for t in ts])) for st, ts in timers.items()}
+
+    def gather_x(self):
+        """Global solution on every rank (testing / small problems)."""
+        x = self.ops.get_vector("X")
+        if self.world == 1:
+            return x
+        import torch
+        parts = [None] * self.world
+        self.dist.all_gather_object(parts, x)
+        return np.concatenate(parts)
+
+
+class InProcessSlabs:
+    """The same schedule over several slabs held by ONE process (all on one GPU, or numpy stand-ins):
+    halo planes are copied tensor to tensor and the per-slab sums concatenated, so the slab kernels,
+    the ghost-plane layout and the rank-ordered reduction can be validated without a second GPU."""
+
+    def __init__(self, ops_list):
+        self.ops_list = ops_list
+        self.world = len(ops_list)
+
+    def _halo(self, name):
+        views = [o.halo_views(name) for o in self.ops_list]
+        for g in range(self.world - 1):
+            lo_send_next, lo_recv_next = views[g + 1][0], views[g + 1][1]
+            hi_send, hi_recv = views[g][2], views[g][3]
+            hi_recv.copy_(lo_send_next)   # my upper ghost <- next slab's first plane
+            lo_recv_next.copy_(hi_send)   # next slab's lower ghost <- my last plane
+
+    def _gather(self):
+        for o in self.ops_list:
+            for g, src in enumerate(self.ops_list):
+                o.gsum[g * NSLOT:(g + 1) * NSLOT].copy_(src.lsum)
+
+    def _run(self, plan, it, tol):
+        for op in plan:
+            if op[0] == "halo":
+                self._sync()
+                self._halo(op[1])
+                self._sync()
+            elif op[0] == "gather":
+                self._sync()
+                self._gather()
+                self._sync()
+            else:
+                for o in self.ops_list:
+                    with o.context():
+                        o.step(op[1], it, tol)
+
+    def _sync(self):
+        for o in self.ops_list:
+            o.synchronize()
+
+    def solve(self, tol, itmax):
+        total = max(0, itmax + 1)
+        self._run(BEGIN_PLAN, 0, tol)
+        for it in range(1, total + 1):
+            self._run(ITER_PLAN, it, 0.0)
+            states = [o.read_state()[0] for o in self.ops_list]
+            assert len(set(states)) == 1, f"slabs disagree on the stop flag: {states}"
+            if states[0] >= 0:
+                return states[0]
+        return total
+
+    def x(self):
+        return np.concatenate([o.get_vector("X") for o in self.ops_list])

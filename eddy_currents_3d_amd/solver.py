@@ -34,7 +34,8 @@ class Geom(C.Structure):
 class MatrixInfo(C.Structure):
     _fields_ = [("n", C.c_int64), ("n_pad", C.c_int64), ("nnz", C.c_int64), ("nbands", C.c_int32),
                 ("band_offset", C.c_int32 * 16), ("tail_rows", C.c_int64),
-                ("tail_entries_padded", C.c_int64), ("device_bytes", C.c_int64)]
+                ("tail_entries_padded", C.c_int64), ("device_bytes", C.c_int64),
+                ("dict_classes", C.c_int32)]
 
 
 VEC = dict(X=0, B=1, R=2, R0=3, P=4, AP=5, S=6, AS=7)
@@ -47,7 +48,9 @@ EXPORTS = ["sprsbcgstabwr_", "ec3d_invalidate", "ec3d_create", "ec3d_destroy", "
            "ec3d_upload", "ec3d_download", "ec3d_device_vector", "ec3d_solve_resident", "ec3d_spmv",
            "ec3d_export_csr", "ec3d_get_cel_bnd", "ec3d_get_reduction_geometry",
            "ec3d_set_workgroups", "ec3d_get_matrix_info", "ec3d_time_kernel", "ec3d_time_iterations",
-           "ec3d_iterate_begin", "ec3d_iterate",
+           "ec3d_iterate_begin", "ec3d_iterate", "ec3d_set_format", "ec3d_set_stream",
+           "ec3d_assemble_poisson_slab", "ec3d_vector_layout", "ec3d_adopt_vectors",
+           "ec3d_dist_configure", "ec3d_dist_step", "ec3d_read_state",
            "ec3d_device_synchronize"]
 
 _f64 = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
@@ -90,6 +93,14 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.ec3d_device_synchronize.argtypes = [hp]
     L.ec3d_iterate_begin.argtypes = [hp]
     L.ec3d_iterate.argtypes = [hp, C.c_int32, C.c_int32, hp]
+    L.ec3d_set_format.argtypes = [hp, C.c_int]
+    L.ec3d_set_stream.argtypes = [hp, hp]
+    L.ec3d_assemble_poisson_slab.argtypes = [hp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f64, _f64]
+    L.ec3d_vector_layout.argtypes = [hp] + [C.POINTER(C.c_int64)] * 4
+    L.ec3d_adopt_vectors.argtypes = [hp, hp]
+    L.ec3d_dist_configure.argtypes = [hp, C.c_int32, hp, hp]
+    L.ec3d_dist_step.argtypes = [hp, C.c_int32, C.c_int32, C.c_double]
+    L.ec3d_read_state.argtypes = [hp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double)]
     L.sprsbcgstabwr_.argtypes = [_f64, _i32, _i32, C.POINTER(C.c_int32), _f64, _f64,
                                  C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.sprsbcgstabwr_.restype = None
@@ -124,12 +135,14 @@ def sprsBCGstabWR(valA, irow, jcol, n, b, x, tolerance, itmax):
 class EC3DSolver:
     """Handle API of include/ec3d_hip.h (one HIP device, one stream)."""
 
-    def __init__(self, device: int = 0, nblk: int | None = None):
+    def __init__(self, device: int = 0, nblk: int | None = None, dictionary: bool | None = None):
         self.L = load_library()
         self.h = C.c_void_p()
         _chk(self.L, self.L.ec3d_create(C.byref(self.h), device), "ec3d_create")
         if nblk:
             self.set_workgroups(nblk)
+        if dictionary is not None:
+            self.set_format(dictionary)
 
     def close(self):
         if getattr(self, "h", None) and self.h.value:
@@ -163,12 +176,21 @@ class EC3DSolver:
             np.ascontiguousarray(np.asarray(BND, np.float64).T).reshape(-1),
             np.ascontiguousarray(delta, np.float64), float(dt)), "ec3d_assemble")
 
-    def assemble_poisson(self, sdx, sdy, sdz, delta=(0.00333, 0.00333, 0.00333), bnd=-0.95):
+    def set_format(self, dictionary: bool):
+        """True (default): 1 class byte per row + coefficient table when the operator allows it;
+        False: plain DIA coefficient streams.  Call before assembling / setting the matrix."""
+        _chk(self.L, self.L.ec3d_set_format(self.h, int(bool(dictionary))), "ec3d_set_format")
+
+    def assemble_poisson(self, sdx, sdy, sdz, delta=(0.00333, 0.00333, 0.00333), bnd=-0.95, slab=None):
+        """Non-conducting Ax block (src/EC3D.f90:528-654).  slab=(k0, k1): only planes [k0, k1)."""
         BND = np.full(6, float(bnd)) if np.isscalar(bnd) else np.ascontiguousarray(
             np.asarray(bnd, np.float64).T).reshape(-1)
-        _chk(self.L, self.L.ec3d_assemble_poisson(self.h, sdx, sdy, sdz, BND,
-                                                  np.ascontiguousarray(delta, np.float64)),
-             "ec3d_assemble_poisson")
+        d = np.ascontiguousarray(delta, np.float64)
+        if slab is None:
+            _chk(self.L, self.L.ec3d_assemble_poisson(self.h, sdx, sdy, sdz, BND, d), "ec3d_assemble_poisson")
+        else:
+            _chk(self.L, self.L.ec3d_assemble_poisson_slab(self.h, sdx, sdy, sdz, int(slab[0]), int(slab[1]),
+                                                           BND, d), "ec3d_assemble_poisson_slab")
 
     def export_csr(self):
         n, nnz = C.c_int32(0), C.c_int64(0)
@@ -268,6 +290,31 @@ class EC3DSolver:
         ms = np.zeros(5)
         _chk(self.L, self.L.ec3d_iterate(self.h, first_iter, count, ms.ctypes.data), "ec3d_iterate")
         return dict(zip(("k1", "k2", "k3", "k4", "k5"), ms.tolist()))
+
+    # ---- multi-rank building blocks (see dist.py) -------------------------------------------
+    def set_stream(self, stream_ptr: int | None):
+        _chk(self.L, self.L.ec3d_set_stream(self.h, C.c_void_p(stream_ptr or 0)), "ec3d_set_stream")
+
+    def vector_layout(self):
+        g, n, npad, halo = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        _chk(self.L, self.L.ec3d_vector_layout(self.h, C.byref(g), C.byref(n), C.byref(npad), C.byref(halo)),
+             "ec3d_vector_layout")
+        return dict(ghost=g.value, n=n.value, n_pad=npad.value, halo=halo.value)
+
+    def adopt_vectors(self, device_ptr: int):
+        _chk(self.L, self.L.ec3d_adopt_vectors(self.h, C.c_void_p(device_ptr)), "ec3d_adopt_vectors")
+
+    def dist_configure(self, nranks: int, lsum_ptr: int, gsum_ptr: int):
+        _chk(self.L, self.L.ec3d_dist_configure(self.h, nranks, C.c_void_p(lsum_ptr), C.c_void_p(gsum_ptr)),
+             "ec3d_dist_configure")
+
+    def dist_step(self, stage: int, it: int = 0, tol: float = 0.0):
+        _chk(self.L, self.L.ec3d_dist_step(self.h, stage, it, float(tol)), "ec3d_dist_step")
+
+    def read_state(self):
+        si, sk, bn = C.c_int32(0), C.c_int32(0), C.c_double(0)
+        _chk(self.L, self.L.ec3d_read_state(self.h, C.byref(si), C.byref(sk), C.byref(bn)), "ec3d_read_state")
+        return si.value, sk.value, bn.value
 
     def synchronize(self):
         _chk(self.L, self.L.ec3d_device_synchronize(self.h), "ec3d_device_synchronize")

@@ -94,6 +94,41 @@ int ec3d_export_csr(ec3d_handle h, int32_t *n, int64_t *nnz, int32_t *irow, int3
  * which = 0..5 -> cel_bndX, Y, Z, Ux, Uy, Uz.  list == NULL -> count only. */
 int ec3d_get_cel_bnd(ec3d_handle h, int which, int32_t *count, int32_t *list);
 
+/* Band storage: 1 (default) = dictionary form whenever the band coefficient tuples of the matrix
+ * take <= 256 distinct values (always true for the reference's operator: 27 boundary types + one
+ * per conducting domain) — 1 byte per row instead of 56; 0 = plain DIA streams.  Same doubles are
+ * multiplied in the same order either way.  Call before ec3d_set_matrix_csr / ec3d_assemble*. */
+int ec3d_set_format(ec3d_handle h, int dictionary);
+
+/* ------------------------------------------------------------------------------------------
+ * 2b. Multi-rank building blocks (z-slab decomposition, one process per GPU).
+ *     No reference counterpart: the reference is serial.  The host
+ *     (eddy_currents_3d_amd/dist.py) owns the communicator; between stages it exchanges the halo
+ *     planes of P and S with the z-neighbours and all-gathers the 8 per-rank partial sums.
+ * ---------------------------------------------------------------------------------------- */
+/* launch on a caller-owned HIP stream (e.g. torch's current stream); NULL = the library's own */
+int ec3d_set_stream(ec3d_handle h, void *hip_stream);
+/* planes [k0, k1) (0-based) of the ec3d_assemble_poisson operator: n = (k1-k0)*sdx*sdy rows; the
+ * z-neighbour planes are read from the vectors' ghost zones: v[-kdz..0) and v[n..n+kdz) */
+int ec3d_assemble_poisson_slab(ec3d_handle h, int32_t sdx, int32_t sdy, int32_t sdz, int32_t k0, int32_t k1,
+                               const double *BND, const double *delta);
+/* every work vector is [ghost | n_pad | ghost] doubles; halo = doubles per z-plane (0 if not a slab) */
+int ec3d_vector_layout(ec3d_handle h, int64_t *ghost, int64_t *n, int64_t *n_pad, int64_t *halo);
+/* use caller-owned, zero-filled device memory (EC3D_NVEC * (2*ghost + n_pad) doubles) for the vectors */
+int ec3d_adopt_vectors(ec3d_handle h, double *device_base);
+/* reductions then come from gsum_device[nranks][8] (the all-gather of every rank's lsum_device[8]) */
+int ec3d_dist_configure(ec3d_handle h, int32_t nranks, double *lsum_device, double *gsum_device);
+enum { EC3D_STAGE_RESID = 0, /* R = B - A X, R0 = P = R; lsum <- B.B, R.R      src/solvers.f90:14-21 */
+       EC3D_STAGE_SETUP = 1, /* Bnorm, rr0 from gsum                                            :21-23 */
+       EC3D_STAGE_K1 = 2,    /* AP = A P; lsum <- AP.R0        (P halo must be current)          :30-32 */
+       EC3D_STAGE_K2 = 3,    /* alpha, S = R - alpha AP; lsum <- S.S                             :32-34 */
+       EC3D_STAGE_K3 = 4,    /* S exit or AS = A S; lsum <- AS.S, AS.AS (S halo current)         :34-40 */
+       EC3D_STAGE_K4 = 5,    /* omega, X, R; lsum <- R.R, R.R0                                   :40-44 */
+       EC3D_STAGE_K5 = 6 };  /* R exit, beta, P, restart                                         :43-49 */
+int ec3d_dist_step(ec3d_handle h, int32_t stage, int32_t it, double tolerance);
+/* drain the stream and read the device-resident state; stop_iter = -1 while still running */
+int ec3d_read_state(ec3d_handle h, int32_t *stop_iter, int32_t *stop_kind, double *bnorm);
+
 /* ------------------------------------------------------------------------------------------
  * 3. Introspection / measurement
  * ---------------------------------------------------------------------------------------- */
@@ -113,6 +148,7 @@ typedef struct {
     int32_t band_offset[16];
     int64_t tail_rows, tail_entries_padded; /* sliced-ELL tail */
     int64_t device_bytes;
+    int32_t dict_classes; /* > 0: bands stored as 1 class byte per row + a table of that many 7-tuples */
 } ec3d_matrix_info;
 int ec3d_get_matrix_info(ec3d_handle h, ec3d_matrix_info *info);
 

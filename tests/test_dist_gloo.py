@@ -1,0 +1,94 @@
+"""N > 1 path on CPU: the slab schedule of eddy_currents_3d_amd/dist.py (halo send/recv, all_gather of
+the partial sums, rank-ordered reduction, stop flag agreement) over gloo with world_size 2 and 3,
+with a numpy stand-in for the per-slab device ops.  Checked against the oracle's serial solve."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from conftest import REPO
+
+N = 12
+TOL = 1e-8
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out):
+    import sys
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import torch.distributed as dist
+    from oracle import oracle as O
+    from eddy_currents_3d_amd.dist import SlabSolver, slab_bounds
+    from slab_numpy_ops import NumpySlabOps
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        k0, k1 = slab_bounds(N, rank, world)
+        ops = NumpySlabOps(O, N, N, N, k0, k1, world)
+        s = SlabSolver(ops, rank, world, k0, k1)
+        b = O.bar_rhs(N).reshape(N, N * N)[k0:k1].reshape(-1)
+        s.set_rhs(b, np.zeros(s.n_local))
+        it = s.solve(TOL, 10000, poll=4)
+        x = s.gather_x()
+        if rank == 0:
+            np.save(out, np.concatenate([[it], x]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_slab_solver_over_gloo_matches_serial_oracle(oracle, tmp_path, world):
+    out = str(tmp_path / "x.npy")
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    res = np.load(out)
+    it, x = int(res[0]), res[1:]
+    valA, irow, jcol = oracle.poisson_csr(N, N, N)
+    b = oracle.bar_rhs(N)
+    xo, ito, _, _ = oracle.bicgstab_wr(valA, irow, jcol, b, np.zeros(N ** 3), TOL, 10000)
+    res_norm = np.linalg.norm(b - oracle.spmv_csr(valA, irow, jcol, x)) / np.linalg.norm(b)
+    assert res_norm < 5 * TOL
+    assert np.linalg.norm(x - xo) <= 1e-5 * np.linalg.norm(xo)
+    assert abs(it - ito) <= 0.35 * ito
+
+
+def test_slab_bounds_partition():
+    from eddy_currents_3d_amd.dist import slab_bounds
+    for sdz in (7, 8, 64, 65):
+        for world in (1, 2, 3, 8):
+            if world > sdz:
+                continue
+            b = [slab_bounds(sdz, r, world) for r in range(world)]
+            assert b[0][0] == 0 and b[-1][1] == sdz
+            assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+            sizes = [k1 - k0 for k0, k1 in b]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_in_process_slabs_equal_single_slab(oracle):
+    """Three slabs in one process (same schedule, tensor-to-tensor halos) vs one slab vs the oracle."""
+    from eddy_currents_3d_amd.dist import InProcessSlabs, slab_bounds
+    from slab_numpy_ops import NumpySlabOps
+    b = oracle.bar_rhs(N)
+    xs, its = [], []
+    for world in (1, 3):
+        ops = []
+        for r in range(world):
+            k0, k1 = slab_bounds(N, r, world)
+            o = NumpySlabOps(oracle, N, N, N, k0, k1, world)
+            o.set_vector("B", b.reshape(N, N * N)[k0:k1].reshape(-1))
+            ops.append(o)
+        drv = InProcessSlabs(ops)
+        its.append(drv.solve(TOL, 10000))
+        xs.append(drv.x())
+    assert np.linalg.norm(xs[0] - xs[1]) <= 1e-6 * np.linalg.norm(xs[0])
+    valA, irow, jcol = oracle.poisson_csr(N, N, N)
+    assert np.linalg.norm(b - oracle.spmv_csr(valA, irow, jcol, xs[1])) / np.linalg.norm(b) < 5 * TOL

@@ -1,0 +1,136 @@
+"""GPU tests (1 GPU) for the two band storage formats and for the z-slab building blocks."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def E():
+    import eddy_currents_3d_amd as E
+    E.load_library()
+    return E
+
+
+@pytest.mark.parametrize("name", ["g2_conducting_hole_16x15x14", "g2v_conducting_moving_16x15x14",
+                                  "g3_moving_coil_18x16x12"])
+def test_dictionary_and_plain_dia_are_bit_identical(E, oracle, name):
+    """Dictionary form (1 class byte/row + table) multiplies the same doubles in the same order."""
+    g = load_golden(name)
+    n = len(g["irow"]) - 1
+    x = np.random.Generator(np.random.PCG64(4)).standard_normal(n)
+    ref = oracle.spmv_csr(g["valA"], g["irow"], g["jcol"], x)
+    res = {}
+    for route in ("csr", "assemble"):
+        for dic in (False, True):
+            with E.EC3DSolver(dictionary=dic) as s:
+                if route == "csr":
+                    s.set_matrix_csr(g["valA"], g["irow"], g["jcol"])
+                else:
+                    s.assemble(g["geoPHYS"], g["geoPHYS_C"], g["valPHYS"], g["BND"], g["delta"], float(g["dt"]))
+                assert (s.info.dict_classes > 0) == dic
+                assert np.array_equal(s.spmv(x), ref)
+                va, ir, jc = s.export_csr()
+                assert np.array_equal(ir, g["irow"]) and np.array_equal(jc, g["jcol"]) and np.array_equal(va, g["valA"])
+                res[(route, dic)] = s.solve(g["b0"], g["xin0"], float(g["tol"]), int(g["itmax"]), hist_cap=64)
+    x0, it0, h0 = res[("csr", False)]
+    for k, (xk, itk, hk) in res.items():
+        assert itk == it0 and np.array_equal(xk, x0) and np.array_equal(hk[:itk], h0[:itk]), k
+
+
+def test_dictionary_falls_back_when_too_many_classes(E, oracle):
+    """More than 256 distinct coefficient tuples: plain DIA streams are kept, results unchanged."""
+    N = 10
+    valA, irow, jcol = oracle.poisson_csr(N, N, N)
+    valA = valA * (1.0 + 1e-3 * np.arange(len(valA)))  # every row different
+    x = np.random.Generator(np.random.PCG64(8)).standard_normal(N ** 3)
+    with E.EC3DSolver(dictionary=True) as s:
+        s.set_matrix_csr(valA, irow, jcol)
+        assert s.info.dict_classes == 0 and s.info.nbands == 7
+        assert np.array_equal(s.spmv(x), oracle.spmv_csr(valA, irow, jcol, x))
+
+
+@pytest.mark.parametrize("dic", [False, True])
+def test_poisson_formats_match_oracle(E, oracle, dic):
+    N = 40
+    valA, irow, jcol = oracle.poisson_csr(N, N, N)
+    x = np.random.Generator(np.random.PCG64(6)).standard_normal(N ** 3)
+    with E.EC3DSolver(dictionary=dic) as s:
+        s.assemble_poisson(N, N, N)
+        assert (s.info.dict_classes > 0) == dic
+        assert np.array_equal(s.spmv(x), oracle.spmv_csr(valA, irow, jcol, x))
+        va, ir, jc = s.export_csr()
+        assert np.array_equal(ir, irow) and np.array_equal(jc, jcol) and np.array_equal(va, valA)
+
+
+# ------------------------------------------------------------------------------------- slabs
+def test_single_slab_dist_path_equals_single_gpu_solve_bitwise(E, oracle):
+    """world = 1 through ec3d_dist_step (finalize -> lsum -> gsum) == ec3d_solve, bit for bit."""
+    from eddy_currents_3d_amd.dist import SlabSolver
+    N, tol = 24, 1e-8
+    b = oracle.bar_rhs(N)
+    with E.EC3DSolver() as s:
+        s.assemble_poisson(N, N, N)
+        x_ref, it_ref, _ = s.solve(b, np.zeros(N ** 3), tol, 10000)
+    sl = SlabSolver.poisson_cube(N, 0, 1)
+    sl.set_rhs(b, np.zeros(N ** 3))
+    it = sl.solve(tol, 10000, poll=5)
+    assert it == it_ref
+    assert np.array_equal(sl.gather_x(), x_ref)
+
+
+@pytest.mark.parametrize("world,N", [(2, 24), (3, 20), (4, 32)])
+def test_slabs_on_one_gpu_match_single_gpu(E, oracle, world, N):
+    """`world` z-slabs held by one process on one GPU (InProcessSlabs: same schedule, halo planes copied
+    tensor to tensor, per-slab sums concatenated) vs the undivided solve."""
+    from eddy_currents_3d_amd.dist import HipSlabOps, InProcessSlabs, slab_bounds
+    tol = 1e-8
+    b = oracle.bar_rhs(N)
+    with E.EC3DSolver() as s:
+        s.assemble_poisson(N, N, N)
+        x_ref, it_ref, _ = s.solve(b, np.zeros(N ** 3), tol, 10000)
+    ops = []
+    for r in range(world):
+        k0, k1 = slab_bounds(N, r, world)
+        o = HipSlabOps(N, N, N, k0, k1, world)
+        o.set_vector("B", b.reshape(N, N * N)[k0:k1].reshape(-1))
+        ops.append(o)
+    drv = InProcessSlabs(ops)
+    it = drv.solve(tol, 10000)
+    x = drv.x()
+    valA, irow, jcol = oracle.poisson_csr(N, N, N)
+    res = np.linalg.norm(b - oracle.spmv_csr(valA, irow, jcol, x)) / np.linalg.norm(b)
+    print(f"{world} slabs of {N}^3: iter {it} / undivided {it_ref}, true residual {res:.2e}, "
+          f"rel diff {np.linalg.norm(x - x_ref) / np.linalg.norm(x_ref):.2e}")
+    assert res < 5 * tol
+    assert np.linalg.norm(x - x_ref) <= 1e-5 * np.linalg.norm(x_ref)
+    assert abs(it - it_ref) <= 0.35 * it_ref
+
+
+def test_slab_spmv_equals_rows_of_global_operator(E, oracle):
+    """A slab's operator applied to [lower ghost | owned | upper ghost] == the matching rows of A x."""
+    from eddy_currents_3d_amd.dist import HipSlabOps, K1
+    N, k0, k1 = 18, 5, 11
+    valA, irow, jcol = oracle.poisson_csr(N, N, N)
+    x = np.random.Generator(np.random.PCG64(10)).standard_normal(N ** 3)
+    y = oracle.spmv_csr(valA, irow, jcol, x)
+    kdz = N * N
+    o = HipSlabOps(N, N, N, k0, k1, 1)
+    o.set_vector("P", x[k0 * kdz:k1 * kdz])
+    lo_send, lo_recv, hi_send, hi_recv = o.halo_views("P")
+    import torch
+    with o.context():
+        lo_recv.copy_(torch.from_numpy(x[(k0 - 1) * kdz:k0 * kdz].copy()))
+        hi_recv.copy_(torch.from_numpy(x[k1 * kdz:(k1 + 1) * kdz].copy()))
+        o.step(K1, 1)
+    o.synchronize()
+    assert np.array_equal(o.get_vector("AP"), y[k0 * kdz:k1 * kdz])
+
+
+def test_slab_handle_refuses_whole_solve(E):
+    with E.EC3DSolver() as s:
+        s.assemble_poisson(16, 16, 16, slab=(4, 8))
+        with pytest.raises(E.EC3DError, match="z-slab"):
+            s.solve(np.zeros(4 * 256), np.zeros(4 * 256), 1e-6, 10)
