@@ -52,6 +52,7 @@ struct Sweep {
     int64_t n; // rows owned; rows in [n, ntiles*EC3D_TILE) are padding
     int nblk;
     int S;
+    int nt; // nontemporal policy for once-touched streams (large problems)
 };
 
 struct SolverState {
@@ -107,7 +108,7 @@ struct ec3d_ctx {
     int64_t ghost = 0;     // zero halo (doubles) on both sides of every vector
     double *vec_base = nullptr;
     double *vec[8] = {nullptr};
-    Sweep sweep{0, 0, 0, 0};
+    Sweep sweep{0, 0, 0, 0, 0};
     bool own_vectors = true;
     bool dist = false;
     // multi-rank (z-slab) mode: reductions come from the all-gathered per-rank sums
@@ -116,6 +117,7 @@ struct ec3d_ctx {
     int64_t halo = 0;                        // doubles per halo plane (kdz), 0 when not a slab
     bool use_dict = true;
     int nblk_request = 0;
+    int nt_request = -1; // -1 auto, 0/1 forced (EC3D_NT)
     double *partials = nullptr; // 8 * nblk doubles
     SolverState *state = nullptr;
     SolverState *state_pinned = nullptr; // 2 slots

@@ -65,6 +65,7 @@ extern "C" int ec3d_create(ec3d_handle *h, int device)
     EC3D_HIP(hipEventCreate(&c->t1));
     if (const char *e = getenv("EC3D_NBLK")) c->nblk_request = atoi(e);
     if (const char *e = getenv("EC3D_DICT")) c->use_dict = atoi(e) != 0;
+    if (const char *e = getenv("EC3D_NT")) c->nt_request = atoi(e);
     *h = c;
     return 0;
 }
@@ -130,6 +131,7 @@ static void choose_sweep(ec3d_ctx *c)
         sw.S = 0;
     }
     sw.nblk = (int)nblk;
+    sw.nt = c->nt_request >= 0 ? c->nt_request : (c->A.n_pad >= (4 << 20));
 }
 
 // vectors: [ghost | n_pad | ghost] doubles each, zero filled; kernels only ever write [0, n_pad)
