@@ -11,9 +11,13 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W     -> one JSO
     before the timed region starts (assembly is on the device, nothing crosses PCIe in the loop);
   * N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), z-slab decomposition, halo
     planes by send/recv and the dot products by all_gather (eddy_currents_3d_amd/dist.py);
-  * roofline: the dominant kernel K1 (AP = A·P fused with AP·R0), algorithmic 80 B/row,
-    duration measured live with hipEvents on the library's stream inside an extra instrumented pass
-    of the same K iterations; peak 8.0 TB/s (MI355X_MICROARCH.md);
+  * roofline: the kernel with the largest share of the iteration (measured, not assumed), its
+    algorithmic bytes per row from SURVEY §8d / DESIGN.md §4, duration measured live with hipEvents on
+    the library's stream inside an extra instrumented pass of the same K iterations; peak 8.0 TB/s
+    (MI355X_MICROARCH.md).  With the default dictionary band format K1/K3 move 25/17 B per row instead
+    of the 80/72 B of the plain-DIA model, so the widest kernel is K4 (X and R updates, 56 B/row);
+    `kernels` lists every stage with both byte models, `spmv` the bare 7-point SpMV the north-star
+    target is quoted on.  --format dia runs the plain DIA streams (the SURVEY's byte model).
   * cpu_baseline (rank 0, N = 1 only): the unmodified reference solver (oracle/_ref/ref_solve,
     src/solvers.f90 compiled with amdflang; "port" = our C restatement when that binary is absent)
     on one host core, fixed iteration count on a bounded cube.
@@ -31,7 +35,13 @@ sys.path.insert(0, REPO)
 
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 ITER_BYTES_PER_DOF = 264       # K1 80 + K2 24 + K3 72 + K4 56 + K5 32
-K1_BYTES_PER_ROW = 80
+# bytes per row each stage has to move: SURVEY §8d model (plain DIA) and the dictionary format
+SURVEY_BYTES = {"k1": 80, "k2": 24, "k3": 72, "k4": 56, "k5": 32, "spmv": 72}
+DICT_BYTES = {"k1": 25, "k2": 24, "k3": 17, "k4": 56, "k5": 32, "spmv": 17}
+KERNEL_NAMES = {"k1": "k1_spmv_dot (AP = A*P, AP.R0)", "k2": "k2_s_update (S = R - alpha*AP, S.S)",
+                "k3": "k3_spmv_dots (AS = A*S, AS.S, AS.AS)",
+                "k4": "k4_x_r_update (X += alpha*P + omega*S, R = S - omega*AS, R.R, R.R0)",
+                "k5": "k5_p_update (P = R + beta*(P - omega*AP))"}
 
 
 def bar_rhs(N, k0=0, k1=None):
@@ -69,7 +79,7 @@ def cpu_baseline(budget_s=20.0):
 
 
 def latest_traffic():
-    """HBM bytes per K1 launch from the committed PMC profile (profiles/*pmc*.json), or None."""
+    """Per-kernel HBM bytes per launch from the committed PMC profile (profiles/*pmc*.json), or None."""
     pdir = os.path.join(REPO, "profiles")
     try:
         cands = sorted(f for f in os.listdir(pdir) if f.endswith(".json") and "pmc" in f)
@@ -87,6 +97,10 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--grid", type=int, default=512, help="cube edge N (512 = headline, 256 = config 2)")
+    ap.add_argument("--format", choices=["dict", "dia"], default="dict",
+                    help="band storage: dictionary (default, 1 B/row) or plain DIA streams (56 B/row)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="use the z-slab/torch.distributed path even with one rank (rehearsal on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
@@ -105,9 +119,12 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU path)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
 
     import numpy as np
     import eddy_currents_3d_amd as E
@@ -115,8 +132,8 @@ def main():
     N, K, W = args.grid, args.steps, args.warmup
     n_global = N ** 3
     kernel_ms = None
-    if world == 1:
-        s = E.EC3DSolver(device=local_rank)
+    if not use_dist:
+        s = E.EC3DSolver(device=local_rank, dictionary=args.format == "dict")
         s.assemble_poisson(N, N, N)
         s.upload("B", bar_rhs(N))
         s.upload("X", np.zeros(n_global))
@@ -132,12 +149,13 @@ def main():
         elapsed = t1 - t0
         # instrumented pass of the same K iterations: hipEvents around every launch, library stream
         kernel_ms = s.iterate(W + K + 1, K, per_kernel=True)
+        spmv_ms = s.time_kernel("spmv", 20)
         geom = s.geometry()
         info = s.info
         parallelism = "single GPU"
     else:
         from eddy_currents_3d_amd.dist import SlabSolver
-        s = SlabSolver.poisson_cube(N, rank, world, device=local_rank)
+        s = SlabSolver.poisson_cube(N, rank, world, device=local_rank, dictionary=args.format == "dict")
         s.set_rhs(bar_rhs(N, s.k0, s.k1), np.zeros(s.n_local))
         s.iterate_begin()
         s.iterate(1, W)
@@ -154,6 +172,7 @@ def main():
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el.item())
         kernel_ms = s.iterate(W + K + 1, min(K, 20), per_kernel=True)
+        spmv_ms = None
         geom = s.local.geometry()
         info = s.local.info
         parallelism = f"z-slab x{world} (halo send/recv + all_gather of dot products, RCCL)"
@@ -161,13 +180,20 @@ def main():
     if rank == 0:
         ms_per_step = elapsed * 1e3 / K
         value = n_global * K / elapsed
-        rows_per_launch = int(info.n)
-        k1_ms = kernel_ms["k1"]
-        achieved = K1_BYTES_PER_ROW * rows_per_launch / (k1_ms * 1e-3) / 1e9
+        rows = int(info.n)                       # rows one launch processes on this rank
+        fmt_bytes = DICT_BYTES if info.dict_classes > 0 else SURVEY_BYTES
+        dom = max(kernel_ms, key=kernel_ms.get)   # dominant kernel by measured share
         tr = latest_traffic()
-        traffic = None
-        if tr and tr.get("grid") == N and tr.get("n_gpus", 1) == world:
-            traffic = tr.get("k1_hbm_bytes_per_launch")
+        use_tr = bool(tr) and tr.get("grid") == N and tr.get("n_gpus", 1) == world and \
+            tr.get("format") == args.format
+        kernels = {}
+        for k, ms in kernel_ms.items():
+            kernels[k] = {"ms": ms, "share": ms / sum(kernel_ms.values()),
+                          "bytes_per_row": fmt_bytes[k], "GBps": fmt_bytes[k] * rows / ms / 1e6,
+                          "survey_bytes_per_row": SURVEY_BYTES[k],
+                          "survey_GBps": SURVEY_BYTES[k] * rows / ms / 1e6}
+        achieved = fmt_bytes[dom] * rows / (kernel_ms[dom] * 1e-3) / 1e9
+        traffic = tr["kernels"].get(dom, {}).get("hbm_bytes") if use_tr else None
         out = {
             "metric": "DOF*iters/s (fp64 BiCGSTAB-with-restart, 7-pt A-V operator)",
             "value": value, "unit": "DOF*iters/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -176,15 +202,24 @@ def main():
             "config": {"workload": f"synthetic {N}^3 7-pt operator (BASELINE config "
                                    f"{'4' if N == 512 else '2'} grid), bar RHS, x0=0, exits disabled",
                        "n": n_global, "grid": [N, N, N], "parallelism": parallelism,
-                       "workgroups": int(geom.nblk), "bytes_per_dof_iter": ITER_BYTES_PER_DOF},
-            "iter_hbm_frac": ITER_BYTES_PER_DOF * value / 1e9 / world / PEAK_HBM_GBS,
-            "kernel_ms": kernel_ms,
-            "roofline": {"bound": "hbm", "kernel": "k1_spmv_dot<7> (AP = A*P fused with AP.R0)",
-                         "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                         "frac": achieved / PEAK_HBM_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": K1_BYTES_PER_ROW * rows_per_launch,
-                         "avg_launch_ms": k1_ms},
+                       "band_format": "dictionary (1 B/row + table)" if info.dict_classes > 0 else "plain DIA",
+                       "workgroups": int(geom.nblk),
+                       "bytes_per_dof_iter": {"survey_model": ITER_BYTES_PER_DOF,
+                                              "this_format": sum(fmt_bytes[k] for k in kernel_ms)}},
+            "iter_hbm_frac_survey_model": ITER_BYTES_PER_DOF * value / 1e9 / world / PEAK_HBM_GBS,
+            "iter_hbm_frac": sum(fmt_bytes[k] for k in kernel_ms) * value / 1e9 / world / PEAK_HBM_GBS,
+            "kernels": kernels,
+            "roofline": {"bound": "hbm", "kernel": KERNEL_NAMES[dom], "achieved": achieved,
+                         "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
+                         "traffic": traffic,
+                         "algorithmic_bytes_per_launch": fmt_bytes[dom] * rows,
+                         "avg_launch_ms": kernel_ms[dom]},
         }
+        if spmv_ms is not None:
+            out["spmv"] = {"kernel": "k_spmv (y = A*x, 7 bands)", "ms": spmv_ms,
+                           "survey_bytes_per_row": 72, "survey_GBps": 72 * rows / spmv_ms / 1e6,
+                           "frac_of_peak_survey_model": 72 * rows / spmv_ms / 1e6 / PEAK_HBM_GBS,
+                           "bytes_per_row": fmt_bytes["spmv"], "GBps": fmt_bytes["spmv"] * rows / spmv_ms / 1e6}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.cpu_budget)
@@ -192,7 +227,7 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "DOF*iters/s", "cores": 1, "kind": "port",
                                        "sample": f"failed: {e!r}"}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

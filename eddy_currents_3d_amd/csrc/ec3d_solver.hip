@@ -122,7 +122,9 @@ static void choose_sweep(ec3d_ctx *c)
     Sweep &sw = c->sweep;
     sw.ntiles = c->A.n_pad / EC3D_TILE;
     sw.n = c->A.n;
-    int want = c->nblk_request > 0 ? c->nblk_request : 2048; // 256 CUs x 8 workgroups
+    // 256 CUs x 3 workgroups: measured best on 512^3 (whole multiples of the CU count matter;
+    // 768 > 1024 > 512 > 2048)
+    int want = c->nblk_request > 0 ? c->nblk_request : 768;
     int64_t nblk = std::min<int64_t>(sw.ntiles, want);
     if (nblk >= 8) {
         nblk -= nblk % 8;
@@ -130,6 +132,8 @@ static void choose_sweep(ec3d_ctx *c)
     } else {
         sw.S = 0;
     }
+    if (const char *e = getenv("EC3D_XCD_MAP"))
+        if (atoi(e) == 0) sw.S = 0;
     sw.nblk = (int)nblk;
     sw.nt = c->nt_request >= 0 ? c->nt_request : (c->A.n_pad >= (4 << 20));
 }
@@ -140,7 +144,9 @@ int ec3d_prepare_vectors(ec3d_ctx *c)
     free_vectors(c);
     int64_t maxoff = 0;
     for (int b = 0; b < c->A.nb; ++b) maxoff = std::max<int64_t>(maxoff, std::llabs(c->A.off[b]));
-    c->ghost = round_up(maxoff + 2, 64);
+    int64_t galign = 64;
+    if (const char *e = getenv("EC3D_GHOST_ALIGN")) galign = std::max<int64_t>(2, atoll(e));
+    c->ghost = round_up(maxoff + 2, galign);
     const int64_t len = c->ghost + c->A.n_pad + c->ghost;
     EC3D_HIP(hipMalloc(&c->vec_base, (size_t)len * EC3D_NVEC * sizeof(double)));
     EC3D_HIP(hipMemsetAsync(c->vec_base, 0, (size_t)len * EC3D_NVEC * sizeof(double), c->stream));

@@ -8,6 +8,7 @@ import csv, glob, json, os, re, sys
 from collections import defaultdict
 
 out, tag, grid = sys.argv[1], sys.argv[2], int(sys.argv[3])
+fmt = sys.argv[4] if len(sys.argv) > 4 else "dict"
 repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 prof = os.path.join(repo, "gpurun_out", "profiles_" + tag)
 os.makedirs(prof, exist_ok=True)
@@ -52,22 +53,21 @@ def pmc(sub, counter):
 
 fetch, write = pmc("pmc_fetch", "FETCH_SIZE"), pmc("pmc_write", "WRITE_SIZE")
 n = grid ** 3
-res = {"tag": tag, "grid": grid, "n_gpus": 1, "units_note":
+res = {"tag": tag, "grid": grid, "n_gpus": 1, "format": fmt, "units_note":
        "FETCH_SIZE/WRITE_SIZE are KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM (gfx950 reports 1/2 of a "
        "16-B-per-lane stream); per launch = mean over the launches of the profiled run", "kernels": {}}
 for k in sorted(set(fetch) | set(write)):
     fv = sum(fetch[k]) / len(fetch[k]) if fetch.get(k) else None
     wv = sum(write[k]) / len(write[k]) if write.get(k) else None
-    res["kernels"][k] = {"fetch_kib_raw": fv, "write_kib_raw": wv,
+    kk = re.match(r"(k[1-5])_", k)
+    kk = kk.group(1) if kk else k
+    res["kernels"][kk] = {"rocprof_name": k, "fetch_kib_raw": fv, "write_kib_raw": wv,
                          "hbm_read_bytes": None if fv is None else 2 * fv * 1024,
                          "hbm_write_bytes": None if wv is None else wv * 1024}
 for k, v in res["kernels"].items():
     if v["hbm_read_bytes"] is not None and v["hbm_write_bytes"] is not None:
         v["hbm_bytes"] = v["hbm_read_bytes"] + v["hbm_write_bytes"]
         v["bytes_per_row"] = v["hbm_bytes"] / n
-k1 = next((v for k, v in res["kernels"].items() if k.startswith("k1_spmv_dot")), None)
-if k1 and "hbm_bytes" in k1:
-    res["k1_hbm_bytes_per_launch"] = k1["hbm_bytes"]
 with open(os.path.join(prof, f"{tag}_pmc_traffic.json"), "w") as f:
     json.dump(res, f, indent=1)
 print(json.dumps(res, indent=1))
