@@ -69,8 +69,10 @@ def read_shipped_vxc(path):
     return vox, names, g("Lattice_Dim"), (g("X_Dim_Adj"), g("Y_Dim_Adj"), g("Z_Dim_Adj"))
 
 
-def run_reference(vox, names, lattice_dim, adj=(1, 1, 1), max_calls=3, all_matrices=False):
-    """Run EC3D_capture on the given case; returns the list of captured calls (dicts)."""
+def run_reference(vox, names, lattice_dim, adj=(1, 1, 1), max_calls=3, all_matrices=False, exe=None,
+                  extra_env=None):
+    """Run EC3D_capture (or another build of the same program, e.g. _ref/EC3D_dropin) on the given
+    case; returns the list of captured calls (dicts)."""
     td = tempfile.mkdtemp(prefix="ec3d_gold_")
     try:
         write_vxc(os.path.join(td, "in.vxc"), vox, names, lattice_dim, adj)
@@ -83,7 +85,8 @@ def run_reference(vox, names, lattice_dim, adj=(1, 1, 1), max_calls=3, all_matri
                    EC3D_CAPTURE_MAX_CALLS=str(max_calls))
         if all_matrices:
             env["EC3D_CAPTURE_ALL_MATRICES"] = "1"
-        p = subprocess.run([EXE], cwd=td, env=env, preexec_fn=O._unlimit_stack,
+        env.update(extra_env or {})
+        p = subprocess.run([exe or EXE], cwd=td, env=env, preexec_fn=O._unlimit_stack,
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         log = p.stdout.decode(errors="replace") + p.stderr.decode(errors="replace")
         calls = []
@@ -177,14 +180,20 @@ def put_coil(vox, ids, k0, k1, j0, j1, i0, i1, w=1):
     vox[k0:k1, j0:j1, i0:i0 + w] = aym
 
 
-def case_g1():
-    """G1: tiny non-conducting box 8x7x6 with one coil, 3 steps."""
+def inputs_g1():
     vox = np.zeros((6, 7, 8), np.uint8)
     put_coil(vox, (1, 2, 3, 4), 2, 4, 1, 6, 1, 7)
     names = coil_names() + ["param tran stop=3m step=1m", "p2 solver tol=1u itmax=10000 dir=g1",
                             "f1 func Fp=a*cos(p2*f*t) a='100/(dx*dz)' p2='2*pi' f=50 t=t",
                             "f2 func Fm=a*cos(p2*f*t) a='-100/(dx*dz)' p2='2*pi' f=50 t=t"]
-    calls, log = run_reference(vox, names, "0.005", max_calls=3)
+    return dict(vox=vox, names=names, lattice_dim="0.005", adj=(1, 1, 1), max_calls=3)
+
+
+def case_g1():
+    """G1: tiny non-conducting box 8x7x6 with one coil, 3 steps."""
+    inp = inputs_g1()
+    vox = inp["vox"]
+    calls, log = run_reference(**inp)
     geo, geoC, _ = geometry_tables(vox, [], 4)
     save("g1_nonconducting_8x7x6", vox=vox, geoPHYS=geo, geoPHYS_C=geoC, delta=np.full(3, 0.005),
          dt=np.float64(1e-3), BND=np.full((3, 2), -0.95), valPHYS=np.zeros((int(geo.max()), 5)),
@@ -200,11 +209,7 @@ def conductor_block(shape, k0, j0, i0, dk, dj, di, hole=True):
     return vox
 
 
-def case_g2(vel=False, itmax_case=False):
-    """G2 (tol 5e-3 like the shipped inputs; g2i: tol 1e-9 with itmax=25 so the itmax exit of
-    src/solvers.f90:25-28 is taken after 26 iterations): conducting 8x7x6 block with a through-hole in a 16x15x14 box + coil above it; every
-    corner/edge/face/interior U-row branch and both one-sided A-U stencils occur.  With vel=True
-    the conductor also moves (VEX/VEY/VEZ terms of src/EC3D.f90:657-662)."""
+def inputs_g2(vel=False, itmax_case=False):
     vox = conductor_block((14, 15, 16), 3, 4, 4, 6, 7, 8)
     put_coil(vox, (2, 3, 4, 5), 10, 12, 3, 12, 3, 13)
     cname = "plast D=1 C='mu0*35.26e6'" + (" Vex=1.5 Vey=-0.7 Vez=0.3" if vel else "")
@@ -213,7 +218,17 @@ def case_g2(vel=False, itmax_case=False):
         "p2 solver tol=1n itmax=25 dir=g2" if itmax_case else "p2 solver tol=5m itmax=10000 dir=g2",
         "f1 func Fp=a*cos(p2*f*t) a='183/(dx*2*dz)' p2='2*pi' f=50 t=t",
         "f2 func Fm=a*cos(p2*f*t) a='-183/(dx*2*dz)' p2='2*pi' f=50 t=t"]
-    calls, log = run_reference(vox, names, "0.004", adj=("1", "1.25", "0.75"), max_calls=3)
+    return dict(vox=vox, names=names, lattice_dim="0.004", adj=("1", "1.25", "0.75"), max_calls=3)
+
+
+def case_g2(vel=False, itmax_case=False):
+    """G2 (tol 5e-3 like the shipped inputs; g2i: tol 1e-9 with itmax=25 so the itmax exit of
+    src/solvers.f90:25-28 is taken after 26 iterations): conducting 8x7x6 block with a through-hole in a 16x15x14 box + coil above it; every
+    corner/edge/face/interior U-row branch and both one-sided A-U stencils occur.  With vel=True
+    the conductor also moves (VEX/VEY/VEZ terms of src/EC3D.f90:657-662)."""
+    inp = inputs_g2(vel, itmax_case)
+    vox = inp["vox"]
+    calls, log = run_reference(**inp)
     geo, geoC, _ = geometry_tables(vox, [1], 5)
     nsubg = int(geo.max())
     valPHYS = np.zeros((nsubg, 5)); valPHYS[:, 0] = 1.0
@@ -229,8 +244,7 @@ def case_g2(vel=False, itmax_case=False):
     return calls
 
 
-def case_g3():
-    """G3: moving coil (constant Vsx and a FUNC velocity Vsy) over a conducting plate: b per step."""
+def inputs_g3():
     vox = conductor_block((12, 16, 18), 2, 3, 3, 3, 10, 12, hole=False)
     put_coil(vox, (2, 3, 4, 5), 7, 9, 4, 10, 4, 10)
     mv = " Vsx=2.0 Vsy=Vmy"
@@ -239,7 +253,14 @@ def case_g3():
         "f1 func Fp=a*cos(p2*f*t) a='183/(dx*2*dz)' p2='2*pi' f=50 t=t",
         "f2 func Fm=a*cos(p2*f*t) a='-183/(dx*2*dz)' p2='2*pi' f=50 t=t",
         "m2 func Vmy=a*p2*f*cos(p2*f*t) a='-dY*3' p2='2*pi' f=100 t=t"]
-    calls, log = run_reference(vox, names, "0.004", max_calls=4)
+    return dict(vox=vox, names=names, lattice_dim="0.004", adj=(1, 1, 1), max_calls=4)
+
+
+def case_g3():
+    """G3: moving coil (constant Vsx and a FUNC velocity Vsy) over a conducting plate: b per step."""
+    inp = inputs_g3()
+    vox = inp["vox"]
+    calls, log = run_reference(**inp)
     geo, geoC, _ = geometry_tables(vox, [1], 5)
     nsubg = int(geo.max())
     valPHYS = np.zeros((nsubg, 5)); valPHYS[:, 0] = 1.0
