@@ -52,7 +52,12 @@ struct Sweep {
     int64_t n; // rows owned; rows in [n, ntiles*EC3D_TILE) are padding
     int nblk;
     int S;
-    int nt; // nontemporal policy for once-touched streams (large problems)
+    int nt;      // nontemporal policy for once-touched streams (large problems)
+    int pstride; // doubles between two slots of the partial-sum buffer
+    // z-marching map of the SpMV kernels (zm_tpp > 0): a workgroup owns one 512-row position of the
+    // xy-plane ("column") and walks zm_pps consecutive planes, so x[r-kdz], x[r] stay in registers
+    int zm_tpp;  // tiles per plane = kdz / 512
+    int zm_pps;  // planes per z segment
 };
 
 struct SolverState {
@@ -108,7 +113,8 @@ struct ec3d_ctx {
     int64_t ghost = 0;     // zero halo (doubles) on both sides of every vector
     double *vec_base = nullptr;
     double *vec[8] = {nullptr};
-    Sweep sweep{0, 0, 0, 0, 0};
+    Sweep sweep{0, 0, 0, 0, 0, 0, 0, 0};   // vector kernels (K2, K4, K5)
+    Sweep sweep_s{0, 0, 0, 0, 0, 0, 0, 0}; // SpMV kernels (K1, K3, residual, spmv)
     bool own_vectors = true;
     bool dist = false;
     // multi-rank (z-slab) mode: reductions come from the all-gathered per-rank sums
@@ -118,6 +124,7 @@ struct ec3d_ctx {
     bool use_dict = true;
     int nblk_request = 0;
     int nt_request = -1; // -1 auto, 0/1 forced (EC3D_NT)
+    int zm_request = 1;  // z-marching SpMV map when the grid allows it (EC3D_ZMARCH)
     double *partials = nullptr; // 8 * nblk doubles
     SolverState *state = nullptr;
     SolverState *state_pinned = nullptr; // 2 slots
@@ -160,7 +167,7 @@ int ec3d_prepare_vectors(ec3d_ctx *c);
 void ec3d_launch_spmv(const MatView &A, const Sweep &sw, const double *x, double *y, hipStream_t s);
 void ec3d_launch_residual(const MatView &A, const Sweep &sw, const double *x, const double *b, double *r,
                           double *r0, double *p, double *part, hipStream_t s);
-void ec3d_launch_finalize(const double *part, int nblk, double *lsum, unsigned mask, hipStream_t s);
+void ec3d_launch_finalize(const RedSrc &src, double *lsum, unsigned mask, hipStream_t s);
 void ec3d_launch_setup(SolverState *st, const RedSrc &src, double tol, hipStream_t s);
 void ec3d_launch_k1(const MatView &A, const Sweep &sw, const SolverState *st, int it, const double *p,
                     const double *r0, double *ap, double *part, hipStream_t s);

@@ -26,6 +26,14 @@ typedef int i2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int64_t ec3d_tile_of(const Sweep &sw, int b, int64_t i)
 {
+    if (sw.zm_tpp > 0) {
+        // XCD label c owns zm_tpp/8 adjacent columns, so the +-sdx lines a column needs were fetched
+        // by a neighbour on the same XCD one step earlier (L2 hit); plane k = seg*pps + i
+        const int cpx = sw.zm_tpp >> 3, c = b & 7, s = b >> 3;
+        const int64_t col = c * cpx + s % cpx, seg = s / cpx;
+        if (i >= sw.zm_pps) return sw.ntiles;
+        return (seg * sw.zm_pps + i) * sw.zm_tpp + col;
+    }
     if (sw.S > 0) {
         int64_t c = b & 7, s = b >> 3;
         return (i * 8 + c) * sw.S + s;
@@ -131,17 +139,29 @@ __device__ __forceinline__ void stage_table(const MatView &A, double *tbl)
     }
 }
 
-// rows r, r+1 of A*x (src/solvers.f90:58-59): bands in ascending column order, then the tail
-template <int FMT>
+// x values of the planes below / at the current row, carried across the steps of a z-march
+struct ZRegs {
+    d2 xm, xc;
+};
+
+// rows r, r+1 of A*x (src/solvers.f90:58-59): bands in ascending column order, then the tail.
+// ZM: band 0 / 3 / 6 (offsets -kdz, 0, +kdz) come from / go to the registers `z`.
+template <int FMT, bool ZM>
 __device__ __forceinline__ void spmv_pair(const MatView &A, const double *tbl, const double *__restrict__ x,
-                                          int64_t r, int64_t tile, double &s0, double &s1)
+                                          int64_t r, int64_t tile, bool first, ZRegs &z, double &s0, double &s1)
 {
     if (FMT == FMT_DIA7) {
         d2 c[7], xv[7];
 #pragma unroll
         for (int b = 0; b < 7; ++b) c[b] = *reinterpret_cast<const d2 *>(A.band[b] + r);
 #pragma unroll
-        for (int b = 0; b < 7; ++b) xv[b] = *reinterpret_cast<const d2u *>(x + r + A.off[b]);
+        for (int b = 0; b < 7; ++b)
+            if (!ZM || (b != 0 && b != 3) || first) xv[b] = *reinterpret_cast<const d2u *>(x + r + A.off[b]);
+        if (ZM) {
+            if (!first) { xv[0] = z.xm; xv[3] = z.xc; }
+            z.xm = xv[3];
+            z.xc = xv[6];
+        }
         s0 = c[0].x * xv[0].x;
         s1 = c[0].y * xv[0].y;
 #pragma unroll
@@ -150,10 +170,16 @@ __device__ __forceinline__ void spmv_pair(const MatView &A, const double *tbl, c
             s1 = s1 + c[b].y * xv[b].y;
         }
     } else if (FMT == FMT_DICT7) {
-        d2u xv[7];
+        d2 xv[7];
         const unsigned short cc = *reinterpret_cast<const unsigned short *>(A.cls + r);
 #pragma unroll
-        for (int b = 0; b < 7; ++b) xv[b] = *reinterpret_cast<const d2u *>(x + r + A.off[b]);
+        for (int b = 0; b < 7; ++b)
+            if (!ZM || (b != 0 && b != 3) || first) xv[b] = *reinterpret_cast<const d2u *>(x + r + A.off[b]);
+        if (ZM) {
+            if (!first) { xv[0] = z.xm; xv[3] = z.xc; }
+            z.xm = xv[3];
+            z.xc = xv[6];
+        }
         const double *t0 = tbl + (cc & 0xFF) * 7, *t1 = tbl + (cc >> 8) * 7;
         s0 = t0[0] * xv[0].x;
         s1 = t1[0] * xv[0].y;
@@ -183,27 +209,30 @@ __device__ __forceinline__ void spmv_pair(const MatView &A, const double *tbl, c
     for (int64_t it_ = 0;; ++it_) {                                                            \
         const int64_t tile = ec3d_tile_of(sw, blockIdx.x, it_);                                \
         if (tile >= sw.ntiles) break;                                                          \
+        const bool first_ = it_ == 0;                                                          \
+        (void)first_;                                                                          \
         const int64_t r = tile * EC3D_TILE + 2 * (int64_t)threadIdx.x;
 #define EC3D_SWEEP_END }
 #define EC3D_TBL_DECL __shared__ double tbl[FMT == FMT_DICT7 ? EC3D_TBL_DOUBLES : 1]
 
 // ---------------------------------------------------------------------------------------------
 // plain y = A x  (src/solvers.f90:54-61)
-template <int FMT, bool NT>
+template <int FMT, bool NT, bool ZM>
 __global__ __launch_bounds__(EC3D_THREADS) void k_spmv(MatView A, Sweep sw, const double *__restrict__ x,
                                                        double *__restrict__ y)
 {
     EC3D_TBL_DECL;
     stage_table<FMT>(A, tbl);
+    ZRegs zr;
     EC3D_SWEEP_BEGIN
     double s0, s1;
-    spmv_pair<FMT>(A, tbl, x, r, tile, s0, s1);
+    spmv_pair<FMT, ZM>(A, tbl, x, r, tile, first_, zr, s0, s1);
     store2<NT>(y, r, sw.n, s0, s1);
     EC3D_SWEEP_END
 }
 
 // setup: R = B - A X ; R0 = R ; P = R ; partials of B·B and R·R   (src/solvers.f90:14-21)
-template <int FMT, bool NT>
+template <int FMT, bool NT, bool ZM>
 __global__ __launch_bounds__(EC3D_THREADS) void k_residual(MatView A, Sweep sw, const double *__restrict__ x,
                                                            const double *__restrict__ b, double *__restrict__ rv,
                                                            double *__restrict__ r0, double *__restrict__ p,
@@ -212,10 +241,11 @@ __global__ __launch_bounds__(EC3D_THREADS) void k_residual(MatView A, Sweep sw, 
     __shared__ double lds[8];
     EC3D_TBL_DECL;
     stage_table<FMT>(A, tbl);
+    ZRegs zr;
     double acc[2] = {0.0, 0.0};
     EC3D_SWEEP_BEGIN
     double s0, s1;
-    spmv_pair<FMT>(A, tbl, x, r, tile, s0, s1);
+    spmv_pair<FMT, ZM>(A, tbl, x, r, tile, first_, zr, s0, s1);
     d2 bv = load2<NT>(b + r);
     double e0 = bv.x - s0, e1 = bv.y - s1, b0 = bv.x, b1 = bv.y;
     store2<NT>(rv, r, sw.n, e0, e1);
@@ -230,17 +260,16 @@ __global__ __launch_bounds__(EC3D_THREADS) void k_residual(MatView A, Sweep sw, 
     EC3D_SWEEP_END
     block_sum<2>(acc, lds);
     if (threadIdx.x == 0) {
-        part[P_BB * sw.nblk + blockIdx.x] = acc[0];
-        part[P_RR_INIT * sw.nblk + blockIdx.x] = acc[1];
+        part[P_BB * sw.pstride + blockIdx.x] = acc[0];
+        part[P_RR_INIT * sw.pstride + blockIdx.x] = acc[1];
     }
 }
 
 // multi-rank only: collapse this rank's per-workgroup partials of the slots in `mask` into lsum[slot]
 // (same tree as reduce_partials), ready for the all_gather
-__global__ __launch_bounds__(EC3D_THREADS) void k_finalize(const double *part, int nblk, double *lsum, unsigned mask)
+__global__ __launch_bounds__(EC3D_THREADS) void k_finalize(RedSrc src, double *lsum, unsigned mask)
 {
     __shared__ double lds[4];
-    const RedSrc src{part, nblk, 1, nblk};
     for (int sl = 0; sl < P_NSLOT; ++sl) {
         if (!(mask & (1u << sl))) continue;
         const int slot[1] = {sl};
@@ -271,7 +300,7 @@ __global__ __launch_bounds__(EC3D_THREADS) void k_setup(SolverState *st, RedSrc 
 }
 
 // K1: AP = A P ; partial AP·R0    (src/solvers.f90:30, :32 denominator)
-template <int FMT, bool NT>
+template <int FMT, bool NT, bool ZM>
 __global__ __launch_bounds__(EC3D_THREADS) void k1_spmv_dot(MatView A, Sweep sw, const SolverState *st, int it,
                                                             const double *__restrict__ p,
                                                             const double *__restrict__ r0,
@@ -281,10 +310,11 @@ __global__ __launch_bounds__(EC3D_THREADS) void k1_spmv_dot(MatView A, Sweep sw,
     EC3D_TBL_DECL;
     if (st->stop_iter < it) return;
     stage_table<FMT>(A, tbl);
+    ZRegs zr;
     double acc[1] = {0.0};
     EC3D_SWEEP_BEGIN
     double s0, s1;
-    spmv_pair<FMT>(A, tbl, p, r, tile, s0, s1);
+    spmv_pair<FMT, ZM>(A, tbl, p, r, tile, first_, zr, s0, s1);
     d2 q = load2<NT>(r0 + r);
     store2<NT>(ap, r, sw.n, s0, s1);
     EC3D_MASK2(r, sw.n, s0, s1);
@@ -292,7 +322,7 @@ __global__ __launch_bounds__(EC3D_THREADS) void k1_spmv_dot(MatView A, Sweep sw,
     acc[0] = acc[0] + s1 * q.y;
     EC3D_SWEEP_END
     block_sum<1>(acc, lds);
-    if (threadIdx.x == 0) part[P_D1 * sw.nblk + blockIdx.x] = acc[0];
+    if (threadIdx.x == 0) part[P_D1 * sw.pstride + blockIdx.x] = acc[0];
 }
 
 // K2: alpha = rr0 / (AP·R0) ; S = R - alpha*AP ; partial S·S   (src/solvers.f90:31-34)
@@ -320,12 +350,12 @@ __global__ __launch_bounds__(EC3D_THREADS) void k2_s_update(Sweep sw, RedSrc src
     acc[0] = acc[0] + s1 * s1;
     EC3D_SWEEP_END
     block_sum<1>(acc, lds);
-    if (threadIdx.x == 0) part[P_SS * sw.nblk + blockIdx.x] = acc[0];
+    if (threadIdx.x == 0) part[P_SS * sw.pstride + blockIdx.x] = acc[0];
 }
 
 // K3: if ‖S‖/Bnorm < tol: X += alpha*P, exit (src/solvers.f90:34-38)
 //     else AS = A S ; partials AS·S and AS·AS (:39-40)
-template <int FMT, bool NT>
+template <int FMT, bool NT, bool ZM>
 __global__ __launch_bounds__(EC3D_THREADS) void k3_spmv_dots(MatView A, Sweep sw, RedSrc src, SolverState *st,
                                                              int it, const double *__restrict__ sv,
                                                              const double *__restrict__ p, double *__restrict__ x,
@@ -354,10 +384,11 @@ __global__ __launch_bounds__(EC3D_THREADS) void k3_spmv_dots(MatView A, Sweep sw
         return;
     }
     stage_table<FMT>(A, tbl);
+    ZRegs zr;
     double acc[2] = {0.0, 0.0};
     EC3D_SWEEP_BEGIN
     double s0, s1;
-    spmv_pair<FMT>(A, tbl, sv, r, tile, s0, s1);
+    spmv_pair<FMT, ZM>(A, tbl, sv, r, tile, first_, zr, s0, s1);
     d2 q = *reinterpret_cast<const d2 *>(sv + r);
     store2<NT>(as, r, sw.n, s0, s1);
     EC3D_MASK2(r, sw.n, s0, s1);
@@ -368,8 +399,8 @@ __global__ __launch_bounds__(EC3D_THREADS) void k3_spmv_dots(MatView A, Sweep sw
     EC3D_SWEEP_END
     block_sum<2>(acc, lds);
     if (threadIdx.x == 0) {
-        part[P_D2 * sw.nblk + blockIdx.x] = acc[0];
-        part[P_D3 * sw.nblk + blockIdx.x] = acc[1];
+        part[P_D2 * sw.pstride + blockIdx.x] = acc[0];
+        part[P_D3 * sw.pstride + blockIdx.x] = acc[1];
     }
 }
 
@@ -409,8 +440,8 @@ __global__ __launch_bounds__(EC3D_THREADS) void k4_x_r_update(Sweep sw, RedSrc s
     EC3D_SWEEP_END
     block_sum<2>(acc, lds);
     if (threadIdx.x == 0) {
-        part[P_RR * sw.nblk + blockIdx.x] = acc[0];
-        part[P_RR0N * sw.nblk + blockIdx.x] = acc[1];
+        part[P_RR * sw.pstride + blockIdx.x] = acc[0];
+        part[P_RR0N * sw.pstride + blockIdx.x] = acc[1];
     }
 }
 
@@ -469,10 +500,15 @@ static inline int fmt_of(const MatView &A)
 static inline bool nt_of(const Sweep &sw) { return sw.nt != 0; }
 #define EC3D_LAUNCH_FMT(F, KERNEL, ...)                                                        \
     do {                                                                                       \
-        if (nt_of(sw))                                                                         \
-            KERNEL<F, true><<<sw.nblk, EC3D_THREADS, 0, s>>>(__VA_ARGS__);                     \
+        const bool zm_ = sw.zm_tpp > 0 && F != FMT_GENERIC;                                    \
+        if (nt_of(sw) && zm_)                                                                  \
+            KERNEL<F, true, (F != FMT_GENERIC)><<<sw.nblk, EC3D_THREADS, 0, s>>>(__VA_ARGS__); \
+        else if (nt_of(sw))                                                                    \
+            KERNEL<F, true, false><<<sw.nblk, EC3D_THREADS, 0, s>>>(__VA_ARGS__);              \
+        else if (zm_)                                                                          \
+            KERNEL<F, false, (F != FMT_GENERIC)><<<sw.nblk, EC3D_THREADS, 0, s>>>(__VA_ARGS__);\
         else                                                                                   \
-            KERNEL<F, false><<<sw.nblk, EC3D_THREADS, 0, s>>>(__VA_ARGS__);                    \
+            KERNEL<F, false, false><<<sw.nblk, EC3D_THREADS, 0, s>>>(__VA_ARGS__);             \
     } while (0)
 #define EC3D_DISPATCH(A, KERNEL, ...)                                                          \
     do {                                                                                       \
@@ -501,9 +537,9 @@ void ec3d_launch_residual(const MatView &A, const Sweep &sw, const double *x, co
     EC3D_DISPATCH(A, k_residual, A, sw, x, b, r, r0, p, part);
 }
 
-void ec3d_launch_finalize(const double *part, int nblk, double *lsum, unsigned mask, hipStream_t s)
+void ec3d_launch_finalize(const RedSrc &src, double *lsum, unsigned mask, hipStream_t s)
 {
-    k_finalize<<<1, EC3D_THREADS, 0, s>>>(part, nblk, lsum, mask);
+    k_finalize<<<1, EC3D_THREADS, 0, s>>>(src, lsum, mask);
 }
 
 void ec3d_launch_setup(SolverState *st, const RedSrc &src, double tol, hipStream_t s)

@@ -117,9 +117,13 @@ extern "C" int ec3d_destroy(ec3d_handle c)
     return 0;
 }
 
+// Launch geometry.  Vector kernels (K2, K4, K5): plain XCD-aware grid stride over 512-row tiles.
+// SpMV kernels: the same, or -- when a plane of the grid is a whole number of tiles -- the z-marching
+// map (one xy position per workgroup, consecutive planes per step; ec3d_tile_of in ec3d_kernels.hip).
 static void choose_sweep(ec3d_ctx *c)
 {
     Sweep &sw = c->sweep;
+    sw = Sweep{0, 0, 0, 0, 0, 0, 0, 0};
     sw.ntiles = c->A.n_pad / EC3D_TILE;
     sw.n = c->A.n;
     // 256 CUs x 3 workgroups: measured best on 512^3 (whole multiples of the CU count matter;
@@ -136,6 +140,25 @@ static void choose_sweep(ec3d_ctx *c)
         if (atoi(e) == 0) sw.S = 0;
     sw.nblk = (int)nblk;
     sw.nt = c->nt_request >= 0 ? c->nt_request : (c->A.n_pad >= (4 << 20));
+
+    Sweep &ss = c->sweep_s;
+    ss = sw;
+    const DevMatrix &A = c->A;
+    int zm = c->zm_request;
+    if (const char *e = getenv("EC3D_ZMARCH")) zm = atoi(e);
+    if (zm != 0 && A.nb == 7 && A.off[3] == 0 && A.off[0] == -A.off[6] && A.off[6] % EC3D_TILE == 0) {
+        const int64_t tpp = A.off[6] / EC3D_TILE;
+        const int64_t nplanes = (sw.ntiles + tpp - 1) / tpp;
+        if (tpp % 8 == 0 && tpp <= 4096 && nplanes >= 8) {
+            int64_t nseg = std::max<int64_t>(1, (want + tpp / 2) / tpp);
+            nseg = std::min<int64_t>(nseg, std::max<int64_t>(1, nplanes / 8));
+            ss.zm_tpp = (int)tpp;
+            ss.zm_pps = (int)((nplanes + nseg - 1) / nseg);
+            ss.nblk = (int)(tpp * nseg);
+            ss.S = 0;
+        }
+    }
+    sw.pstride = ss.pstride = std::max(sw.nblk, ss.nblk);
 }
 
 // vectors: [ghost | n_pad | ghost] doubles each, zero filled; kernels only ever write [0, n_pad)
@@ -152,8 +175,8 @@ int ec3d_prepare_vectors(ec3d_ctx *c)
     EC3D_HIP(hipMemsetAsync(c->vec_base, 0, (size_t)len * EC3D_NVEC * sizeof(double), c->stream));
     for (int v = 0; v < EC3D_NVEC; ++v) c->vec[v] = c->vec_base + (size_t)v * len + c->ghost;
     choose_sweep(c);
-    EC3D_HIP(hipMalloc(&c->partials, (size_t)P_NSLOT * c->sweep.nblk * sizeof(double)));
-    EC3D_HIP(hipMemsetAsync(c->partials, 0, (size_t)P_NSLOT * c->sweep.nblk * sizeof(double), c->stream));
+    EC3D_HIP(hipMalloc(&c->partials, (size_t)P_NSLOT * c->sweep.pstride * sizeof(double)));
+    EC3D_HIP(hipMemsetAsync(c->partials, 0, (size_t)P_NSLOT * c->sweep.pstride * sizeof(double), c->stream));
     EC3D_HIP(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -166,8 +189,8 @@ extern "C" int ec3d_set_workgroups(ec3d_handle c, int32_t nblk)
         // partial buffer depends on nblk; vectors are kept
         choose_sweep(c);
         if (c->partials) (void)hipFree(c->partials);
-        EC3D_HIP(hipMalloc(&c->partials, (size_t)P_NSLOT * c->sweep.nblk * sizeof(double)));
-        EC3D_HIP(hipMemset(c->partials, 0, (size_t)P_NSLOT * c->sweep.nblk * sizeof(double)));
+        EC3D_HIP(hipMalloc(&c->partials, (size_t)P_NSLOT * c->sweep.pstride * sizeof(double)));
+        EC3D_HIP(hipMemset(c->partials, 0, (size_t)P_NSLOT * c->sweep.pstride * sizeof(double)));
     }
     return 0;
 }
@@ -345,15 +368,25 @@ extern "C" int ec3d_get_cel_bnd(ec3d_handle c, int which, int32_t *count, int32_
     return 0;
 }
 
-extern "C" int ec3d_get_reduction_geometry(ec3d_handle c, ec3d_geom *g)
+extern "C" int ec3d_get_reduction_geometry(ec3d_handle c, int which, ec3d_geom *g)
 {
     int rc = need_matrix(c, "ec3d_get_reduction_geometry");
     if (rc) return rc;
+    const Sweep &sw = which == 1 ? c->sweep_s : c->sweep;
     g->n_pad = (int32_t)c->A.n_pad;
     g->tile = EC3D_TILE;
-    g->nblk = c->sweep.nblk;
+    g->nblk = sw.nblk;
     g->threads = EC3D_THREADS;
-    g->xcd_group = c->sweep.S;
+    g->xcd_group = sw.S;
+    g->zm_tpp = sw.zm_tpp;
+    g->zm_pps = sw.zm_pps;
+    return 0;
+}
+
+extern "C" int ec3d_set_zmarch(ec3d_handle c, int on)
+{
+    c->zm_request = on;
+    if (c->have_matrix) return ec3d_set_workgroups(c, c->nblk_request);
     return 0;
 }
 
@@ -417,7 +450,7 @@ extern "C" int ec3d_spmv(ec3d_handle c, const double *x, double *y)
     if (rc) return rc;
     // P and AP serve as scratch
     EC3D_HIP(hipMemcpyAsync(c->vec[EC3D_VEC_P], x, (size_t)c->A.n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    ec3d_launch_spmv(c->A.view(), c->sweep, c->vec[EC3D_VEC_P], c->vec[EC3D_VEC_AP], c->stream);
+    ec3d_launch_spmv(c->A.view(), c->sweep_s, c->vec[EC3D_VEC_P], c->vec[EC3D_VEC_AP], c->stream);
     EC3D_HIP(hipGetLastError());
     EC3D_HIP(hipMemcpyAsync(y, c->vec[EC3D_VEC_AP], (size_t)c->A.n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     EC3D_HIP(hipStreamSynchronize(c->stream));
@@ -425,38 +458,48 @@ extern "C" int ec3d_spmv(ec3d_handle c, const double *x, double *y)
 }
 
 // ---------------------------------------------------------------------------------------------
-static RedSrc local_src(const ec3d_ctx *c) { return RedSrc{c->partials, c->sweep.nblk, 1, c->sweep.nblk}; }
-static RedSrc dist_src(const ec3d_ctx *c) { return RedSrc{c->gsum, c->nranks, P_NSLOT, 1}; }
-
-// the five launches of one iteration; `k` selects one of them (1..5) or all (0)
-static void launch_stage(ec3d_ctx *c, const MatView &A, const RedSrc &src, int it, int k)
+// Where a consumer finds the sums it needs.  Single GPU: the producer's per-workgroup partials; the
+// producers of slots BB, RR_INIT, D1, D2, D3 are SpMV-type kernels (sweep_s), those of SS, RR, RR0N
+// vector kernels (sweep) -- every consumer reads slots of one producer class only.
+static RedSrc src_of(const ec3d_ctx *c, bool produced_by_spmv)
 {
-    double **v = c->vec;
-    const Sweep &sw = c->sweep;
-    hipStream_t s = c->stream;
-    if (k == 0 || k == 1)
-        ec3d_launch_k1(A, sw, c->state, it, v[EC3D_VEC_P], v[EC3D_VEC_R0], v[EC3D_VEC_AP], c->partials, s);
-    if (k == 0 || k == 2)
-        ec3d_launch_k2(sw, src, c->state, it, v[EC3D_VEC_R], v[EC3D_VEC_AP], v[EC3D_VEC_S], c->partials, s);
-    if (k == 0 || k == 3)
-        ec3d_launch_k3(A, sw, src, c->state, it, v[EC3D_VEC_S], v[EC3D_VEC_P], v[EC3D_VEC_X], v[EC3D_VEC_AS],
-                       c->partials, c->hist, c->hist_cap, s);
-    if (k == 0 || k == 4)
-        ec3d_launch_k4(sw, src, c->state, it, v[EC3D_VEC_P], v[EC3D_VEC_S], v[EC3D_VEC_AS], v[EC3D_VEC_R0],
-                       v[EC3D_VEC_X], v[EC3D_VEC_R], c->partials, s);
-    if (k == 0 || k == 5)
-        ec3d_launch_k5(sw, src, c->state, it, v[EC3D_VEC_R], v[EC3D_VEC_AP], v[EC3D_VEC_P], v[EC3D_VEC_R0], c->hist,
-                       c->hist_cap, s);
+    if (c->dist) return RedSrc{c->gsum, c->nranks, P_NSLOT, 1};
+    return RedSrc{c->partials, produced_by_spmv ? c->sweep_s.nblk : c->sweep.nblk, 1, c->sweep.pstride};
+}
+static RedSrc part_of(const ec3d_ctx *c, bool produced_by_spmv)
+{
+    return RedSrc{c->partials, produced_by_spmv ? c->sweep_s.nblk : c->sweep.nblk, 1, c->sweep.pstride};
 }
 
-static void launch_iteration(ec3d_ctx *c, const MatView &A, int it) { launch_stage(c, A, local_src(c), it, 0); }
+// the five launches of one iteration; `k` selects one of them (1..5) or all (0)
+static void launch_stage(ec3d_ctx *c, const MatView &A, int it, int k)
+{
+    double **v = c->vec;
+    const Sweep &sw = c->sweep, &ss = c->sweep_s;
+    hipStream_t s = c->stream;
+    if (k == 0 || k == 1)
+        ec3d_launch_k1(A, ss, c->state, it, v[EC3D_VEC_P], v[EC3D_VEC_R0], v[EC3D_VEC_AP], c->partials, s);
+    if (k == 0 || k == 2)
+        ec3d_launch_k2(sw, src_of(c, true), c->state, it, v[EC3D_VEC_R], v[EC3D_VEC_AP], v[EC3D_VEC_S], c->partials, s);
+    if (k == 0 || k == 3)
+        ec3d_launch_k3(A, ss, src_of(c, false), c->state, it, v[EC3D_VEC_S], v[EC3D_VEC_P], v[EC3D_VEC_X],
+                       v[EC3D_VEC_AS], c->partials, c->hist, c->hist_cap, s);
+    if (k == 0 || k == 4)
+        ec3d_launch_k4(sw, src_of(c, true), c->state, it, v[EC3D_VEC_P], v[EC3D_VEC_S], v[EC3D_VEC_AS], v[EC3D_VEC_R0],
+                       v[EC3D_VEC_X], v[EC3D_VEC_R], c->partials, s);
+    if (k == 0 || k == 5)
+        ec3d_launch_k5(sw, src_of(c, false), c->state, it, v[EC3D_VEC_R], v[EC3D_VEC_AP], v[EC3D_VEC_P],
+                       v[EC3D_VEC_R0], c->hist, c->hist_cap, s);
+}
+
+static void launch_iteration(ec3d_ctx *c, const MatView &A, int it) { launch_stage(c, A, it, 0); }
 
 static int launch_setup(ec3d_ctx *c, const MatView &A, double tol)
 {
     double **v = c->vec;
-    ec3d_launch_residual(A, c->sweep, v[EC3D_VEC_X], v[EC3D_VEC_B], v[EC3D_VEC_R], v[EC3D_VEC_R0], v[EC3D_VEC_P],
+    ec3d_launch_residual(A, c->sweep_s, v[EC3D_VEC_X], v[EC3D_VEC_B], v[EC3D_VEC_R], v[EC3D_VEC_R0], v[EC3D_VEC_P],
                          c->partials, c->stream);
-    ec3d_launch_setup(c->state, local_src(c), tol, c->stream);
+    ec3d_launch_setup(c->state, src_of(c, true), tol, c->stream);
     EC3D_HIP(hipGetLastError());
     return 0;
 }
@@ -522,16 +565,16 @@ static int solve_core(ec3d_ctx *c, double tol, int32_t itmax, int32_t *iter, dou
         *iter = (int32_t)total; // itmax exit: the reference prints norm2(R) and returns (:25-28)
         if (print_on_itmax) {
             // ‖R‖ = sqrt(sum of the last K4 partials), summed here in workgroup order
-            std::vector<double> part((size_t)c->sweep.nblk);
-            EC3D_HIP(hipMemcpy(part.data(), c->partials + (size_t)P_RR * c->sweep.nblk,
+            std::vector<double> part((size_t)c->sweep.pstride);
+            EC3D_HIP(hipMemcpy(part.data(), c->partials + (size_t)P_RR * c->sweep.pstride,
                                part.size() * sizeof(double), hipMemcpyDeviceToHost));
             double s = 0.0;
-            for (double p : part) s += p;
+            for (int q = 0; q < c->sweep.nblk; ++q) s += part[(size_t)q];
             if (total == 0) {
-                EC3D_HIP(hipMemcpy(part.data(), c->partials + (size_t)P_RR_INIT * c->sweep.nblk,
+                EC3D_HIP(hipMemcpy(part.data(), c->partials + (size_t)P_RR_INIT * c->sweep.pstride,
                                    part.size() * sizeof(double), hipMemcpyDeviceToHost));
                 s = 0.0;
-                for (double p : part) s += p;
+                for (int q = 0; q < c->sweep_s.nblk; ++q) s += part[(size_t)q];
             }
             printf(" %.17g\n", std::sqrt(s));
             fflush(stdout);
@@ -610,13 +653,12 @@ extern "C" int ec3d_iterate(ec3d_handle c, int32_t first_iter, int32_t count, do
     std::vector<hipEvent_t> ev((size_t)count * 6);
     for (auto &e : ev) EC3D_HIP(hipEventCreate(&e));
     hipStream_t s = c->stream;
-    const RedSrc src = local_src(c);
     for (int i = 0; i < count; ++i) {
         const int it = first_iter + i;
         hipEvent_t *e = &ev[(size_t)i * 6];
         EC3D_HIP(hipEventRecord(e[0], s));
         for (int k = 1; k <= 5; ++k) {
-            launch_stage(c, A, src, it, k);
+            launch_stage(c, A, it, k);
             EC3D_HIP(hipEventRecord(e[k], s));
         }
     }
@@ -639,17 +681,15 @@ extern "C" int ec3d_time_kernel(ec3d_handle c, int kernel, int32_t reps, double 
     if (rc) return rc;
     const MatView A = c->A.view();
     double **v = c->vec;
-    const Sweep &sw = c->sweep;
     hipStream_t s = c->stream;
     c->hist_cap = 0;
     if ((rc = launch_setup(c, A, -1.0))) return rc;
     launch_iteration(c, A, 1); // populate every partial slot and the scalars
-    const RedSrc src = local_src(c);
     auto one = [&]() {
         if (kernel == EC3D_K_SPMV)
-            ec3d_launch_spmv(A, sw, v[EC3D_VEC_P], v[EC3D_VEC_AP], s);
+            ec3d_launch_spmv(A, c->sweep_s, v[EC3D_VEC_P], v[EC3D_VEC_AP], s);
         else
-            launch_stage(c, A, src, 2, kernel);
+            launch_stage(c, A, 2, kernel);
     };
     one(); // warm
     EC3D_HIP(hipEventRecord(c->t0, s));
@@ -714,22 +754,23 @@ extern "C" int ec3d_dist_step(ec3d_handle c, int32_t stage, int32_t it, double t
         return 3;
     }
     const MatView A = c->A.view();
-    const RedSrc src = dist_src(c);
     double **v = c->vec;
-    auto fin = [&](unsigned mask) { ec3d_launch_finalize(c->partials, c->sweep.nblk, c->lsum, mask, c->stream); };
+    auto fin = [&](bool spmv_producer, unsigned mask) {
+        ec3d_launch_finalize(part_of(c, spmv_producer), c->lsum, mask, c->stream);
+    };
     switch (stage) {
     case EC3D_STAGE_RESID:
         c->hist_cap = 0;
-        ec3d_launch_residual(A, c->sweep, v[EC3D_VEC_X], v[EC3D_VEC_B], v[EC3D_VEC_R], v[EC3D_VEC_R0], v[EC3D_VEC_P],
-                             c->partials, c->stream);
-        fin(1u << P_BB | 1u << P_RR_INIT);
+        ec3d_launch_residual(A, c->sweep_s, v[EC3D_VEC_X], v[EC3D_VEC_B], v[EC3D_VEC_R], v[EC3D_VEC_R0],
+                             v[EC3D_VEC_P], c->partials, c->stream);
+        fin(true, 1u << P_BB | 1u << P_RR_INIT);
         break;
-    case EC3D_STAGE_SETUP: ec3d_launch_setup(c->state, src, tolerance, c->stream); break;
-    case EC3D_STAGE_K1: launch_stage(c, A, src, it, 1); fin(1u << P_D1); break;
-    case EC3D_STAGE_K2: launch_stage(c, A, src, it, 2); fin(1u << P_SS); break;
-    case EC3D_STAGE_K3: launch_stage(c, A, src, it, 3); fin(1u << P_D2 | 1u << P_D3); break;
-    case EC3D_STAGE_K4: launch_stage(c, A, src, it, 4); fin(1u << P_RR | 1u << P_RR0N); break;
-    case EC3D_STAGE_K5: launch_stage(c, A, src, it, 5); break;
+    case EC3D_STAGE_SETUP: ec3d_launch_setup(c->state, src_of(c, true), tolerance, c->stream); break;
+    case EC3D_STAGE_K1: launch_stage(c, A, it, 1); fin(true, 1u << P_D1); break;
+    case EC3D_STAGE_K2: launch_stage(c, A, it, 2); fin(false, 1u << P_SS); break;
+    case EC3D_STAGE_K3: launch_stage(c, A, it, 3); fin(true, 1u << P_D2 | 1u << P_D3); break;
+    case EC3D_STAGE_K4: launch_stage(c, A, it, 4); fin(false, 1u << P_RR | 1u << P_RR0N); break;
+    case EC3D_STAGE_K5: launch_stage(c, A, it, 5); break;
     default: ec3d_set_error("ec3d_dist_step: unknown stage"); return 2;
     }
     EC3D_HIP(hipGetLastError());

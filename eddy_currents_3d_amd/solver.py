@@ -28,7 +28,8 @@ class EC3DError(RuntimeError):
 
 class Geom(C.Structure):
     _fields_ = [("n_pad", C.c_int32), ("tile", C.c_int32), ("nblk", C.c_int32),
-                ("threads", C.c_int32), ("xcd_group", C.c_int32)]
+                ("threads", C.c_int32), ("xcd_group", C.c_int32), ("zm_tpp", C.c_int32),
+                ("zm_pps", C.c_int32)]
 
 
 class MatrixInfo(C.Structure):
@@ -50,7 +51,7 @@ EXPORTS = ["sprsbcgstabwr_", "ec3d_invalidate", "ec3d_create", "ec3d_destroy", "
            "ec3d_set_workgroups", "ec3d_get_matrix_info", "ec3d_time_kernel", "ec3d_time_iterations",
            "ec3d_iterate_begin", "ec3d_iterate", "ec3d_set_format", "ec3d_set_stream",
            "ec3d_assemble_poisson_slab", "ec3d_vector_layout", "ec3d_adopt_vectors",
-           "ec3d_dist_configure", "ec3d_dist_step", "ec3d_read_state",
+           "ec3d_dist_configure", "ec3d_dist_step", "ec3d_read_state", "ec3d_set_zmarch",
            "ec3d_device_synchronize"]
 
 _f64 = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
@@ -85,7 +86,8 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.ec3d_spmv.argtypes = [hp, _f64, _f64]
     L.ec3d_export_csr.argtypes = [hp, C.POINTER(C.c_int32), C.POINTER(C.c_int64), hp, hp, hp]
     L.ec3d_get_cel_bnd.argtypes = [hp, C.c_int, C.POINTER(C.c_int32), hp]
-    L.ec3d_get_reduction_geometry.argtypes = [hp, C.POINTER(Geom)]
+    L.ec3d_get_reduction_geometry.argtypes = [hp, C.c_int, C.POINTER(Geom)]
+    L.ec3d_set_zmarch.argtypes = [hp, C.c_int]
     L.ec3d_set_workgroups.argtypes = [hp, C.c_int32]
     L.ec3d_get_matrix_info.argtypes = [hp, C.POINTER(MatrixInfo)]
     L.ec3d_time_kernel.argtypes = [hp, C.c_int, C.c_int32, C.POINTER(C.c_double)]
@@ -222,10 +224,14 @@ class EC3DSolver:
     def n(self) -> int:
         return int(self.info.n)
 
-    def geometry(self) -> Geom:
+    def geometry(self, which: int = 0) -> Geom:
+        """Reduction geometry of the vector kernels (which=0) or of the SpMV kernels (which=1)."""
         g = Geom()
-        _chk(self.L, self.L.ec3d_get_reduction_geometry(self.h, C.byref(g)), "ec3d_get_reduction_geometry")
+        _chk(self.L, self.L.ec3d_get_reduction_geometry(self.h, which, C.byref(g)), "ec3d_get_reduction_geometry")
         return g
+
+    def set_zmarch(self, on: bool):
+        _chk(self.L, self.L.ec3d_set_zmarch(self.h, int(bool(on))), "ec3d_set_zmarch")
 
     def set_workgroups(self, nblk: int):
         _chk(self.L, self.L.ec3d_set_workgroups(self.h, int(nblk)), "ec3d_set_workgroups")

@@ -119,7 +119,12 @@ void oracle_sprsbcgstabwr_(const double *valA, const int32_t *irow, const int32_
 int64_t oracle_gpu_tile_of(const oracle_gpu_geom *g, int32_t b, int64_t i)
 {
     int64_t ntiles = g->n_pad / g->tile, t;
-    if (g->xcd_group > 0) {
+    if (g->zm_tpp > 0) { /* z-marching map: ec3d_tile_of, first branch */
+        int64_t cpx = g->zm_tpp / 8, c = b % 8, s = b / 8;
+        int64_t col = c * cpx + s % cpx, seg = s / cpx;
+        if (i >= g->zm_pps) return -1;
+        t = (seg * g->zm_pps + i) * g->zm_tpp + col;
+    } else if (g->xcd_group > 0) {
         int64_t S = g->xcd_group, c = b % 8, s = b / 8;
         t = (i * 8 + c) * S + s;
     } else {
@@ -172,9 +177,9 @@ double oracle_dot_gpuorder(const oracle_gpu_geom *g, const double *a, const doub
     return r;
 }
 
-int oracle_bicgstab_wr_gpuorder(const oracle_gpu_geom *g, const double *valA, const int32_t *irow,
-                                const int32_t *jcol, int32_t n, const double *b, double *x,
-                                double tolerance, int32_t itmax, int32_t *iter, double *hist_s,
+int oracle_bicgstab_wr_gpuorder(const oracle_gpu_geom *gv, const oracle_gpu_geom *gs, const double *valA,
+                                const int32_t *irow, const int32_t *jcol, int32_t n, const double *b,
+                                double *x, double tolerance, int32_t itmax, int32_t *iter, double *hist_s,
                                 double *hist_r, int32_t hist_cap)
 {
     size_t nb = (size_t)(n > 0 ? n : 1) * sizeof(double);
@@ -187,29 +192,30 @@ int oracle_bicgstab_wr_gpuorder(const oracle_gpu_geom *g, const double *valA, co
     for (int32_t j = 0; j < n; ++j) R[j] = b[j] - R[j];
     memcpy(R0, R, nb);
     memcpy(P, R, nb);
-    Bnorm = sqrt(oracle_dot_gpuorder(g, b, b, n));
+    Bnorm = sqrt(oracle_dot_gpuorder(gs, b, b, n));           /* k_residual */
     if (Bnorm == 0.0) goto done;
     for (;;) {
         if (*iter > itmax) { hit_itmax = 1; break; }
         *iter = *iter + 1;
         oracle_spmv_csr(valA, irow, jcol, n, P, AP);
-        rr0 = oracle_dot_gpuorder(g, R, R0, n);
-        alpha = rr0 / oracle_dot_gpuorder(g, AP, R0, n);
+        rr0 = (*iter == 1) ? oracle_dot_gpuorder(gs, R, R0, n)     /* k_residual: R.R */
+                           : oracle_dot_gpuorder(gv, R, R0, n);    /* K4 of the previous iteration */
+        alpha = rr0 / oracle_dot_gpuorder(gs, AP, R0, n);         /* K1 */
         for (int32_t j = 0; j < n; ++j) S[j] = R[j] - alpha * AP[j];
-        nrm = sqrt(oracle_dot_gpuorder(g, S, S, n));
+        nrm = sqrt(oracle_dot_gpuorder(gv, S, S, n));             /* K2 */
         if (hist_s && *iter <= hist_cap) hist_s[*iter - 1] = nrm;
         if (nrm / Bnorm < tolerance) {
             for (int32_t j = 0; j < n; ++j) x[j] = x[j] + alpha * P[j];
             break;
         }
         oracle_spmv_csr(valA, irow, jcol, n, S, AS);
-        omega = oracle_dot_gpuorder(g, AS, S, n) / oracle_dot_gpuorder(g, AS, AS, n);
+        omega = oracle_dot_gpuorder(gs, AS, S, n) / oracle_dot_gpuorder(gs, AS, AS, n); /* K3 */
         for (int32_t j = 0; j < n; ++j) x[j] = (x[j] + alpha * P[j]) + omega * S[j];
         for (int32_t j = 0; j < n; ++j) R[j] = S[j] - omega * AS[j];
-        nrm = sqrt(oracle_dot_gpuorder(g, R, R, n));
+        nrm = sqrt(oracle_dot_gpuorder(gv, R, R, n));             /* K4 */
         if (hist_r && *iter <= hist_cap) hist_r[*iter - 1] = nrm;
         if (nrm / Bnorm < tolerance) break;
-        rr0_new = oracle_dot_gpuorder(g, R, R0, n);
+        rr0_new = oracle_dot_gpuorder(gv, R, R0, n);              /* K4 */
         beta = (alpha / omega) * rr0_new / rr0;
         for (int32_t j = 0; j < n; ++j) P[j] = R[j] + beta * (P[j] - omega * AP[j]);
         if (fabs(rr0_new) / Bnorm < tolerance) {

@@ -31,7 +31,8 @@ _i8p = np.ctypeslib.ndpointer(np.int8, flags="C_CONTIGUOUS")
 class GpuGeom(C.Structure):
     """Reduction geometry of the HIP kernels (ec3d_get_reduction_geometry)."""
     _fields_ = [("n_pad", C.c_int32), ("tile", C.c_int32), ("nblk", C.c_int32),
-                ("threads", C.c_int32), ("xcd_group", C.c_int32)]
+                ("threads", C.c_int32), ("xcd_group", C.c_int32), ("zm_tpp", C.c_int32),
+                ("zm_pps", C.c_int32)]
 
 
 def build(with_ref: bool = True) -> None:
@@ -63,7 +64,7 @@ def lib() -> C.CDLL:
         L.oracle_bicgstab_wr.restype = C.c_int
         L.oracle_dot_gpuorder.argtypes = [C.POINTER(GpuGeom), _f64p, _f64p, C.c_int64]
         L.oracle_dot_gpuorder.restype = C.c_double
-        L.oracle_bicgstab_wr_gpuorder.argtypes = [C.POINTER(GpuGeom), _f64p, _i32p, _i32p, C.c_int32,
+        L.oracle_bicgstab_wr_gpuorder.argtypes = [C.POINTER(GpuGeom), C.POINTER(GpuGeom), _f64p, _i32p, _i32p, C.c_int32,
                                                   _f64p, _f64p, C.c_double, C.c_int32,
                                                   C.POINTER(C.c_int32), C.c_void_p, C.c_void_p,
                                                   C.c_int32]
@@ -113,13 +114,25 @@ def bicgstab_wr(valA, irow, jcol, b, x0, tol, itmax, hist_cap=0):
     return x, it.value, hs, hr
 
 
+def geoms_of(solver):
+    """(vector-kernel geometry, SpMV-kernel geometry) of an eddy_currents_3d_amd.EC3DSolver."""
+    out = []
+    for which in (0, 1):
+        g = solver.geometry(which)
+        out.append(GpuGeom(n_pad=g.n_pad, tile=g.tile, nblk=g.nblk, threads=g.threads, xcd_group=g.xcd_group,
+                           zm_tpp=g.zm_tpp, zm_pps=g.zm_pps))
+    return tuple(out)
+
+
 def bicgstab_wr_gpuorder(geom, valA, irow, jcol, b, x0, tol, itmax, hist_cap=0):
-    """Same algorithm with the HIP kernels' summation order.  geom: GpuGeom."""
+    """Same algorithm with the HIP kernels' summation order.  geom: (vector GpuGeom, SpMV GpuGeom)
+    as returned by geoms_of(), or one GpuGeom used for both."""
+    gv, gs = geom if isinstance(geom, tuple) else (geom, geom)
     n = len(irow) - 1
     x = np.array(x0, dtype=np.float64, copy=True)
     it = C.c_int32(0)
     hs, hr = _hist(hist_cap)
-    lib().oracle_bicgstab_wr_gpuorder(C.byref(geom), valA, irow, jcol, n,
+    lib().oracle_bicgstab_wr_gpuorder(C.byref(gv), C.byref(gs), valA, irow, jcol, n,
                                       np.ascontiguousarray(b, np.float64), x, tol, itmax,
                                       C.byref(it), hs.ctypes.data, hr.ctypes.data, hist_cap)
     return x, it.value, hs, hr

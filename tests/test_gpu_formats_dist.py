@@ -134,3 +134,53 @@ def test_slab_handle_refuses_whole_solve(E):
         s.assemble_poisson(16, 16, 16, slab=(4, 8))
         with pytest.raises(E.EC3DError, match="z-slab"):
             s.solve(np.zeros(4 * 256), np.zeros(4 * 256), 1e-6, 10)
+
+
+# ------------------------------------------------------------------------------ z-marching map
+@pytest.mark.parametrize("dims", [(64, 64, 24), (128, 32, 16)])
+@pytest.mark.parametrize("dic", [False, True])
+def test_zmarch_spmv_and_solve_bitwise(E, oracle, dims, dic):
+    """Grids whose xy-plane is a whole number of 512-row tiles use the z-marching SpMV map (x of the
+    planes below/at the row carried in registers).  Same products, same row-sum order: SpMV bit-identical
+    to the oracle; the solve bit-identical to the oracle's twin run with the two launch geometries."""
+    sdx, sdy, sdz = dims
+    valA, irow, jcol = oracle.poisson_csr(sdx, sdy, sdz)
+    n = sdx * sdy * sdz
+    rng = np.random.Generator(np.random.PCG64(21))
+    x = rng.standard_normal(n)
+    b = rng.standard_normal(n)
+    with E.EC3DSolver(dictionary=dic) as s:
+        s.assemble_poisson(sdx, sdy, sdz)
+        gs = s.geometry(1)
+        assert gs.zm_tpp == sdx * sdy // 512 and gs.zm_pps >= 8
+        assert np.array_equal(s.spmv(x), oracle.spmv_csr(valA, irow, jcol, x))
+        xs, it, hist = s.solve(b, np.zeros(n), 1e-9, 5000, hist_cap=64)
+        xo, ito, hs, hr = oracle.bicgstab_wr_gpuorder(oracle.geoms_of(s), valA, irow, jcol, b, np.zeros(n), 1e-9,
+                                                      5000, hist_cap=64)
+        assert it == ito and np.array_equal(xs, xo)
+        k = min(it, 64)
+        assert np.array_equal(hist[:k, 0], hs[:k])
+        s.set_zmarch(False)
+        assert s.geometry(1).zm_tpp == 0
+        assert np.array_equal(s.spmv(x), oracle.spmv_csr(valA, irow, jcol, x))
+        x2, it2, _ = s.solve(b, np.zeros(n), 1e-9, 5000)
+        xo2, ito2, _, _ = oracle.bicgstab_wr_gpuorder(oracle.geoms_of(s), valA, irow, jcol, b, np.zeros(n), 1e-9, 5000)
+        assert it2 == ito2 and np.array_equal(x2, xo2)
+
+
+def test_zmarch_slabs_on_one_gpu(E, oracle):
+    from eddy_currents_3d_amd.dist import HipSlabOps, InProcessSlabs, slab_bounds
+    sdx, sdy, sdz, world, tol = 64, 64, 32, 2, 1e-8
+    valA, irow, jcol = oracle.poisson_csr(sdx, sdy, sdz)
+    b = np.random.Generator(np.random.PCG64(5)).standard_normal(sdx * sdy * sdz)
+    ops = []
+    for r in range(world):
+        k0, k1 = slab_bounds(sdz, r, world)
+        o = HipSlabOps(sdx, sdy, sdz, k0, k1, world)
+        assert o.local.geometry(1).zm_tpp == 8
+        o.set_vector("B", b.reshape(sdz, sdx * sdy)[k0:k1].reshape(-1))
+        ops.append(o)
+    drv = InProcessSlabs(ops)
+    it = drv.solve(tol, 5000)
+    x = drv.x()
+    assert np.linalg.norm(b - oracle.spmv_csr(valA, irow, jcol, x)) / np.linalg.norm(b) < 5 * tol

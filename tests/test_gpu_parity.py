@@ -26,8 +26,6 @@ def E():
     return E
 
 
-def _geom(oracle, g):
-    return oracle.GpuGeom(n_pad=g.n_pad, tile=g.tile, nblk=g.nblk, threads=g.threads, xcd_group=g.xcd_group)
 
 
 # ------------------------------------------------------------------------------------ SpMV
@@ -127,7 +125,7 @@ def test_solve_bitwise_vs_gpu_order_oracle(E, oracle, name):
     tol, itmax = float(g["tol"]), int(g["itmax"])
     with E.EC3DSolver() as s:
         s.set_matrix_csr(g["valA"], g["irow"], g["jcol"])
-        geom = _geom(oracle, s.geometry())
+        geom = oracle.geoms_of(s)
         for k in range(len(g["iters"])):
             x, it, hist = s.solve(g[f"b{k}"], g[f"xin{k}"], tol, itmax, hist_cap=400)
             xo, ito, hs, hr = oracle.bicgstab_wr_gpuorder(geom, g["valA"], g["irow"], g["jcol"], g[f"b{k}"],
@@ -207,7 +205,7 @@ def test_itmax_exit_matches_reference(E, oracle, capfd):
     g = load_golden("g2i_itmax_exit_16x15x14")
     with E.EC3DSolver() as s:
         s.set_matrix_csr(g["valA"], g["irow"], g["jcol"])
-        geom = _geom(oracle, s.geometry())
+        geom = oracle.geoms_of(s)
         x, it, _ = s.solve(g["b0"], g["xin0"], float(g["tol"]), int(g["itmax"]))
         assert it == 26 == int(g["iters"][0])
         xo, ito, _, _ = oracle.bicgstab_wr_gpuorder(geom, g["valA"], g["irow"], g["jcol"], g["b0"], g["xin0"],
@@ -222,7 +220,7 @@ def test_loose_tolerance_takes_the_s_exit(E, oracle):
     g = load_golden("g1_nonconducting_8x7x6")
     with E.EC3DSolver() as s:
         s.set_matrix_csr(g["valA"], g["irow"], g["jcol"])
-        geom = _geom(oracle, s.geometry())
+        geom = oracle.geoms_of(s)
         x, it, hist = s.solve(g["b0"], g["xin0"], 0.9, 100, hist_cap=4)
         xo, ito, hs, _ = oracle.bicgstab_wr_gpuorder(geom, g["valA"], g["irow"], g["jcol"], g["b0"], g["xin0"],
                                                      0.9, 100, hist_cap=4)
@@ -236,7 +234,7 @@ def test_restart_rule_is_exercised(E, oracle):
     tol = 3e-2
     with E.EC3DSolver() as s:
         s.set_matrix_csr(g["valA"], g["irow"], g["jcol"])
-        geom = _geom(oracle, s.geometry())
+        geom = oracle.geoms_of(s)
         x, it, _ = s.solve(g["b0"], g["xin0"], tol, 1000)
         xo, ito, _, _ = oracle.bicgstab_wr_gpuorder(geom, g["valA"], g["irow"], g["jcol"], g["b0"], g["xin0"],
                                                     tol, 1000)
