@@ -494,5 +494,6 @@ int ec3d_assemble_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t sdz, con
     }
     c->have_matrix = true;
     c->sdx = sdx; c->sdy = sdy; c->sdz = sdz;
-    return ec3d_prepare_vectors(c);
+    if ((rc = ec3d_prepare_vectors(c))) return rc;
+    return ec3d_setup_rhs(c, g.nCells, geoPHYS, geoPHYS_C, valPHYS, nsub_glob, dt);
 }

@@ -136,6 +136,17 @@ struct ec3d_ctx {
     std::vector<int32_t> cel_bnd[6];
     // grid of the last native assembly (0 when the matrix came from CSR)
     int32_t sdx = 0, sdy = 0, sdz = 0;
+    // per-step RHS build / post-update on the device (src/EC3D.f90:370-404, :412-433)
+    int64_t n_cond = 0;            // conducting cells (U unknowns), scan order
+    int n_cond_domains = 0;
+    int32_t *cond_cell = nullptr;  // [n_cond] 0-based cell index
+    double *cond_a = nullptr;      // [n_cond] 2*C/dt of the cell's domain (PHYS_C%valdom)
+    int32_t *bnd_list = nullptr;   // the six cel_bnd* lists, 0-based unknown ids, concatenated
+    int64_t bnd_off[7] = {0};
+    double *rhs_tmp = nullptr;     // [3*n_cond] scratch for the moving-source reset
+    int32_t *src_idx = nullptr;    // per-step source scatter staging
+    double *src_val = nullptr;
+    int64_t src_cap = 0;
 };
 
 // partial-sum slots inside ctx->partials (each nblk doubles)
@@ -189,3 +200,7 @@ int ec3d_assemble_poisson_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t 
                                  const double *BND, const double *delta);
 // ec3d_format.cpp / ec3d_solver.hip: dictionary compression of the bands
 int ec3d_build_dictionary_host(HostMatrix &M);
+// ec3d_rhs.hip
+void ec3d_free_rhs(ec3d_ctx *c);
+int ec3d_setup_rhs(ec3d_ctx *c, int64_t nCells, const int8_t *geoPHYS, const int32_t *geoPHYS_C,
+                   const double *valPHYS, int32_t nsub_glob, double dt);

@@ -93,6 +93,7 @@ void ec3d_free_matrix(ec3d_ctx *c)
     if (A.table) (void)hipFree(A.table);
     A = DevMatrix();
     c->halo = 0;
+    ec3d_free_rhs(c);
     c->have_matrix = false;
     free_vectors(c);
     for (auto &l : c->cel_bnd) l.clear();

@@ -52,6 +52,7 @@ EXPORTS = ["sprsbcgstabwr_", "ec3d_invalidate", "ec3d_create", "ec3d_destroy", "
            "ec3d_iterate_begin", "ec3d_iterate", "ec3d_set_format", "ec3d_set_stream",
            "ec3d_assemble_poisson_slab", "ec3d_vector_layout", "ec3d_adopt_vectors",
            "ec3d_dist_configure", "ec3d_dist_step", "ec3d_read_state", "ec3d_set_zmarch",
+           "ec3d_rhs_step", "ec3d_post_update",
            "ec3d_device_synchronize"]
 
 _f64 = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
@@ -88,6 +89,8 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.ec3d_get_cel_bnd.argtypes = [hp, C.c_int, C.POINTER(C.c_int32), hp]
     L.ec3d_get_reduction_geometry.argtypes = [hp, C.c_int, C.POINTER(Geom)]
     L.ec3d_set_zmarch.argtypes = [hp, C.c_int]
+    L.ec3d_rhs_step.argtypes = [hp, C.c_int32, C.c_int32, _i32, _f64]
+    L.ec3d_post_update.argtypes = [hp]
     L.ec3d_set_workgroups.argtypes = [hp, C.c_int32]
     L.ec3d_get_matrix_info.argtypes = [hp, C.POINTER(MatrixInfo)]
     L.ec3d_time_kernel.argtypes = [hp, C.c_int, C.c_int32, C.POINTER(C.c_double)]
@@ -267,6 +270,18 @@ class EC3DSolver:
                                                 hist.ctypes.data if hist_cap else None, hist_cap),
              "ec3d_solve_resident")
         return it.value, hist[:hist_cap]
+
+    # ---- time-loop field work on the resident vectors (src/EC3D.f90:275-404, :412-433) --------
+    def rhs_step(self, src_index, src_value, moving: bool = False):
+        """Jaf for this step: source scatter (1-based unknown ids, values from the host's source
+        functions), inertial terms, U-row right-hand sides, cel_bnd* zero-fills."""
+        idx = np.ascontiguousarray(src_index, np.int32)
+        val = np.ascontiguousarray(src_value, np.float64)
+        _chk(self.L, self.L.ec3d_rhs_step(self.h, int(bool(moving)), len(idx), idx if len(idx) else np.zeros(1, np.int32),
+                                          val if len(val) else np.zeros(1)), "ec3d_rhs_step")
+
+    def post_update(self):
+        _chk(self.L, self.L.ec3d_post_update(self.h), "ec3d_post_update")
 
     def spmv(self, x):
         y = np.empty(self.n)

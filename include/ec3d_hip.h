@@ -83,6 +83,17 @@ int ec3d_device_vector(ec3d_handle h, int which, double **device_ptr, int64_t *n
 int ec3d_solve_resident(ec3d_handle h, double tolerance, int32_t itmax, int32_t *iter,
                         double *resid_hist, int32_t hist_cap);
 
+/* Per-time-step field work around the solve, on the resident vectors (B = Jaf, X = Uaf), so only the
+ * coil cells' source values cross PCIe each step.  Needs a matrix from ec3d_assemble.
+ * ec3d_rhs_step  replaces src/EC3D.f90:275-404: with moving != 0 first keeps only the inertial part
+ *   of Jaf (:277-296); then Jaf(src_index(q)) = src_value(q), q in order (1-based unknown ids; the
+ *   host evaluates the source functions and the coil motion, :245-340); then Jaf = a*Uaf + Jaf on the
+ *   conductor cells, the U-row right-hand sides (:385-392) and the zero-fills at cel_bnd* (:396-402).
+ * ec3d_post_update  replaces :412-433 after the solve. */
+int ec3d_rhs_step(ec3d_handle h, int32_t moving, int32_t nsrc, const int32_t *src_index,
+                  const double *src_value);
+int ec3d_post_update(ec3d_handle h);
+
 /* y = A*x through the device format (src/solvers.f90:54-61), host vectors.  Parity probe. */
 int ec3d_spmv(ec3d_handle h, const double *x, double *y);
 
