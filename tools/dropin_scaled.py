@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""End-to-end drop-in run on the GPU box: the UNMODIFIED reference program (oracle/_ref/EC3D_dropin:
+its own .vxc ingest, assembly, coil motion, RHS build, time loop) with every solve going through the
+`sprsbcgstabwr_` exported by libec3d_hip.so, on a shipped input refined by integer factors
+(BASELINE config 3 style).  With --reference the same input is also run through the pure reference
+(oracle/_ref/EC3D_capture) for `--ref-steps` steps to time the CPU solver on the same box.
+
+usage: dropin_scaled.py <compare_to_Elmer|ec_src_move_hole|LIM> fx fy fz steps [--reference --ref-steps K]
+"""
+import argparse, os, re, subprocess, sys, tempfile, time
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import numpy as np
+from oracle import make_goldens as G
+from oracle import oracle as O
+
+ap = argparse.ArgumentParser()
+ap.add_argument("case"); ap.add_argument("fx", type=int); ap.add_argument("fy", type=int); ap.add_argument("fz", type=int)
+ap.add_argument("steps", type=int)
+ap.add_argument("--reference", action="store_true"); ap.add_argument("--ref-steps", type=int, default=1)
+a = ap.parse_args()
+
+g = np.load(os.path.join(REPO, "tests", "golden", f"g4_{a.case}.npz"))
+vox = np.repeat(np.repeat(np.repeat(g["vox"], a.fz, axis=0), a.fy, axis=1), a.fx, axis=2)
+names = [str(s) for s in g["names"]]
+adj = [float(x) for x in g["adj"]]
+ld = float(str(g["lattice_dim"]))
+# keep the physical size: cell size / factor per axis (Lattice_Dim * Adj, src/vxc2data.f90:103-124)
+adj = (adj[0] / a.fx, adj[1] / a.fy, adj[2] / a.fz)
+# no VTK output during the timed run: JUMP beyond the stop time (src/vxc2data.f90:191-195, EC3D.f90:143-144)
+names = [re.sub(r"(tran\b.*)", r"\1 jump=1000", s, flags=re.I) if re.search(r"\btran\b", s, re.I) else s for s in names]
+sdz, sdy, sdx = vox.shape
+print(f"{a.case} x({a.fx},{a.fy},{a.fz}): grid {sdx}x{sdy}x{sdz} = {vox.size} cells", flush=True)
+
+
+def run(exe, steps, env_extra):
+    t0 = time.time()
+    td = tempfile.mkdtemp(prefix="ec3d_dropin_")
+    G.write_vxc(os.path.join(td, "in.vxc"), vox, names, repr(ld), tuple(repr(x) for x in adj))
+    with open(os.path.join(td, "del"), "w") as f:
+        f.write("#!/bin/sh\nexit 0\n")
+    os.chmod(os.path.join(td, "del"), 0o755)
+    env = dict(os.environ, PATH=td + ":" + os.environ["PATH"], EC3D_CAPTURE_MAX_CALLS=str(steps), **env_extra)
+    env.pop("EC3D_CAPTURE_DIR", None)
+    p = subprocess.run([exe], cwd=td, env=env, preexec_fn=O._unlimit_stack, stdout=subprocess.DEVNULL,
+                       stderr=subprocess.PIPE)
+    calls = re.findall(r"\[capture\] call (\d+) n=(\d+) nnz=(\d+) iter=(\d+) t=([\d.]+)s", p.stderr.decode())
+    subprocess.run(["rm", "-rf", td])
+    return calls, time.time() - t0, p.stderr.decode()[-500:]
+
+
+lib = os.path.join(REPO, "eddy_currents_3d_amd", "libec3d_hip.so")
+calls, wall, err = run(os.path.join(REPO, "oracle", "_ref", "EC3D_dropin"), a.steps, {"EC3D_HIP_LIB": lib})
+if not calls:
+    print("no solver call captured:", err); sys.exit(1)
+n, nnz = int(calls[0][1]), int(calls[0][2])
+its = [int(c[3]) for c in calls]; ts = [float(c[4]) for c in calls]
+print(f"GPU drop-in : n={n} nnz={nnz} steps={len(calls)} iters={its}")
+print(f"              solve call s/step={['%.3f' % t for t in ts]}  (first includes CSR->device conversion)")
+print(f"              whole program wall {wall:.1f} s (ingest + reference assembly + {len(calls)} steps)")
+rate = [n * i / t for i, t in zip(its[1:], ts[1:])] or [n * its[0] / ts[0]]
+print(f"              DOF*iters/s per call incl. H2D/D2H: {np.mean(rate):.3e}")
+if a.reference:
+    calls, wall, err = run(os.path.join(REPO, "oracle", "_ref", "EC3D_capture"), a.ref_steps, {})
+    its = [int(c[3]) for c in calls]; ts = [float(c[4]) for c in calls]
+    print(f"CPU reference: steps={len(calls)} iters={its} solve s/step={['%.2f' % t for t in ts]} "
+          f"-> {np.mean([n * i / t for i, t in zip(its, ts)]):.3e} DOF*iters/s (1 core); program wall {wall:.1f} s")
