@@ -184,11 +184,11 @@ void ec3d_launch_k1(const MatView &A, const Sweep &sw, const SolverState *st, in
                     const double *r0, double *ap, double *part, hipStream_t s);
 void ec3d_launch_k2(const Sweep &sw, const RedSrc &src, SolverState *st, int it, const double *r, const double *ap,
                     double *sv, double *part, hipStream_t s);
-void ec3d_launch_k3(const MatView &A, const Sweep &sw, const RedSrc &src, SolverState *st, int it, const double *sv,
-                    const double *p, double *x, double *as, double *part, double *hist, int64_t hist_cap,
-                    hipStream_t s);
-void ec3d_launch_k4(const Sweep &sw, const RedSrc &src, SolverState *st, int it, const double *p, const double *sv,
-                    const double *as, const double *r0, double *x, double *r, double *part, hipStream_t s);
+void ec3d_launch_k3(const MatView &A, const Sweep &sw, SolverState *st, int it, const double *sv, double *as,
+                    double *part, hipStream_t s);
+void ec3d_launch_k4(const Sweep &sw, const RedSrc &src_ss, const RedSrc &src, SolverState *st, int it,
+                    const double *p, const double *sv, const double *as, const double *r0, double *x, double *r,
+                    double *part, double *hist, int64_t hist_cap, hipStream_t s);
 void ec3d_launch_k5(const Sweep &sw, const RedSrc &src, SolverState *st, int it, const double *r, const double *ap,
                     double *p, double *r0, double *hist, int64_t hist_cap, hipStream_t s);
 

@@ -353,36 +353,17 @@ __global__ __launch_bounds__(EC3D_THREADS) void k2_s_update(Sweep sw, RedSrc src
     if (threadIdx.x == 0) part[P_SS * sw.pstride + blockIdx.x] = acc[0];
 }
 
-// K3: if ‖S‖/Bnorm < tol: X += alpha*P, exit (src/solvers.f90:34-38)
-//     else AS = A S ; partials AS·S and AS·AS (:39-40)
+// K3: AS = A S ; partials AS·S and AS·AS (src/solvers.f90:39-40).  Launched before ‖S‖ is known
+// (one global reduction point less per iteration): when the ‖S‖ exit of :34-38 is then
+// taken by K4, AS is simply never used -- results are unchanged.
 template <int FMT, bool NT, bool ZM>
-__global__ __launch_bounds__(EC3D_THREADS) void k3_spmv_dots(MatView A, Sweep sw, RedSrc src, SolverState *st,
-                                                             int it, const double *__restrict__ sv,
-                                                             const double *__restrict__ p, double *__restrict__ x,
-                                                             double *__restrict__ as, double *__restrict__ part,
-                                                             double *hist, int64_t hist_cap)
+__global__ __launch_bounds__(EC3D_THREADS) void k3_spmv_dots(MatView A, Sweep sw, SolverState *st, int it,
+                                                             const double *__restrict__ sv,
+                                                             double *__restrict__ as, double *__restrict__ part)
 {
     __shared__ double lds[8];
     EC3D_TBL_DECL;
     if (st->stop_iter < it) return;
-    const int slot[1] = {P_SS};
-    double ss[1];
-    reduce_partials<1>(src, slot, ss, lds);
-    const double snorm = sqrt(ss[0]);
-    if (blockIdx.x == 0 && threadIdx.x == 0 && hist && it <= hist_cap) hist[2 * (int64_t)(it - 1)] = snorm;
-    if (snorm / st->bnorm < st->tol) {
-        const double alpha = st->alpha;
-        EC3D_SWEEP_BEGIN
-        d2 xv = *reinterpret_cast<const d2 *>(x + r);
-        d2 pv = *reinterpret_cast<const d2 *>(p + r);
-        store2<NT>(x, r, sw.n, xv.x + alpha * pv.x, xv.y + alpha * pv.y);
-        EC3D_SWEEP_END
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
-            st->stop_kind = 1;
-            st->stop_iter = it; // K4/K5 of this iteration test stop_iter <= it
-        }
-        return;
-    }
     stage_table<FMT>(A, tbl);
     ZRegs zr;
     double acc[2] = {0.0, 0.0};
@@ -404,24 +385,45 @@ __global__ __launch_bounds__(EC3D_THREADS) void k3_spmv_dots(MatView A, Sweep sw
     }
 }
 
-// K4: omega = (AS·S)/(AS·AS) ; X = X + alpha*P + omega*S ; R = S - omega*AS ;
-//     partials R·R and R·R0   (src/solvers.f90:40-44)
+// K4: if ‖S‖/Bnorm < tol: X += alpha*P, exit (src/solvers.f90:34-38); else
+//     omega = (AS·S)/(AS·AS) ; X = X + alpha*P + omega*S ; R = S - omega*AS ;
+//     partials R·R and R·R0   (:40-44)
 template <bool NT>
-__global__ __launch_bounds__(EC3D_THREADS) void k4_x_r_update(Sweep sw, RedSrc src, SolverState *st, int it,
-                                                              const double *__restrict__ p,
+__global__ __launch_bounds__(EC3D_THREADS) void k4_x_r_update(Sweep sw, RedSrc src_ss, RedSrc src, SolverState *st,
+                                                              int it, const double *__restrict__ p,
                                                               const double *__restrict__ sv,
                                                               const double *__restrict__ as,
                                                               const double *__restrict__ r0, double *__restrict__ x,
-                                                              double *__restrict__ rv, double *__restrict__ part)
+                                                              double *__restrict__ rv, double *__restrict__ part,
+                                                              double *hist, int64_t hist_cap)
 {
     __shared__ double lds[8];
-    if (st->stop_iter <= it) return;
+    if (st->stop_iter < it) return; // (this kernel is the one that may set stop_iter = it)
+    const int slot_ss[1] = {P_SS};
+    double ss[1];
+    reduce_partials<1>(src_ss, slot_ss, ss, lds);
+    const double snorm = sqrt(ss[0]);
+    const double alpha = st->alpha;
+    const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+    if (lead && hist && it <= hist_cap) hist[2 * (int64_t)(it - 1)] = snorm;
+    if (snorm / st->bnorm < st->tol) {
+        EC3D_SWEEP_BEGIN
+        d2 xv = *reinterpret_cast<const d2 *>(x + r);
+        d2 pv = *reinterpret_cast<const d2 *>(p + r);
+        store2<false>(x, r, sw.n, xv.x + alpha * pv.x, xv.y + alpha * pv.y);
+        EC3D_SWEEP_END
+        if (lead) st->stop_kind = 1;
+        // every workgroup has read stop_iter above; K5 of this iteration tests stop_iter <= it.
+        // Written last and only by the lead thread; other workgroups of THIS launch may already
+        // have passed their entry test, which only compares against earlier iterations.
+        if (lead) st->stop_iter = it;
+        return;
+    }
     const int slot[2] = {P_D2, P_D3};
     double d[2];
     reduce_partials<2>(src, slot, d, lds);
     const double omega = d[0] / d[1];
-    const double alpha = st->alpha;
-    if (blockIdx.x == 0 && threadIdx.x == 0) st->omega = omega;
+    if (lead) st->omega = omega;
     double acc[2] = {0.0, 0.0};
     EC3D_SWEEP_BEGIN
     d2 xv = load2<NT>(x + r);
@@ -559,17 +561,17 @@ void ec3d_launch_k2(const Sweep &sw, const RedSrc &src, SolverState *st, int it,
     EC3D_LAUNCH_VEC(k2_s_update, sw, src, st, it, r, ap, sv, part);
 }
 
-void ec3d_launch_k3(const MatView &A, const Sweep &sw, const RedSrc &src, SolverState *st, int it, const double *sv,
-                    const double *p, double *x, double *as, double *part, double *hist, int64_t hist_cap,
-                    hipStream_t s)
+void ec3d_launch_k3(const MatView &A, const Sweep &sw, SolverState *st, int it, const double *sv, double *as,
+                    double *part, hipStream_t s)
 {
-    EC3D_DISPATCH(A, k3_spmv_dots, A, sw, src, st, it, sv, p, x, as, part, hist, hist_cap);
+    EC3D_DISPATCH(A, k3_spmv_dots, A, sw, st, it, sv, as, part);
 }
 
-void ec3d_launch_k4(const Sweep &sw, const RedSrc &src, SolverState *st, int it, const double *p, const double *sv,
-                    const double *as, const double *r0, double *x, double *r, double *part, hipStream_t s)
+void ec3d_launch_k4(const Sweep &sw, const RedSrc &src_ss, const RedSrc &src, SolverState *st, int it,
+                    const double *p, const double *sv, const double *as, const double *r0, double *x, double *r,
+                    double *part, double *hist, int64_t hist_cap, hipStream_t s)
 {
-    EC3D_LAUNCH_VEC(k4_x_r_update, sw, src, st, it, p, sv, as, r0, x, r, part);
+    EC3D_LAUNCH_VEC(k4_x_r_update, sw, src_ss, src, st, it, p, sv, as, r0, x, r, part, hist, hist_cap);
 }
 
 void ec3d_launch_k5(const Sweep &sw, const RedSrc &src, SolverState *st, int it, const double *r, const double *ap,

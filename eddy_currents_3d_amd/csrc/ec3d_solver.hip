@@ -32,7 +32,7 @@ MatView DevMatrix::view() const
     v.cls = cls;
     v.table = table;
     v.ncls = ncls;
-    v.has_tail = ntail > 0;
+    v.has_tail = ntail > 0 && !getenv("EC3D_EXPERIMENT_NOTAIL"); // experiment knob: timing only, wrong results
     v.tail_id = tail_id;
     v.tile_flag = tile_flag;
     v.chunk_ptr = chunk_ptr;
@@ -483,11 +483,11 @@ static void launch_stage(ec3d_ctx *c, const MatView &A, int it, int k)
     if (k == 0 || k == 2)
         ec3d_launch_k2(sw, src_of(c, true), c->state, it, v[EC3D_VEC_R], v[EC3D_VEC_AP], v[EC3D_VEC_S], c->partials, s);
     if (k == 0 || k == 3)
-        ec3d_launch_k3(A, ss, src_of(c, false), c->state, it, v[EC3D_VEC_S], v[EC3D_VEC_P], v[EC3D_VEC_X],
-                       v[EC3D_VEC_AS], c->partials, c->hist, c->hist_cap, s);
+        ec3d_launch_k3(A, ss, c->state, it, v[EC3D_VEC_S], v[EC3D_VEC_AS], c->partials, s);
     if (k == 0 || k == 4)
-        ec3d_launch_k4(sw, src_of(c, true), c->state, it, v[EC3D_VEC_P], v[EC3D_VEC_S], v[EC3D_VEC_AS], v[EC3D_VEC_R0],
-                       v[EC3D_VEC_X], v[EC3D_VEC_R], c->partials, s);
+        ec3d_launch_k4(sw, src_of(c, false), src_of(c, true), c->state, it, v[EC3D_VEC_P], v[EC3D_VEC_S],
+                       v[EC3D_VEC_AS], v[EC3D_VEC_R0], v[EC3D_VEC_X], v[EC3D_VEC_R], c->partials, c->hist,
+                       c->hist_cap, s);
     if (k == 0 || k == 5)
         ec3d_launch_k5(sw, src_of(c, false), c->state, it, v[EC3D_VEC_R], v[EC3D_VEC_AP], v[EC3D_VEC_P],
                        v[EC3D_VEC_R0], c->hist, c->hist_cap, s);

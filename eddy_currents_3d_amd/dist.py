@@ -5,7 +5,7 @@ The reference is serial; this is new design.  Rank g of G owns the
 [k0, k1) of the structured grid, i.e. one contiguous index range (k is the slowest index,
 /root/reference/src/EC3D.f90:506-510).  Per iteration (src/solvers.f90:24-50):
 
-    halo(P) -> K1 -> gather -> K2 -> gather -> halo(S) -> K3 -> gather -> K4 -> gather -> K5
+    halo(P) -> K1 -> gather -> K2 -> halo(S) -> K3 -> gather -> K4 -> gather -> K5
 
 * halo(v): the first/last owned plane of v goes to the z-neighbours' ghost planes (send/recv pairs,
   nearest neighbours only; the planes are contiguous, so tensors are sent in place, no packing);
@@ -26,7 +26,9 @@ RESID, SETUP, K1, K2, K3, K4, K5 = range(7)
 NSLOT = 8
 # the communication/compute schedule, shared by every driver below
 BEGIN_PLAN = (("halo", "X"), ("step", RESID), ("gather",), ("step", SETUP))
-ITER_PLAN = (("halo", "P"), ("step", K1), ("gather",), ("step", K2), ("gather",), ("halo", "S"),
+# three global reduction points per iteration: K3 (A*S) is launched before ||S|| is known and K4 takes
+# the ||S|| exit, so S.S travels with AS.S and AS.AS (results unchanged)
+ITER_PLAN = (("halo", "P"), ("step", K1), ("gather",), ("step", K2), ("halo", "S"),
              ("step", K3), ("gather",), ("step", K4), ("gather",), ("step", K5))
 
 

@@ -133,8 +133,9 @@ enum { EC3D_STAGE_RESID = 0, /* R = B - A X, R0 = P = R; lsum <- B.B, R.R      s
        EC3D_STAGE_SETUP = 1, /* Bnorm, rr0 from gsum                                            :21-23 */
        EC3D_STAGE_K1 = 2,    /* AP = A P; lsum <- AP.R0        (P halo must be current)          :30-32 */
        EC3D_STAGE_K2 = 3,    /* alpha, S = R - alpha AP; lsum <- S.S                             :32-34 */
-       EC3D_STAGE_K3 = 4,    /* S exit or AS = A S; lsum <- AS.S, AS.AS (S halo current)         :34-40 */
-       EC3D_STAGE_K4 = 5,    /* omega, X, R; lsum <- R.R, R.R0                                   :40-44 */
+       EC3D_STAGE_K3 = 4,    /* AS = A S; lsum <- AS.S, AS.AS (S halo current; no gather needed
+                                between K2 and K3: the S exit is taken by K4)                     :39-40 */
+       EC3D_STAGE_K4 = 5,    /* S exit (X += alpha P) or omega, X, R; lsum <- R.R, R.R0          :34-44 */
        EC3D_STAGE_K5 = 6 };  /* R exit, beta, P, restart                                         :43-49 */
 int ec3d_dist_step(ec3d_handle h, int32_t stage, int32_t it, double tolerance);
 /* drain the stream and read the device-resident state; stop_iter = -1 while still running */

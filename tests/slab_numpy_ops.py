@@ -97,15 +97,15 @@ class NumpySlabOps:
             L[SS] = float(s @ s)
         elif stage == K3:
             if stopped_before: return
-            if np.sqrt(self._g(SS)) / st["bnorm"] < st["tol"]:
-                self._own("X")[:] += st["alpha"] * self._own("P")
-                st["stop_kind"], st["stop_iter"] = 1, it
-                return
             a = self._spmv("S")
             self._own("AS")[:] = a
             L[D2] = float(a @ self._own("S")); L[D3] = float(a @ a)
         elif stage == K4:
-            if stopped_now: return
+            if stopped_before: return
+            if np.sqrt(self._g(SS)) / st["bnorm"] < st["tol"]:
+                self._own("X")[:] += st["alpha"] * self._own("P")
+                st["stop_kind"], st["stop_iter"] = 1, it
+                return
             st["omega"] = self._g(D2) / self._g(D3)
             self._own("X")[:] = (self._own("X") + st["alpha"] * self._own("P")) + st["omega"] * self._own("S")
             r = self._own("S") - st["omega"] * self._own("AS")
