@@ -20,6 +20,7 @@ namespace {
 struct GridPar {
     int sdx, sdy, sdz; // global grid
     int k0;            // first plane held (z-slab; 0 otherwise)
+    int own_k0, own_k1; // global planes [own_k0, own_k1) are owned; others held only as halos
     int zero_cls;      // dictionary class whose coefficients are all 0 (U rows, padding)
     int64_t kdz, nCells, n_pad;
     double s[3];     // 1/delta^2          :496-498
@@ -151,9 +152,16 @@ __global__ __launch_bounds__(256) void k_assemble_av(GridPar g, const int8_t *__
 {
     const int64_t nn0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (nn0 >= g.nCells) return;
-    const int i = (int)(nn0 % g.sdx) + 1, j = (int)((nn0 / g.sdx) % g.sdy) + 1, k = (int)(nn0 / g.kdz) + 1;
-    const int32_t nn = (int32_t)nn0 + 1; // the reference's 1-based cell id
+    const int i = (int)(nn0 % g.sdx) + 1, j = (int)((nn0 / g.sdx) % g.sdy) + 1, k = g.k0 + (int)(nn0 / g.kdz) + 1;
+    const int32_t nn = (int32_t)nn0 + 1; // the reference's 1-based cell id (local to the planes held)
     const int32_t nC = (int32_t)g.nCells;
+    if (k - 1 < g.own_k0 || k - 1 >= g.own_k1) { // halo plane of a z-slab: inert rows
+        if (cls) {
+            cls[nn0] = cls[g.nCells + nn0] = cls[2 * g.nCells + nn0] = (uint8_t)g.zero_cls;
+        }
+        if (flags) flags[nn0] = 0;
+        return;
+    }
     double c[7];
     bool on_box;
     a_row_bands(g, i, j, k, c, on_box);
@@ -169,7 +177,7 @@ __global__ __launch_bounds__(256) void k_assemble_av(GridPar g, const int8_t *__
         const int64_t m = uidx[nn0];
         const int64_t step[3] = {1, g.sdx, g.kdz};
         const int pos[3] = {i, j, k}, sd[3] = {g.sdx, g.sdy, g.sdz};
-        int32_t nb6[6]; // U ids of the -x,+x,-y,+y,-z,+z neighbours
+        int32_t nb6[6]; // U ids of the -x,+x,-y,+y,-z,+z neighbours (owned cells have 2 planes around them)
         for (int d = 0; d < 3; ++d) {
             nb6[2 * d] = geoC[nn0 - step[d]];
             nb6[2 * d + 1] = geoC[nn0 + step[d]];
@@ -380,15 +388,20 @@ int ec3d_assemble_poisson_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t 
     return ec3d_prepare_vectors(c);
 }
 
-int ec3d_assemble_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t sdz, const int8_t *geoPHYS,
-                         const int32_t *geoPHYS_C, const double *valPHYS, int32_t nsub_glob,
-                         const double *BND, const double *delta, double dt)
+int ec3d_assemble_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t sdz, int32_t e0, int32_t e1, int32_t k0,
+                         int32_t k1, const int8_t *geoPHYS, const int32_t *geoPHYS_C, const double *valPHYS,
+                         int32_t nsub_glob, const double *BND, const double *delta, double dt)
 {
     GridPar g;
     memset(&g, 0, sizeof g);
     int rc = fill_gridpar(g, sdx, sdy, sdz, BND, delta, dt);
     if (rc) return rc;
     g.nsub_glob = nsub_glob;
+    g.k0 = e0;
+    g.own_k0 = k0;
+    g.own_k1 = k1;
+    g.nCells = g.kdz * (e1 - e0); // cells held
+    const bool slab = !(e0 == 0 && e1 == sdz);
     // scan-order index of the conducting cells = U row order (src/EC3D.f90:519-522, :955)
     std::vector<int32_t> uidx((size_t)g.nCells, -1);
     int64_t nc0 = 0;
@@ -494,6 +507,24 @@ int ec3d_assemble_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t sdz, con
     }
     c->have_matrix = true;
     c->sdx = sdx; c->sdy = sdy; c->sdz = sdz;
+    if (slab) { // rows that count in dot products: the owned planes of each component and their U cells
+        const int64_t lo = (int64_t)(k0 - e0) * g.kdz, hi = (int64_t)(k1 - e0) * g.kdz;
+        int64_t u_lo = 0, u_hi = 0;
+        for (int64_t q = 0; q < hi; ++q)
+            if (uidx[(size_t)q] >= 0) {
+                if (q < lo) ++u_lo;
+                ++u_hi;
+            }
+        c->nown = 4;
+        for (int d = 0; d < 3; ++d) {
+            c->own_lo[d] = d * g.nCells + lo;
+            c->own_hi[d] = d * g.nCells + hi;
+        }
+        c->own_lo[3] = 3 * g.nCells + u_lo;
+        c->own_hi[3] = 3 * g.nCells + u_hi;
+        c->halo = g.kdz;
+        return ec3d_prepare_vectors(c);
+    }
     if ((rc = ec3d_prepare_vectors(c))) return rc;
     return ec3d_setup_rhs(c, g.nCells, geoPHYS, geoPHYS_C, valPHYS, nsub_glob, dt);
 }

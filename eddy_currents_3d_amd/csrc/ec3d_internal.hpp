@@ -58,6 +58,10 @@ struct Sweep {
     // xy-plane ("column") and walks zm_pps consecutive planes, so x[r-kdz], x[r] stay in registers
     int zm_tpp;  // tiles per plane = kdz / 512
     int zm_pps;  // planes per z segment
+    // rows that count in the dot products when this handle holds an A-V slab on an extended grid
+    // (nown > 0): [Ax | Ay | Az | U] each contribute one owned index range
+    int nown;
+    int64_t own_lo[4], own_hi[4];
 };
 
 struct SolverState {
@@ -113,8 +117,10 @@ struct ec3d_ctx {
     int64_t ghost = 0;     // zero halo (doubles) on both sides of every vector
     double *vec_base = nullptr;
     double *vec[8] = {nullptr};
-    Sweep sweep{0, 0, 0, 0, 0, 0, 0, 0};   // vector kernels (K2, K4, K5)
-    Sweep sweep_s{0, 0, 0, 0, 0, 0, 0, 0}; // SpMV kernels (K1, K3, residual, spmv)
+    Sweep sweep{};   // vector kernels (K2, K4, K5)
+    Sweep sweep_s{}; // SpMV kernels (K1, K3, residual, spmv)
+    int nown = 0;    // ownership ranges of an A-V slab (see Sweep)
+    int64_t own_lo[4] = {0}, own_hi[4] = {0};
     bool own_vectors = true;
     bool dist = false;
     // multi-rank (z-slab) mode: reductions come from the all-gathered per-rank sums
@@ -193,9 +199,11 @@ void ec3d_launch_k5(const Sweep &sw, const RedSrc &src, SolverState *st, int it,
                     double *p, double *r0, double *hist, int64_t hist_cap, hipStream_t s);
 
 // ec3d_assemble.hip
-int ec3d_assemble_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t sdz, const int8_t *geoPHYS,
-                         const int32_t *geoPHYS_C, const double *valPHYS, int32_t nsub_glob,
-                         const double *BND, const double *delta, double dt);
+// planes [e0, e1) of the global grid are held (e0 = 0, e1 = sdz: everything); rows of planes outside
+// [k0, k1) are inert (zero coefficients): they only carry the neighbours' values
+int ec3d_assemble_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t sdz, int32_t e0, int32_t e1, int32_t k0,
+                         int32_t k1, const int8_t *geoPHYS, const int32_t *geoPHYS_C, const double *valPHYS,
+                         int32_t nsub_glob, const double *BND, const double *delta, double dt);
 int ec3d_assemble_poisson_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t sdz, int32_t k0, int32_t k1,
                                  const double *BND, const double *delta);
 // ec3d_format.cpp / ec3d_solver.hip: dictionary compression of the bands

@@ -105,12 +105,19 @@ __device__ __forceinline__ void store2(double *__restrict__ v, int64_t r, int64_
         v[r] = a;
     }
 }
-#define EC3D_MASK2(r, n, a, b)                                                                 \
+// rows that take part in the dot products: all rows < n, or -- for one z-slab of the A-V system held
+// on an extended grid (own planes + halo planes of every component) -- the owned index ranges only
+__device__ __forceinline__ bool row_owned(const Sweep &sw, int64_t r)
+{
+    if (sw.nown == 0) return r < sw.n;
+    bool o = false;
+    for (int q = 0; q < sw.nown; ++q) o |= (r >= sw.own_lo[q]) & (r < sw.own_hi[q]);
+    return o;
+}
+#define EC3D_MASK2(r, sw_, a, b)                                                               \
     do {                                                                                       \
-        if ((r) + 1 >= (n)) {                                                                  \
-            (b) = 0.0;                                                                         \
-            if ((r) >= (n)) (a) = 0.0;                                                         \
-        }                                                                                      \
+        if (!row_owned(sw_, (r))) (a) = 0.0;                                                   \
+        if (!row_owned(sw_, (r) + 1)) (b) = 0.0;                                               \
     } while (0)
 
 __device__ __forceinline__ double tail_add(const MatView &A, const double *__restrict__ x, int t, double s)
@@ -251,8 +258,8 @@ __global__ __launch_bounds__(EC3D_THREADS) void k_residual(MatView A, Sweep sw, 
     store2<NT>(rv, r, sw.n, e0, e1);
     store2<NT>(r0, r, sw.n, e0, e1);
     store2<NT>(p, r, sw.n, e0, e1);
-    EC3D_MASK2(r, sw.n, e0, e1);
-    EC3D_MASK2(r, sw.n, b0, b1);
+    EC3D_MASK2(r, sw, e0, e1);
+    EC3D_MASK2(r, sw, b0, b1);
     acc[0] = acc[0] + b0 * b0;
     acc[0] = acc[0] + b1 * b1;
     acc[1] = acc[1] + e0 * e0;
@@ -317,7 +324,7 @@ __global__ __launch_bounds__(EC3D_THREADS) void k1_spmv_dot(MatView A, Sweep sw,
     spmv_pair<FMT, ZM>(A, tbl, p, r, tile, first_, zr, s0, s1);
     d2 q = load2<NT>(r0 + r);
     store2<NT>(ap, r, sw.n, s0, s1);
-    EC3D_MASK2(r, sw.n, s0, s1);
+    EC3D_MASK2(r, sw, s0, s1);
     acc[0] = acc[0] + s0 * q.x;
     acc[0] = acc[0] + s1 * q.y;
     EC3D_SWEEP_END
@@ -345,7 +352,7 @@ __global__ __launch_bounds__(EC3D_THREADS) void k2_s_update(Sweep sw, RedSrc src
     d2 q = load2<NT>(rv + r);
     double s0 = q.x - alpha * a.x, s1 = q.y - alpha * a.y;
     store2<NT>(sv, r, sw.n, s0, s1);
-    EC3D_MASK2(r, sw.n, s0, s1);
+    EC3D_MASK2(r, sw, s0, s1);
     acc[0] = acc[0] + s0 * s0;
     acc[0] = acc[0] + s1 * s1;
     EC3D_SWEEP_END
@@ -372,7 +379,7 @@ __global__ __launch_bounds__(EC3D_THREADS) void k3_spmv_dots(MatView A, Sweep sw
     spmv_pair<FMT, ZM>(A, tbl, sv, r, tile, first_, zr, s0, s1);
     d2 q = *reinterpret_cast<const d2 *>(sv + r);
     store2<NT>(as, r, sw.n, s0, s1);
-    EC3D_MASK2(r, sw.n, s0, s1);
+    EC3D_MASK2(r, sw, s0, s1);
     acc[0] = acc[0] + s0 * q.x;
     acc[0] = acc[0] + s1 * q.y;
     acc[1] = acc[1] + s0 * s0;
@@ -434,7 +441,7 @@ __global__ __launch_bounds__(EC3D_THREADS) void k4_x_r_update(Sweep sw, RedSrc s
     store2<NT>(x, r, sw.n, (xv.x + alpha * pv.x) + omega * s.x, (xv.y + alpha * pv.y) + omega * s.y);
     double e0 = s.x - omega * a.x, e1 = s.y - omega * a.y;
     store2<NT>(rv, r, sw.n, e0, e1);
-    EC3D_MASK2(r, sw.n, e0, e1);
+    EC3D_MASK2(r, sw, e0, e1);
     acc[0] = acc[0] + e0 * e0;
     acc[0] = acc[0] + e1 * e1;
     acc[1] = acc[1] + e0 * q.x;

@@ -93,6 +93,7 @@ void ec3d_free_matrix(ec3d_ctx *c)
     if (A.table) (void)hipFree(A.table);
     A = DevMatrix();
     c->halo = 0;
+    c->nown = 0;
     ec3d_free_rhs(c);
     c->have_matrix = false;
     free_vectors(c);
@@ -124,9 +125,14 @@ extern "C" int ec3d_destroy(ec3d_handle c)
 static void choose_sweep(ec3d_ctx *c)
 {
     Sweep &sw = c->sweep;
-    sw = Sweep{0, 0, 0, 0, 0, 0, 0, 0};
+    sw = Sweep{};
     sw.ntiles = c->A.n_pad / EC3D_TILE;
     sw.n = c->A.n;
+    sw.nown = c->nown;
+    for (int q = 0; q < 4; ++q) {
+        sw.own_lo[q] = c->own_lo[q];
+        sw.own_hi[q] = c->own_hi[q];
+    }
     // 256 CUs x 3 workgroups: measured best on 512^3 (whole multiples of the CU count matter;
     // 768 > 1024 > 512 > 2048)
     int want = c->nblk_request > 0 ? c->nblk_request : 768;
@@ -308,7 +314,26 @@ extern "C" int ec3d_assemble(ec3d_handle c, int32_t sdx, int32_t sdy, int32_t sd
                              const double *BND, const double *delta, double dt)
 {
     EC3D_HIP(hipSetDevice(c->device));
-    return ec3d_assemble_device(c, sdx, sdy, sdz, geoPHYS, geoPHYS_C, valPHYS, nsub_glob, BND, delta, dt);
+    return ec3d_assemble_device(c, sdx, sdy, sdz, 0, sdz, 0, sdz, geoPHYS, geoPHYS_C, valPHYS, nsub_glob, BND, delta,
+                                dt);
+}
+
+extern "C" int ec3d_assemble_slab(ec3d_handle c, int32_t sdx, int32_t sdy, int32_t sdz, int32_t e0, int32_t e1,
+                                  int32_t k0, int32_t k1, const int8_t *geoPHYS_ext, const int32_t *geoPHYS_C_ext,
+                                  const double *valPHYS, int32_t nsub_glob, const double *BND, const double *delta,
+                                  double dt)
+{
+    EC3D_HIP(hipSetDevice(c->device));
+    if (!(0 <= e0 && e0 <= k0 && k0 < k1 && k1 <= e1 && e1 <= sdz)) {
+        ec3d_set_error("ec3d_assemble_slab: need 0 <= e0 <= k0 < k1 <= e1 <= sdz");
+        return 2;
+    }
+    if ((k0 - e0 < 2 && e0 != 0) || (e1 - k1 < 2 && e1 != sdz)) {
+        ec3d_set_error("ec3d_assemble_slab: two halo planes are needed on every interior side");
+        return 2;
+    }
+    return ec3d_assemble_device(c, sdx, sdy, sdz, e0, e1, k0, k1, geoPHYS_ext, geoPHYS_C_ext, valPHYS, nsub_glob, BND,
+                                delta, dt);
 }
 
 extern "C" int ec3d_assemble_poisson(ec3d_handle c, int32_t sdx, int32_t sdy, int32_t sdz, const double *BND,

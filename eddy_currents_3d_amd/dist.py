@@ -54,6 +54,7 @@ class HipSlabOps:
         self.local = EC3DSolver(device=device, dictionary=dictionary)
         self.local.set_stream(self.stream.cuda_stream)
         self.local.assemble_poisson(sdx, sdy, sdz, delta, bnd, slab=(k0, k1))
+        self.k0, self.k1 = k0, k1
         lay = self.local.vector_layout()
         self.n, self.ghost, self.kdz = lay["n"], lay["ghost"], sdx * sdy
         self.len = 2 * lay["ghost"] + lay["n_pad"]
@@ -80,6 +81,15 @@ class HipSlabOps:
         return (self.store[b:b + p], self.store[b - p:b],          # lo: send first plane, recv ghost
                 self.store[b + n - p:b + n], self.store[b + n:b + n + p])  # hi
 
+    def halo_pairs(self, name):
+        """[(direction, send view, recv view)]: direction -1 = lower z-neighbour, +1 = upper."""
+        lo_s, lo_r, hi_s, hi_r = self.halo_views(name)
+        return [(-1, lo_s, lo_r), (+1, hi_s, hi_r)]
+
+    def export_owned(self, name, out):
+        """Write this slab's part of vector `name` into the global array `out` (reference numbering)."""
+        out[self.k0 * self.kdz:self.k1 * self.kdz] = self.get_vector(name)
+
     def set_vector(self, name, host_array):
         with self.context():
             self.owned(name).copy_(self.torch.from_numpy(np.ascontiguousarray(host_array, np.float64)))
@@ -104,6 +114,98 @@ class HipSlabOps:
 
     def synchronize(self):
         self.stream.synchronize()
+
+
+class HipAVSlabOps(HipSlabOps):
+    """One z-slab of the full A-V system [Ax | Ay | Az | U] on one MI355X (ec3d_assemble_slab).
+
+    The handle holds the owned planes [k0, k1) plus H = 2 halo planes on every interior side (the
+    one-sided A-U stencils of /root/reference/src/EC3D.f90:697-706 reach two cells) for each of the
+    three A components, and the U unknowns of all those planes.  Rows of halo planes are inert and
+    masked out of the dot products; their vector entries are overwritten by the halo exchange, which
+    moves 4 contiguous ranges per neighbour (2 planes of Ax, Ay, Az and the U cells in them)."""
+
+    H = 2
+
+    def __init__(self, geoPHYS, geoPHYS_C, valPHYS, BND, delta, dt, k0, k1, world, device=0, dictionary=None):
+        import torch
+        from .solver import EC3DSolver
+        self.torch = torch
+        sdz, sdy, sdx = geoPHYS.shape
+        H = self.H
+        if k1 - k0 < H:
+            raise ValueError("a slab needs at least two planes")
+        e0, e1 = max(0, k0 - H), min(sdz, k1 + H)
+        self.k0, self.k1, self.e0, self.e1 = k0, k1, e0, e1
+        self.kdz = sdx * sdy
+        kdz = self.kdz
+        cond = np.asarray(geoPHYS_C) != 0                        # [k, j, i]
+        per_plane = cond.reshape(sdz, -1).sum(axis=1)
+        self.nC_global = sdz * kdz
+        self.nU_global = int(per_plane.sum())
+        self.u_global0 = int(per_plane[:e0].sum())               # global U index of my first (extended) U
+        nC = (e1 - e0) * kdz
+        self.nC = nC
+        cond_ext = cond[e0:e1]
+        geoC_ext = np.zeros(cond_ext.shape, np.int32)
+        self.nU = int(cond_ext.sum())
+        geoC_ext[cond_ext] = 3 * nC + 1 + np.arange(self.nU, dtype=np.int32)
+        u_in = lambda a, b: int(per_plane[a:b].sum())            # conducting cells in global planes [a, b)
+        self.device = torch.device("cuda", device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.local = EC3DSolver(device=device, dictionary=dictionary)
+        self.local.set_stream(self.stream.cuda_stream)
+        self.local.assemble_slab(sdz, e0, e1, k0, k1, np.asarray(geoPHYS)[e0:e1], geoC_ext, valPHYS, BND, delta, dt)
+        lay = self.local.vector_layout()
+        self.n, self.ghost = lay["n"], lay["ghost"]
+        assert self.n == 3 * nC + self.nU
+        self.len = 2 * lay["ghost"] + lay["n_pad"]
+        with torch.cuda.stream(self.stream):
+            self.store = torch.zeros(8 * self.len, dtype=torch.float64, device=self.device)
+            self.lsum = torch.zeros(NSLOT, dtype=torch.float64, device=self.device)
+            self.gsum = torch.zeros(world * NSLOT, dtype=torch.float64, device=self.device)
+        self.stream.synchronize()
+        self.local.adopt_vectors(self.store.data_ptr())
+        self.local.dist_configure(world, self.lsum.data_ptr(), self.gsum.data_ptr())
+        # contiguous (send, recv) row ranges per neighbour, local row numbering
+        p0, p1 = k0 - e0, k1 - e0
+        self._ranges = []
+        if e0 < k0:   # lower neighbour exists: send my first H owned planes, receive my lower halo planes
+            for d in range(3):
+                self._ranges.append((-1, (d * nC + p0 * kdz, d * nC + (p0 + H) * kdz),
+                                     (d * nC + (p0 - H) * kdz, d * nC + p0 * kdz)))
+            ulo = u_in(e0, k0)
+            self._ranges.append((-1, (3 * nC + ulo, 3 * nC + ulo + u_in(k0, k0 + H)), (3 * nC, 3 * nC + ulo)))
+        if k1 < e1:   # upper neighbour
+            for d in range(3):
+                self._ranges.append((+1, (d * nC + (p1 - H) * kdz, d * nC + p1 * kdz),
+                                     (d * nC + p1 * kdz, d * nC + (p1 + H) * kdz)))
+            uown_end = u_in(e0, k1)
+            self._ranges.append((+1, (3 * nC + uown_end - u_in(k1 - H, k1), 3 * nC + uown_end),
+                                 (3 * nC + uown_end, 3 * nC + self.nU)))
+        self._own = [(d * nC + p0 * kdz, d * nC + p1 * kdz) for d in range(3)] + \
+                    [(3 * nC + u_in(e0, k0), 3 * nC + u_in(e0, k1))]
+
+    def halo_pairs(self, name):
+        b = self._base(name)
+        return [(d, self.store[b + s0:b + s1], self.store[b + r0:b + r1]) for d, (s0, s1), (r0, r1) in self._ranges]
+
+    def _global_index(self):
+        """global (reference) index of every local row of the extended slab"""
+        nC, kdz = self.nC, self.kdz
+        cell = self.e0 * kdz + np.arange(nC)
+        return np.concatenate([d * self.nC_global + cell for d in range(3)] +
+                              [3 * self.nC_global + self.u_global0 + np.arange(self.nU)])
+
+    def set_vector_global(self, name, global_vec):
+        """Fill owned AND halo entries from a global vector in the reference's numbering."""
+        self.set_vector(name, np.asarray(global_vec, np.float64)[self._global_index()])
+
+    def export_owned(self, name, out):
+        v = self.get_vector(name)
+        gi = self._global_index()
+        for lo, hi in self._own:
+            out[gi[lo:hi]] = v[lo:hi]
 
 
 class SlabSolver:
@@ -139,14 +241,14 @@ class SlabSolver:
         if self.world == 1:
             return
         d = self.dist
-        lo_send, lo_recv, hi_send, hi_recv = self.ops.halo_views(name)
         p2p = []
-        if self.rank > 0:
-            p2p += [d.P2POp(d.isend, lo_send, self.rank - 1), d.P2POp(d.irecv, lo_recv, self.rank - 1)]
-        if self.rank < self.world - 1:
-            p2p += [d.P2POp(d.isend, hi_send, self.rank + 1), d.P2POp(d.irecv, hi_recv, self.rank + 1)]
-        for req in d.batch_isend_irecv(p2p):
-            req.wait()
+        for direction, send, recv in self.ops.halo_pairs(name):
+            peer = self.rank + direction
+            if 0 <= peer < self.world and send.numel() > 0:
+                p2p += [d.P2POp(d.isend, send, peer), d.P2POp(d.irecv, recv, peer)]
+        if p2p:
+            for req in d.batch_isend_irecv(p2p):
+                req.wait()
 
     def gather(self):
         """gsum[g*8 + slot] <- rank g's lsum[slot]; summed in rank order inside the next kernel."""
@@ -233,12 +335,14 @@ class InProcessSlabs:
         self.world = len(ops_list)
 
     def _halo(self, name):
-        views = [o.halo_views(name) for o in self.ops_list]
+        pairs = [o.halo_pairs(name) for o in self.ops_list]
         for g in range(self.world - 1):
-            lo_send_next, lo_recv_next = views[g + 1][0], views[g + 1][1]
-            hi_send, hi_recv = views[g][2], views[g][3]
-            hi_recv.copy_(lo_send_next)   # my upper ghost <- next slab's first plane
-            lo_recv_next.copy_(hi_send)   # next slab's lower ghost <- my last plane
+            up = [(s_, r_) for d_, s_, r_ in pairs[g] if d_ == +1]        # slab g talking to g+1
+            down = [(s_, r_) for d_, s_, r_ in pairs[g + 1] if d_ == -1]  # slab g+1 talking to g
+            assert len(up) == len(down)
+            for (s_up, r_up), (s_dn, r_dn) in zip(up, down):
+                r_up.copy_(s_dn)   # my upper ghost <- next slab's first planes
+                r_dn.copy_(s_up)   # next slab's lower ghost <- my last planes
 
     def _gather(self):
         for o in self.ops_list:
@@ -275,5 +379,11 @@ class InProcessSlabs:
                 return states[0]
         return total
 
-    def x(self):
-        return np.concatenate([o.get_vector("X") for o in self.ops_list])
+    def x(self, n_global=None):
+        """Global solution in the reference's numbering."""
+        if n_global is None:
+            return np.concatenate([o.get_vector("X") for o in self.ops_list])
+        out = np.zeros(n_global)
+        for o in self.ops_list:
+            o.export_owned("X", out)
+        return out

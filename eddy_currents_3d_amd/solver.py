@@ -52,7 +52,7 @@ EXPORTS = ["sprsbcgstabwr_", "ec3d_invalidate", "ec3d_create", "ec3d_destroy", "
            "ec3d_iterate_begin", "ec3d_iterate", "ec3d_set_format", "ec3d_set_stream",
            "ec3d_assemble_poisson_slab", "ec3d_vector_layout", "ec3d_adopt_vectors",
            "ec3d_dist_configure", "ec3d_dist_step", "ec3d_read_state", "ec3d_set_zmarch",
-           "ec3d_rhs_step", "ec3d_post_update",
+           "ec3d_rhs_step", "ec3d_post_update", "ec3d_assemble_slab",
            "ec3d_device_synchronize"]
 
 _f64 = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
@@ -89,6 +89,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.ec3d_get_cel_bnd.argtypes = [hp, C.c_int, C.POINTER(C.c_int32), hp]
     L.ec3d_get_reduction_geometry.argtypes = [hp, C.c_int, C.POINTER(Geom)]
     L.ec3d_set_zmarch.argtypes = [hp, C.c_int]
+    L.ec3d_assemble_slab.argtypes = [hp] + [C.c_int32] * 7 + [_i8, _i32, _f64, C.c_int32, _f64, _f64, C.c_double]
     L.ec3d_rhs_step.argtypes = [hp, C.c_int32, C.c_int32, _i32, _f64]
     L.ec3d_post_update.argtypes = [hp]
     L.ec3d_set_workgroups.argtypes = [hp, C.c_int32]
@@ -180,6 +181,20 @@ class EC3DSolver:
             np.ascontiguousarray(vp.T).reshape(-1), vp.shape[0],
             np.ascontiguousarray(np.asarray(BND, np.float64).T).reshape(-1),
             np.ascontiguousarray(delta, np.float64), float(dt)), "ec3d_assemble")
+
+    def assemble_slab(self, sdz_global, e0, e1, k0, k1, geoPHYS_ext, geoPHYS_C_ext, valPHYS, BND, delta, dt):
+        """One z-slab of the A-V system on the extended grid [e0, e1) (owned planes [k0, k1) + 2 halo
+        planes per interior side); geoPHYS_C_ext numbers the extended slab's conducting cells locally."""
+        nz, sdy, sdx = geoPHYS_ext.shape
+        assert nz == e1 - e0
+        vp = np.asarray(valPHYS, np.float64)
+        _chk(self.L, self.L.ec3d_assemble_slab(
+            self.h, sdx, sdy, sdz_global, e0, e1, k0, k1,
+            np.ascontiguousarray(geoPHYS_ext, np.int8).reshape(-1),
+            np.ascontiguousarray(geoPHYS_C_ext, np.int32).reshape(-1),
+            np.ascontiguousarray(vp.T).reshape(-1), vp.shape[0],
+            np.ascontiguousarray(np.asarray(BND, np.float64).T).reshape(-1),
+            np.ascontiguousarray(delta, np.float64), float(dt)), "ec3d_assemble_slab")
 
     def set_format(self, dictionary: bool):
         """True (default): 1 class byte per row + coefficient table when the operator allows it;

@@ -123,6 +123,16 @@ int ec3d_set_stream(ec3d_handle h, void *hip_stream);
  * z-neighbour planes are read from the vectors' ghost zones: v[-kdz..0) and v[n..n+kdz) */
 int ec3d_assemble_poisson_slab(ec3d_handle h, int32_t sdx, int32_t sdy, int32_t sdz, int32_t k0, int32_t k1,
                                const double *BND, const double *delta);
+/* One z-slab of the full A-V system (ec3d_assemble) on an EXTENDED grid: the handle holds planes
+ * [e0, e1) of the global grid = the owned planes [k0, k1) plus two halo planes on every interior side
+ * (the one-sided A-U stencils reach two cells, src/EC3D.f90:697-706).  geoPHYS_ext / geoPHYS_C_ext
+ * cover the extended planes; geoPHYS_C_ext numbers the conducting cells of the extended slab in
+ * scan order (3*nCells_ext + m).  Local unknowns [Ax_ext | Ay_ext | Az_ext | U_ext]; rows of halo
+ * planes are inert and excluded from every dot product; their vector entries are filled by the
+ * host's halo exchange (contiguous ranges, eddy_currents_3d_amd/dist.py). */
+int ec3d_assemble_slab(ec3d_handle h, int32_t sdx, int32_t sdy, int32_t sdz, int32_t e0, int32_t e1, int32_t k0,
+                       int32_t k1, const int8_t *geoPHYS_ext, const int32_t *geoPHYS_C_ext, const double *valPHYS,
+                       int32_t nsub_glob, const double *BND, const double *delta, double dt);
 /* every work vector is [ghost | n_pad | ghost] doubles; halo = doubles per z-plane (0 if not a slab) */
 int ec3d_vector_layout(ec3d_handle h, int64_t *ghost, int64_t *n, int64_t *n_pad, int64_t *halo);
 /* use caller-owned, zero-filled device memory (EC3D_NVEC * (2*ghost + n_pad) doubles) for the vectors */

@@ -57,6 +57,10 @@ class NumpySlabOps:
         s = self.store
         return s[b:b + p], s[b - p:b], s[b + n - p:b + n], s[b + n:b + n + p]
 
+    def halo_pairs(self, name):
+        lo_s, lo_r, hi_s, hi_r = self.halo_views(name)
+        return [(-1, lo_s, lo_r), (+1, hi_s, hi_r)]
+
     def set_vector(self, name, a):
         self._own(name)[:] = a
 
