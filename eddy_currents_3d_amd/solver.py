@@ -61,6 +61,30 @@ _i8 = np.ctypeslib.ndpointer(np.int8, flags="C_CONTIGUOUS")
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch-ROCm bundles its own libamdhip64.so (soname
+    libamdhip64.so.7, the same as /opt/rocm's).  If this library pulled in the system copy first and
+    torch were imported later (dist.py, bench.py), the process would hold two runtimes and torch would
+    see no GPU.  So when torch is installed but not imported yet, load ITS runtime first; our DT_NEEDED
+    then resolves to it by soname.  EC3D_HIP_RUNTIME=system keeps /opt/rocm's (torch-free processes)."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("EC3D_HIP_RUNTIME") == "system":
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if not spec or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load_library(path: str | None = None) -> C.CDLL:
     """dlopen libec3d_hip.so and declare every prototype of include/ec3d_hip.h."""
     global _lib
@@ -70,6 +94,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     if not os.path.exists(p):
         raise EC3DError(f"{p} not built: run `python -m eddy_currents_3d_amd.build` "
                         "(there is no CPU fallback)")
+    _share_hip_runtime_with_torch()
     L = C.CDLL(p)
     hp = C.c_void_p
     L.ec3d_last_error.restype = C.c_char_p
