@@ -120,11 +120,42 @@ __device__ __forceinline__ bool row_owned(const Sweep &sw, int64_t r)
         if (!row_owned(sw_, (r) + 1)) (b) = 0.0;                                               \
     } while (0)
 
+// Tail of one row: s += tval[e] * x[tcol[e]] over the row's slots of its 64-row slice, in stored order.
+// The loads are issued in batches (all values/columns of a batch, then all gathers, then the adds in
+// order): a plain loop is a chain of two dependent global loads per entry, ~1-2 us each, and a 13-entry
+// U row then costs more than the whole banded part of the tile.
+template <int B>
+__device__ __forceinline__ double tail_batch(const MatView &A, const double *__restrict__ x, int64_t e0, int cnt,
+                                             double s)
+{
+    double tv[B], xv[B];
+    int tc[B];
+#pragma unroll
+    for (int j = 0; j < B; ++j) {
+        const bool on = j < cnt;
+        tv[j] = on ? A.tval[e0 + (int64_t)j * EC3D_CHUNK] : 0.0;
+        tc[j] = on ? A.tcol[e0 + (int64_t)j * EC3D_CHUNK] : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < B; ++j) xv[j] = j < cnt ? x[tc[j]] : 0.0;
+#pragma unroll
+    for (int j = 0; j < B; ++j)
+        if (j < cnt) s = s + tv[j] * xv[j];
+    return s;
+}
+
 __device__ __forceinline__ double tail_add(const MatView &A, const double *__restrict__ x, int t, double s)
 {
     const int64_t base = A.chunk_ptr[t >> 6], end = A.chunk_ptr[(t >> 6) + 1];
-    const int lane = t & 63;
-    for (int64_t e = base + lane; e < end; e += EC3D_CHUNK) s = s + A.tval[e] * x[A.tcol[e]];
+    int w = (int)((end - base) >> 6); // slots per row in this slice
+    int64_t e = base + (t & 63);
+    if (w <= 4) return tail_batch<4>(A, x, e, w, s);
+    while (w > 0) {
+        const int c = w < 8 ? w : 8;
+        s = tail_batch<8>(A, x, e, c, s);
+        e += (int64_t)8 * EC3D_CHUNK;
+        w -= 8;
+    }
     return s;
 }
 

@@ -105,7 +105,13 @@ extern "C" int ec3d_destroy(ec3d_handle c)
 {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    // an adopted stream (ec3d_set_stream) may already have been destroyed by its owner: never touch it
+    // here; draining the device covers whatever was enqueued on it
+    if (c->stream != c->own_stream_obj)
+        (void)hipDeviceSynchronize();
+    else
+        (void)hipStreamSynchronize(c->stream);
+    c->stream = c->own_stream_obj;
     ec3d_free_matrix(c);
     if (c->hist) (void)hipFree(c->hist);
     if (c->state) (void)hipFree(c->state);

@@ -69,6 +69,23 @@ class HipSlabOps:
     def context(self):
         return self.torch.cuda.stream(self.stream)
 
+    def close(self):
+        """Detach the library from the torch-owned stream and vectors BEFORE torch frees them."""
+        local = getattr(self, "local", None)
+        if local is not None and getattr(local, "h", None) and local.h.value:
+            try:
+                self.stream.synchronize()
+                local.set_stream(None)
+            finally:
+                local.close()
+        self.local = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def _base(self, name):
         return self.VEC[name] * self.len + self.ghost
 
