@@ -231,6 +231,7 @@ class SlabSolver:
     def __init__(self, ops, rank: int, world: int, k0: int, k1: int):
         self.ops, self.rank, self.world, self.k0, self.k1 = ops, rank, world, k0, k1
         self.n_local = ops.n
+        self._p2p_cache = {}
         self.dist = None
         if world > 1:
             import torch.distributed as dist
@@ -258,11 +259,14 @@ class SlabSolver:
         if self.world == 1:
             return
         d = self.dist
-        p2p = []
-        for direction, send, recv in self.ops.halo_pairs(name):
-            peer = self.rank + direction
-            if 0 <= peer < self.world and send.numel() > 0:
-                p2p += [d.P2POp(d.isend, send, peer), d.P2POp(d.irecv, recv, peer)]
+        p2p = self._p2p_cache.get(name)
+        if p2p is None:  # the views stay valid for the life of the vectors: build the op list once
+            p2p = []
+            for direction, send, recv in self.ops.halo_pairs(name):
+                peer = self.rank + direction
+                if 0 <= peer < self.world and send.numel() > 0:
+                    p2p += [d.P2POp(d.isend, send, peer), d.P2POp(d.irecv, recv, peer)]
+            self._p2p_cache[name] = p2p
         if p2p:
             for req in d.batch_isend_irecv(p2p):
                 req.wait()
