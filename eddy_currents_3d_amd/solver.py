@@ -52,7 +52,7 @@ EXPORTS = ["sprsbcgstabwr_", "ec3d_invalidate", "ec3d_create", "ec3d_destroy", "
            "ec3d_iterate_begin", "ec3d_iterate", "ec3d_set_format", "ec3d_set_stream",
            "ec3d_assemble_poisson_slab", "ec3d_vector_layout", "ec3d_adopt_vectors",
            "ec3d_dist_configure", "ec3d_dist_step", "ec3d_read_state", "ec3d_set_zmarch",
-           "ec3d_rhs_step", "ec3d_post_update", "ec3d_assemble_slab",
+           "ec3d_rhs_step", "ec3d_post_update", "ec3d_assemble_slab", "ec3d_vtk_fields",
            "ec3d_device_synchronize"]
 
 _f64 = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
@@ -117,6 +117,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.ec3d_assemble_slab.argtypes = [hp] + [C.c_int32] * 7 + [_i8, _i32, _f64, C.c_int32, _f64, _f64, C.c_double]
     L.ec3d_rhs_step.argtypes = [hp, C.c_int32, C.c_int32, _i32, _f64]
     L.ec3d_post_update.argtypes = [hp]
+    L.ec3d_vtk_fields.argtypes = [hp, _f64, hp, hp, hp, hp]
     L.ec3d_set_workgroups.argtypes = [hp, C.c_int32]
     L.ec3d_get_matrix_info.argtypes = [hp, C.POINTER(MatrixInfo)]
     L.ec3d_time_kernel.argtypes = [hp, C.c_int, C.c_int32, C.POINTER(C.c_double)]
@@ -322,6 +323,17 @@ class EC3DSolver:
 
     def post_update(self):
         _chk(self.L, self.L.ec3d_post_update(self.h), "ec3d_post_update")
+
+    def vtk_fields(self, delta, ncells: int, conducting: bool):
+        """float32 point vectors of field_N.vtk (src/utilites.f90:222-289) from the resident X, B.
+        Returns dict(A, eddy (None without conductors), source, B), each (ncells, 3)."""
+        mk = lambda: np.empty((ncells, 3), np.float32)
+        fa, fs, fb = mk(), mk(), mk()
+        fe = mk() if conducting else None
+        _chk(self.L, self.L.ec3d_vtk_fields(self.h, np.ascontiguousarray(delta, np.float64), fa.ctypes.data,
+                                            fe.ctypes.data if conducting else None, fs.ctypes.data,
+                                            fb.ctypes.data), "ec3d_vtk_fields")
+        return dict(A=fa, eddy=fe, source=fs, B=fb)
 
     def spmv(self, x):
         y = np.empty(self.n)

@@ -94,6 +94,13 @@ int ec3d_rhs_step(ec3d_handle h, int32_t moving, int32_t nsrc, const int32_t *sr
                   const double *src_value);
 int ec3d_post_update(ec3d_handle h);
 
+/* The four float32 point vectors of the reference's field_N.vtk (writeVtk_field, src/utilites.f90:222-289)
+ * from the resident Uaf (X) and Jaf (B): Field_A, Vector_field_eddy (NULL allowed when there is no
+ * conductor), Vector_field_SOURCE, Vector_field_B = curl A (central differences clamped at the box
+ * faces, :276-289).  Each output: 3*nCells floats, xyz interleaved, cell order nn.  Host byte order. */
+int ec3d_vtk_fields(ec3d_handle h, const double *delta, float *field_A, float *field_eddy,
+                    float *field_source, float *field_B);
+
 /* y = A*x through the device format (src/solvers.f90:54-61), host vectors.  Parity probe. */
 int ec3d_spmv(ec3d_handle h, const double *x, double *y);
 

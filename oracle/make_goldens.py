@@ -105,6 +105,14 @@ def run_reference(vox, names, lattice_dim, adj=(1, 1, 1), max_calls=3, all_matri
                 calls.append(c)
         if not calls:
             raise RuntimeError("reference produced no solver call:\n" + log[-4000:])
+        # the reference's own output files (<DIR>/field_N.vtk, src/utilites.f90:171-293)
+        vtk = {}
+        for root, _, files in os.walk(td):
+            for fn in files:
+                if fn.startswith("field_") and fn.endswith(".vtk"):
+                    with open(os.path.join(root, fn), "rb") as f:
+                        vtk[fn] = f.read()
+        calls[0]["vtk"] = vtk
         return calls, log
     finally:
         shutil.rmtree(td, ignore_errors=True)
@@ -159,6 +167,8 @@ def save(name, **arrs):
 
 def pack_calls(calls):
     d = dict(irow=calls[0]["irow"], jcol=calls[0]["jcol"], valA=calls[0]["valA"],
+             **{"vtk_" + k.replace(".vtk", ""): np.frombuffer(v, np.uint8)
+                for k, v in calls[0].get("vtk", {}).items()},
              iters=np.array([c["iter"] for c in calls], np.int32),
              tol=np.float64(calls[0]["tol"]), itmax=np.int32(calls[0]["itmax"]))
     for s, c in enumerate(calls):
