@@ -205,8 +205,9 @@ def case_g1():
     vox = inp["vox"]
     calls, log = run_reference(**inp)
     geo, geoC, _ = geometry_tables(vox, [], 4)
+    valPHYS = np.zeros((int(geo.max()), 5)); valPHYS[:, 0] = 1.0      # D = 1 everywhere (vxc2data.f90:365-371)
     save("g1_nonconducting_8x7x6", vox=vox, geoPHYS=geo, geoPHYS_C=geoC, delta=np.full(3, 0.005),
-         dt=np.float64(1e-3), BND=np.full((3, 2), -0.95), valPHYS=np.zeros((int(geo.max()), 5)),
+         dt=np.float64(1e-3), BND=np.full((3, 2), -0.95), valPHYS=valPHYS,
          **pack_calls(calls))
     return calls
 

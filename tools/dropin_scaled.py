@@ -20,15 +20,14 @@ ap.add_argument("steps", type=int)
 ap.add_argument("--reference", action="store_true"); ap.add_argument("--ref-steps", type=int, default=1)
 a = ap.parse_args()
 
+from eddy_currents_3d_amd import vxc
 g = np.load(os.path.join(REPO, "tests", "golden", f"g4_{a.case}.npz"))
-vox = np.repeat(np.repeat(np.repeat(g["vox"], a.fz, axis=0), a.fy, axis=1), a.fx, axis=2)
-names = [str(s) for s in g["names"]]
-adj = [float(x) for x in g["adj"]]
-ld = float(str(g["lattice_dim"]))
-# keep the physical size: cell size / factor per axis (Lattice_Dim * Adj, src/vxc2data.f90:103-124)
-adj = (adj[0] / a.fx, adj[1] / a.fy, adj[2] / a.fz)
 # no VTK output during the timed run: JUMP beyond the stop time (src/vxc2data.f90:191-195, EC3D.f90:143-144)
-names = [re.sub(r"(tran\b.*)", r"\1 jump=1000", s, flags=re.I) if re.search(r"\btran\b", s, re.I) else s for s in names]
+names = [re.sub(r"(tran\b.*)", r"\1 jump=1000", str(s), flags=re.I) if re.search(r"\btran\b", str(s), re.I)
+         else str(s) for s in g["names"]]
+base = vxc.VxcModel(g["vox"], names, float(str(g["lattice_dim"])), tuple(float(x) for x in g["adj"]))
+model = vxc.refine(base, a.fx, a.fy, a.fz)   # keeps the physical size: cell size / factor per axis
+vox = model.vox
 sdz, sdy, sdx = vox.shape
 print(f"{a.case} x({a.fx},{a.fy},{a.fz}): grid {sdx}x{sdy}x{sdz} = {vox.size} cells", flush=True)
 
@@ -36,7 +35,7 @@ print(f"{a.case} x({a.fx},{a.fy},{a.fz}): grid {sdx}x{sdy}x{sdz} = {vox.size} ce
 def run(exe, steps, env_extra):
     t0 = time.time()
     td = tempfile.mkdtemp(prefix="ec3d_dropin_")
-    G.write_vxc(os.path.join(td, "in.vxc"), vox, names, repr(ld), tuple(repr(x) for x in adj))
+    vxc.write_vxc(os.path.join(td, "in.vxc"), model, compression="ASCII_READABLE")
     with open(os.path.join(td, "del"), "w") as f:
         f.write("#!/bin/sh\nexit 0\n")
     os.chmod(os.path.join(td, "del"), 0o755)
