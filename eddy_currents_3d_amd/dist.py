@@ -233,9 +233,15 @@ class SlabSolver:
         self.n_local = ops.n
         self._p2p_cache = {}
         self.dist = None
+        self.host_staged = False
         if world > 1:
+            import torch
             import torch.distributed as dist
             self.dist = dist
+            self.torch = torch
+            # RCCL moves device memory directly; gloo (CPU tests, single-GPU rehearsals) cannot send
+            # or gather GPU tensors, so device data is staged through the host for it
+            self.host_staged = dist.get_backend() == "gloo" and getattr(ops.lsum, "is_cuda", False)
         else:
             try:  # a 1-rank process group (rehearsal): still go through the collective
                 import torch.distributed as dist
@@ -267,14 +273,32 @@ class SlabSolver:
                 if 0 <= peer < self.world and send.numel() > 0:
                     p2p += [d.P2POp(d.isend, send, peer), d.P2POp(d.irecv, recv, peer)]
             self._p2p_cache[name] = p2p
-        if p2p:
-            for req in d.batch_isend_irecv(p2p):
+        if not p2p:
+            return
+        if self.host_staged:  # gloo has no GPU send/recv: stage the planes through pinned-free host copies
+            pairs = [(p2p[i].tensor, p2p[i + 1].tensor, p2p[i].peer) for i in range(0, len(p2p), 2)]
+            sends = [t.cpu() for t, _, _ in pairs]
+            recvs = [self.torch.empty(r.shape, dtype=r.dtype) for _, r, _ in pairs]
+            ops = []
+            for (_, _, peer), sc, rc in zip(pairs, sends, recvs):
+                ops += [d.P2POp(d.isend, sc, peer), d.P2POp(d.irecv, rc, peer)]
+            for req in d.batch_isend_irecv(ops):
                 req.wait()
+            for (_, r, _), rc in zip(pairs, recvs):
+                r.copy_(rc)
+            return
+        for req in d.batch_isend_irecv(p2p):
+            req.wait()
 
     def gather(self):
         """gsum[g*8 + slot] <- rank g's lsum[slot]; summed in rank order inside the next kernel."""
         if self.dist is None:
             self.ops.gsum.copy_(self.ops.lsum)
+        elif self.host_staged:
+            l_cpu = self.ops.lsum.cpu()
+            g_cpu = self.torch.empty(self.world * NSLOT, dtype=l_cpu.dtype)
+            self.dist.all_gather_into_tensor(g_cpu, l_cpu)
+            self.ops.gsum.copy_(g_cpu)
         else:
             self.dist.all_gather_into_tensor(self.ops.gsum, self.ops.lsum)
 

@@ -30,7 +30,8 @@ def _worker(rank, world, port, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
     try:
         s = SlabSolver.poisson_cube(N, rank, world, device=0)
         s.set_rhs(bar_rhs(N, s.k0, s.k1), np.zeros(s.n_local))
