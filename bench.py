@@ -181,7 +181,14 @@ def main():
         ms_per_step = elapsed * 1e3 / K
         value = n_global * K / elapsed
         rows = int(info.n)                       # rows one launch processes on this rank
-        fmt_bytes = DICT_BYTES if info.dict_classes > 0 else SURVEY_BYTES
+        fmt_bytes = dict(DICT_BYTES if info.dict_classes > 0 else SURVEY_BYTES)
+        survey_bytes = dict(SURVEY_BYTES)
+        if geom.ss_by_spmv:                      # K2 fused into K3 (single GPU): one launch, S not re-read
+            kernel_ms = dict(kernel_ms)
+            kernel_ms["k3"] += kernel_ms.pop("k2")
+            fmt_bytes["k3"] += fmt_bytes.pop("k2") - 8
+            survey_bytes["k3"] += survey_bytes.pop("k2")
+            KERNEL_NAMES["k3"] = "k23_s_spmv_dots (S = R - alpha*AP on the fly, AS = A*S, S.S, AS.S, AS.AS)"
         dom = max(kernel_ms, key=kernel_ms.get)   # dominant kernel by measured share
         tr = latest_traffic()
         use_tr = bool(tr) and tr.get("grid") == N and tr.get("n_gpus", 1) == world and \
@@ -190,8 +197,8 @@ def main():
         for k, ms in kernel_ms.items():
             kernels[k] = {"ms": ms, "share": ms / sum(kernel_ms.values()),
                           "bytes_per_row": fmt_bytes[k], "GBps": fmt_bytes[k] * rows / ms / 1e6,
-                          "survey_bytes_per_row": SURVEY_BYTES[k],
-                          "survey_GBps": SURVEY_BYTES[k] * rows / ms / 1e6}
+                          "survey_bytes_per_row": survey_bytes[k],
+                          "survey_GBps": survey_bytes[k] * rows / ms / 1e6}
         achieved = fmt_bytes[dom] * rows / (kernel_ms[dom] * 1e-3) / 1e9
         traffic = tr["kernels"].get(dom, {}).get("hbm_bytes") if use_tr else None
         out = {

@@ -120,13 +120,32 @@ __device__ __forceinline__ bool row_owned(const Sweep &sw, int64_t r)
         if (!row_owned(sw_, (r) + 1)) (b) = 0.0;                                               \
     } while (0)
 
+// The vector a row kernel multiplies by, as an accessor: a plain vector, or S = R - alpha*AP formed on
+// the fly (K2 fused into K3: S is produced and consumed by the same kernel, bit-identical to the
+// stored S because it is the same expression on the same operands).
+struct VecPlain {
+    const double *__restrict__ x;
+    __device__ __forceinline__ d2 pair(int64_t i) const { return *reinterpret_cast<const d2u *>(x + i); }
+    __device__ __forceinline__ double at(int64_t i) const { return x[i]; }
+};
+struct VecS {
+    const double *__restrict__ r;
+    const double *__restrict__ ap;
+    double alpha;
+    __device__ __forceinline__ d2 pair(int64_t i) const
+    {
+        const d2 q = *reinterpret_cast<const d2u *>(r + i), a = *reinterpret_cast<const d2u *>(ap + i);
+        return d2{q.x - alpha * a.x, q.y - alpha * a.y};
+    }
+    __device__ __forceinline__ double at(int64_t i) const { return r[i] - alpha * ap[i]; }
+};
+
 // Tail of one row: s += tval[e] * x[tcol[e]] over the row's slots of its 64-row slice, in stored order.
 // The loads are issued in batches (all values/columns of a batch, then all gathers, then the adds in
 // order): a plain loop is a chain of two dependent global loads per entry, ~1-2 us each, and a 13-entry
 // U row then costs more than the whole banded part of the tile.
-template <int B>
-__device__ __forceinline__ double tail_batch(const MatView &A, const double *__restrict__ x, int64_t e0, int cnt,
-                                             double s)
+template <int B, class V>
+__device__ __forceinline__ double tail_batch(const MatView &A, const V &x, int64_t e0, int cnt, double s)
 {
     double tv[B], xv[B];
     int tc[B];
@@ -137,22 +156,23 @@ __device__ __forceinline__ double tail_batch(const MatView &A, const double *__r
         tc[j] = on ? A.tcol[e0 + (int64_t)j * EC3D_CHUNK] : 0;
     }
 #pragma unroll
-    for (int j = 0; j < B; ++j) xv[j] = j < cnt ? x[tc[j]] : 0.0;
+    for (int j = 0; j < B; ++j) xv[j] = j < cnt ? x.at(tc[j]) : 0.0;
 #pragma unroll
     for (int j = 0; j < B; ++j)
         if (j < cnt) s = s + tv[j] * xv[j];
     return s;
 }
 
-__device__ __forceinline__ double tail_add(const MatView &A, const double *__restrict__ x, int t, double s)
+template <class V>
+__device__ __forceinline__ double tail_add(const MatView &A, const V &x, int t, double s)
 {
     const int64_t base = A.chunk_ptr[t >> 6], end = A.chunk_ptr[(t >> 6) + 1];
     int w = (int)((end - base) >> 6); // slots per row in this slice
     int64_t e = base + (t & 63);
-    if (w <= 4) return tail_batch<4>(A, x, e, w, s);
+    if (w <= 4) return tail_batch<4, V>(A, x, e, w, s);
     while (w > 0) {
         const int c = w < 8 ? w : 8;
-        s = tail_batch<8>(A, x, e, c, s);
+        s = tail_batch<8, V>(A, x, e, c, s);
         e += (int64_t)8 * EC3D_CHUNK;
         w -= 8;
     }
@@ -184,57 +204,54 @@ struct ZRegs {
 
 // rows r, r+1 of A*x (src/solvers.f90:58-59): bands in ascending column order, then the tail.
 // ZM: band 0 / 3 / 6 (offsets -kdz, 0, +kdz) come from / go to the registers `z`.
-template <int FMT, bool ZM>
-__device__ __forceinline__ void spmv_pair(const MatView &A, const double *tbl, const double *__restrict__ x,
-                                          int64_t r, int64_t tile, bool first, ZRegs &z, double &s0, double &s1)
+// `ctr` returns x[r], x[r+1] (the centre band's operand).
+template <int FMT, bool ZM, class V>
+__device__ __forceinline__ void spmv_pair(const MatView &A, const double *tbl, const V &x, int64_t r, int64_t tile,
+                                          bool first, ZRegs &z, double &s0, double &s1, d2 &ctr)
 {
-    if (FMT == FMT_DIA7) {
-        d2 c[7], xv[7];
-#pragma unroll
-        for (int b = 0; b < 7; ++b) c[b] = *reinterpret_cast<const d2 *>(A.band[b] + r);
-#pragma unroll
-        for (int b = 0; b < 7; ++b)
-            if (!ZM || (b != 0 && b != 3) || first) xv[b] = *reinterpret_cast<const d2u *>(x + r + A.off[b]);
-        if (ZM) {
-            if (!first) { xv[0] = z.xm; xv[3] = z.xc; }
-            z.xm = xv[3];
-            z.xc = xv[6];
-        }
-        s0 = c[0].x * xv[0].x;
-        s1 = c[0].y * xv[0].y;
-#pragma unroll
-        for (int b = 1; b < 7; ++b) {
-            s0 = s0 + c[b].x * xv[b].x;
-            s1 = s1 + c[b].y * xv[b].y;
-        }
-    } else if (FMT == FMT_DICT7) {
+    if (FMT == FMT_DIA7 || FMT == FMT_DICT7) {
         d2 xv[7];
-        const unsigned short cc = *reinterpret_cast<const unsigned short *>(A.cls + r);
 #pragma unroll
         for (int b = 0; b < 7; ++b)
-            if (!ZM || (b != 0 && b != 3) || first) xv[b] = *reinterpret_cast<const d2u *>(x + r + A.off[b]);
+            if (!ZM || (b != 0 && b != 3) || first) xv[b] = x.pair(r + A.off[b]);
         if (ZM) {
             if (!first) { xv[0] = z.xm; xv[3] = z.xc; }
             z.xm = xv[3];
             z.xc = xv[6];
         }
-        const double *t0 = tbl + (cc & 0xFF) * 7, *t1 = tbl + (cc >> 8) * 7;
-        s0 = t0[0] * xv[0].x;
-        s1 = t1[0] * xv[0].y;
+        ctr = xv[3];
+        if (FMT == FMT_DIA7) {
+            d2 c[7];
 #pragma unroll
-        for (int b = 1; b < 7; ++b) {
-            s0 = s0 + t0[b] * xv[b].x;
-            s1 = s1 + t1[b] * xv[b].y;
+            for (int b = 0; b < 7; ++b) c[b] = *reinterpret_cast<const d2 *>(A.band[b] + r);
+            s0 = c[0].x * xv[0].x;
+            s1 = c[0].y * xv[0].y;
+#pragma unroll
+            for (int b = 1; b < 7; ++b) {
+                s0 = s0 + c[b].x * xv[b].x;
+                s1 = s1 + c[b].y * xv[b].y;
+            }
+        } else {
+            const unsigned short cc = *reinterpret_cast<const unsigned short *>(A.cls + r);
+            const double *t0 = tbl + (cc & 0xFF) * 7, *t1 = tbl + (cc >> 8) * 7;
+            s0 = t0[0] * xv[0].x;
+            s1 = t1[0] * xv[0].y;
+#pragma unroll
+            for (int b = 1; b < 7; ++b) {
+                s0 = s0 + t0[b] * xv[b].x;
+                s1 = s1 + t1[b] * xv[b].y;
+            }
         }
     } else {
         s0 = 0.0;
         s1 = 0.0;
         for (int b = 0; b < A.nb; ++b) {
-            d2 c = *reinterpret_cast<const d2 *>(A.band[b] + r);
-            d2u xv = *reinterpret_cast<const d2u *>(x + r + A.off[b]);
+            const d2 c = *reinterpret_cast<const d2 *>(A.band[b] + r);
+            const d2 xv = x.pair(r + A.off[b]);
             s0 = s0 + c.x * xv.x;
             s1 = s1 + c.y * xv.y;
         }
+        ctr = x.pair(r);
     }
     if (A.has_tail && A.tile_flag[tile]) {
         i2 t = *reinterpret_cast<const i2 *>(A.tail_id + r);
@@ -264,7 +281,8 @@ __global__ __launch_bounds__(EC3D_THREADS) void k_spmv(MatView A, Sweep sw, cons
     ZRegs zr;
     EC3D_SWEEP_BEGIN
     double s0, s1;
-    spmv_pair<FMT, ZM>(A, tbl, x, r, tile, first_, zr, s0, s1);
+    d2 ctr;
+    spmv_pair<FMT, ZM>(A, tbl, VecPlain{x}, r, tile, first_, zr, s0, s1, ctr);
     store2<NT>(y, r, sw.n, s0, s1);
     EC3D_SWEEP_END
 }
@@ -283,7 +301,8 @@ __global__ __launch_bounds__(EC3D_THREADS) void k_residual(MatView A, Sweep sw, 
     double acc[2] = {0.0, 0.0};
     EC3D_SWEEP_BEGIN
     double s0, s1;
-    spmv_pair<FMT, ZM>(A, tbl, x, r, tile, first_, zr, s0, s1);
+    d2 ctr;
+    spmv_pair<FMT, ZM>(A, tbl, VecPlain{x}, r, tile, first_, zr, s0, s1, ctr);
     d2 bv = load2<NT>(b + r);
     double e0 = bv.x - s0, e1 = bv.y - s1, b0 = bv.x, b1 = bv.y;
     store2<NT>(rv, r, sw.n, e0, e1);
@@ -352,7 +371,8 @@ __global__ __launch_bounds__(EC3D_THREADS) void k1_spmv_dot(MatView A, Sweep sw,
     double acc[1] = {0.0};
     EC3D_SWEEP_BEGIN
     double s0, s1;
-    spmv_pair<FMT, ZM>(A, tbl, p, r, tile, first_, zr, s0, s1);
+    d2 ctr;
+    spmv_pair<FMT, ZM>(A, tbl, VecPlain{p}, r, tile, first_, zr, s0, s1, ctr);
     d2 q = load2<NT>(r0 + r);
     store2<NT>(ap, r, sw.n, s0, s1);
     EC3D_MASK2(r, sw, s0, s1);
@@ -407,8 +427,8 @@ __global__ __launch_bounds__(EC3D_THREADS) void k3_spmv_dots(MatView A, Sweep sw
     double acc[2] = {0.0, 0.0};
     EC3D_SWEEP_BEGIN
     double s0, s1;
-    spmv_pair<FMT, ZM>(A, tbl, sv, r, tile, first_, zr, s0, s1);
-    d2 q = *reinterpret_cast<const d2 *>(sv + r);
+    d2 q;
+    spmv_pair<FMT, ZM>(A, tbl, VecPlain{sv}, r, tile, first_, zr, s0, s1, q);
     store2<NT>(as, r, sw.n, s0, s1);
     EC3D_MASK2(r, sw, s0, s1);
     acc[0] = acc[0] + s0 * q.x;
@@ -420,6 +440,52 @@ __global__ __launch_bounds__(EC3D_THREADS) void k3_spmv_dots(MatView A, Sweep sw
     if (threadIdx.x == 0) {
         part[P_D2 * sw.pstride + blockIdx.x] = acc[0];
         part[P_D3 * sw.pstride + blockIdx.x] = acc[1];
+    }
+}
+
+// K2+K3 fused (single GPU): alpha = rr0/(AP·R0) ; S = R - alpha*AP formed on the fly for the 7 stencil
+// points (and the tail columns) ; AS = A S ; S stored once ; partials S·S, AS·S, AS·AS.
+// Saves the S round trip of K2 -> K3 (8 B/row) and one launch; same products, same order.
+template <int FMT, bool NT, bool ZM>
+__global__ __launch_bounds__(EC3D_THREADS) void k23_s_spmv_dots(MatView A, Sweep sw, RedSrc src, SolverState *st,
+                                                                int it, const double *__restrict__ rv,
+                                                                const double *__restrict__ ap,
+                                                                double *__restrict__ sv, double *__restrict__ as,
+                                                                double *__restrict__ part)
+{
+    __shared__ double lds[12];
+    EC3D_TBL_DECL;
+    if (st->stop_iter < it) return;
+    const int slot[1] = {P_D1};
+    double d[1];
+    reduce_partials<1>(src, slot, d, lds);
+    const double alpha = st->rr0[it & 1] / d[0];
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->alpha = alpha;
+    stage_table<FMT>(A, tbl);
+    ZRegs zr;
+    const VecS S{rv, ap, alpha};
+    double acc[3] = {0.0, 0.0, 0.0};
+    EC3D_SWEEP_BEGIN
+    double s0, s1;
+    d2 q;
+    spmv_pair<FMT, ZM>(A, tbl, S, r, tile, first_, zr, s0, s1, q);
+    store2<NT>(sv, r, sw.n, q.x, q.y);
+    store2<NT>(as, r, sw.n, s0, s1);
+    double q0 = q.x, q1 = q.y;
+    EC3D_MASK2(r, sw, q0, q1);
+    EC3D_MASK2(r, sw, s0, s1);
+    acc[0] = acc[0] + q0 * q0;
+    acc[0] = acc[0] + q1 * q1;
+    acc[1] = acc[1] + s0 * q0;
+    acc[1] = acc[1] + s1 * q1;
+    acc[2] = acc[2] + s0 * s0;
+    acc[2] = acc[2] + s1 * s1;
+    EC3D_SWEEP_END
+    block_sum<3>(acc, lds);
+    if (threadIdx.x == 0) {
+        part[P_SS * sw.pstride + blockIdx.x] = acc[0];
+        part[P_D2 * sw.pstride + blockIdx.x] = acc[1];
+        part[P_D3 * sw.pstride + blockIdx.x] = acc[2];
     }
 }
 
@@ -603,6 +669,12 @@ void ec3d_launch_k3(const MatView &A, const Sweep &sw, SolverState *st, int it, 
                     double *part, hipStream_t s)
 {
     EC3D_DISPATCH(A, k3_spmv_dots, A, sw, st, it, sv, as, part);
+}
+
+void ec3d_launch_k23(const MatView &A, const Sweep &sw, const RedSrc &src, SolverState *st, int it, const double *r,
+                     const double *ap, double *sv, double *as, double *part, hipStream_t s)
+{
+    EC3D_DISPATCH(A, k23_s_spmv_dots, A, sw, src, st, it, r, ap, sv, as, part);
 }
 
 void ec3d_launch_k4(const Sweep &sw, const RedSrc &src_ss, const RedSrc &src, SolverState *st, int it,
