@@ -183,12 +183,6 @@ def main():
         rows = int(info.n)                       # rows one launch processes on this rank
         fmt_bytes = dict(DICT_BYTES if info.dict_classes > 0 else SURVEY_BYTES)
         survey_bytes = dict(SURVEY_BYTES)
-        if geom.ss_by_spmv:                      # K2 fused into K3 (single GPU): one launch, S not re-read
-            kernel_ms = dict(kernel_ms)
-            kernel_ms["k3"] += kernel_ms.pop("k2")
-            fmt_bytes["k3"] += fmt_bytes.pop("k2") - 8
-            survey_bytes["k3"] += survey_bytes.pop("k2")
-            KERNEL_NAMES["k3"] = "k23_s_spmv_dots (S = R - alpha*AP on the fly, AS = A*S, S.S, AS.S, AS.AS)"
         dom = max(kernel_ms, key=kernel_ms.get)   # dominant kernel by measured share
         tr = latest_traffic()
         use_tr = bool(tr) and tr.get("grid") == N and tr.get("n_gpus", 1) == world and \

@@ -35,6 +35,7 @@ struct MatView {
     const uint8_t *cls; // [n_pad]
     const double *table;
     int ncls;
+    int pm1; // bands 2 and 4 of a 7-band operator are the offsets -1 and +1
 };
 
 // where a kernel finds the partial sums it has to finish: value i of slot s is
@@ -131,7 +132,7 @@ struct ec3d_ctx {
     int nblk_request = 0;
     int nt_request = -1; // -1 auto, 0/1 forced (EC3D_NT)
     int zm_request = 1;  // z-marching SpMV map when the grid allows it (EC3D_ZMARCH)
-    int fuse_request = 1; // K2 fused into K3 on a single GPU (EC3D_FUSE)
+    int shuffle_request = 1; // +-1 neighbours by lane shuffle (EC3D_SHUFFLE)
     double *partials = nullptr; // 8 * nblk doubles
     SolverState *state = nullptr;
     SolverState *state_pinned = nullptr; // 2 slots
@@ -193,8 +194,6 @@ void ec3d_launch_k2(const Sweep &sw, const RedSrc &src, SolverState *st, int it,
                     double *sv, double *part, hipStream_t s);
 void ec3d_launch_k3(const MatView &A, const Sweep &sw, SolverState *st, int it, const double *sv, double *as,
                     double *part, hipStream_t s);
-void ec3d_launch_k23(const MatView &A, const Sweep &sw, const RedSrc &src, SolverState *st, int it, const double *r,
-                     const double *ap, double *sv, double *as, double *part, hipStream_t s);
 void ec3d_launch_k4(const Sweep &sw, const RedSrc &src_ss, const RedSrc &src, SolverState *st, int it,
                     const double *p, const double *sv, const double *as, const double *r0, double *x, double *r,
                     double *part, double *hist, int64_t hist_cap, hipStream_t s);

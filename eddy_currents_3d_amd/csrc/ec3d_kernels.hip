@@ -120,26 +120,13 @@ __device__ __forceinline__ bool row_owned(const Sweep &sw, int64_t r)
         if (!row_owned(sw_, (r) + 1)) (b) = 0.0;                                               \
     } while (0)
 
-// The vector a row kernel multiplies by, as an accessor: a plain vector, or S = R - alpha*AP formed on
-// the fly (K2 fused into K3: S is produced and consumed by the same kernel, bit-identical to the
-// stored S because it is the same expression on the same operands).
+// The vector a row kernel multiplies by, behind a small accessor (pair = two consecutive entries from
+// an 8-byte-aligned address, at = one gathered entry).
 struct VecPlain {
     const double *__restrict__ x;
     __device__ __forceinline__ d2 pair(int64_t i) const { return *reinterpret_cast<const d2u *>(x + i); }
     __device__ __forceinline__ double at(int64_t i) const { return x[i]; }
 };
-struct VecS {
-    const double *__restrict__ r;
-    const double *__restrict__ ap;
-    double alpha;
-    __device__ __forceinline__ d2 pair(int64_t i) const
-    {
-        const d2 q = *reinterpret_cast<const d2u *>(r + i), a = *reinterpret_cast<const d2u *>(ap + i);
-        return d2{q.x - alpha * a.x, q.y - alpha * a.y};
-    }
-    __device__ __forceinline__ double at(int64_t i) const { return r[i] - alpha * ap[i]; }
-};
-
 // Tail of one row: s += tval[e] * x[tcol[e]] over the row's slots of its 64-row slice, in stored order.
 // The loads are issued in batches (all values/columns of a batch, then all gathers, then the adds in
 // order): a plain loop is a chain of two dependent global loads per entry, ~1-2 us each, and a 13-entry
@@ -211,15 +198,31 @@ __device__ __forceinline__ void spmv_pair(const MatView &A, const double *tbl, c
 {
     if (FMT == FMT_DIA7 || FMT == FMT_DICT7) {
         d2 xv[7];
+        // the +-1 neighbours (bands 2 and 4 of the 7-point operator) are the centre pairs of the
+        // adjacent lanes: take them by lane shuffle instead of two unaligned 16-byte loads; only the
+        // first/last lane of a wave reads its outer neighbour from memory.  The SpMV kernels are
+        // bound by L1/TA load issue, not by HBM, so 3 full-wave loads per step instead of 5 matter.
+        const bool pm1 = A.pm1 != 0;
 #pragma unroll
-        for (int b = 0; b < 7; ++b)
-            if (!ZM || (b != 0 && b != 3) || first) xv[b] = x.pair(r + A.off[b]);
+        for (int b = 0; b < 7; ++b) {
+            if (ZM && (b == 0 || b == 3) && !first) continue;
+            if (pm1 && (b == 2 || b == 4)) continue;
+            xv[b] = x.pair(r + A.off[b]);
+        }
         if (ZM) {
             if (!first) { xv[0] = z.xm; xv[3] = z.xc; }
             z.xm = xv[3];
             z.xc = xv[6];
         }
         ctr = xv[3];
+        if (pm1) {
+            const int lane = threadIdx.x & 63;
+            double left = __shfl_up(ctr.y, 1, 64), right = __shfl_down(ctr.x, 1, 64);
+            if (lane == 0) left = x.at(r - 1);
+            if (lane == 63) right = x.at(r + 2);
+            xv[2] = d2{left, ctr.x};
+            xv[4] = d2{ctr.y, right};
+        }
         if (FMT == FMT_DIA7) {
             d2 c[7];
 #pragma unroll
@@ -443,52 +446,6 @@ __global__ __launch_bounds__(EC3D_THREADS) void k3_spmv_dots(MatView A, Sweep sw
     }
 }
 
-// K2+K3 fused (single GPU): alpha = rr0/(AP·R0) ; S = R - alpha*AP formed on the fly for the 7 stencil
-// points (and the tail columns) ; AS = A S ; S stored once ; partials S·S, AS·S, AS·AS.
-// Saves the S round trip of K2 -> K3 (8 B/row) and one launch; same products, same order.
-template <int FMT, bool NT, bool ZM>
-__global__ __launch_bounds__(EC3D_THREADS) void k23_s_spmv_dots(MatView A, Sweep sw, RedSrc src, SolverState *st,
-                                                                int it, const double *__restrict__ rv,
-                                                                const double *__restrict__ ap,
-                                                                double *__restrict__ sv, double *__restrict__ as,
-                                                                double *__restrict__ part)
-{
-    __shared__ double lds[12];
-    EC3D_TBL_DECL;
-    if (st->stop_iter < it) return;
-    const int slot[1] = {P_D1};
-    double d[1];
-    reduce_partials<1>(src, slot, d, lds);
-    const double alpha = st->rr0[it & 1] / d[0];
-    if (blockIdx.x == 0 && threadIdx.x == 0) st->alpha = alpha;
-    stage_table<FMT>(A, tbl);
-    ZRegs zr;
-    const VecS S{rv, ap, alpha};
-    double acc[3] = {0.0, 0.0, 0.0};
-    EC3D_SWEEP_BEGIN
-    double s0, s1;
-    d2 q;
-    spmv_pair<FMT, ZM>(A, tbl, S, r, tile, first_, zr, s0, s1, q);
-    store2<NT>(sv, r, sw.n, q.x, q.y);
-    store2<NT>(as, r, sw.n, s0, s1);
-    double q0 = q.x, q1 = q.y;
-    EC3D_MASK2(r, sw, q0, q1);
-    EC3D_MASK2(r, sw, s0, s1);
-    acc[0] = acc[0] + q0 * q0;
-    acc[0] = acc[0] + q1 * q1;
-    acc[1] = acc[1] + s0 * q0;
-    acc[1] = acc[1] + s1 * q1;
-    acc[2] = acc[2] + s0 * s0;
-    acc[2] = acc[2] + s1 * s1;
-    EC3D_SWEEP_END
-    block_sum<3>(acc, lds);
-    if (threadIdx.x == 0) {
-        part[P_SS * sw.pstride + blockIdx.x] = acc[0];
-        part[P_D2 * sw.pstride + blockIdx.x] = acc[1];
-        part[P_D3 * sw.pstride + blockIdx.x] = acc[2];
-    }
-}
-
 // K4: if ‖S‖/Bnorm < tol: X += alpha*P, exit (src/solvers.f90:34-38); else
 //     omega = (AS·S)/(AS·AS) ; X = X + alpha*P + omega*S ; R = S - omega*AS ;
 //     partials R·R and R·R0   (:40-44)
@@ -669,12 +626,6 @@ void ec3d_launch_k3(const MatView &A, const Sweep &sw, SolverState *st, int it, 
                     double *part, hipStream_t s)
 {
     EC3D_DISPATCH(A, k3_spmv_dots, A, sw, st, it, sv, as, part);
-}
-
-void ec3d_launch_k23(const MatView &A, const Sweep &sw, const RedSrc &src, SolverState *st, int it, const double *r,
-                     const double *ap, double *sv, double *as, double *part, hipStream_t s)
-{
-    EC3D_DISPATCH(A, k23_s_spmv_dots, A, sw, src, st, it, r, ap, sv, as, part);
 }
 
 void ec3d_launch_k4(const Sweep &sw, const RedSrc &src_ss, const RedSrc &src, SolverState *st, int it,

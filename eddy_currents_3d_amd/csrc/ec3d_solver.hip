@@ -19,7 +19,6 @@ void ec3d_set_error(const std::string &msg) { g_err = msg; }
 extern "C" const char *ec3d_last_error(void) { return g_err.c_str(); }
 
 static int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
-static bool ec3d_fused(const ec3d_ctx *c);
 
 MatView DevMatrix::view() const
 {
@@ -33,6 +32,8 @@ MatView DevMatrix::view() const
     v.cls = cls;
     v.table = table;
     v.ncls = ncls;
+    static const bool shuffle_off = getenv("EC3D_SHUFFLE") && atoi(getenv("EC3D_SHUFFLE")) == 0;
+    v.pm1 = (nb == 7 && off[2] == -1 && off[4] == 1 && !shuffle_off) ? 1 : 0;
     v.has_tail = ntail > 0 && !getenv("EC3D_EXPERIMENT_NOTAIL"); // experiment knob: timing only, wrong results
     v.tail_id = tail_id;
     v.tile_flag = tile_flag;
@@ -67,7 +68,6 @@ extern "C" int ec3d_create(ec3d_handle *h, int device)
     if (const char *e = getenv("EC3D_NBLK")) c->nblk_request = atoi(e);
     if (const char *e = getenv("EC3D_DICT")) c->use_dict = atoi(e) != 0;
     if (const char *e = getenv("EC3D_NT")) c->nt_request = atoi(e);
-    if (const char *e = getenv("EC3D_FUSE")) c->fuse_request = atoi(e);
     *h = c;
     return 0;
 }
@@ -414,13 +414,6 @@ extern "C" int ec3d_get_reduction_geometry(ec3d_handle c, int which, ec3d_geom *
     g->xcd_group = sw.S;
     g->zm_tpp = sw.zm_tpp;
     g->zm_pps = sw.zm_pps;
-    g->ss_by_spmv = ec3d_fused(c) ? 1 : 0;
-    return 0;
-}
-
-extern "C" int ec3d_set_fusion(ec3d_handle c, int on)
-{
-    c->fuse_request = on;
     return 0;
 }
 
@@ -512,9 +505,6 @@ static RedSrc part_of(const ec3d_ctx *c, bool produced_by_spmv)
     return RedSrc{c->partials, produced_by_spmv ? c->sweep_s.nblk : c->sweep.nblk, 1, c->sweep.pstride};
 }
 
-// K2 fused into K3: single-GPU only (a z-slab needs the halo exchange of S between the two)
-static bool ec3d_fused(const ec3d_ctx *c) { return c->fuse_request != 0 && !c->dist && c->halo == 0; }
-
 // the five launches of one iteration; `k` selects one of them (1..5) or all (0)
 static void launch_stage(ec3d_ctx *c, const MatView &A, int it, int k)
 {
@@ -523,20 +513,12 @@ static void launch_stage(ec3d_ctx *c, const MatView &A, int it, int k)
     hipStream_t s = c->stream;
     if (k == 0 || k == 1)
         ec3d_launch_k1(A, ss, c->state, it, v[EC3D_VEC_P], v[EC3D_VEC_R0], v[EC3D_VEC_AP], c->partials, s);
-    const bool fused = ec3d_fused(c);
-    if (fused) { // K2+K3 in one launch: S.S is then produced by an SpMV-type kernel
-        if (k == 0 || k == 3)
-            ec3d_launch_k23(A, ss, src_of(c, true), c->state, it, v[EC3D_VEC_R], v[EC3D_VEC_AP], v[EC3D_VEC_S],
-                            v[EC3D_VEC_AS], c->partials, s);
-    } else {
-        if (k == 0 || k == 2)
-            ec3d_launch_k2(sw, src_of(c, true), c->state, it, v[EC3D_VEC_R], v[EC3D_VEC_AP], v[EC3D_VEC_S],
-                           c->partials, s);
-        if (k == 0 || k == 3)
-            ec3d_launch_k3(A, ss, c->state, it, v[EC3D_VEC_S], v[EC3D_VEC_AS], c->partials, s);
-    }
+    if (k == 0 || k == 2)
+        ec3d_launch_k2(sw, src_of(c, true), c->state, it, v[EC3D_VEC_R], v[EC3D_VEC_AP], v[EC3D_VEC_S], c->partials, s);
+    if (k == 0 || k == 3)
+        ec3d_launch_k3(A, ss, c->state, it, v[EC3D_VEC_S], v[EC3D_VEC_AS], c->partials, s);
     if (k == 0 || k == 4)
-        ec3d_launch_k4(sw, src_of(c, fused), src_of(c, true), c->state, it, v[EC3D_VEC_P], v[EC3D_VEC_S],
+        ec3d_launch_k4(sw, src_of(c, false), src_of(c, true), c->state, it, v[EC3D_VEC_P], v[EC3D_VEC_S],
                        v[EC3D_VEC_AS], v[EC3D_VEC_R0], v[EC3D_VEC_X], v[EC3D_VEC_R], c->partials, c->hist,
                        c->hist_cap, s);
     if (k == 0 || k == 5)

@@ -29,7 +29,7 @@ class EC3DError(RuntimeError):
 class Geom(C.Structure):
     _fields_ = [("n_pad", C.c_int32), ("tile", C.c_int32), ("nblk", C.c_int32),
                 ("threads", C.c_int32), ("xcd_group", C.c_int32), ("zm_tpp", C.c_int32),
-                ("zm_pps", C.c_int32), ("ss_by_spmv", C.c_int32)]
+                ("zm_pps", C.c_int32)]
 
 
 class MatrixInfo(C.Structure):
@@ -52,7 +52,7 @@ EXPORTS = ["sprsbcgstabwr_", "ec3d_invalidate", "ec3d_create", "ec3d_destroy", "
            "ec3d_iterate_begin", "ec3d_iterate", "ec3d_set_format", "ec3d_set_stream",
            "ec3d_assemble_poisson_slab", "ec3d_vector_layout", "ec3d_adopt_vectors",
            "ec3d_dist_configure", "ec3d_dist_step", "ec3d_read_state", "ec3d_set_zmarch",
-           "ec3d_rhs_step", "ec3d_post_update", "ec3d_assemble_slab", "ec3d_vtk_fields", "ec3d_set_fusion",
+           "ec3d_rhs_step", "ec3d_post_update", "ec3d_assemble_slab", "ec3d_vtk_fields",
            "ec3d_device_synchronize"]
 
 _f64 = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
@@ -114,7 +114,6 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.ec3d_get_cel_bnd.argtypes = [hp, C.c_int, C.POINTER(C.c_int32), hp]
     L.ec3d_get_reduction_geometry.argtypes = [hp, C.c_int, C.POINTER(Geom)]
     L.ec3d_set_zmarch.argtypes = [hp, C.c_int]
-    L.ec3d_set_fusion.argtypes = [hp, C.c_int]
     L.ec3d_assemble_slab.argtypes = [hp] + [C.c_int32] * 7 + [_i8, _i32, _f64, C.c_int32, _f64, _f64, C.c_double]
     L.ec3d_rhs_step.argtypes = [hp, C.c_int32, C.c_int32, _i32, _f64]
     L.ec3d_post_update.argtypes = [hp]
@@ -274,9 +273,6 @@ class EC3DSolver:
         g = Geom()
         _chk(self.L, self.L.ec3d_get_reduction_geometry(self.h, which, C.byref(g)), "ec3d_get_reduction_geometry")
         return g
-
-    def set_fusion(self, on: bool):
-        _chk(self.L, self.L.ec3d_set_fusion(self.h, int(bool(on))), "ec3d_set_fusion")
 
     def set_zmarch(self, on: bool):
         _chk(self.L, self.L.ec3d_set_zmarch(self.h, int(bool(on))), "ec3d_set_zmarch")

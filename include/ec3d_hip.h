@@ -169,16 +169,12 @@ typedef struct {
     int32_t xcd_group; /* S in the XCD-aware blockIdx -> tile map (0: plain grid stride) */
     int32_t zm_tpp;    /* > 0: z-marching map, tiles per xy-plane                          */
     int32_t zm_pps;    /*      planes per z segment                                        */
-    int32_t ss_by_spmv; /* 1: S.S is summed by the fused K2+K3 kernel, i.e. in the SpMV geometry   */
 } ec3d_geom;
 /* which = 0: vector kernels (dots S.S, R.R, R.R0); 1: SpMV kernels (B.B, initial R.R, AP.R0, AS.S, AS.AS) */
 int ec3d_get_reduction_geometry(ec3d_handle h, int which, ec3d_geom *g);
 /* 1 (default): SpMV kernels walk the z direction per workgroup and keep x[r-kdz], x[r] in registers
  * when a grid plane is a whole number of 512-row tiles; 0: plain tile order. */
 int ec3d_set_zmarch(ec3d_handle h, int on);
-/* 1 (default): on a single GPU K2 is fused into K3 (S = R - alpha*AP formed on the fly inside the
- * SpMV; one launch and 8 B/row less per iteration); 0: separate kernels (always so for z-slabs). */
-int ec3d_set_fusion(ec3d_handle h, int on);
 int ec3d_set_workgroups(ec3d_handle h, int32_t nblk); /* 0 = default; multiple of 8 enables the XCD map */
 
 typedef struct {

@@ -202,7 +202,7 @@ int oracle_bicgstab_wr_gpuorder(const oracle_gpu_geom *gv, const oracle_gpu_geom
                            : oracle_dot_gpuorder(gv, R, R0, n);    /* K4 of the previous iteration */
         alpha = rr0 / oracle_dot_gpuorder(gs, AP, R0, n);         /* K1 */
         for (int32_t j = 0; j < n; ++j) S[j] = R[j] - alpha * AP[j];
-        nrm = sqrt(oracle_dot_gpuorder(gv->ss_by_spmv ? gs : gv, S, S, n)); /* K2, or the fused K2+K3 */
+        nrm = sqrt(oracle_dot_gpuorder(gv, S, S, n));             /* K2 */
         if (hist_s && *iter <= hist_cap) hist_s[*iter - 1] = nrm;
         if (nrm / Bnorm < tolerance) {
             for (int32_t j = 0; j < n; ++j) x[j] = x[j] + alpha * P[j];

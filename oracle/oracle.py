@@ -32,7 +32,7 @@ class GpuGeom(C.Structure):
     """Reduction geometry of the HIP kernels (ec3d_get_reduction_geometry)."""
     _fields_ = [("n_pad", C.c_int32), ("tile", C.c_int32), ("nblk", C.c_int32),
                 ("threads", C.c_int32), ("xcd_group", C.c_int32), ("zm_tpp", C.c_int32),
-                ("zm_pps", C.c_int32), ("ss_by_spmv", C.c_int32)]
+                ("zm_pps", C.c_int32)]
 
 
 def build(with_ref: bool = True) -> None:
@@ -120,7 +120,7 @@ def geoms_of(solver):
     for which in (0, 1):
         g = solver.geometry(which)
         out.append(GpuGeom(n_pad=g.n_pad, tile=g.tile, nblk=g.nblk, threads=g.threads, xcd_group=g.xcd_group,
-                           zm_tpp=g.zm_tpp, zm_pps=g.zm_pps, ss_by_spmv=g.ss_by_spmv))
+                           zm_tpp=g.zm_tpp, zm_pps=g.zm_pps))
     return tuple(out)
 
 
