@@ -1,0 +1,114 @@
+"""Edge cases of the hot path on the GPU: ragged/tiny/odd grids, explicit zeros, unsorted and duplicate
+CSR entries, degenerate iteration limits, the drop-in's matrix cache."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def E():
+    import eddy_currents_3d_amd as E
+    E.load_library()
+    return E
+
+
+@pytest.mark.parametrize("dims,bnd", [((3, 3, 3), -0.95), ((7, 5, 4), -0.95), ((17, 9, 5), 0.0),
+                                      ((33, 1 + 30, 3), 1.0)])
+def test_odd_tiny_grids_and_explicit_zero_coefficients(E, oracle, dims, bnd):
+    """sdx odd (the +-sdx pairs are only 8-byte aligned), n < one tile, BND = 0 (the reference then stores
+    explicit zeros in its CSR; ours are band slots holding 0.0): SpMV and solve bit-identical."""
+    sdx, sdy, sdz = dims
+    delta = (0.004, 0.003, 0.005)
+    valA, irow, jcol = oracle.poisson_csr(sdx, sdy, sdz, delta, bnd)
+    n = sdx * sdy * sdz
+    rng = np.random.Generator(np.random.PCG64(n))
+    x, b = rng.standard_normal(n), rng.standard_normal(n)
+    for route in ("native", "csr"):
+        with E.EC3DSolver() as s:
+            if route == "native":
+                s.assemble_poisson(sdx, sdy, sdz, delta, bnd)
+            else:
+                s.set_matrix_csr(valA, irow, jcol)
+            assert np.array_equal(s.spmv(x), oracle.spmv_csr(valA, irow, jcol, x))
+            xs, it, _ = s.solve(b, np.zeros(n), 1e-10, 3000)
+            xo, ito, _, _ = oracle.bicgstab_wr_gpuorder(oracle.geoms_of(s), valA, irow, jcol, b, np.zeros(n),
+                                                        1e-10, 3000)
+            assert it == ito and np.array_equal(xs, xo)
+
+
+def test_csr_stored_order_is_kept_for_unsorted_and_duplicate_entries(E, oracle):
+    """src/solvers.f90:59 sums a row in STORED order; a CSR that is not column-sorted or repeats a column
+    must give the same bits (such rows go to the tail as they are)."""
+    N = 9
+    valA, irow, jcol = oracle.poisson_csr(N, N, N)
+    valA, jcol = valA.copy(), jcol.copy()
+    rng = np.random.Generator(np.random.PCG64(17))
+    for r in rng.choice(N ** 3, 200, replace=False):           # shuffle some rows
+        p0, p1 = irow[r] - 1, irow[r + 1] - 1
+        perm = rng.permutation(p1 - p0)
+        valA[p0:p1], jcol[p0:p1] = valA[p0:p1][perm], jcol[p0:p1][perm]
+    rows = [(jcol[irow[r] - 1:irow[r + 1] - 1], valA[irow[r] - 1:irow[r + 1] - 1]) for r in range(N ** 3)]
+    for r in rng.choice(N ** 3, 50, replace=False):            # and repeat a column in others
+        c, v = rows[r]
+        rows[r] = (np.append(c, c[0]), np.append(v, 0.125))
+    irow2 = np.concatenate([[1], 1 + np.cumsum([len(c) for c, _ in rows])]).astype(np.int32)
+    jcol2 = np.concatenate([c for c, _ in rows]).astype(np.int32)
+    valA2 = np.concatenate([v for _, v in rows])
+    x = rng.standard_normal(N ** 3)
+    with E.EC3DSolver() as s:
+        s.set_matrix_csr(valA2, irow2, jcol2)
+        assert np.array_equal(s.spmv(x), oracle.spmv_csr(valA2, irow2, jcol2, x))
+
+
+@pytest.mark.parametrize("itmax,expect", [(0, 1), (-1, 0), (-5, 0)])
+def test_degenerate_iteration_limits(E, oracle, capfd, itmax, expect):
+    """src/solvers.f90:25-29: the limit is tested before the increment: itmax = 0 -> one iteration,
+    itmax < 0 -> none (x untouched), ||R|| printed in both cases."""
+    N = 8
+    valA, irow, jcol = oracle.poisson_csr(N, N, N)
+    b = oracle.bar_rhs(N)
+    x0 = np.full(N ** 3, 1e-3)
+    with E.EC3DSolver() as s:
+        s.assemble_poisson(N, N, N)
+        x, it, _ = s.solve(b, x0, 1e-30, itmax)
+    xo, ito, _, _ = oracle.bicgstab_wr(valA, irow, jcol, b, x0, 1e-30, itmax)
+    out = capfd.readouterr().out.split()
+    assert it == ito == expect
+    if expect == 0:
+        assert np.array_equal(x, x0)
+    else:
+        assert np.allclose(x, xo, rtol=1e-12, atol=0)
+    assert len(out) >= 2 and float(out[0]) == pytest.approx(float(out[1]), rel=1e-10)   # both printed ||R||
+
+
+def test_dropin_cache_notices_a_matrix_rebuilt_in_place(E, oracle):
+    """The device copy of the matrix is cached across calls (the reference assembles once); a host that
+    rewrites valA in place is still served correctly (value signature), and ec3d_invalidate() exists."""
+    N = 10
+    valA, irow, jcol = oracle.poisson_csr(N, N, N)
+    valA = valA.copy()
+    b = oracle.bar_rhs(N)
+    n = N ** 3
+    x1 = np.zeros(n)
+    it1 = E.sprsBCGstabWR(valA, irow, jcol, n, b, x1, 1e-9, 5000)
+    valA *= 2.0                                   # same arrays, new operator: solution halves
+    x2 = np.zeros(n)
+    it2 = E.sprsBCGstabWR(valA, irow, jcol, n, b, x2, 1e-9, 5000)
+    assert np.linalg.norm(2 * x2 - x1) <= 1e-6 * np.linalg.norm(x1)
+    E.load_library().ec3d_invalidate()
+    x3 = np.zeros(n)
+    E.sprsBCGstabWR(valA, irow, jcol, n, b, x3, 1e-9, 5000)
+    assert np.array_equal(x3, x2)
+
+
+def test_nan_rhs_propagates_like_the_reference(E, oracle):
+    """No breakdown guards in the reference (src/solvers.f90:32, :40, :45): NaNs propagate and the loop
+    runs to itmax; same here (no hang, iter = itmax + 1)."""
+    N = 6
+    b = oracle.bar_rhs(N).copy()
+    b[10] = np.nan
+    with E.EC3DSolver() as s:
+        s.assemble_poisson(N, N, N)
+        x, it, _ = s.solve(b, np.zeros(N ** 3), 1e-6, 7)
+    assert it == 8 and np.all(np.isnan(x[np.isfinite(x) == False])) and np.isnan(x).any()
