@@ -63,6 +63,12 @@ struct Sweep {
     // (nown > 0): [Ax | Ay | Az | U] each contribute one owned index range
     int nown;
     int64_t own_lo[4], own_hi[4];
+    // split launches of the SpMV kernels in a z-slab, so the halo exchange overlaps the interior:
+    // zm_pl0 > 0: z-march over planes [zm_pl0, zm_pl0 + zm_npl) only (interior launch);
+    // bnd_last >= 0: the launch covers planes 0 and bnd_last only (boundary launch, plain tile order)
+    int zm_pl0, zm_npl;
+    int bnd_last;  // -1: not a boundary launch
+    int part_off;  // first partial-sum index this launch writes within a slot
 };
 
 struct SolverState {
@@ -120,6 +126,8 @@ struct ec3d_ctx {
     double *vec[8] = {nullptr};
     Sweep sweep{};   // vector kernels (K2, K4, K5)
     Sweep sweep_s{}; // SpMV kernels (K1, K3, residual, spmv)
+    Sweep sweep_int{}, sweep_bnd{}; // z-slab: interior / boundary-plane launches of K1 and K3
+    bool can_overlap = false;
     int nown = 0;    // ownership ranges of an A-V slab (see Sweep)
     int64_t own_lo[4] = {0}, own_hi[4] = {0};
     bool own_vectors = true;

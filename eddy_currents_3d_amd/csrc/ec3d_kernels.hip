@@ -26,13 +26,20 @@ typedef int i2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int64_t ec3d_tile_of(const Sweep &sw, int b, int64_t i)
 {
+    if (sw.bnd_last >= 0) {
+        // boundary launch of a z-slab: the first and the last owned plane, plain tile order
+        const int64_t t = i * (int64_t)sw.nblk + b;
+        if (t >= 2 * (int64_t)sw.zm_tpp) return sw.ntiles;
+        return (t < sw.zm_tpp ? 0 : (int64_t)sw.bnd_last * sw.zm_tpp) + t % sw.zm_tpp;
+    }
     if (sw.zm_tpp > 0) {
         // XCD label c owns zm_tpp/8 adjacent columns, so the +-sdx lines a column needs were fetched
-        // by a neighbour on the same XCD one step earlier (L2 hit); plane k = seg*pps + i
+        // by a neighbour on the same XCD one step earlier (L2 hit); plane k = pl0 + seg*pps + i
         const int cpx = sw.zm_tpp >> 3, c = b & 7, s = b >> 3;
         const int64_t col = c * cpx + s % cpx, seg = s / cpx;
-        if (i >= sw.zm_pps) return sw.ntiles;
-        return (seg * sw.zm_pps + i) * sw.zm_tpp + col;
+        const int64_t pl = seg * sw.zm_pps + i;
+        if (i >= sw.zm_pps || (sw.zm_npl > 0 && pl >= sw.zm_npl)) return sw.ntiles;
+        return (sw.zm_pl0 + pl) * sw.zm_tpp + col;
     }
     if (sw.S > 0) {
         int64_t c = b & 7, s = b >> 3;
@@ -320,8 +327,8 @@ __global__ __launch_bounds__(EC3D_THREADS) void k_residual(MatView A, Sweep sw, 
     EC3D_SWEEP_END
     block_sum<2>(acc, lds);
     if (threadIdx.x == 0) {
-        part[P_BB * sw.pstride + blockIdx.x] = acc[0];
-        part[P_RR_INIT * sw.pstride + blockIdx.x] = acc[1];
+        part[P_BB * sw.pstride + sw.part_off + blockIdx.x] = acc[0];
+        part[P_RR_INIT * sw.pstride + sw.part_off + blockIdx.x] = acc[1];
     }
 }
 
@@ -383,7 +390,7 @@ __global__ __launch_bounds__(EC3D_THREADS) void k1_spmv_dot(MatView A, Sweep sw,
     acc[0] = acc[0] + s1 * q.y;
     EC3D_SWEEP_END
     block_sum<1>(acc, lds);
-    if (threadIdx.x == 0) part[P_D1 * sw.pstride + blockIdx.x] = acc[0];
+    if (threadIdx.x == 0) part[P_D1 * sw.pstride + sw.part_off + blockIdx.x] = acc[0];
 }
 
 // K2: alpha = rr0 / (AP·R0) ; S = R - alpha*AP ; partial S·S   (src/solvers.f90:31-34)
@@ -411,7 +418,7 @@ __global__ __launch_bounds__(EC3D_THREADS) void k2_s_update(Sweep sw, RedSrc src
     acc[0] = acc[0] + s1 * s1;
     EC3D_SWEEP_END
     block_sum<1>(acc, lds);
-    if (threadIdx.x == 0) part[P_SS * sw.pstride + blockIdx.x] = acc[0];
+    if (threadIdx.x == 0) part[P_SS * sw.pstride + sw.part_off + blockIdx.x] = acc[0];
 }
 
 // K3: AS = A S ; partials AS·S and AS·AS (src/solvers.f90:39-40).  Launched before ‖S‖ is known
@@ -441,8 +448,8 @@ __global__ __launch_bounds__(EC3D_THREADS) void k3_spmv_dots(MatView A, Sweep sw
     EC3D_SWEEP_END
     block_sum<2>(acc, lds);
     if (threadIdx.x == 0) {
-        part[P_D2 * sw.pstride + blockIdx.x] = acc[0];
-        part[P_D3 * sw.pstride + blockIdx.x] = acc[1];
+        part[P_D2 * sw.pstride + sw.part_off + blockIdx.x] = acc[0];
+        part[P_D3 * sw.pstride + sw.part_off + blockIdx.x] = acc[1];
     }
 }
 
@@ -503,8 +510,8 @@ __global__ __launch_bounds__(EC3D_THREADS) void k4_x_r_update(Sweep sw, RedSrc s
     EC3D_SWEEP_END
     block_sum<2>(acc, lds);
     if (threadIdx.x == 0) {
-        part[P_RR * sw.pstride + blockIdx.x] = acc[0];
-        part[P_RR0N * sw.pstride + blockIdx.x] = acc[1];
+        part[P_RR * sw.pstride + sw.part_off + blockIdx.x] = acc[0];
+        part[P_RR0N * sw.pstride + sw.part_off + blockIdx.x] = acc[1];
     }
 }
 
@@ -563,7 +570,7 @@ static inline int fmt_of(const MatView &A)
 static inline bool nt_of(const Sweep &sw) { return sw.nt != 0; }
 #define EC3D_LAUNCH_FMT(F, KERNEL, ...)                                                        \
     do {                                                                                       \
-        const bool zm_ = sw.zm_tpp > 0 && F != FMT_GENERIC;                                    \
+        const bool zm_ = sw.zm_tpp > 0 && sw.bnd_last < 0 && F != FMT_GENERIC;                 \
         if (nt_of(sw) && zm_)                                                                  \
             KERNEL<F, true, (F != FMT_GENERIC)><<<sw.nblk, EC3D_THREADS, 0, s>>>(__VA_ARGS__); \
         else if (nt_of(sw))                                                                    \

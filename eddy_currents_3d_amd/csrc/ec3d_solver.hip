@@ -134,6 +134,7 @@ static void choose_sweep(ec3d_ctx *c)
 {
     Sweep &sw = c->sweep;
     sw = Sweep{};
+    sw.bnd_last = -1;
     sw.ntiles = c->A.n_pad / EC3D_TILE;
     sw.n = c->A.n;
     sw.nown = c->nown;
@@ -173,7 +174,32 @@ static void choose_sweep(ec3d_ctx *c)
             ss.S = 0;
         }
     }
-    sw.pstride = ss.pstride = std::max(sw.nblk, ss.nblk);
+    // z-slab of the single-component operator on a z-marching grid: K1/K3 can be split into an interior
+    // launch (planes 1 .. np-2, independent of the halo) and a boundary launch (planes 0 and np-1)
+    c->can_overlap = false;
+    c->sweep_int = c->sweep_bnd = ss;
+    int parts = ss.nblk;
+    if (c->halo > 0 && c->nown == 0 && ss.zm_tpp > 0) {
+        const int64_t np = sw.ntiles / ss.zm_tpp; // planes held (n is a whole number of planes here)
+        if (np * ss.zm_tpp == sw.ntiles && np >= 10) {
+            Sweep &si = c->sweep_int, &sb = c->sweep_bnd;
+            const int64_t tpp = ss.zm_tpp, npl = np - 2;
+            int64_t nseg = std::max<int64_t>(1, (want + tpp / 2) / tpp);
+            nseg = std::min<int64_t>(nseg, std::max<int64_t>(1, npl / 8));
+            si.zm_pl0 = 1;
+            si.zm_npl = (int)npl;
+            si.zm_pps = (int)((npl + nseg - 1) / nseg);
+            si.nblk = (int)(tpp * nseg);
+            si.part_off = 0;
+            sb.bnd_last = (int)(np - 1);
+            sb.nblk = (int)std::min<int64_t>(2 * tpp, 768);
+            sb.part_off = si.nblk;
+            parts = si.nblk + sb.nblk;
+            c->can_overlap = true;
+        }
+    }
+    const int ps = std::max(sw.nblk, std::max(ss.nblk, parts));
+    sw.pstride = ss.pstride = c->sweep_int.pstride = c->sweep_bnd.pstride = ps;
 }
 
 // vectors: [ghost | n_pad | ghost] doubles each, zero filled; kernels only ever write [0, n_pad)
@@ -500,9 +526,12 @@ static RedSrc src_of(const ec3d_ctx *c, bool produced_by_spmv)
     if (c->dist) return RedSrc{c->gsum, c->nranks, P_NSLOT, 1};
     return RedSrc{c->partials, produced_by_spmv ? c->sweep_s.nblk : c->sweep.nblk, 1, c->sweep.pstride};
 }
-static RedSrc part_of(const ec3d_ctx *c, bool produced_by_spmv)
+static RedSrc part_of(const ec3d_ctx *c, bool produced_by_spmv, bool split = false)
 {
-    return RedSrc{c->partials, produced_by_spmv ? c->sweep_s.nblk : c->sweep.nblk, 1, c->sweep.pstride};
+    const int cnt = !produced_by_spmv ? c->sweep.nblk
+                    : split           ? c->sweep_int.nblk + c->sweep_bnd.nblk
+                                      : c->sweep_s.nblk;
+    return RedSrc{c->partials, cnt, 1, c->sweep.pstride};
 }
 
 // the five launches of one iteration; `k` selects one of them (1..5) or all (0)
@@ -789,8 +818,12 @@ extern "C" int ec3d_dist_step(ec3d_handle c, int32_t stage, int32_t it, double t
     }
     const MatView A = c->A.view();
     double **v = c->vec;
-    auto fin = [&](bool spmv_producer, unsigned mask) {
-        ec3d_launch_finalize(part_of(c, spmv_producer), c->lsum, mask, c->stream);
+    auto fin = [&](bool spmv_producer, unsigned mask, bool split = false) {
+        ec3d_launch_finalize(part_of(c, spmv_producer, split), c->lsum, mask, c->stream);
+    };
+    auto need_split = [&]() {
+        if (!c->can_overlap) ec3d_set_error("ec3d_dist_step: this slab cannot split K1/K3 (see ec3d_can_overlap)");
+        return c->can_overlap;
     };
     switch (stage) {
     case EC3D_STAGE_RESID:
@@ -805,11 +838,33 @@ extern "C" int ec3d_dist_step(ec3d_handle c, int32_t stage, int32_t it, double t
     case EC3D_STAGE_K3: launch_stage(c, A, it, 3); fin(true, 1u << P_D2 | 1u << P_D3); break;
     case EC3D_STAGE_K4: launch_stage(c, A, it, 4); fin(false, 1u << P_RR | 1u << P_RR0N); break;
     case EC3D_STAGE_K5: launch_stage(c, A, it, 5); break;
+    case EC3D_STAGE_K1_INT:
+        if (!need_split()) return 3;
+        ec3d_launch_k1(A, c->sweep_int, c->state, it, v[EC3D_VEC_P], v[EC3D_VEC_R0], v[EC3D_VEC_AP], c->partials,
+                       c->stream);
+        break;
+    case EC3D_STAGE_K1_BND:
+        if (!need_split()) return 3;
+        ec3d_launch_k1(A, c->sweep_bnd, c->state, it, v[EC3D_VEC_P], v[EC3D_VEC_R0], v[EC3D_VEC_AP], c->partials,
+                       c->stream);
+        fin(true, 1u << P_D1, true);
+        break;
+    case EC3D_STAGE_K3_INT:
+        if (!need_split()) return 3;
+        ec3d_launch_k3(A, c->sweep_int, c->state, it, v[EC3D_VEC_S], v[EC3D_VEC_AS], c->partials, c->stream);
+        break;
+    case EC3D_STAGE_K3_BND:
+        if (!need_split()) return 3;
+        ec3d_launch_k3(A, c->sweep_bnd, c->state, it, v[EC3D_VEC_S], v[EC3D_VEC_AS], c->partials, c->stream);
+        fin(true, 1u << P_D2 | 1u << P_D3, true);
+        break;
     default: ec3d_set_error("ec3d_dist_step: unknown stage"); return 2;
     }
     EC3D_HIP(hipGetLastError());
     return 0;
 }
+
+extern "C" int ec3d_can_overlap(ec3d_handle c) { return c && c->have_matrix && c->can_overlap ? 1 : 0; }
 
 // synchronous read of the device-resident solver state (stream is drained first)
 extern "C" int ec3d_read_state(ec3d_handle c, int32_t *stop_iter, int32_t *stop_kind, double *bnorm)

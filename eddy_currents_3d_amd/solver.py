@@ -51,7 +51,7 @@ EXPORTS = ["sprsbcgstabwr_", "ec3d_invalidate", "ec3d_create", "ec3d_destroy", "
            "ec3d_set_workgroups", "ec3d_get_matrix_info", "ec3d_time_kernel", "ec3d_time_iterations",
            "ec3d_iterate_begin", "ec3d_iterate", "ec3d_set_format", "ec3d_set_stream",
            "ec3d_assemble_poisson_slab", "ec3d_vector_layout", "ec3d_adopt_vectors",
-           "ec3d_dist_configure", "ec3d_dist_step", "ec3d_read_state", "ec3d_set_zmarch",
+           "ec3d_dist_configure", "ec3d_dist_step", "ec3d_read_state", "ec3d_set_zmarch", "ec3d_can_overlap",
            "ec3d_rhs_step", "ec3d_post_update", "ec3d_assemble_slab", "ec3d_vtk_fields",
            "ec3d_device_synchronize"]
 
@@ -114,6 +114,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.ec3d_get_cel_bnd.argtypes = [hp, C.c_int, C.POINTER(C.c_int32), hp]
     L.ec3d_get_reduction_geometry.argtypes = [hp, C.c_int, C.POINTER(Geom)]
     L.ec3d_set_zmarch.argtypes = [hp, C.c_int]
+    L.ec3d_can_overlap.argtypes = [hp]
     L.ec3d_assemble_slab.argtypes = [hp] + [C.c_int32] * 7 + [_i8, _i32, _f64, C.c_int32, _f64, _f64, C.c_double]
     L.ec3d_rhs_step.argtypes = [hp, C.c_int32, C.c_int32, _i32, _f64]
     L.ec3d_post_update.argtypes = [hp]
@@ -383,6 +384,9 @@ class EC3DSolver:
 
     def dist_step(self, stage: int, it: int = 0, tol: float = 0.0):
         _chk(self.L, self.L.ec3d_dist_step(self.h, stage, it, float(tol)), "ec3d_dist_step")
+
+    def can_overlap(self) -> bool:
+        return bool(self.L.ec3d_can_overlap(self.h))
 
     def read_state(self):
         si, sk, bn = C.c_int32(0), C.c_int32(0), C.c_double(0)

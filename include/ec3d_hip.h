@@ -153,8 +153,15 @@ enum { EC3D_STAGE_RESID = 0, /* R = B - A X, R0 = P = R; lsum <- B.B, R.R      s
        EC3D_STAGE_K3 = 4,    /* AS = A S; lsum <- AS.S, AS.AS (S halo current; no gather needed
                                 between K2 and K3: the S exit is taken by K4)                     :39-40 */
        EC3D_STAGE_K4 = 5,    /* S exit (X += alpha P) or omega, X, R; lsum <- R.R, R.R0          :34-44 */
-       EC3D_STAGE_K5 = 6 };  /* R exit, beta, P, restart                                         :43-49 */
+       EC3D_STAGE_K5 = 6,    /* R exit, beta, P, restart                                         :43-49 */
+       /* K1 and K3 in two launches, so the halo exchange of P / S overlaps the first one:
+        * *_INT = owned planes 1 .. np-2 (need no halo), *_BND = planes 0 and np-1 (after the exchange;
+        * also collapses both launches' partials into lsum).  Only when ec3d_can_overlap(). */
+       EC3D_STAGE_K1_INT = 7, EC3D_STAGE_K1_BND = 8, EC3D_STAGE_K3_INT = 9, EC3D_STAGE_K3_BND = 10 };
 int ec3d_dist_step(ec3d_handle h, int32_t stage, int32_t it, double tolerance);
+/* 1 when the slab held can run K1/K3 split into interior + boundary launches (single-component slab
+ * on a grid whose xy-plane is a whole number of 512-row tiles, at least 10 planes) */
+int ec3d_can_overlap(ec3d_handle h);
 /* drain the stream and read the device-resident state; stop_iter = -1 while still running */
 int ec3d_read_state(ec3d_handle h, int32_t *stop_iter, int32_t *stop_kind, double *bnorm);
 

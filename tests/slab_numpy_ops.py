@@ -8,7 +8,8 @@ import contextlib
 import numpy as np
 import torch
 
-from eddy_currents_3d_amd.dist import K1, K2, K3, K4, K5, NSLOT, RESID, SETUP
+from eddy_currents_3d_amd.dist import (K1, K1_BND, K1_INT, K2, K3, K3_BND, K3_INT, K4, K5, NSLOT, RESID,
+                                       SETUP)
 
 BB, RR_INIT, D1, SS, D2, D3, RR, RR0N = range(8)
 VEC = dict(X=0, B=1, R=2, R0=3, P=4, AP=5, S=6, AS=7)
@@ -32,6 +33,7 @@ class NumpySlabOps:
         self.lsum = torch.zeros(NSLOT, dtype=torch.float64)
         self.gsum = torch.zeros(world * NSLOT, dtype=torch.float64)
         self.world = world
+        self.overlap = True
         self.st = dict(stop_iter=-1, stop_kind=0, rr0=[0.0, 0.0], alpha=0.0, omega=0.0, bnorm=0.0, tol=0.0)
 
     def context(self):
@@ -76,6 +78,21 @@ class NumpySlabOps:
     def read_state(self):
         return self.st["stop_iter"], self.st["stop_kind"], self.st["bnorm"]
 
+    def can_overlap(self):
+        return self.overlap and self.n >= 4 * self.kdz
+
+    def _split(self, src, dst, interior):
+        """rows of planes 1 .. np-2 (interior) or planes 0 and np-1 of dst = A * src, with the halos as
+        they are at this moment"""
+        y = self._spmv(src)
+        p = self.kdz
+        rows = slice(p, self.n - p) if interior else None
+        if interior:
+            self._own(dst)[rows] = y[rows]
+        else:
+            self._own(dst)[:p] = y[:p]
+            self._own(dst)[self.n - p:] = y[self.n - p:]
+
     def step(self, stage, it=0, tol=0.0):
         st, L = self.st, self.lsum
         stopped_before = st["stop_iter"] >= 0 and st["stop_iter"] < it
@@ -93,6 +110,17 @@ class NumpySlabOps:
             ap = self._spmv("P")
             self._own("AP")[:] = ap
             L[D1] = float(ap @ self._own("R0"))
+        elif stage in (K1_INT, K1_BND):
+            if stopped_before: return
+            self._split("P", "AP", stage == K1_INT)
+            if stage == K1_BND:
+                L[D1] = float(self._own("AP") @ self._own("R0"))
+        elif stage in (K3_INT, K3_BND):
+            if stopped_before: return
+            self._split("S", "AS", stage == K3_INT)
+            if stage == K3_BND:
+                a = self._own("AS")
+                L[D2] = float(a @ self._own("S")); L[D3] = float(a @ a)
         elif stage == K2:
             if stopped_before: return
             st["alpha"] = st["rr0"][it & 1] / self._g(D1)

@@ -215,3 +215,59 @@ def test_av_slabs_on_one_gpu_match_reference(E, name, world):
         print(f"{name} in {world} slabs, step {k}: iter {it} / reference {int(g['iters'][k])}, rel diff {rel:.2e}")
         assert rel <= 10 * tol
         assert abs(it - int(g["iters"][k])) <= max(3, 0.15 * int(g["iters"][k]))
+
+
+@pytest.mark.parametrize("world,sdz", [(2, 40), (3, 48)])
+def test_overlap_split_launches_match_unsplit(E, oracle, world, sdz):
+    """K1/K3 as interior + boundary launches (the schedule that hides the halo exchange) vs the plain
+    schedule on the same slabs: same converged solution; interior launches do not read the ghost planes
+    (the exchange happens between the two launches)."""
+    from eddy_currents_3d_amd.dist import HipSlabOps, InProcessSlabs, slab_bounds
+    sdx = sdy = 64
+    tol = 1e-9
+    valA, irow, jcol = oracle.poisson_csr(sdx, sdy, sdz)
+    b = np.random.Generator(np.random.PCG64(3)).standard_normal(sdx * sdy * sdz)
+    res = {}
+    for overlap in (True, False):
+        ops = []
+        for r in range(world):
+            k0, k1 = slab_bounds(sdz, r, world)
+            o = HipSlabOps(sdx, sdy, sdz, k0, k1, world)
+            assert o.can_overlap()
+            o.set_vector("B", b.reshape(sdz, sdx * sdy)[k0:k1].reshape(-1))
+            ops.append(o)
+        drv = InProcessSlabs(ops, overlap=overlap)
+        it = drv.solve(tol, 5000)
+        x = drv.x()
+        assert np.linalg.norm(b - oracle.spmv_csr(valA, irow, jcol, x)) / np.linalg.norm(b) < 5 * tol
+        res[overlap] = (it, x)
+        for o in ops:
+            o.close()
+    print(f"{world} slabs of {sdx}x{sdy}x{sdz}: iterations split {res[True][0]} / unsplit {res[False][0]}")
+    assert np.linalg.norm(res[True][1] - res[False][1]) <= 1e-6 * np.linalg.norm(res[False][1])
+
+
+def test_split_spmv_is_the_same_operator(E, oracle):
+    """AP from K1_INT + K1_BND == AP from K1, bit for bit (same row sums, only the launch geometry differs)."""
+    from eddy_currents_3d_amd.dist import HipSlabOps, K1, K1_BND, K1_INT
+    sdx, sdy, sdz, k0, k1 = 64, 64, 40, 8, 28
+    kdz = sdx * sdy
+    rng = np.random.Generator(np.random.PCG64(12))
+    x = rng.standard_normal(sdx * sdy * sdz)
+    import torch
+    out = []
+    for stages in ((K1,), (K1_INT, K1_BND)):
+        o = HipSlabOps(sdx, sdy, sdz, k0, k1, 1)
+        o.set_vector("P", x[k0 * kdz:k1 * kdz])
+        lo_s, lo_r, hi_s, hi_r = o.halo_views("P")
+        with o.context():
+            lo_r.copy_(torch.from_numpy(x[(k0 - 1) * kdz:k0 * kdz].copy()))
+            hi_r.copy_(torch.from_numpy(x[k1 * kdz:(k1 + 1) * kdz].copy()))
+            for st in stages:
+                o.step(st, 1)
+        o.synchronize()
+        out.append(o.get_vector("AP"))
+        o.close()
+    valA, irow, jcol = oracle.poisson_csr(sdx, sdy, sdz)
+    y = oracle.spmv_csr(valA, irow, jcol, x)[k0 * kdz:k1 * kdz]
+    assert np.array_equal(out[0], y) and np.array_equal(out[1], y)
