@@ -12,7 +12,11 @@ module ec3d_hip
     implicit none
     private
     public :: ec3d_create, ec3d_destroy, ec3d_assemble, ec3d_assemble_poisson, ec3d_set_matrix_csr, &
-              ec3d_solve, ec3d_spmv, ec3d_get_cel_bnd, ec3d_error_text, ec3d_set_format
+              ec3d_solve, ec3d_spmv, ec3d_get_cel_bnd, ec3d_error_text, ec3d_set_format, &
+              ec3d_upload, ec3d_download, ec3d_solve_resident, ec3d_rhs_step, ec3d_post_update, &
+              ec3d_vtk_fields, EC3D_VEC_X, EC3D_VEC_B
+
+    integer(c_int), parameter :: EC3D_VEC_X = 0, EC3D_VEC_B = 1   ! Uaf, Jaf
 
     interface
         integer(c_int) function ec3d_create(h, device) bind(C, name="ec3d_create")
@@ -66,6 +70,49 @@ module ec3d_hip
             integer(c_int32_t), value :: itmax, hist_cap
             integer(c_int32_t), intent(out) :: iter
             type(c_ptr), value :: resid_hist
+        end function
+        ! fields resident on the device across time steps (which = EC3D_VEC_X / EC3D_VEC_B)
+        integer(c_int) function ec3d_upload(h, which, host) bind(C, name="ec3d_upload")
+            import :: c_ptr, c_int, c_double
+            type(c_ptr), value :: h
+            integer(c_int), value :: which
+            real(c_double), intent(in) :: host(*)
+        end function
+        integer(c_int) function ec3d_download(h, which, host) bind(C, name="ec3d_download")
+            import :: c_ptr, c_int, c_double
+            type(c_ptr), value :: h
+            integer(c_int), value :: which
+            real(c_double), intent(out) :: host(*)
+        end function
+        integer(c_int) function ec3d_solve_resident(h, tolerance, itmax, iter, resid_hist, hist_cap) &
+                bind(C, name="ec3d_solve_resident")
+            import :: c_ptr, c_int, c_int32_t, c_double
+            type(c_ptr), value :: h
+            real(c_double), value :: tolerance
+            integer(c_int32_t), value :: itmax, hist_cap
+            integer(c_int32_t), intent(out) :: iter
+            type(c_ptr), value :: resid_hist
+        end function
+        ! replaces src/EC3D.f90:275-404: source scatter (1-based unknown ids), inertial terms, U-row RHS,
+        ! zero-fills -- on the resident Jaf / Uaf
+        integer(c_int) function ec3d_rhs_step(h, moving, nsrc, src_index, src_value) bind(C, name="ec3d_rhs_step")
+            import :: c_ptr, c_int, c_int32_t, c_double
+            type(c_ptr), value :: h
+            integer(c_int32_t), value :: moving, nsrc
+            integer(c_int32_t), intent(in) :: src_index(*)
+            real(c_double), intent(in) :: src_value(*)
+        end function
+        ! replaces src/EC3D.f90:412-433
+        integer(c_int) function ec3d_post_update(h) bind(C, name="ec3d_post_update")
+            import :: c_ptr, c_int
+            type(c_ptr), value :: h
+        end function
+        ! the four point vectors of writeVtk_field (src/utilites.f90:222-289), 3*nCells REAL(4) each
+        integer(c_int) function ec3d_vtk_fields(h, delta, fA, fEddy, fSource, fB) bind(C, name="ec3d_vtk_fields")
+            import :: c_ptr, c_int, c_double, c_float
+            type(c_ptr), value :: h
+            real(c_double), intent(in) :: delta(*)
+            real(c_float), intent(out) :: fA(*), fEddy(*), fSource(*), fB(*)
         end function
         integer(c_int) function ec3d_spmv(h, x, y) bind(C, name="ec3d_spmv")
             import :: c_ptr, c_int, c_double
