@@ -166,7 +166,11 @@ static void choose_sweep(ec3d_ctx *c)
         const int64_t tpp = A.off[6] / EC3D_TILE;
         const int64_t nplanes = (sw.ntiles + tpp - 1) / tpp;
         if (tpp % 8 == 0 && tpp <= 4096 && nplanes >= 8) {
-            int64_t nseg = std::max<int64_t>(1, (want + tpp / 2) / tpp);
+            // the SpMV kernels like twice the workgroups of the vector kernels: 1536 (6 per CU) and 3072
+            // beat 1024 and 2048 at both 256^3 and 512^3
+            int want_s = c->nblk_request > 0 ? c->nblk_request : 1536;
+            if (const char *e = getenv("EC3D_NBLK_SPMV")) want_s = atoi(e);
+            int64_t nseg = std::max<int64_t>(1, (want_s + tpp / 2) / tpp);
             nseg = std::min<int64_t>(nseg, std::max<int64_t>(1, nplanes / 8));
             ss.zm_tpp = (int)tpp;
             ss.zm_pps = (int)((nplanes + nseg - 1) / nseg);
@@ -184,7 +188,7 @@ static void choose_sweep(ec3d_ctx *c)
         if (np * ss.zm_tpp == sw.ntiles && np >= 10) {
             Sweep &si = c->sweep_int, &sb = c->sweep_bnd;
             const int64_t tpp = ss.zm_tpp, npl = np - 2;
-            int64_t nseg = std::max<int64_t>(1, (want + tpp / 2) / tpp);
+            int64_t nseg = std::max<int64_t>(1, ((int64_t)ss.nblk + tpp / 2) / tpp);
             nseg = std::min<int64_t>(nseg, std::max<int64_t>(1, npl / 8));
             si.zm_pl0 = 1;
             si.zm_npl = (int)npl;
