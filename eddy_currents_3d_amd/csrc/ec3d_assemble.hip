@@ -495,8 +495,6 @@ int ec3d_assemble_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t sdz, int
         return err;
     }
     A.nnz = (int64_t)nnz;
-    c->have_matrix = true;
-    if ((rc = ec3d_compress_tail(c))) return rc;
     // cel_bnd* lists in scan order (src/EC3D.f90:758-760, :938-940)
     for (auto &l : c->cel_bnd) l.clear();
     for (int64_t q = 0; q < g.nCells; ++q) {

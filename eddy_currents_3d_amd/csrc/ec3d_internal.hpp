@@ -30,9 +30,7 @@ struct MatView {
     const uint8_t *tile_flag; // [ntiles] 1 when any row of the tile has a tail
     const int64_t *chunk_ptr; // [nchunk+1] entry offsets of the 64-row slices
     const int32_t *tcol;      // 0-based column
-    const double *tval;       // tail values, or nullptr when they are dictionary coded:
-    const uint8_t *tvidx;     //   value of entry e = vtable[tvidx[e]]  (256 doubles, staged in LDS)
-    const double *vtable;
+    const double *tval;
     // dictionary form of the bands (ncls > 0): band[b][r] == table[cls[r] * nb + b]
     const uint8_t *cls; // [n_pad]
     const double *table;
@@ -110,8 +108,6 @@ struct DevMatrix {
     int64_t *chunk_ptr = nullptr;
     int32_t *tcol = nullptr;
     double *tval = nullptr;
-    uint8_t *tvidx = nullptr; // dictionary-coded tail values (tval == nullptr then)
-    double *vtable = nullptr; // 256 doubles
     uint8_t *cls = nullptr; // dictionary form (ncls > 0): bands == nullptr
     double *table = nullptr;
     int ncls = 0;
@@ -222,8 +218,6 @@ int ec3d_assemble_poisson_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t 
                                  const double *BND, const double *delta);
 // ec3d_format.cpp / ec3d_solver.hip: dictionary compression of the bands
 int ec3d_build_dictionary_host(HostMatrix &M);
-// ec3d_solver.hip: replace the 8-byte tail values by 1-byte indices into a table of <= 256 distinct values
-int ec3d_compress_tail(ec3d_ctx *c);
 // ec3d_rhs.hip
 void ec3d_free_rhs(ec3d_ctx *c);
 int ec3d_setup_rhs(ec3d_ctx *c, int64_t nCells, const int8_t *geoPHYS, const int32_t *geoPHYS_C,

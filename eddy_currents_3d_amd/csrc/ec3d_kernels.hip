@@ -139,21 +139,15 @@ struct VecPlain {
 // order): a plain loop is a chain of two dependent global loads per entry, ~1-2 us each, and a 13-entry
 // U row then costs more than the whole banded part of the tile.
 template <int B, class V>
-__device__ __forceinline__ double tail_batch(const MatView &A, const double *vt, const V &x, int64_t e0, int cnt,
-                                             double s)
+__device__ __forceinline__ double tail_batch(const MatView &A, const V &x, int64_t e0, int cnt, double s)
 {
     double tv[B], xv[B];
     int tc[B];
 #pragma unroll
     for (int j = 0; j < B; ++j) {
         const bool on = j < cnt;
+        tv[j] = on ? A.tval[e0 + (int64_t)j * EC3D_CHUNK] : 0.0;
         tc[j] = on ? A.tcol[e0 + (int64_t)j * EC3D_CHUNK] : 0;
-        if (A.tvidx) { // dictionary-coded values: 1 byte from HBM, the double from the LDS table
-            const int vi = on ? A.tvidx[e0 + (int64_t)j * EC3D_CHUNK] : 0;
-            tv[j] = on ? vt[vi] : 0.0;
-        } else {
-            tv[j] = on ? A.tval[e0 + (int64_t)j * EC3D_CHUNK] : 0.0;
-        }
     }
 #pragma unroll
     for (int j = 0; j < B; ++j) xv[j] = j < cnt ? x.at(tc[j]) : 0.0;
@@ -164,15 +158,15 @@ __device__ __forceinline__ double tail_batch(const MatView &A, const double *vt,
 }
 
 template <class V>
-__device__ __forceinline__ double tail_add(const MatView &A, const double *vt, const V &x, int t, double s)
+__device__ __forceinline__ double tail_add(const MatView &A, const V &x, int t, double s)
 {
     const int64_t base = A.chunk_ptr[t >> 6], end = A.chunk_ptr[(t >> 6) + 1];
     int w = (int)((end - base) >> 6); // slots per row in this slice
     int64_t e = base + (t & 63);
-    if (w <= 4) return tail_batch<4, V>(A, vt, x, e, w, s);
+    if (w <= 4) return tail_batch<4, V>(A, x, e, w, s);
     while (w > 0) {
         const int c = w < 8 ? w : 8;
-        s = tail_batch<8, V>(A, vt, x, e, c, s);
+        s = tail_batch<8, V>(A, x, e, c, s);
         e += (int64_t)8 * EC3D_CHUNK;
         w -= 8;
     }
@@ -189,12 +183,12 @@ enum { FMT_GENERIC = 0, FMT_DIA7 = 7, FMT_DICT7 = 107 };
 #define EC3D_TBL_DOUBLES (256 * 7)
 
 template <int FMT>
-__device__ __forceinline__ void stage_table(const MatView &A, double *tbl, double *vtab)
+__device__ __forceinline__ void stage_table(const MatView &A, double *tbl)
 {
-    if (FMT == FMT_DICT7)
+    if (FMT == FMT_DICT7) {
         for (int i = threadIdx.x; i < A.ncls * 7; i += EC3D_THREADS) tbl[i] = A.table[i];
-    if (A.tvidx) vtab[threadIdx.x] = A.vtable[threadIdx.x]; // 256 threads, 256 values
-    if (FMT == FMT_DICT7 || A.tvidx) __syncthreads();
+        __syncthreads();
+    }
 }
 
 // x values of the planes below / at the current row, carried across the steps of a z-march
@@ -206,8 +200,8 @@ struct ZRegs {
 // ZM: band 0 / 3 / 6 (offsets -kdz, 0, +kdz) come from / go to the registers `z`.
 // `ctr` returns x[r], x[r+1] (the centre band's operand).
 template <int FMT, bool ZM, class V>
-__device__ __forceinline__ void spmv_pair(const MatView &A, const double *tbl, const double *vt, const V &x, int64_t r,
-                                          int64_t tile, bool first, ZRegs &z, double &s0, double &s1, d2 &ctr)
+__device__ __forceinline__ void spmv_pair(const MatView &A, const double *tbl, const V &x, int64_t r, int64_t tile,
+                                          bool first, ZRegs &z, double &s0, double &s1, d2 &ctr)
 {
     if (FMT == FMT_DIA7 || FMT == FMT_DICT7) {
         d2 xv[7];
@@ -271,8 +265,8 @@ __device__ __forceinline__ void spmv_pair(const MatView &A, const double *tbl, c
     }
     if (A.has_tail && A.tile_flag[tile]) {
         i2 t = *reinterpret_cast<const i2 *>(A.tail_id + r);
-        if (t.x >= 0) s0 = tail_add(A, vt, x, t.x, s0);
-        if (t.y >= 0) s1 = tail_add(A, vt, x, t.y, s1);
+        if (t.x >= 0) s0 = tail_add(A, x, t.x, s0);
+        if (t.y >= 0) s1 = tail_add(A, x, t.y, s1);
     }
 }
 
@@ -284,9 +278,7 @@ __device__ __forceinline__ void spmv_pair(const MatView &A, const double *tbl, c
         (void)first_;                                                                          \
         const int64_t r = tile * EC3D_TILE + 2 * (int64_t)threadIdx.x;
 #define EC3D_SWEEP_END }
-#define EC3D_TBL_DECL                                                                          \
-    __shared__ double tbl[FMT == FMT_DICT7 ? EC3D_TBL_DOUBLES : 1];                            \
-    __shared__ double vtab[EC3D_THREADS]
+#define EC3D_TBL_DECL __shared__ double tbl[FMT == FMT_DICT7 ? EC3D_TBL_DOUBLES : 1]
 
 // ---------------------------------------------------------------------------------------------
 // plain y = A x  (src/solvers.f90:54-61)
@@ -295,12 +287,12 @@ __global__ __launch_bounds__(EC3D_THREADS) void k_spmv(MatView A, Sweep sw, cons
                                                        double *__restrict__ y)
 {
     EC3D_TBL_DECL;
-    stage_table<FMT>(A, tbl, vtab);
+    stage_table<FMT>(A, tbl);
     ZRegs zr;
     EC3D_SWEEP_BEGIN
     double s0, s1;
     d2 ctr;
-    spmv_pair<FMT, ZM>(A, tbl, vtab, VecPlain{x}, r, tile, first_, zr, s0, s1, ctr);
+    spmv_pair<FMT, ZM>(A, tbl, VecPlain{x}, r, tile, first_, zr, s0, s1, ctr);
     store2<NT>(y, r, sw.n, s0, s1);
     EC3D_SWEEP_END
 }
@@ -314,13 +306,13 @@ __global__ __launch_bounds__(EC3D_THREADS) void k_residual(MatView A, Sweep sw, 
 {
     __shared__ double lds[8];
     EC3D_TBL_DECL;
-    stage_table<FMT>(A, tbl, vtab);
+    stage_table<FMT>(A, tbl);
     ZRegs zr;
     double acc[2] = {0.0, 0.0};
     EC3D_SWEEP_BEGIN
     double s0, s1;
     d2 ctr;
-    spmv_pair<FMT, ZM>(A, tbl, vtab, VecPlain{x}, r, tile, first_, zr, s0, s1, ctr);
+    spmv_pair<FMT, ZM>(A, tbl, VecPlain{x}, r, tile, first_, zr, s0, s1, ctr);
     d2 bv = load2<NT>(b + r);
     double e0 = bv.x - s0, e1 = bv.y - s1, b0 = bv.x, b1 = bv.y;
     store2<NT>(rv, r, sw.n, e0, e1);
@@ -384,13 +376,13 @@ __global__ __launch_bounds__(EC3D_THREADS) void k1_spmv_dot(MatView A, Sweep sw,
     __shared__ double lds[4];
     EC3D_TBL_DECL;
     if (st->stop_iter < it) return;
-    stage_table<FMT>(A, tbl, vtab);
+    stage_table<FMT>(A, tbl);
     ZRegs zr;
     double acc[1] = {0.0};
     EC3D_SWEEP_BEGIN
     double s0, s1;
     d2 ctr;
-    spmv_pair<FMT, ZM>(A, tbl, vtab, VecPlain{p}, r, tile, first_, zr, s0, s1, ctr);
+    spmv_pair<FMT, ZM>(A, tbl, VecPlain{p}, r, tile, first_, zr, s0, s1, ctr);
     d2 q = load2<NT>(r0 + r);
     store2<NT>(ap, r, sw.n, s0, s1);
     EC3D_MASK2(r, sw, s0, s1);
@@ -440,13 +432,13 @@ __global__ __launch_bounds__(EC3D_THREADS) void k3_spmv_dots(MatView A, Sweep sw
     __shared__ double lds[8];
     EC3D_TBL_DECL;
     if (st->stop_iter < it) return;
-    stage_table<FMT>(A, tbl, vtab);
+    stage_table<FMT>(A, tbl);
     ZRegs zr;
     double acc[2] = {0.0, 0.0};
     EC3D_SWEEP_BEGIN
     double s0, s1;
     d2 q;
-    spmv_pair<FMT, ZM>(A, tbl, vtab, VecPlain{sv}, r, tile, first_, zr, s0, s1, q);
+    spmv_pair<FMT, ZM>(A, tbl, VecPlain{sv}, r, tile, first_, zr, s0, s1, q);
     store2<NT>(as, r, sw.n, s0, s1);
     EC3D_MASK2(r, sw, s0, s1);
     acc[0] = acc[0] + s0 * q.x;

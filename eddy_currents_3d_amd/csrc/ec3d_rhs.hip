@@ -55,8 +55,7 @@ __global__ void k_rhs_inertial(MatView A, const int32_t *cond_cell, const double
         const int64_t base = A.chunk_ptr[t >> 6], end = A.chunk_ptr[(t >> 6) + 1];
         for (int64_t e = base + (t & 63); e < end; e += EC3D_CHUNK) {
             const int32_t col = A.tcol[e];
-            const double v = A.tvidx ? A.vtable[A.tvidx[e]] : A.tval[e];
-            if (col < 3 * nCells && v != 0.0) s = s + v * x[col];
+            if (col < 3 * nCells && A.tval[e] != 0.0) s = s + A.tval[e] * x[col];
         }
     }
     b[row] = s;

@@ -40,8 +40,6 @@ MatView DevMatrix::view() const
     v.chunk_ptr = chunk_ptr;
     v.tcol = tcol;
     v.tval = tval;
-    v.tvidx = tvidx;
-    v.vtable = vtable;
     return v;
 }
 
@@ -93,8 +91,6 @@ void ec3d_free_matrix(ec3d_ctx *c)
     if (A.chunk_ptr) (void)hipFree(A.chunk_ptr);
     if (A.tcol) (void)hipFree(A.tcol);
     if (A.tval) (void)hipFree(A.tval);
-    if (A.tvidx) (void)hipFree(A.tvidx);
-    if (A.vtable) (void)hipFree(A.vtable);
     if (A.cls) (void)hipFree(A.cls);
     if (A.table) (void)hipFree(A.table);
     A = DevMatrix();
@@ -282,84 +278,7 @@ int ec3d_upload_matrix(ec3d_ctx *c, const HostMatrix &M)
     if ((rc = up(A.tval, M.tval, A.bytes, c->stream))) return rc;
     EC3D_HIP(hipStreamSynchronize(c->stream));
     c->have_matrix = true;
-    if ((rc = ec3d_compress_tail(c))) return rc;
     return ec3d_prepare_vectors(c);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Tail values as 1-byte indices.  The reference's couplings take a handful of distinct values
-// (+-C*ds_d*{1,3,4}, -s_d, -2 s_d, the U diagonal, +-2/(dt*delta_d), +-0.5/(dt*delta_d)); a 256-slot open
-// addressing table keyed on the bit pattern is filled by the entries themselves.  More than 255
-// distinct values: the 8-byte values are kept.  Lossless, so results do not change.
-namespace {
-constexpr unsigned long long kEmpty = ~0ull;
-__device__ __forceinline__ unsigned slot_of(unsigned long long bits)
-{
-    return (unsigned)(((bits ^ (bits >> 29)) * 0x9E3779B97F4A7C15ull) >> 56);
-}
-__global__ void k_tail_dict_build(const double *tval, int64_t cnt, unsigned long long *keys, int *fail)
-{
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < cnt; e += (int64_t)gridDim.x * blockDim.x) {
-        const unsigned long long bits = (unsigned long long)__double_as_longlong(tval[e]);
-        if (bits == kEmpty) { *fail = 1; return; }
-        unsigned s = slot_of(bits);
-        int probes = 0;
-        for (;; s = (s + 1) & 255u) {
-            const unsigned long long cur = keys[s];
-            if (cur == bits) break;
-            if (cur == kEmpty) {
-                const unsigned long long old = atomicCAS(&keys[s], kEmpty, bits);
-                if (old == kEmpty || old == bits) break;
-            }
-            if (++probes > 255) { *fail = 1; return; }
-        }
-    }
-}
-__global__ void k_tail_dict_index(const double *tval, int64_t cnt, const unsigned long long *keys, uint8_t *idx)
-{
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < cnt; e += (int64_t)gridDim.x * blockDim.x) {
-        const unsigned long long bits = (unsigned long long)__double_as_longlong(tval[e]);
-        unsigned s = slot_of(bits);
-        while (keys[s] != bits) s = (s + 1) & 255u;
-        idx[e] = (uint8_t)s;
-    }
-}
-__global__ void k_tail_dict_table(const unsigned long long *keys, double *vtable)
-{
-    const unsigned long long k = keys[threadIdx.x];
-    vtable[threadIdx.x] = k == kEmpty ? 0.0 : __longlong_as_double((long long)k);
-}
-} // namespace
-
-int ec3d_compress_tail(ec3d_ctx *c)
-{
-    DevMatrix &A = c->A;
-    if (!c->use_dict || A.tail_entries <= 0 || !A.tval || A.tvidx) return 0;
-    unsigned long long *keys = nullptr;
-    int *fail = nullptr;
-    EC3D_HIP(hipMalloc(&keys, 256 * sizeof(unsigned long long)));
-    EC3D_HIP(hipMalloc(&fail, sizeof(int)));
-    EC3D_HIP(hipMemsetAsync(keys, 0xFF, 256 * sizeof(unsigned long long), c->stream));
-    EC3D_HIP(hipMemsetAsync(fail, 0, sizeof(int), c->stream));
-    const unsigned nb = (unsigned)std::min<int64_t>((A.tail_entries + 255) / 256, 4096);
-    k_tail_dict_build<<<nb, 256, 0, c->stream>>>(A.tval, A.tail_entries, keys, fail);
-    int failed = 0;
-    EC3D_HIP(hipMemcpyAsync(&failed, fail, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    EC3D_HIP(hipStreamSynchronize(c->stream));
-    if (!failed) {
-        EC3D_HIP(hipMalloc(&A.tvidx, (size_t)A.tail_entries));
-        EC3D_HIP(hipMalloc(&A.vtable, 256 * sizeof(double)));
-        k_tail_dict_index<<<nb, 256, 0, c->stream>>>(A.tval, A.tail_entries, keys, A.tvidx);
-        k_tail_dict_table<<<1, 256, 0, c->stream>>>(keys, A.vtable);
-        EC3D_HIP(hipGetLastError());
-        EC3D_HIP(hipStreamSynchronize(c->stream));
-        (void)hipFree(A.tval);
-        A.tval = nullptr;
-        A.bytes -= A.tail_entries * 7;
-    }
-    (void)hipFree(keys);
-    (void)hipFree(fail);
-    return 0;
 }
 
 template <class T>
@@ -404,15 +323,6 @@ int ec3d_download_matrix(ec3d_ctx *c, HostMatrix &M)
     if ((rc = down(M.tile_flag, A.tile_flag, (size_t)(A.n_pad / EC3D_TILE)))) return rc;
     if ((rc = down(M.chunk_ptr, A.chunk_ptr, (size_t)A.nchunk + 1))) return rc;
     if ((rc = down(M.tcol, A.tcol, (size_t)A.tail_entries))) return rc;
-    if (A.tvidx) { // expand the value dictionary
-        std::vector<uint8_t> vi;
-        std::vector<double> vt;
-        if ((rc = down(vi, A.tvidx, (size_t)A.tail_entries))) return rc;
-        if ((rc = down(vt, A.vtable, (size_t)256))) return rc;
-        M.tval.resize((size_t)A.tail_entries);
-        for (size_t e = 0; e < vi.size(); ++e) M.tval[e] = vt[vi[e]];
-        return 0;
-    }
     if ((rc = down(M.tval, A.tval, (size_t)A.tail_entries))) return rc;
     return 0;
 }
