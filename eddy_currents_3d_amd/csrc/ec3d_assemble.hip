@@ -320,6 +320,147 @@ void set_offsets(DevMatrix &A, const GridPar &g)
     for (int b = 0; b < 7; ++b) A.off[b] = off[b];
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Structured A-V form (MatView::sav): classes instead of entries.
+//   class 0..26                      A row, position type bt, no coupling
+//   27 + ((dom-1)*3 + d)*3 + pat-1   A_d row of an interior conducting cell of domain dom;
+//                                    pat 1 central, 2 one-sided low (U(+1) missing), 3 one-sided high
+//   u0 + stx + 3 sty + 9 stz         U row; st = 0 both neighbours, 1 minus one missing, 2 plus one missing
+//   zero                             no coefficients (inactive U slot, padding)
+struct SavIds {
+    int a0, u0, zero, ncls;
+};
+__host__ __device__ inline SavIds sav_ids(int nsub_glob)
+{
+    SavIds s;
+    s.a0 = 27;
+    s.u0 = 27 + 9 * nsub_glob;
+    s.zero = s.u0 + 27;
+    s.ncls = s.zero + 1;
+    return s;
+}
+
+__global__ void k_build_table_sav(GridPar g, const double *__restrict__ valPHYS, double *table)
+{
+    const SavIds id = sav_ids(g.nsub_glob);
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= id.ncls) return;
+    double t[16];
+    for (int j = 0; j < 16; ++j) t[j] = 0.0;
+    double c[7] = {0, 0, 0, 0, 0, 0, 0};
+    bool on_box;
+    if (q < 27) {
+        const int tt[3] = {q % 3, (q / 3) % 3, q / 9}, sd[3] = {g.sdx, g.sdy, g.sdz};
+        int p[3];
+        for (int d = 0; d < 3; ++d) p[d] = tt[d] == 0 ? 1 : (tt[d] == 2 ? sd[d] : 2);
+        a_row_bands(g, p[0], p[1], p[2], c, on_box);
+        for (int b = 0; b < 7; ++b) t[b] = c[b];
+    } else if (q < id.u0) {
+        const int e = q - 27, pat = e % 3 + 1, d = (e / 3) % 3, dom = e / 9 + 1;
+        a_row_bands(g, 2, 2, 2, c, on_box);
+        conductor_terms(g, valPHYS, dom, c);
+        for (int b = 0; b < 7; ++b) t[b] = c[b];
+        const double C = valPHYS[1 * (int64_t)g.nsub_glob + dom - 1];
+        double *u = t + 7 + 2; // u[m], m = -2..2 : coefficient of U(cell + m*step_d)
+        if (pat == 1) {        // :678-679 (x), :692-693, :707-708
+            u[+1] = -C * g.ds[d];
+            u[-1] = +C * g.ds[d];
+        } else if (pat == 2) { // U(+1) missing  :667-671
+            u[0] = -3.0 * C * g.ds[d];
+            u[-1] = +4.0 * C * g.ds[d];
+            u[-2] = -1.0 * C * g.ds[d];
+        } else {               // U(-1) missing  :672-676
+            u[0] = +3.0 * C * g.ds[d];
+            u[+1] = -4.0 * C * g.ds[d];
+            u[+2] = +1.0 * C * g.ds[d];
+        }
+    } else if (q < id.zero) { // U row, src/EC3D.f90:766-922
+        const int p = q - id.u0, st[3] = {p % 3, (p / 3) % 3, p / 9};
+        const int nmiss = (st[0] != 0) + (st[1] != 0) + (st[2] != 0);
+        const double h = 0.5 / g.dt;
+        const bool quirk = st[0] == 1 && st[1] == 2 && st[2] == 2; // :803-804
+        for (int d = 0; d < 3; ++d) {
+            double &cm = t[2 - d], &cp = t[4 + d]; // bands -step_d / +step_d
+            if (st[d] == 0) { cm = -g.s[d]; cp = -g.s[d]; }
+            else if (st[d] == 1) { cm = 0.0; cp = -2.0 * g.s[d]; }
+            else { cm = -2.0 * g.s[d]; cp = 0.0; }
+            double *a = t + 7 + 3 * d; // A_d(cell - step), A_d(cell), A_d(cell + step)
+            if (nmiss == 0) {
+                a[0] = h * (1.0 / g.delta[d]);  // kim / kjm / kkm
+                a[2] = h * (-1.0 / g.delta[d]); // kip / kjp / kkp
+            } else if (st[d] != 0) {
+                const double av = 2.0 / (g.dt * g.delta[d]);
+                bool neg = st[d] == 1;
+                if (quirk && d < 2) neg = !neg;
+                a[1] = neg ? -av : av;
+            }
+        }
+        t[3] = 2.0 * ((g.s[0] + g.s[1]) + g.s[2]);
+    }
+    for (int j = 0; j < 16; ++j) table[q * 16 + j] = t[j];
+}
+
+__global__ __launch_bounds__(256) void k_assemble_sav(GridPar g, const int8_t *__restrict__ geo,
+                                                      const int32_t *__restrict__ geoC, uint8_t *cls,
+                                                      uint8_t *tile_flag, uint8_t *flags, int *err,
+                                                      unsigned long long *nnz)
+{
+    const SavIds id = sav_ids(g.nsub_glob);
+    const int64_t nn0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (nn0 >= g.nCells) return;
+    const int i = (int)(nn0 % g.sdx) + 1, j = (int)((nn0 / g.sdx) % g.sdy) + 1, k = (int)(nn0 / g.kdz) + 1;
+    const int bt = a_row_class(g, i, j, k, 0);
+    const int32_t u0 = geoC[nn0];
+    const bool on_box = bt != 13;
+    uint8_t fl = 0;
+    // nonzeros of the plain A row: 7 minus one per box face the cell touches
+    const int tx = bt % 3, ty = (bt / 3) % 3, tz = bt / 9;
+    unsigned long long cnt = 3ull * (7 - (tx != 1) - (ty != 1) - (tz != 1));
+    if (u0 == 0) {
+        cls[nn0] = cls[g.nCells + nn0] = cls[2 * g.nCells + nn0] = (uint8_t)bt;
+        flags[nn0] = 0;
+        atomicAdd(nnz, cnt);
+        return;
+    }
+    if (on_box) { atomicMax(err, 3); return; }
+    const int dom = geo[nn0];
+    const int64_t step[3] = {1, g.sdx, g.kdz};
+    const int pos[3] = {i, j, k}, sd[3] = {g.sdx, g.sdy, g.sdz};
+    int pu = 0, mul = 1;
+    for (int d = 0; d < 3; ++d, mul *= 3) {
+        const int32_t um = geoC[nn0 - step[d]], up = geoC[nn0 + step[d]];
+        int pat;
+        if (up == 0) { // :667-671: needs U(-1), U(-2)
+            if (pos[d] - 2 < 1) { atomicMax(err, 3); return; }
+            if (um == 0 || geoC[nn0 - 2 * step[d]] == 0) { atomicMax(err, 1); return; }
+            pat = 2;
+        } else if (um == 0) {
+            if (pos[d] + 2 > sd[d]) { atomicMax(err, 3); return; }
+            if (geoC[nn0 + 2 * step[d]] == 0) { atomicMax(err, 1); return; }
+            pat = 3;
+        } else {
+            pat = 1;
+        }
+        if (pat != 1) fl |= (uint8_t)(1u << d);
+        cnt += pat == 1 ? 2 : 3;
+        const int64_t row = (int64_t)d * g.nCells + nn0;
+        cls[row] = (uint8_t)(id.a0 + ((dom - 1) * 3 + d) * 3 + pat - 1);
+        tile_flag[row / EC3D_TILE] = 1;
+        // U row: which neighbours are missing
+        if (um == 0 && up == 0) { atomicMax(err, 1); return; } // the reference meets a zero column here
+        const int st = um == 0 ? 1 : (up == 0 ? 2 : 0);
+        if (st) fl |= (uint8_t)(8u << d);
+        pu += st * mul;
+    }
+    const int64_t urow = 3 * g.nCells + nn0;
+    cls[urow] = (uint8_t)(id.u0 + pu);
+    tile_flag[urow / EC3D_TILE] = 1;
+    cnt += pu == 0 ? 13 : 7;
+    flags[nn0] = fl;
+    atomicAdd(nnz, cnt);
+}
+
 } // namespace
 
 static int64_t round_up64(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
@@ -525,6 +666,116 @@ int ec3d_assemble_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t sdz, int
         c->halo = g.kdz;
         return ec3d_prepare_vectors(c);
     }
+    if ((rc = ec3d_prepare_vectors(c))) return rc;
+    return ec3d_setup_rhs(c, g.nCells, geoPHYS, geoPHYS_C, valPHYS, nsub_glob, dt);
+}
+
+// The structured form of the A-V system (MatView::sav).  Returns -1 when it does not apply.
+int ec3d_assemble_sav_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t sdz, const int8_t *geoPHYS,
+                             const int32_t *geoPHYS_C, const double *valPHYS, int32_t nsub_glob,
+                             const double *BND, const double *delta, double dt)
+{
+    GridPar g;
+    memset(&g, 0, sizeof g);
+    int rc = fill_gridpar(g, sdx, sdy, sdz, BND, delta, dt);
+    if (rc) return rc;
+    g.nsub_glob = nsub_glob;
+    g.own_k1 = sdz;
+    const SavIds id = sav_ids(nsub_glob);
+    if (id.ncls > 256 || sdx < 5 || sdy < 5 || sdz < 5) return -1;
+    // conducting cells in scan order; one conducting domain only (U numbering = scan order)
+    std::vector<int32_t> uidx((size_t)g.nCells, -1);
+    int64_t nc0 = 0;
+    int dom_seen = 0;
+    for (int64_t q = 0; q < g.nCells; ++q)
+        if (geoPHYS_C[q] != 0) {
+            const int dom = geoPHYS[q];
+            if (dom < 1 || dom > nsub_glob) {
+                ec3d_set_error("ec3d_assemble: geoPHYS domain id out of range");
+                return 2;
+            }
+            if (dom_seen && dom != dom_seen) return -1;
+            dom_seen = dom;
+            if (geoPHYS_C[q] != 3 * g.nCells + nc0 + 1) return -1; // not scan-order numbering
+            uidx[(size_t)q] = (int32_t)nc0++;
+        }
+    const int64_t n_dev = 4 * g.nCells;
+    if (n_dev > (int64_t)INT32_MAX - EC3D_TILE) return -1;
+    g.ncells0 = nc0;
+    ec3d_free_matrix(c);
+    DevMatrix &A = c->A;
+    A.n = n_dev;
+    A.n_pad = g.n_pad = round_up64(n_dev, EC3D_TILE);
+    set_offsets(A, g);
+    A.sav = 1;
+    A.sav_a0 = id.a0;
+    A.sav_u0 = id.u0;
+    A.sav_zero = id.zero;
+    A.sav_nC = g.nCells;
+    A.sav_step[0] = 1; A.sav_step[1] = sdx; A.sav_step[2] = g.kdz;
+    A.ncls = id.ncls;
+    c->n_ref = 3 * g.nCells + nc0;
+    EC3D_HIP(hipMalloc(&A.tail_id, 8));
+    EC3D_HIP(hipMalloc(&A.chunk_ptr, 8));
+    EC3D_HIP(hipMalloc(&A.tcol, 8));
+    EC3D_HIP(hipMalloc(&A.tval, 8));
+    EC3D_HIP(hipMalloc(&A.cls, (size_t)A.n_pad));
+    EC3D_HIP(hipMemsetAsync(A.cls, id.zero, (size_t)A.n_pad, c->stream));
+    EC3D_HIP(hipMalloc(&A.tile_flag, (size_t)(A.n_pad / EC3D_TILE)));
+    EC3D_HIP(hipMemsetAsync(A.tile_flag, 0, (size_t)(A.n_pad / EC3D_TILE), c->stream));
+    EC3D_HIP(hipMalloc(&A.table, (size_t)id.ncls * 16 * sizeof(double)));
+    A.bytes = A.n_pad + A.n_pad / EC3D_TILE + id.ncls * 128;
+
+    int8_t *d_geo = nullptr;
+    int32_t *d_geoC = nullptr;
+    double *d_val = nullptr;
+    uint8_t *d_flags = nullptr;
+    int *d_err = nullptr;
+    unsigned long long *d_nnz = nullptr;
+    EC3D_HIP(hipMalloc(&d_geo, (size_t)g.nCells));
+    EC3D_HIP(hipMalloc(&d_geoC, (size_t)g.nCells * 4));
+    EC3D_HIP(hipMalloc(&d_val, (size_t)nsub_glob * 5 * 8));
+    EC3D_HIP(hipMalloc(&d_flags, (size_t)g.nCells));
+    EC3D_HIP(hipMalloc(&d_err, sizeof(int)));
+    EC3D_HIP(hipMalloc(&d_nnz, sizeof(unsigned long long)));
+    EC3D_HIP(hipMemcpyAsync(d_geo, geoPHYS, (size_t)g.nCells, hipMemcpyHostToDevice, c->stream));
+    EC3D_HIP(hipMemcpyAsync(d_geoC, geoPHYS_C, (size_t)g.nCells * 4, hipMemcpyHostToDevice, c->stream));
+    EC3D_HIP(hipMemcpyAsync(d_val, valPHYS, (size_t)nsub_glob * 5 * 8, hipMemcpyHostToDevice, c->stream));
+    EC3D_HIP(hipMemsetAsync(d_err, 0, sizeof(int), c->stream));
+    EC3D_HIP(hipMemsetAsync(d_nnz, 0, sizeof(unsigned long long), c->stream));
+    k_build_table_sav<<<(id.ncls + 63) / 64, 64, 0, c->stream>>>(g, d_val, A.table);
+    k_assemble_sav<<<(unsigned)((g.nCells + 255) / 256), 256, 0, c->stream>>>(g, d_geo, d_geoC, A.cls, A.tile_flag,
+                                                                              d_flags, d_err, d_nnz);
+    EC3D_HIP(hipGetLastError());
+    int err = 0;
+    unsigned long long nnz = 0;
+    std::vector<uint8_t> flags((size_t)g.nCells);
+    EC3D_HIP(hipMemcpyAsync(&err, d_err, sizeof err, hipMemcpyDeviceToHost, c->stream));
+    EC3D_HIP(hipMemcpyAsync(&nnz, d_nnz, sizeof nnz, hipMemcpyDeviceToHost, c->stream));
+    EC3D_HIP(hipMemcpyAsync(flags.data(), d_flags, flags.size(), hipMemcpyDeviceToHost, c->stream));
+    EC3D_HIP(hipStreamSynchronize(c->stream));
+    (void)hipFree(d_geo); (void)hipFree(d_geoC); (void)hipFree(d_val);
+    (void)hipFree(d_flags); (void)hipFree(d_err); (void)hipFree(d_nnz);
+    if (err) {
+        ec3d_free_matrix(c);
+        ec3d_set_error(err == 3 ? "ec3d_assemble: conductor touches the box boundary or is thinner than 3 cells "
+                                  "(the reference indexes out of range here)"
+                                : "ec3d_assemble: non-positive column (src/EC3D.f90:717-720, :945-948)");
+        return err;
+    }
+    A.nnz = (int64_t)nnz;
+    for (auto &l : c->cel_bnd) l.clear();
+    for (int64_t q = 0; q < g.nCells; ++q) {
+        const uint8_t f = flags[(size_t)q];
+        if (!f) continue;
+        for (int d = 0; d < 3; ++d) {
+            if (f & (1u << d)) c->cel_bnd[d].push_back((int32_t)(d * g.nCells + q + 1));
+            if (f & (8u << d)) c->cel_bnd[3 + d].push_back(geoPHYS_C[q]);
+        }
+    }
+    c->have_matrix = true;
+    c->sdx = sdx; c->sdy = sdy; c->sdz = sdz;
+    if (nc0) EC3D_HIP(hipMalloc(&c->io_tmp, (size_t)nc0 * sizeof(double)));
     if ((rc = ec3d_prepare_vectors(c))) return rc;
     return ec3d_setup_rhs(c, g.nCells, geoPHYS, geoPHYS_C, valPHYS, nsub_glob, dt);
 }

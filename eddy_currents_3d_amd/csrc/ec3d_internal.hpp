@@ -36,6 +36,15 @@ struct MatView {
     const double *table;
     int ncls;
     int pm1; // bands 2 and 4 of a 7-band operator are the offsets -1 and +1
+    // Structured A-V form (sav != 0): unknowns [Ax | Ay | Az | U] with U EMBEDDED in the grid (one U
+    // slot per cell, 4*nC rows), so the A<->U couplings are fixed-offset stencil slots too and there is
+    // no tail.  A class = 7 band coefficients + 9 coupling coefficients (table stride 16):
+    //   row of block d < 3, classes [sav_a0, sav_u0): + sum_{m=-2..2} t[7+m+2] * x[r + (3-d)*nC + m*step_d]
+    //   row of block 3,     classes [sav_u0, sav_zero): sum_{d,j} t[7+3d+j] * x[r - (3-d)*nC + (j-1)*step_d]
+    //                       added BEFORE the bands (the A columns are the lower ones)
+    int sav;
+    int sav_a0, sav_u0, sav_zero;
+    int64_t sav_nC, sav_step[3];
 };
 
 // where a kernel finds the partial sums it has to finish: value i of slot s is
@@ -111,6 +120,9 @@ struct DevMatrix {
     uint8_t *cls = nullptr; // dictionary form (ncls > 0): bands == nullptr
     double *table = nullptr;
     int ncls = 0;
+    // structured A-V form (see MatView)
+    int sav = 0, sav_a0 = 0, sav_u0 = 0, sav_zero = 0;
+    int64_t sav_nC = 0, sav_step[3] = {0, 0, 0};
     int64_t bytes = 0;
     MatView view() const;
 };
@@ -137,6 +149,9 @@ struct ec3d_ctx {
     double *lsum = nullptr, *gsum = nullptr; // caller-owned device buffers (P_NSLOT, nranks*P_NSLOT)
     int64_t halo = 0;                        // doubles per halo plane (kdz), 0 when not a slab
     bool use_dict = true;
+    bool use_sav = true;   // structured A-V form for ec3d_assemble when the problem allows it (EC3D_SAV)
+    int64_t n_ref = 0;     // unknowns in the reference's numbering (what host vectors hold); = A.n unless sav
+    double *io_tmp = nullptr; // sav: staging for the U part of host<->device vector copies
     int nblk_request = 0;
     int nt_request = -1; // -1 auto, 0/1 forced (EC3D_NT)
     int zm_request = 1;  // z-marching SpMV map when the grid allows it (EC3D_ZMARCH)
@@ -189,6 +204,9 @@ int ec3d_upload_matrix(ec3d_ctx *c, const HostMatrix &M);
 int ec3d_download_matrix(ec3d_ctx *c, HostMatrix &M);
 void ec3d_free_matrix(ec3d_ctx *c);
 int ec3d_prepare_vectors(ec3d_ctx *c);
+// host vector (reference numbering, n_ref entries) <-> device vector (device numbering)
+int ec3d_vec_h2d(ec3d_ctx *c, double *dev, const double *host);
+int ec3d_vec_d2h(ec3d_ctx *c, double *host, const double *dev);
 
 // ec3d_kernels.hip — launchers (all asynchronous on `s`)
 void ec3d_launch_spmv(const MatView &A, const Sweep &sw, const double *x, double *y, hipStream_t s);
@@ -214,6 +232,9 @@ void ec3d_launch_k5(const Sweep &sw, const RedSrc &src, SolverState *st, int it,
 int ec3d_assemble_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t sdz, int32_t e0, int32_t e1, int32_t k0,
                          int32_t k1, const int8_t *geoPHYS, const int32_t *geoPHYS_C, const double *valPHYS,
                          int32_t nsub_glob, const double *BND, const double *delta, double dt);
+int ec3d_assemble_sav_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t sdz, const int8_t *geoPHYS,
+                             const int32_t *geoPHYS_C, const double *valPHYS, int32_t nsub_glob,
+                             const double *BND, const double *delta, double dt);
 int ec3d_assemble_poisson_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t sdz, int32_t k0, int32_t k1,
                                  const double *BND, const double *delta);
 // ec3d_format.cpp / ec3d_solver.hip: dictionary compression of the bands

@@ -179,16 +179,49 @@ __device__ __forceinline__ double tail_add(const MatView &A, const V &x, int t, 
 //   FMT_DICT7    7 bands whose coefficient 7-tuples take <= 256 distinct values ("stencil classes"):
 //                one class byte per row + a table staged in LDS (17 B/row: 1 + x + y).  The values
 //                multiplied are the same doubles, so results are bit-identical to FMT_DIA7.
-enum { FMT_GENERIC = 0, FMT_DIA7 = 7, FMT_DICT7 = 107 };
+enum { FMT_GENERIC = 0, FMT_DIA7 = 7, FMT_DICT7 = 107, FMT_SAV = 207 };
 #define EC3D_TBL_DOUBLES (256 * 7)
+#define EC3D_SAV_STRIDE 16
+#define EC3D_SAV_TBL_DOUBLES (256 * EC3D_SAV_STRIDE)
 
 template <int FMT>
 __device__ __forceinline__ void stage_table(const MatView &A, double *tbl)
 {
-    if (FMT == FMT_DICT7) {
-        for (int i = threadIdx.x; i < A.ncls * 7; i += EC3D_THREADS) tbl[i] = A.table[i];
+    if (FMT == FMT_DICT7 || FMT == FMT_SAV) {
+        const int cnt = A.ncls * (FMT == FMT_SAV ? EC3D_SAV_STRIDE : 7);
+        for (int i = threadIdx.x; i < cnt; i += EC3D_THREADS) tbl[i] = A.table[i];
         __syncthreads();
     }
+}
+
+// Structured A-V form: the coupling slots of a row (see MatView).  Loads first, then the adds in slot
+// order = ascending column order = the reference's row-sum order.
+template <class V>
+__device__ __forceinline__ double sav_u_pre(const MatView &A, const double *t, const V &x, int64_t r)
+{
+    double xv[9];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int64_t base = r - (3 - d) * A.sav_nC;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) xv[3 * d + j] = x.at(base + (j - 1) * A.sav_step[d]);
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) s = s + t[7 + j] * xv[j];
+    return s;
+}
+template <class V>
+__device__ __forceinline__ double sav_a_post(const MatView &A, const double *t, const V &x, int64_t r, double s)
+{
+    const int d = (r >= A.sav_nC) + (r >= 2 * A.sav_nC);
+    const int64_t base = r + (3 - d) * A.sav_nC, step = A.sav_step[d];
+    double xv[5];
+#pragma unroll
+    for (int m = 0; m < 5; ++m) xv[m] = x.at(base + (m - 2) * step);
+#pragma unroll
+    for (int m = 0; m < 5; ++m) s = s + t[7 + m] * xv[m];
+    return s;
 }
 
 // x values of the planes below / at the current row, carried across the steps of a z-march
@@ -203,7 +236,7 @@ template <int FMT, bool ZM, class V>
 __device__ __forceinline__ void spmv_pair(const MatView &A, const double *tbl, const V &x, int64_t r, int64_t tile,
                                           bool first, ZRegs &z, double &s0, double &s1, d2 &ctr)
 {
-    if (FMT == FMT_DIA7 || FMT == FMT_DICT7) {
+    if (FMT == FMT_DIA7 || FMT == FMT_DICT7 || FMT == FMT_SAV) {
         d2 xv[7];
         // the +-1 neighbours (bands 2 and 4 of the 7-point operator) are the centre pairs of the
         // adjacent lanes: take them by lane shuffle instead of two unaligned 16-byte loads; only the
@@ -241,7 +274,7 @@ __device__ __forceinline__ void spmv_pair(const MatView &A, const double *tbl, c
                 s0 = s0 + c[b].x * xv[b].x;
                 s1 = s1 + c[b].y * xv[b].y;
             }
-        } else {
+        } else if (FMT == FMT_DICT7) {
             const unsigned short cc = *reinterpret_cast<const unsigned short *>(A.cls + r);
             const double *t0 = tbl + (cc & 0xFF) * 7, *t1 = tbl + (cc >> 8) * 7;
             s0 = t0[0] * xv[0].x;
@@ -250,6 +283,26 @@ __device__ __forceinline__ void spmv_pair(const MatView &A, const double *tbl, c
             for (int b = 1; b < 7; ++b) {
                 s0 = s0 + t0[b] * xv[b].x;
                 s1 = s1 + t1[b] * xv[b].y;
+            }
+        } else { // FMT_SAV: U rows take their A couplings first, A rows their U couplings last
+            const unsigned short cc = *reinterpret_cast<const unsigned short *>(A.cls + r);
+            const int c0 = cc & 0xFF, c1 = cc >> 8;
+            const double *t0 = tbl + c0 * EC3D_SAV_STRIDE, *t1 = tbl + c1 * EC3D_SAV_STRIDE;
+            const bool cpl = A.tile_flag[tile] != 0; // any coupled row in this tile (uniform)
+            s0 = 0.0;
+            s1 = 0.0;
+            if (cpl) {
+                if (c0 >= A.sav_u0 && c0 < A.sav_zero) s0 = sav_u_pre(A, t0, x, r);
+                if (c1 >= A.sav_u0 && c1 < A.sav_zero) s1 = sav_u_pre(A, t1, x, r + 1);
+            }
+#pragma unroll
+            for (int b = 0; b < 7; ++b) {
+                s0 = s0 + t0[b] * xv[b].x;
+                s1 = s1 + t1[b] * xv[b].y;
+            }
+            if (cpl) {
+                if (c0 >= A.sav_a0 && c0 < A.sav_u0) s0 = sav_a_post(A, t0, x, r, s0);
+                if (c1 >= A.sav_a0 && c1 < A.sav_u0) s1 = sav_a_post(A, t1, x, r + 1, s1);
             }
         }
     } else {
@@ -278,7 +331,8 @@ __device__ __forceinline__ void spmv_pair(const MatView &A, const double *tbl, c
         (void)first_;                                                                          \
         const int64_t r = tile * EC3D_TILE + 2 * (int64_t)threadIdx.x;
 #define EC3D_SWEEP_END }
-#define EC3D_TBL_DECL __shared__ double tbl[FMT == FMT_DICT7 ? EC3D_TBL_DOUBLES : 1]
+#define EC3D_TBL_DECL                                                                          \
+    __shared__ double tbl[FMT == FMT_DICT7 ? EC3D_TBL_DOUBLES : (FMT == FMT_SAV ? EC3D_SAV_TBL_DOUBLES : 1)]
 
 // ---------------------------------------------------------------------------------------------
 // plain y = A x  (src/solvers.f90:54-61)
@@ -562,6 +616,7 @@ __global__ __launch_bounds__(EC3D_THREADS) void k5_p_update(Sweep sw, RedSrc src
 // launchers
 static inline int fmt_of(const MatView &A)
 {
+    if (A.sav) return FMT_SAV;
     if (A.nb == 7 && A.ncls > 0) return FMT_DICT7;
     if (A.nb == 7) return FMT_DIA7;
     return FMT_GENERIC;
@@ -583,6 +638,7 @@ static inline bool nt_of(const Sweep &sw) { return sw.nt != 0; }
 #define EC3D_DISPATCH(A, KERNEL, ...)                                                          \
     do {                                                                                       \
         switch (fmt_of(A)) {                                                                   \
+        case FMT_SAV: EC3D_LAUNCH_FMT(FMT_SAV, KERNEL, __VA_ARGS__); break;                    \
         case FMT_DICT7: EC3D_LAUNCH_FMT(FMT_DICT7, KERNEL, __VA_ARGS__); break;                \
         case FMT_DIA7: EC3D_LAUNCH_FMT(FMT_DIA7, KERNEL, __VA_ARGS__); break;                  \
         default: EC3D_LAUNCH_FMT(FMT_GENERIC, KERNEL, __VA_ARGS__);                            \

@@ -47,10 +47,21 @@ __global__ void k_rhs_inertial(MatView A, const int32_t *cond_cell, const double
         const int64_t q = c * nCells + L;
         b[q] = a * x[q] + b[q]; // :380-382
     }
+    double s = 0.0;
+    if (A.sav) { // structured form: the U row of cell L is 3*nC + L; its A columns are slots 7..15
+        const int64_t row = 3 * nCells + L;
+        const double *t = A.table + (int64_t)A.cls[row] * 16;
+        for (int d = 0; d < 3; ++d)
+            for (int j = 0; j < 3; ++j) {
+                const double v = t[7 + 3 * d + j];
+                if (v != 0.0) s = s + v * x[d * nCells + L + (j - 1) * A.sav_step[d]];
+            }
+        b[row] = s;
+        return;
+    }
     // :385-392  U row m restricted to its A columns (stored ascending, A columns first)
     const int64_t row = 3 * nCells + m;
     const int32_t t = A.tail_id[row];
-    double s = 0.0;
     if (t >= 0) {
         const int64_t base = A.chunk_ptr[t >> 6], end = A.chunk_ptr[(t >> 6) + 1];
         for (int64_t e = base + (t & 63); e < end; e += EC3D_CHUNK) {
@@ -119,7 +130,11 @@ int ec3d_setup_rhs(ec3d_ctx *c, int64_t nCells, const int8_t *geoPHYS, const int
     std::vector<int32_t> lists;
     for (int w = 0; w < 6; ++w) {
         c->bnd_off[w] = (int64_t)lists.size();
-        for (int32_t id : c->cel_bnd[w]) lists.push_back(id - 1);
+        for (int32_t id : c->cel_bnd[w]) {
+            int64_t dev = (int64_t)id - 1;
+            if (c->A.sav && dev >= 3 * nCells) dev = 3 * nCells + cell[(size_t)(dev - 3 * nCells)]; // U(m) -> its cell
+            lists.push_back((int32_t)dev);
+        }
     }
     c->bnd_off[6] = (int64_t)lists.size();
     if (c->n_cond == 0) return 0;
@@ -170,8 +185,8 @@ extern "C" int ec3d_rhs_step(ec3d_handle c, int32_t moving, int32_t nsrc, const 
         std::vector<double> val;
         bool dup = false;
         for (int32_t q = 0; q < nsrc; ++q) {
-            if (src_index[q] < 1 || src_index[q] > c->A.n) {
-                ec3d_set_error("ec3d_rhs_step: source index out of range");
+            if (src_index[q] < 1 || src_index[q] > 3 * nCells) {
+                ec3d_set_error("ec3d_rhs_step: source index out of range (sources act on Ax, Ay, Az)");
                 return 2;
             }
             dup |= !last.emplace(src_index[q], src_value[q]).second;

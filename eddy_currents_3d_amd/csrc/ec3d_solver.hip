@@ -32,6 +32,12 @@ MatView DevMatrix::view() const
     v.cls = cls;
     v.table = table;
     v.ncls = ncls;
+    v.sav = sav;
+    v.sav_a0 = sav_a0;
+    v.sav_u0 = sav_u0;
+    v.sav_zero = sav_zero;
+    v.sav_nC = sav_nC;
+    for (int d = 0; d < 3; ++d) v.sav_step[d] = sav_step[d];
     static const bool shuffle_off = getenv("EC3D_SHUFFLE") && atoi(getenv("EC3D_SHUFFLE")) == 0;
     v.pm1 = (nb == 7 && off[2] == -1 && off[4] == 1 && !shuffle_off) ? 1 : 0;
     v.has_tail = ntail > 0 && !getenv("EC3D_EXPERIMENT_NOTAIL"); // experiment knob: timing only, wrong results
@@ -68,6 +74,7 @@ extern "C" int ec3d_create(ec3d_handle *h, int device)
     if (const char *e = getenv("EC3D_NBLK")) c->nblk_request = atoi(e);
     if (const char *e = getenv("EC3D_DICT")) c->use_dict = atoi(e) != 0;
     if (const char *e = getenv("EC3D_NT")) c->nt_request = atoi(e);
+    if (const char *e = getenv("EC3D_SAV")) c->use_sav = atoi(e) != 0;
     *h = c;
     return 0;
 }
@@ -94,6 +101,9 @@ void ec3d_free_matrix(ec3d_ctx *c)
     if (A.cls) (void)hipFree(A.cls);
     if (A.table) (void)hipFree(A.table);
     A = DevMatrix();
+    if (c->io_tmp) (void)hipFree(c->io_tmp);
+    c->io_tmp = nullptr;
+    c->n_ref = 0;
     c->halo = 0;
     c->nown = 0;
     ec3d_free_rhs(c);
@@ -212,6 +222,7 @@ int ec3d_prepare_vectors(ec3d_ctx *c)
     free_vectors(c);
     int64_t maxoff = 0;
     for (int b = 0; b < c->A.nb; ++b) maxoff = std::max<int64_t>(maxoff, std::llabs(c->A.off[b]));
+    if (c->A.sav) maxoff *= 2; // the one-sided A-U slots reach two planes
     int64_t galign = 64;
     if (const char *e = getenv("EC3D_GHOST_ALIGN")) galign = std::max<int64_t>(2, atoll(e));
     c->ghost = round_up(maxoff + 2, galign);
@@ -219,6 +230,7 @@ int ec3d_prepare_vectors(ec3d_ctx *c)
     EC3D_HIP(hipMalloc(&c->vec_base, (size_t)len * EC3D_NVEC * sizeof(double)));
     EC3D_HIP(hipMemsetAsync(c->vec_base, 0, (size_t)len * EC3D_NVEC * sizeof(double), c->stream));
     for (int v = 0; v < EC3D_NVEC; ++v) c->vec[v] = c->vec_base + (size_t)v * len + c->ghost;
+    if (c->n_ref == 0) c->n_ref = c->A.n;
     choose_sweep(c);
     EC3D_HIP(hipMalloc(&c->partials, (size_t)P_NSLOT * c->sweep.pstride * sizeof(double)));
     EC3D_HIP(hipMemsetAsync(c->partials, 0, (size_t)P_NSLOT * c->sweep.pstride * sizeof(double), c->stream));
@@ -352,6 +364,10 @@ extern "C" int ec3d_assemble(ec3d_handle c, int32_t sdx, int32_t sdy, int32_t sd
                              const double *BND, const double *delta, double dt)
 {
     EC3D_HIP(hipSetDevice(c->device));
+    if (c->use_sav && c->use_dict) {
+        const int rc = ec3d_assemble_sav_device(c, sdx, sdy, sdz, geoPHYS, geoPHYS_C, valPHYS, nsub_glob, BND, delta, dt);
+        if (rc != -1) return rc; // -1: the structured form does not apply, use the general one
+    }
     return ec3d_assemble_device(c, sdx, sdy, sdz, 0, sdz, 0, sdz, geoPHYS, geoPHYS_C, valPHYS, nsub_glob, BND, delta,
                                 dt);
 }
@@ -398,6 +414,12 @@ extern "C" int ec3d_set_format(ec3d_handle c, int dictionary)
     return 0;
 }
 
+extern "C" int ec3d_set_structured(ec3d_handle c, int on)
+{
+    c->use_sav = on != 0;
+    return 0;
+}
+
 extern "C" int ec3d_set_stream(ec3d_handle c, void *stream)
 {
     EC3D_HIP(hipSetDevice(c->device));
@@ -406,17 +428,67 @@ extern "C" int ec3d_set_stream(ec3d_handle c, void *stream)
     return 0;
 }
 
+// structured form -> the reference's CSR (1-based, reference numbering, ascending columns)
+static int sav_to_csr(ec3d_ctx *c, std::vector<int32_t> &irow, std::vector<int32_t> &jcol, std::vector<double> &valA)
+{
+    const DevMatrix &A = c->A;
+    const int64_t nC = A.sav_nC, nU = c->n_cond;
+    std::vector<uint8_t> cls((size_t)A.n_pad);
+    std::vector<double> tab((size_t)A.ncls * 16);
+    std::vector<int32_t> cell((size_t)nU), uidx((size_t)nC, -1);
+    EC3D_HIP(hipStreamSynchronize(c->stream));
+    EC3D_HIP(hipMemcpy(cls.data(), A.cls, cls.size(), hipMemcpyDeviceToHost));
+    EC3D_HIP(hipMemcpy(tab.data(), A.table, tab.size() * 8, hipMemcpyDeviceToHost));
+    if (nU) EC3D_HIP(hipMemcpy(cell.data(), c->cond_cell, cell.size() * 4, hipMemcpyDeviceToHost));
+    for (int64_t m = 0; m < nU; ++m) uidx[(size_t)cell[(size_t)m]] = (int32_t)m;
+    irow.assign((size_t)c->n_ref + 1, 0);
+    jcol.clear();
+    valA.clear();
+    irow[0] = 1;
+    auto put = [&](int64_t col1, double v) {
+        if (v != 0.0) { jcol.push_back((int32_t)col1); valA.push_back(v); }
+    };
+    int64_t row = 0;
+    for (int d = 0; d < 3; ++d)
+        for (int64_t q = 0; q < nC; ++q, ++row) {
+            const int cc = cls[(size_t)(d * nC + q)];
+            const double *t = &tab[(size_t)cc * 16];
+            for (int b = 0; b < 7; ++b) put(d * nC + q + A.off[b] + 1, t[b]);
+            if (cc >= A.sav_a0 && cc < A.sav_u0)
+                for (int m = -2; m <= 2; ++m) {
+                    const double v = t[7 + m + 2];
+                    if (v != 0.0) put(3 * nC + uidx[(size_t)(q + m * A.sav_step[d])] + 1, v);
+                }
+            irow[(size_t)row + 1] = (int32_t)(jcol.size() + 1);
+        }
+    for (int64_t m = 0; m < nU; ++m, ++row) {
+        const int64_t q = cell[(size_t)m];
+        const double *t = &tab[(size_t)cls[(size_t)(3 * nC + q)] * 16];
+        for (int d = 0; d < 3; ++d)
+            for (int j = 0; j < 3; ++j) put(d * nC + q + (j - 1) * A.sav_step[d] + 1, t[7 + 3 * d + j]);
+        for (int b = 0; b < 7; ++b) {
+            if (t[b] != 0.0) put(3 * nC + uidx[(size_t)(q + A.off[b])] + 1, t[b]);
+        }
+        irow[(size_t)row + 1] = (int32_t)(jcol.size() + 1);
+    }
+    return 0;
+}
+
 extern "C" int ec3d_export_csr(ec3d_handle c, int32_t *n, int64_t *nnz, int32_t *irow, int32_t *jcol,
                                double *valA)
 {
     int rc = need_matrix(c, "ec3d_export_csr");
     if (rc) return rc;
-    HostMatrix M;
-    if ((rc = ec3d_download_matrix(c, M))) return rc;
     std::vector<int32_t> ir, jc;
     std::vector<double> va;
-    ec3d_host_matrix_to_csr(M, ir, jc, va);
-    *n = (int32_t)M.n;
+    if (c->A.sav) {
+        if ((rc = sav_to_csr(c, ir, jc, va))) return rc;
+    } else {
+        HostMatrix M;
+        if ((rc = ec3d_download_matrix(c, M))) return rc;
+        ec3d_host_matrix_to_csr(M, ir, jc, va);
+    }
+    *n = (int32_t)c->n_ref;
     *nnz = (int64_t)jc.size();
     if (irow) memcpy(irow, ir.data(), ir.size() * sizeof(int32_t));
     if (jcol) memcpy(jcol, jc.data(), jc.size() * sizeof(int32_t));
@@ -459,7 +531,7 @@ extern "C" int ec3d_get_matrix_info(ec3d_handle c, ec3d_matrix_info *info)
     int rc = need_matrix(c, "ec3d_get_matrix_info");
     if (rc) return rc;
     memset(info, 0, sizeof *info);
-    info->n = c->A.n;
+    info->n = c->n_ref;
     info->n_pad = c->A.n_pad;
     info->nnz = c->A.nnz;
     info->nbands = c->A.nb;
@@ -471,12 +543,79 @@ extern "C" int ec3d_get_matrix_info(ec3d_handle c, ec3d_matrix_info *info)
     return 0;
 }
 
+// host vectors are in the reference's numbering [Ax | Ay | Az | U(scan order)].  The structured A-V form
+// keeps the three A blocks as they are and spreads U over a 4th grid-shaped block: U(m) lives at
+// 3*nC + cell(m).  Inactive U slots are never written and stay 0.
+namespace {
+__global__ void k_u_scatter(double *ublock, const int32_t *cell, const double *src, int64_t nu)
+{
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m < nu) ublock[cell[m]] = src[m];
+}
+__global__ void k_u_gather(const double *ublock, const int32_t *cell, double *dst, int64_t nu)
+{
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m < nu) dst[m] = ublock[cell[m]];
+}
+} // namespace
+
+int ec3d_vec_h2d(ec3d_ctx *c, double *dev, const double *host)
+{
+    if (!c->A.sav) {
+        EC3D_HIP(hipMemcpyAsync(dev, host, (size_t)c->A.n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        return 0;
+    }
+    const int64_t nA = 3 * c->A.sav_nC, nu = c->n_cond;
+    EC3D_HIP(hipMemcpyAsync(dev, host, (size_t)nA * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (nu) {
+        EC3D_HIP(hipMemcpyAsync(c->io_tmp, host + nA, (size_t)nu * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        k_u_scatter<<<(unsigned)((nu + 255) / 256), 256, 0, c->stream>>>(dev + nA, c->cond_cell, c->io_tmp, nu);
+        EC3D_HIP(hipGetLastError());
+        EC3D_HIP(hipStreamSynchronize(c->stream)); // io_tmp is shared by consecutive copies
+    }
+    return 0;
+}
+
+int ec3d_vec_d2h(ec3d_ctx *c, double *host, const double *dev)
+{
+    if (!c->A.sav) {
+        EC3D_HIP(hipMemcpyAsync(host, dev, (size_t)c->A.n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        return 0;
+    }
+    const int64_t nA = 3 * c->A.sav_nC, nu = c->n_cond;
+    EC3D_HIP(hipMemcpyAsync(host, dev, (size_t)nA * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (nu) {
+        k_u_gather<<<(unsigned)((nu + 255) / 256), 256, 0, c->stream>>>(dev + nA, c->cond_cell, c->io_tmp, nu);
+        EC3D_HIP(hipGetLastError());
+        EC3D_HIP(hipMemcpyAsync(host + nA, c->io_tmp, (size_t)nu * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        EC3D_HIP(hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
+// tests: device row of every reference unknown
+extern "C" int ec3d_get_row_map(ec3d_handle c, int32_t *ref_to_dev)
+{
+    int rc = need_matrix(c, "ec3d_get_row_map");
+    if (rc) return rc;
+    if (!c->A.sav) {
+        for (int64_t i = 0; i < c->A.n; ++i) ref_to_dev[i] = (int32_t)i;
+        return 0;
+    }
+    const int64_t nA = 3 * c->A.sav_nC;
+    for (int64_t i = 0; i < nA; ++i) ref_to_dev[i] = (int32_t)i;
+    std::vector<int32_t> cell((size_t)c->n_cond);
+    if (c->n_cond) EC3D_HIP(hipMemcpy(cell.data(), c->cond_cell, cell.size() * 4, hipMemcpyDeviceToHost));
+    for (int64_t m = 0; m < c->n_cond; ++m) ref_to_dev[nA + m] = (int32_t)(nA + cell[(size_t)m]);
+    return 0;
+}
+
 extern "C" int ec3d_upload(ec3d_handle c, int which, const double *host)
 {
     int rc = need_matrix(c, "ec3d_upload");
     if (rc) return rc;
     if (which < 0 || which >= EC3D_NVEC) return 2;
-    EC3D_HIP(hipMemcpyAsync(c->vec[which], host, (size_t)c->A.n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if ((rc = ec3d_vec_h2d(c, c->vec[which], host))) return rc;
     EC3D_HIP(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -486,7 +625,7 @@ extern "C" int ec3d_download(ec3d_handle c, int which, double *host)
     int rc = need_matrix(c, "ec3d_download");
     if (rc) return rc;
     if (which < 0 || which >= EC3D_NVEC) return 2;
-    EC3D_HIP(hipMemcpyAsync(host, c->vec[which], (size_t)c->A.n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if ((rc = ec3d_vec_d2h(c, host, c->vec[which]))) return rc;
     EC3D_HIP(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -513,10 +652,10 @@ extern "C" int ec3d_spmv(ec3d_handle c, const double *x, double *y)
     int rc = need_matrix(c, "ec3d_spmv");
     if (rc) return rc;
     // P and AP serve as scratch
-    EC3D_HIP(hipMemcpyAsync(c->vec[EC3D_VEC_P], x, (size_t)c->A.n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if ((rc = ec3d_vec_h2d(c, c->vec[EC3D_VEC_P], x))) return rc;
     ec3d_launch_spmv(c->A.view(), c->sweep_s, c->vec[EC3D_VEC_P], c->vec[EC3D_VEC_AP], c->stream);
     EC3D_HIP(hipGetLastError());
-    EC3D_HIP(hipMemcpyAsync(y, c->vec[EC3D_VEC_AP], (size_t)c->A.n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if ((rc = ec3d_vec_d2h(c, y, c->vec[EC3D_VEC_AP]))) return rc;
     EC3D_HIP(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -667,11 +806,10 @@ extern "C" int ec3d_solve(ec3d_handle c, const double *b, double *x, double tole
     int rc = need_matrix(c, "ec3d_solve");
     if (rc) return rc;
     if ((rc = single_rank_only(c, "ec3d_solve"))) return rc;
-    const size_t nb = (size_t)c->A.n * sizeof(double);
-    EC3D_HIP(hipMemcpyAsync(c->vec[EC3D_VEC_B], b, nb, hipMemcpyHostToDevice, c->stream));
-    EC3D_HIP(hipMemcpyAsync(c->vec[EC3D_VEC_X], x, nb, hipMemcpyHostToDevice, c->stream));
+    if ((rc = ec3d_vec_h2d(c, c->vec[EC3D_VEC_B], b))) return rc;
+    if ((rc = ec3d_vec_h2d(c, c->vec[EC3D_VEC_X], x))) return rc;
     if ((rc = solve_core(c, tolerance, itmax, iter, resid_hist, hist_cap, true))) return rc;
-    EC3D_HIP(hipMemcpyAsync(x, c->vec[EC3D_VEC_X], nb, hipMemcpyDeviceToHost, c->stream));
+    if ((rc = ec3d_vec_d2h(c, x, c->vec[EC3D_VEC_X]))) return rc;
     EC3D_HIP(hipStreamSynchronize(c->stream));
     return 0;
 }

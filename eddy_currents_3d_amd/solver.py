@@ -53,6 +53,7 @@ EXPORTS = ["sprsbcgstabwr_", "ec3d_invalidate", "ec3d_create", "ec3d_destroy", "
            "ec3d_assemble_poisson_slab", "ec3d_vector_layout", "ec3d_adopt_vectors",
            "ec3d_dist_configure", "ec3d_dist_step", "ec3d_read_state", "ec3d_set_zmarch", "ec3d_can_overlap",
            "ec3d_rhs_step", "ec3d_post_update", "ec3d_assemble_slab", "ec3d_vtk_fields",
+           "ec3d_set_structured", "ec3d_get_row_map",
            "ec3d_device_synchronize"]
 
 _f64 = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
@@ -127,6 +128,8 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.ec3d_iterate_begin.argtypes = [hp]
     L.ec3d_iterate.argtypes = [hp, C.c_int32, C.c_int32, hp]
     L.ec3d_set_format.argtypes = [hp, C.c_int]
+    L.ec3d_set_structured.argtypes = [hp, C.c_int]
+    L.ec3d_get_row_map.argtypes = [hp, _i32]
     L.ec3d_set_stream.argtypes = [hp, hp]
     L.ec3d_assemble_poisson_slab.argtypes = [hp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f64, _f64]
     L.ec3d_vector_layout.argtypes = [hp] + [C.POINTER(C.c_int64)] * 4
@@ -168,7 +171,8 @@ def sprsBCGstabWR(valA, irow, jcol, n, b, x, tolerance, itmax):
 class EC3DSolver:
     """Handle API of include/ec3d_hip.h (one HIP device, one stream)."""
 
-    def __init__(self, device: int = 0, nblk: int | None = None, dictionary: bool | None = None):
+    def __init__(self, device: int = 0, nblk: int | None = None, dictionary: bool | None = None,
+                 structured: bool | None = None):
         self.L = load_library()
         self.h = C.c_void_p()
         _chk(self.L, self.L.ec3d_create(C.byref(self.h), device), "ec3d_create")
@@ -176,6 +180,8 @@ class EC3DSolver:
             self.set_workgroups(nblk)
         if dictionary is not None:
             self.set_format(dictionary)
+        if structured is not None:
+            _chk(self.L, self.L.ec3d_set_structured(self.h, int(bool(structured))), "ec3d_set_structured")
 
     def close(self):
         if getattr(self, "h", None) and self.h.value:
@@ -222,6 +228,12 @@ class EC3DSolver:
             np.ascontiguousarray(vp.T).reshape(-1), vp.shape[0],
             np.ascontiguousarray(np.asarray(BND, np.float64).T).reshape(-1),
             np.ascontiguousarray(delta, np.float64), float(dt)), "ec3d_assemble_slab")
+
+    def row_map(self):
+        """Device row of every unknown of the reference's numbering (identity unless structured)."""
+        m = np.empty(self.n, np.int32)
+        _chk(self.L, self.L.ec3d_get_row_map(self.h, m), "ec3d_get_row_map")
+        return m
 
     def set_format(self, dictionary: bool):
         """True (default): 1 class byte per row + coefficient table when the operator allows it;

@@ -138,6 +138,26 @@ def bicgstab_wr_gpuorder(geom, valA, irow, jcol, b, x0, tol, itmax, hist_cap=0):
     return x, it.value, hs, hr
 
 
+def device_system(solver, valA, irow, jcol, *vectors):
+    """The reference's system in the DEVICE numbering of `solver` (identity unless it holds the structured
+    A-V form, where U is embedded in the grid: rows without an unknown are empty).  Returns
+    (valA, irow_dev, jcol_dev, row_map, [vectors in device numbering...]) for the GPU-order twin."""
+    rm = solver.row_map().astype(np.int64)
+    g = solver.geometry(0)
+    n_dev = int(rm.max()) + 1 if len(rm) else 0
+    n_dev = max(n_dev, min(int(g.n_pad), n_dev))
+    lens = np.zeros(n_dev, np.int64)
+    lens[rm] = np.diff(irow)
+    irow_d = np.concatenate([[1], 1 + np.cumsum(lens)]).astype(np.int32)
+    jcol_d = (rm[np.asarray(jcol, np.int64) - 1] + 1).astype(np.int32)   # rm is increasing: order kept
+    out = []
+    for v in vectors:
+        d = np.zeros(n_dev)
+        d[rm] = v
+        out.append(d)
+    return (valA, irow_d, jcol_d, rm, *out)
+
+
 def dot_gpuorder(geom, a, b):
     return lib().oracle_dot_gpuorder(C.byref(geom), np.ascontiguousarray(a), np.ascontiguousarray(b),
                                      len(a))

@@ -25,7 +25,7 @@ def test_dictionary_and_plain_dia_are_bit_identical(E, oracle, name):
     res = {}
     for route in ("csr", "assemble"):
         for dic in (False, True):
-            with E.EC3DSolver(dictionary=dic) as s:
+            with E.EC3DSolver(dictionary=dic, structured=False) as s:
                 if route == "csr":
                     s.set_matrix_csr(g["valA"], g["irow"], g["jcol"])
                 else:
@@ -271,3 +271,46 @@ def test_split_spmv_is_the_same_operator(E, oracle):
     valA, irow, jcol = oracle.poisson_csr(sdx, sdy, sdz)
     y = oracle.spmv_csr(valA, irow, jcol, x)[k0 * kdz:k1 * kdz]
     assert np.array_equal(out[0], y) and np.array_equal(out[1], y)
+
+
+# ------------------------------------------------------------------------- structured A-V form
+@pytest.mark.parametrize("name", ["g2_conducting_hole_16x15x14", "g2v_conducting_moving_16x15x14",
+                                  "g3_moving_coil_18x16x12", "g2i_itmax_exit_16x15x14"])
+def test_structured_av_form(E, oracle, name):
+    """ec3d_assemble's default storage for the A-V system: U embedded in the grid, every coupling a
+    class-coded stencil slot, no tail.  The operator is the reference's (exported CSR and SpMV bit-identical)
+    and the solve is bit-identical to the oracle's twin run on the system in device numbering."""
+    g = load_golden(name)
+    n = len(g["irow"]) - 1
+    tol, itmax = float(g["tol"]), int(g["itmax"])
+    x = np.random.Generator(np.random.PCG64(31)).standard_normal(n)
+    with E.EC3DSolver() as s:
+        s.assemble(g["geoPHYS"], g["geoPHYS_C"], g["valPHYS"], g["BND"], g["delta"], float(g["dt"]))
+        mi = s.info
+        assert mi.n == n and mi.tail_rows == 0 and mi.dict_classes > 27
+        rm = s.row_map()
+        assert rm.max() < 4 * g["geoPHYS"].size and np.all(np.diff(rm) > 0)
+        va, ir, jc = s.export_csr()
+        assert np.array_equal(ir, g["irow"]) and np.array_equal(jc, g["jcol"]) and np.array_equal(va, g["valA"])
+        assert np.array_equal(s.spmv(x), oracle.spmv_csr(g["valA"], g["irow"], g["jcol"], x))
+        for k in range(len(g["iters"])):
+            xs, it, hist = s.solve(g[f"b{k}"], g[f"xin{k}"], tol, itmax, hist_cap=64)
+            vd, ird, jcd, rmap, bd, xd = oracle.device_system(s, g["valA"], g["irow"], g["jcol"], g[f"b{k}"],
+                                                              g[f"xin{k}"])
+            xo, ito, hs, hr = oracle.bicgstab_wr_gpuorder(oracle.geoms_of(s), vd, ird, jcd, bd, xd, tol, itmax,
+                                                          hist_cap=64)
+            assert it == ito and np.array_equal(xs, xo[rmap])
+            assert np.all(np.delete(xo, rmap) == 0.0)          # inactive U slots never move
+            kk = min(it, 64)
+            assert np.array_equal(hist[:kk, 0], hs[:kk])
+            xr = g[f"xout{k}"]
+            assert np.linalg.norm(xs - xr) <= 10 * tol * np.linalg.norm(xr)
+
+
+def test_structured_form_falls_back(E, oracle):
+    """Geometries the structured form does not cover (here: dictionary format switched off) use bands + tail."""
+    g = load_golden("g2_conducting_hole_16x15x14")
+    with E.EC3DSolver(dictionary=False) as s:
+        s.assemble(g["geoPHYS"], g["geoPHYS_C"], g["valPHYS"], g["BND"], g["delta"], float(g["dt"]))
+        assert s.info.tail_rows > 0
+        assert np.array_equal(s.row_map(), np.arange(s.n))
