@@ -764,6 +764,19 @@ int ec3d_assemble_sav_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t sdz,
         return err;
     }
     A.nnz = (int64_t)nnz;
+    { // tiles lying entirely in the U block: visit only those that hold an unknown
+        const int64_t ntiles = A.n_pad / EC3D_TILE;
+        std::vector<uint8_t> tf((size_t)ntiles);
+        EC3D_HIP(hipMemcpy(tf.data(), A.tile_flag, tf.size(), hipMemcpyDeviceToHost));
+        const int64_t first_u = (3 * g.nCells + EC3D_TILE - 1) / EC3D_TILE;
+        std::vector<int32_t> ul;
+        for (int64_t t = first_u; t < ntiles; ++t)
+            if (tf[(size_t)t]) ul.push_back((int32_t)t);
+        A.ntiles_front = first_u;
+        A.ulist_n = (int)ul.size();
+        EC3D_HIP(hipMalloc(&A.ulist, std::max<size_t>(ul.size(), 1) * 4));
+        if (!ul.empty()) EC3D_HIP(hipMemcpy(A.ulist, ul.data(), ul.size() * 4, hipMemcpyHostToDevice));
+    }
     for (auto &l : c->cel_bnd) l.clear();
     for (int64_t q = 0; q < g.nCells; ++q) {
         const uint8_t f = flags[(size_t)q];

@@ -78,6 +78,11 @@ struct Sweep {
     int zm_pl0, zm_npl;
     int bnd_last;  // -1: not a boundary launch
     int part_off;  // first partial-sum index this launch writes within a slot
+    // structured A-V form: tiles [0, ntiles) are swept as usual (the three A blocks); of the tiles
+    // behind them (the grid-shaped U block) only those holding an unknown are visited, from a list --
+    // everything else there is identically zero in every vector and stays so
+    const int32_t *ulist;
+    int ulist_n;
 };
 
 struct SolverState {
@@ -122,6 +127,9 @@ struct DevMatrix {
     int ncls = 0;
     // structured A-V form (see MatView)
     int sav = 0, sav_a0 = 0, sav_u0 = 0, sav_zero = 0;
+    int32_t *ulist = nullptr; // tiles of the U block that hold at least one unknown
+    int ulist_n = 0;
+    int64_t ntiles_front = 0; // tiles swept unconditionally
     int64_t sav_nC = 0, sav_step[3] = {0, 0, 0};
     int64_t bytes = 0;
     MatView view() const;

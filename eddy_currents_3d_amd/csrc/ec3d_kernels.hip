@@ -324,10 +324,25 @@ __device__ __forceinline__ void spmv_pair(const MatView &A, const double *tbl, c
 }
 
 #define EC3D_SWEEP_BEGIN                                                                       \
+    bool need_first_ = true;                                                                   \
+    int64_t lst_ = -1; /* >= 0: walking the list of occupied U tiles */                        \
     for (int64_t it_ = 0;; ++it_) {                                                            \
-        const int64_t tile = ec3d_tile_of(sw, blockIdx.x, it_);                                \
-        if (tile >= sw.ntiles) break;                                                          \
-        const bool first_ = it_ == 0;                                                          \
+        int64_t tile = 0;                                                                      \
+        if (lst_ < 0) {                                                                        \
+            tile = ec3d_tile_of(sw, blockIdx.x, it_);                                          \
+            if (tile >= sw.ntiles) {                                                           \
+                if (sw.ulist_n == 0) break;                                                    \
+                lst_ = blockIdx.x;                                                             \
+            }                                                                                  \
+        }                                                                                      \
+        if (lst_ >= 0) {                                                                       \
+            if (lst_ >= sw.ulist_n) break;                                                     \
+            tile = sw.ulist[lst_];                                                             \
+            lst_ += sw.nblk;                                                                   \
+            need_first_ = true;                                                                \
+        }                                                                                      \
+        const bool first_ = need_first_;                                                       \
+        need_first_ = false;                                                                   \
         (void)first_;                                                                          \
         const int64_t r = tile * EC3D_TILE + 2 * (int64_t)threadIdx.x;
 #define EC3D_SWEEP_END }

@@ -98,6 +98,7 @@ void ec3d_free_matrix(ec3d_ctx *c)
     if (A.chunk_ptr) (void)hipFree(A.chunk_ptr);
     if (A.tcol) (void)hipFree(A.tcol);
     if (A.tval) (void)hipFree(A.tval);
+    if (A.ulist) (void)hipFree(A.ulist);
     if (A.cls) (void)hipFree(A.cls);
     if (A.table) (void)hipFree(A.table);
     A = DevMatrix();
@@ -147,6 +148,11 @@ static void choose_sweep(ec3d_ctx *c)
     sw.bnd_last = -1;
     sw.ntiles = c->A.n_pad / EC3D_TILE;
     sw.n = c->A.n;
+    if (c->A.ulist) { // structured A-V form: plain sweep over the A blocks, list for the U block
+        sw.ntiles = c->A.ntiles_front;
+        sw.ulist = c->A.ulist;
+        sw.ulist_n = c->A.ulist_n;
+    }
     sw.nown = c->nown;
     for (int q = 0; q < 4; ++q) {
         sw.own_lo[q] = c->own_lo[q];
@@ -516,6 +522,16 @@ extern "C" int ec3d_get_reduction_geometry(ec3d_handle c, int which, ec3d_geom *
     g->xcd_group = sw.S;
     g->zm_tpp = sw.zm_tpp;
     g->zm_pps = sw.zm_pps;
+    g->ntiles_front = (int32_t)sw.ntiles;
+    g->ulist_n = sw.ulist_n;
+    return 0;
+}
+
+extern "C" int ec3d_get_ulist(ec3d_handle c, int32_t *tiles)
+{
+    int rc = need_matrix(c, "ec3d_get_ulist");
+    if (rc) return rc;
+    if (c->A.ulist_n) EC3D_HIP(hipMemcpy(tiles, c->A.ulist, (size_t)c->A.ulist_n * 4, hipMemcpyDeviceToHost));
     return 0;
 }
 

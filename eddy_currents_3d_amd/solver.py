@@ -29,7 +29,7 @@ class EC3DError(RuntimeError):
 class Geom(C.Structure):
     _fields_ = [("n_pad", C.c_int32), ("tile", C.c_int32), ("nblk", C.c_int32),
                 ("threads", C.c_int32), ("xcd_group", C.c_int32), ("zm_tpp", C.c_int32),
-                ("zm_pps", C.c_int32)]
+                ("zm_pps", C.c_int32), ("ntiles_front", C.c_int32), ("ulist_n", C.c_int32)]
 
 
 class MatrixInfo(C.Structure):
@@ -53,7 +53,7 @@ EXPORTS = ["sprsbcgstabwr_", "ec3d_invalidate", "ec3d_create", "ec3d_destroy", "
            "ec3d_assemble_poisson_slab", "ec3d_vector_layout", "ec3d_adopt_vectors",
            "ec3d_dist_configure", "ec3d_dist_step", "ec3d_read_state", "ec3d_set_zmarch", "ec3d_can_overlap",
            "ec3d_rhs_step", "ec3d_post_update", "ec3d_assemble_slab", "ec3d_vtk_fields",
-           "ec3d_set_structured", "ec3d_get_row_map",
+           "ec3d_set_structured", "ec3d_get_row_map", "ec3d_get_ulist",
            "ec3d_device_synchronize"]
 
 _f64 = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
@@ -130,6 +130,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.ec3d_set_format.argtypes = [hp, C.c_int]
     L.ec3d_set_structured.argtypes = [hp, C.c_int]
     L.ec3d_get_row_map.argtypes = [hp, _i32]
+    L.ec3d_get_ulist.argtypes = [hp, _i32]
     L.ec3d_set_stream.argtypes = [hp, hp]
     L.ec3d_assemble_poisson_slab.argtypes = [hp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f64, _f64]
     L.ec3d_vector_layout.argtypes = [hp] + [C.POINTER(C.c_int64)] * 4
@@ -228,6 +229,13 @@ class EC3DSolver:
             np.ascontiguousarray(vp.T).reshape(-1), vp.shape[0],
             np.ascontiguousarray(np.asarray(BND, np.float64).T).reshape(-1),
             np.ascontiguousarray(delta, np.float64), float(dt)), "ec3d_assemble_slab")
+
+    def ulist(self):
+        """Occupied tiles of the U block (structured A-V form), in the order the kernels visit them."""
+        k = self.geometry(0).ulist_n
+        t = np.zeros(max(k, 1), np.int32)
+        _chk(self.L, self.L.ec3d_get_ulist(self.h, t), "ec3d_get_ulist")
+        return t[:k]
 
     def row_map(self):
         """Device row of every unknown of the reference's numbering (identity unless structured)."""

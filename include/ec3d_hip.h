@@ -184,9 +184,13 @@ typedef struct {
     int32_t xcd_group; /* S in the XCD-aware blockIdx -> tile map (0: plain grid stride) */
     int32_t zm_tpp;    /* > 0: z-marching map, tiles per xy-plane                          */
     int32_t zm_pps;    /*      planes per z segment                                        */
+    int32_t ntiles_front; /* tiles swept by the map above (all of them unless structured A-V form)  */
+    int32_t ulist_n;   /* structured A-V form: occupied tiles of the U block, visited afterwards,
+                          workgroup b taking entries b, b+nblk, ... of ec3d_get_ulist()             */
 } ec3d_geom;
 /* which = 0: vector kernels (dots S.S, R.R, R.R0); 1: SpMV kernels (B.B, initial R.R, AP.R0, AS.S, AS.AS) */
 int ec3d_get_reduction_geometry(ec3d_handle h, int which, ec3d_geom *g);
+int ec3d_get_ulist(ec3d_handle h, int32_t *tiles); /* ulist_n entries */
 /* 1 (default): SpMV kernels walk the z direction per workgroup and keep x[r-kdz], x[r] in registers
  * when a grid plane is a whole number of 512-row tiles; 0: plain tile order. */
 int ec3d_set_zmarch(ec3d_handle h, int on);

@@ -118,7 +118,7 @@ void oracle_sprsbcgstabwr_(const double *valA, const int32_t *irow, const int32_
 /* GPU summation order                                                                   */
 int64_t oracle_gpu_tile_of(const oracle_gpu_geom *g, int32_t b, int64_t i)
 {
-    int64_t ntiles = g->n_pad / g->tile, t;
+    int64_t ntiles = g->ntiles_front > 0 ? g->ntiles_front : g->n_pad / g->tile, t;
     if (g->zm_tpp > 0) { /* z-marching map: ec3d_tile_of, first branch */
         int64_t cpx = g->zm_tpp / 8, c = b % 8, s = b / 8;
         int64_t col = c * cpx + s % cpx, seg = s / cpx;
@@ -154,9 +154,21 @@ double oracle_dot_gpuorder(const oracle_gpu_geom *g, const double *a, const doub
     double *acc = malloc((size_t)T * sizeof(double));
     for (int32_t blk = 0; blk < g->nblk; ++blk) {
         for (int t = 0; t < T; ++t) acc[t] = 0.0;
+        int64_t lst = -1; /* >= 0: walking the list of occupied U tiles (structured A-V form) */
         for (int64_t i = 0;; ++i) {
-            int64_t tile = oracle_gpu_tile_of(g, blk, i);
-            if (tile < 0) break;
+            int64_t tile = -1;
+            if (lst < 0) {
+                tile = oracle_gpu_tile_of(g, blk, i);
+                if (tile < 0) {
+                    if (g->ulist_n == 0) break;
+                    lst = blk;
+                }
+            }
+            if (lst >= 0) {
+                if (lst >= g->ulist_n) break;
+                tile = g->ulist[lst];
+                lst += g->nblk;
+            }
             for (int t = 0; t < T; ++t) {
                 int64_t r = tile * g->tile + 2 * (int64_t)t;
                 double p0 = r < n ? a[r] * b[r] : 0.0;

@@ -32,7 +32,8 @@ class GpuGeom(C.Structure):
     """Reduction geometry of the HIP kernels (ec3d_get_reduction_geometry)."""
     _fields_ = [("n_pad", C.c_int32), ("tile", C.c_int32), ("nblk", C.c_int32),
                 ("threads", C.c_int32), ("xcd_group", C.c_int32), ("zm_tpp", C.c_int32),
-                ("zm_pps", C.c_int32)]
+                ("zm_pps", C.c_int32), ("ntiles_front", C.c_int32), ("ulist_n", C.c_int32),
+                ("ulist", C.POINTER(C.c_int32))]
 
 
 def build(with_ref: bool = True) -> None:
@@ -117,10 +118,14 @@ def bicgstab_wr(valA, irow, jcol, b, x0, tol, itmax, hist_cap=0):
 def geoms_of(solver):
     """(vector-kernel geometry, SpMV-kernel geometry) of an eddy_currents_3d_amd.EC3DSolver."""
     out = []
+    ul = np.ascontiguousarray(solver.ulist(), np.int32)
     for which in (0, 1):
         g = solver.geometry(which)
-        out.append(GpuGeom(n_pad=g.n_pad, tile=g.tile, nblk=g.nblk, threads=g.threads, xcd_group=g.xcd_group,
-                           zm_tpp=g.zm_tpp, zm_pps=g.zm_pps))
+        gg = GpuGeom(n_pad=g.n_pad, tile=g.tile, nblk=g.nblk, threads=g.threads, xcd_group=g.xcd_group,
+                     zm_tpp=g.zm_tpp, zm_pps=g.zm_pps, ntiles_front=g.ntiles_front, ulist_n=g.ulist_n,
+                     ulist=ul.ctypes.data_as(C.POINTER(C.c_int32)))
+        gg._keep = ul  # the struct only holds a pointer
+        out.append(gg)
     return tuple(out)
 
 

@@ -44,5 +44,7 @@ for dic in (True, False):
         out.append(f"iter={ms / 50 * 1e3:.1f}us -> {n * 50 / ms / 1e6:.2f} GDOF.it/s")
         t = time.perf_counter()
         x, it, _ = s.solve(b, np.zeros(n), 5e-3, 10000)
-        out.append(f"solve(tol 5e-3): iter={it} wall={1e3 * (time.perf_counter() - t):.1f}ms")
+        wall = time.perf_counter() - t
+        res = np.linalg.norm(b - s.spmv(x)) / np.linalg.norm(b)
+        out.append(f"solve(tol 5e-3): iter={it} wall={1e3 * wall:.1f}ms true_resid={res:.2e} |x|={np.linalg.norm(x):.6e}")
         print(" ".join(out), flush=True)
