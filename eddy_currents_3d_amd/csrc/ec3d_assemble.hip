@@ -23,6 +23,7 @@ struct GridPar {
     int own_k0, own_k1; // global planes [own_k0, own_k1) are owned; others held only as halos
     int zero_cls;      // dictionary class whose coefficients are all 0 (U rows, padding)
     int64_t kdz, nCells, n_pad;
+    int64_t pitch, nCd; // structured form: device rows per plane / per component block (kdz, nCells if unpitched)
     double s[3];     // 1/delta^2          :496-498
     double ds[3];    // 0.5/delta          :499-501
     double delta[3];
@@ -417,8 +418,9 @@ __global__ __launch_bounds__(256) void k_assemble_sav(GridPar g, const int8_t *_
     // nonzeros of the plain A row: 7 minus one per box face the cell touches
     const int tx = bt % 3, ty = (bt / 3) % 3, tz = bt / 9;
     unsigned long long cnt = 3ull * (7 - (tx != 1) - (ty != 1) - (tz != 1));
+    const int64_t pc = (int64_t)(k - 1) * g.pitch + nn0 % g.kdz; // device cell
     if (u0 == 0) {
-        cls[nn0] = cls[g.nCells + nn0] = cls[2 * g.nCells + nn0] = (uint8_t)bt;
+        cls[pc] = cls[g.nCd + pc] = cls[2 * g.nCd + pc] = (uint8_t)bt;
         flags[nn0] = 0;
         atomicAdd(nnz, cnt);
         return;
@@ -444,7 +446,7 @@ __global__ __launch_bounds__(256) void k_assemble_sav(GridPar g, const int8_t *_
         }
         if (pat != 1) fl |= (uint8_t)(1u << d);
         cnt += pat == 1 ? 2 : 3;
-        const int64_t row = (int64_t)d * g.nCells + nn0;
+        const int64_t row = (int64_t)d * g.nCd + pc;
         cls[row] = (uint8_t)(id.a0 + ((dom - 1) * 3 + d) * 3 + pat - 1);
         tile_flag[row / EC3D_TILE] = 1;
         // U row: which neighbours are missing
@@ -453,7 +455,7 @@ __global__ __launch_bounds__(256) void k_assemble_sav(GridPar g, const int8_t *_
         if (st) fl |= (uint8_t)(8u << d);
         pu += st * mul;
     }
-    const int64_t urow = 3 * g.nCells + nn0;
+    const int64_t urow = 3 * g.nCd + pc;
     cls[urow] = (uint8_t)(id.u0 + pu);
     tile_flag[urow / EC3D_TILE] = 1;
     cnt += pu == 0 ? 13 : 7;
@@ -699,7 +701,17 @@ int ec3d_assemble_sav_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t sdz,
             if (geoPHYS_C[q] != 3 * g.nCells + nc0 + 1) return -1; // not scan-order numbering
             uidx[(size_t)q] = (int32_t)nc0++;
         }
-    const int64_t n_dev = 4 * g.nCells;
+    // plane pitch: whole tiles per xy plane whenever that costs < 1/16 in rows
+    // (EC3D_PITCH=0: never, 2: always -- the tests use it to cover the pitched layout on small grids)
+    g.pitch = g.kdz;
+    {
+        const int64_t p = round_up64(g.kdz, EC3D_TILE);
+        bool want = (p - g.kdz) * 16 <= g.kdz && sdz >= 8;
+        if (const char *e = getenv("EC3D_PITCH")) want = atoi(e) == 2 || (want && atoi(e) != 0);
+        if (want) g.pitch = p;
+    }
+    g.nCd = g.pitch * sdz;
+    const int64_t n_dev = 4 * g.nCd;
     if (n_dev > (int64_t)INT32_MAX - EC3D_TILE) return -1;
     g.ncells0 = nc0;
     ec3d_free_matrix(c);
@@ -707,12 +719,15 @@ int ec3d_assemble_sav_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t sdz,
     A.n = n_dev;
     A.n_pad = g.n_pad = round_up64(n_dev, EC3D_TILE);
     set_offsets(A, g);
+    A.off[0] = -g.pitch;
+    A.off[6] = g.pitch;
     A.sav = 1;
     A.sav_a0 = id.a0;
     A.sav_u0 = id.u0;
     A.sav_zero = id.zero;
-    A.sav_nC = g.nCells;
-    A.sav_step[0] = 1; A.sav_step[1] = sdx; A.sav_step[2] = g.kdz;
+    A.sav_nC = g.nCd;
+    A.sav_step[0] = 1; A.sav_step[1] = sdx; A.sav_step[2] = g.pitch;
+    c->plane = g.kdz; c->pitch = g.pitch; c->nCd = g.nCd;
     A.ncls = id.ncls;
     c->n_ref = 3 * g.nCells + nc0;
     EC3D_HIP(hipMalloc(&A.tail_id, 8));
@@ -768,7 +783,7 @@ int ec3d_assemble_sav_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t sdz,
         const int64_t ntiles = A.n_pad / EC3D_TILE;
         std::vector<uint8_t> tf((size_t)ntiles);
         EC3D_HIP(hipMemcpy(tf.data(), A.tile_flag, tf.size(), hipMemcpyDeviceToHost));
-        const int64_t first_u = (3 * g.nCells + EC3D_TILE - 1) / EC3D_TILE;
+        const int64_t first_u = (3 * g.nCd + EC3D_TILE - 1) / EC3D_TILE;
         std::vector<int32_t> ul;
         for (int64_t t = first_u; t < ntiles; ++t)
             if (tf[(size_t)t]) ul.push_back((int32_t)t);

@@ -159,6 +159,12 @@ struct ec3d_ctx {
     bool use_dict = true;
     bool use_sav = true;   // structured A-V form for ec3d_assemble when the problem allows it (EC3D_SAV)
     int64_t n_ref = 0;     // unknowns in the reference's numbering (what host vectors hold); = A.n unless sav
+    // sav: every xy plane starts on a tile boundary (pitch >= plane cells, multiple of EC3D_TILE) so the
+    // z-marching SpMV map always applies; plane == pitch == 0 otherwise.  Device cell of reference cell q:
+    // (q / plane) * pitch + q % plane; a component block holds nCd = sdz * pitch device rows.
+    int64_t plane = 0, pitch = 0, nCd = 0;
+    int64_t dev_cell(int64_t q) const { return pitch == plane ? q : (q / plane) * pitch + q % plane; }
+    int64_t ref_cell(int64_t p) const { return pitch == plane ? p : (p / pitch) * plane + p % pitch; }
     double *io_tmp = nullptr; // sav: staging for the U part of host<->device vector copies
     int nblk_request = 0;
     int nt_request = -1; // -1 auto, 0/1 forced (EC3D_NT)
@@ -178,7 +184,7 @@ struct ec3d_ctx {
     // per-step RHS build / post-update on the device (src/EC3D.f90:370-404, :412-433)
     int64_t n_cond = 0;            // conducting cells (U unknowns), scan order
     int n_cond_domains = 0;
-    int32_t *cond_cell = nullptr;  // [n_cond] 0-based cell index
+    int32_t *cond_cell = nullptr;  // [n_cond] 0-based DEVICE cell index (dev_cell)
     double *cond_a = nullptr;      // [n_cond] 2*C/dt of the cell's domain (PHYS_C%valdom)
     int32_t *bnd_list = nullptr;   // the six cel_bnd* lists, 0-based unknown ids, concatenated
     int64_t bnd_off[7] = {0};

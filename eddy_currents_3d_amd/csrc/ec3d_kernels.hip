@@ -35,10 +35,10 @@ __device__ __forceinline__ int64_t ec3d_tile_of(const Sweep &sw, int b, int64_t 
     if (sw.zm_tpp > 0) {
         // XCD label c owns zm_tpp/8 adjacent columns, so the +-sdx lines a column needs were fetched
         // by a neighbour on the same XCD one step earlier (L2 hit); plane k = pl0 + seg*pps + i
-        const int cpx = sw.zm_tpp >> 3, c = b & 7, s = b >> 3;
+        const int cpx = (sw.zm_tpp + 7) >> 3, c = b & 7, s = b >> 3;
         const int64_t col = c * cpx + s % cpx, seg = s / cpx;
         const int64_t pl = seg * sw.zm_pps + i;
-        if (i >= sw.zm_pps || (sw.zm_npl > 0 && pl >= sw.zm_npl)) return sw.ntiles;
+        if (col >= sw.zm_tpp || i >= sw.zm_pps || (sw.zm_npl > 0 && pl >= sw.zm_npl)) return sw.ntiles;
         return (sw.zm_pl0 + pl) * sw.zm_tpp + col;
     }
     if (sw.S > 0) {
@@ -180,9 +180,7 @@ __device__ __forceinline__ double tail_add(const MatView &A, const V &x, int t, 
 //                one class byte per row + a table staged in LDS (17 B/row: 1 + x + y).  The values
 //                multiplied are the same doubles, so results are bit-identical to FMT_DIA7.
 enum { FMT_GENERIC = 0, FMT_DIA7 = 7, FMT_DICT7 = 107, FMT_SAV = 207 };
-#define EC3D_TBL_DOUBLES (256 * 7)
 #define EC3D_SAV_STRIDE 16
-#define EC3D_SAV_TBL_DOUBLES (256 * EC3D_SAV_STRIDE)
 
 template <int FMT>
 __device__ __forceinline__ void stage_table(const MatView &A, double *tbl)
@@ -194,34 +192,42 @@ __device__ __forceinline__ void stage_table(const MatView &A, double *tbl)
     }
 }
 
-// Structured A-V form: the coupling slots of a row (see MatView).  Loads first, then the adds in slot
-// order = ascending column order = the reference's row-sum order.
+// Structured A-V form: the coupling slots of rows r, r+1 (see MatView), added in slot order = ascending
+// column order = the reference's row-sum order.  A slot whose coefficient is zero is not an entry of the
+// reference's row: it is neither loaded nor added.  Both rows take their operands from one 16-byte load
+// per slot; most rows use 2 of the 5 (A rows) or 6 of the 9 (U rows) slots.
 template <class V>
-__device__ __forceinline__ double sav_u_pre(const MatView &A, const double *t, const V &x, int64_t r)
+__device__ __forceinline__ void sav_u_pre(const MatView &A, const double *t0, const double *t1, const V &x,
+                                          int64_t r, double &s0, double &s1)
 {
-    double xv[9];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         const int64_t base = r - (3 - d) * A.sav_nC;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) xv[3 * d + j] = x.at(base + (j - 1) * A.sav_step[d]);
+        for (int j = 0; j < 3; ++j) {
+            const double v0 = t0[7 + 3 * d + j], v1 = t1[7 + 3 * d + j];
+            if (v0 != 0.0 || v1 != 0.0) {
+                const d2 xx = x.pair(base + (j - 1) * A.sav_step[d]);
+                if (v0 != 0.0) s0 = s0 + v0 * xx.x;
+                if (v1 != 0.0) s1 = s1 + v1 * xx.y;
+            }
+        }
     }
-    double s = 0.0;
-#pragma unroll
-    for (int j = 0; j < 9; ++j) s = s + t[7 + j] * xv[j];
-    return s;
 }
 template <class V>
-__device__ __forceinline__ double sav_a_post(const MatView &A, const double *t, const V &x, int64_t r, double s)
+__device__ __forceinline__ void sav_a_post(const MatView &A, const double *t0, const double *t1, const V &x,
+                                           int64_t r, int d, double &s0, double &s1)
 {
-    const int d = (r >= A.sav_nC) + (r >= 2 * A.sav_nC);
     const int64_t base = r + (3 - d) * A.sav_nC, step = A.sav_step[d];
-    double xv[5];
 #pragma unroll
-    for (int m = 0; m < 5; ++m) xv[m] = x.at(base + (m - 2) * step);
-#pragma unroll
-    for (int m = 0; m < 5; ++m) s = s + t[7 + m] * xv[m];
-    return s;
+    for (int m = 0; m < 5; ++m) {
+        const double v0 = t0[7 + m], v1 = t1[7 + m];
+        if (v0 != 0.0 || v1 != 0.0) {
+            const d2 xx = x.pair(base + (m - 2) * step);
+            if (v0 != 0.0) s0 = s0 + v0 * xx.x;
+            if (v1 != 0.0) s1 = s1 + v1 * xx.y;
+        }
+    }
 }
 
 // x values of the planes below / at the current row, carried across the steps of a z-march
@@ -289,20 +295,29 @@ __device__ __forceinline__ void spmv_pair(const MatView &A, const double *tbl, c
             const int c0 = cc & 0xFF, c1 = cc >> 8;
             const double *t0 = tbl + c0 * EC3D_SAV_STRIDE, *t1 = tbl + c1 * EC3D_SAV_STRIDE;
             const bool cpl = A.tile_flag[tile] != 0; // any coupled row in this tile (uniform)
+            // the coupling slots of an A class mean U columns, those of a U class A columns: a row of the
+            // other kind goes through the all-zero class
+            const double *zt = tbl + A.sav_zero * EC3D_SAV_STRIDE;
+            const int64_t nA = 3 * A.sav_nC;
             s0 = 0.0;
             s1 = 0.0;
-            if (cpl) {
-                if (c0 >= A.sav_u0 && c0 < A.sav_zero) s0 = sav_u_pre(A, t0, x, r);
-                if (c1 >= A.sav_u0 && c1 < A.sav_zero) s1 = sav_u_pre(A, t1, x, r + 1);
-            }
+            if (cpl && r + 1 >= nA) sav_u_pre(A, r >= nA ? t0 : zt, t1, x, r, s0, s1);
 #pragma unroll
             for (int b = 0; b < 7; ++b) {
                 s0 = s0 + t0[b] * xv[b].x;
                 s1 = s1 + t1[b] * xv[b].y;
             }
-            if (cpl) {
-                if (c0 >= A.sav_a0 && c0 < A.sav_u0) s0 = sav_a_post(A, t0, x, r, s0);
-                if (c1 >= A.sav_a0 && c1 < A.sav_u0) s1 = sav_a_post(A, t1, x, r + 1, s1);
+            if (cpl && r < nA) {
+                const int d0 = (r >= A.sav_nC) + (r >= 2 * A.sav_nC);
+                const int d1 = (r + 1 >= A.sav_nC) + (r + 1 >= 2 * A.sav_nC);
+                const bool in0 = c0 >= A.sav_a0 && c0 < A.sav_u0, in1 = c1 >= A.sav_a0 && c1 < A.sav_u0 && r + 1 < nA;
+                if (d0 == d1) {
+                    sav_a_post(A, in0 ? t0 : zt, in1 ? t1 : zt, x, r, d0, s0, s1);
+                } else { // the pair straddles two component blocks (odd block length)
+                    double dummy = 0.0;
+                    if (in0) sav_a_post(A, t0, zt, x, r, d0, s0, dummy);
+                    if (in1) sav_a_post(A, zt, t1, x, r, d1, dummy, s1);
+                }
             }
         }
     } else {
@@ -323,6 +338,8 @@ __device__ __forceinline__ void spmv_pair(const MatView &A, const double *tbl, c
     }
 }
 
+// the SpMV grids are sized for 6 workgroups per CU (choose_sweep): keep the register count within that
+#define EC3D_SPMV_OCC __attribute__((amdgpu_waves_per_eu(6)))
 #define EC3D_SWEEP_BEGIN                                                                       \
     bool need_first_ = true;                                                                   \
     int64_t lst_ = -1; /* >= 0: walking the list of occupied U tiles */                        \
@@ -347,12 +364,12 @@ __device__ __forceinline__ void spmv_pair(const MatView &A, const double *tbl, c
         const int64_t r = tile * EC3D_TILE + 2 * (int64_t)threadIdx.x;
 #define EC3D_SWEEP_END }
 #define EC3D_TBL_DECL                                                                          \
-    __shared__ double tbl[FMT == FMT_DICT7 ? EC3D_TBL_DOUBLES : (FMT == FMT_SAV ? EC3D_SAV_TBL_DOUBLES : 1)]
+    extern __shared__ double tbl[] /* the class table, sized at launch (EC3D_TBL_BYTES) */
 
 // ---------------------------------------------------------------------------------------------
 // plain y = A x  (src/solvers.f90:54-61)
 template <int FMT, bool NT, bool ZM>
-__global__ __launch_bounds__(EC3D_THREADS) void k_spmv(MatView A, Sweep sw, const double *__restrict__ x,
+__global__ __launch_bounds__(EC3D_THREADS) EC3D_SPMV_OCC void k_spmv(MatView A, Sweep sw, const double *__restrict__ x,
                                                        double *__restrict__ y)
 {
     EC3D_TBL_DECL;
@@ -368,7 +385,7 @@ __global__ __launch_bounds__(EC3D_THREADS) void k_spmv(MatView A, Sweep sw, cons
 
 // setup: R = B - A X ; R0 = R ; P = R ; partials of B·B and R·R   (src/solvers.f90:14-21)
 template <int FMT, bool NT, bool ZM>
-__global__ __launch_bounds__(EC3D_THREADS) void k_residual(MatView A, Sweep sw, const double *__restrict__ x,
+__global__ __launch_bounds__(EC3D_THREADS) EC3D_SPMV_OCC void k_residual(MatView A, Sweep sw, const double *__restrict__ x,
                                                            const double *__restrict__ b, double *__restrict__ rv,
                                                            double *__restrict__ r0, double *__restrict__ p,
                                                            double *__restrict__ part)
@@ -437,7 +454,7 @@ __global__ __launch_bounds__(EC3D_THREADS) void k_setup(SolverState *st, RedSrc 
 
 // K1: AP = A P ; partial AP·R0    (src/solvers.f90:30, :32 denominator)
 template <int FMT, bool NT, bool ZM>
-__global__ __launch_bounds__(EC3D_THREADS) void k1_spmv_dot(MatView A, Sweep sw, const SolverState *st, int it,
+__global__ __launch_bounds__(EC3D_THREADS) EC3D_SPMV_OCC void k1_spmv_dot(MatView A, Sweep sw, const SolverState *st, int it,
                                                             const double *__restrict__ p,
                                                             const double *__restrict__ r0,
                                                             double *__restrict__ ap, double *__restrict__ part)
@@ -494,7 +511,7 @@ __global__ __launch_bounds__(EC3D_THREADS) void k2_s_update(Sweep sw, RedSrc src
 // (one global reduction point less per iteration): when the ‖S‖ exit of :34-38 is then
 // taken by K4, AS is simply never used -- results are unchanged.
 template <int FMT, bool NT, bool ZM>
-__global__ __launch_bounds__(EC3D_THREADS) void k3_spmv_dots(MatView A, Sweep sw, SolverState *st, int it,
+__global__ __launch_bounds__(EC3D_THREADS) EC3D_SPMV_OCC void k3_spmv_dots(MatView A, Sweep sw, SolverState *st, int it,
                                                              const double *__restrict__ sv,
                                                              double *__restrict__ as, double *__restrict__ part)
 {
@@ -638,17 +655,21 @@ static inline int fmt_of(const MatView &A)
 }
 // streaming policy: vectors of >= 32 MiB each (n_pad >= 4 Mi rows) cannot live in the caches
 static inline bool nt_of(const Sweep &sw) { return sw.nt != 0; }
+// dynamic LDS: the class table only (a full 256-class table of the structured form would be 32 KiB and
+// cap the CU at 4 workgroups; real problems have ~100 classes)
+#define EC3D_TBL_BYTES(F)                                                                      \
+    ((F) == FMT_DICT7 ? (size_t)A.ncls * 7 * 8 : ((F) == FMT_SAV ? (size_t)A.ncls * EC3D_SAV_STRIDE * 8 : 0))
 #define EC3D_LAUNCH_FMT(F, KERNEL, ...)                                                        \
     do {                                                                                       \
         const bool zm_ = sw.zm_tpp > 0 && sw.bnd_last < 0 && F != FMT_GENERIC;                 \
         if (nt_of(sw) && zm_)                                                                  \
-            KERNEL<F, true, (F != FMT_GENERIC)><<<sw.nblk, EC3D_THREADS, 0, s>>>(__VA_ARGS__); \
+            KERNEL<F, true, (F != FMT_GENERIC)><<<sw.nblk, EC3D_THREADS, EC3D_TBL_BYTES(F), s>>>(__VA_ARGS__); \
         else if (nt_of(sw))                                                                    \
-            KERNEL<F, true, false><<<sw.nblk, EC3D_THREADS, 0, s>>>(__VA_ARGS__);              \
+            KERNEL<F, true, false><<<sw.nblk, EC3D_THREADS, EC3D_TBL_BYTES(F), s>>>(__VA_ARGS__);              \
         else if (zm_)                                                                          \
-            KERNEL<F, false, (F != FMT_GENERIC)><<<sw.nblk, EC3D_THREADS, 0, s>>>(__VA_ARGS__);\
+            KERNEL<F, false, (F != FMT_GENERIC)><<<sw.nblk, EC3D_THREADS, EC3D_TBL_BYTES(F), s>>>(__VA_ARGS__);\
         else                                                                                   \
-            KERNEL<F, false, false><<<sw.nblk, EC3D_THREADS, 0, s>>>(__VA_ARGS__);             \
+            KERNEL<F, false, false><<<sw.nblk, EC3D_THREADS, EC3D_TBL_BYTES(F), s>>>(__VA_ARGS__);             \
     } while (0)
 #define EC3D_DISPATCH(A, KERNEL, ...)                                                          \
     do {                                                                                       \

@@ -10,7 +10,8 @@
 #include "ec3d_internal.hpp"
 
 namespace {
-__global__ void k_vtk_fields(int sdx, int sdy, int sdz, double dx, double dy, double dz, int has_cond,
+// U and J are device vectors: cell m of component c sits at c*nCd + (m / kdz)*pitch + m % kdz
+__global__ void k_vtk_fields(int sdx, int sdy, int sdz, int64_t pitch, double dx, double dy, double dz, int has_cond,
                              const int32_t *__restrict__ geoC, const double *__restrict__ U,
                              const double *__restrict__ J, float *fa, float *fe, float *fs, float *fb)
 {
@@ -18,25 +19,26 @@ __global__ void k_vtk_fields(int sdx, int sdy, int sdz, double dx, double dy, do
     const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; // 0-based cell
     if (m >= nC) return;
     const int i = (int)(m % sdx) + 1, j = (int)((m / sdx) % sdy) + 1, k = (int)(m / kdz) + 1;
-    fa[3 * m + 0] = (float)U[m];
-    fa[3 * m + 1] = (float)U[nC + m];
-    fa[3 * m + 2] = (float)U[2 * nC + m];
+    const int64_t nCd = pitch * sdz, pm = (int64_t)(k - 1) * pitch + m % kdz;
+    fa[3 * m + 0] = (float)U[pm];
+    fa[3 * m + 1] = (float)U[nCd + pm];
+    fa[3 * m + 2] = (float)U[2 * nCd + pm];
     if (has_cond) {
         const double s = -0.07957747154594766788444e7;
         const bool cond = geoC[m] != 0;
         for (int c = 0; c < 3; ++c) {
-            fe[3 * m + c] = cond ? (float)(s * J[c * nC + m]) : 0.0f;
-            fs[3 * m + c] = cond ? 0.0f : (float)J[c * nC + m];
+            fe[3 * m + c] = cond ? (float)(s * J[c * nCd + pm]) : 0.0f;
+            fs[3 * m + c] = cond ? 0.0f : (float)J[c * nCd + pm];
         }
     } else {
-        for (int c = 0; c < 3; ++c) fs[3 * m + c] = (float)J[c * nC + m];
+        for (int c = 0; c < 3; ++c) fs[3 * m + c] = (float)J[c * nCd + pm];
     }
-    const int64_t nim = i == 1 ? m : m - 1, nip = i == sdx ? m : m + 1;
-    const int64_t njm = j == 1 ? m : m - sdx, njp = j == sdy ? m : m + sdx;
-    const int64_t nkm = k == 1 ? m : m - kdz, nkp = k == sdz ? m : m + kdz;
-    const double bx = 0.5 * (U[2 * nC + njp] - U[2 * nC + njm]) / dy - 0.5 * (U[nC + nkp] - U[nC + nkm]) / dz;
-    const double by = 0.5 * (U[nkp] - U[nkm]) / dz - 0.5 * (U[2 * nC + nip] - U[2 * nC + nim]) / dx;
-    const double bz = 0.5 * (U[nC + nip] - U[nC + nim]) / dx - 0.5 * (U[njp] - U[njm]) / dy;
+    const int64_t nim = i == 1 ? pm : pm - 1, nip = i == sdx ? pm : pm + 1;
+    const int64_t njm = j == 1 ? pm : pm - sdx, njp = j == sdy ? pm : pm + sdx;
+    const int64_t nkm = k == 1 ? pm : pm - pitch, nkp = k == sdz ? pm : pm + pitch;
+    const double bx = 0.5 * (U[2 * nCd + njp] - U[2 * nCd + njm]) / dy - 0.5 * (U[nCd + nkp] - U[nCd + nkm]) / dz;
+    const double by = 0.5 * (U[nkp] - U[nkm]) / dz - 0.5 * (U[2 * nCd + nip] - U[2 * nCd + nim]) / dx;
+    const double bz = 0.5 * (U[nCd + nip] - U[nCd + nim]) / dx - 0.5 * (U[njp] - U[njm]) / dy;
     fb[3 * m + 0] = (float)bx;
     fb[3 * m + 1] = (float)by;
     fb[3 * m + 2] = (float)bz;
@@ -69,13 +71,14 @@ extern "C" int ec3d_vtk_fields(ec3d_handle c, const double *delta, float *field_
         EC3D_HIP(hipMemsetAsync(d_geoC, 0, (size_t)nC * 4, c->stream));
         std::vector<int32_t> cell((size_t)c->n_cond), mask((size_t)nC, 0);
         EC3D_HIP(hipMemcpy(cell.data(), c->cond_cell, cell.size() * 4, hipMemcpyDeviceToHost));
-        for (int32_t q : cell) mask[(size_t)q] = 1;
+        for (int32_t q : cell) mask[(size_t)c->ref_cell(q)] = 1;
         EC3D_HIP(hipMemcpyAsync(d_geoC, mask.data(), mask.size() * 4, hipMemcpyHostToDevice, c->stream));
         EC3D_HIP(hipStreamSynchronize(c->stream));
     }
     float *fa = d, *fe = d + 3 * nC, *fs = d + 6 * nC, *fb = d + 9 * nC;
     k_vtk_fields<<<(unsigned)((nC + 255) / 256), 256, 0, c->stream>>>(
-        c->sdx, c->sdy, c->sdz, delta[0], delta[1], delta[2], has_cond, d_geoC, c->vec[EC3D_VEC_X],
+        c->sdx, c->sdy, c->sdz, c->pitch ? c->pitch : (int64_t)c->sdx * c->sdy, delta[0], delta[1], delta[2], has_cond,
+        d_geoC, c->vec[EC3D_VEC_X],
         c->vec[EC3D_VEC_B], fa, fe, fs, fb);
     EC3D_HIP(hipGetLastError());
     const size_t nb = (size_t)3 * nC * sizeof(float);

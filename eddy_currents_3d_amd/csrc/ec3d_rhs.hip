@@ -116,13 +116,14 @@ int ec3d_setup_rhs(ec3d_ctx *c, int64_t nCells, const int8_t *geoPHYS, const int
                    const double *valPHYS, int32_t nsub_glob, double dt)
 {
     ec3d_free_rhs(c);
+    const int64_t nCd = c->nCd ? c->nCd : nCells; // device rows per component block
     std::vector<int32_t> cell;
     std::vector<double> a;
     std::vector<char> seen((size_t)nsub_glob + 1, 0);
     for (int64_t q = 0; q < nCells; ++q)
         if (geoPHYS_C[q] != 0) {
             const int dom = geoPHYS[q];
-            cell.push_back((int32_t)q);
+            cell.push_back((int32_t)c->dev_cell(q));
             a.push_back(2.0 * valPHYS[1 * (int64_t)nsub_glob + dom - 1] / dt); // PHYS_C%valdom, vxc2data.f90:461
             if (!seen[(size_t)dom]) { seen[(size_t)dom] = 1; ++c->n_cond_domains; }
         }
@@ -132,7 +133,10 @@ int ec3d_setup_rhs(ec3d_ctx *c, int64_t nCells, const int8_t *geoPHYS, const int
         c->bnd_off[w] = (int64_t)lists.size();
         for (int32_t id : c->cel_bnd[w]) {
             int64_t dev = (int64_t)id - 1;
-            if (c->A.sav && dev >= 3 * nCells) dev = 3 * nCells + cell[(size_t)(dev - 3 * nCells)]; // U(m) -> its cell
+            if (dev < 3 * nCells)
+                dev = (dev / nCells) * nCd + c->dev_cell(dev % nCells);
+            else if (c->A.sav)
+                dev = 3 * nCd + cell[(size_t)(dev - 3 * nCells)]; // U(m) -> its cell
             lists.push_back((int32_t)dev);
         }
     }
@@ -172,12 +176,13 @@ extern "C" int ec3d_rhs_step(ec3d_handle c, int32_t moving, int32_t nsrc, const 
     int rc = need_grid(c, "ec3d_rhs_step");
     if (rc) return rc;
     const int64_t nCells = (int64_t)c->sdx * c->sdy * c->sdz, nc = c->n_cond;
+    const int64_t nCd = c->nCd ? c->nCd : nCells;
     double *b = c->vec[EC3D_VEC_B], *x = c->vec[EC3D_VEC_X];
     hipStream_t s = c->stream;
     if (moving) { // :277-296
-        if (nc) k_gather_inertial<<<blocks(nc), 256, 0, s>>>(c->cond_cell, nc, nCells, b, c->rhs_tmp);
+        if (nc) k_gather_inertial<<<blocks(nc), 256, 0, s>>>(c->cond_cell, nc, nCd, b, c->rhs_tmp);
         EC3D_HIP(hipMemsetAsync(b, 0, (size_t)c->A.n * sizeof(double), s));
-        if (nc) k_scatter_inertial<<<blocks(nc), 256, 0, s>>>(c->cond_cell, nc, nCells, c->rhs_tmp, b);
+        if (nc) k_scatter_inertial<<<blocks(nc), 256, 0, s>>>(c->cond_cell, nc, nCd, c->rhs_tmp, b);
     }
     if (nsrc > 0) { // :298-367; the reference assigns in order, so a repeated cell keeps its LAST value
         std::unordered_map<int32_t, double> last;
@@ -192,11 +197,15 @@ extern "C" int ec3d_rhs_step(ec3d_handle c, int32_t moving, int32_t nsrc, const 
             dup |= !last.emplace(src_index[q], src_value[q]).second;
             last[src_index[q]] = src_value[q];
         }
+        auto dev_of = [&](int32_t id1) { // 1-based reference id of an A unknown -> device row
+            const int64_t r0 = (int64_t)id1 - 1;
+            return (int32_t)((r0 / nCells) * nCd + c->dev_cell(r0 % nCells));
+        };
         if (dup) {
-            for (auto &kv : last) { idx.push_back(kv.first - 1); val.push_back(kv.second); }
+            for (auto &kv : last) { idx.push_back(dev_of(kv.first)); val.push_back(kv.second); }
         } else {
             idx.resize((size_t)nsrc); val.assign(src_value, src_value + nsrc);
-            for (int32_t q = 0; q < nsrc; ++q) idx[(size_t)q] = src_index[q] - 1;
+            for (int32_t q = 0; q < nsrc; ++q) idx[(size_t)q] = dev_of(src_index[q]);
         }
         const int64_t ns = (int64_t)idx.size();
         if (ns > c->src_cap) {
@@ -212,7 +221,7 @@ extern "C" int ec3d_rhs_step(ec3d_handle c, int32_t moving, int32_t nsrc, const 
         EC3D_HIP(hipStreamSynchronize(s)); // idx/val are stack-owned
     }
     if (nc) { // :370-404
-        k_rhs_inertial<<<blocks(nc), 256, 0, s>>>(c->A.view(), c->cond_cell, c->cond_a, nc, nCells, x, b);
+        k_rhs_inertial<<<blocks(nc), 256, 0, s>>>(c->A.view(), c->cond_cell, c->cond_a, nc, nCd, x, b);
         const int64_t cnt = c->bnd_off[6];
         if (cnt) k_zero_list<<<blocks(cnt), 256, 0, s>>>(c->bnd_list, cnt, b, nullptr);
     }
@@ -225,9 +234,10 @@ extern "C" int ec3d_post_update(ec3d_handle c)
     int rc = need_grid(c, "ec3d_post_update");
     if (rc) return rc;
     const int64_t nCells = (int64_t)c->sdx * c->sdy * c->sdz, nc = c->n_cond;
+    const int64_t nCd = c->nCd ? c->nCd : nCells;
     if (!nc) return 0; // :411 IF (size_PHYS_C /= 0)
     double *b = c->vec[EC3D_VEC_B], *x = c->vec[EC3D_VEC_X];
-    k_post_inertial<<<blocks(nc), 256, 0, c->stream>>>(c->cond_cell, c->cond_a, nc, nCells, x, b);
+    k_post_inertial<<<blocks(nc), 256, 0, c->stream>>>(c->cond_cell, c->cond_a, nc, nCd, x, b);
     const int64_t cnt = c->bnd_off[3]; // cel_bndX, Y, Z only (:426-432)
     if (cnt) k_zero_list<<<blocks(cnt), 256, 0, c->stream>>>(c->bnd_list, cnt, b, x);
     EC3D_HIP(hipGetLastError());

@@ -105,6 +105,7 @@ void ec3d_free_matrix(ec3d_ctx *c)
     if (c->io_tmp) (void)hipFree(c->io_tmp);
     c->io_tmp = nullptr;
     c->n_ref = 0;
+    c->plane = c->pitch = c->nCd = 0;
     c->halo = 0;
     c->nown = 0;
     ec3d_free_rhs(c);
@@ -181,16 +182,19 @@ static void choose_sweep(ec3d_ctx *c)
     if (zm != 0 && A.nb == 7 && A.off[3] == 0 && A.off[0] == -A.off[6] && A.off[6] % EC3D_TILE == 0) {
         const int64_t tpp = A.off[6] / EC3D_TILE;
         const int64_t nplanes = (sw.ntiles + tpp - 1) / tpp;
-        if (tpp % 8 == 0 && tpp <= 4096 && nplanes >= 8) {
+        if (tpp <= 4096 && nplanes >= 8) {
             // the SpMV kernels like twice the workgroups of the vector kernels: 1536 (6 per CU) and 3072
             // beat 1024 and 2048 at both 256^3 and 512^3
             int want_s = c->nblk_request > 0 ? c->nblk_request : 1536;
             if (const char *e = getenv("EC3D_NBLK_SPMV")) want_s = atoi(e);
-            int64_t nseg = std::max<int64_t>(1, (want_s + tpp / 2) / tpp);
+            // columns are dealt to the 8 XCD labels in runs of cpx; with tpp % 8 != 0 the last run is short
+            // and 8*cpx - tpp workgroups per segment stay idle
+            const int64_t cols = (tpp + 7) / 8 * 8;
+            int64_t nseg = std::max<int64_t>(1, (want_s + cols / 2) / cols);
             nseg = std::min<int64_t>(nseg, std::max<int64_t>(1, nplanes / 8));
             ss.zm_tpp = (int)tpp;
             ss.zm_pps = (int)((nplanes + nseg - 1) / nseg);
-            ss.nblk = (int)(tpp * nseg);
+            ss.nblk = (int)(cols * nseg);
             ss.S = 0;
         }
     }
@@ -203,13 +207,13 @@ static void choose_sweep(ec3d_ctx *c)
         const int64_t np = sw.ntiles / ss.zm_tpp; // planes held (n is a whole number of planes here)
         if (np * ss.zm_tpp == sw.ntiles && np >= 10) {
             Sweep &si = c->sweep_int, &sb = c->sweep_bnd;
-            const int64_t tpp = ss.zm_tpp, npl = np - 2;
-            int64_t nseg = std::max<int64_t>(1, ((int64_t)ss.nblk + tpp / 2) / tpp);
+            const int64_t tpp = ss.zm_tpp, npl = np - 2, cols = (tpp + 7) / 8 * 8;
+            int64_t nseg = std::max<int64_t>(1, ((int64_t)ss.nblk + cols / 2) / cols);
             nseg = std::min<int64_t>(nseg, std::max<int64_t>(1, npl / 8));
             si.zm_pl0 = 1;
             si.zm_npl = (int)npl;
             si.zm_pps = (int)((npl + nseg - 1) / nseg);
-            si.nblk = (int)(tpp * nseg);
+            si.nblk = (int)(cols * nseg);
             si.part_off = 0;
             sb.bnd_last = (int)(np - 1);
             sb.nblk = (int)std::min<int64_t>(2 * tpp, 768);
@@ -438,10 +442,10 @@ extern "C" int ec3d_set_stream(ec3d_handle c, void *stream)
 static int sav_to_csr(ec3d_ctx *c, std::vector<int32_t> &irow, std::vector<int32_t> &jcol, std::vector<double> &valA)
 {
     const DevMatrix &A = c->A;
-    const int64_t nC = A.sav_nC, nU = c->n_cond;
+    const int64_t nCd = A.sav_nC, nC = c->plane * c->sdz, nU = c->n_cond; // device / reference cells per block
     std::vector<uint8_t> cls((size_t)A.n_pad);
     std::vector<double> tab((size_t)A.ncls * 16);
-    std::vector<int32_t> cell((size_t)nU), uidx((size_t)nC, -1);
+    std::vector<int32_t> cell((size_t)nU), uidx((size_t)nCd, -1);
     EC3D_HIP(hipStreamSynchronize(c->stream));
     EC3D_HIP(hipMemcpy(cls.data(), A.cls, cls.size(), hipMemcpyDeviceToHost));
     EC3D_HIP(hipMemcpy(tab.data(), A.table, tab.size() * 8, hipMemcpyDeviceToHost));
@@ -456,10 +460,12 @@ static int sav_to_csr(ec3d_ctx *c, std::vector<int32_t> &irow, std::vector<int32
     };
     int64_t row = 0;
     for (int d = 0; d < 3; ++d)
-        for (int64_t q = 0; q < nC; ++q, ++row) {
-            const int cc = cls[(size_t)(d * nC + q)];
+        for (int64_t qr = 0; qr < nC; ++qr, ++row) {
+            const int64_t q = c->dev_cell(qr);
+            const int cc = cls[(size_t)(d * nCd + q)];
             const double *t = &tab[(size_t)cc * 16];
-            for (int b = 0; b < 7; ++b) put(d * nC + q + A.off[b] + 1, t[b]);
+            for (int b = 0; b < 7; ++b)
+                if (t[b] != 0.0) put(d * nC + c->ref_cell(q + A.off[b]) + 1, t[b]);
             if (cc >= A.sav_a0 && cc < A.sav_u0)
                 for (int m = -2; m <= 2; ++m) {
                     const double v = t[7 + m + 2];
@@ -469,9 +475,12 @@ static int sav_to_csr(ec3d_ctx *c, std::vector<int32_t> &irow, std::vector<int32
         }
     for (int64_t m = 0; m < nU; ++m, ++row) {
         const int64_t q = cell[(size_t)m];
-        const double *t = &tab[(size_t)cls[(size_t)(3 * nC + q)] * 16];
+        const double *t = &tab[(size_t)cls[(size_t)(3 * nCd + q)] * 16];
         for (int d = 0; d < 3; ++d)
-            for (int j = 0; j < 3; ++j) put(d * nC + q + (j - 1) * A.sav_step[d] + 1, t[7 + 3 * d + j]);
+            for (int j = 0; j < 3; ++j) {
+                const double v = t[7 + 3 * d + j];
+                if (v != 0.0) put(d * nC + c->ref_cell(q + (j - 1) * A.sav_step[d]) + 1, v);
+            }
         for (int b = 0; b < 7; ++b) {
             if (t[b] != 0.0) put(3 * nC + uidx[(size_t)(q + A.off[b])] + 1, t[b]);
         }
@@ -581,10 +590,14 @@ int ec3d_vec_h2d(ec3d_ctx *c, double *dev, const double *host)
         EC3D_HIP(hipMemcpyAsync(dev, host, (size_t)c->A.n * sizeof(double), hipMemcpyHostToDevice, c->stream));
         return 0;
     }
-    const int64_t nA = 3 * c->A.sav_nC, nu = c->n_cond;
-    EC3D_HIP(hipMemcpyAsync(dev, host, (size_t)nA * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    const int64_t nA = 3 * c->A.sav_nC, nu = c->n_cond, nAref = 3 * c->plane * c->sdz;
+    if (c->pitch == c->plane)
+        EC3D_HIP(hipMemcpyAsync(dev, host, (size_t)nA * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    else // one row per xy plane; the padding between planes stays zero
+        EC3D_HIP(hipMemcpy2DAsync(dev, (size_t)c->pitch * 8, host, (size_t)c->plane * 8, (size_t)c->plane * 8,
+                                  (size_t)3 * c->sdz, hipMemcpyHostToDevice, c->stream));
     if (nu) {
-        EC3D_HIP(hipMemcpyAsync(c->io_tmp, host + nA, (size_t)nu * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        EC3D_HIP(hipMemcpyAsync(c->io_tmp, host + nAref, (size_t)nu * sizeof(double), hipMemcpyHostToDevice, c->stream));
         k_u_scatter<<<(unsigned)((nu + 255) / 256), 256, 0, c->stream>>>(dev + nA, c->cond_cell, c->io_tmp, nu);
         EC3D_HIP(hipGetLastError());
         EC3D_HIP(hipStreamSynchronize(c->stream)); // io_tmp is shared by consecutive copies
@@ -598,12 +611,16 @@ int ec3d_vec_d2h(ec3d_ctx *c, double *host, const double *dev)
         EC3D_HIP(hipMemcpyAsync(host, dev, (size_t)c->A.n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         return 0;
     }
-    const int64_t nA = 3 * c->A.sav_nC, nu = c->n_cond;
-    EC3D_HIP(hipMemcpyAsync(host, dev, (size_t)nA * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    const int64_t nA = 3 * c->A.sav_nC, nu = c->n_cond, nAref = 3 * c->plane * c->sdz;
+    if (c->pitch == c->plane)
+        EC3D_HIP(hipMemcpyAsync(host, dev, (size_t)nA * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    else
+        EC3D_HIP(hipMemcpy2DAsync(host, (size_t)c->plane * 8, dev, (size_t)c->pitch * 8, (size_t)c->plane * 8,
+                                  (size_t)3 * c->sdz, hipMemcpyDeviceToHost, c->stream));
     if (nu) {
         k_u_gather<<<(unsigned)((nu + 255) / 256), 256, 0, c->stream>>>(dev + nA, c->cond_cell, c->io_tmp, nu);
         EC3D_HIP(hipGetLastError());
-        EC3D_HIP(hipMemcpyAsync(host + nA, c->io_tmp, (size_t)nu * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        EC3D_HIP(hipMemcpyAsync(host + nAref, c->io_tmp, (size_t)nu * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         EC3D_HIP(hipStreamSynchronize(c->stream));
     }
     return 0;
@@ -618,11 +635,12 @@ extern "C" int ec3d_get_row_map(ec3d_handle c, int32_t *ref_to_dev)
         for (int64_t i = 0; i < c->A.n; ++i) ref_to_dev[i] = (int32_t)i;
         return 0;
     }
-    const int64_t nA = 3 * c->A.sav_nC;
-    for (int64_t i = 0; i < nA; ++i) ref_to_dev[i] = (int32_t)i;
+    const int64_t nA = 3 * c->A.sav_nC, nC = c->plane * c->sdz;
+    for (int d = 0; d < 3; ++d)
+        for (int64_t q = 0; q < nC; ++q) ref_to_dev[d * nC + q] = (int32_t)(d * c->nCd + c->dev_cell(q));
     std::vector<int32_t> cell((size_t)c->n_cond);
     if (c->n_cond) EC3D_HIP(hipMemcpy(cell.data(), c->cond_cell, cell.size() * 4, hipMemcpyDeviceToHost));
-    for (int64_t m = 0; m < c->n_cond; ++m) ref_to_dev[nA + m] = (int32_t)(nA + cell[(size_t)m]);
+    for (int64_t m = 0; m < c->n_cond; ++m) ref_to_dev[3 * nC + m] = (int32_t)(nA + cell[(size_t)m]);
     return 0;
 }
 

@@ -120,9 +120,9 @@ int64_t oracle_gpu_tile_of(const oracle_gpu_geom *g, int32_t b, int64_t i)
 {
     int64_t ntiles = g->ntiles_front > 0 ? g->ntiles_front : g->n_pad / g->tile, t;
     if (g->zm_tpp > 0) { /* z-marching map: ec3d_tile_of, first branch */
-        int64_t cpx = g->zm_tpp / 8, c = b % 8, s = b / 8;
+        int64_t cpx = (g->zm_tpp + 7) / 8, c = b % 8, s = b / 8;
         int64_t col = c * cpx + s % cpx, seg = s / cpx;
-        if (i >= g->zm_pps) return -1;
+        if (col >= g->zm_tpp || i >= g->zm_pps) return -1;
         t = (seg * g->zm_pps + i) * g->zm_tpp + col;
     } else if (g->xcd_group > 0) {
         int64_t S = g->xcd_group, c = b % 8, s = b / 8;

@@ -25,3 +25,15 @@ def oracle():
 def load_golden(name):
     import numpy as np
     return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+@pytest.fixture(params=["auto", "pitched"])
+def plane_pitch(request, monkeypatch):
+    """Structured A-V form with the default plane pitch (tile-aligned planes only when cheap: never on the
+    small fixture grids) and with tile-aligned planes forced (device layout != reference layout, the
+    z-marching SpMV map with a ragged column count)."""
+    if request.param == "pitched":
+        monkeypatch.setenv("EC3D_PITCH", "2")
+    else:
+        monkeypatch.delenv("EC3D_PITCH", raising=False)
+    return request.param

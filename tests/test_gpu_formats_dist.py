@@ -276,7 +276,7 @@ def test_split_spmv_is_the_same_operator(E, oracle):
 # ------------------------------------------------------------------------- structured A-V form
 @pytest.mark.parametrize("name", ["g2_conducting_hole_16x15x14", "g2v_conducting_moving_16x15x14",
                                   "g3_moving_coil_18x16x12", "g2i_itmax_exit_16x15x14"])
-def test_structured_av_form(E, oracle, name):
+def test_structured_av_form(E, oracle, name, plane_pitch):
     """ec3d_assemble's default storage for the A-V system: U embedded in the grid, every coupling a
     class-coded stencil slot, no tail.  The operator is the reference's (exported CSR and SpMV bit-identical)
     and the solve is bit-identical to the oracle's twin run on the system in device numbering."""
@@ -289,7 +289,10 @@ def test_structured_av_form(E, oracle, name):
         mi = s.info
         assert mi.n == n and mi.tail_rows == 0 and mi.dict_classes > 27
         rm = s.row_map()
-        assert rm.max() < 4 * g["geoPHYS"].size and np.all(np.diff(rm) > 0)
+        sdz, sdy, sdx = g["geoPHYS"].shape
+        nC_dev = g["geoPHYS"].size if plane_pitch == "auto" else sdz * (-(-sdx * sdy // 512) * 512)
+        assert rm.max() < 4 * nC_dev and np.all(np.diff(rm) > 0)
+        assert (s.geometry(1).zm_tpp > 0) == (plane_pitch == "pitched")
         va, ir, jc = s.export_csr()
         assert np.array_equal(ir, g["irow"]) and np.array_equal(jc, g["jcol"]) and np.array_equal(va, g["valA"])
         assert np.array_equal(s.spmv(x), oracle.spmv_csr(g["valA"], g["irow"], g["jcol"], x))

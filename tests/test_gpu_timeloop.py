@@ -32,7 +32,7 @@ def coil_sources(g, k, moving):
                                          ("g2v_conducting_moving_16x15x14", False),
                                          ("g3_moving_coil_18x16x12", True),
                                          ("g1_nonconducting_8x7x6", False)])
-def test_rhs_build_and_post_update_bitwise(name, moving):
+def test_rhs_build_and_post_update_bitwise(name, moving, plane_pitch):
     import eddy_currents_3d_amd as E
     g = load_golden(name)
     n = len(g["irow"]) - 1

@@ -42,7 +42,7 @@ def test_vtk_formatter_reproduces_reference_bytes(name):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,steps", [("g1_nonconducting_8x7x6", [1]), ("g2_conducting_hole_16x15x14", [1]),
                                         ("g3_moving_coil_18x16x12", [1, 2])])
-def test_device_fields_and_curl_reproduce_reference_file(name, steps):
+def test_device_fields_and_curl_reproduce_reference_file(name, steps, plane_pitch):
     """GPU: state right after the reference's solve k (x = its solution, b = its RHS) -> post_update on
     the device (src/EC3D.f90:412-433) -> ec3d_vtk_fields (curl A etc. on the device) -> file bytes
     identical to the reference's field_k.vtk."""
