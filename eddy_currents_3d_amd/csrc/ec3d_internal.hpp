@@ -111,6 +111,17 @@ struct HostMatrix {
     int ncls = 0;
 };
 
+// host-side image of the structured A-V form recognised in a CSR matrix (ec3d_sav_csr.cpp)
+struct SavHost {
+    int64_t n_ref = 0, n_dev = 0, n_pad = 0, nnz = 0;
+    int64_t sdx = 0, plane = 0, pitch = 0, nCd = 0;
+    int a0 = 0, u0 = 0, zero = 0, ncls = 0;
+    std::vector<uint8_t> cls, tile_flag;
+    std::vector<double> table; // ncls * 16
+    std::vector<int32_t> ulist, cond_cell;
+    int64_t ntiles_front = 0;
+};
+
 struct DevMatrix {
     int64_t n = 0, n_pad = 0, nnz = 0;
     int nb = 0;
@@ -165,6 +176,7 @@ struct ec3d_ctx {
     int64_t plane = 0, pitch = 0, nCd = 0;
     int64_t dev_cell(int64_t q) const { return pitch == plane ? q : (q / plane) * pitch + q % plane; }
     int64_t ref_cell(int64_t p) const { return pitch == plane ? p : (p / pitch) * plane + p % pitch; }
+    int64_t planes() const { return pitch ? nCd / pitch : 0; } // xy planes per component block
     double *io_tmp = nullptr; // sav: staging for the U part of host<->device vector copies
     int nblk_request = 0;
     int nt_request = -1; // -1 auto, 0/1 forced (EC3D_NT)
@@ -213,7 +225,11 @@ int ec3d_csr_to_host_matrix(int64_t n, const double *valA, const int32_t *irow, 
 void ec3d_host_matrix_to_csr(const HostMatrix &M, std::vector<int32_t> &irow, std::vector<int32_t> &jcol,
                              std::vector<double> &valA);
 
+// ec3d_sav_csr.cpp: 0, or -1 when the matrix does not have the structure
+int ec3d_csr_to_sav_host(int64_t n, const double *valA, const int32_t *irow, const int32_t *jcol, SavHost &S);
+
 // ec3d_solver.hip
+int ec3d_upload_sav(ec3d_ctx *c, const SavHost &S);
 int ec3d_upload_matrix(ec3d_ctx *c, const HostMatrix &M);
 int ec3d_download_matrix(ec3d_ctx *c, HostMatrix &M);
 void ec3d_free_matrix(ec3d_ctx *c);

@@ -153,6 +153,7 @@ static void choose_sweep(ec3d_ctx *c)
         sw.ntiles = c->A.ntiles_front;
         sw.ulist = c->A.ulist;
         sw.ulist_n = c->A.ulist_n;
+        if (getenv("EC3D_EXPERIMENT_NOULIST")) sw.ulist_n = 0;
     }
     sw.nown = c->nown;
     for (int q = 0; q < 4; ++q) {
@@ -359,9 +360,60 @@ static int need_matrix(ec3d_ctx *c, const char *who)
     return 0;
 }
 
+// device image of a structured form found in CSR: same fields ec3d_assemble_sav_device fills natively,
+// minus the grid-dependent by-products (cel_bnd lists, per-step RHS tables: sdx stays 0)
+int ec3d_upload_sav(ec3d_ctx *c, const SavHost &S)
+{
+    EC3D_HIP(hipSetDevice(c->device));
+    ec3d_free_matrix(c);
+    DevMatrix &A = c->A;
+    A.n = S.n_dev;
+    A.n_pad = S.n_pad;
+    A.nnz = S.nnz;
+    A.nb = 7;
+    const int64_t off[7] = {-S.pitch, -S.sdx, -1, 0, 1, S.sdx, S.pitch};
+    for (int b = 0; b < 7; ++b) A.off[b] = off[b];
+    A.sav = 1;
+    A.sav_a0 = S.a0;
+    A.sav_u0 = S.u0;
+    A.sav_zero = S.zero;
+    A.sav_nC = S.nCd;
+    A.sav_step[0] = 1; A.sav_step[1] = S.sdx; A.sav_step[2] = S.pitch;
+    A.ncls = S.ncls;
+    c->n_ref = S.n_ref;
+    c->plane = S.plane; c->pitch = S.pitch; c->nCd = S.nCd;
+    EC3D_HIP(hipMalloc(&A.tail_id, 8));
+    EC3D_HIP(hipMalloc(&A.chunk_ptr, 8));
+    EC3D_HIP(hipMalloc(&A.tcol, 8));
+    EC3D_HIP(hipMalloc(&A.tval, 8));
+    EC3D_HIP(hipMalloc(&A.cls, S.cls.size()));
+    EC3D_HIP(hipMalloc(&A.tile_flag, S.tile_flag.size()));
+    EC3D_HIP(hipMalloc(&A.table, S.table.size() * 8));
+    EC3D_HIP(hipMalloc(&A.ulist, std::max<size_t>(S.ulist.size(), 1) * 4));
+    EC3D_HIP(hipMemcpy(A.cls, S.cls.data(), S.cls.size(), hipMemcpyHostToDevice));
+    EC3D_HIP(hipMemcpy(A.tile_flag, S.tile_flag.data(), S.tile_flag.size(), hipMemcpyHostToDevice));
+    EC3D_HIP(hipMemcpy(A.table, S.table.data(), S.table.size() * 8, hipMemcpyHostToDevice));
+    if (!S.ulist.empty()) EC3D_HIP(hipMemcpy(A.ulist, S.ulist.data(), S.ulist.size() * 4, hipMemcpyHostToDevice));
+    A.ulist_n = (int)S.ulist.size();
+    A.ntiles_front = S.ntiles_front;
+    A.bytes = (int64_t)(S.cls.size() + S.tile_flag.size() + S.table.size() * 8 + S.ulist.size() * 4);
+    c->n_cond = (int64_t)S.cond_cell.size();
+    if (c->n_cond) {
+        EC3D_HIP(hipMalloc(&c->cond_cell, S.cond_cell.size() * 4));
+        EC3D_HIP(hipMemcpy(c->cond_cell, S.cond_cell.data(), S.cond_cell.size() * 4, hipMemcpyHostToDevice));
+        EC3D_HIP(hipMalloc(&c->io_tmp, S.cond_cell.size() * sizeof(double)));
+    }
+    c->have_matrix = true;
+    return ec3d_prepare_vectors(c);
+}
+
 extern "C" int ec3d_set_matrix_csr(ec3d_handle c, int32_t n, const double *valA, const int32_t *irow,
                                    const int32_t *jcol)
 {
+    if (c->use_sav && c->use_dict) { // the reference's A-V matrix: class-coded stencil form
+        SavHost S;
+        if (ec3d_csr_to_sav_host(n, valA, irow, jcol, S) == 0) return ec3d_upload_sav(c, S);
+    }
     HostMatrix M;
     int rc = ec3d_csr_to_host_matrix(n, valA, irow, jcol, M);
     if (rc) return rc;
@@ -442,7 +494,7 @@ extern "C" int ec3d_set_stream(ec3d_handle c, void *stream)
 static int sav_to_csr(ec3d_ctx *c, std::vector<int32_t> &irow, std::vector<int32_t> &jcol, std::vector<double> &valA)
 {
     const DevMatrix &A = c->A;
-    const int64_t nCd = A.sav_nC, nC = c->plane * c->sdz, nU = c->n_cond; // device / reference cells per block
+    const int64_t nCd = A.sav_nC, nC = c->plane * c->planes(), nU = c->n_cond; // device / reference cells per block
     std::vector<uint8_t> cls((size_t)A.n_pad);
     std::vector<double> tab((size_t)A.ncls * 16);
     std::vector<int32_t> cell((size_t)nU), uidx((size_t)nCd, -1);
@@ -590,12 +642,12 @@ int ec3d_vec_h2d(ec3d_ctx *c, double *dev, const double *host)
         EC3D_HIP(hipMemcpyAsync(dev, host, (size_t)c->A.n * sizeof(double), hipMemcpyHostToDevice, c->stream));
         return 0;
     }
-    const int64_t nA = 3 * c->A.sav_nC, nu = c->n_cond, nAref = 3 * c->plane * c->sdz;
+    const int64_t nA = 3 * c->A.sav_nC, nu = c->n_cond, nAref = 3 * c->plane * c->planes();
     if (c->pitch == c->plane)
         EC3D_HIP(hipMemcpyAsync(dev, host, (size_t)nA * sizeof(double), hipMemcpyHostToDevice, c->stream));
     else // one row per xy plane; the padding between planes stays zero
         EC3D_HIP(hipMemcpy2DAsync(dev, (size_t)c->pitch * 8, host, (size_t)c->plane * 8, (size_t)c->plane * 8,
-                                  (size_t)3 * c->sdz, hipMemcpyHostToDevice, c->stream));
+                                  (size_t)3 * c->planes(), hipMemcpyHostToDevice, c->stream));
     if (nu) {
         EC3D_HIP(hipMemcpyAsync(c->io_tmp, host + nAref, (size_t)nu * sizeof(double), hipMemcpyHostToDevice, c->stream));
         k_u_scatter<<<(unsigned)((nu + 255) / 256), 256, 0, c->stream>>>(dev + nA, c->cond_cell, c->io_tmp, nu);
@@ -611,12 +663,12 @@ int ec3d_vec_d2h(ec3d_ctx *c, double *host, const double *dev)
         EC3D_HIP(hipMemcpyAsync(host, dev, (size_t)c->A.n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         return 0;
     }
-    const int64_t nA = 3 * c->A.sav_nC, nu = c->n_cond, nAref = 3 * c->plane * c->sdz;
+    const int64_t nA = 3 * c->A.sav_nC, nu = c->n_cond, nAref = 3 * c->plane * c->planes();
     if (c->pitch == c->plane)
         EC3D_HIP(hipMemcpyAsync(host, dev, (size_t)nA * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     else
         EC3D_HIP(hipMemcpy2DAsync(host, (size_t)c->plane * 8, dev, (size_t)c->pitch * 8, (size_t)c->plane * 8,
-                                  (size_t)3 * c->sdz, hipMemcpyDeviceToHost, c->stream));
+                                  (size_t)3 * c->planes(), hipMemcpyDeviceToHost, c->stream));
     if (nu) {
         k_u_gather<<<(unsigned)((nu + 255) / 256), 256, 0, c->stream>>>(dev + nA, c->cond_cell, c->io_tmp, nu);
         EC3D_HIP(hipGetLastError());
@@ -635,7 +687,7 @@ extern "C" int ec3d_get_row_map(ec3d_handle c, int32_t *ref_to_dev)
         for (int64_t i = 0; i < c->A.n; ++i) ref_to_dev[i] = (int32_t)i;
         return 0;
     }
-    const int64_t nA = 3 * c->A.sav_nC, nC = c->plane * c->sdz;
+    const int64_t nA = 3 * c->A.sav_nC, nC = c->plane * c->planes();
     for (int d = 0; d < 3; ++d)
         for (int64_t q = 0; q < nC; ++q) ref_to_dev[d * nC + q] = (int32_t)(d * c->nCd + c->dev_cell(q));
     std::vector<int32_t> cell((size_t)c->n_cond);

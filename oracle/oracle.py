@@ -163,6 +163,15 @@ def device_system(solver, valA, irow, jcol, *vectors):
     return (valA, irow_d, jcol_d, rm, *out)
 
 
+def twin_solve(solver, valA, irow, jcol, b, x0, tol, itmax, hist_cap=0):
+    """The GPU-order twin on the system `solver` holds, whatever its device numbering; x comes back in
+    the reference's numbering.  Rows the device adds (inactive U slots, plane padding) must stay zero."""
+    vd, ird, jcd, rm, bd, xd = device_system(solver, valA, irow, jcol, b, x0)
+    xo, it, hs, hr = bicgstab_wr_gpuorder(geoms_of(solver), vd, ird, jcd, bd, xd, tol, itmax, hist_cap=hist_cap)
+    assert np.all(np.delete(xo, rm) == 0.0)
+    return xo[rm], it, hs, hr
+
+
 def dot_gpuorder(geom, a, b):
     return lib().oracle_dot_gpuorder(C.byref(geom), np.ascontiguousarray(a), np.ascontiguousarray(b),
                                      len(a))

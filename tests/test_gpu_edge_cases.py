@@ -32,7 +32,7 @@ def test_odd_tiny_grids_and_explicit_zero_coefficients(E, oracle, dims, bnd):
                 s.set_matrix_csr(valA, irow, jcol)
             assert np.array_equal(s.spmv(x), oracle.spmv_csr(valA, irow, jcol, x))
             xs, it, _ = s.solve(b, np.zeros(n), 1e-10, 3000)
-            xo, ito, _, _ = oracle.bicgstab_wr_gpuorder(oracle.geoms_of(s), valA, irow, jcol, b, np.zeros(n),
+            xo, ito, _, _ = oracle.twin_solve(s, valA, irow, jcol, b, np.zeros(n),
                                                         1e-10, 3000)
             assert it == ito and np.array_equal(xs, xo)
 

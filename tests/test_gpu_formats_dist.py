@@ -155,7 +155,7 @@ def test_zmarch_spmv_and_solve_bitwise(E, oracle, dims, dic):
         assert gs.zm_tpp == sdx * sdy // 512 and gs.zm_pps >= 8
         assert np.array_equal(s.spmv(x), oracle.spmv_csr(valA, irow, jcol, x))
         xs, it, hist = s.solve(b, np.zeros(n), 1e-9, 5000, hist_cap=64)
-        xo, ito, hs, hr = oracle.bicgstab_wr_gpuorder(oracle.geoms_of(s), valA, irow, jcol, b, np.zeros(n), 1e-9,
+        xo, ito, hs, hr = oracle.twin_solve(s, valA, irow, jcol, b, np.zeros(n), 1e-9,
                                                       5000, hist_cap=64)
         assert it == ito and np.array_equal(xs, xo)
         k = min(it, 64)
@@ -164,7 +164,7 @@ def test_zmarch_spmv_and_solve_bitwise(E, oracle, dims, dic):
         assert s.geometry(1).zm_tpp == 0
         assert np.array_equal(s.spmv(x), oracle.spmv_csr(valA, irow, jcol, x))
         x2, it2, _ = s.solve(b, np.zeros(n), 1e-9, 5000)
-        xo2, ito2, _, _ = oracle.bicgstab_wr_gpuorder(oracle.geoms_of(s), valA, irow, jcol, b, np.zeros(n), 1e-9, 5000)
+        xo2, ito2, _, _ = oracle.twin_solve(s, valA, irow, jcol, b, np.zeros(n), 1e-9, 5000)
         assert it2 == ito2 and np.array_equal(x2, xo2)
 
 
@@ -308,6 +308,48 @@ def test_structured_av_form(E, oracle, name, plane_pitch):
             assert np.array_equal(hist[:kk, 0], hs[:kk])
             xr = g[f"xout{k}"]
             assert np.linalg.norm(xs - xr) <= 10 * tol * np.linalg.norm(xr)
+
+
+@pytest.mark.parametrize("name", ["g2_conducting_hole_16x15x14", "g3_moving_coil_18x16x12", "g1_nonconducting_8x7x6"])
+def test_structured_form_recognised_in_csr(E, oracle, name, plane_pitch):
+    """The drop-in route: the reference's CSR goes in, the structure is recognised entry by entry
+    (ec3d_sav_csr.cpp) and the handle ends up in the same class-coded form ec3d_assemble builds natively --
+    same row map, same operator bit for bit, same solve."""
+    g = load_golden(name)
+    n = len(g["irow"]) - 1
+    tol, itmax = float(g["tol"]), int(g["itmax"])
+    x = np.random.Generator(np.random.PCG64(32)).standard_normal(n)
+    with E.EC3DSolver() as s, E.EC3DSolver() as nat:
+        s.set_matrix_csr(g["valA"], g["irow"], g["jcol"])
+        nat.assemble(g["geoPHYS"], g["geoPHYS_C"], g["valPHYS"], g["BND"], g["delta"], float(g["dt"]))
+        mi = s.info
+        assert mi.n == n and mi.tail_rows == 0 and mi.dict_classes > 0 and mi.nnz == len(g["valA"])
+        assert np.array_equal(s.row_map(), nat.row_map())
+        va, ir, jc = s.export_csr()
+        assert np.array_equal(ir, g["irow"]) and np.array_equal(jc, g["jcol"]) and np.array_equal(va, g["valA"])
+        assert np.array_equal(s.spmv(x), oracle.spmv_csr(g["valA"], g["irow"], g["jcol"], x))
+        xs, it, hist = s.solve(g["b0"], g["xin0"], tol, itmax, hist_cap=64)
+        xo, ito, hs, hr = oracle.twin_solve(s, g["valA"], g["irow"], g["jcol"], g["b0"], g["xin0"], tol, itmax,
+                                            hist_cap=64)
+        assert it == ito and np.array_equal(xs, xo) and np.array_equal(hist[:min(it, 64), 0], hs[:min(it, 64)])
+        xn, itn, _ = nat.solve(g["b0"], g["xin0"], tol, itmax)
+        assert itn == it and np.array_equal(xn, xs)
+
+
+def test_structured_form_needs_the_reference_row_order(E, oracle):
+    """A row whose stored order is not the order the kernels add the slots in (here: two entries of one U
+    row swapped) must not be taken into the structured form: bands + tail keep the stored order."""
+    g = load_golden("g2_conducting_hole_16x15x14")
+    valA, irow, jcol = g["valA"].copy(), g["irow"], g["jcol"].copy()
+    r = len(irow) - 2  # last U row
+    p = irow[r] - 1
+    valA[[p, p + 1]] = valA[[p + 1, p]]
+    jcol[[p, p + 1]] = jcol[[p + 1, p]]
+    x = np.random.Generator(np.random.PCG64(33)).standard_normal(len(irow) - 1)
+    with E.EC3DSolver() as s:
+        s.set_matrix_csr(valA, irow, jcol)
+        assert s.info.tail_rows > 0 and np.array_equal(s.row_map(), np.arange(s.n))
+        assert np.array_equal(s.spmv(x), oracle.spmv_csr(valA, irow, jcol, x))
 
 
 def test_structured_form_falls_back(E, oracle):

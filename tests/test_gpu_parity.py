@@ -125,10 +125,9 @@ def test_solve_bitwise_vs_gpu_order_oracle(E, oracle, name):
     tol, itmax = float(g["tol"]), int(g["itmax"])
     with E.EC3DSolver() as s:
         s.set_matrix_csr(g["valA"], g["irow"], g["jcol"])
-        geom = oracle.geoms_of(s)
         for k in range(len(g["iters"])):
             x, it, hist = s.solve(g[f"b{k}"], g[f"xin{k}"], tol, itmax, hist_cap=400)
-            xo, ito, hs, hr = oracle.bicgstab_wr_gpuorder(geom, g["valA"], g["irow"], g["jcol"], g[f"b{k}"],
+            xo, ito, hs, hr = oracle.twin_solve(s, g["valA"], g["irow"], g["jcol"], g[f"b{k}"],
                                                           g[f"xin{k}"], tol, itmax, hist_cap=400)
             assert it == ito
             assert np.array_equal(x, xo)
@@ -207,10 +206,9 @@ def test_itmax_exit_matches_reference(E, oracle, capfd):
     g = load_golden("g2i_itmax_exit_16x15x14")
     with E.EC3DSolver() as s:
         s.set_matrix_csr(g["valA"], g["irow"], g["jcol"])
-        geom = oracle.geoms_of(s)
         x, it, _ = s.solve(g["b0"], g["xin0"], float(g["tol"]), int(g["itmax"]))
         assert it == 26 == int(g["iters"][0])
-        xo, ito, _, _ = oracle.bicgstab_wr_gpuorder(geom, g["valA"], g["irow"], g["jcol"], g["b0"], g["xin0"],
+        xo, ito, _, _ = oracle.twin_solve(s, g["valA"], g["irow"], g["jcol"], g["b0"], g["xin0"],
                                                     float(g["tol"]), int(g["itmax"]))
         assert np.array_equal(x, xo)
         assert np.linalg.norm(x - g["xout0"]) <= 1e-6 * np.linalg.norm(g["xout0"])
@@ -222,9 +220,8 @@ def test_loose_tolerance_takes_the_s_exit(E, oracle):
     g = load_golden("g1_nonconducting_8x7x6")
     with E.EC3DSolver() as s:
         s.set_matrix_csr(g["valA"], g["irow"], g["jcol"])
-        geom = oracle.geoms_of(s)
         x, it, hist = s.solve(g["b0"], g["xin0"], 0.9, 100, hist_cap=4)
-        xo, ito, hs, _ = oracle.bicgstab_wr_gpuorder(geom, g["valA"], g["irow"], g["jcol"], g["b0"], g["xin0"],
+        xo, ito, hs, _ = oracle.twin_solve(s, g["valA"], g["irow"], g["jcol"], g["b0"], g["xin0"],
                                                      0.9, 100, hist_cap=4)
         assert it == ito == 1 and np.array_equal(x, xo) and hist[0, 0] == hs[0]
 
@@ -236,9 +233,8 @@ def test_restart_rule_is_exercised(E, oracle):
     tol = 3e-2
     with E.EC3DSolver() as s:
         s.set_matrix_csr(g["valA"], g["irow"], g["jcol"])
-        geom = oracle.geoms_of(s)
         x, it, _ = s.solve(g["b0"], g["xin0"], tol, 1000)
-        xo, ito, _, _ = oracle.bicgstab_wr_gpuorder(geom, g["valA"], g["irow"], g["jcol"], g["b0"], g["xin0"],
+        xo, ito, _, _ = oracle.twin_solve(s, g["valA"], g["irow"], g["jcol"], g["b0"], g["xin0"],
                                                     tol, 1000)
         assert it == ito and np.array_equal(x, xo)
 
