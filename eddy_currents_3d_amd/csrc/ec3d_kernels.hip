@@ -196,22 +196,32 @@ __device__ __forceinline__ void stage_table(const MatView &A, double *tbl)
 // column order = the reference's row-sum order.  A slot whose coefficient is zero is not an entry of the
 // reference's row: it is neither loaded nor added.  Both rows take their operands from one 16-byte load
 // per slot; most rows use 2 of the 5 (A rows) or 6 of the 9 (U rows) slots.
+// the two running sums are final here and no load moves across (register pressure, see the callers)
+#define EC3D_PIN(a, b) asm volatile("" : "+v"(a), "+v"(b)::"memory")
 template <class V>
 __device__ __forceinline__ void sav_u_pre(const MatView &A, const double *t0, const double *t1, const V &x,
                                           int64_t r, double &s0, double &s1)
 {
+    // per component: the (up to) three loads first, then the adds in slot order -- a load inside the
+    // add chain would cost one memory round trip per slot
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         const int64_t base = r - (3 - d) * A.sav_nC;
+        double v0[3], v1[3];
+        d2 xx[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const double v0 = t0[7 + 3 * d + j], v1 = t1[7 + 3 * d + j];
-            if (v0 != 0.0 || v1 != 0.0) {
-                const d2 xx = x.pair(base + (j - 1) * A.sav_step[d]);
-                if (v0 != 0.0) s0 = s0 + v0 * xx.x;
-                if (v1 != 0.0) s1 = s1 + v1 * xx.y;
-            }
+            v0[j] = t0[7 + 3 * d + j];
+            v1[j] = t1[7 + 3 * d + j];
+            xx[j] = d2{0.0, 0.0};
+            if (v0[j] != 0.0 || v1[j] != 0.0) xx[j] = x.pair(base + (j - 1) * A.sav_step[d]);
         }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            if (v0[j] != 0.0) s0 = s0 + v0[j] * xx[j].x;
+            if (v1[j] != 0.0) s1 = s1 + v1[j] * xx[j].y;
+        }
+        EC3D_PIN(s0, s1); // keep the batches apart: nine operand pairs in flight would cost 36 registers
     }
 }
 template <class V>
@@ -219,14 +229,19 @@ __device__ __forceinline__ void sav_a_post(const MatView &A, const double *t0, c
                                            int64_t r, int d, double &s0, double &s1)
 {
     const int64_t base = r + (3 - d) * A.sav_nC, step = A.sav_step[d];
+    double v0[5], v1[5];
+    d2 xx[5];
 #pragma unroll
     for (int m = 0; m < 5; ++m) {
-        const double v0 = t0[7 + m], v1 = t1[7 + m];
-        if (v0 != 0.0 || v1 != 0.0) {
-            const d2 xx = x.pair(base + (m - 2) * step);
-            if (v0 != 0.0) s0 = s0 + v0 * xx.x;
-            if (v1 != 0.0) s1 = s1 + v1 * xx.y;
-        }
+        v0[m] = t0[7 + m];
+        v1[m] = t1[7 + m];
+        xx[m] = d2{0.0, 0.0};
+        if (v0[m] != 0.0 || v1[m] != 0.0) xx[m] = x.pair(base + (m - 2) * step);
+    }
+#pragma unroll
+    for (int m = 0; m < 5; ++m) {
+        if (v0[m] != 0.0) s0 = s0 + v0[m] * xx[m].x;
+        if (v1[m] != 0.0) s1 = s1 + v1[m] * xx[m].y;
     }
 }
 
@@ -242,6 +257,7 @@ template <int FMT, bool ZM, class V>
 __device__ __forceinline__ void spmv_pair(const MatView &A, const double *tbl, const V &x, int64_t r, int64_t tile,
                                           bool first, ZRegs &z, double &s0, double &s1, d2 &ctr)
 {
+    uint8_t tflag = 0; // per tile: any tail row (bands + tail) / any coupled row (structured form)
     if (FMT == FMT_DIA7 || FMT == FMT_DICT7 || FMT == FMT_SAV) {
         d2 xv[7];
         // the +-1 neighbours (bands 2 and 4 of the 7-point operator) are the centre pairs of the
@@ -249,6 +265,17 @@ __device__ __forceinline__ void spmv_pair(const MatView &A, const double *tbl, c
         // first/last lane of a wave reads its outer neighbour from memory.  The SpMV kernels are
         // bound by L1/TA load issue, not by HBM, so 3 full-wave loads per step instead of 5 matter.
         const bool pm1 = A.pm1 != 0;
+        // every load of the step is issued before the first use: class bytes, the two edge-lane
+        // neighbours, then the band operands (one round trip per step instead of three)
+        unsigned short cc = 0;
+        if (FMT == FMT_DICT7 || FMT == FMT_SAV) cc = *reinterpret_cast<const unsigned short *>(A.cls + r);
+        if (FMT == FMT_SAV || A.has_tail) tflag = A.tile_flag[tile];
+        const int lane = threadIdx.x & 63;
+        double left = 0.0, right = 0.0;
+        if (pm1) {
+            if (lane == 0) left = x.at(r - 1);
+            if (lane == 63) right = x.at(r + 2);
+        }
 #pragma unroll
         for (int b = 0; b < 7; ++b) {
             if (ZM && (b == 0 || b == 3) && !first) continue;
@@ -262,10 +289,9 @@ __device__ __forceinline__ void spmv_pair(const MatView &A, const double *tbl, c
         }
         ctr = xv[3];
         if (pm1) {
-            const int lane = threadIdx.x & 63;
-            double left = __shfl_up(ctr.y, 1, 64), right = __shfl_down(ctr.x, 1, 64);
-            if (lane == 0) left = x.at(r - 1);
-            if (lane == 63) right = x.at(r + 2);
+            const double l = __shfl_up(ctr.y, 1, 64), rr = __shfl_down(ctr.x, 1, 64);
+            if (lane != 0) left = l;
+            if (lane != 63) right = rr;
             xv[2] = d2{left, ctr.x};
             xv[4] = d2{ctr.y, right};
         }
@@ -281,7 +307,6 @@ __device__ __forceinline__ void spmv_pair(const MatView &A, const double *tbl, c
                 s1 = s1 + c[b].y * xv[b].y;
             }
         } else if (FMT == FMT_DICT7) {
-            const unsigned short cc = *reinterpret_cast<const unsigned short *>(A.cls + r);
             const double *t0 = tbl + (cc & 0xFF) * 7, *t1 = tbl + (cc >> 8) * 7;
             s0 = t0[0] * xv[0].x;
             s1 = t1[0] * xv[0].y;
@@ -291,10 +316,9 @@ __device__ __forceinline__ void spmv_pair(const MatView &A, const double *tbl, c
                 s1 = s1 + t1[b] * xv[b].y;
             }
         } else { // FMT_SAV: U rows take their A couplings first, A rows their U couplings last
-            const unsigned short cc = *reinterpret_cast<const unsigned short *>(A.cls + r);
             const int c0 = cc & 0xFF, c1 = cc >> 8;
             const double *t0 = tbl + c0 * EC3D_SAV_STRIDE, *t1 = tbl + c1 * EC3D_SAV_STRIDE;
-            const bool cpl = A.tile_flag[tile] != 0; // any coupled row in this tile (uniform)
+            const bool cpl = tflag != 0; // any coupled row in this tile (uniform)
             // the coupling slots of an A class mean U columns, those of a U class A columns: a row of the
             // other kind goes through the all-zero class
             const double *zt = tbl + A.sav_zero * EC3D_SAV_STRIDE;
@@ -308,6 +332,7 @@ __device__ __forceinline__ void spmv_pair(const MatView &A, const double *tbl, c
                 s1 = s1 + t1[b] * xv[b].y;
             }
             if (cpl && r < nA) {
+                EC3D_PIN(s0, s1); // the band operands are dead from here: their registers take the slots'
                 const int d0 = (r >= A.sav_nC) + (r >= 2 * A.sav_nC);
                 const int d1 = (r + 1 >= A.sav_nC) + (r + 1 >= 2 * A.sav_nC);
                 const bool in0 = c0 >= A.sav_a0 && c0 < A.sav_u0, in1 = c1 >= A.sav_a0 && c1 < A.sav_u0 && r + 1 < nA;
@@ -330,8 +355,9 @@ __device__ __forceinline__ void spmv_pair(const MatView &A, const double *tbl, c
             s1 = s1 + c.y * xv.y;
         }
         ctr = x.pair(r);
+        if (A.has_tail) tflag = A.tile_flag[tile];
     }
-    if (A.has_tail && A.tile_flag[tile]) {
+    if (A.has_tail && tflag) {
         i2 t = *reinterpret_cast<const i2 *>(A.tail_id + r);
         if (t.x >= 0) s0 = tail_add(A, x, t.x, s0);
         if (t.y >= 0) s1 = tail_add(A, x, t.y, s1);
