@@ -407,6 +407,23 @@ int ec3d_upload_sav(ec3d_ctx *c, const SavHost &S)
     return ec3d_prepare_vectors(c);
 }
 
+extern "C" int ec3d_probe_csr(int32_t n, const double *valA, const int32_t *irow, const int32_t *jcol,
+                              ec3d_csr_probe *out)
+{
+    if (!out || !valA || !irow || !jcol) return 2;
+    *out = ec3d_csr_probe{};
+    SavHost S;
+    if (ec3d_csr_to_sav_host(n, valA, irow, jcol, S) != 0) return 0;
+    out->structured = 1;
+    out->sdx = (int32_t)S.sdx;
+    out->sdy = (int32_t)(S.plane / S.sdx);
+    out->sdz = (int32_t)(S.nCd / S.pitch);
+    out->n_cond = (int32_t)S.cond_cell.size();
+    out->classes = S.ncls;
+    out->plane_pitch = (int32_t)S.pitch;
+    return 0;
+}
+
 extern "C" int ec3d_set_matrix_csr(ec3d_handle c, int32_t n, const double *valA, const int32_t *irow,
                                    const int32_t *jcol)
 {

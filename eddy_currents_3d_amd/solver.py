@@ -39,6 +39,11 @@ class MatrixInfo(C.Structure):
                 ("dict_classes", C.c_int32)]
 
 
+class CsrProbe(C.Structure):
+    _fields_ = [("structured", C.c_int32), ("sdx", C.c_int32), ("sdy", C.c_int32), ("sdz", C.c_int32),
+                ("n_cond", C.c_int32), ("classes", C.c_int32), ("plane_pitch", C.c_int32)]
+
+
 VEC = dict(X=0, B=1, R=2, R0=3, P=4, AP=5, S=6, AS=7)
 KERNEL = dict(spmv=0, k1=1, k2=2, k3=3, k4=4, k5=5)
 # algorithmic bytes per row of each kernel with 7 bands
@@ -53,7 +58,7 @@ EXPORTS = ["sprsbcgstabwr_", "ec3d_invalidate", "ec3d_create", "ec3d_destroy", "
            "ec3d_assemble_poisson_slab", "ec3d_vector_layout", "ec3d_adopt_vectors",
            "ec3d_dist_configure", "ec3d_dist_step", "ec3d_read_state", "ec3d_set_zmarch", "ec3d_can_overlap",
            "ec3d_rhs_step", "ec3d_post_update", "ec3d_assemble_slab", "ec3d_vtk_fields",
-           "ec3d_set_structured", "ec3d_get_row_map", "ec3d_get_ulist",
+           "ec3d_set_structured", "ec3d_get_row_map", "ec3d_get_ulist", "ec3d_probe_csr",
            "ec3d_device_synchronize"]
 
 _f64 = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
@@ -130,6 +135,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.ec3d_set_format.argtypes = [hp, C.c_int]
     L.ec3d_set_structured.argtypes = [hp, C.c_int]
     L.ec3d_get_row_map.argtypes = [hp, _i32]
+    L.ec3d_probe_csr.argtypes = [C.c_int32, _f64, _i32, _i32, C.POINTER(CsrProbe)]
     L.ec3d_get_ulist.argtypes = [hp, _i32]
     L.ec3d_set_stream.argtypes = [hp, hp]
     L.ec3d_assemble_poisson_slab.argtypes = [hp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f64, _f64]
@@ -150,6 +156,19 @@ def load_library(path: str | None = None) -> C.CDLL:
 def _chk(L, rc, what):
     if rc != 0:
         raise EC3DError(f"{what} failed ({rc}): {L.ec3d_last_error().decode()}")
+
+
+def probe_csr(valA, irow, jcol):
+    """Host-only (no GPU): how would the library store this CSR matrix?  Returns a CsrProbe; `.structured`
+    says whether the class-coded A-V form applies (include/ec3d_hip.h, ec3d_probe_csr)."""
+    L = load_library()
+    out = CsrProbe()
+    irow = np.ascontiguousarray(irow, np.int32)
+    rc = L.ec3d_probe_csr(len(irow) - 1, np.ascontiguousarray(valA, np.float64), irow,
+                          np.ascontiguousarray(jcol, np.int32), C.byref(out))
+    if rc:
+        raise EC3DError(f"ec3d_probe_csr failed ({rc})")
+    return out
 
 
 def sprsBCGstabWR(valA, irow, jcol, n, b, x, tolerance, itmax):

@@ -206,6 +206,20 @@ typedef struct {
 } ec3d_matrix_info;
 int ec3d_get_matrix_info(ec3d_handle h, ec3d_matrix_info *info);
 
+/* Host-only check (no GPU needed, no handle): would ec3d_set_matrix_csr / sprsbcgstabwr_ store this
+ * matrix in the structured A-V form?  structured = 0 means bands + tail (still exact, slower on the U
+ * couplings).  The test is the one the library runs: every entry of the matrix gen_sparse_matrix builds
+ * (src/EC3D.f90:465-1049) must land in a stencil slot, rows stored in ascending column order. */
+typedef struct {
+    int32_t structured;
+    int32_t sdx, sdy, sdz;   /* grid found                                                     */
+    int32_t n_cond;          /* conducting cells = U unknowns                                   */
+    int32_t classes;         /* distinct 16-coefficient rows (<= 256)                           */
+    int32_t plane_pitch;     /* device rows per xy plane (>= sdx*sdy, whole tiles when pitched) */
+} ec3d_csr_probe;
+int ec3d_probe_csr(int32_t n, const double *valA, const int32_t *irow, const int32_t *jcol,
+                   ec3d_csr_probe *out);
+
 /* Time `reps` back-to-back launches of one kernel with hipEvents on the library's stream and
  * return the average per launch in milliseconds.  kernel: */
 enum { EC3D_K_SPMV = 0,   /* y = A p                        72 B/row             */
