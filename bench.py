@@ -58,6 +58,36 @@ def bar_rhs(N, k0=0, k1=None):
     return b.reshape(-1)
 
 
+def av_system(refine):
+    """The shipped compare_to_Elmer geometry (tests/golden/g4: plate, hole, two coil pairs), refined by an
+    integer factor per axis (physical size kept), as the arrays ec3d_assemble takes, plus a coil RHS:
+    the full A-V system [Ax | Ay | Az | U] of BASELINE config 3 at a size worth timing."""
+    import numpy as np
+    mu0 = 0.12566370964050292e-05
+    g = np.load(os.path.join(REPO, "tests", "golden", "g4_compare_to_Elmer.npz"))
+    f = int(refine)
+    vox = np.repeat(np.repeat(np.repeat(g["vox"], f, axis=0), f, axis=1), f, axis=2)
+    dx = float(g["lattice_dim"])
+    flat = vox.reshape(-1)
+    ncell = flat.size
+    geo = flat.astype(np.int8).copy()
+    geo[geo == 0] = 6
+    geoC = np.zeros(ncell, np.int32)
+    idx = np.flatnonzero(flat == 1)
+    geoC[idx] = 3 * ncell + 1 + np.arange(idx.size)
+    valPHYS = np.zeros((6, 5))
+    valPHYS[:, 0] = 1.0
+    valPHYS[0, 1] = mu0 * 35.26e6
+    b = np.zeros(3 * ncell + idx.size)
+    a = 183.0 / (6 * dx * 6 * dx)
+    b[np.flatnonzero(flat == 2)] = a * mu0
+    b[np.flatnonzero(flat == 3)] = -a * mu0
+    b[ncell + np.flatnonzero(flat == 4)] = a * mu0
+    b[ncell + np.flatnonzero(flat == 5)] = -a * mu0
+    return (geo.reshape(vox.shape), geoC.reshape(vox.shape), valPHYS, np.full((3, 2), -0.95),
+            np.array([dx / f] * 3), 1e-3, b)
+
+
 def cpu_baseline(budget_s=20.0):
     """Reference solver on one host core, bounded sample (never the thing measured as product)."""
     import numpy as np
@@ -99,6 +129,10 @@ def main():
     ap.add_argument("--grid", type=int, default=512, help="cube edge N (512 = headline, 256 = config 2)")
     ap.add_argument("--format", choices=["dict", "dia"], default="dict",
                     help="band storage: dictionary (default, 1 B/row) or plain DIA streams (56 B/row)")
+    ap.add_argument("--workload", choices=["cube", "av"], default="cube",
+                    help="cube: the synthetic N^3 operator the metric is quoted on (default); av: the full A-V "
+                         "system of the shipped compare_to_Elmer geometry refined by --refine (1 GPU only)")
+    ap.add_argument("--refine", type=int, default=3)
     ap.add_argument("--force-dist", action="store_true",
                     help="use the z-slab/torch.distributed path even with one rank (rehearsal on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -132,10 +166,25 @@ def main():
     N, K, W = args.grid, args.steps, args.warmup
     n_global = N ** 3
     kernel_ms = None
+    workload = (f"synthetic {N}^3 7-pt operator (BASELINE config {'4' if N == 512 else '2'} grid), bar RHS, "
+                f"x0=0, exits disabled")
+    grid = [N, N, N]
+    if args.workload == "av" and use_dist:
+        raise SystemExit("bench.py --workload av runs on one GPU")
     if not use_dist:
         s = E.EC3DSolver(device=local_rank, dictionary=args.format == "dict")
-        s.assemble_poisson(N, N, N)
-        s.upload("B", bar_rhs(N))
+        if args.workload == "av":
+            geo, geoC, valPHYS, BND, delta, dt, b = av_system(args.refine)
+            s.assemble(geo, geoC, valPHYS, BND, delta, dt)
+            n_global = len(b)
+            grid = list(geo.shape[::-1])
+            workload = (f"full A-V system [Ax|Ay|Az|U] of the shipped compare_to_Elmer geometry refined x"
+                        f"{args.refine} per axis (BASELINE config 3 style): grid {grid[0]}x{grid[1]}x{grid[2]}, "
+                        f"{int(np.count_nonzero(geoC))} conducting cells, coil RHS, x0=0, exits disabled")
+            s.upload("B", b)
+        else:
+            s.assemble_poisson(N, N, N)
+            s.upload("B", bar_rhs(N))
         s.upload("X", np.zeros(n_global))
         s.iterate_begin()
         s.iterate(1, W)
@@ -150,7 +199,7 @@ def main():
         # instrumented pass of the same K iterations: hipEvents around every launch, library stream
         kernel_ms = s.iterate(W + K + 1, K, per_kernel=True)
         spmv_ms = s.time_kernel("spmv", 20)
-        geom = s.geometry()
+        geom = {"vector": int(s.geometry(0).nblk), "spmv": int(s.geometry(1).nblk)}
         info = s.info
         parallelism = "single GPU"
     else:
@@ -173,7 +222,7 @@ def main():
         elapsed = float(el.item())
         kernel_ms = s.iterate(W + K + 1, min(K, 20), per_kernel=True)
         spmv_ms = None
-        geom = s.local.geometry()
+        geom = {"vector": int(s.local.geometry(0).nblk), "spmv": int(s.local.geometry(1).nblk)}
         info = s.local.info
         parallelism = f"z-slab x{world} (halo send/recv + all_gather of dot products, RCCL)"
 
@@ -186,7 +235,7 @@ def main():
         dom = max(kernel_ms, key=kernel_ms.get)   # dominant kernel by measured share
         tr = latest_traffic()
         use_tr = bool(tr) and tr.get("grid") == N and tr.get("n_gpus", 1) == world and \
-            tr.get("format") == args.format
+            tr.get("format") == args.format and tr.get("workload", "cube") == args.workload
         kernels = {}
         for k, ms in kernel_ms.items():
             kernels[k] = {"ms": ms, "share": ms / sum(kernel_ms.values()),
@@ -200,11 +249,13 @@ def main():
             "value": value, "unit": "DOF*iters/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"synthetic {N}^3 7-pt operator (BASELINE config "
-                                   f"{'4' if N == 512 else '2'} grid), bar RHS, x0=0, exits disabled",
-                       "n": n_global, "grid": [N, N, N], "parallelism": parallelism,
-                       "band_format": "dictionary (1 B/row + table)" if info.dict_classes > 0 else "plain DIA",
-                       "workgroups": int(geom.nblk),
+            "config": {"workload": workload,
+                       "n": n_global, "grid": grid, "parallelism": parallelism,
+                       "band_format": ("structured A-V form (1 class byte/row, U on the grid)"
+                                       if args.workload == "av" and info.tail_rows == 0 and info.dict_classes > 0
+                                       else "dictionary (1 B/row + table)" if info.dict_classes > 0
+                                       else "plain DIA"),
+                       "workgroups": geom,
                        "bytes_per_dof_iter": {"survey_model": ITER_BYTES_PER_DOF,
                                               "this_format": sum(fmt_bytes[k] for k in kernel_ms)}},
             "iter_hbm_frac_survey_model": ITER_BYTES_PER_DOF * value / 1e9 / world / PEAK_HBM_GBS,
