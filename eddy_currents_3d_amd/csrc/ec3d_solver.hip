@@ -40,7 +40,7 @@ MatView DevMatrix::view() const
     for (int d = 0; d < 3; ++d) v.sav_step[d] = sav_step[d];
     static const bool shuffle_off = getenv("EC3D_SHUFFLE") && atoi(getenv("EC3D_SHUFFLE")) == 0;
     v.pm1 = (nb == 7 && off[2] == -1 && off[4] == 1 && !shuffle_off) ? 1 : 0;
-    v.has_tail = ntail > 0 && !getenv("EC3D_EXPERIMENT_NOTAIL"); // experiment knob: timing only, wrong results
+    v.has_tail = ntail > 0;
     v.tail_id = tail_id;
     v.tile_flag = tile_flag;
     v.chunk_ptr = chunk_ptr;
@@ -153,7 +153,6 @@ static void choose_sweep(ec3d_ctx *c)
         sw.ntiles = c->A.ntiles_front;
         sw.ulist = c->A.ulist;
         sw.ulist_n = c->A.ulist_n;
-        if (getenv("EC3D_EXPERIMENT_NOULIST")) sw.ulist_n = 0;
     }
     sw.nown = c->nown;
     for (int q = 0; q < 4; ++q) {

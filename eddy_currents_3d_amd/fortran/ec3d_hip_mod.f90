@@ -12,7 +12,7 @@ module ec3d_hip
     implicit none
     private
     public :: ec3d_create, ec3d_destroy, ec3d_assemble, ec3d_assemble_poisson, ec3d_set_matrix_csr, &
-              ec3d_solve, ec3d_spmv, ec3d_get_cel_bnd, ec3d_error_text, ec3d_set_format, &
+              ec3d_solve, ec3d_spmv, ec3d_get_cel_bnd, ec3d_error_text, ec3d_set_format, ec3d_set_structured, &
               ec3d_upload, ec3d_download, ec3d_solve_resident, ec3d_rhs_step, ec3d_post_update, &
               ec3d_vtk_fields, EC3D_VEC_X, EC3D_VEC_B
 
@@ -32,6 +32,12 @@ module ec3d_hip
             import :: c_ptr, c_int
             type(c_ptr), value :: h
             integer(c_int), value :: dictionary
+        end function
+        ! 0: keep the A-V matrix as bands + tail instead of the structured form (DESIGN.md section 2)
+        integer(c_int) function ec3d_set_structured(h, on) bind(C, name="ec3d_set_structured")
+            import :: c_ptr, c_int
+            type(c_ptr), value :: h
+            integer(c_int), value :: on
         end function
         ! replaces CALL gen_sparse_matrix (src/EC3D.f90:115)
         integer(c_int) function ec3d_assemble(h, sdx, sdy, sdz, geoPHYS, geoPHYS_C, valPHYS, nsub_glob, &
