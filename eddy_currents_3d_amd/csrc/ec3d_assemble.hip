@@ -666,9 +666,11 @@ int ec3d_assemble_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t sdz, int
         c->own_lo[3] = 3 * g.nCells + u_lo;
         c->own_hi[3] = 3 * g.nCells + u_hi;
         c->halo = g.kdz;
-        return ec3d_prepare_vectors(c);
     }
+    c->n_cells = g.nCells;
     if ((rc = ec3d_prepare_vectors(c))) return rc;
+    // per-step RHS tables; in a slab they cover the held planes in local numbering (halo rows included:
+    // what is computed there is overwritten by the next halo exchange or never read)
     return ec3d_setup_rhs(c, g.nCells, geoPHYS, geoPHYS_C, valPHYS, nsub_glob, dt);
 }
 
@@ -803,6 +805,7 @@ int ec3d_assemble_sav_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t sdz,
     }
     c->have_matrix = true;
     c->sdx = sdx; c->sdy = sdy; c->sdz = sdz;
+    c->n_cells = g.nCells;
     if (nc0) EC3D_HIP(hipMalloc(&c->io_tmp, (size_t)nc0 * sizeof(double)));
     if ((rc = ec3d_prepare_vectors(c))) return rc;
     return ec3d_setup_rhs(c, g.nCells, geoPHYS, geoPHYS_C, valPHYS, nsub_glob, dt);

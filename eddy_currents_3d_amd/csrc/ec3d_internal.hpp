@@ -193,6 +193,7 @@ struct ec3d_ctx {
     std::vector<int32_t> cel_bnd[6];
     // grid of the last native assembly (0 when the matrix came from CSR)
     int32_t sdx = 0, sdy = 0, sdz = 0;
+    int64_t n_cells = 0; // cells this handle holds per component (a z-slab: its extended planes only)
     // per-step RHS build / post-update on the device (src/EC3D.f90:370-404, :412-433)
     int64_t n_cond = 0;            // conducting cells (U unknowns), scan order
     int n_cond_domains = 0;

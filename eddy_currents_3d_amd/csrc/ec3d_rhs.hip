@@ -156,8 +156,8 @@ int ec3d_setup_rhs(ec3d_ctx *c, int64_t nCells, const int8_t *geoPHYS, const int
 
 static int need_grid(ec3d_ctx *c, const char *who)
 {
-    if (!c || !c->have_matrix || c->sdx == 0 || c->halo != 0) {
-        ec3d_set_error(std::string(who) + ": needs a matrix assembled with ec3d_assemble");
+    if (!c || !c->have_matrix || c->sdx == 0 || c->n_cells == 0 || c->A.n < 3 * c->n_cells) {
+        ec3d_set_error(std::string(who) + ": needs a matrix assembled with ec3d_assemble / ec3d_assemble_slab");
         return 3;
     }
     if (c->n_cond_domains > 1) {
@@ -175,7 +175,7 @@ extern "C" int ec3d_rhs_step(ec3d_handle c, int32_t moving, int32_t nsrc, const 
 {
     int rc = need_grid(c, "ec3d_rhs_step");
     if (rc) return rc;
-    const int64_t nCells = (int64_t)c->sdx * c->sdy * c->sdz, nc = c->n_cond;
+    const int64_t nCells = c->n_cells, nc = c->n_cond; // a slab: held cells, local numbering
     const int64_t nCd = c->nCd ? c->nCd : nCells;
     double *b = c->vec[EC3D_VEC_B], *x = c->vec[EC3D_VEC_X];
     hipStream_t s = c->stream;
@@ -233,7 +233,7 @@ extern "C" int ec3d_post_update(ec3d_handle c)
 {
     int rc = need_grid(c, "ec3d_post_update");
     if (rc) return rc;
-    const int64_t nCells = (int64_t)c->sdx * c->sdy * c->sdz, nc = c->n_cond;
+    const int64_t nCells = c->n_cells, nc = c->n_cond;
     const int64_t nCd = c->nCd ? c->nCd : nCells;
     if (!nc) return 0; // :411 IF (size_PHYS_C /= 0)
     double *b = c->vec[EC3D_VEC_B], *x = c->vec[EC3D_VEC_X];

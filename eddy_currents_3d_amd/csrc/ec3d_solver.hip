@@ -113,6 +113,7 @@ void ec3d_free_matrix(ec3d_ctx *c)
     free_vectors(c);
     for (auto &l : c->cel_bnd) l.clear();
     c->sdx = c->sdy = c->sdz = 0;
+    c->n_cells = 0;
 }
 
 extern "C" int ec3d_destroy(ec3d_handle c)

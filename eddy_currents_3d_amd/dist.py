@@ -223,6 +223,25 @@ class HipAVSlabOps(HipSlabOps):
         return np.concatenate([d * self.nC_global + cell for d in range(3)] +
                               [3 * self.nC_global + self.u_global0 + np.arange(self.nU)])
 
+    # ---- the time loop around the solve (src/EC3D.f90:275-404, :412-433) on this slab -------------
+    def rhs_step(self, src_index, src_value, moving=False):
+        """Jaf of this step on the held planes.  src_index: 1-based GLOBAL ids of the A unknowns the host's
+        source functions act on (what a single-device ec3d_rhs_step takes); sources outside the extended
+        slab are dropped, the rest renumbered locally.  Needs current X halo planes (the U-row right-hand
+        sides read A one plane away): the drivers exchange X first."""
+        g0 = np.asarray(src_index, np.int64) - 1
+        val = np.asarray(src_value, np.float64)
+        d, cell = np.divmod(g0, self.nC_global)
+        plane = cell // self.kdz
+        keep = (plane >= self.e0) & (plane < self.e1)
+        local = d[keep] * self.nC + (cell[keep] - self.e0 * self.kdz) + 1
+        with self.context():
+            self.local.rhs_step(local.astype(np.int32), val[keep], moving=moving)
+
+    def post_update(self):
+        with self.context():
+            self.local.post_update()
+
     def set_vector_global(self, name, global_vec):
         """Fill owned AND halo entries from a global vector in the reference's numbering."""
         self.set_vector(name, np.asarray(global_vec, np.float64)[self._global_index()])
@@ -368,6 +387,18 @@ class SlabSolver:
         stop_iter, _, _ = self.ops.read_state()
         return stop_iter if stop_iter >= 0 else total
 
+    # ---- the time loop around the solve (A-V slabs) ---------------------------------------------
+    def rhs_step(self, src_index, src_value, moving=False):
+        """Build this step's right-hand side on every rank (src/EC3D.f90:275-404): same arguments on all
+        ranks (global source ids and values); b and x stay resident."""
+        with self.ops.context():
+            self.exchange("X")
+        self.ops.rhs_step(src_index, src_value, moving)
+
+    def post_update(self):
+        """src/EC3D.f90:412-433 on the owned planes (and their halo copies)."""
+        self.ops.post_update()
+
     # ---- bench "steps": exits disabled ---------------------------------------------------------
     def iterate_begin(self):
         self.begin(-1.0)
@@ -456,6 +487,25 @@ class InProcessSlabs:
             if states[0] >= 0:
                 return states[0]
         return total
+
+    def rhs_step(self, src_index, src_value, moving=False):
+        self._sync()
+        self._halo("X")
+        self._sync()
+        for o in self.ops_list:
+            o.rhs_step(src_index, src_value, moving)
+
+    def post_update(self):
+        for o in self.ops_list:
+            o.post_update()
+
+    def vector(self, name, n_global):
+        """Global vector `name` in the reference's numbering, owned parts of every slab."""
+        out = np.zeros(n_global)
+        self._sync()
+        for o in self.ops_list:
+            o.export_owned(name, out)
+        return out
 
     def x(self, n_global=None):
         """Global solution in the reference's numbering."""

@@ -84,7 +84,9 @@ int ec3d_solve_resident(ec3d_handle h, double tolerance, int32_t itmax, int32_t 
                         double *resid_hist, int32_t hist_cap);
 
 /* Per-time-step field work around the solve, on the resident vectors (B = Jaf, X = Uaf), so only the
- * coil cells' source values cross PCIe each step.  Needs a matrix from ec3d_assemble.
+ * coil cells' source values cross PCIe each step.  Needs a matrix from ec3d_assemble, or from
+ * ec3d_assemble_slab: ids are then local to the held planes (d*nC_held + cell + 1) and the caller
+ * refreshes the X halo planes first (eddy_currents_3d_amd/dist.py, SlabSolver.rhs_step).
  * ec3d_rhs_step  replaces src/EC3D.f90:275-404: with moving != 0 first keeps only the inertial part
  *   of Jaf (:277-296); then Jaf(src_index(q)) = src_value(q), q in order (1-based unknown ids; the
  *   host evaluates the source functions and the coil motion, :245-340); then Jaf = a*Uaf + Jaf on the
