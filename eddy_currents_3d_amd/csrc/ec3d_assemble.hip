@@ -410,7 +410,12 @@ __global__ __launch_bounds__(256) void k_assemble_sav(GridPar g, const int8_t *_
     const SavIds id = sav_ids(g.nsub_glob);
     const int64_t nn0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (nn0 >= g.nCells) return;
-    const int i = (int)(nn0 % g.sdx) + 1, j = (int)((nn0 / g.sdx) % g.sdy) + 1, k = (int)(nn0 / g.kdz) + 1;
+    const int kl = (int)(nn0 / g.kdz); // plane within the planes held
+    const int i = (int)(nn0 % g.sdx) + 1, j = (int)((nn0 / g.sdx) % g.sdy) + 1, k = g.k0 + kl + 1;
+    if (k - 1 < g.own_k0 || k - 1 >= g.own_k1) { // halo plane of a z-slab: inert rows (class zero already)
+        flags[nn0] = 0;
+        return;
+    }
     const int bt = a_row_class(g, i, j, k, 0);
     const int32_t u0 = geoC[nn0];
     const bool on_box = bt != 13;
@@ -418,7 +423,7 @@ __global__ __launch_bounds__(256) void k_assemble_sav(GridPar g, const int8_t *_
     // nonzeros of the plain A row: 7 minus one per box face the cell touches
     const int tx = bt % 3, ty = (bt / 3) % 3, tz = bt / 9;
     unsigned long long cnt = 3ull * (7 - (tx != 1) - (ty != 1) - (tz != 1));
-    const int64_t pc = (int64_t)(k - 1) * g.pitch + nn0 % g.kdz; // device cell
+    const int64_t pc = (int64_t)kl * g.pitch + nn0 % g.kdz; // device cell
     if (u0 == 0) {
         cls[pc] = cls[g.nCd + pc] = cls[2 * g.nCd + pc] = (uint8_t)bt;
         flags[nn0] = 0;
@@ -675,16 +680,21 @@ int ec3d_assemble_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t sdz, int
 }
 
 // The structured form of the A-V system (MatView::sav).  Returns -1 when it does not apply.
-int ec3d_assemble_sav_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t sdz, const int8_t *geoPHYS,
-                             const int32_t *geoPHYS_C, const double *valPHYS, int32_t nsub_glob,
-                             const double *BND, const double *delta, double dt)
+int ec3d_assemble_sav_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t sdz, int32_t e0, int32_t e1, int32_t k0,
+                             int32_t k1, const int8_t *geoPHYS, const int32_t *geoPHYS_C, const double *valPHYS,
+                             int32_t nsub_glob, const double *BND, const double *delta, double dt)
 {
     GridPar g;
     memset(&g, 0, sizeof g);
     int rc = fill_gridpar(g, sdx, sdy, sdz, BND, delta, dt);
     if (rc) return rc;
     g.nsub_glob = nsub_glob;
-    g.own_k1 = sdz;
+    g.k0 = e0;
+    g.own_k0 = k0;
+    g.own_k1 = k1;
+    const int32_t np = e1 - e0;           // planes held (a z-slab: owned planes + halo planes)
+    g.nCells = g.kdz * np;
+    const bool slab = !(e0 == 0 && e1 == sdz);
     const SavIds id = sav_ids(nsub_glob);
     if (id.ncls > 256 || sdx < 5 || sdy < 5 || sdz < 5) return -1;
     // conducting cells in scan order; one conducting domain only (U numbering = scan order)
@@ -708,11 +718,11 @@ int ec3d_assemble_sav_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t sdz,
     g.pitch = g.kdz;
     {
         const int64_t p = round_up64(g.kdz, EC3D_TILE);
-        bool want = (p - g.kdz) * 16 <= g.kdz && sdz >= 8;
+        bool want = (p - g.kdz) * 16 <= g.kdz && np >= 8;
         if (const char *e = getenv("EC3D_PITCH")) want = atoi(e) == 2 || (want && atoi(e) != 0);
         if (want) g.pitch = p;
     }
-    g.nCd = g.pitch * sdz;
+    g.nCd = g.pitch * np;
     const int64_t n_dev = 4 * g.nCd;
     if (n_dev > (int64_t)INT32_MAX - EC3D_TILE) return -1;
     g.ncells0 = nc0;
@@ -806,6 +816,14 @@ int ec3d_assemble_sav_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t sdz,
     c->have_matrix = true;
     c->sdx = sdx; c->sdy = sdy; c->sdz = sdz;
     c->n_cells = g.nCells;
+    if (slab) { // rows that count in dot products: the owned planes of each of the four blocks
+        c->nown = 4;
+        for (int d = 0; d < 4; ++d) {
+            c->own_lo[d] = d * g.nCd + (int64_t)(k0 - e0) * g.pitch;
+            c->own_hi[d] = d * g.nCd + (int64_t)(k1 - e0) * g.pitch;
+        }
+        c->halo = g.pitch;
+    }
     if (nc0) EC3D_HIP(hipMalloc(&c->io_tmp, (size_t)nc0 * sizeof(double)));
     if ((rc = ec3d_prepare_vectors(c))) return rc;
     return ec3d_setup_rhs(c, g.nCells, geoPHYS, geoPHYS_C, valPHYS, nsub_glob, dt);

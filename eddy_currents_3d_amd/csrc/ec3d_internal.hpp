@@ -263,9 +263,10 @@ void ec3d_launch_k5(const Sweep &sw, const RedSrc &src, SolverState *st, int it,
 int ec3d_assemble_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t sdz, int32_t e0, int32_t e1, int32_t k0,
                          int32_t k1, const int8_t *geoPHYS, const int32_t *geoPHYS_C, const double *valPHYS,
                          int32_t nsub_glob, const double *BND, const double *delta, double dt);
-int ec3d_assemble_sav_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t sdz, const int8_t *geoPHYS,
-                             const int32_t *geoPHYS_C, const double *valPHYS, int32_t nsub_glob,
-                             const double *BND, const double *delta, double dt);
+// same plane arguments as ec3d_assemble_device; returns -1 when the structured form does not apply
+int ec3d_assemble_sav_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t sdz, int32_t e0, int32_t e1, int32_t k0,
+                             int32_t k1, const int8_t *geoPHYS, const int32_t *geoPHYS_C, const double *valPHYS,
+                             int32_t nsub_glob, const double *BND, const double *delta, double dt);
 int ec3d_assemble_poisson_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t sdz, int32_t k0, int32_t k1,
                                  const double *BND, const double *delta);
 // ec3d_format.cpp / ec3d_solver.hip: dictionary compression of the bands

@@ -444,7 +444,8 @@ extern "C" int ec3d_assemble(ec3d_handle c, int32_t sdx, int32_t sdy, int32_t sd
 {
     EC3D_HIP(hipSetDevice(c->device));
     if (c->use_sav && c->use_dict) {
-        const int rc = ec3d_assemble_sav_device(c, sdx, sdy, sdz, geoPHYS, geoPHYS_C, valPHYS, nsub_glob, BND, delta, dt);
+        const int rc = ec3d_assemble_sav_device(c, sdx, sdy, sdz, 0, sdz, 0, sdz, geoPHYS, geoPHYS_C, valPHYS,
+                                                nsub_glob, BND, delta, dt);
         if (rc != -1) return rc; // -1: the structured form does not apply, use the general one
     }
     return ec3d_assemble_device(c, sdx, sdy, sdz, 0, sdz, 0, sdz, geoPHYS, geoPHYS_C, valPHYS, nsub_glob, BND, delta,
@@ -464,6 +465,11 @@ extern "C" int ec3d_assemble_slab(ec3d_handle c, int32_t sdx, int32_t sdy, int32
     if ((k0 - e0 < 2 && e0 != 0) || (e1 - k1 < 2 && e1 != sdz)) {
         ec3d_set_error("ec3d_assemble_slab: two halo planes are needed on every interior side");
         return 2;
+    }
+    if (c->use_sav && c->use_dict) {
+        const int rc = ec3d_assemble_sav_device(c, sdx, sdy, sdz, e0, e1, k0, k1, geoPHYS_ext, geoPHYS_C_ext, valPHYS,
+                                                nsub_glob, BND, delta, dt);
+        if (rc != -1) return rc;
     }
     return ec3d_assemble_device(c, sdx, sdy, sdz, e0, e1, k0, k1, geoPHYS_ext, geoPHYS_C_ext, valPHYS, nsub_glob, BND,
                                 delta, dt);

@@ -153,7 +153,8 @@ class HipAVSlabOps(HipSlabOps):
 
     H = 2
 
-    def __init__(self, geoPHYS, geoPHYS_C, valPHYS, BND, delta, dt, k0, k1, world, device=0, dictionary=None):
+    def __init__(self, geoPHYS, geoPHYS_C, valPHYS, BND, delta, dt, k0, k1, world, device=0, dictionary=None,
+                 structured=None):
         import torch
         from .solver import EC3DSolver
         self.torch = torch
@@ -179,38 +180,63 @@ class HipAVSlabOps(HipSlabOps):
         u_in = lambda a, b: int(per_plane[a:b].sum())            # conducting cells in global planes [a, b)
         self.device = torch.device("cuda", device)
         self.stream = torch.cuda.Stream(device=self.device)
-        self.local = EC3DSolver(device=device, dictionary=dictionary)
+        self.local = EC3DSolver(device=device, dictionary=dictionary, structured=structured)
         self.local.set_stream(self.stream.cuda_stream)
         self.local.assemble_slab(sdz, e0, e1, k0, k1, np.asarray(geoPHYS)[e0:e1], geoC_ext, valPHYS, BND, delta, dt)
         lay = self.local.vector_layout()
-        self.n, self.ghost = lay["n"], lay["ghost"]
-        assert self.n == 3 * nC + self.nU
+        self.n, self.ghost = lay["n"], lay["ghost"]          # device rows
+        self.n_ref = 3 * nC + self.nU                         # local unknowns, reference order [Ax|Ay|Az|U]
+        # device row of every local unknown: identity for bands + tail; the structured form embeds U in the
+        # grid and may pad the planes
+        rm = self.local.row_map().astype(np.int64)
+        assert len(rm) == self.n_ref
+        self.structured = self.n != self.n_ref
         self.len = 2 * lay["ghost"] + lay["n_pad"]
         with torch.cuda.stream(self.stream):
             self.store = torch.zeros(8 * self.len, dtype=torch.float64, device=self.device)
             self.lsum = torch.zeros(NSLOT, dtype=torch.float64, device=self.device)
             self.gsum = torch.zeros(world * NSLOT, dtype=torch.float64, device=self.device)
+            self._rm = torch.from_numpy(rm).to(self.device)
         self.stream.synchronize()
         self.local.adopt_vectors(self.store.data_ptr())
         self.local.dist_configure(world, self.lsum.data_ptr(), self.gsum.data_ptr())
-        # contiguous (send, recv) row ranges per neighbour, local row numbering
+        # contiguous (send, recv) DEVICE row ranges per neighbour
         p0, p1 = k0 - e0, k1 - e0
         self._ranges = []
+        if self.structured:   # four grid-shaped blocks of nCd rows, `pitch` rows per plane
+            nCd = self.n // 4
+            pitch = nCd // (e1 - e0)
+            blocks = [(d * nCd, pitch) for d in range(4)]
+        else:                 # three grid-shaped blocks; the U block is compact (handled below)
+            blocks = [(d * nC, kdz) for d in range(3)]
         if e0 < k0:   # lower neighbour exists: send my first H owned planes, receive my lower halo planes
-            for d in range(3):
-                self._ranges.append((-1, (d * nC + p0 * kdz, d * nC + (p0 + H) * kdz),
-                                     (d * nC + (p0 - H) * kdz, d * nC + p0 * kdz)))
-            ulo = u_in(e0, k0)
-            self._ranges.append((-1, (3 * nC + ulo, 3 * nC + ulo + u_in(k0, k0 + H)), (3 * nC, 3 * nC + ulo)))
+            for base, pl in blocks:
+                self._ranges.append((-1, (base + p0 * pl, base + (p0 + H) * pl), (base + (p0 - H) * pl, base + p0 * pl)))
+            if not self.structured:
+                ulo = u_in(e0, k0)
+                self._ranges.append((-1, (3 * nC + ulo, 3 * nC + ulo + u_in(k0, k0 + H)), (3 * nC, 3 * nC + ulo)))
         if k1 < e1:   # upper neighbour
-            for d in range(3):
-                self._ranges.append((+1, (d * nC + (p1 - H) * kdz, d * nC + p1 * kdz),
-                                     (d * nC + p1 * kdz, d * nC + (p1 + H) * kdz)))
-            uown_end = u_in(e0, k1)
-            self._ranges.append((+1, (3 * nC + uown_end - u_in(k1 - H, k1), 3 * nC + uown_end),
-                                 (3 * nC + uown_end, 3 * nC + self.nU)))
+            for base, pl in blocks:
+                self._ranges.append((+1, (base + (p1 - H) * pl, base + p1 * pl), (base + p1 * pl, base + (p1 + H) * pl)))
+            if not self.structured:
+                uown_end = u_in(e0, k1)
+                self._ranges.append((+1, (3 * nC + uown_end - u_in(k1 - H, k1), 3 * nC + uown_end),
+                                     (3 * nC + uown_end, 3 * nC + self.nU)))
+        # owned rows in LOCAL reference numbering (what get_vector returns)
         self._own = [(d * nC + p0 * kdz, d * nC + p1 * kdz) for d in range(3)] + \
                     [(3 * nC + u_in(e0, k0), 3 * nC + u_in(e0, k1))]
+
+    def set_vector(self, name, host_array):
+        """host_array: the slab's unknowns in local reference order [Ax | Ay | Az | U] (held planes)."""
+        with self.context():
+            src = self.torch.from_numpy(np.ascontiguousarray(host_array, np.float64)).to(self.device)
+            b = self._base(name)
+            self.store[b:b + self.n].index_copy_(0, self._rm, src)
+
+    def get_vector(self, name):
+        with self.context():
+            b = self._base(name)
+            return self.store[b:b + self.n].index_select(0, self._rm).cpu().numpy()
 
     def halo_pairs(self, name):
         b = self._base(name)

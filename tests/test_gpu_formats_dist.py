@@ -189,7 +189,8 @@ def test_zmarch_slabs_on_one_gpu(E, oracle):
 # --------------------------------------------------------------------------- A-V system in slabs
 @pytest.mark.parametrize("name,world", [("g2_conducting_hole_16x15x14", 2), ("g2_conducting_hole_16x15x14", 3),
                                         ("g3_moving_coil_18x16x12", 2), ("g2v_conducting_moving_16x15x14", 4)])
-def test_av_slabs_on_one_gpu_match_reference(E, name, world):
+@pytest.mark.parametrize("structured", [True, False])
+def test_av_slabs_on_one_gpu_match_reference(E, name, world, structured, plane_pitch):
     """The full A-V system [Ax|Ay|Az|U] cut into z-slabs (extended grid: 2 halo planes per side, inert halo
     rows, ownership-masked dot products), all slabs held by one process on one GPU; the cuts go through
     the conductor.  Against the unmodified reference's solution of the same captured system."""
@@ -203,7 +204,8 @@ def test_av_slabs_on_one_gpu_match_reference(E, name, world):
         for r in range(world):
             k0, k1 = slab_bounds(sdz, r, world)
             o = HipAVSlabOps(g["geoPHYS"], g["geoPHYS_C"], g["valPHYS"], g["BND"], g["delta"], float(g["dt"]),
-                             k0, k1, world)
+                             k0, k1, world, structured=structured)
+            assert o.structured == structured
             o.set_vector_global("B", g[f"b{k}"])
             o.set_vector_global("X", g[f"xin{k}"])
             ops.append(o)

@@ -84,7 +84,8 @@ def test_resident_time_loop_matches_reference():
 @pytest.mark.parametrize("name,moving,world", [("g2_conducting_hole_16x15x14", False, 2),
                                                ("g3_moving_coil_18x16x12", True, 2),
                                                ("g3_moving_coil_18x16x12", True, 3)])
-def test_rhs_build_and_post_update_on_slabs_bitwise(name, moving, world):
+@pytest.mark.parametrize("structured", [True, False])
+def test_rhs_build_and_post_update_on_slabs_bitwise(name, moving, world, structured, plane_pitch):
     """The same per-step field work on z-slabs of the A-V system (multi-GPU layout, all slabs on this one
     GPU): each slab builds the right-hand side of its planes from global source ids after an X halo
     exchange; the assembled b and the post-updated x are bit-identical to the reference's."""
@@ -96,7 +97,7 @@ def test_rhs_build_and_post_update_on_slabs_bitwise(name, moving, world):
     for r in range(world):
         k0, k1 = slab_bounds(sdz, r, world)
         o = HipAVSlabOps(g["geoPHYS"], g["geoPHYS_C"], g["valPHYS"], g["BND"], g["delta"], float(g["dt"]),
-                         k0, k1, world)
+                         k0, k1, world, structured=structured)
         o.set_vector_global("X", np.zeros(n))
         o.set_vector_global("B", np.zeros(n))
         ops.append(o)
