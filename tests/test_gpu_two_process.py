@@ -65,3 +65,63 @@ def test_two_ranks_share_one_gpu(tmp_path):
     print(f"2 processes on one GPU: iter {it} / undivided {itr}, true residual {res_norm:.2e}")
     assert res_norm < 5 * TOL
     assert np.linalg.norm(x - xr) <= 1e-5 * np.linalg.norm(xr)
+
+
+def _av_worker(rank, world, port, out):
+    """The whole resident time loop of the A-V system on two ranks: rhs_step (X halo exchange, global source
+    ids) -> solve -> post_update, fields never leaving the GPU between steps."""
+    import sys
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import torch
+    import torch.distributed as dist
+    from conftest import load_golden
+    from test_gpu_timeloop import coil_sources
+    from eddy_currents_3d_amd.dist import HipAVSlabOps, SlabSolver, slab_bounds
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    try:
+        g = load_golden("g3_moving_coil_18x16x12")
+        n = len(g["irow"]) - 1
+        tol, itmax = float(g["tol"]), int(g["itmax"])
+        k0, k1 = slab_bounds(g["geoPHYS"].shape[0], rank, world)
+        ops = HipAVSlabOps(g["geoPHYS"], g["geoPHYS_C"], g["valPHYS"], g["BND"], g["delta"], float(g["dt"]),
+                           k0, k1, world)
+        assert ops.structured
+        s = SlabSolver(ops, rank, world, k0, k1)
+        ops.set_vector_global("X", np.zeros(n))
+        ops.set_vector_global("B", np.zeros(n))
+        res = []
+        for k in range(len(g["iters"])):
+            idx, val = coil_sources(g, k, True)
+            s.rhs_step(idx, val, moving=True)
+            it = s.solve(tol, itmax, poll=4)
+            x = np.zeros(n)
+            ops.export_owned("X", x)
+            xt = torch.from_numpy(x)
+            dist.all_reduce(xt)
+            res.append(np.concatenate([[it], xt.numpy()]))
+            s.post_update()
+        if rank == 0:
+            np.save(out, np.stack(res))
+        ops.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_run_the_av_time_loop(tmp_path):
+    from conftest import load_golden
+    out = str(tmp_path / "av.npy")
+    mp.spawn(_av_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    res = np.load(out)
+    g = load_golden("g3_moving_coil_18x16x12")
+    tol = float(g["tol"])
+    for k, it_ref in enumerate(g["iters"]):
+        it, x = int(res[k, 0]), res[k, 1:]
+        xr = g[f"xout{k}"]
+        rel = np.linalg.norm(x - xr) / np.linalg.norm(xr)
+        print(f"step {k}: iter 2 ranks {it} / reference {int(it_ref)}, rel diff {rel:.2e}")
+        assert rel <= 10 * tol
