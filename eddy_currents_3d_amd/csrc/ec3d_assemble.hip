@@ -600,19 +600,19 @@ int ec3d_assemble_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t sdz, int
     A.bytes = (int64_t)(bb + (size_t)A.n_pad * 4 + A.n_pad / EC3D_TILE + cp.size() * 8 + te * 12);
 
     // inputs
-    int8_t *d_geo = nullptr;
-    int32_t *d_geoC = nullptr, *d_uidx = nullptr;
-    double *d_val = nullptr;
-    uint8_t *d_flags = nullptr;
-    int *d_err = nullptr;
-    unsigned long long *d_nnz = nullptr;
-    EC3D_HIP(hipMalloc(&d_geo, (size_t)g.nCells));
-    EC3D_HIP(hipMalloc(&d_geoC, (size_t)g.nCells * 4));
-    EC3D_HIP(hipMalloc(&d_uidx, (size_t)g.nCells * 4));
-    EC3D_HIP(hipMalloc(&d_val, (size_t)nsub_glob * 5 * 8));
-    EC3D_HIP(hipMalloc(&d_flags, (size_t)g.nCells));
-    EC3D_HIP(hipMalloc(&d_err, sizeof(int)));
-    EC3D_HIP(hipMalloc(&d_nnz, sizeof(unsigned long long)));
+    DevTmp<int8_t> d_geo;
+    DevTmp<int32_t> d_geoC, d_uidx;
+    DevTmp<double> d_val;
+    DevTmp<uint8_t> d_flags;
+    DevTmp<int> d_err;
+    DevTmp<unsigned long long> d_nnz;
+    EC3D_HIP(d_geo.alloc((size_t)g.nCells));
+    EC3D_HIP(d_geoC.alloc((size_t)g.nCells));
+    EC3D_HIP(d_uidx.alloc((size_t)g.nCells));
+    EC3D_HIP(d_val.alloc((size_t)nsub_glob * 5));
+    EC3D_HIP(d_flags.alloc((size_t)g.nCells));
+    EC3D_HIP(d_err.alloc(1));
+    EC3D_HIP(d_nnz.alloc(1));
     EC3D_HIP(hipMemcpyAsync(d_geo, geoPHYS, (size_t)g.nCells, hipMemcpyHostToDevice, c->stream));
     EC3D_HIP(hipMemcpyAsync(d_geoC, geoPHYS_C, (size_t)g.nCells * 4, hipMemcpyHostToDevice, c->stream));
     EC3D_HIP(hipMemcpyAsync(d_uidx, uidx.data(), (size_t)g.nCells * 4, hipMemcpyHostToDevice, c->stream));
@@ -632,8 +632,6 @@ int ec3d_assemble_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t sdz, int
     EC3D_HIP(hipMemcpyAsync(&nnz, d_nnz, sizeof nnz, hipMemcpyDeviceToHost, c->stream));
     EC3D_HIP(hipMemcpyAsync(flags.data(), d_flags, flags.size(), hipMemcpyDeviceToHost, c->stream));
     EC3D_HIP(hipStreamSynchronize(c->stream));
-    (void)hipFree(d_geo); (void)hipFree(d_geoC); (void)hipFree(d_uidx); (void)hipFree(d_val);
-    (void)hipFree(d_flags); (void)hipFree(d_err); (void)hipFree(d_nnz);
     if (err) {
         ec3d_free_matrix(c);
         ec3d_set_error(err == 3 ? "ec3d_assemble: conductor touches the box boundary or is thinner than 3 cells "
@@ -673,6 +671,7 @@ int ec3d_assemble_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t sdz, int
         c->halo = g.kdz;
     }
     c->n_cells = g.nCells;
+    c->slab_e0 = e0; c->slab_k0 = k0; c->slab_k1 = k1;
     if ((rc = ec3d_prepare_vectors(c))) return rc;
     // per-step RHS tables; in a slab they cover the held planes in local numbering (halo rows included:
     // what is computed there is overwritten by the next halo exchange or never read)
@@ -753,18 +752,18 @@ int ec3d_assemble_sav_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t sdz,
     EC3D_HIP(hipMalloc(&A.table, (size_t)id.ncls * 16 * sizeof(double)));
     A.bytes = A.n_pad + A.n_pad / EC3D_TILE + id.ncls * 128;
 
-    int8_t *d_geo = nullptr;
-    int32_t *d_geoC = nullptr;
-    double *d_val = nullptr;
-    uint8_t *d_flags = nullptr;
-    int *d_err = nullptr;
-    unsigned long long *d_nnz = nullptr;
-    EC3D_HIP(hipMalloc(&d_geo, (size_t)g.nCells));
-    EC3D_HIP(hipMalloc(&d_geoC, (size_t)g.nCells * 4));
-    EC3D_HIP(hipMalloc(&d_val, (size_t)nsub_glob * 5 * 8));
-    EC3D_HIP(hipMalloc(&d_flags, (size_t)g.nCells));
-    EC3D_HIP(hipMalloc(&d_err, sizeof(int)));
-    EC3D_HIP(hipMalloc(&d_nnz, sizeof(unsigned long long)));
+    DevTmp<int8_t> d_geo;
+    DevTmp<int32_t> d_geoC;
+    DevTmp<double> d_val;
+    DevTmp<uint8_t> d_flags;
+    DevTmp<int> d_err;
+    DevTmp<unsigned long long> d_nnz;
+    EC3D_HIP(d_geo.alloc((size_t)g.nCells));
+    EC3D_HIP(d_geoC.alloc((size_t)g.nCells));
+    EC3D_HIP(d_val.alloc((size_t)nsub_glob * 5));
+    EC3D_HIP(d_flags.alloc((size_t)g.nCells));
+    EC3D_HIP(d_err.alloc(1));
+    EC3D_HIP(d_nnz.alloc(1));
     EC3D_HIP(hipMemcpyAsync(d_geo, geoPHYS, (size_t)g.nCells, hipMemcpyHostToDevice, c->stream));
     EC3D_HIP(hipMemcpyAsync(d_geoC, geoPHYS_C, (size_t)g.nCells * 4, hipMemcpyHostToDevice, c->stream));
     EC3D_HIP(hipMemcpyAsync(d_val, valPHYS, (size_t)nsub_glob * 5 * 8, hipMemcpyHostToDevice, c->stream));
@@ -781,8 +780,6 @@ int ec3d_assemble_sav_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t sdz,
     EC3D_HIP(hipMemcpyAsync(&nnz, d_nnz, sizeof nnz, hipMemcpyDeviceToHost, c->stream));
     EC3D_HIP(hipMemcpyAsync(flags.data(), d_flags, flags.size(), hipMemcpyDeviceToHost, c->stream));
     EC3D_HIP(hipStreamSynchronize(c->stream));
-    (void)hipFree(d_geo); (void)hipFree(d_geoC); (void)hipFree(d_val);
-    (void)hipFree(d_flags); (void)hipFree(d_err); (void)hipFree(d_nnz);
     if (err) {
         ec3d_free_matrix(c);
         ec3d_set_error(err == 3 ? "ec3d_assemble: conductor touches the box boundary or is thinner than 3 cells "
@@ -816,6 +813,7 @@ int ec3d_assemble_sav_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t sdz,
     c->have_matrix = true;
     c->sdx = sdx; c->sdy = sdy; c->sdz = sdz;
     c->n_cells = g.nCells;
+    c->slab_e0 = e0; c->slab_k0 = k0; c->slab_k1 = k1;
     if (slab) { // rows that count in dot products: the owned planes of each of the four blocks
         c->nown = 4;
         for (int d = 0; d < 4; ++d) {

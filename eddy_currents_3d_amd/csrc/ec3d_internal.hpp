@@ -194,6 +194,7 @@ struct ec3d_ctx {
     // grid of the last native assembly (0 when the matrix came from CSR)
     int32_t sdx = 0, sdy = 0, sdz = 0;
     int64_t n_cells = 0; // cells this handle holds per component (a z-slab: its extended planes only)
+    int32_t slab_e0 = 0, slab_k0 = 0, slab_k1 = 0; // global planes: first held, owned range [k0, k1)
     // per-step RHS build / post-update on the device (src/EC3D.f90:370-404, :412-433)
     int64_t n_cond = 0;            // conducting cells (U unknowns), scan order
     int n_cond_domains = 0;
@@ -219,6 +220,17 @@ void ec3d_set_error(const std::string &msg);
             return 100;                                                                        \
         }                                                                                      \
     } while (0)
+
+// scratch device memory released at scope exit, error returns included
+template <class T> struct DevTmp {
+    T *p = nullptr;
+    DevTmp() = default;
+    DevTmp(const DevTmp &) = delete;
+    DevTmp &operator=(const DevTmp &) = delete;
+    ~DevTmp() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t count) { return hipMalloc(&p, count * sizeof(T)); }
+    operator T *() const { return p; }
+};
 
 // ec3d_format.cpp
 int ec3d_csr_to_host_matrix(int64_t n, const double *valA, const int32_t *irow, const int32_t *jcol,

@@ -114,6 +114,7 @@ void ec3d_free_matrix(ec3d_ctx *c)
     for (auto &l : c->cel_bnd) l.clear();
     c->sdx = c->sdy = c->sdz = 0;
     c->n_cells = 0;
+    c->slab_e0 = c->slab_k0 = c->slab_k1 = 0;
 }
 
 extern "C" int ec3d_destroy(ec3d_handle c)

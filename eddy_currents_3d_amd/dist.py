@@ -268,6 +268,15 @@ class HipAVSlabOps(HipSlabOps):
         with self.context():
             self.local.post_update()
 
+    def vtk_fields(self, delta, conducting=True):
+        """The four float32 point vectors of field_N.vtk for the OWNED planes (ec3d_vtk_fields); needs
+        current X halo planes for the curl.  conducting: the problem has conductors somewhere (the eddy
+        field exists in the file even where this slab holds none)."""
+        ncell = (self.k1 - self.k0) * self.kdz
+        with self.context():
+            f = self.local.vtk_fields(delta, ncell, conducting, zero_eddy=True)
+        return f
+
     def set_vector_global(self, name, global_vec):
         """Fill owned AND halo entries from a global vector in the reference's numbering."""
         self.set_vector(name, np.asarray(global_vec, np.float64)[self._global_index()])
@@ -425,6 +434,20 @@ class SlabSolver:
         """src/EC3D.f90:412-433 on the owned planes (and their halo copies)."""
         self.ops.post_update()
 
+    def vtk_fields(self, delta, conducting=True):
+        """Field vectors of the whole grid on rank 0 (None elsewhere): every rank computes its owned planes
+        on its GPU (X halo refreshed first), the float32 slabs are gathered in rank order."""
+        with self.ops.context():
+            self.exchange("X")
+        mine = self.ops.vtk_fields(delta, conducting)
+        if self.world == 1:
+            return mine
+        parts = [None] * self.world if self.rank == 0 else None
+        self.dist.gather_object(mine, parts, dst=0)
+        if self.rank != 0:
+            return None
+        return {k: (None if parts[0][k] is None else np.concatenate([p[k] for p in parts])) for k in parts[0]}
+
     # ---- bench "steps": exits disabled ---------------------------------------------------------
     def iterate_begin(self):
         self.begin(-1.0)
@@ -524,6 +547,13 @@ class InProcessSlabs:
     def post_update(self):
         for o in self.ops_list:
             o.post_update()
+
+    def vtk_fields(self, delta, conducting=True):
+        self._sync()
+        self._halo("X")
+        self._sync()
+        parts = [o.vtk_fields(delta, conducting) for o in self.ops_list]
+        return {k: (None if parts[0][k] is None else np.concatenate([p[k] for p in parts])) for k in parts[0]}
 
     def vector(self, name, n_global):
         """Global vector `name` in the reference's numbering, owned parts of every slab."""

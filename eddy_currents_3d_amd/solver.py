@@ -364,12 +364,13 @@ class EC3DSolver:
     def post_update(self):
         _chk(self.L, self.L.ec3d_post_update(self.h), "ec3d_post_update")
 
-    def vtk_fields(self, delta, ncells: int, conducting: bool):
+    def vtk_fields(self, delta, ncells: int, conducting: bool, zero_eddy: bool = False):
         """float32 point vectors of field_N.vtk (src/utilites.f90:222-289) from the resident X, B.
-        Returns dict(A, eddy (None without conductors), source, B), each (ncells, 3)."""
+        Returns dict(A, eddy (None without conductors), source, B), each (ncells, 3); ncells = the cells the
+        handle owns.  zero_eddy: start the eddy field from zeros (a z-slab that holds no conductor)."""
         mk = lambda: np.empty((ncells, 3), np.float32)
         fa, fs, fb = mk(), mk(), mk()
-        fe = mk() if conducting else None
+        fe = (np.zeros((ncells, 3), np.float32) if zero_eddy else mk()) if conducting else None
         _chk(self.L, self.L.ec3d_vtk_fields(self.h, np.ascontiguousarray(delta, np.float64), fa.ctypes.data,
                                             fe.ctypes.data if conducting else None, fs.ctypes.data,
                                             fb.ctypes.data), "ec3d_vtk_fields")

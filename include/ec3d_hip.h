@@ -99,7 +99,10 @@ int ec3d_post_update(ec3d_handle h);
 /* The four float32 point vectors of the reference's field_N.vtk (writeVtk_field, src/utilites.f90:222-289)
  * from the resident Uaf (X) and Jaf (B): Field_A, Vector_field_eddy (NULL allowed when there is no
  * conductor), Vector_field_SOURCE, Vector_field_B = curl A (central differences clamped at the box
- * faces, :276-289).  Each output: 3*nCells floats, xyz interleaved, cell order nn.  Host byte order. */
+ * faces, :276-289).  Each output: 3*nCells floats, xyz interleaved, cell order nn.  Host byte order.
+ * On a handle from ec3d_assemble_slab: the owned planes only (3*sdx*sdy*(k1-k0) floats per output, in
+ * order), the curl reading the halo planes at the slab's edges -- refresh the X halo first; a slab without
+ * conducting cells leaves field_eddy untouched (pass zeros). */
 int ec3d_vtk_fields(ec3d_handle h, const double *delta, float *field_A, float *field_eddy,
                     float *field_source, float *field_B);
 

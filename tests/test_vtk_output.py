@@ -60,3 +60,30 @@ def test_device_fields_and_curl_reproduce_reference_file(name, steps, plane_pitc
             s.post_update()
             f = s.vtk_fields(g["delta"], ncell, conducting)
             assert field_vtk_bytes(sdx, sdy, sdz, g["delta"], f) == g[f"vtk_field_{k}"].tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_device_fields_on_slabs_reproduce_reference_file(world, plane_pitch):
+    """The same on z-slabs (multi-GPU layout, slabs on this one GPU): each slab computes the fields of its
+    owned planes, the curl reading the exchanged halo planes; concatenated -> the reference's file bytes."""
+    import eddy_currents_3d_amd as E  # noqa: F401
+    from eddy_currents_3d_amd.dist import HipAVSlabOps, InProcessSlabs, slab_bounds
+    from eddy_currents_3d_amd.vtk import field_vtk_bytes
+    g = load_golden("g3_moving_coil_18x16x12")
+    sdz, sdy, sdx = g["geoPHYS"].shape
+    ops = []
+    for r in range(world):
+        k0, k1 = slab_bounds(sdz, r, world)
+        ops.append(HipAVSlabOps(g["geoPHYS"], g["geoPHYS_C"], g["valPHYS"], g["BND"], g["delta"], float(g["dt"]),
+                                k0, k1, world))
+    drv = InProcessSlabs(ops)
+    for k in (1, 2):
+        for o in ops:
+            o.set_vector_global("X", g[f"xout{k}"])
+            o.set_vector_global("B", g[f"b{k}"])
+        drv.post_update()
+        f = drv.vtk_fields(g["delta"], True)
+        assert field_vtk_bytes(sdx, sdy, sdz, g["delta"], f) == g[f"vtk_field_{k}"].tobytes()
+    for o in ops:
+        o.close()
