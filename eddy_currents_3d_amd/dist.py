@@ -141,6 +141,11 @@ class HipSlabOps:
     def synchronize(self):
         self.stream.synchronize()
 
+    def device_synchronize(self):
+        """Everything enqueued on the device, whatever the stream (InProcessSlabs copies between slabs on
+        the caller's current stream)."""
+        self.torch.cuda.synchronize(self.device)
+
 
 class HipAVSlabOps(HipSlabOps):
     """One z-slab of the full A-V system [Ax | Ay | Az | U] on one MI355X (ec3d_assemble_slab).
@@ -149,7 +154,7 @@ class HipAVSlabOps(HipSlabOps):
     one-sided A-U stencils of /root/reference/src/EC3D.f90:697-706 reach two cells) for each of the
     three A components, and the U unknowns of all those planes.  Rows of halo planes are inert and
     masked out of the dot products; their vector entries are overwritten by the halo exchange, which
-    moves 4 contiguous ranges per neighbour (2 planes of Ax, Ay, Az and the U cells in them)."""
+    moves 4 contiguous ranges per neighbour (the nearest plane of Ax, Ay, Az and two planes of U)."""
 
     H = 2
 
@@ -203,21 +208,23 @@ class HipAVSlabOps(HipSlabOps):
         # contiguous (send, recv) DEVICE row ranges per neighbour
         p0, p1 = k0 - e0, k1 - e0
         self._ranges = []
+        # planes exchanged per block: the 7-point stencil and the U rows read A one plane away; only the
+        # one-sided A-U stencils reach two planes, and they read U
         if self.structured:   # four grid-shaped blocks of nCd rows, `pitch` rows per plane
             nCd = self.n // 4
             pitch = nCd // (e1 - e0)
-            blocks = [(d * nCd, pitch) for d in range(4)]
+            blocks = [(d * nCd, pitch, 1 if d < 3 else H) for d in range(4)]
         else:                 # three grid-shaped blocks; the U block is compact (handled below)
-            blocks = [(d * nC, kdz) for d in range(3)]
-        if e0 < k0:   # lower neighbour exists: send my first H owned planes, receive my lower halo planes
-            for base, pl in blocks:
-                self._ranges.append((-1, (base + p0 * pl, base + (p0 + H) * pl), (base + (p0 - H) * pl, base + p0 * pl)))
+            blocks = [(d * nC, kdz, 1) for d in range(3)]
+        if e0 < k0:   # lower neighbour exists: send my first owned planes, receive my lower halo planes
+            for base, pl, h in blocks:
+                self._ranges.append((-1, (base + p0 * pl, base + (p0 + h) * pl), (base + (p0 - h) * pl, base + p0 * pl)))
             if not self.structured:
                 ulo = u_in(e0, k0)
                 self._ranges.append((-1, (3 * nC + ulo, 3 * nC + ulo + u_in(k0, k0 + H)), (3 * nC, 3 * nC + ulo)))
         if k1 < e1:   # upper neighbour
-            for base, pl in blocks:
-                self._ranges.append((+1, (base + (p1 - H) * pl, base + p1 * pl), (base + p1 * pl, base + (p1 + H) * pl)))
+            for base, pl, h in blocks:
+                self._ranges.append((+1, (base + (p1 - h) * pl, base + p1 * pl), (base + p1 * pl, base + (p1 + h) * pl)))
             if not self.structured:
                 uown_end = u_in(e0, k1)
                 self._ranges.append((+1, (3 * nC + uown_end - u_in(k1 - H, k1), 3 * nC + uown_end),
@@ -525,6 +532,11 @@ class InProcessSlabs:
     def _sync(self):
         for o in self.ops_list:
             o.synchronize()
+        # the slab-to-slab copies of _halo/_gather run on the caller's current stream, which the slabs' own
+        # (non-blocking) streams do not wait for
+        ds = getattr(self.ops_list[0], "device_synchronize", None)
+        if ds is not None:
+            ds()
 
     def solve(self, tol, itmax):
         total = max(0, itmax + 1)
