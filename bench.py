@@ -98,10 +98,12 @@ def cpu_baseline(budget_s=20.0):
     b = bar_rhs(N)
     n = N ** 3
     # calibrate on 2 iterations, then spend the budget
-    x, it, sec = O.solve_process(kind, valA, irow, jcol, b, np.zeros(n), 1e-300, 1)
+    # capture_stdout: the reference prints ||R|| on the itmax exit (src/solvers.f90:25-28); this script's
+    # stdout carries exactly one JSON line
+    x, it, sec, _ = O.solve_process(kind, valA, irow, jcol, b, np.zeros(n), 1e-300, 1, capture_stdout=True)
     per_iter = sec / max(it, 1)
     iters = int(max(4, min(200, budget_s / max(per_iter, 1e-3))))
-    x, it, sec = O.solve_process(kind, valA, irow, jcol, b, np.zeros(n), 1e-300, iters - 1)
+    x, it, sec, _ = O.solve_process(kind, valA, irow, jcol, b, np.zeros(n), 1e-300, iters - 1, capture_stdout=True)
     return {"value": n * it / sec, "unit": "DOF*iters/s", "cores": 1, "kind": kind,
             "sample": f"{N}^3 cube of the same operator/RHS (n={n}), {it} iterations of "
                       f"{'src/solvers.f90 (amdflang -O2)' if kind == 'reference' else 'oracle/ec3d_oracle.c'}"
