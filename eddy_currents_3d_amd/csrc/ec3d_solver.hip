@@ -1173,6 +1173,10 @@ extern "C" void ec3d_invalidate(void)
 extern "C" void sprsbcgstabwr_(double *valA, int32_t *irow, int32_t *jcol, int32_t *n, double *b, double *x,
                                double *tolerance, int32_t *itmax, int32_t *iter)
 {
+    if (*n <= 0) { // empty system: Bnorm = 0, the reference returns at once with iter = 0 (src/solvers.f90:13,:23)
+        *iter = 0;
+        return;
+    }
     std::lock_guard<std::mutex> lk(g_drop.mu);
     if (!g_drop.ctx) {
         int dev = 0;

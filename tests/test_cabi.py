@@ -60,3 +60,13 @@ def test_fails_loudly_without_a_device(lib):
         pytest.skip("a GPU is present")
     with pytest.raises(E.EC3DError, match="no HIP device"):
         E.EC3DSolver()
+
+
+def test_empty_system_is_answered_without_a_device(lib):
+    """n = 0: the reference computes Bnorm = 0 and returns with iter = 0 (src/solvers.f90:13, :23); the
+    drop-in symbol does the same before it touches the GPU."""
+    import numpy as np
+    import eddy_currents_3d_amd as E
+    x = np.zeros(0)
+    it = E.sprsBCGstabWR(np.zeros(0), np.ones(1, np.int32), np.zeros(0, np.int32), 0, np.zeros(0), x, 1e-8, 100)
+    assert it == 0
