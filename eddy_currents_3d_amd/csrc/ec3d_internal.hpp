@@ -159,6 +159,10 @@ struct ec3d_ctx {
     Sweep sweep_s{}; // SpMV kernels (K1, K3, residual, spmv)
     Sweep sweep_int{}, sweep_bnd{}; // z-slab: interior / boundary-plane launches of K1 and K3
     bool can_overlap = false;
+    // K2/K5 as boundary + interior launches (ec3d_dist_set_boundary_rows): tile lists on the device
+    Sweep sweep_vb{}, sweep_vi{};
+    int32_t *vb_list = nullptr, *vi_list = nullptr;
+    bool can_vsplit = false;
     int nown = 0;    // ownership ranges of an A-V slab (see Sweep)
     int64_t own_lo[4] = {0}, own_hi[4] = {0};
     bool own_vectors = true;

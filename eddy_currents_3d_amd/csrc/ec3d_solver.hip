@@ -104,6 +104,10 @@ void ec3d_free_matrix(ec3d_ctx *c)
     A = DevMatrix();
     if (c->io_tmp) (void)hipFree(c->io_tmp);
     c->io_tmp = nullptr;
+    if (c->vb_list) (void)hipFree(c->vb_list);
+    if (c->vi_list) (void)hipFree(c->vi_list);
+    c->vb_list = c->vi_list = nullptr;
+    c->can_vsplit = false;
     c->n_ref = 0;
     c->plane = c->pitch = c->nCd = 0;
     c->halo = 0;
@@ -224,7 +228,8 @@ static void choose_sweep(ec3d_ctx *c)
             c->can_overlap = true;
         }
     }
-    const int ps = std::max(sw.nblk, std::max(ss.nblk, parts));
+    // room for a vector kernel in two launches as well (boundary list <= 256 workgroups)
+    const int ps = std::max(sw.nblk + 256, std::max(ss.nblk, parts));
     sw.pstride = ss.pstride = c->sweep_int.pstride = c->sweep_bnd.pstride = ps;
 }
 
@@ -1060,6 +1065,55 @@ extern "C" int ec3d_dist_configure(ec3d_handle c, int32_t nranks, double *lsum_d
     return 0;
 }
 
+extern "C" int ec3d_dist_set_boundary_rows(ec3d_handle c, int32_t nranges, const int64_t *lo, const int64_t *hi,
+                                           int32_t *enabled)
+{
+    int rc = need_matrix(c, "ec3d_dist_set_boundary_rows");
+    if (rc) return rc;
+    if (nranges < 0 || (nranges > 0 && (!lo || !hi))) return 2;
+    if (enabled) *enabled = 0;
+    // tiles the vector kernels visit: the front sweep and the occupied U tiles of the structured form
+    const Sweep &sw = c->sweep;
+    std::vector<int32_t> visit((size_t)sw.ntiles);
+    for (int64_t t = 0; t < sw.ntiles; ++t) visit[(size_t)t] = (int32_t)t;
+    if (sw.ulist_n) {
+        std::vector<int32_t> ul((size_t)sw.ulist_n);
+        EC3D_HIP(hipMemcpy(ul.data(), sw.ulist, ul.size() * 4, hipMemcpyDeviceToHost));
+        visit.insert(visit.end(), ul.begin(), ul.end());
+    }
+    std::vector<int32_t> vb, vi;
+    for (int32_t t : visit) {
+        const int64_t r0 = (int64_t)t * EC3D_TILE, r1 = r0 + EC3D_TILE;
+        bool bnd = false;
+        for (int32_t q = 0; q < nranges && !bnd; ++q) bnd = lo[q] < r1 && hi[q] > r0;
+        (bnd ? vb : vi).push_back(t);
+    }
+    if (c->vb_list) (void)hipFree(c->vb_list);
+    if (c->vi_list) (void)hipFree(c->vi_list);
+    c->vb_list = c->vi_list = nullptr;
+    c->can_vsplit = false;
+    if (vb.empty() || vi.empty()) return 0; // nothing to split (single rank, or a slab that is all boundary)
+    EC3D_HIP(hipMalloc(&c->vb_list, vb.size() * 4));
+    EC3D_HIP(hipMalloc(&c->vi_list, vi.size() * 4));
+    EC3D_HIP(hipMemcpy(c->vb_list, vb.data(), vb.size() * 4, hipMemcpyHostToDevice));
+    EC3D_HIP(hipMemcpy(c->vi_list, vi.data(), vi.size() * 4, hipMemcpyHostToDevice));
+    auto list_sweep = [&](const int32_t *list, size_t len, int max_blk, int part_off) {
+        Sweep s = sw;
+        s.ntiles = 0; // list only
+        s.ulist = list;
+        s.ulist_n = (int)len;
+        s.nblk = (int)std::min<size_t>(len, (size_t)max_blk);
+        s.S = 0;
+        s.part_off = part_off;
+        return s;
+    };
+    c->sweep_vb = list_sweep(c->vb_list, vb.size(), 256, 0);
+    c->sweep_vi = list_sweep(c->vi_list, vi.size(), sw.nblk, c->sweep_vb.nblk);
+    c->can_vsplit = true;
+    if (enabled) *enabled = 1;
+    return 0;
+}
+
 extern "C" int ec3d_dist_step(ec3d_handle c, int32_t stage, int32_t it, double tolerance)
 {
     int rc = need_matrix(c, "ec3d_dist_step");
@@ -1109,6 +1163,29 @@ extern "C" int ec3d_dist_step(ec3d_handle c, int32_t stage, int32_t it, double t
         if (!need_split()) return 3;
         ec3d_launch_k3(A, c->sweep_bnd, c->state, it, v[EC3D_VEC_S], v[EC3D_VEC_AS], c->partials, c->stream);
         fin(true, 1u << P_D2 | 1u << P_D3, true);
+        break;
+    case EC3D_STAGE_K2_BND:
+    case EC3D_STAGE_K2_INT: {
+        if (!c->can_vsplit) {
+            ec3d_set_error("ec3d_dist_step: call ec3d_dist_set_boundary_rows first");
+            return 3;
+        }
+        const bool bnd = stage == EC3D_STAGE_K2_BND;
+        ec3d_launch_k2(bnd ? c->sweep_vb : c->sweep_vi, src_of(c, true), c->state, it, v[EC3D_VEC_R], v[EC3D_VEC_AP],
+                       v[EC3D_VEC_S], c->partials, c->stream);
+        if (!bnd)
+            ec3d_launch_finalize(RedSrc{c->partials, c->sweep_vb.nblk + c->sweep_vi.nblk, 1, c->sweep.pstride}, c->lsum,
+                                 1u << P_SS, c->stream);
+        break;
+    }
+    case EC3D_STAGE_K5_BND:
+    case EC3D_STAGE_K5_INT:
+        if (!c->can_vsplit) {
+            ec3d_set_error("ec3d_dist_step: call ec3d_dist_set_boundary_rows first");
+            return 3;
+        }
+        ec3d_launch_k5(stage == EC3D_STAGE_K5_BND ? c->sweep_vb : c->sweep_vi, src_of(c, false), c->state, it,
+                       v[EC3D_VEC_R], v[EC3D_VEC_AP], v[EC3D_VEC_P], v[EC3D_VEC_R0], c->hist, c->hist_cap, c->stream);
         break;
     default: ec3d_set_error("ec3d_dist_step: unknown stage"); return 2;
     }

@@ -22,7 +22,7 @@ from __future__ import annotations
 
 import numpy as np
 
-RESID, SETUP, K1, K2, K3, K4, K5, K1_INT, K1_BND, K3_INT, K3_BND = range(11)
+RESID, SETUP, K1, K2, K3, K4, K5, K1_INT, K1_BND, K3_INT, K3_BND, K2_BND, K2_INT, K5_BND, K5_INT = range(15)
 NSLOT = 8
 # the communication/compute schedule, shared by every driver below
 BEGIN_PLAN = (("halo", "X"), ("step", RESID), ("gather",), ("step", SETUP))
@@ -36,6 +36,21 @@ ITER_PLAN = (("halo", "P"), ("step", K1), ("gather",), ("step", K2), ("halo", "S
 ITER_PLAN_OVERLAP = (("halo_start", "P"), ("step", K1_INT), ("halo_wait", "P"), ("step", K1_BND), ("gather",),
                      ("step", K2), ("halo_start", "S"), ("step", K3_INT), ("halo_wait", "S"), ("step", K3_BND),
                      ("gather",), ("step", K4), ("gather",), ("step", K5))
+
+
+# the same idea from the producers' side, for any slab and storage format (A-V slabs): K2 (makes S) and K5
+# (makes P) run their boundary tiles first, the exchange starts, the interior tiles run while the planes
+# travel; the consumer (K3 / next K1) waits for the exchange.  P is exchanged once before the first iteration.
+BEGIN_PLAN_VSPLIT = BEGIN_PLAN + (("halo", "P"),)
+ITER_PLAN_VSPLIT = (("halo_wait", "P"), ("step", K1), ("gather",), ("step", K2_BND), ("halo_start", "S"),
+                    ("step", K2_INT), ("halo_wait", "S"), ("step", K3), ("gather",), ("step", K4), ("gather",),
+                    ("step", K5_BND), ("halo_start", "P"), ("step", K5_INT))
+
+
+def unsplit_stage(stage):
+    """A rank whose slab is all boundary runs the whole kernel where the others run *_BND and nothing where
+    they run *_INT: same order of exchanges and collectives on every rank."""
+    return {K2_BND: K2, K5_BND: K5, K2_INT: None, K5_INT: None}.get(stage, stage)
 
 
 def slab_bounds(sdz: int, rank: int, world: int):
@@ -127,6 +142,22 @@ class HipSlabOps:
     def can_overlap(self):
         return self.local.can_overlap()
 
+    def enable_vsplit(self):
+        """Tell the library which rows are sent in a halo exchange (the send views of halo_pairs), so K2/K5
+        can run boundary-first.  Returns False when there is nothing to split."""
+        b0 = self._base("P")
+        ranges = []
+        for _, send, recv in self.halo_pairs("P"):
+            # the rows sent must be final before the exchange starts; the rows RECEIVED must not be written
+            # after it (halo rows of an extended slab are swept like any other row): both go first
+            for view in (send, recv):
+                if view.numel():
+                    lo = view.storage_offset() - b0
+                    ranges.append((lo, lo + view.numel()))
+        if not ranges:
+            return False
+        return self.local.dist_set_boundary_rows(ranges)
+
     def read_state(self):
         return self.local.read_state()
 
@@ -157,6 +188,9 @@ class HipAVSlabOps(HipSlabOps):
     moves 4 contiguous ranges per neighbour (the nearest plane of Ax, Ay, Az and two planes of U)."""
 
     H = 2
+    # every rank of an A-V job uses the exchange order of ITER_PLAN_VSPLIT (a property of the job, not of
+    # the slab: ranks must agree on it)
+    producer_side_overlap = True
 
     def __init__(self, geoPHYS, geoPHYS_C, valPHYS, BND, delta, dt, k0, k1, world, device=0, dictionary=None,
                  structured=None):
@@ -305,7 +339,17 @@ class SlabSolver:
         self._pending = {}
         self.dist = None
         self.host_staged = False
-        self.iter_plan = ITER_PLAN_OVERLAP if getattr(ops, "can_overlap", lambda: False)() else ITER_PLAN
+        self.begin_plan = BEGIN_PLAN
+        self.split_ok = True
+        if getattr(ops, "can_overlap", lambda: False)():
+            self.iter_plan = ITER_PLAN_OVERLAP           # single-component slab: K1/K3 interior + boundary
+        elif world > 1 and getattr(ops, "producer_side_overlap", False):
+            # any other slab (A-V): K2/K5 boundary first.  The ORDER of exchanges is what all ranks share; a
+            # rank with nothing to split runs the whole kernels in that order (unsplit_stage)
+            self.iter_plan, self.begin_plan = ITER_PLAN_VSPLIT, BEGIN_PLAN_VSPLIT
+            self.split_ok = bool(ops.enable_vsplit())
+        else:
+            self.iter_plan = ITER_PLAN
         if world > 1:
             import torch
             import torch.distributed as dist
@@ -372,6 +416,12 @@ class SlabSolver:
         for req in self._pending.pop(name, ()):
             req.wait()
 
+    def _drain_exchanges(self):
+        """An exit leaves the exchange started by the last producer stage un-waited: join it before the
+        vectors are touched again."""
+        for name in list(self._pending):
+            self.exchange_wait(name)
+
     def gather(self):
         """gsum[g*8 + slot] <- rank g's lsum[slot]; summed in rank order inside the next kernel."""
         if self.dist is None:
@@ -392,7 +442,7 @@ class SlabSolver:
     def begin(self, tol):
         """R = B - A X, R0 = P = R, Bnorm, rr0 (src/solvers.f90:14-23)."""
         with self.ops.context():
-            self._run(BEGIN_PLAN, 0, tol, None)
+            self._run(self.begin_plan, 0, tol, None)
 
     def _run(self, plan, it, tol, timers):
         ops = self.ops
@@ -405,10 +455,14 @@ class SlabSolver:
                 self.exchange_wait(op[1])
             elif op[0] == "gather":
                 self.gather()
-            elif timers is None:
-                ops.step(op[1], it, tol)
             else:
-                timers.setdefault(op[1], []).append(ops.timed(lambda st=op[1]: ops.step(st, it, tol)))
+                stage = op[1] if self.split_ok else unsplit_stage(op[1])
+                if stage is None:
+                    continue
+                if timers is None:
+                    ops.step(stage, it, tol)
+                else:
+                    timers.setdefault(stage, []).append(ops.timed(lambda st=stage: ops.step(st, it, tol)))
 
     def iteration(self, it, timers=None):
         self._run(self.iter_plan, it, 0.0, timers)
@@ -425,7 +479,9 @@ class SlabSolver:
                     self.iteration(it)
                 stop_iter, _, _ = self.ops.read_state()
                 if stop_iter >= 0:
+                    self._drain_exchanges()
                     return stop_iter
+            self._drain_exchanges()
         stop_iter, _, _ = self.ops.read_state()
         return stop_iter if stop_iter >= 0 else total
 
@@ -467,9 +523,11 @@ class SlabSolver:
                 self.iteration(it, timers)
         if not per_kernel:
             return None
+        with self.ops.context():
+            self._drain_exchanges()
         self.ops.synchronize()
         names = {K1: "k1", K2: "k2", K3: "k3", K4: "k4", K5: "k5", K1_INT: "k1", K1_BND: "k1", K3_INT: "k3",
-                 K3_BND: "k3"}
+                 K3_BND: "k3", K2_BND: "k2", K2_INT: "k2", K5_BND: "k5", K5_INT: "k5"}
         out = {}
         for st, ts in timers.items():  # split launches add up to the kernel they stand for
             out[names[st]] = out.get(names[st], 0.0) + float(np.mean([t() for t in ts]))
@@ -491,11 +549,16 @@ class InProcessSlabs:
     halo planes are copied tensor to tensor and the per-slab sums concatenated, so the slab kernels,
     the ghost-plane layout and the rank-ordered reduction can be validated without a second GPU."""
 
-    def __init__(self, ops_list, overlap=None):
+    def __init__(self, ops_list, overlap=None, vsplit=False):
         self.ops_list = ops_list
         self.world = len(ops_list)
         can = all(getattr(o, "can_overlap", lambda: False)() for o in ops_list)
+        self.begin_plan = BEGIN_PLAN
         self.iter_plan = ITER_PLAN_OVERLAP if (can if overlap is None else overlap) else ITER_PLAN
+        self.split_ok = [True] * self.world
+        if vsplit:  # K2/K5 boundary-first (what SlabSolver picks for A-V slabs)
+            self.split_ok = [bool(o.enable_vsplit()) for o in ops_list]
+            self.iter_plan, self.begin_plan = ITER_PLAN_VSPLIT, BEGIN_PLAN_VSPLIT
 
     def _halo(self, name):
         pairs = [o.halo_pairs(name) for o in self.ops_list]
@@ -525,9 +588,12 @@ class InProcessSlabs:
                 self._gather()
                 self._sync()
             else:
-                for o in self.ops_list:
+                for o, ok in zip(self.ops_list, self.split_ok):
+                    stage = op[1] if ok else unsplit_stage(op[1])
+                    if stage is None:
+                        continue
                     with o.context():
-                        o.step(op[1], it, tol)
+                        o.step(stage, it, tol)
 
     def _sync(self):
         for o in self.ops_list:
@@ -540,7 +606,7 @@ class InProcessSlabs:
 
     def solve(self, tol, itmax):
         total = max(0, itmax + 1)
-        self._run(BEGIN_PLAN, 0, tol)
+        self._run(self.begin_plan, 0, tol)
         for it in range(1, total + 1):
             self._run(self.iter_plan, it, 0.0)
             states = [o.read_state()[0] for o in self.ops_list]

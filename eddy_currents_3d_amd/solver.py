@@ -56,7 +56,7 @@ EXPORTS = ["sprsbcgstabwr_", "ec3d_invalidate", "ec3d_create", "ec3d_destroy", "
            "ec3d_set_workgroups", "ec3d_get_matrix_info", "ec3d_time_kernel", "ec3d_time_iterations",
            "ec3d_iterate_begin", "ec3d_iterate", "ec3d_set_format", "ec3d_set_stream",
            "ec3d_assemble_poisson_slab", "ec3d_vector_layout", "ec3d_adopt_vectors",
-           "ec3d_dist_configure", "ec3d_dist_step", "ec3d_read_state", "ec3d_set_zmarch", "ec3d_can_overlap",
+           "ec3d_dist_configure", "ec3d_dist_step", "ec3d_dist_set_boundary_rows", "ec3d_read_state", "ec3d_set_zmarch", "ec3d_can_overlap",
            "ec3d_rhs_step", "ec3d_post_update", "ec3d_assemble_slab", "ec3d_vtk_fields",
            "ec3d_set_structured", "ec3d_get_row_map", "ec3d_get_ulist", "ec3d_probe_csr",
            "ec3d_device_synchronize"]
@@ -135,6 +135,9 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.ec3d_set_format.argtypes = [hp, C.c_int]
     L.ec3d_set_structured.argtypes = [hp, C.c_int]
     L.ec3d_get_row_map.argtypes = [hp, _i32]
+    L.ec3d_dist_set_boundary_rows.argtypes = [hp, C.c_int32, np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS"),
+                                              np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS"),
+                                              C.POINTER(C.c_int32)]
     L.ec3d_probe_csr.argtypes = [C.c_int32, _f64, _i32, _i32, C.POINTER(CsrProbe)]
     L.ec3d_get_ulist.argtypes = [hp, _i32]
     L.ec3d_set_stream.argtypes = [hp, hp]
@@ -424,6 +427,15 @@ class EC3DSolver:
 
     def dist_step(self, stage: int, it: int = 0, tol: float = 0.0):
         _chk(self.L, self.L.ec3d_dist_step(self.h, stage, it, float(tol)), "ec3d_dist_step")
+
+    def dist_set_boundary_rows(self, ranges):
+        """ranges: [(lo, hi)] device rows this rank sends in a halo exchange; enables the K2/K5 split stages."""
+        lo = np.ascontiguousarray([r[0] for r in ranges] or [0], np.int64)
+        hi = np.ascontiguousarray([r[1] for r in ranges] or [0], np.int64)
+        on = C.c_int32(0)
+        _chk(self.L, self.L.ec3d_dist_set_boundary_rows(self.h, len(ranges), lo, hi, C.byref(on)),
+             "ec3d_dist_set_boundary_rows")
+        return bool(on.value)
 
     def can_overlap(self) -> bool:
         return bool(self.L.ec3d_can_overlap(self.h))

@@ -170,8 +170,20 @@ enum { EC3D_STAGE_RESID = 0, /* R = B - A X, R0 = P = R; lsum <- B.B, R.R      s
        /* K1 and K3 in two launches, so the halo exchange of P / S overlaps the first one:
         * *_INT = owned planes 1 .. np-2 (need no halo), *_BND = planes 0 and np-1 (after the exchange;
         * also collapses both launches' partials into lsum).  Only when ec3d_can_overlap(). */
-       EC3D_STAGE_K1_INT = 7, EC3D_STAGE_K1_BND = 8, EC3D_STAGE_K3_INT = 9, EC3D_STAGE_K3_BND = 10 };
+       EC3D_STAGE_K1_INT = 7, EC3D_STAGE_K1_BND = 8, EC3D_STAGE_K3_INT = 9, EC3D_STAGE_K3_BND = 10,
+       /* The other way to hide the exchange, for any slab and storage format: the PRODUCERS of the
+        * exchanged vectors run in two launches -- *_BND first (the tiles holding the rows the neighbours
+        * receive, ec3d_dist_set_boundary_rows), then the exchange starts, then *_INT (everything else)
+        * while the planes travel.  K2 produces S (K2_INT also collapses both launches' S.S partials),
+        * K5 produces P. */
+       EC3D_STAGE_K2_BND = 11, EC3D_STAGE_K2_INT = 12, EC3D_STAGE_K5_BND = 13, EC3D_STAGE_K5_INT = 14 };
 int ec3d_dist_step(ec3d_handle h, int32_t stage, int32_t it, double tolerance);
+/* Device-row ranges [lo, hi) this rank sends AND receives in a halo exchange (the first/last owned planes
+ * of every block; the halo rows of an extended slab, which the interior launch must not overwrite once
+ * the exchange has started); *enabled = 1 when the K2/K5 boundary/interior stages can be used (0: no range given, or every
+ * tile touches a boundary). */
+int ec3d_dist_set_boundary_rows(ec3d_handle h, int32_t nranges, const int64_t *lo, const int64_t *hi,
+                                int32_t *enabled);
 /* 1 when the slab held can run K1/K3 split into interior + boundary launches (single-component slab
  * on a grid whose xy-plane is a whole number of 512-row tiles, at least 10 planes) */
 int ec3d_can_overlap(ec3d_handle h);

@@ -190,7 +190,8 @@ def test_zmarch_slabs_on_one_gpu(E, oracle):
 @pytest.mark.parametrize("name,world", [("g2_conducting_hole_16x15x14", 2), ("g2_conducting_hole_16x15x14", 3),
                                         ("g3_moving_coil_18x16x12", 2), ("g2v_conducting_moving_16x15x14", 4)])
 @pytest.mark.parametrize("structured", [True, False])
-def test_av_slabs_on_one_gpu_match_reference(E, name, world, structured, plane_pitch):
+@pytest.mark.parametrize("vsplit", [False, True])
+def test_av_slabs_on_one_gpu_match_reference(E, name, world, structured, plane_pitch, vsplit):
     """The full A-V system [Ax|Ay|Az|U] cut into z-slabs (extended grid: 2 halo planes per side, inert halo
     rows, ownership-masked dot products), all slabs held by one process on one GPU; the cuts go through
     the conductor.  Against the unmodified reference's solution of the same captured system."""
@@ -209,7 +210,7 @@ def test_av_slabs_on_one_gpu_match_reference(E, name, world, structured, plane_p
             o.set_vector_global("B", g[f"b{k}"])
             o.set_vector_global("X", g[f"xin{k}"])
             ops.append(o)
-        drv = InProcessSlabs(ops)
+        drv = InProcessSlabs(ops, vsplit=vsplit)   # vsplit: K2/K5 boundary tiles first (exchange hidden)
         it = drv.solve(tol, itmax)
         x = drv.x(n)
         xr = g[f"xout{k}"]
