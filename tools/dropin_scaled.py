@@ -18,6 +18,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("case"); ap.add_argument("fx", type=int); ap.add_argument("fy", type=int); ap.add_argument("fz", type=int)
 ap.add_argument("steps", type=int)
 ap.add_argument("--reference", action="store_true"); ap.add_argument("--ref-steps", type=int, default=1)
+ap.add_argument("--compare", action="store_true",
+                help="with --reference: capture every call's x on both sides and print the relative difference")
 a = ap.parse_args()
 
 from eddy_currents_3d_amd import vxc
@@ -32,7 +34,18 @@ sdz, sdy, sdx = vox.shape
 print(f"{a.case} x({a.fx},{a.fy},{a.fz}): grid {sdx}x{sdy}x{sdz} = {vox.size} cells", flush=True)
 
 
-def run(exe, steps, env_extra):
+def read_x(cap_dir):
+    """x_out of every captured call (layout: oracle/capture_interposer.c)."""
+    xs = []
+    for fn in sorted(os.listdir(cap_dir)):
+        with open(os.path.join(cap_dir, fn), "rb") as f:
+            n, nnz, itmax, it = np.fromfile(f, np.int64, 4)
+            f.seek(16 + 4 * (n + 1) + (12 * nnz if nnz else 0) + 8 * 2 * n, 1)
+            xs.append(np.fromfile(f, np.float64, n))
+    return xs
+
+
+def run(exe, steps, env_extra, capture=False):
     t0 = time.time()
     td = tempfile.mkdtemp(prefix="ec3d_dropin_")
     vxc.write_vxc(os.path.join(td, "in.vxc"), model, compression="ASCII_READABLE")
@@ -41,10 +54,16 @@ def run(exe, steps, env_extra):
     os.chmod(os.path.join(td, "del"), 0o755)
     env = dict(os.environ, PATH=td + ":" + os.environ["PATH"], EC3D_CAPTURE_MAX_CALLS=str(steps), **env_extra)
     env.pop("EC3D_CAPTURE_DIR", None)
+    if capture:
+        env["EC3D_CAPTURE_DIR"] = os.path.join(td, "cap")
+        os.mkdir(env["EC3D_CAPTURE_DIR"])
     p = subprocess.run([exe], cwd=td, env=env, preexec_fn=O._unlimit_stack, stdout=subprocess.DEVNULL,
                        stderr=subprocess.PIPE)
     calls = re.findall(r"\[capture\] call (\d+) n=(\d+) nnz=(\d+) iter=(\d+) t=([\d.]+)s", p.stderr.decode())
+    xs = read_x(env["EC3D_CAPTURE_DIR"]) if capture else None
     subprocess.run(["rm", "-rf", td])
+    if capture:
+        return calls, time.time() - t0, p.stderr.decode()[-500:], xs
     return calls, time.time() - t0, p.stderr.decode()[-500:]
 
 
@@ -59,7 +78,15 @@ print(f"              solve call s/step={['%.3f' % t for t in ts]}  (first inclu
 print(f"              whole program wall {wall:.1f} s (ingest + reference assembly + {len(calls)} steps)")
 rate = [n * i / t for i, t in zip(its[1:], ts[1:])] or [n * its[0] / ts[0]]
 print(f"              DOF*iters/s per call incl. H2D/D2H: {np.mean(rate):.3e}")
-if a.reference:
+if a.reference and a.compare:
+    k = a.ref_steps
+    gc, _, _, gx = run(os.path.join(REPO, "oracle", "_ref", "EC3D_dropin"), k, {"EC3D_HIP_LIB": lib}, capture=True)
+    rc, wall, err, rx = run(os.path.join(REPO, "oracle", "_ref", "EC3D_capture"), k, {}, capture=True)
+    for q in range(min(len(gx), len(rx))):
+        rel = np.linalg.norm(gx[q] - rx[q]) / np.linalg.norm(rx[q])
+        print(f"step {q}: iter gpu {gc[q][3]} / reference {rc[q][3]}  ||x_gpu - x_ref|| / ||x_ref|| = {rel:.3e}"
+              f"  (reference solve {float(rc[q][4]):.1f} s on one core, gpu call {float(gc[q][4]):.3f} s)")
+elif a.reference:
     calls, wall, err = run(os.path.join(REPO, "oracle", "_ref", "EC3D_capture"), a.ref_steps, {})
     its = [int(c[3]) for c in calls]; ts = [float(c[4]) for c in calls]
     print(f"CPU reference: steps={len(calls)} iters={its} solve s/step={['%.2f' % t for t in ts]} "
