@@ -18,6 +18,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("case"); ap.add_argument("fx", type=int); ap.add_argument("fy", type=int); ap.add_argument("fz", type=int)
 ap.add_argument("steps", type=int)
 ap.add_argument("--reference", action="store_true"); ap.add_argument("--ref-steps", type=int, default=1)
+ap.add_argument("--tol", default=None, help="override the input's solver tolerance, e.g. 1e-8 (palette 'solver tol=')")
 ap.add_argument("--compare", action="store_true",
                 help="with --reference: capture every call's x on both sides and print the relative difference")
 a = ap.parse_args()
@@ -27,6 +28,8 @@ g = np.load(os.path.join(REPO, "tests", "golden", f"g4_{a.case}.npz"))
 # no VTK output during the timed run: JUMP beyond the stop time (src/vxc2data.f90:191-195, EC3D.f90:143-144)
 names = [re.sub(r"(tran\b.*)", r"\1 jump=1000", str(s), flags=re.I) if re.search(r"\btran\b", str(s), re.I)
          else str(s) for s in g["names"]]
+if a.tol:
+    names = [re.sub(r"\btol=\S+", "tol=" + a.tol, n) if re.search(r"\bsolver\b", n, re.I) else n for n in names]
 base = vxc.VxcModel(g["vox"], names, float(str(g["lattice_dim"])), tuple(float(x) for x in g["adj"]))
 model = vxc.refine(base, a.fx, a.fy, a.fz)   # keeps the physical size: cell size / factor per axis
 vox = model.vox
@@ -57,8 +60,16 @@ def run(exe, steps, env_extra, capture=False):
     if capture:
         env["EC3D_CAPTURE_DIR"] = os.path.join(td, "cap")
         os.mkdir(env["EC3D_CAPTURE_DIR"])
+    import threading
+    done = threading.Event()
+
+    def heartbeat():  # long CPU runs must not look hung to the job runner
+        while not done.wait(60.0):
+            print(f"  ... {os.path.basename(exe)} running, {time.time() - t0:.0f} s", flush=True)
+    threading.Thread(target=heartbeat, daemon=True).start()
     p = subprocess.run([exe], cwd=td, env=env, preexec_fn=O._unlimit_stack, stdout=subprocess.DEVNULL,
                        stderr=subprocess.PIPE)
+    done.set()
     calls = re.findall(r"\[capture\] call (\d+) n=(\d+) nnz=(\d+) iter=(\d+) t=([\d.]+)s", p.stderr.decode())
     xs = read_x(env["EC3D_CAPTURE_DIR"]) if capture else None
     subprocess.run(["rm", "-rf", td])
