@@ -141,6 +141,13 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
 
+    # This script's stdout carries exactly one JSON line.  Native libraries write there too (RCCL prints its
+    # version banner when the box exports NCCL_DEBUG=VERSION; the reference solver prints ||R|| on the itmax
+    # exit), so file descriptor 1 is pointed at stderr for the whole run and the line goes to the saved one.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch  # first: the library then shares torch's HIP runtime
     import torch.distributed as dist
 
@@ -280,7 +287,8 @@ def main():
             except Exception as e:  # the baseline is reporting only; never fail the GPU number on it
                 out["cpu_baseline"] = {"value": None, "unit": "DOF*iters/s", "cores": 1, "kind": "port",
                                        "sample": f"failed: {e!r}"}
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
