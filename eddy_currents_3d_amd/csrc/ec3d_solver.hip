@@ -1195,6 +1195,14 @@ extern "C" int ec3d_dist_step(ec3d_handle c, int32_t stage, int32_t it, double t
 
 extern "C" int ec3d_can_overlap(ec3d_handle c) { return c && c->have_matrix && c->can_overlap ? 1 : 0; }
 
+extern "C" int ec3d_read_state_async(ec3d_handle c, int32_t *stop_iter_pinned)
+{
+    if (!c || !c->state || !stop_iter_pinned) return 2;
+    EC3D_HIP(hipSetDevice(c->device));
+    EC3D_HIP(hipMemcpyAsync(stop_iter_pinned, &c->state->stop_iter, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    return 0;
+}
+
 // synchronous read of the device-resident solver state (stream is drained first)
 extern "C" int ec3d_read_state(ec3d_handle c, int32_t *stop_iter, int32_t *stop_kind, double *bnorm)
 {

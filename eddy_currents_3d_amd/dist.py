@@ -161,6 +161,25 @@ class HipSlabOps:
     def read_state(self):
         return self.local.read_state()
 
+    def stop_flag_probe(self):
+        """Non-blocking look at the stop flag: enqueue a copy into pinned memory behind the work issued so
+        far; returns a function that waits for that copy only and gives the flag (-1 = still running)."""
+        torch = self.torch
+        if not hasattr(self, "_pin"):
+            self._pin = torch.zeros(2, dtype=torch.int32).pin_memory()
+            self._pin_ev = [torch.cuda.Event(), torch.cuda.Event()]
+            self._pin_i = 0
+        i = self._pin_i & 1
+        self._pin_i += 1
+        self.local.read_state_async(self._pin.data_ptr() + 4 * i)
+        self._pin_ev[i].record(self.stream)
+
+        def result():
+            self._pin_ev[i].synchronize()
+            v = int(self._pin[i])
+            return -1 if v == 2147483647 else v
+        return result
+
     def timed(self, fn):
         """Run fn() on the stream between two events; returns a closure giving ms after a sync."""
         e0, e1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
@@ -472,15 +491,23 @@ class SlabSolver:
         total = max(0, itmax + 1)                      # src/solvers.f90:25-29
         self.begin(tol)
         it = 0
+        probe = getattr(self.ops, "stop_flag_probe", None)
         with self.ops.context():
+            pending = None   # look at chunk c-1 only after chunk c is enqueued: the GPU never waits for the host
             while it < total:
                 for _ in range(min(poll, total - it)):
                     it += 1
                     self.iteration(it)
-                stop_iter, _, _ = self.ops.read_state()
+                if probe is None:
+                    stop_iter = self.ops.read_state()[0]
+                else:
+                    pending, prev = probe(), pending
+                    stop_iter = prev() if prev is not None else -1
+                # every rank sees the same flag at the same chunk (the exit decision is computed from the
+                # same gathered sums everywhere), so all ranks leave the loop together; iterations enqueued
+                # past the exit return at once and touch nothing
                 if stop_iter >= 0:
-                    self._drain_exchanges()
-                    return stop_iter
+                    break
             self._drain_exchanges()
         stop_iter, _, _ = self.ops.read_state()
         return stop_iter if stop_iter >= 0 else total

@@ -56,7 +56,7 @@ EXPORTS = ["sprsbcgstabwr_", "ec3d_invalidate", "ec3d_create", "ec3d_destroy", "
            "ec3d_set_workgroups", "ec3d_get_matrix_info", "ec3d_time_kernel", "ec3d_time_iterations",
            "ec3d_iterate_begin", "ec3d_iterate", "ec3d_set_format", "ec3d_set_stream",
            "ec3d_assemble_poisson_slab", "ec3d_vector_layout", "ec3d_adopt_vectors",
-           "ec3d_dist_configure", "ec3d_dist_step", "ec3d_dist_set_boundary_rows", "ec3d_read_state", "ec3d_set_zmarch", "ec3d_can_overlap",
+           "ec3d_dist_configure", "ec3d_dist_step", "ec3d_dist_set_boundary_rows", "ec3d_read_state_async", "ec3d_read_state", "ec3d_set_zmarch", "ec3d_can_overlap",
            "ec3d_rhs_step", "ec3d_post_update", "ec3d_assemble_slab", "ec3d_vtk_fields",
            "ec3d_set_structured", "ec3d_get_row_map", "ec3d_get_ulist", "ec3d_probe_csr",
            "ec3d_device_synchronize"]
@@ -146,6 +146,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.ec3d_adopt_vectors.argtypes = [hp, hp]
     L.ec3d_dist_configure.argtypes = [hp, C.c_int32, hp, hp]
     L.ec3d_dist_step.argtypes = [hp, C.c_int32, C.c_int32, C.c_double]
+    L.ec3d_read_state_async.argtypes = [hp, C.c_void_p]
     L.ec3d_read_state.argtypes = [hp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double)]
     L.sprsbcgstabwr_.argtypes = [_f64, _i32, _i32, C.POINTER(C.c_int32), _f64, _f64,
                                  C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
@@ -439,6 +440,10 @@ class EC3DSolver:
 
     def can_overlap(self) -> bool:
         return bool(self.L.ec3d_can_overlap(self.h))
+
+    def read_state_async(self, pinned_int32_ptr: int):
+        """Enqueue a copy of the stop flag into pinned host memory (see include/ec3d_hip.h)."""
+        _chk(self.L, self.L.ec3d_read_state_async(self.h, C.c_void_p(pinned_int32_ptr)), "ec3d_read_state_async")
 
     def read_state(self):
         si, sk, bn = C.c_int32(0), C.c_int32(0), C.c_double(0)

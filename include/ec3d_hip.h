@@ -187,6 +187,11 @@ int ec3d_dist_set_boundary_rows(ec3d_handle h, int32_t nranges, const int64_t *l
 /* 1 when the slab held can run K1/K3 split into interior + boundary launches (single-component slab
  * on a grid whose xy-plane is a whole number of 512-row tiles, at least 10 planes) */
 int ec3d_can_overlap(ec3d_handle h);
+/* Without draining: enqueue, on the handle's stream, a copy of the stop flag into PINNED host memory
+ * (2147483647 while running, else the iteration at which an exit was taken); the caller records an event
+ * behind it and reads the value once the event has completed -- lets a multi-rank driver keep a chunk of
+ * iterations in flight while it looks at the previous one (as ec3d_solve does on a single device). */
+int ec3d_read_state_async(ec3d_handle h, int32_t *stop_iter_pinned);
 /* drain the stream and read the device-resident state; stop_iter = -1 while still running */
 int ec3d_read_state(ec3d_handle h, int32_t *stop_iter, int32_t *stop_kind, double *bnorm);
 
