@@ -5,6 +5,9 @@ its own .vxc ingest, assembly, coil motion, RHS build, time loop) with every sol
 (BASELINE config 3 style).  With --reference the same input is also run through the pure reference
 (oracle/_ref/EC3D_capture) for `--ref-steps` steps to time the CPU solver on the same box.
 
+Lives under tests/ because it runs the reference's own binaries (oracle/_ref): checker infrastructure, not
+product.  Not collected by pytest (run it by hand on the GPU box).
+
 usage: dropin_scaled.py <compare_to_Elmer|ec_src_move_hole|LIM> fx fy fz steps [--reference --ref-steps K]
 """
 import argparse, os, re, subprocess, sys, tempfile, time
