@@ -8,8 +8,8 @@ import contextlib
 import numpy as np
 import torch
 
-from eddy_currents_3d_amd.dist import (K1, K1_BND, K1_INT, K2, K3, K3_BND, K3_INT, K4, K5, NSLOT, RESID,
-                                       SETUP)
+from eddy_currents_3d_amd.dist import (K1, K1_BND, K1_INT, K2, K2_BND, K2_INT, K3, K3_BND, K3_INT, K4, K5, K5_BND,
+                                       K5_INT, NSLOT, RESID, SETUP)
 
 BB, RR_INIT, D1, SS, D2, D3, RR, RR0N = range(8)
 VEC = dict(X=0, B=1, R=2, R0=3, P=4, AP=5, S=6, AS=7)
@@ -34,6 +34,8 @@ class NumpySlabOps:
         self.gsum = torch.zeros(world * NSLOT, dtype=torch.float64)
         self.world = world
         self.overlap = True
+        self.producer_side_overlap = False   # True: the A-V slabs' exchange order (ITER_PLAN_VSPLIT)
+        self._ss_bnd = 0.0
         self.st = dict(stop_iter=-1, stop_kind=0, rr0=[0.0, 0.0], alpha=0.0, omega=0.0, bnorm=0.0, tol=0.0)
 
     def context(self):
@@ -81,6 +83,16 @@ class NumpySlabOps:
     def can_overlap(self):
         return self.overlap and self.n >= 4 * self.kdz
 
+    def enable_vsplit(self):
+        """K2/K5 boundary rows (first and last plane) first; False when there is no interior row."""
+        return self.n > 2 * self.kdz
+
+    def _rows(self, boundary):
+        m = np.zeros(self.n, bool)
+        m[:self.kdz] = True
+        m[self.n - self.kdz:] = True
+        return m if boundary else ~m
+
     def _split(self, src, dst, interior):
         """rows of planes 1 .. np-2 (interior) or planes 0 and np-1 of dst = A * src, with the halos as
         they are at this moment"""
@@ -127,6 +139,30 @@ class NumpySlabOps:
             s = self._own("R") - st["alpha"] * self._own("AP")
             self._own("S")[:] = s
             L[SS] = float(s @ s)
+        elif stage in (K2_BND, K2_INT):
+            if stopped_before: return
+            st["alpha"] = st["rr0"][it & 1] / self._g(D1)
+            m = self._rows(stage == K2_BND)
+            s = self._own("R")[m] - st["alpha"] * self._own("AP")[m]
+            self._own("S")[m] = s
+            if stage == K2_BND:
+                self._ss_bnd = float(s @ s)
+            else:
+                L[SS] = self._ss_bnd + float(s @ s)
+        elif stage in (K5_BND, K5_INT):
+            if stopped_now: return
+            rr, rr0n = self._g(RR), self._g(RR0N)
+            if np.sqrt(rr) / st["bnorm"] < st["tol"]:
+                st["stop_kind"], st["stop_iter"] = 2, it
+                return
+            beta = (st["alpha"] / st["omega"]) * rr0n / st["rr0"][it & 1]
+            restart = abs(rr0n) / st["bnorm"] < st["tol"]
+            st["rr0"][(it + 1) & 1] = rr if restart else rr0n
+            m = self._rows(stage == K5_BND)
+            if restart:
+                self._own("R0")[m] = self._own("R")[m]; self._own("P")[m] = self._own("R")[m]
+            else:
+                self._own("P")[m] = self._own("R")[m] + beta * (self._own("P")[m] - st["omega"] * self._own("AP")[m])
         elif stage == K3:
             if stopped_before: return
             a = self._spmv("S")

@@ -20,7 +20,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, producer_side=False):
     import sys
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, "tests"))
@@ -34,7 +34,13 @@ def _worker(rank, world, port, out):
     try:
         k0, k1 = slab_bounds(N, rank, world)
         ops = NumpySlabOps(O, N, N, N, k0, k1, world)
+        ops.producer_side_overlap = producer_side
+        if producer_side:
+            ops.overlap = False
         s = SlabSolver(ops, rank, world, k0, k1)
+        if producer_side:
+            from eddy_currents_3d_amd.dist import ITER_PLAN_VSPLIT
+            assert s.iter_plan is ITER_PLAN_VSPLIT
         b = O.bar_rhs(N).reshape(N, N * N)[k0:k1].reshape(-1)
         s.set_rhs(b, np.zeros(s.n_local))
         it = s.solve(TOL, 10000, poll=4)
@@ -46,9 +52,12 @@ def _worker(rank, world, port, out):
 
 
 @pytest.mark.parametrize("world", [2, 3])
-def test_slab_solver_over_gloo_matches_serial_oracle(oracle, tmp_path, world):
+@pytest.mark.parametrize("producer_side", [False, True])
+def test_slab_solver_over_gloo_matches_serial_oracle(oracle, tmp_path, world, producer_side):
+    """producer_side: the A-V slabs' schedule (K2/K5 boundary rows first, asynchronous send/recv started
+    behind them and joined before the consumer) over real processes and real non-blocking transfers."""
     out = str(tmp_path / "x.npy")
-    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out, producer_side), nprocs=world, join=True)
     res = np.load(out)
     it, x = int(res[0]), res[1:]
     valA, irow, jcol = oracle.poisson_csr(N, N, N)
