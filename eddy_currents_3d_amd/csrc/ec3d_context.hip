@@ -1,9 +1,5 @@
-// ec3d_solver.hip — context, device memory, the solve loop and the C ABI (include/ec3d_hip.h).
-//
-// Host side of src/solvers.f90:3-50.  The loop body is five asynchronous launches per iteration
-// (ec3d_kernels.hip); all scalars and the convergence decision stay on the device.  The host runs
-// ahead by up to two chunks of iterations and learns about an exit from an asynchronous copy of the
-// SolverState; launches issued past the exit are no-ops, so the result is exactly the reference's.
+// ec3d_context.hip — the handle: device memory, launch geometry, matrix upload/export, host<->device vector
+// copies, and the option / introspection entry points of the C ABI (include/ec3d_hip.h).
 #include "../../include/ec3d_hip.h"
 #include "ec3d_internal.hpp"
 
@@ -356,7 +352,7 @@ int ec3d_download_matrix(ec3d_ctx *c, HostMatrix &M)
     return 0;
 }
 
-static int need_matrix(ec3d_ctx *c, const char *who)
+int ec3d_need_matrix(ec3d_ctx *c, const char *who)
 {
     if (!c || !c->have_matrix) {
         ec3d_set_error(std::string(who) + ": no matrix (call ec3d_set_matrix_csr / ec3d_assemble first)");
@@ -573,7 +569,7 @@ static int sav_to_csr(ec3d_ctx *c, std::vector<int32_t> &irow, std::vector<int32
 extern "C" int ec3d_export_csr(ec3d_handle c, int32_t *n, int64_t *nnz, int32_t *irow, int32_t *jcol,
                                double *valA)
 {
-    int rc = need_matrix(c, "ec3d_export_csr");
+    int rc = ec3d_need_matrix(c, "ec3d_export_csr");
     if (rc) return rc;
     std::vector<int32_t> ir, jc;
     std::vector<double> va;
@@ -602,7 +598,7 @@ extern "C" int ec3d_get_cel_bnd(ec3d_handle c, int which, int32_t *count, int32_
 
 extern "C" int ec3d_get_reduction_geometry(ec3d_handle c, int which, ec3d_geom *g)
 {
-    int rc = need_matrix(c, "ec3d_get_reduction_geometry");
+    int rc = ec3d_need_matrix(c, "ec3d_get_reduction_geometry");
     if (rc) return rc;
     const Sweep &sw = which == 1 ? c->sweep_s : c->sweep;
     g->n_pad = (int32_t)c->A.n_pad;
@@ -619,7 +615,7 @@ extern "C" int ec3d_get_reduction_geometry(ec3d_handle c, int which, ec3d_geom *
 
 extern "C" int ec3d_get_ulist(ec3d_handle c, int32_t *tiles)
 {
-    int rc = need_matrix(c, "ec3d_get_ulist");
+    int rc = ec3d_need_matrix(c, "ec3d_get_ulist");
     if (rc) return rc;
     if (c->A.ulist_n) EC3D_HIP(hipMemcpy(tiles, c->A.ulist, (size_t)c->A.ulist_n * 4, hipMemcpyDeviceToHost));
     return 0;
@@ -634,7 +630,7 @@ extern "C" int ec3d_set_zmarch(ec3d_handle c, int on)
 
 extern "C" int ec3d_get_matrix_info(ec3d_handle c, ec3d_matrix_info *info)
 {
-    int rc = need_matrix(c, "ec3d_get_matrix_info");
+    int rc = ec3d_need_matrix(c, "ec3d_get_matrix_info");
     if (rc) return rc;
     memset(info, 0, sizeof *info);
     info->n = c->n_ref;
@@ -710,7 +706,7 @@ int ec3d_vec_d2h(ec3d_ctx *c, double *host, const double *dev)
 // tests: device row of every reference unknown
 extern "C" int ec3d_get_row_map(ec3d_handle c, int32_t *ref_to_dev)
 {
-    int rc = need_matrix(c, "ec3d_get_row_map");
+    int rc = ec3d_need_matrix(c, "ec3d_get_row_map");
     if (rc) return rc;
     if (!c->A.sav) {
         for (int64_t i = 0; i < c->A.n; ++i) ref_to_dev[i] = (int32_t)i;
@@ -727,7 +723,7 @@ extern "C" int ec3d_get_row_map(ec3d_handle c, int32_t *ref_to_dev)
 
 extern "C" int ec3d_upload(ec3d_handle c, int which, const double *host)
 {
-    int rc = need_matrix(c, "ec3d_upload");
+    int rc = ec3d_need_matrix(c, "ec3d_upload");
     if (rc) return rc;
     if (which < 0 || which >= EC3D_NVEC) return 2;
     if ((rc = ec3d_vec_h2d(c, c->vec[which], host))) return rc;
@@ -737,7 +733,7 @@ extern "C" int ec3d_upload(ec3d_handle c, int which, const double *host)
 
 extern "C" int ec3d_download(ec3d_handle c, int which, double *host)
 {
-    int rc = need_matrix(c, "ec3d_download");
+    int rc = ec3d_need_matrix(c, "ec3d_download");
     if (rc) return rc;
     if (which < 0 || which >= EC3D_NVEC) return 2;
     if ((rc = ec3d_vec_d2h(c, host, c->vec[which]))) return rc;
@@ -747,7 +743,7 @@ extern "C" int ec3d_download(ec3d_handle c, int which, double *host)
 
 extern "C" int ec3d_device_vector(ec3d_handle c, int which, double **device_ptr, int64_t *n)
 {
-    int rc = need_matrix(c, "ec3d_device_vector");
+    int rc = ec3d_need_matrix(c, "ec3d_device_vector");
     if (rc) return rc;
     if (which < 0 || which >= EC3D_NVEC) return 2;
     *device_ptr = c->vec[which];
@@ -764,7 +760,7 @@ extern "C" int ec3d_device_synchronize(ec3d_handle c)
 
 extern "C" int ec3d_spmv(ec3d_handle c, const double *x, double *y)
 {
-    int rc = need_matrix(c, "ec3d_spmv");
+    int rc = ec3d_need_matrix(c, "ec3d_spmv");
     if (rc) return rc;
     // P and AP serve as scratch
     if ((rc = ec3d_vec_h2d(c, c->vec[EC3D_VEC_P], x))) return rc;
@@ -775,510 +771,3 @@ extern "C" int ec3d_spmv(ec3d_handle c, const double *x, double *y)
     return 0;
 }
 
-// ---------------------------------------------------------------------------------------------
-// Where a consumer finds the sums it needs.  Single GPU: the producer's per-workgroup partials; the
-// producers of slots BB, RR_INIT, D1, D2, D3 are SpMV-type kernels (sweep_s), those of SS, RR, RR0N
-// vector kernels (sweep) -- every consumer reads slots of one producer class only.
-static RedSrc src_of(const ec3d_ctx *c, bool produced_by_spmv)
-{
-    if (c->dist) return RedSrc{c->gsum, c->nranks, P_NSLOT, 1};
-    return RedSrc{c->partials, produced_by_spmv ? c->sweep_s.nblk : c->sweep.nblk, 1, c->sweep.pstride};
-}
-static RedSrc part_of(const ec3d_ctx *c, bool produced_by_spmv, bool split = false)
-{
-    const int cnt = !produced_by_spmv ? c->sweep.nblk
-                    : split           ? c->sweep_int.nblk + c->sweep_bnd.nblk
-                                      : c->sweep_s.nblk;
-    return RedSrc{c->partials, cnt, 1, c->sweep.pstride};
-}
-
-// the five launches of one iteration; `k` selects one of them (1..5) or all (0)
-static void launch_stage(ec3d_ctx *c, const MatView &A, int it, int k)
-{
-    double **v = c->vec;
-    const Sweep &sw = c->sweep, &ss = c->sweep_s;
-    hipStream_t s = c->stream;
-    if (k == 0 || k == 1)
-        ec3d_launch_k1(A, ss, c->state, it, v[EC3D_VEC_P], v[EC3D_VEC_R0], v[EC3D_VEC_AP], c->partials, s);
-    if (k == 0 || k == 2)
-        ec3d_launch_k2(sw, src_of(c, true), c->state, it, v[EC3D_VEC_R], v[EC3D_VEC_AP], v[EC3D_VEC_S], c->partials, s);
-    if (k == 0 || k == 3)
-        ec3d_launch_k3(A, ss, c->state, it, v[EC3D_VEC_S], v[EC3D_VEC_AS], c->partials, s);
-    if (k == 0 || k == 4)
-        ec3d_launch_k4(sw, src_of(c, false), src_of(c, true), c->state, it, v[EC3D_VEC_P], v[EC3D_VEC_S],
-                       v[EC3D_VEC_AS], v[EC3D_VEC_R0], v[EC3D_VEC_X], v[EC3D_VEC_R], c->partials, c->hist,
-                       c->hist_cap, s);
-    if (k == 0 || k == 5)
-        ec3d_launch_k5(sw, src_of(c, false), c->state, it, v[EC3D_VEC_R], v[EC3D_VEC_AP], v[EC3D_VEC_P],
-                       v[EC3D_VEC_R0], c->hist, c->hist_cap, s);
-}
-
-static void launch_iteration(ec3d_ctx *c, const MatView &A, int it) { launch_stage(c, A, it, 0); }
-
-static int launch_setup(ec3d_ctx *c, const MatView &A, double tol)
-{
-    double **v = c->vec;
-    ec3d_launch_residual(A, c->sweep_s, v[EC3D_VEC_X], v[EC3D_VEC_B], v[EC3D_VEC_R], v[EC3D_VEC_R0], v[EC3D_VEC_P],
-                         c->partials, c->stream);
-    ec3d_launch_setup(c->state, src_of(c, true), tol, c->stream);
-    EC3D_HIP(hipGetLastError());
-    return 0;
-}
-
-static int single_rank_only(ec3d_ctx *c, const char *who)
-{
-    if (c->halo > 0 || c->nranks > 1) {
-        ec3d_set_error(std::string(who) + ": this handle holds one z-slab of a multi-rank problem; drive it "
-                                          "with ec3d_dist_step (eddy_currents_3d_amd/dist.py)");
-        return 4;
-    }
-    return 0;
-}
-
-static int ensure_hist(ec3d_ctx *c, int64_t cap)
-{
-    if (cap <= 0) {
-        c->hist_cap = 0;
-        return 0;
-    }
-    if (c->hist) (void)hipFree(c->hist);
-    c->hist = nullptr;
-    EC3D_HIP(hipMalloc(&c->hist, (size_t)cap * 2 * sizeof(double)));
-    EC3D_HIP(hipMemsetAsync(c->hist, 0xFF, (size_t)cap * 2 * sizeof(double), c->stream)); // NaN = "not reached"
-    c->hist_cap = cap;
-    return 0;
-}
-
-static int solve_core(ec3d_ctx *c, double tol, int32_t itmax, int32_t *iter, double *hist_host, int32_t hist_cap,
-                      bool print_on_itmax)
-{
-    const MatView A = c->A.view();
-    const int64_t total = std::max<int64_t>(0, (int64_t)itmax + 1); // src/solvers.f90:25-29
-    int rc = ensure_hist(c, hist_host ? std::min<int64_t>(hist_cap, total) : 0);
-    if (rc) return rc;
-    if ((rc = launch_setup(c, A, tol))) return rc;
-
-    // iterations per poll: about 0.4 ms of device work, so an exit is noticed within ~1 ms
-    const double est_us = (double)c->A.n_pad * 264.0 / 4.0e6 + 12.0;
-    const int chunk = (int)std::min<double>(32.0, std::max<double>(1.0, 400.0 / est_us));
-    int64_t launched = 0;
-    int ci = 0;
-    bool stopped = false;
-    while (launched < total && !stopped) {
-        const int64_t m = std::min<int64_t>(chunk, total - launched);
-        for (int64_t i = 0; i < m; ++i) launch_iteration(c, A, (int)(++launched));
-        EC3D_HIP(hipGetLastError());
-        EC3D_HIP(hipMemcpyAsync(&c->state_pinned[ci & 1], c->state, sizeof(SolverState), hipMemcpyDeviceToHost,
-                                c->stream));
-        EC3D_HIP(hipEventRecord(c->ev[ci & 1], c->stream));
-        if (ci > 0) {
-            EC3D_HIP(hipEventSynchronize(c->ev[(ci - 1) & 1]));
-            if (c->state_pinned[(ci - 1) & 1].stop_iter != INT_MAX) stopped = true;
-        }
-        ++ci;
-    }
-    EC3D_HIP(hipStreamSynchronize(c->stream));
-    SolverState fin;
-    EC3D_HIP(hipMemcpy(&fin, c->state, sizeof fin, hipMemcpyDeviceToHost));
-    if (fin.stop_iter != INT_MAX) {
-        *iter = fin.stop_iter;
-    } else {
-        *iter = (int32_t)total; // itmax exit: the reference prints norm2(R) and returns (:25-28)
-        if (print_on_itmax) {
-            // ‖R‖ = sqrt(sum of the last K4 partials), summed here in workgroup order
-            std::vector<double> part((size_t)c->sweep.pstride);
-            EC3D_HIP(hipMemcpy(part.data(), c->partials + (size_t)P_RR * c->sweep.pstride,
-                               part.size() * sizeof(double), hipMemcpyDeviceToHost));
-            double s = 0.0;
-            for (int q = 0; q < c->sweep.nblk; ++q) s += part[(size_t)q];
-            if (total == 0) {
-                EC3D_HIP(hipMemcpy(part.data(), c->partials + (size_t)P_RR_INIT * c->sweep.pstride,
-                                   part.size() * sizeof(double), hipMemcpyDeviceToHost));
-                s = 0.0;
-                for (int q = 0; q < c->sweep_s.nblk; ++q) s += part[(size_t)q];
-            }
-            printf(" %.17g\n", std::sqrt(s));
-            fflush(stdout);
-        }
-    }
-    if (hist_host && c->hist_cap > 0)
-        EC3D_HIP(hipMemcpy(hist_host, c->hist, (size_t)c->hist_cap * 2 * sizeof(double), hipMemcpyDeviceToHost));
-    return 0;
-}
-
-extern "C" int ec3d_solve_resident(ec3d_handle c, double tolerance, int32_t itmax, int32_t *iter,
-                                   double *resid_hist, int32_t hist_cap)
-{
-    int rc = need_matrix(c, "ec3d_solve_resident");
-    if (rc) return rc;
-    if ((rc = single_rank_only(c, "ec3d_solve_resident"))) return rc;
-    return solve_core(c, tolerance, itmax, iter, resid_hist, hist_cap, true);
-}
-
-extern "C" int ec3d_solve(ec3d_handle c, const double *b, double *x, double tolerance, int32_t itmax,
-                          int32_t *iter, double *resid_hist, int32_t hist_cap)
-{
-    int rc = need_matrix(c, "ec3d_solve");
-    if (rc) return rc;
-    if ((rc = single_rank_only(c, "ec3d_solve"))) return rc;
-    if ((rc = ec3d_vec_h2d(c, c->vec[EC3D_VEC_B], b))) return rc;
-    if ((rc = ec3d_vec_h2d(c, c->vec[EC3D_VEC_X], x))) return rc;
-    if ((rc = solve_core(c, tolerance, itmax, iter, resid_hist, hist_cap, true))) return rc;
-    if ((rc = ec3d_vec_d2h(c, x, c->vec[EC3D_VEC_X]))) return rc;
-    EC3D_HIP(hipStreamSynchronize(c->stream));
-    return 0;
-}
-
-// ---------------------------------------------------------------------------------------------
-// measurement
-extern "C" int ec3d_time_iterations(ec3d_handle c, int32_t iters, double *ms_total)
-{
-    int rc = need_matrix(c, "ec3d_time_iterations");
-    if (rc) return rc;
-    const MatView A = c->A.view();
-    c->hist_cap = 0;
-    if ((rc = launch_setup(c, A, -1.0))) return rc; // tol < 0: no exit, no restart
-    EC3D_HIP(hipEventRecord(c->t0, c->stream));
-    for (int it = 1; it <= iters; ++it) launch_iteration(c, A, it);
-    EC3D_HIP(hipEventRecord(c->t1, c->stream));
-    EC3D_HIP(hipGetLastError());
-    EC3D_HIP(hipEventSynchronize(c->t1));
-    float ms = 0.f;
-    EC3D_HIP(hipEventElapsedTime(&ms, c->t0, c->t1));
-    *ms_total = ms;
-    return 0;
-}
-
-// Bench "steps": exits disabled (tol < 0), launches only, no host synchronisation.
-extern "C" int ec3d_iterate_begin(ec3d_handle c)
-{
-    int rc = need_matrix(c, "ec3d_iterate_begin");
-    if (rc) return rc;
-    if ((rc = single_rank_only(c, "ec3d_iterate_begin"))) return rc;
-    c->hist_cap = 0;
-    return launch_setup(c, c->A.view(), -1.0);
-}
-
-extern "C" int ec3d_iterate(ec3d_handle c, int32_t first_iter, int32_t count, double *kernel_ms)
-{
-    int rc = need_matrix(c, "ec3d_iterate");
-    if (rc) return rc;
-    const MatView A = c->A.view();
-    if (!kernel_ms) {
-        for (int it = first_iter; it < first_iter + count; ++it) launch_iteration(c, A, it);
-        EC3D_HIP(hipGetLastError());
-        return 0;
-    }
-    // per-kernel durations: an event at every kernel boundary of every iteration, on our stream
-    std::vector<hipEvent_t> ev((size_t)count * 6);
-    for (auto &e : ev) EC3D_HIP(hipEventCreate(&e));
-    hipStream_t s = c->stream;
-    for (int i = 0; i < count; ++i) {
-        const int it = first_iter + i;
-        hipEvent_t *e = &ev[(size_t)i * 6];
-        EC3D_HIP(hipEventRecord(e[0], s));
-        for (int k = 1; k <= 5; ++k) {
-            launch_stage(c, A, it, k);
-            EC3D_HIP(hipEventRecord(e[k], s));
-        }
-    }
-    EC3D_HIP(hipGetLastError());
-    EC3D_HIP(hipStreamSynchronize(s));
-    for (int k = 0; k < 5; ++k) kernel_ms[k] = 0.0;
-    for (int i = 0; i < count; ++i)
-        for (int k = 0; k < 5; ++k) {
-            float ms = 0.f;
-            EC3D_HIP(hipEventElapsedTime(&ms, ev[(size_t)i * 6 + k], ev[(size_t)i * 6 + k + 1]));
-            kernel_ms[k] += (double)ms / count;
-        }
-    for (auto &e : ev) (void)hipEventDestroy(e);
-    return 0;
-}
-
-extern "C" int ec3d_time_kernel(ec3d_handle c, int kernel, int32_t reps, double *ms_per_launch)
-{
-    int rc = need_matrix(c, "ec3d_time_kernel");
-    if (rc) return rc;
-    const MatView A = c->A.view();
-    double **v = c->vec;
-    hipStream_t s = c->stream;
-    c->hist_cap = 0;
-    if ((rc = launch_setup(c, A, -1.0))) return rc;
-    launch_iteration(c, A, 1); // populate every partial slot and the scalars
-    auto one = [&]() {
-        if (kernel == EC3D_K_SPMV)
-            ec3d_launch_spmv(A, c->sweep_s, v[EC3D_VEC_P], v[EC3D_VEC_AP], s);
-        else
-            launch_stage(c, A, 2, kernel);
-    };
-    one(); // warm
-    EC3D_HIP(hipEventRecord(c->t0, s));
-    for (int i = 0; i < reps; ++i) one();
-    EC3D_HIP(hipEventRecord(c->t1, s));
-    EC3D_HIP(hipGetLastError());
-    EC3D_HIP(hipEventSynchronize(c->t1));
-    float ms = 0.f;
-    EC3D_HIP(hipEventElapsedTime(&ms, c->t0, c->t1));
-    *ms_per_launch = (double)ms / std::max(1, reps);
-    return 0;
-}
-
-// ---------------------------------------------------------------------------------------------
-// multi-rank (z-slab) building blocks: one process per GPU drives these from
-// eddy_currents_3d_amd/dist.py with torch.distributed (RCCL) between the stages
-extern "C" int ec3d_vector_layout(ec3d_handle c, int64_t *ghost, int64_t *n, int64_t *n_pad, int64_t *halo)
-{
-    int rc = need_matrix(c, "ec3d_vector_layout");
-    if (rc) return rc;
-    *ghost = c->ghost;
-    *n = c->A.n;
-    *n_pad = c->A.n_pad;
-    *halo = c->halo;
-    return 0;
-}
-
-// Use caller-owned device memory for the 8 work vectors: EC3D_NVEC * (ghost + n_pad + ghost) doubles,
-// zero filled by the caller.  Vector v's element 0 is at base[v*len + ghost].
-extern "C" int ec3d_adopt_vectors(ec3d_handle c, double *base)
-{
-    int rc = need_matrix(c, "ec3d_adopt_vectors");
-    if (rc) return rc;
-    EC3D_HIP(hipStreamSynchronize(c->stream));
-    if (c->vec_base && c->own_vectors) (void)hipFree(c->vec_base);
-    const int64_t len = c->ghost + c->A.n_pad + c->ghost;
-    c->vec_base = base;
-    c->own_vectors = false;
-    for (int v = 0; v < EC3D_NVEC; ++v) c->vec[v] = base + (size_t)v * len + c->ghost;
-    return 0;
-}
-
-extern "C" int ec3d_dist_configure(ec3d_handle c, int32_t nranks, double *lsum_device, double *gsum_device)
-{
-    if (nranks < 1 || !lsum_device || !gsum_device) {
-        ec3d_set_error("ec3d_dist_configure: need nranks >= 1 and two device buffers");
-        return 2;
-    }
-    c->nranks = nranks;
-    c->lsum = lsum_device;
-    c->gsum = gsum_device;
-    c->dist = true;
-    return 0;
-}
-
-extern "C" int ec3d_dist_set_boundary_rows(ec3d_handle c, int32_t nranges, const int64_t *lo, const int64_t *hi,
-                                           int32_t *enabled)
-{
-    int rc = need_matrix(c, "ec3d_dist_set_boundary_rows");
-    if (rc) return rc;
-    if (nranges < 0 || (nranges > 0 && (!lo || !hi))) return 2;
-    if (enabled) *enabled = 0;
-    // tiles the vector kernels visit: the front sweep and the occupied U tiles of the structured form
-    const Sweep &sw = c->sweep;
-    std::vector<int32_t> visit((size_t)sw.ntiles);
-    for (int64_t t = 0; t < sw.ntiles; ++t) visit[(size_t)t] = (int32_t)t;
-    if (sw.ulist_n) {
-        std::vector<int32_t> ul((size_t)sw.ulist_n);
-        EC3D_HIP(hipMemcpy(ul.data(), sw.ulist, ul.size() * 4, hipMemcpyDeviceToHost));
-        visit.insert(visit.end(), ul.begin(), ul.end());
-    }
-    std::vector<int32_t> vb, vi;
-    for (int32_t t : visit) {
-        const int64_t r0 = (int64_t)t * EC3D_TILE, r1 = r0 + EC3D_TILE;
-        bool bnd = false;
-        for (int32_t q = 0; q < nranges && !bnd; ++q) bnd = lo[q] < r1 && hi[q] > r0;
-        (bnd ? vb : vi).push_back(t);
-    }
-    if (c->vb_list) (void)hipFree(c->vb_list);
-    if (c->vi_list) (void)hipFree(c->vi_list);
-    c->vb_list = c->vi_list = nullptr;
-    c->can_vsplit = false;
-    if (vb.empty() || vi.empty()) return 0; // nothing to split (single rank, or a slab that is all boundary)
-    EC3D_HIP(hipMalloc(&c->vb_list, vb.size() * 4));
-    EC3D_HIP(hipMalloc(&c->vi_list, vi.size() * 4));
-    EC3D_HIP(hipMemcpy(c->vb_list, vb.data(), vb.size() * 4, hipMemcpyHostToDevice));
-    EC3D_HIP(hipMemcpy(c->vi_list, vi.data(), vi.size() * 4, hipMemcpyHostToDevice));
-    auto list_sweep = [&](const int32_t *list, size_t len, int max_blk, int part_off) {
-        Sweep s = sw;
-        s.ntiles = 0; // list only
-        s.ulist = list;
-        s.ulist_n = (int)len;
-        s.nblk = (int)std::min<size_t>(len, (size_t)max_blk);
-        s.S = 0;
-        s.part_off = part_off;
-        return s;
-    };
-    c->sweep_vb = list_sweep(c->vb_list, vb.size(), 256, 0);
-    c->sweep_vi = list_sweep(c->vi_list, vi.size(), sw.nblk, c->sweep_vb.nblk);
-    c->can_vsplit = true;
-    if (enabled) *enabled = 1;
-    return 0;
-}
-
-extern "C" int ec3d_dist_step(ec3d_handle c, int32_t stage, int32_t it, double tolerance)
-{
-    int rc = need_matrix(c, "ec3d_dist_step");
-    if (rc) return rc;
-    if (!c->dist) {
-        ec3d_set_error("ec3d_dist_step: call ec3d_dist_configure first");
-        return 3;
-    }
-    const MatView A = c->A.view();
-    double **v = c->vec;
-    auto fin = [&](bool spmv_producer, unsigned mask, bool split = false) {
-        ec3d_launch_finalize(part_of(c, spmv_producer, split), c->lsum, mask, c->stream);
-    };
-    auto need_split = [&]() {
-        if (!c->can_overlap) ec3d_set_error("ec3d_dist_step: this slab cannot split K1/K3 (see ec3d_can_overlap)");
-        return c->can_overlap;
-    };
-    switch (stage) {
-    case EC3D_STAGE_RESID:
-        c->hist_cap = 0;
-        ec3d_launch_residual(A, c->sweep_s, v[EC3D_VEC_X], v[EC3D_VEC_B], v[EC3D_VEC_R], v[EC3D_VEC_R0],
-                             v[EC3D_VEC_P], c->partials, c->stream);
-        fin(true, 1u << P_BB | 1u << P_RR_INIT);
-        break;
-    case EC3D_STAGE_SETUP: ec3d_launch_setup(c->state, src_of(c, true), tolerance, c->stream); break;
-    case EC3D_STAGE_K1: launch_stage(c, A, it, 1); fin(true, 1u << P_D1); break;
-    case EC3D_STAGE_K2: launch_stage(c, A, it, 2); fin(false, 1u << P_SS); break;
-    case EC3D_STAGE_K3: launch_stage(c, A, it, 3); fin(true, 1u << P_D2 | 1u << P_D3); break;
-    case EC3D_STAGE_K4: launch_stage(c, A, it, 4); fin(false, 1u << P_RR | 1u << P_RR0N); break;
-    case EC3D_STAGE_K5: launch_stage(c, A, it, 5); break;
-    case EC3D_STAGE_K1_INT:
-        if (!need_split()) return 3;
-        ec3d_launch_k1(A, c->sweep_int, c->state, it, v[EC3D_VEC_P], v[EC3D_VEC_R0], v[EC3D_VEC_AP], c->partials,
-                       c->stream);
-        break;
-    case EC3D_STAGE_K1_BND:
-        if (!need_split()) return 3;
-        ec3d_launch_k1(A, c->sweep_bnd, c->state, it, v[EC3D_VEC_P], v[EC3D_VEC_R0], v[EC3D_VEC_AP], c->partials,
-                       c->stream);
-        fin(true, 1u << P_D1, true);
-        break;
-    case EC3D_STAGE_K3_INT:
-        if (!need_split()) return 3;
-        ec3d_launch_k3(A, c->sweep_int, c->state, it, v[EC3D_VEC_S], v[EC3D_VEC_AS], c->partials, c->stream);
-        break;
-    case EC3D_STAGE_K3_BND:
-        if (!need_split()) return 3;
-        ec3d_launch_k3(A, c->sweep_bnd, c->state, it, v[EC3D_VEC_S], v[EC3D_VEC_AS], c->partials, c->stream);
-        fin(true, 1u << P_D2 | 1u << P_D3, true);
-        break;
-    case EC3D_STAGE_K2_BND:
-    case EC3D_STAGE_K2_INT: {
-        if (!c->can_vsplit) {
-            ec3d_set_error("ec3d_dist_step: call ec3d_dist_set_boundary_rows first");
-            return 3;
-        }
-        const bool bnd = stage == EC3D_STAGE_K2_BND;
-        ec3d_launch_k2(bnd ? c->sweep_vb : c->sweep_vi, src_of(c, true), c->state, it, v[EC3D_VEC_R], v[EC3D_VEC_AP],
-                       v[EC3D_VEC_S], c->partials, c->stream);
-        if (!bnd)
-            ec3d_launch_finalize(RedSrc{c->partials, c->sweep_vb.nblk + c->sweep_vi.nblk, 1, c->sweep.pstride}, c->lsum,
-                                 1u << P_SS, c->stream);
-        break;
-    }
-    case EC3D_STAGE_K5_BND:
-    case EC3D_STAGE_K5_INT:
-        if (!c->can_vsplit) {
-            ec3d_set_error("ec3d_dist_step: call ec3d_dist_set_boundary_rows first");
-            return 3;
-        }
-        ec3d_launch_k5(stage == EC3D_STAGE_K5_BND ? c->sweep_vb : c->sweep_vi, src_of(c, false), c->state, it,
-                       v[EC3D_VEC_R], v[EC3D_VEC_AP], v[EC3D_VEC_P], v[EC3D_VEC_R0], c->hist, c->hist_cap, c->stream);
-        break;
-    default: ec3d_set_error("ec3d_dist_step: unknown stage"); return 2;
-    }
-    EC3D_HIP(hipGetLastError());
-    return 0;
-}
-
-extern "C" int ec3d_can_overlap(ec3d_handle c) { return c && c->have_matrix && c->can_overlap ? 1 : 0; }
-
-extern "C" int ec3d_read_state_async(ec3d_handle c, int32_t *stop_iter_pinned)
-{
-    if (!c || !c->state || !stop_iter_pinned) return 2;
-    EC3D_HIP(hipSetDevice(c->device));
-    EC3D_HIP(hipMemcpyAsync(stop_iter_pinned, &c->state->stop_iter, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    return 0;
-}
-
-// synchronous read of the device-resident solver state (stream is drained first)
-extern "C" int ec3d_read_state(ec3d_handle c, int32_t *stop_iter, int32_t *stop_kind, double *bnorm)
-{
-    EC3D_HIP(hipSetDevice(c->device));
-    EC3D_HIP(hipStreamSynchronize(c->stream));
-    SolverState st;
-    EC3D_HIP(hipMemcpy(&st, c->state, sizeof st, hipMemcpyDeviceToHost));
-    if (stop_iter) *stop_iter = st.stop_iter == INT_MAX ? -1 : st.stop_iter;
-    if (stop_kind) *stop_kind = st.stop_kind;
-    if (bnorm) *bnorm = st.bnorm;
-    return 0;
-}
-
-// ---------------------------------------------------------------------------------------------
-// drop-in for src/solvers.f90:3 (called from src/EC3D.f90:408)
-namespace {
-struct DropIn {
-    ec3d_ctx *ctx = nullptr;
-    const void *valA = nullptr, *irow = nullptr, *jcol = nullptr;
-    int64_t n = 0, nnz = 0;
-    uint64_t sig = 0;
-    std::mutex mu;
-} g_drop;
-
-uint64_t sample_signature(const double *valA, const int32_t *jcol, int64_t nnz)
-{
-    // cheap change detector for callers that rebuild the matrix in place without telling us
-    uint64_t h = 1469598103934665603ull;
-    const int64_t step = std::max<int64_t>(1, nnz / 4096);
-    for (int64_t p = 0; p < nnz; p += step) {
-        uint64_t bits;
-        memcpy(&bits, &valA[p], 8);
-        h = (h ^ bits) * 1099511628211ull;
-        h = (h ^ (uint64_t)jcol[p]) * 1099511628211ull;
-    }
-    return h;
-}
-
-[[noreturn]] void die(const char *what)
-{
-    fprintf(stderr, "libec3d_hip: %s: %s\n", what, ec3d_last_error());
-    abort();
-}
-} // namespace
-
-extern "C" void ec3d_invalidate(void)
-{
-    std::lock_guard<std::mutex> lk(g_drop.mu);
-    if (g_drop.ctx) ec3d_free_matrix(g_drop.ctx);
-    g_drop.valA = nullptr;
-}
-
-extern "C" void sprsbcgstabwr_(double *valA, int32_t *irow, int32_t *jcol, int32_t *n, double *b, double *x,
-                               double *tolerance, int32_t *itmax, int32_t *iter)
-{
-    if (*n <= 0) { // empty system: Bnorm = 0, the reference returns at once with iter = 0 (src/solvers.f90:13,:23)
-        *iter = 0;
-        return;
-    }
-    std::lock_guard<std::mutex> lk(g_drop.mu);
-    if (!g_drop.ctx) {
-        int dev = 0;
-        if (const char *e = getenv("EC3D_DEVICE")) dev = atoi(e);
-        if (ec3d_create(&g_drop.ctx, dev)) die("ec3d_create");
-    }
-    const int64_t nn = *n, nnz = (int64_t)irow[nn] - 1;
-    const uint64_t sig = sample_signature(valA, jcol, nnz);
-    if (!(g_drop.ctx->have_matrix && g_drop.valA == valA && g_drop.irow == irow && g_drop.jcol == jcol &&
-          g_drop.n == nn && g_drop.nnz == nnz && g_drop.sig == sig)) {
-        if (ec3d_set_matrix_csr(g_drop.ctx, *n, valA, irow, jcol)) die("ec3d_set_matrix_csr");
-        g_drop.valA = valA;
-        g_drop.irow = irow;
-        g_drop.jcol = jcol;
-        g_drop.n = nn;
-        g_drop.nnz = nnz;
-        g_drop.sig = sig;
-    }
-    if (ec3d_solve(g_drop.ctx, b, x, *tolerance, *itmax, iter, nullptr, 0)) die("ec3d_solve");
-}

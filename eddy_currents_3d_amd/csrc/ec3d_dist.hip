@@ -1,0 +1,206 @@
+// ec3d_dist.hip — per-stage entry points for the multi-rank (z-slab) schedule driven by
+// eddy_currents_3d_amd/dist.py: the library launches, the host moves halos and sums between the stages.
+#include "../../include/ec3d_hip.h"
+#include "ec3d_internal.hpp"
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+// ---------------------------------------------------------------------------------------------
+// multi-rank (z-slab) building blocks: one process per GPU drives these from
+// eddy_currents_3d_amd/dist.py with torch.distributed (RCCL) between the stages
+extern "C" int ec3d_vector_layout(ec3d_handle c, int64_t *ghost, int64_t *n, int64_t *n_pad, int64_t *halo)
+{
+    int rc = ec3d_need_matrix(c, "ec3d_vector_layout");
+    if (rc) return rc;
+    *ghost = c->ghost;
+    *n = c->A.n;
+    *n_pad = c->A.n_pad;
+    *halo = c->halo;
+    return 0;
+}
+
+// Use caller-owned device memory for the 8 work vectors: EC3D_NVEC * (ghost + n_pad + ghost) doubles,
+// zero filled by the caller.  Vector v's element 0 is at base[v*len + ghost].
+extern "C" int ec3d_adopt_vectors(ec3d_handle c, double *base)
+{
+    int rc = ec3d_need_matrix(c, "ec3d_adopt_vectors");
+    if (rc) return rc;
+    EC3D_HIP(hipStreamSynchronize(c->stream));
+    if (c->vec_base && c->own_vectors) (void)hipFree(c->vec_base);
+    const int64_t len = c->ghost + c->A.n_pad + c->ghost;
+    c->vec_base = base;
+    c->own_vectors = false;
+    for (int v = 0; v < EC3D_NVEC; ++v) c->vec[v] = base + (size_t)v * len + c->ghost;
+    return 0;
+}
+
+extern "C" int ec3d_dist_configure(ec3d_handle c, int32_t nranks, double *lsum_device, double *gsum_device)
+{
+    if (nranks < 1 || !lsum_device || !gsum_device) {
+        ec3d_set_error("ec3d_dist_configure: need nranks >= 1 and two device buffers");
+        return 2;
+    }
+    c->nranks = nranks;
+    c->lsum = lsum_device;
+    c->gsum = gsum_device;
+    c->dist = true;
+    return 0;
+}
+
+extern "C" int ec3d_dist_set_boundary_rows(ec3d_handle c, int32_t nranges, const int64_t *lo, const int64_t *hi,
+                                           int32_t *enabled)
+{
+    int rc = ec3d_need_matrix(c, "ec3d_dist_set_boundary_rows");
+    if (rc) return rc;
+    if (nranges < 0 || (nranges > 0 && (!lo || !hi))) return 2;
+    if (enabled) *enabled = 0;
+    // tiles the vector kernels visit: the front sweep and the occupied U tiles of the structured form
+    const Sweep &sw = c->sweep;
+    std::vector<int32_t> visit((size_t)sw.ntiles);
+    for (int64_t t = 0; t < sw.ntiles; ++t) visit[(size_t)t] = (int32_t)t;
+    if (sw.ulist_n) {
+        std::vector<int32_t> ul((size_t)sw.ulist_n);
+        EC3D_HIP(hipMemcpy(ul.data(), sw.ulist, ul.size() * 4, hipMemcpyDeviceToHost));
+        visit.insert(visit.end(), ul.begin(), ul.end());
+    }
+    std::vector<int32_t> vb, vi;
+    for (int32_t t : visit) {
+        const int64_t r0 = (int64_t)t * EC3D_TILE, r1 = r0 + EC3D_TILE;
+        bool bnd = false;
+        for (int32_t q = 0; q < nranges && !bnd; ++q) bnd = lo[q] < r1 && hi[q] > r0;
+        (bnd ? vb : vi).push_back(t);
+    }
+    if (c->vb_list) (void)hipFree(c->vb_list);
+    if (c->vi_list) (void)hipFree(c->vi_list);
+    c->vb_list = c->vi_list = nullptr;
+    c->can_vsplit = false;
+    if (vb.empty() || vi.empty()) return 0; // nothing to split (single rank, or a slab that is all boundary)
+    EC3D_HIP(hipMalloc(&c->vb_list, vb.size() * 4));
+    EC3D_HIP(hipMalloc(&c->vi_list, vi.size() * 4));
+    EC3D_HIP(hipMemcpy(c->vb_list, vb.data(), vb.size() * 4, hipMemcpyHostToDevice));
+    EC3D_HIP(hipMemcpy(c->vi_list, vi.data(), vi.size() * 4, hipMemcpyHostToDevice));
+    auto list_sweep = [&](const int32_t *list, size_t len, int max_blk, int part_off) {
+        Sweep s = sw;
+        s.ntiles = 0; // list only
+        s.ulist = list;
+        s.ulist_n = (int)len;
+        s.nblk = (int)std::min<size_t>(len, (size_t)max_blk);
+        s.S = 0;
+        s.part_off = part_off;
+        return s;
+    };
+    c->sweep_vb = list_sweep(c->vb_list, vb.size(), 256, 0);
+    c->sweep_vi = list_sweep(c->vi_list, vi.size(), sw.nblk, c->sweep_vb.nblk);
+    c->can_vsplit = true;
+    if (enabled) *enabled = 1;
+    return 0;
+}
+
+extern "C" int ec3d_dist_step(ec3d_handle c, int32_t stage, int32_t it, double tolerance)
+{
+    int rc = ec3d_need_matrix(c, "ec3d_dist_step");
+    if (rc) return rc;
+    if (!c->dist) {
+        ec3d_set_error("ec3d_dist_step: call ec3d_dist_configure first");
+        return 3;
+    }
+    const MatView A = c->A.view();
+    double **v = c->vec;
+    auto fin = [&](bool spmv_producer, unsigned mask, bool split = false) {
+        ec3d_launch_finalize(ec3d_part_of(c, spmv_producer, split), c->lsum, mask, c->stream);
+    };
+    auto need_split = [&]() {
+        if (!c->can_overlap) ec3d_set_error("ec3d_dist_step: this slab cannot split K1/K3 (see ec3d_can_overlap)");
+        return c->can_overlap;
+    };
+    switch (stage) {
+    case EC3D_STAGE_RESID:
+        c->hist_cap = 0;
+        ec3d_launch_residual(A, c->sweep_s, v[EC3D_VEC_X], v[EC3D_VEC_B], v[EC3D_VEC_R], v[EC3D_VEC_R0],
+                             v[EC3D_VEC_P], c->partials, c->stream);
+        fin(true, 1u << P_BB | 1u << P_RR_INIT);
+        break;
+    case EC3D_STAGE_SETUP: ec3d_launch_setup(c->state, ec3d_src_of(c, true), tolerance, c->stream); break;
+    case EC3D_STAGE_K1: ec3d_launch_stage(c, A, it, 1); fin(true, 1u << P_D1); break;
+    case EC3D_STAGE_K2: ec3d_launch_stage(c, A, it, 2); fin(false, 1u << P_SS); break;
+    case EC3D_STAGE_K3: ec3d_launch_stage(c, A, it, 3); fin(true, 1u << P_D2 | 1u << P_D3); break;
+    case EC3D_STAGE_K4: ec3d_launch_stage(c, A, it, 4); fin(false, 1u << P_RR | 1u << P_RR0N); break;
+    case EC3D_STAGE_K5: ec3d_launch_stage(c, A, it, 5); break;
+    case EC3D_STAGE_K1_INT:
+        if (!need_split()) return 3;
+        ec3d_launch_k1(A, c->sweep_int, c->state, it, v[EC3D_VEC_P], v[EC3D_VEC_R0], v[EC3D_VEC_AP], c->partials,
+                       c->stream);
+        break;
+    case EC3D_STAGE_K1_BND:
+        if (!need_split()) return 3;
+        ec3d_launch_k1(A, c->sweep_bnd, c->state, it, v[EC3D_VEC_P], v[EC3D_VEC_R0], v[EC3D_VEC_AP], c->partials,
+                       c->stream);
+        fin(true, 1u << P_D1, true);
+        break;
+    case EC3D_STAGE_K3_INT:
+        if (!need_split()) return 3;
+        ec3d_launch_k3(A, c->sweep_int, c->state, it, v[EC3D_VEC_S], v[EC3D_VEC_AS], c->partials, c->stream);
+        break;
+    case EC3D_STAGE_K3_BND:
+        if (!need_split()) return 3;
+        ec3d_launch_k3(A, c->sweep_bnd, c->state, it, v[EC3D_VEC_S], v[EC3D_VEC_AS], c->partials, c->stream);
+        fin(true, 1u << P_D2 | 1u << P_D3, true);
+        break;
+    case EC3D_STAGE_K2_BND:
+    case EC3D_STAGE_K2_INT: {
+        if (!c->can_vsplit) {
+            ec3d_set_error("ec3d_dist_step: call ec3d_dist_set_boundary_rows first");
+            return 3;
+        }
+        const bool bnd = stage == EC3D_STAGE_K2_BND;
+        ec3d_launch_k2(bnd ? c->sweep_vb : c->sweep_vi, ec3d_src_of(c, true), c->state, it, v[EC3D_VEC_R], v[EC3D_VEC_AP],
+                       v[EC3D_VEC_S], c->partials, c->stream);
+        if (!bnd)
+            ec3d_launch_finalize(RedSrc{c->partials, c->sweep_vb.nblk + c->sweep_vi.nblk, 1, c->sweep.pstride}, c->lsum,
+                                 1u << P_SS, c->stream);
+        break;
+    }
+    case EC3D_STAGE_K5_BND:
+    case EC3D_STAGE_K5_INT:
+        if (!c->can_vsplit) {
+            ec3d_set_error("ec3d_dist_step: call ec3d_dist_set_boundary_rows first");
+            return 3;
+        }
+        ec3d_launch_k5(stage == EC3D_STAGE_K5_BND ? c->sweep_vb : c->sweep_vi, ec3d_src_of(c, false), c->state, it,
+                       v[EC3D_VEC_R], v[EC3D_VEC_AP], v[EC3D_VEC_P], v[EC3D_VEC_R0], c->hist, c->hist_cap, c->stream);
+        break;
+    default: ec3d_set_error("ec3d_dist_step: unknown stage"); return 2;
+    }
+    EC3D_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int ec3d_can_overlap(ec3d_handle c) { return c && c->have_matrix && c->can_overlap ? 1 : 0; }
+
+extern "C" int ec3d_read_state_async(ec3d_handle c, int32_t *stop_iter_pinned)
+{
+    if (!c || !c->state || !stop_iter_pinned) return 2;
+    EC3D_HIP(hipSetDevice(c->device));
+    EC3D_HIP(hipMemcpyAsync(stop_iter_pinned, &c->state->stop_iter, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    return 0;
+}
+
+// synchronous read of the device-resident solver state (stream is drained first)
+extern "C" int ec3d_read_state(ec3d_handle c, int32_t *stop_iter, int32_t *stop_kind, double *bnorm)
+{
+    EC3D_HIP(hipSetDevice(c->device));
+    EC3D_HIP(hipStreamSynchronize(c->stream));
+    SolverState st;
+    EC3D_HIP(hipMemcpy(&st, c->state, sizeof st, hipMemcpyDeviceToHost));
+    if (stop_iter) *stop_iter = st.stop_iter == INT_MAX ? -1 : st.stop_iter;
+    if (stop_kind) *stop_kind = st.stop_kind;
+    if (bnorm) *bnorm = st.bnorm;
+    return 0;
+}
+

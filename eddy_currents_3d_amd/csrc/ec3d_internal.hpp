@@ -245,7 +245,7 @@ void ec3d_host_matrix_to_csr(const HostMatrix &M, std::vector<int32_t> &irow, st
 // ec3d_sav_csr.cpp: 0, or -1 when the matrix does not have the structure
 int ec3d_csr_to_sav_host(int64_t n, const double *valA, const int32_t *irow, const int32_t *jcol, SavHost &S);
 
-// ec3d_solver.hip
+// ec3d_context.hip
 int ec3d_upload_sav(ec3d_ctx *c, const SavHost &S);
 int ec3d_upload_matrix(ec3d_ctx *c, const HostMatrix &M);
 int ec3d_download_matrix(ec3d_ctx *c, HostMatrix &M);
@@ -254,6 +254,16 @@ int ec3d_prepare_vectors(ec3d_ctx *c);
 // host vector (reference numbering, n_ref entries) <-> device vector (device numbering)
 int ec3d_vec_h2d(ec3d_ctx *c, double *dev, const double *host);
 int ec3d_vec_d2h(ec3d_ctx *c, double *host, const double *dev);
+
+// ec3d_context.hip
+int ec3d_need_matrix(ec3d_ctx *c, const char *who); // 0, or 3 + error text when the handle has no matrix
+// ec3d_solve.hip: where a consumer kernel finds its sums, and the launches of one iteration
+RedSrc ec3d_src_of(const ec3d_ctx *c, bool produced_by_spmv);
+RedSrc ec3d_part_of(const ec3d_ctx *c, bool produced_by_spmv, bool split = false);
+void ec3d_launch_stage(ec3d_ctx *c, const MatView &A, int it, int k); // k = 1..5, 0 = all five
+void ec3d_launch_iteration(ec3d_ctx *c, const MatView &A, int it);
+int ec3d_launch_begin(ec3d_ctx *c, const MatView &A, double tol);
+int ec3d_single_rank_only(ec3d_ctx *c, const char *who);
 
 // ec3d_kernels.hip — launchers (all asynchronous on `s`)
 void ec3d_launch_spmv(const MatView &A, const Sweep &sw, const double *x, double *y, hipStream_t s);
@@ -285,7 +295,7 @@ int ec3d_assemble_sav_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t sdz,
                              int32_t nsub_glob, const double *BND, const double *delta, double dt);
 int ec3d_assemble_poisson_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t sdz, int32_t k0, int32_t k1,
                                  const double *BND, const double *delta);
-// ec3d_format.cpp / ec3d_solver.hip: dictionary compression of the bands
+// ec3d_format.cpp / ec3d_context.hip: dictionary compression of the bands
 int ec3d_build_dictionary_host(HostMatrix &M);
 // ec3d_rhs.hip
 void ec3d_free_rhs(ec3d_ctx *c);

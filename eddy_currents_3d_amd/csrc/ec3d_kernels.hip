@@ -12,7 +12,7 @@
 //     inter-workgroup handshake and no host round trip; scalars (alpha, omega, beta, rr0) live
 //     in a device-resident SolverState;
 //   * convergence is decided on the device: an exit writes stop_iter, later launches become
-//     no-ops, the host polls asynchronously (ec3d_solver.hip);
+//     no-ops, the host polls asynchronously (ec3d_solve.hip);
 //   * blockIdx -> tile map is XCD aware: the 8 XCD labels (blockIdx % 8) sweep disjoint
 //     contiguous groups of S tiles of one moving window, so x[r ± sdx] re-reads hit the L2 of
 //     the XCD that fetched them and the window's planes stay in the Infinity Cache.

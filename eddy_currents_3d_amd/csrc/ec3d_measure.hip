@@ -1,0 +1,106 @@
+// ec3d_measure.hip — timing entry points used by bench.py and the tools (hipEvents on the handle's stream).
+#include "../../include/ec3d_hip.h"
+#include "ec3d_internal.hpp"
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+// ---------------------------------------------------------------------------------------------
+// measurement
+extern "C" int ec3d_time_iterations(ec3d_handle c, int32_t iters, double *ms_total)
+{
+    int rc = ec3d_need_matrix(c, "ec3d_time_iterations");
+    if (rc) return rc;
+    const MatView A = c->A.view();
+    c->hist_cap = 0;
+    if ((rc = ec3d_launch_begin(c, A, -1.0))) return rc; // tol < 0: no exit, no restart
+    EC3D_HIP(hipEventRecord(c->t0, c->stream));
+    for (int it = 1; it <= iters; ++it) ec3d_launch_iteration(c, A, it);
+    EC3D_HIP(hipEventRecord(c->t1, c->stream));
+    EC3D_HIP(hipGetLastError());
+    EC3D_HIP(hipEventSynchronize(c->t1));
+    float ms = 0.f;
+    EC3D_HIP(hipEventElapsedTime(&ms, c->t0, c->t1));
+    *ms_total = ms;
+    return 0;
+}
+
+// Bench "steps": exits disabled (tol < 0), launches only, no host synchronisation.
+extern "C" int ec3d_iterate_begin(ec3d_handle c)
+{
+    int rc = ec3d_need_matrix(c, "ec3d_iterate_begin");
+    if (rc) return rc;
+    if ((rc = ec3d_single_rank_only(c, "ec3d_iterate_begin"))) return rc;
+    c->hist_cap = 0;
+    return ec3d_launch_begin(c, c->A.view(), -1.0);
+}
+
+extern "C" int ec3d_iterate(ec3d_handle c, int32_t first_iter, int32_t count, double *kernel_ms)
+{
+    int rc = ec3d_need_matrix(c, "ec3d_iterate");
+    if (rc) return rc;
+    const MatView A = c->A.view();
+    if (!kernel_ms) {
+        for (int it = first_iter; it < first_iter + count; ++it) ec3d_launch_iteration(c, A, it);
+        EC3D_HIP(hipGetLastError());
+        return 0;
+    }
+    // per-kernel durations: an event at every kernel boundary of every iteration, on our stream
+    std::vector<hipEvent_t> ev((size_t)count * 6);
+    for (auto &e : ev) EC3D_HIP(hipEventCreate(&e));
+    hipStream_t s = c->stream;
+    for (int i = 0; i < count; ++i) {
+        const int it = first_iter + i;
+        hipEvent_t *e = &ev[(size_t)i * 6];
+        EC3D_HIP(hipEventRecord(e[0], s));
+        for (int k = 1; k <= 5; ++k) {
+            ec3d_launch_stage(c, A, it, k);
+            EC3D_HIP(hipEventRecord(e[k], s));
+        }
+    }
+    EC3D_HIP(hipGetLastError());
+    EC3D_HIP(hipStreamSynchronize(s));
+    for (int k = 0; k < 5; ++k) kernel_ms[k] = 0.0;
+    for (int i = 0; i < count; ++i)
+        for (int k = 0; k < 5; ++k) {
+            float ms = 0.f;
+            EC3D_HIP(hipEventElapsedTime(&ms, ev[(size_t)i * 6 + k], ev[(size_t)i * 6 + k + 1]));
+            kernel_ms[k] += (double)ms / count;
+        }
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    return 0;
+}
+
+extern "C" int ec3d_time_kernel(ec3d_handle c, int kernel, int32_t reps, double *ms_per_launch)
+{
+    int rc = ec3d_need_matrix(c, "ec3d_time_kernel");
+    if (rc) return rc;
+    const MatView A = c->A.view();
+    double **v = c->vec;
+    hipStream_t s = c->stream;
+    c->hist_cap = 0;
+    if ((rc = ec3d_launch_begin(c, A, -1.0))) return rc;
+    ec3d_launch_iteration(c, A, 1); // populate every partial slot and the scalars
+    auto one = [&]() {
+        if (kernel == EC3D_K_SPMV)
+            ec3d_launch_spmv(A, c->sweep_s, v[EC3D_VEC_P], v[EC3D_VEC_AP], s);
+        else
+            ec3d_launch_stage(c, A, 2, kernel);
+    };
+    one(); // warm
+    EC3D_HIP(hipEventRecord(c->t0, s));
+    for (int i = 0; i < reps; ++i) one();
+    EC3D_HIP(hipEventRecord(c->t1, s));
+    EC3D_HIP(hipGetLastError());
+    EC3D_HIP(hipEventSynchronize(c->t1));
+    float ms = 0.f;
+    EC3D_HIP(hipEventElapsedTime(&ms, c->t0, c->t1));
+    *ms_per_launch = (double)ms / std::max(1, reps);
+    return 0;
+}
+

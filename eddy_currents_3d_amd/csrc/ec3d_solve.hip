@@ -1,0 +1,171 @@
+// ec3d_solve.hip — the solve loop, host side of src/solvers.f90:3-50.
+//
+// The loop body is five asynchronous launches per iteration (ec3d_kernels.hip); all scalars and the
+// convergence decision stay on the device.  The host runs ahead by up to two chunks of iterations and
+// learns about an exit from an asynchronous copy of the SolverState; launches issued past the exit are
+// no-ops, so the result is exactly the reference's.
+#include "../../include/ec3d_hip.h"
+#include "ec3d_internal.hpp"
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+// ---------------------------------------------------------------------------------------------
+// Where a consumer finds the sums it needs.  Single GPU: the producer's per-workgroup partials; the
+// producers of slots BB, RR_INIT, D1, D2, D3 are SpMV-type kernels (sweep_s), those of SS, RR, RR0N
+// vector kernels (sweep) -- every consumer reads slots of one producer class only.
+RedSrc ec3d_src_of(const ec3d_ctx *c, bool produced_by_spmv)
+{
+    if (c->dist) return RedSrc{c->gsum, c->nranks, P_NSLOT, 1};
+    return RedSrc{c->partials, produced_by_spmv ? c->sweep_s.nblk : c->sweep.nblk, 1, c->sweep.pstride};
+}
+RedSrc ec3d_part_of(const ec3d_ctx *c, bool produced_by_spmv, bool split)
+{
+    const int cnt = !produced_by_spmv ? c->sweep.nblk
+                    : split           ? c->sweep_int.nblk + c->sweep_bnd.nblk
+                                      : c->sweep_s.nblk;
+    return RedSrc{c->partials, cnt, 1, c->sweep.pstride};
+}
+
+// the five launches of one iteration; `k` selects one of them (1..5) or all (0)
+void ec3d_launch_stage(ec3d_ctx *c, const MatView &A, int it, int k)
+{
+    double **v = c->vec;
+    const Sweep &sw = c->sweep, &ss = c->sweep_s;
+    hipStream_t s = c->stream;
+    if (k == 0 || k == 1)
+        ec3d_launch_k1(A, ss, c->state, it, v[EC3D_VEC_P], v[EC3D_VEC_R0], v[EC3D_VEC_AP], c->partials, s);
+    if (k == 0 || k == 2)
+        ec3d_launch_k2(sw, ec3d_src_of(c, true), c->state, it, v[EC3D_VEC_R], v[EC3D_VEC_AP], v[EC3D_VEC_S], c->partials, s);
+    if (k == 0 || k == 3)
+        ec3d_launch_k3(A, ss, c->state, it, v[EC3D_VEC_S], v[EC3D_VEC_AS], c->partials, s);
+    if (k == 0 || k == 4)
+        ec3d_launch_k4(sw, ec3d_src_of(c, false), ec3d_src_of(c, true), c->state, it, v[EC3D_VEC_P], v[EC3D_VEC_S],
+                       v[EC3D_VEC_AS], v[EC3D_VEC_R0], v[EC3D_VEC_X], v[EC3D_VEC_R], c->partials, c->hist,
+                       c->hist_cap, s);
+    if (k == 0 || k == 5)
+        ec3d_launch_k5(sw, ec3d_src_of(c, false), c->state, it, v[EC3D_VEC_R], v[EC3D_VEC_AP], v[EC3D_VEC_P],
+                       v[EC3D_VEC_R0], c->hist, c->hist_cap, s);
+}
+
+void ec3d_launch_iteration(ec3d_ctx *c, const MatView &A, int it) { ec3d_launch_stage(c, A, it, 0); }
+
+int ec3d_launch_begin(ec3d_ctx *c, const MatView &A, double tol)
+{
+    double **v = c->vec;
+    ec3d_launch_residual(A, c->sweep_s, v[EC3D_VEC_X], v[EC3D_VEC_B], v[EC3D_VEC_R], v[EC3D_VEC_R0], v[EC3D_VEC_P],
+                         c->partials, c->stream);
+    ec3d_launch_setup(c->state, ec3d_src_of(c, true), tol, c->stream);
+    EC3D_HIP(hipGetLastError());
+    return 0;
+}
+
+int ec3d_single_rank_only(ec3d_ctx *c, const char *who)
+{
+    if (c->halo > 0 || c->nranks > 1) {
+        ec3d_set_error(std::string(who) + ": this handle holds one z-slab of a multi-rank problem; drive it "
+                                          "with ec3d_dist_step (eddy_currents_3d_amd/dist.py)");
+        return 4;
+    }
+    return 0;
+}
+
+static int ensure_hist(ec3d_ctx *c, int64_t cap)
+{
+    if (cap <= 0) {
+        c->hist_cap = 0;
+        return 0;
+    }
+    if (c->hist) (void)hipFree(c->hist);
+    c->hist = nullptr;
+    EC3D_HIP(hipMalloc(&c->hist, (size_t)cap * 2 * sizeof(double)));
+    EC3D_HIP(hipMemsetAsync(c->hist, 0xFF, (size_t)cap * 2 * sizeof(double), c->stream)); // NaN = "not reached"
+    c->hist_cap = cap;
+    return 0;
+}
+
+static int solve_core(ec3d_ctx *c, double tol, int32_t itmax, int32_t *iter, double *hist_host, int32_t hist_cap,
+                      bool print_on_itmax)
+{
+    const MatView A = c->A.view();
+    const int64_t total = std::max<int64_t>(0, (int64_t)itmax + 1); // src/solvers.f90:25-29
+    int rc = ensure_hist(c, hist_host ? std::min<int64_t>(hist_cap, total) : 0);
+    if (rc) return rc;
+    if ((rc = ec3d_launch_begin(c, A, tol))) return rc;
+
+    // iterations per poll: about 0.4 ms of device work, so an exit is noticed within ~1 ms
+    const double est_us = (double)c->A.n_pad * 264.0 / 4.0e6 + 12.0;
+    const int chunk = (int)std::min<double>(32.0, std::max<double>(1.0, 400.0 / est_us));
+    int64_t launched = 0;
+    int ci = 0;
+    bool stopped = false;
+    while (launched < total && !stopped) {
+        const int64_t m = std::min<int64_t>(chunk, total - launched);
+        for (int64_t i = 0; i < m; ++i) ec3d_launch_iteration(c, A, (int)(++launched));
+        EC3D_HIP(hipGetLastError());
+        EC3D_HIP(hipMemcpyAsync(&c->state_pinned[ci & 1], c->state, sizeof(SolverState), hipMemcpyDeviceToHost,
+                                c->stream));
+        EC3D_HIP(hipEventRecord(c->ev[ci & 1], c->stream));
+        if (ci > 0) {
+            EC3D_HIP(hipEventSynchronize(c->ev[(ci - 1) & 1]));
+            if (c->state_pinned[(ci - 1) & 1].stop_iter != INT_MAX) stopped = true;
+        }
+        ++ci;
+    }
+    EC3D_HIP(hipStreamSynchronize(c->stream));
+    SolverState fin;
+    EC3D_HIP(hipMemcpy(&fin, c->state, sizeof fin, hipMemcpyDeviceToHost));
+    if (fin.stop_iter != INT_MAX) {
+        *iter = fin.stop_iter;
+    } else {
+        *iter = (int32_t)total; // itmax exit: the reference prints norm2(R) and returns (:25-28)
+        if (print_on_itmax) {
+            // ‖R‖ = sqrt(sum of the last K4 partials), summed here in workgroup order
+            std::vector<double> part((size_t)c->sweep.pstride);
+            EC3D_HIP(hipMemcpy(part.data(), c->partials + (size_t)P_RR * c->sweep.pstride,
+                               part.size() * sizeof(double), hipMemcpyDeviceToHost));
+            double s = 0.0;
+            for (int q = 0; q < c->sweep.nblk; ++q) s += part[(size_t)q];
+            if (total == 0) {
+                EC3D_HIP(hipMemcpy(part.data(), c->partials + (size_t)P_RR_INIT * c->sweep.pstride,
+                                   part.size() * sizeof(double), hipMemcpyDeviceToHost));
+                s = 0.0;
+                for (int q = 0; q < c->sweep_s.nblk; ++q) s += part[(size_t)q];
+            }
+            printf(" %.17g\n", std::sqrt(s));
+            fflush(stdout);
+        }
+    }
+    if (hist_host && c->hist_cap > 0)
+        EC3D_HIP(hipMemcpy(hist_host, c->hist, (size_t)c->hist_cap * 2 * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int ec3d_solve_resident(ec3d_handle c, double tolerance, int32_t itmax, int32_t *iter,
+                                   double *resid_hist, int32_t hist_cap)
+{
+    int rc = ec3d_need_matrix(c, "ec3d_solve_resident");
+    if (rc) return rc;
+    if ((rc = ec3d_single_rank_only(c, "ec3d_solve_resident"))) return rc;
+    return solve_core(c, tolerance, itmax, iter, resid_hist, hist_cap, true);
+}
+
+extern "C" int ec3d_solve(ec3d_handle c, const double *b, double *x, double tolerance, int32_t itmax,
+                          int32_t *iter, double *resid_hist, int32_t hist_cap)
+{
+    int rc = ec3d_need_matrix(c, "ec3d_solve");
+    if (rc) return rc;
+    if ((rc = ec3d_single_rank_only(c, "ec3d_solve"))) return rc;
+    if ((rc = ec3d_vec_h2d(c, c->vec[EC3D_VEC_B], b))) return rc;
+    if ((rc = ec3d_vec_h2d(c, c->vec[EC3D_VEC_X], x))) return rc;
+    if ((rc = solve_core(c, tolerance, itmax, iter, resid_hist, hist_cap, true))) return rc;
+    if ((rc = ec3d_vec_d2h(c, x, c->vec[EC3D_VEC_X]))) return rc;
+    EC3D_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
