@@ -192,8 +192,20 @@ static void choose_sweep(ec3d_ctx *c)
             // columns are dealt to the 8 XCD labels in runs of cpx; with tpp % 8 != 0 the last run is short
             // and 8*cpx - tpp workgroups per segment stay idle
             const int64_t cols = (tpp + 7) / 8 * 8;
-            int64_t nseg = std::max<int64_t>(1, (want_s + cols / 2) / cols);
-            nseg = std::min<int64_t>(nseg, std::max<int64_t>(1, nplanes / 8));
+            // z segments per column.  6 workgroups per CU are resident (want_s = 6 * 256): a grid just above
+            // that leaves a second, nearly empty round (2048 at 512^3: +5 %, 1600 at 640^3: +30 % on K1), a
+            // grid well below it wastes latency hiding.  So: the fewest segments that fill one round to
+            // >= 5/6 as full as the columns allow, or else >= 1.5 rounds, where the hardware's dynamic dispatch
+            // evens things out (2400 at 640^3, 3072 at 512^3 are as good as an exact fit).
+            int64_t nseg = 1;
+            const int64_t max_seg = std::max<int64_t>(1, nplanes / 8);
+            if (c->nblk_request > 0 || getenv("EC3D_NBLK_SPMV")) {
+                nseg = std::max<int64_t>(1, (want_s + cols / 2) / cols); // explicit request: nearest
+            } else {
+                const int64_t fit = want_s / cols; // most segments that still fit one round
+                nseg = (fit >= 1 && 6 * cols * fit >= 5 * want_s) ? fit : (3 * want_s + 2 * cols - 1) / (2 * cols);
+            }
+            nseg = std::min<int64_t>(nseg, max_seg);
             ss.zm_tpp = (int)tpp;
             ss.zm_pps = (int)((nplanes + nseg - 1) / nseg);
             ss.nblk = (int)(cols * nseg);
