@@ -1,0 +1,252 @@
+"""Python host for a whole run: what the reference's main program does around the solve.
+
+The library covers assembly, the per-step right-hand side, the solve, the post-update and the field output
+(include/ec3d_hip.h); this module supplies the rest of /root/reference/src/EC3D.f90's time loop for a
+``.vxc`` model, so a file the reference runs can be run on the GPU without the Fortran program:
+
+* the palette's source mini-language (src/vxc2data.f90:416-560, :836-890): ``SRCx=F`` / ``SRCy=F`` materials,
+  ``FUNC`` definitions with named parameters, source velocities ``Vsx/Vsy/Vsz`` given as numbers or functions;
+* the expression evaluator the reference uses for them (src/m_fparser.f90:76-100, :195-240: ``sind cosd tgd
+  sh ch th cth lg ln impls impl2 pos int nint floor ceil atg`` ...);
+* per step (src/EC3D.f90:241-367): function values at time T (times mu0), motion of the source cells
+  (``motion_calc`` / ``new_m``, :1052-1114: accumulated distance in cells, rounded, clamped two cells off the
+  box), the list of (unknown id, value) pairs handed to ``ec3d_rhs_step``;
+* the loop itself (:137-152, :404-455): solve, post-update, ``field_N.vtk`` every ``jump`` (default: every
+  step but the first), ``T += dt`` until ``T >= stop``.
+
+``SRCz`` is parsed but ignored: the reference stores its axis as 'D', never matches it against 'Z' again
+(src/vxc2data.f90:489, :694) and stops in its time loop (src/EC3D.f90:327) -- there is no behaviour to mirror.
+"""
+from __future__ import annotations
+
+import ast
+import math
+import os
+
+import numpy as np
+
+from . import vxc
+from .vtk import write_field_vtk
+
+MU0 = 0.12566370964050292e-05  # src/EC3D.f90:255
+
+
+def _nint(x: float) -> int:
+    """Fortran NINT: nearest integer, halves away from zero."""
+    return int(math.floor(abs(x) + 0.5)) * (1 if x >= 0 else -1)
+
+
+_FUNCS = {
+    "ABS": abs, "EXP": math.exp, "LG": math.log10, "LN": math.log, "SQRT": math.sqrt,
+    "SH": math.sinh, "CH": math.cosh, "TH": lambda x: math.sinh(x) / math.cosh(x),
+    "CTH": lambda x: math.cosh(x) / math.sinh(x),
+    "SIND": lambda x: math.sin(math.radians(x)), "COSD": lambda x: math.cos(math.radians(x)),
+    "TGD": lambda x: math.tan(math.radians(x)),
+    "SIN": math.sin, "COS": math.cos, "TG": math.tan, "ASIN": math.asin, "ACOS": math.acos,
+    "IMPLS": lambda x: 1.0 if x > 0.0 else 0.0, "IMPL2": lambda x: 1.0 if x >= 0.0 else -1.0,
+    "POS": lambda x: x if x > 0.0 else 0.0, "INT": lambda x: float(math.trunc(x)),
+    "NINT": lambda x: float(_nint(x)), "FLOOR": lambda x: float(math.floor(x)),
+    "CEIL": lambda x: float(math.ceil(x)), "ATG": math.atan,
+}
+
+
+class Expression:
+    """One FUNC right-hand side (upper-cased, as the reference sees it after ``Upp``)."""
+
+    def __init__(self, text: str):
+        self.text = text
+        self.tree = ast.parse(text.replace("^", "**"), mode="eval").body
+
+    def __call__(self, variables: dict) -> float:
+        def ev(n):
+            if isinstance(n, ast.Constant) and isinstance(n.value, (int, float)):
+                return float(n.value)
+            if isinstance(n, ast.Name):
+                return float(variables[n.id])
+            if isinstance(n, ast.UnaryOp) and isinstance(n.op, (ast.USub, ast.UAdd)):
+                v = ev(n.operand)
+                return -v if isinstance(n.op, ast.USub) else v
+            if isinstance(n, ast.BinOp):
+                a, b = ev(n.left), ev(n.right)
+                if isinstance(n.op, ast.Add): return a + b
+                if isinstance(n.op, ast.Sub): return a - b
+                if isinstance(n.op, ast.Mult): return a * b
+                if isinstance(n.op, ast.Div): return a / b
+                if isinstance(n.op, ast.Pow): return a ** b
+            if isinstance(n, ast.Call) and isinstance(n.func, ast.Name) and n.func.id in _FUNCS and len(n.args) == 1:
+                return float(_FUNCS[n.func.id](ev(n.args[0])))
+            raise ValueError(f"unsupported construct in source expression {self.text!r}")
+        return ev(self.tree)
+
+
+class _Func:
+    def __init__(self, name):
+        self.name, self.expr, self.argnames, self.argvals = name, None, [], []
+
+    def value(self, T):
+        if self.expr is None:
+            raise ValueError(f"source function {self.name} is used but has no FUNC definition")
+        v = {a: (T if a == "T" else x) for a, x in zip(self.argnames, self.argvals)}
+        return self.expr(v)
+
+
+class SourceProgram:
+    """The independent sources of a model: which unknowns they act on and with what value at time T."""
+
+    def __init__(self, model: vxc.VxcModel, tables: dict):
+        vox = model.vox
+        self.sdz, self.sdy, self.sdx = vox.shape
+        self.ncells = vox.size
+        self.delta = np.asarray(tables["delta"], np.float64)
+        self.dt = float(tables["dt"])
+        nsub = tables["nsub"]
+        consts = dict(PI=math.pi, E=0.27182818284590451e+001, MU0=MU0, E0=vxc.E0, DT=self.dt, DX=self.delta[0],
+                      DY=self.delta[1], DZ=self.delta[2], TIME=float(tables["time"] or 0.0), NX=self.sdx,
+                      NY=self.sdy, NZ=self.sdz)
+        self.funs = []    # one per SRC keyword: dict(mat, axis, f, vel=[const or None]*3, mech=[_Func or None]*3, move)
+        defs = {}         # name -> _Func (shared by every use of the name, as nameFun / nameVmech matching does)
+
+        def func(name):
+            return defs.setdefault(name, _Func(name))
+
+        lines = [nm.replace("=", " ").split() for nm in model.names]
+        for kp, w in enumerate(lines, start=1):
+            W = [x.upper() for x in w]
+            for i in range(1, len(W)):
+                if W[i][:1] == "D" and kp <= nsub and not W[i].startswith("DIR"):
+                    if i + 2 < len(W) and "SRC" in W[i + 2]:            # src/vxc2data.f90:478
+                        for j in range(i + 2, len(W) - 1):
+                            ax = {"SRCX": 0, "SRCY": 1}.get(W[j])
+                            if ax is None:
+                                continue                                # SRCZ: see the module docstring
+                            f = dict(mat=kp, axis=ax, f=func(W[j + 1]), vel=[0.0] * 3, mech=[None] * 3, move=[0] * 3)
+                            for n in range(1, 7):                       # calcVmech (:844-888): Vs? name/number pairs
+                                if j + 1 + n + 1 > len(W) - 1:
+                                    continue
+                                key = W[j + 1 + n]
+                                d = 0 if "VSX" in key else 1 if "VSY" in key else 2 if "VSZ" in key else None
+                                if d is None:
+                                    continue
+                                val = w[j + 1 + n + 1]
+                                f["move"][d] = 1
+                                if val[:1].upper().isalpha():           # a function name
+                                    f["mech"][d] = func(val.upper())
+                                else:                                   # a number or a quoted expression
+                                    f["vel"][d] = vxc.evaluate(val, consts)
+                            self.funs.append(f)
+                    break
+                if "FUNC" in W[i] and i + 2 < len(W):                   # :497-548
+                    fn = func(W[i + 1])
+                    fn.expr = Expression(W[i + 2])
+                    fn.argnames, fn.argvals = [], []
+                    for a, b in zip(W[i + 3::2], w[i + 4::2]):
+                        fn.argnames.append(a[:8])
+                        fn.argvals.append(0.0 if b.strip("'\"").upper() == "T" else vxc.evaluate(b, consts))
+                    break
+        flat = vox.reshape(-1)
+        for f in self.funs:   # cells of the material, in the order the reference's LIFO list yields them
+            f["nodes"] = (np.flatnonzero(flat == f["mat"])[::-1] + 1).astype(np.int64)   # 1-based cell ids
+            f["distance"] = np.zeros(3)
+            f["shift"] = np.array([f["vel"][d] * self.dt / self.delta[d] if f["move"][d] and f["mech"][d] is None
+                                   else 0.0 for d in range(3)])
+        self.moving = any(any(f["move"]) for f in self.funs)           # flag_move, src/EC3D.f90:158-187
+        self.movestop = [1, 1, 1]
+
+    def _moved(self, f):
+        """new_m for all nodes of one function (src/EC3D.f90:1064-1114)."""
+        sd = (self.sdx, self.sdy, self.sdz)
+        m = f["nodes"] - 1
+        pos = [m % self.sdx + 1, (m // self.sdx) % self.sdy + 1, m // (self.sdx * self.sdy) + 1]
+        new = []
+        for d in (2, 1, 0):   # the reference tests z, then y, then x
+            p = pos[d] + int(f["length"][d])
+            hi, lo = sd[d] - 2, 2
+            clamped = (p > hi) | (p < lo)
+            p = np.clip(p, lo, hi)
+            # movestop(d) after the reference's node-by-node pass: a clamped node clears it, a later node that
+            # is inside the range sets it again
+            inside = ~clamped & ((p < hi) | (p > lo))
+            if clamped.any():
+                last = int(np.flatnonzero(clamped)[-1])
+                self.movestop[d] = 1 if inside[last + 1:].any() else 0
+            elif self.movestop[d] == 0 and inside.any():
+                self.movestop[d] = 1
+            new.append(p)
+        Lz, jy, ix = new
+        return ix + self.sdx * (jy - 1) + self.sdx * self.sdy * (Lz - 1)
+
+    def step(self, T: float):
+        """(src_index, src_value, moving) for ec3d_rhs_step at time T; advances the motion state."""
+        idx, val = [], []
+        mech_cache = {}
+        for f in self.funs:
+            a = f["f"].value(T) * MU0
+            nodes = f["nodes"]
+            if self.moving:
+                for d in range(3):                                      # motion_calc, :1052-1062
+                    if f["mech"][d] is None:
+                        f["distance"][d] += self.movestop[0] * f["shift"][d]
+                    else:
+                        fn = f["mech"][d]
+                        if fn.name not in mech_cache:
+                            mech_cache[fn.name] = fn.value(T)
+                        f["distance"][d] += mech_cache[fn.name] * self.dt / self.delta[d]
+                f["length"] = [_nint(x) for x in f["distance"]]
+                nodes = self._moved(f)
+            idx.append(nodes + f["axis"] * self.ncells)
+            val.append(np.full(len(nodes), a))
+        if not idx:
+            return np.zeros(0, np.int32), np.zeros(0), self.moving
+        return np.concatenate(idx).astype(np.int32), np.concatenate(val), self.moving
+
+
+def run(model: vxc.VxcModel, solver, steps: int | None = None, out_dir: str | None = None, on_step=None,
+        on_rhs=None, on_solved=None):
+    """The reference's run of ``model`` on ``solver`` (an EC3DSolver): assemble, then step until T >= stop (or
+    ``steps`` steps).  Returns a list of per-step dicts (T, iter).  ``out_dir``: write ``field_N.vtk`` there at
+    the reference's output cadence.  Hooks, all ``(k, solver, info)``: ``on_rhs`` when Jaf (B) of step k is
+    built -- what the reference passes to its solver --, ``on_solved`` when Uaf (X) holds the solver's result,
+    ``on_step`` after the post-update."""
+    t = vxc.domain_tables(model)
+    if t["dt"] is None or t["time"] is None:
+        raise ValueError("the model has no 'tran stop=... step=...' line")
+    solver.assemble(t["geoPHYS"], t["geoPHYS_C"], t["valPHYS"], t["BND"], t["delta"], t["dt"])
+    n = solver.n
+    solver.upload("X", np.zeros(n))
+    solver.upload("B", np.zeros(n))
+    prog = SourceProgram(model, t)
+    sdz, sdy, sdx = model.vox.shape
+    conducting = t["ncells0"] > 0
+    DT, Time = float(t["dt"]), float(t["time"])
+    DTT = float(t["jump"] or 0.0)                        # src/vxc2data.f90:191-195: unset -> 0 -> every step
+    Nout = _nint(DTT / DT)
+    T, Ntime, Nprint, Npoint = 0.0, 0, Nout, 0           # src/EC3D.f90:137-144
+    if out_dir:
+        os.makedirs(out_dir, exist_ok=True)
+    log = []
+    while True:
+        idx, val, moving = prog.step(T)
+        info = dict(T=T, nsrc=len(idx))
+        solver.rhs_step(idx, val, moving=moving)
+        if on_rhs is not None:
+            on_rhs(len(log), solver, info)
+        it, _ = solver.solve_resident(t["tol"], t["itmax"])
+        info["iter"] = it
+        if on_solved is not None:
+            on_solved(len(log), solver, info)
+        solver.post_update()
+        if Ntime >= Nprint and Ntime != 0:               # :437-446
+            Nprint = Ntime + Nout
+            Npoint += 1
+            if out_dir:
+                f = solver.vtk_fields(t["delta"], sdx * sdy * sdz, conducting)
+                write_field_vtk(os.path.join(out_dir, f"field_{Npoint}.vtk"), sdx, sdy, sdz, t["delta"], f)
+            info["output"] = Npoint
+        log.append(info)
+        if on_step is not None:
+            on_step(len(log) - 1, solver, info)
+        Ntime += 1
+        T = T + DT
+        if not T < Time or (steps is not None and len(log) >= steps):
+            break
+    return log

@@ -1,0 +1,60 @@
+"""CPU-only: the palette source language and the motion of the sources (eddy_currents_3d_amd/host.py) on the
+reference's three shipped inputs.  At T = 0 nothing but the sources is in the right-hand side, so its norm is
+the ||b|| the unmodified reference handed to its solver in step 0 (tests/golden/g4_*)."""
+import math
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+
+def _program(case):
+    from eddy_currents_3d_amd import host, vxc
+    g = load_golden("g4_" + case)
+    model = vxc.VxcModel(g["vox"], [str(s) for s in g["names"]], float(str(g["lattice_dim"])),
+                         tuple(float(x) for x in g["adj"]))
+    t = vxc.domain_tables(model)
+    return g, model, t, host.SourceProgram(model, t)
+
+
+@pytest.mark.parametrize("case,nfun,moving", [("compare_to_Elmer", 4, False), ("ec_src_move_hole", 4, True),
+                                              ("LIM", 12, True)])
+def test_step0_sources_equal_the_reference_rhs(case, nfun, moving):
+    g, model, t, prog = _program(case)
+    assert len(prog.funs) == nfun and prog.moving == moving
+    idx, val, mv = prog.step(0.0)
+    assert mv == moving and idx.min() >= 1 and idx.max() <= 2 * model.vox.size   # X and Y components only
+    b = np.zeros(3 * model.vox.size)
+    b[idx - 1] = val
+    assert np.linalg.norm(b) == pytest.approx(float(g["bnorm"][0]), rel=1e-14)
+
+
+def test_source_motion_follows_the_velocity_functions():
+    """ec_src_move_hole: Vsx = Vmx(t) = a*2pi*f*sin(2pi f t), Vsy = Vmy(t) = -b*2pi*f*cos(2pi f t): the coil
+    starts moving in -y; the accumulated distance is rounded to whole cells (src/EC3D.f90:1052-1062)."""
+    g, model, t, prog = _program("ec_src_move_hole")
+    sdz, sdy, sdx = model.vox.shape
+    dist = np.zeros(2)
+    for k in range(5):
+        T = k * t["dt"]
+        idx, _, _ = prog.step(T)
+        w = 2 * math.pi * 25
+        dist += np.array([t["delta"][0] * (sdx - 42) / 2 * w * math.sin(w * T),
+                          -t["delta"][1] * (sdy - 42) / 2 * w * math.cos(w * T)]) * t["dt"] / np.asarray(t["delta"])[:2]
+        f = prog.funs[0]
+        assert list(f["length"][:2]) == [int(math.floor(abs(d) + 0.5)) * (1 if d >= 0 else -1) for d in dist]
+        cells0 = f["nodes"] - 1
+        moved = idx[:len(cells0)] - 1
+        assert np.array_equal(moved % sdx, cells0 % sdx + f["length"][0])
+        assert np.array_equal((moved // sdx) % sdy, (cells0 // sdx) % sdy + f["length"][1])
+
+
+def test_expression_functions():
+    from eddy_currents_3d_amd.host import Expression
+    v = dict(A=2.0, T=0.25)
+    assert Expression("A*COSD(360*T)+IMPL2(-1)+IMPLS(0)+POS(-3)+NINT(2.5)+INT(-1.7)")(v) == pytest.approx(
+        2.0 * math.cos(math.pi / 2) - 1.0 + 0.0 + 0.0 + 3.0 - 1.0)
+    assert Expression("A^3-LG(100)+LN(EXP(1))+TH(0)+ATG(0)")(v) == pytest.approx(8.0 - 2.0 + 1.0)
+    with pytest.raises(ValueError):
+        Expression("__IMPORT__(1)")(v)
