@@ -14,7 +14,8 @@ The library covers assembly, the per-step right-hand side, the solve, the post-u
 * the loop itself (:137-152, :404-455): solve, post-update, ``field_N.vtk`` every ``jump`` (default: every
   step but the first), ``T += dt`` until ``T >= stop``.
 
-``SRCz`` is parsed but ignored: the reference stores its axis as 'D', never matches it against 'Z' again
+Both output files of the reference are written: ``field_N.vtk`` (fields from the device) and ``src_N.vtk`` (the
+source cells as hexahedra).  ``SRCz`` is parsed but ignored: the reference stores its axis as 'D', never matches it against 'Z' again
 (src/vxc2data.f90:489, :694) and stops in its time loop (src/EC3D.f90:327) -- there is no behaviour to mirror.
 """
 from __future__ import annotations
@@ -26,7 +27,7 @@ import os
 import numpy as np
 
 from . import vxc
-from .vtk import write_field_vtk
+from .vtk import write_field_vtk, write_src_vtk
 
 MU0 = 0.12566370964050292e-05  # src/EC3D.f90:255
 
@@ -178,6 +179,7 @@ class SourceProgram:
     def step(self, T: float):
         """(src_index, src_value, moving) for ec3d_rhs_step at time T; advances the motion state."""
         idx, val = [], []
+        self.groups = []   # what src_N.vtk shows: per function (axis, cells of one component, value)
         mech_cache = {}
         for f in self.funs:
             a = f["f"].value(T) * MU0
@@ -195,6 +197,7 @@ class SourceProgram:
                 nodes = self._moved(f)
             idx.append(nodes + f["axis"] * self.ncells)
             val.append(np.full(len(nodes), a))
+            self.groups.append((f["axis"], nodes, a))
         if not idx:
             return np.zeros(0, np.int32), np.zeros(0), self.moving
         return np.concatenate(idx).astype(np.int32), np.concatenate(val), self.moving
@@ -241,6 +244,8 @@ def run(model: vxc.VxcModel, solver, steps: int | None = None, out_dir: str | No
             if out_dir:
                 f = solver.vtk_fields(t["delta"], sdx * sdy * sdz, conducting)
                 write_field_vtk(os.path.join(out_dir, f"field_{Npoint}.vtk"), sdx, sdy, sdz, t["delta"], f)
+                if prog.groups:                          # :446  CALL writeVtk_src
+                    write_src_vtk(os.path.join(out_dir, f"src_{Npoint}.vtk"), sdx, sdy, sdz, t["delta"], prog.groups)
             info["output"] = Npoint
         log.append(info)
         if on_step is not None:

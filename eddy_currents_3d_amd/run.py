@@ -4,8 +4,8 @@
 
 Reads the file (eddy_currents_3d_amd/vxc.py), assembles the A-V system on the device, and runs the
 reference's time loop (eddy_currents_3d_amd/host.py) with the fields resident in HBM; ``field_N.vtk`` files
-go to ``--out`` (default: the ``dir=`` name of the model's solver line, as the reference does).  Not written:
-the reference's second file per output step (``src_N.vtk``, the coil cells as hexahedra).
+and ``src_N.vtk`` files go to ``--out`` (default: the ``dir=`` name of the model's solver line, as the
+reference does).
 """
 from __future__ import annotations
 

@@ -1,7 +1,8 @@
 """Legacy-VTK field file exactly as the reference writes it (writeVtk_field,
 /root/reference/src/utilites.f90:171-293): big-endian binary STRUCTURED_GRID with float32 points and
 the point vectors Field_A, [Vector_field_eddy,] Vector_field_SOURCE, Vector_field_B.  The vectors come
-from the device (EC3DSolver.vtk_fields); this module only formats the bytes."""
+from the device (EC3DSolver.vtk_fields); this module only formats the bytes.  Also the reference's second
+file per output step, src_N.vtk (writeVtk_src, src/utilites.f90:3-168): the source cells as hexahedra."""
 from __future__ import annotations
 
 import numpy as np
@@ -41,3 +42,38 @@ def field_vtk_bytes(sdx, sdy, sdz, delta, fields) -> bytes:
 def write_field_vtk(path, sdx, sdy, sdz, delta, fields):
     with open(path, "wb") as f:
         f.write(field_vtk_bytes(sdx, sdy, sdz, delta, fields))
+
+
+def src_vtk_bytes(sdx, sdy, sdz, delta, groups) -> bytes:
+    """src_N.vtk (src/utilites.f90:3-168): big-endian UNSTRUCTURED_GRID, one hexahedron (VTK type 11) per
+    source cell with 8 double-precision corner points, and the cell vector Vector_field_SRC.
+    groups: per source function, in the reference's order, (axis 0/1/2, cell ids (1-based, within one
+    component), value) -- the cells where the function acts this step and its value (already times mu0)."""
+    ncell = sum(len(g[1]) for g in groups)
+    out = [b"# vtk DataFile Version 3.0\nout data result\nBINARY\n", b"DATASET UNSTRUCTURED_GRID\n",
+           ("POINTS %s double\n" % _i8(8 * ncell)).encode()]
+    d = np.asarray(delta, np.float64)
+    corner = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0], [0, 0, 1], [1, 0, 1], [0, 1, 1], [1, 1, 1]])
+    for _, cells, _ in groups:                                  # find_coord / write_coord, :107-166
+        m = np.asarray(cells, np.int64) - 1
+        ijk = np.stack([m % sdx + 1, (m // sdx) % sdy + 1, m // (sdx * sdy) + 1], axis=1)   # 1-based i, j, k
+        p = (ijk[:, None, :] + corner[None, :, :]).astype(np.float64) * d - d            # REAL(i,8)*delta - delta
+        out.append(p.astype(">f8").tobytes())
+    out += [b"\n", ("CELLS %s %s\n" % (_i8(ncell), _i8(9 * ncell))).encode()]
+    conn = np.empty((ncell, 9), ">i4")
+    conn[:, 0] = 8
+    conn[:, 1:] = 8 * np.arange(ncell)[:, None] + np.arange(8)[None, :]
+    out += [conn.tobytes(), b"\n", ("CELL_TYPES %s\n" % _i8(ncell)).encode(),
+            np.full(ncell, 11, ">i4").tobytes(), b"\n", ("CELL_DATA %s\n" % _i8(ncell)).encode(),
+            b"VECTORS Vector_field_SRC double\n"]
+    for axis, cells, value in groups:
+        v = np.zeros((len(cells), 3), ">f8")
+        v[:, axis] = value
+        out.append(v.tobytes())
+    out.append(b"\n")
+    return b"".join(out)
+
+
+def write_src_vtk(path, sdx, sdy, sdz, delta, groups):
+    with open(path, "wb") as f:
+        f.write(src_vtk_bytes(sdx, sdy, sdz, delta, groups))

@@ -109,7 +109,7 @@ def run_reference(vox, names, lattice_dim, adj=(1, 1, 1), max_calls=3, all_matri
         vtk = {}
         for root, _, files in os.walk(td):
             for fn in files:
-                if fn.startswith("field_") and fn.endswith(".vtk"):
+                if fn.startswith(("field_", "src_")) and fn.endswith(".vtk"):
                     with open(os.path.join(root, fn), "rb") as f:
                         vtk[fn] = f.read()
         calls[0]["vtk"] = vtk
@@ -279,6 +279,18 @@ def case_g3():
     save("g3_moving_coil_18x16x12", vox=vox, geoPHYS=geo, geoPHYS_C=geoC, delta=np.full(3, 0.004),
          dt=np.float64(1e-3), BND=np.full((3, 2), -0.95), valPHYS=valPHYS, **pack_calls(calls))
     return calls
+
+
+def case_g3_src_vtk():
+    """The reference's second output file (src_N.vtk: the coil cells as hexahedra with their source vector,
+    src/utilites.f90:3-168) for the moving-coil case, with the palette it was run on."""
+    inp = inputs_g3()
+    calls, log = run_reference(**inp)
+    vtk = {k: v for k, v in calls[0]["vtk"].items() if k.startswith("src_")}
+    assert vtk, "the reference wrote no src_N.vtk"
+    save("g3_src_vtk", vox=inp["vox"], names=np.array(inp["names"]), lattice_dim=np.array(inp["lattice_dim"]),
+         adj=np.array(inp["adj"], np.float64),
+         **{"vtk_" + k.replace(".vtk", ""): np.frombuffer(v, np.uint8) for k, v in vtk.items()})
 
 
 def case_g4():

@@ -36,7 +36,7 @@ def test_shipped_input_runs_like_the_reference(case, tmp_path):
         log = host.run(model, s, steps=3, out_dir=str(tmp_path), on_rhs=on_rhs, on_solved=on_solved)
         assert s.n == int(g["n"]) and s.info.nnz == int(g["nnz"])
     assert len(log) == 3 and [i.get("output") for i in log] == [None, 1, 2]
-    assert sorted(os.listdir(tmp_path)) == ["field_1.vtk", "field_2.vtk"]
+    assert sorted(os.listdir(tmp_path)) == ["field_1.vtk", "field_2.vtk", "src_1.vtk", "src_2.vtk"]
     for k, info in enumerate(seen):
         it_ref = int(g["iters"][k])
         print(f"{case} step {k}: iter {info['iter']} / reference {it_ref}; ||b|| {info['bnorm']:.9e} / "

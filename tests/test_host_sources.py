@@ -58,3 +58,20 @@ def test_expression_functions():
     assert Expression("A^3-LG(100)+LN(EXP(1))+TH(0)+ATG(0)")(v) == pytest.approx(8.0 - 2.0 + 1.0)
     with pytest.raises(ValueError):
         Expression("__IMPORT__(1)")(v)
+
+
+def test_source_cell_file_is_the_reference_file():
+    """src_N.vtk of the moving-coil case (constant Vsx, FUNC Vsy): bytes equal to what the unmodified reference
+    wrote (tests/golden/g3_src_vtk.npz, oracle/make_goldens.py case_g3_src_vtk) at its output points 1 and 2."""
+    from eddy_currents_3d_amd import host, vxc
+    from eddy_currents_3d_amd.vtk import src_vtk_bytes
+    g = load_golden("g3_src_vtk")
+    model = vxc.VxcModel(g["vox"], [str(s) for s in g["names"]], float(str(g["lattice_dim"])),
+                         tuple(float(x) for x in g["adj"]))
+    t = vxc.domain_tables(model)
+    prog = host.SourceProgram(model, t)
+    sdz, sdy, sdx = model.vox.shape
+    for k in range(3):                        # output point N is written at the end of step N (N >= 1)
+        prog.step(k * t["dt"])
+        if k >= 1:
+            assert src_vtk_bytes(sdx, sdy, sdz, t["delta"], prog.groups) == g[f"vtk_src_{k}"].tobytes(), k
