@@ -255,3 +255,59 @@ def run(model: vxc.VxcModel, solver, steps: int | None = None, out_dir: str | No
         if not T < Time or (steps is not None and len(log) >= steps):
             break
     return log
+
+
+def run_slabs(model: vxc.VxcModel, rank: int, world: int, device: int = 0, steps: int | None = None,
+              out_dir: str | None = None, on_step=None):
+    """The same run on ``world`` GPUs, one process per GPU (torch.distributed initialised by the caller):
+    z-slabs of the A-V system (eddy_currents_3d_amd/dist.py), every rank evaluates the (tiny) source program
+    itself and keeps its part of the fields resident; rank 0 writes the output files.  Returns the per-step
+    log (identical on all ranks)."""
+    from .dist import HipAVSlabOps, SlabSolver, slab_bounds
+    t = vxc.domain_tables(model)
+    if t["dt"] is None or t["time"] is None:
+        raise ValueError("the model has no 'tran stop=... step=...' line")
+    sdz, sdy, sdx = model.vox.shape
+    k0, k1 = slab_bounds(sdz, rank, world)
+    ops = HipAVSlabOps(t["geoPHYS"], t["geoPHYS_C"], t["valPHYS"], t["BND"], t["delta"], t["dt"], k0, k1, world,
+                       device=device)
+    s = SlabSolver(ops, rank, world, k0, k1)
+    n = 3 * model.vox.size + t["ncells0"]
+    ops.set_vector_global("X", np.zeros(n))
+    ops.set_vector_global("B", np.zeros(n))
+    prog = SourceProgram(model, t)
+    conducting = t["ncells0"] > 0
+    DT, Time = float(t["dt"]), float(t["time"])
+    Nout = _nint(float(t["jump"] or 0.0) / DT)
+    T, Ntime, Nprint, Npoint = 0.0, 0, Nout, 0
+    if out_dir and rank == 0:
+        os.makedirs(out_dir, exist_ok=True)
+    log = []
+    try:
+        while True:
+            idx, val, moving = prog.step(T)
+            s.rhs_step(idx, val, moving=moving)
+            it = s.solve(t["tol"], t["itmax"])
+            s.post_update()
+            info = dict(T=T, iter=it)
+            if Ntime >= Nprint and Ntime != 0:
+                Nprint = Ntime + Nout
+                Npoint += 1
+                info["output"] = Npoint
+                if out_dir:
+                    f = s.vtk_fields(t["delta"], conducting)      # gathered on rank 0
+                    if rank == 0:
+                        write_field_vtk(os.path.join(out_dir, f"field_{Npoint}.vtk"), sdx, sdy, sdz, t["delta"], f)
+                        if prog.groups:
+                            write_src_vtk(os.path.join(out_dir, f"src_{Npoint}.vtk"), sdx, sdy, sdz, t["delta"],
+                                          prog.groups)
+            log.append(info)
+            if on_step is not None:
+                on_step(len(log) - 1, s, info)
+            Ntime += 1
+            T = T + DT
+            if not T < Time or (steps is not None and len(log) >= steps):
+                break
+    finally:
+        ops.close()
+    return log

@@ -1,6 +1,7 @@
 """Run a VoxCad ``.vxc`` model the way the reference program does, on one MI355X.
 
     python -m eddy_currents_3d_amd.run model.vxc [--steps N] [--out DIR] [--device D]
+    python -m torch.distributed.run --nproc-per-node G -m eddy_currents_3d_amd.run model.vxc ...   (G GPUs)
 
 Reads the file (eddy_currents_3d_amd/vxc.py), assembles the A-V system on the device, and runs the
 reference's time loop (eddy_currents_3d_amd/host.py) with the fields resident in HBM; ``field_N.vtk`` files
@@ -10,6 +11,7 @@ reference does).
 from __future__ import annotations
 
 import argparse
+import os
 import sys
 import time
 
@@ -36,9 +38,25 @@ def main(argv=None):
         print(f"step {k:4d}  T={info['T']:.6g}  iter={info['iter']}"
               + (f"  -> field_{info['output']}.vtk" if "output" in info and out_dir else ""), flush=True)
 
-    with EC3DSolver(device=a.device) as s:
-        log = host.run(model, s, steps=a.steps, out_dir=out_dir, on_step=on_step)
-        n = s.n
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:   # one process per GPU: z-slabs, halo exchange and reductions over RCCL
+        import torch
+        import torch.distributed as dist
+        rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        try:
+            log = host.run_slabs(model, rank, world, device=local, steps=a.steps, out_dir=out_dir,
+                                 on_step=on_step if rank == 0 else None)
+        finally:
+            dist.destroy_process_group()
+        if rank != 0:
+            return 0
+        n = 3 * model.vox.size + t["ncells0"]
+    else:
+        with EC3DSolver(device=a.device) as s:
+            log = host.run(model, s, steps=a.steps, out_dir=out_dir, on_step=on_step)
+            n = s.n
     wall = time.perf_counter() - t0
     its = sum(i["iter"] for i in log)
     print(f"{len(log)} steps, {its} solver iterations, n={n}, {wall:.2f} s wall "

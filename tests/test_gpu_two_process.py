@@ -125,3 +125,42 @@ def test_two_ranks_run_the_av_time_loop(tmp_path):
         rel = np.linalg.norm(x - xr) / np.linalg.norm(xr)
         print(f"step {k}: iter 2 ranks {it} / reference {int(it_ref)}, rel diff {rel:.2e}")
         assert rel <= 10 * tol
+
+
+def _host_worker(rank, world, port, out):
+    """host.run_slabs: the reference's whole run of a model (sources, motion, time loop, output) on two ranks."""
+    import sys
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import torch
+    import torch.distributed as dist
+    from conftest import load_golden
+    from eddy_currents_3d_amd import host, vxc
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    try:
+        g = load_golden("g4_LIM")
+        model = vxc.VxcModel(g["vox"], [str(s) for s in g["names"]], float(str(g["lattice_dim"])),
+                             tuple(float(x) for x in g["adj"]))
+        log = host.run_slabs(model, rank, world, device=0, steps=3, out_dir=out if rank == 0 else out)
+        if rank == 0:
+            np.save(os.path.join(out, "iters.npy"), np.array([i["iter"] for i in log]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_run_a_shipped_model_end_to_end(tmp_path):
+    """LIM.vxc (12 coil materials, three-phase currents, moving primary, anisotropic grid) on two ranks: the
+    reference's iteration counts, and output files equal to the single-GPU run's up to the solver tolerance."""
+    from conftest import load_golden
+    out = str(tmp_path)
+    mp.spawn(_host_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    g = load_golden("g4_LIM")
+    iters = np.load(os.path.join(out, "iters.npy"))
+    print("2 ranks:", iters, "reference:", g["iters"])
+    assert np.all(np.abs(iters - g["iters"]) <= np.maximum(3, 0.15 * g["iters"]))
+    assert sorted(f for f in os.listdir(out) if f.endswith(".vtk")) == ["field_1.vtk", "field_2.vtk", "src_1.vtk",
+                                                                        "src_2.vtk"]
