@@ -23,10 +23,14 @@ def main(argv=None):
     ap.add_argument("--out", default=None, help="directory for field_N.vtk (default: the model's dir= name)")
     ap.add_argument("--no-output", action="store_true", help="do not write VTK files")
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--refine", type=int, nargs=3, metavar=("FX", "FY", "FZ"), default=None,
+                    help="split every cell FX x FY x FZ times first (same physical size, finer grid)")
     a = ap.parse_args(argv)
 
     from . import EC3DSolver, host, vxc
     model = vxc.read_vxc(a.model)
+    if a.refine:
+        model = vxc.refine(model, *a.refine)
     t = vxc.domain_tables(model)
     sdz, sdy, sdx = model.vox.shape
     out_dir = None if a.no_output else (a.out or str(t["directory"]).upper())
