@@ -231,6 +231,16 @@ def domain_tables(model: VxcModel):
                     elif W[jx] in ("SRCX", "SRCY", "SRCZ"):
                         sources[kp] = (W[jx][-1], W[jx + 1])
                 break
+            if "ENVIRON" in W[i]:                 # :571-592: properties of the LAST environment domain
+                for jx in range(i + 1, len(W) - 1):
+                    if W[jx][:1] == "D": valPHYS[nsub_glob - 1, 0] = evaluate(w[jx + 1], consts)
+                    elif W[jx][:1] == "C":
+                        valPHYS[nsub_glob - 1, 1] = evaluate(w[jx + 1], consts)
+                        if valPHYS[nsub_glob - 1, 1] != 0.0:
+                            conductors.append(nsub_glob)
+                    elif "VEX" in W[jx]: valPHYS[nsub_glob - 1, 2] = evaluate(w[jx + 1], consts)
+                    elif "VEY" in W[jx]: valPHYS[nsub_glob - 1, 3] = evaluate(w[jx + 1], consts)
+                    elif "VEZ" in W[jx]: valPHYS[nsub_glob - 1, 4] = evaluate(w[jx + 1], consts)
             if "BOUNDARY" in W[i]:
                 for a, b in zip(W[i + 1::2], w[i + 2::2]):
                     val = evaluate(b, consts)
