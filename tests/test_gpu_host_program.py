@@ -48,3 +48,18 @@ def test_shipped_input_runs_like_the_reference(case, tmp_path):
         assert info["xnorm"] == pytest.approx(float(g["xnorm"][k]), rel=10 * tol)
         assert np.abs(info["xprobe"] - g["xprobe"][k]).max() <= 10 * tol * np.abs(g["xprobe"][k]).max()
         assert abs(info["iter"] - it_ref) <= max(5, 0.3 * it_ref)
+
+
+def test_command_line_runs_a_vxc_file(tmp_path, capsys):
+    """python -m eddy_currents_3d_amd.run: a ZLIB-compressed .vxc file in, the reference's output files out."""
+    from eddy_currents_3d_amd import run, vxc
+    g = load_golden("g4_compare_to_Elmer")
+    model = vxc.VxcModel(g["vox"], [str(s) for s in g["names"]], float(str(g["lattice_dim"])),
+                         tuple(float(x) for x in g["adj"]))
+    path = str(tmp_path / "model.vxc")
+    vxc.write_vxc(path, model, compression="ZLIB")
+    out = str(tmp_path / "vec")
+    assert run.main([path, "--steps", "3", "--out", out]) == 0
+    text = capsys.readouterr().out
+    assert "iter=173" in text and "iter=160" in text and "iter=80" in text     # the reference's counts
+    assert sorted(os.listdir(out)) == ["field_1.vtk", "field_2.vtk", "src_1.vtk", "src_2.vtk"]
