@@ -285,9 +285,12 @@ def case_g3_src_vtk():
     """The reference's second output file (src_N.vtk: the coil cells as hexahedra with their source vector,
     src/utilites.f90:3-168) for the moving-coil case, with the palette it was run on."""
     inp = inputs_g3()
+    # long enough for the coil to run into the clamp two cells off the box (src/EC3D.f90:1064-1114)
+    inp["names"] = [n.replace("stop=4m", "stop=24m") for n in inp["names"]]
+    inp["max_calls"] = 24
     calls, log = run_reference(**inp)
     vtk = {k: v for k, v in calls[0]["vtk"].items() if k.startswith("src_")}
-    assert vtk, "the reference wrote no src_N.vtk"
+    assert len(vtk) >= 20, "the reference wrote too few src_N.vtk"
     save("g3_src_vtk", vox=inp["vox"], names=np.array(inp["names"]), lattice_dim=np.array(inp["lattice_dim"]),
          adj=np.array(inp["adj"], np.float64),
          **{"vtk_" + k.replace(".vtk", ""): np.frombuffer(v, np.uint8) for k, v in vtk.items()})

@@ -62,7 +62,9 @@ def test_expression_functions():
 
 def test_source_cell_file_is_the_reference_file():
     """src_N.vtk of the moving-coil case (constant Vsx, FUNC Vsy): bytes equal to what the unmodified reference
-    wrote (tests/golden/g3_src_vtk.npz, oracle/make_goldens.py case_g3_src_vtk) at its output points 1 and 2."""
+    wrote (tests/golden/g3_src_vtk.npz, oracle/make_goldens.py case_g3_src_vtk) at every output point of a
+    24-step run -- long enough for the coil to reach the clamp two cells off the box (src/EC3D.f90:1064-1114),
+    where the constant-velocity motion stops through ``movestop``."""
     from eddy_currents_3d_amd import host, vxc
     from eddy_currents_3d_amd.vtk import src_vtk_bytes
     g = load_golden("g3_src_vtk")
@@ -71,7 +73,14 @@ def test_source_cell_file_is_the_reference_file():
     t = vxc.domain_tables(model)
     prog = host.SourceProgram(model, t)
     sdz, sdy, sdx = model.vox.shape
-    for k in range(3):                        # output point N is written at the end of step N (N >= 1)
-        prog.step(k * t["dt"])
+    npoints = sum(1 for k in g.files if k.startswith("vtk_src_"))
+    assert npoints >= 20
+    T, clamped = 0.0, False
+    for k in range(npoints + 1):              # output point N is written at the end of step N (N >= 1)
+        prog.step(T)
+        T = T + t["dt"]
         if k >= 1:
             assert src_vtk_bytes(sdx, sdy, sdz, t["delta"], prog.groups) == g[f"vtk_src_{k}"].tobytes(), k
+        cells = np.concatenate([gr[1] for gr in prog.groups]) - 1
+        clamped |= bool(((cells % sdx + 1) >= sdx - 2).any())
+    assert clamped, "the run was meant to reach the clamp"
