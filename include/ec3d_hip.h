@@ -45,7 +45,10 @@ int ec3d_destroy(ec3d_handle h);
 const char *ec3d_last_error(void);
 
 /* Matrix from the reference's CSR triple (src/EC3D.f90:36-38 irow/jcol/valA, 1-based).
- * Converted once on the host to the device format: DIA bands + sliced-ELL tail. */
+ * Converted once on the host to a device format: the structured A-V form (1 class byte per row, U
+ * embedded in the grid) when the matrix is recognised, entry by entry, as the one gen_sparse_matrix
+ * builds (see ec3d_probe_csr); otherwise 7 bands (class-coded or plain) + a sliced-ELL tail that keeps
+ * every row's stored order.  Results do not depend on the format. */
 int ec3d_set_matrix_csr(ec3d_handle h, int32_t n, const double *valA, const int32_t *irow,
                         const int32_t *jcol);
 
@@ -55,7 +58,9 @@ int ec3d_set_matrix_csr(ec3d_handle h, int32_t n, const double *valA, const int3
  *   valPHYS   f64   (nsub_glob,5)   src/m_vxc2data.f90:52   column-major
  *   BND       f64   (3,2)           src/EC3D.f90:77         column-major
  *   delta     f64   [3], dt                                  src/EC3D.f90:60-61
- * Unknown layout [Ax | Ay | Az | U], n = 3*nCells + Ncells0 (src/EC3D.f90:101-106).
+ * Unknown layout [Ax | Ay | Az | U], n = 3*nCells + Ncells0 (src/EC3D.f90:101-106): that is the
+ * numbering of every host vector; on the device U is embedded in the grid and xy planes may be
+ * padded (ec3d_get_row_map), which only callers of ec3d_device_vector ever see.
  * Returns 3 where the reference would index out of range (conductor on the box boundary or
  * thinner than 3 cells), 1/2 for its two STOPs (:717-720, :924-936). */
 int ec3d_assemble(ec3d_handle h, int32_t sdx, int32_t sdy, int32_t sdz, const int8_t *geoPHYS,
