@@ -127,9 +127,10 @@ int ec3d_get_cel_bnd(ec3d_handle h, int which, int32_t *count, int32_t *list);
  * per conducting domain) — 1 byte per row instead of 56; 0 = plain DIA streams.  Same doubles are
  * multiplied in the same order either way.  Call before ec3d_set_matrix_csr / ec3d_assemble*. */
 int ec3d_set_format(ec3d_handle h, int dictionary);
-/* 1 (default): ec3d_assemble stores the A-V system in its structured form when it can (dictionary
- * format on, at most 25 domains, conducting cells of one domain): U is embedded in the grid (device
- * vectors hold 4*nCells entries), every A<->U coupling is a fixed-offset stencil slot with a
+/* 1 (default): ec3d_assemble, ec3d_assemble_slab and ec3d_set_matrix_csr store the A-V system in its
+ * structured form when they can (dictionary format on, <= 256 coefficient classes, conducting cells of
+ * one domain numbered in scan order): U is embedded in the grid (device vectors hold 4 blocks of
+ * planes*pitch rows, pitch >= sdx*sdy), every A<->U coupling is a fixed-offset stencil slot with a
  * class-coded coefficient, and there is no sliced-ELL tail.  Host vectors keep the reference's
  * numbering (3*nCells + Ncells0); the library permutes on upload/download.  0: bands + tail. */
 int ec3d_set_structured(ec3d_handle h, int on);
