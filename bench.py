@@ -110,17 +110,24 @@ def cpu_baseline(budget_s=20.0):
                       f" in {sec:.1f} s, 1 thread, host cores available: {os.cpu_count()}"}
 
 
-def latest_traffic():
-    """Per-kernel HBM bytes per launch from the committed PMC profile (profiles/*pmc*.json), or None."""
+def latest_traffic(grid, fmt, workload, n_gpus):
+    """Per-kernel HBM bytes per launch from the committed PMC profile of the SAME configuration
+    (profiles/*pmc*.json, written by tools/parse_rocprof.py), or None."""
     pdir = os.path.join(REPO, "profiles")
     try:
         cands = sorted(f for f in os.listdir(pdir) if f.endswith(".json") and "pmc" in f)
-        if not cands:
-            return None
-        with open(os.path.join(pdir, cands[-1])) as f:
-            return json.load(f)
     except OSError:
         return None
+    for fn in reversed(cands):
+        try:
+            with open(os.path.join(pdir, fn)) as f:
+                tr = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if tr.get("grid") == grid and tr.get("format") == fmt and tr.get("workload", "cube") == workload and \
+                tr.get("n_gpus", 1) == n_gpus:
+            return tr
+    return None
 
 
 def main():
@@ -242,9 +249,8 @@ def main():
         fmt_bytes = dict(DICT_BYTES if info.dict_classes > 0 else SURVEY_BYTES)
         survey_bytes = dict(SURVEY_BYTES)
         dom = max(kernel_ms, key=kernel_ms.get)   # dominant kernel by measured share
-        tr = latest_traffic()
-        use_tr = bool(tr) and tr.get("grid") == N and tr.get("n_gpus", 1) == world and \
-            tr.get("format") == args.format and tr.get("workload", "cube") == args.workload
+        tr = latest_traffic(N, args.format, args.workload, world)
+        use_tr = bool(tr)
         kernels = {}
         for k, ms in kernel_ms.items():
             kernels[k] = {"ms": ms, "share": ms / sum(kernel_ms.values()),
