@@ -296,8 +296,11 @@ def main():
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if use_dist:
+        s.ops.close()          # detach the library from the torch-owned stream and vectors before torch goes away
         dist.barrier()
         dist.destroy_process_group()
+    else:
+        s.close()
 
 
 if __name__ == "__main__":
