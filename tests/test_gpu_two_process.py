@@ -67,7 +67,7 @@ def test_two_ranks_share_one_gpu(tmp_path):
     assert np.linalg.norm(x - xr) <= 1e-5 * np.linalg.norm(xr)
 
 
-def _av_worker(rank, world, port, out):
+def _av_worker(rank, world, port, out, name="g3_moving_coil_18x16x12", moving=True):
     """The whole resident time loop of the A-V system on two ranks: rhs_step (X halo exchange, global source
     ids) -> solve -> post_update, fields never leaving the GPU between steps."""
     import sys
@@ -84,7 +84,7 @@ def _av_worker(rank, world, port, out):
     import datetime
     dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
     try:
-        g = load_golden("g3_moving_coil_18x16x12")
+        g = load_golden(name)
         n = len(g["irow"]) - 1
         tol, itmax = float(g["tol"]), int(g["itmax"])
         k0, k1 = slab_bounds(g["geoPHYS"].shape[0], rank, world)
@@ -92,12 +92,13 @@ def _av_worker(rank, world, port, out):
                            k0, k1, world)
         assert ops.structured
         s = SlabSolver(ops, rank, world, k0, k1)
+        print(f"rank {rank}: planes [{k0}, {k1}), vector kernels split: {s.split_ok}", flush=True)
         ops.set_vector_global("X", np.zeros(n))
         ops.set_vector_global("B", np.zeros(n))
         res = []
         for k in range(len(g["iters"])):
-            idx, val = coil_sources(g, k, True)
-            s.rhs_step(idx, val, moving=True)
+            idx, val = coil_sources(g, k, moving)
+            s.rhs_step(idx, val, moving=moving)
             it = s.solve(tol, itmax, poll=4)
             x = np.zeros(n)
             ops.export_owned("X", x)
@@ -112,18 +113,23 @@ def _av_worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def test_two_ranks_run_the_av_time_loop(tmp_path):
+@pytest.mark.parametrize("world,name,moving", [(2, "g3_moving_coil_18x16x12", True), (3, "g3_moving_coil_18x16x12", True),
+                                               (4, "g2v_conducting_moving_16x15x14", False)])
+def test_ranks_run_the_av_time_loop(tmp_path, world, name, moving):
+    """Several ranks, thin slabs: with 4 ranks on 14 planes the inner ranks are all boundary (they run the whole
+    kernels in the shared exchange order) while the outer ranks split theirs -- mixed capabilities over real
+    processes."""
     from conftest import load_golden
     out = str(tmp_path / "av.npy")
-    mp.spawn(_av_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_av_worker, args=(world, _free_port(), out, name, moving), nprocs=world, join=True)
     res = np.load(out)
-    g = load_golden("g3_moving_coil_18x16x12")
+    g = load_golden(name)
     tol = float(g["tol"])
     for k, it_ref in enumerate(g["iters"]):
         it, x = int(res[k, 0]), res[k, 1:]
         xr = g[f"xout{k}"]
         rel = np.linalg.norm(x - xr) / np.linalg.norm(xr)
-        print(f"step {k}: iter 2 ranks {it} / reference {int(it_ref)}, rel diff {rel:.2e}")
+        print(f"step {k}: iter {world} ranks {it} / reference {int(it_ref)}, rel diff {rel:.2e}")
         assert rel <= 10 * tol
 
 
