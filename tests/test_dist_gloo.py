@@ -1,5 +1,5 @@
 """N > 1 path on CPU: the slab schedule of eddy_currents_3d_amd/dist.py (halo send/recv, all_gather of
-the partial sums, rank-ordered reduction, stop flag agreement) over gloo with world_size 2 and 3,
+the partial sums, rank-ordered reduction, stop flag agreement) over gloo with world_size 2, 3 and 8,
 with a numpy stand-in for the per-slab device ops.  Checked against the oracle's serial solve."""
 import os
 import socket
@@ -20,7 +20,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out, producer_side=False):
+def _worker(rank, world, port, out, producer_side=False, N=N):
     import sys
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, "tests"))
@@ -51,13 +51,14 @@ def _worker(rank, world, port, out, producer_side=False):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 @pytest.mark.parametrize("producer_side", [False, True])
 def test_slab_solver_over_gloo_matches_serial_oracle(oracle, tmp_path, world, producer_side):
     """producer_side: the A-V slabs' schedule (K2/K5 boundary rows first, asynchronous send/recv started
     behind them and joined before the consumer) over real processes and real non-blocking transfers."""
     out = str(tmp_path / "x.npy")
-    mp.spawn(_worker, args=(world, _free_port(), out, producer_side), nprocs=world, join=True)
+    N = 32 if world == 8 else 12   # 8 ranks: 4 planes each, so the split (interior + boundary) schedules run
+    mp.spawn(_worker, args=(world, _free_port(), out, producer_side, N), nprocs=world, join=True)
     res = np.load(out)
     it, x = int(res[0]), res[1:]
     valA, irow, jcol = oracle.poisson_csr(N, N, N)
