@@ -70,3 +70,15 @@ def test_empty_system_is_answered_without_a_device(lib):
     x = np.zeros(0)
     it = E.sprsBCGstabWR(np.zeros(0), np.ones(1, np.int32), np.zeros(0, np.int32), 0, np.zeros(0), x, 1e-8, 100)
     assert it == 0
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/ec3d_hip.h must compile as C (the boundary is a C ABI, not C++): strict C99, all warnings."""
+    src = tmp_path / "use_header.c"
+    src.write_text('#include "ec3d_hip.h"\n'
+                   "int probe(const double *v, const int32_t *ir, const int32_t *jc, int32_t n) {\n"
+                   "    ec3d_csr_probe p; ec3d_geom g; ec3d_matrix_info mi; (void)g; (void)mi;\n"
+                   "    return ec3d_probe_csr(n, v, ir, jc, &p) ? -1 : p.structured;\n}\n")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-fsyntax-only",
+                        "-I", os.path.join(REPO, "include"), str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
