@@ -3,6 +3,8 @@ CSR entries, degenerate iteration limits, the drop-in's matrix cache."""
 import numpy as np
 import pytest
 
+from conftest import load_golden
+
 pytestmark = pytest.mark.gpu
 
 
@@ -112,3 +114,32 @@ def test_nan_rhs_propagates_like_the_reference(E, oracle):
         s.assemble_poisson(N, N, N)
         x, it, _ = s.solve(b, np.zeros(N ** 3), 1e-6, 7)
     assert it == 8 and np.all(np.isnan(x[np.isfinite(x) == False])) and np.isnan(x).any()
+
+
+@pytest.mark.parametrize("structured", [True, False])
+@pytest.mark.parametrize("case", ["on_the_box", "two_cells_thin"])
+def test_assembly_stops_where_the_reference_stops(E, oracle, case, structured):
+    """Geometries the reference cannot assemble (it STOPs at src/EC3D.f90:717-720 / :945-948 or indexes out of
+    range): the device assembly refuses them with the status the oracle's restatement reports, in both storage
+    formats, and the handle stays usable."""
+    g = load_golden("g2_conducting_hole_16x15x14")
+    geo, geoC = g["geoPHYS"].copy(), np.zeros_like(g["geoPHYS_C"])
+    cond = np.zeros(geo.shape, bool)
+    if case == "on_the_box":
+        cond[0:4, 4:9, 4:9] = True          # touches the z = 1 face
+    else:
+        cond[5:7, 4:9, 4:9] = True          # only two cells thick in z: the one-sided stencil has no third cell
+    geo[cond] = 1
+    geo[~cond & (geo == 1)] = geo.max()
+    n_cells = geo.size
+    geoC[cond] = 3 * n_cells + 1 + np.arange(int(cond.sum()))
+    args = (geo, geoC, g["valPHYS"], g["BND"], g["delta"], float(g["dt"]))
+    with pytest.raises(RuntimeError, match="STOP") as ref:
+        oracle.gen_sparse_matrix(*args)
+    code = int(str(ref.value).split("code ")[1].rstrip(")"))
+    with E.EC3DSolver(structured=structured) as s:
+        with pytest.raises(E.EC3DError) as err:
+            s.assemble(*args)
+        assert f"({code})" in str(err.value), (str(err.value), code)
+        s.assemble(g["geoPHYS"], g["geoPHYS_C"], g["valPHYS"], g["BND"], g["delta"], float(g["dt"]))   # still usable
+        assert s.n == len(g["irow"]) - 1
