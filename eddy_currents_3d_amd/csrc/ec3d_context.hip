@@ -270,6 +270,8 @@ extern "C" int ec3d_set_workgroups(ec3d_handle c, int32_t nblk)
         EC3D_HIP(hipSetDevice(c->device));
         // partial buffer depends on nblk; vectors are kept
         choose_sweep(c);
+        c->can_vsplit = false; // the boundary/interior tile sweeps were derived from the old geometry:
+                               // ec3d_dist_set_boundary_rows has to be called again
         if (c->partials) (void)hipFree(c->partials);
         EC3D_HIP(hipMalloc(&c->partials, (size_t)P_NSLOT * c->sweep.pstride * sizeof(double)));
         EC3D_HIP(hipMemset(c->partials, 0, (size_t)P_NSLOT * c->sweep.pstride * sizeof(double)));
