@@ -9,8 +9,14 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W     -> one JSO
     targets are quoted on; it fits one GPU (16 GB), so every N runs the SAME grid: scaling "strong".
     RHS = the deterministic bar source of SURVEY §8c, x0 = 0; operator, b and x are resident in HBM
     before the timed region starts (assembly is on the device, nothing crosses PCIe in the loop);
-  * N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), z-slab decomposition, halo
-    planes by send/recv and the dot products by all_gather (eddy_currents_3d_amd/dist.py);
+  * N > 1, two ways to the same z-slab decomposition (rank g owns planes [g*N/G, (g+1)*N/G)):
+      - plain `python bench.py --gpus N`: ONE process, N devices, inside the library (include/ec3d_hip.h
+        section 2c, csrc/ec3d_multi.hip): one host thread per slab, halo planes pulled over peer access
+        (xGMI) behind the interior planes, partial sums read in place, rank-ordered.  Exits with
+        "needs N devices" before touching a GPU when the machine has fewer;
+      - under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` (the driver's form):
+        one process per GPU, torch.distributed (backend nccl = RCCL), halo planes by send/recv and the dot
+        products by all_gather (eddy_currents_3d_amd/dist.py);
   * roofline: the kernel with the largest share of the iteration (measured, not assumed), its
     algorithmic bytes per row from SURVEY §8d / DESIGN.md §4, duration measured live with hipEvents on
     the library's stream inside an extra instrumented pass of the same K iterations; peak 8.0 TB/s
@@ -20,7 +26,8 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W     -> one JSO
     target is quoted on.  --format dia runs the plain DIA streams (the SURVEY's byte model).
   * cpu_baseline (rank 0, N = 1 only): the unmodified reference solver (oracle/_ref/ref_solve,
     src/solvers.f90 compiled with amdflang; "port" = our C restatement when that binary is absent)
-    on one host core, fixed iteration count on a bounded cube.
+    on one host core: 20 fixed iterations on the 256^3 cube of BASELINE config 2, its
+    wall time reported next to it (`wall_s`).
 """
 from __future__ import annotations
 
@@ -88,26 +95,25 @@ def av_system(refine):
             np.array([dx / f] * 3), 1e-3, b)
 
 
-def cpu_baseline(budget_s=20.0):
-    """Reference solver on one host core, bounded sample (never the thing measured as product)."""
+def cpu_baseline(N=256, iters=20):
+    """Reference solver on one host core, bounded sample (never the thing measured as product): a fixed
+    number of iterations on the 256^3 cube of BASELINE config 2, as SURVEY section 8d prescribes for the
+    256^3 / 512^3 grids (convergence would take hours)."""
     import numpy as np
     from oracle import oracle as O
+    t_wall = time.perf_counter()
     kind = "reference" if O.have_ref() else "port"
-    N = 192
     valA, irow, jcol = O.poisson_csr(N, N, N)
     b = bar_rhs(N)
     n = N ** 3
-    # calibrate on 2 iterations, then spend the budget
-    # capture_stdout: the reference prints ||R|| on the itmax exit (src/solvers.f90:25-28); this script's
-    # stdout carries exactly one JSON line
-    x, it, sec, _ = O.solve_process(kind, valA, irow, jcol, b, np.zeros(n), 1e-300, 1, capture_stdout=True)
-    per_iter = sec / max(it, 1)
-    iters = int(max(4, min(200, budget_s / max(per_iter, 1e-3))))
+    # itmax = iters - 1: the reference then runs exactly `iters` iterations (src/solvers.f90:25-29).
+    # capture_stdout: it prints ||R|| on that exit (:25-28); this script's stdout carries exactly one JSON line
     x, it, sec, _ = O.solve_process(kind, valA, irow, jcol, b, np.zeros(n), 1e-300, iters - 1, capture_stdout=True)
     return {"value": n * it / sec, "unit": "DOF*iters/s", "cores": 1, "kind": kind,
-            "sample": f"{N}^3 cube of the same operator/RHS (n={n}), {it} iterations of "
+            "sample": f"{N}^3 cube of the same operator/RHS (n={n}, BASELINE config 2 grid), {it} fixed iterations of "
                       f"{'src/solvers.f90 (amdflang -O2)' if kind == 'reference' else 'oracle/ec3d_oracle.c'}"
-                      f" in {sec:.1f} s, 1 thread, host cores available: {os.cpu_count()}"}
+                      f" in {sec:.2f} s inside the solver call, 1 thread, host cores available: {os.cpu_count()}",
+            "solver_s": sec, "wall_s": time.perf_counter() - t_wall}
 
 
 def latest_traffic(grid, fmt, workload, n_gpus):
@@ -126,6 +132,7 @@ def latest_traffic(grid, fmt, workload, n_gpus):
             continue
         if tr.get("grid") == grid and tr.get("format") == fmt and tr.get("workload", "cube") == workload and \
                 tr.get("n_gpus", 1) == n_gpus:
+            tr["_file"] = fn
             return tr
     return None
 
@@ -145,7 +152,11 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="use the z-slab/torch.distributed path even with one rank (rehearsal on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--cpu-grid", type=int, default=256, help="cube edge of the cpu_baseline sample")
+    ap.add_argument("--cpu-iters", type=int, default=20, help="fixed iteration count of the cpu_baseline sample")
+    ap.add_argument("--devices", type=str, default=None,
+                    help="in-library multi-GPU path: comma-separated device ordinals, one per slab; a device may "
+                         "repeat (rehearsal of N slabs on one card, e.g. --gpus 2 --devices 0,0)")
     args = ap.parse_args()
 
     # This script's stdout carries exactly one JSON line.  Native libraries write there too (RCCL prints its
@@ -161,10 +172,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run "
-                             "(--nproc-per-node N)")
+    under_launcher = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    # plain `python bench.py --gpus N`: N devices inside the library, this one process (no re-exec, no spawn)
+    in_library = (not under_launcher and (args.gpus > 1 or args.devices is not None)) and not args.force_dist
+    devices = None
+    if in_library:
+        if args.devices is not None:
+            devices = [int(t) for t in args.devices.split(",")]
+            if len(devices) != args.gpus:
+                raise SystemExit(f"bench.py: --devices names {len(devices)} devices for --gpus {args.gpus}")
+        have = torch.cuda.device_count()     # counting does not initialise the GPU
+        if (devices is None and have < args.gpus) or (devices and max(devices) >= have):
+            raise SystemExit(f"bench.py --gpus {args.gpus} needs {args.gpus} devices, this machine has {have}")
+    elif world != args.gpus:
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU path)")
@@ -186,8 +206,43 @@ def main():
                 f"x0=0, exits disabled")
     grid = [N, N, N]
     if args.workload == "av" and use_dist:
-        raise SystemExit("bench.py --workload av runs on one GPU")
-    if not use_dist:
+        raise SystemExit("bench.py --workload av runs on one GPU or on the in-library multi-GPU path")
+    if in_library:
+        G = args.gpus
+        s = E.EC3DMulti(G, devices=devices, dictionary=args.format == "dict")
+        if args.workload == "av":
+            geo, geoC, valPHYS, BND, delta, dt, b = av_system(args.refine)
+            s.assemble(geo, geoC, valPHYS, BND, delta, dt)
+            n_global = len(b)
+            grid = list(geo.shape[::-1])
+            workload = (f"full A-V system [Ax|Ay|Az|U] of the shipped compare_to_Elmer geometry refined x"
+                        f"{args.refine} per axis (BASELINE config 3 style): grid {grid[0]}x{grid[1]}x{grid[2]}, "
+                        f"{int(np.count_nonzero(geoC))} conducting cells, coil RHS, x0=0, exits disabled")
+            s.upload("B", b)
+        else:
+            s.assemble_poisson(N, N, N)
+            s.upload("B", bar_rhs(N))
+        s.upload("X", np.zeros(n_global))
+        s.iterate_begin()
+        s.iterate(1, W)
+        s.synchronize()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        s.iterate(W + 1, K)
+        s.synchronize()
+        for d in sorted(set(devices or range(G))):
+            torch.cuda.synchronize(d)
+        t1 = time.perf_counter()
+        elapsed = t1 - t0
+        kernel_ms = s.iterate(W + K + 1, min(K, 20), per_kernel=True)   # rank 0's stages
+        spmv_ms = None
+        slab0 = s.slab(0)[0]
+        geom = {"vector": int(slab0.geometry(0).nblk), "spmv": int(slab0.geometry(1).nblk)}
+        info = slab0.info
+        world = G
+        parallelism = (f"z-slab x{G} inside the library (one process, one host thread per slab, halo planes pulled "
+                       f"over peer access, partial sums read in place), devices {devices or list(range(G))}")
+    elif not use_dist:
         s = E.EC3DSolver(device=local_rank, dictionary=args.format == "dict")
         if args.workload == "av":
             geo, geoC, valPHYS, BND, delta, dt, b = av_system(args.refine)
@@ -279,6 +334,10 @@ def main():
             "roofline": {"bound": "hbm", "kernel": KERNEL_NAMES[dom], "achieved": achieved,
                          "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
                          "traffic": traffic,
+                         # not measured in this run: PMC counters need their own rocprofv3 passes
+                         # (tools/profile_bench.sh); this is the committed profile of the same configuration
+                         "traffic_source": (f"profiles/{tr['_file']} (rocprofv3 --pmc passes of this configuration, "
+                                            f"FETCH_SIZE/WRITE_SIZE per the guide)" if traffic is not None else None),
                          "algorithmic_bytes_per_launch": fmt_bytes[dom] * rows,
                          "avg_launch_ms": kernel_ms[dom]},
         }
@@ -289,13 +348,15 @@ def main():
                            "bytes_per_row": fmt_bytes["spmv"], "GBps": fmt_bytes["spmv"] * rows / spmv_ms / 1e6}
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(args.cpu_budget)
+                out["cpu_baseline"] = cpu_baseline(args.cpu_grid, args.cpu_iters)
             except Exception as e:  # the baseline is reporting only; never fail the GPU number on it
                 out["cpu_baseline"] = {"value": None, "unit": "DOF*iters/s", "cores": 1, "kind": "port",
                                        "sample": f"failed: {e!r}"}
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
-    if use_dist:
+    if in_library:
+        s.close()
+    elif use_dist:
         s.ops.close()          # detach the library from the torch-owned stream and vectors before torch goes away
         dist.barrier()
         dist.destroy_process_group()

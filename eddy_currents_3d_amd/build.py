@@ -14,7 +14,7 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libec3d_hip.so")
-SOURCES = ["ec3d_kernels.hip", "ec3d_context.hip", "ec3d_solve.hip", "ec3d_measure.hip", "ec3d_dist.hip", "ec3d_dropin.hip", "ec3d_assemble.hip", "ec3d_rhs.hip", "ec3d_output.hip", "ec3d_format.cpp", "ec3d_sav_csr.cpp"]
+SOURCES = ["ec3d_kernels.hip", "ec3d_context.hip", "ec3d_solve.hip", "ec3d_measure.hip", "ec3d_dist.hip", "ec3d_multi.hip", "ec3d_dropin.hip", "ec3d_assemble.hip", "ec3d_rhs.hip", "ec3d_output.hip", "ec3d_format.cpp", "ec3d_sav_csr.cpp"]
 HEADERS = [os.path.join(CSRC, "ec3d_internal.hpp"), os.path.join(os.path.dirname(PKG), "include", "ec3d_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared",
          "-Wall", "-Wno-unused-function"]

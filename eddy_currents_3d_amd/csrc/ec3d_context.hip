@@ -108,6 +108,11 @@ void ec3d_free_matrix(ec3d_ctx *c)
     c->plane = c->pitch = c->nCd = 0;
     c->halo = 0;
     c->nown = 0;
+    // the multi-rank configuration pointed at caller-owned buffers sized for the old matrix
+    c->dist = false;
+    c->nranks = 1;
+    c->lsum = c->gsum = nullptr;
+    c->lsum_ptrs = nullptr;
     ec3d_free_rhs(c);
     c->have_matrix = false;
     free_vectors(c);
@@ -418,6 +423,14 @@ int ec3d_upload_sav(ec3d_ctx *c, const SavHost &S)
         EC3D_HIP(hipMalloc(&c->cond_cell, S.cond_cell.size() * 4));
         EC3D_HIP(hipMemcpy(c->cond_cell, S.cond_cell.data(), S.cond_cell.size() * 4, hipMemcpyHostToDevice));
         EC3D_HIP(hipMalloc(&c->io_tmp, S.cond_cell.size() * sizeof(double)));
+    }
+    if (S.nown) { // a z-slab cut out of a recognised system (ec3d_sav_slice)
+        c->nown = S.nown;
+        for (int d = 0; d < 4; ++d) {
+            c->own_lo[d] = S.own_lo[d];
+            c->own_hi[d] = S.own_hi[d];
+        }
+        c->halo = S.halo;
     }
     c->have_matrix = true;
     return ec3d_prepare_vectors(c);

@@ -42,6 +42,13 @@ extern "C" int ec3d_adopt_vectors(ec3d_handle c, double *base)
 
 extern "C" int ec3d_dist_configure(ec3d_handle c, int32_t nranks, double *lsum_device, double *gsum_device)
 {
+    if (nranks == 1 && !lsum_device && !gsum_device) { // back to the single-rank loop (ec3d_solve & co.)
+        c->nranks = 1;
+        c->lsum = c->gsum = nullptr;
+        c->lsum_ptrs = nullptr;
+        c->dist = false;
+        return 0;
+    }
     if (nranks < 1 || !lsum_device || !gsum_device) {
         ec3d_set_error("ec3d_dist_configure: need nranks >= 1 and two device buffers");
         return 2;
@@ -162,7 +169,7 @@ extern "C" int ec3d_dist_step(ec3d_handle c, int32_t stage, int32_t it, double t
         ec3d_launch_k2(bnd ? c->sweep_vb : c->sweep_vi, ec3d_src_of(c, true), c->state, it, v[EC3D_VEC_R], v[EC3D_VEC_AP],
                        v[EC3D_VEC_S], c->partials, c->stream);
         if (!bnd)
-            ec3d_launch_finalize(RedSrc{c->partials, c->sweep_vb.nblk + c->sweep_vi.nblk, 1, c->sweep.pstride}, c->lsum,
+            ec3d_launch_finalize(RedSrc{c->partials, c->sweep_vb.nblk + c->sweep_vi.nblk, 1, c->sweep.pstride, nullptr}, c->lsum,
                                  1u << P_SS, c->stream);
         break;
     }

@@ -15,24 +15,32 @@
 namespace {
 struct DropIn {
     ec3d_ctx *ctx = nullptr;
+    // EC3D_NGPU=N (N > 1): the solve runs on N devices behind this symbol (ec3d_multi.hip); the caller of
+    // src/EC3D.f90:408 sees nothing of it.  EC3D_DEVICES="0,1,2,3" names them (default 0 .. N-1).
+    ec3d_multi_handle multi = nullptr;
+    bool multi_has_matrix = false;
+    int ngpu = -1;
     const void *valA = nullptr, *irow = nullptr, *jcol = nullptr;
     int64_t n = 0, nnz = 0;
     uint64_t sig = 0;
     std::mutex mu;
 } g_drop;
 
-uint64_t sample_signature(const double *valA, const int32_t *jcol, int64_t nnz)
+uint64_t matrix_signature(const double *valA, const int32_t *irow, const int32_t *jcol, int64_t n, int64_t nnz)
 {
-    // cheap change detector for callers that rebuild the matrix in place without telling us
-    uint64_t h = 1469598103934665603ull;
-    const int64_t step = std::max<int64_t>(1, nnz / 4096);
-    for (int64_t p = 0; p < nnz; p += step) {
+    // change detector for callers that rebuild the matrix in place without telling us: EVERY entry of
+    // valA, jcol and irow goes in (one streaming pass, ~12 B/nonzero -- small next to a solve, which reads
+    // the matrix twice per iteration).  Four independent lanes so the multiply chain is not the limit.
+    uint64_t h[4] = {1469598103934665603ull, 0x9E3779B97F4A7C15ull, 0xC2B2AE3D27D4EB4Full, 0x165667B19E3779F9ull};
+    for (int64_t p = 0; p < nnz; ++p) {
         uint64_t bits;
         memcpy(&bits, &valA[p], 8);
-        h = (h ^ bits) * 1099511628211ull;
-        h = (h ^ (uint64_t)jcol[p]) * 1099511628211ull;
+        uint64_t &q = h[p & 3];
+        q = (q ^ bits) * 1099511628211ull;
+        q = (q ^ (uint64_t)(uint32_t)jcol[p]) * 1099511628211ull;
     }
-    return h;
+    for (int64_t r = 0; r <= n; ++r) h[r & 3] = (h[r & 3] ^ (uint64_t)(uint32_t)irow[r]) * 1099511628211ull;
+    return ((h[0] * 31 + h[1]) * 31 + h[2]) * 31 + h[3];
 }
 
 [[noreturn]] void die(const char *what)
@@ -46,6 +54,7 @@ extern "C" void ec3d_invalidate(void)
 {
     std::lock_guard<std::mutex> lk(g_drop.mu);
     if (g_drop.ctx) ec3d_free_matrix(g_drop.ctx);
+    g_drop.multi_has_matrix = false;
     g_drop.valA = nullptr;
 }
 
@@ -57,15 +66,58 @@ extern "C" void sprsbcgstabwr_(double *valA, int32_t *irow, int32_t *jcol, int32
         return;
     }
     std::lock_guard<std::mutex> lk(g_drop.mu);
-    if (!g_drop.ctx) {
+    if (g_drop.ngpu < 0) {
+        g_drop.ngpu = 1;
+        if (const char *e = getenv("EC3D_NGPU")) g_drop.ngpu = std::max(1, atoi(e));
+    }
+    if (g_drop.ngpu > 1 && !g_drop.multi) {
+        std::vector<int32_t> devs;
+        if (const char *e = getenv("EC3D_DEVICES"))
+            for (const char *p = e; *p;) {
+                devs.push_back((int32_t)strtol(p, const_cast<char **>(&p), 10));
+                while (*p == ',' || *p == ' ') ++p;
+            }
+        if (!devs.empty() && (int)devs.size() != g_drop.ngpu) {
+            ec3d_set_error("EC3D_DEVICES must name EC3D_NGPU devices");
+            die("EC3D_NGPU");
+        }
+        if (ec3d_multi_create(&g_drop.multi, g_drop.ngpu, devs.empty() ? nullptr : devs.data())) die("ec3d_multi_create");
+    }
+    if (g_drop.ngpu <= 1 && !g_drop.ctx) {
         int dev = 0;
         if (const char *e = getenv("EC3D_DEVICE")) dev = atoi(e);
         if (ec3d_create(&g_drop.ctx, dev)) die("ec3d_create");
     }
     const int64_t nn = *n, nnz = (int64_t)irow[nn] - 1;
-    const uint64_t sig = sample_signature(valA, jcol, nnz);
-    if (!(g_drop.ctx->have_matrix && g_drop.valA == valA && g_drop.irow == irow && g_drop.jcol == jcol &&
-          g_drop.n == nn && g_drop.nnz == nnz && g_drop.sig == sig)) {
+    const uint64_t sig = matrix_signature(valA, irow, jcol, nn, nnz);
+    const bool same = g_drop.valA == valA && g_drop.irow == irow && g_drop.jcol == jcol && g_drop.n == nn &&
+                      g_drop.nnz == nnz && g_drop.sig == sig;
+    if (g_drop.ngpu > 1) {
+        if (!(g_drop.multi_has_matrix && same)) {
+            g_drop.multi_has_matrix = false;
+            const int rc = ec3d_multi_set_matrix_csr(g_drop.multi, *n, valA, irow, jcol);
+            if (rc == 7) { // no grid to cut: this matrix runs on one GPU
+                fprintf(stderr, "libec3d_hip: EC3D_NGPU=%d ignored: %s\n", g_drop.ngpu, ec3d_last_error());
+                g_drop.ngpu = 1;
+                if (!g_drop.ctx) {
+                    int dev = 0;
+                    if (const char *e = getenv("EC3D_DEVICE")) dev = atoi(e);
+                    if (ec3d_create(&g_drop.ctx, dev)) die("ec3d_create");
+                }
+            } else if (rc) {
+                die("ec3d_multi_set_matrix_csr");
+            } else {
+                g_drop.multi_has_matrix = true;
+                g_drop.valA = valA; g_drop.irow = irow; g_drop.jcol = jcol;
+                g_drop.n = nn; g_drop.nnz = nnz; g_drop.sig = sig;
+            }
+        }
+        if (g_drop.ngpu > 1) {
+            if (ec3d_multi_solve(g_drop.multi, b, x, *tolerance, *itmax, iter)) die("ec3d_multi_solve");
+            return;
+        }
+    }
+    if (!(g_drop.ctx->have_matrix && same)) {
         if (ec3d_set_matrix_csr(g_drop.ctx, *n, valA, irow, jcol)) die("ec3d_set_matrix_csr");
         g_drop.valA = valA;
         g_drop.irow = irow;

@@ -50,10 +50,13 @@ struct MatView {
 // where a kernel finds the partial sums it has to finish: value i of slot s is
 // base[s * slot_mul + i * stride], i < count.  Single GPU: the producer's per-workgroup partials
 // (count = nblk, stride = 1, slot_mul = nblk).  Multi rank: the all-gathered per-rank sums
-// (count = nranks, stride = P_NSLOT, slot_mul = 1).
+// (count = nranks, stride = P_NSLOT, slot_mul = 1).  In-library multi-GPU (ec3d_multi.hip): no gathered
+// copy at all -- ptrs[i] is rank i's own lsum[P_NSLOT], read in place through the peer mapping
+// (value i of slot s = ptrs[i][s]).
 struct RedSrc {
     const double *base;
     int count, stride, slot_mul;
+    const double *const *ptrs;
 };
 
 // blockIdx -> tile map (XCD aware when S > 0): see ec3d_tile_of() in ec3d_kernels.hip
@@ -120,6 +123,12 @@ struct SavHost {
     std::vector<double> table; // ncls * 16
     std::vector<int32_t> ulist, cond_cell;
     int64_t ntiles_front = 0;
+    // a z-slab cut out of a recognised system (ec3d_sav_slice): rows of the halo planes are inert and only the
+    // owned planes of each block count in the dot products (as ec3d_assemble_slab sets it up natively)
+    int nown = 0;
+    int64_t own_lo[4] = {0, 0, 0, 0}, own_hi[4] = {0, 0, 0, 0};
+    int64_t halo = 0;
+    int64_t u_first = 0; // index, among the whole system's U unknowns, of the slab's first held one
 };
 
 struct DevMatrix {
@@ -170,6 +179,7 @@ struct ec3d_ctx {
     // multi-rank (z-slab) mode: reductions come from the all-gathered per-rank sums
     int nranks = 1;
     double *lsum = nullptr, *gsum = nullptr; // caller-owned device buffers (P_NSLOT, nranks*P_NSLOT)
+    const double *const *lsum_ptrs = nullptr; // device array of nranks pointers: every rank's lsum (ec3d_multi.hip)
     int64_t halo = 0;                        // doubles per halo plane (kdz), 0 when not a slab
     bool use_dict = true;
     bool use_sav = true;   // structured A-V form for ec3d_assemble when the problem allows it (EC3D_SAV)
@@ -244,6 +254,8 @@ void ec3d_host_matrix_to_csr(const HostMatrix &M, std::vector<int32_t> &irow, st
 
 // ec3d_sav_csr.cpp: 0, or -1 when the matrix does not have the structure
 int ec3d_csr_to_sav_host(int64_t n, const double *valA, const int32_t *irow, const int32_t *jcol, SavHost &S);
+// planes [e0, e1) of a recognised system as a slab that owns [k0, k1) (same pitch, classes and table)
+void ec3d_sav_slice(const SavHost &G, int64_t e0, int64_t e1, int64_t k0, int64_t k1, SavHost &L);
 
 // ec3d_context.hip
 int ec3d_upload_sav(ec3d_ctx *c, const SavHost &S);

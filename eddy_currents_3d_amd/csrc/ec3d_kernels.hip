@@ -79,9 +79,13 @@ __device__ __forceinline__ void reduce_partials(const RedSrc &src, const int (&s
 {
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
-        const double *p = src.base + (int64_t)slot[k] * src.slot_mul;
         double a = 0.0;
-        for (int i = threadIdx.x; i < src.count; i += EC3D_THREADS) a = a + p[(int64_t)i * src.stride];
+        if (src.ptrs) { // one value per rank, each in that rank's own memory
+            for (int i = threadIdx.x; i < src.count; i += EC3D_THREADS) a = a + src.ptrs[i][slot[k]];
+        } else {
+            const double *p = src.base + (int64_t)slot[k] * src.slot_mul;
+            for (int i = threadIdx.x; i < src.count; i += EC3D_THREADS) a = a + p[(int64_t)i * src.stride];
+        }
         out[k] = a;
     }
     block_sum<NV>(out, lds);
@@ -636,7 +640,15 @@ __global__ __launch_bounds__(EC3D_THREADS) void k5_p_update(Sweep sw, RedSrc src
                                                             double *__restrict__ r0, double *hist, int64_t hist_cap)
 {
     __shared__ double lds[8];
-    if (st->stop_iter <= it) return;
+    // Only exits taken by EARLIER launches end this one: the ||S|| exit of this iteration's K4
+    // (stop_iter == it, kind 1) or anything before.  The lead thread of THIS launch writes stop_iter = it
+    // (kind 2) below while other workgroups may still be at this test; a wave that returned on seeing it
+    // would leave its workgroup's barriers in reduce_partials short of a wave.  Every workgroup reaches the
+    // same ||R|| decision from the same sums anyway.  (kind is written before stop_iter, by one thread.)
+    {
+        const int si = st->stop_iter;
+        if (si < it || (si == it && st->stop_kind == 1)) return;
+    }
     const int slot[2] = {P_RR, P_RR0N};
     double d[2];
     reduce_partials<2>(src, slot, d, lds);

@@ -16,6 +16,7 @@ extern "C" int ec3d_time_iterations(ec3d_handle c, int32_t iters, double *ms_tot
 {
     int rc = ec3d_need_matrix(c, "ec3d_time_iterations");
     if (rc) return rc;
+    if ((rc = ec3d_single_rank_only(c, "ec3d_time_iterations"))) return rc;
     const MatView A = c->A.view();
     c->hist_cap = 0;
     if ((rc = ec3d_launch_begin(c, A, -1.0))) return rc; // tol < 0: no exit, no restart
@@ -44,6 +45,7 @@ extern "C" int ec3d_iterate(ec3d_handle c, int32_t first_iter, int32_t count, do
 {
     int rc = ec3d_need_matrix(c, "ec3d_iterate");
     if (rc) return rc;
+    if ((rc = ec3d_single_rank_only(c, "ec3d_iterate"))) return rc;
     const MatView A = c->A.view();
     if (!kernel_ms) {
         for (int it = first_iter; it < first_iter + count; ++it) ec3d_launch_iteration(c, A, it);
@@ -80,6 +82,7 @@ extern "C" int ec3d_time_kernel(ec3d_handle c, int kernel, int32_t reps, double 
 {
     int rc = ec3d_need_matrix(c, "ec3d_time_kernel");
     if (rc) return rc;
+    if ((rc = ec3d_single_rank_only(c, "ec3d_time_kernel"))) return rc;
     const MatView A = c->A.view();
     double **v = c->vec;
     hipStream_t s = c->stream;

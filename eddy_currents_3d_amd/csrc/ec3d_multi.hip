@@ -1,0 +1,1073 @@
+// ec3d_multi.hip — z-slab multi-GPU INSIDE the library: one process, N devices, one host thread per slab.
+//
+// The reference is serial; its caller (src/EC3D.f90:408) must not have to know that the solve
+// runs on several GPUs (SURVEY §8b "Threading").  So the decomposition of eddy_currents_3d_amd/dist.py --
+// rank g owns the z-planes [k0, k1), halo planes of P and S once per SpMV, three reduction points per
+// iteration, rank-ordered sums -- is driven here from C++, behind one handle:
+//
+//   * every slab is an ordinary ec3d_ctx on its own device (ec3d_assemble_poisson_slab / ec3d_assemble_slab)
+//     and runs the stages of ec3d_dist_step; one host thread per slab enqueues them, so the enqueue cost
+//     per iteration does not grow with the number of GPUs;
+//   * halo planes are PULLED: the consumer's side stream waits for the neighbour's "boundary rows are final"
+//     event and copies the planes out of the neighbour's vector (peer access over xGMI) straight into its own
+//     ghost rows -- contiguous, in place, no packing -- while the interior launch runs on the compute stream;
+//   * dot products are not gathered at all: every rank collapses its partials into its own lsum[8]
+//     (k_finalize), records an event, and the consumer kernels of ALL ranks read the N lsum arrays in place
+//     through a pointer table (RedSrc::ptrs) and add them in rank order -- identical decisions everywhere,
+//     bit-identical to the staged drivers in dist.py; lsum lives in fine-grained memory;
+//   * cross-device ordering is hipStreamWaitEvent on events recorded by the other slabs' threads; a thread
+//     announces "recorded" through a per-slab sequence counter the others spin on (every thread runs the
+//     same plan, and always posts before it waits, so there is no cycle).
+// Several slabs may share one device (tests and rehearsals on a one-GPU box): same code, the peer copies
+// become local ones.
+#include "../../include/ec3d_hip.h"
+#include "ec3d_internal.hpp"
+
+#include <algorithm>
+#include <atomic>
+#include <climits>
+#include <cmath>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <thread>
+
+namespace {
+constexpr int RING = 4;
+enum { CH_P = 0, CH_S = 1, CH_X = 2, CH_SUM = 3, NCH = 4 };
+const int kVecOf[3] = {EC3D_VEC_P, EC3D_VEC_S, EC3D_VEC_X};
+
+// a run of halo planes inside one work vector: `planes` pieces of `payload` doubles, `pitch` apart
+struct Run {
+    int64_t start = 0, pitch = 0, payload = 0;
+    int planes = 0;
+    int64_t lo() const { return start; }
+    int64_t hi() const { return start + (int64_t)(planes - 1) * pitch + std::max(payload, planes > 1 ? pitch : payload); }
+};
+struct Copy {
+    int64_t dst, src, cnt;
+};
+
+enum { OP_HALO = 0, OP_HALO_START, OP_HALO_WAIT, OP_GATHER, OP_STEP };
+struct Op {
+    int kind, arg;
+};
+#define ST(x) Op{OP_STEP, EC3D_STAGE_##x}
+const std::vector<Op> kBegin = {{OP_HALO, CH_X}, ST(RESID), {OP_GATHER, 0}, ST(SETUP)};
+const std::vector<Op> kBeginVsplit = {{OP_HALO, CH_X}, ST(RESID), {OP_GATHER, 0}, ST(SETUP), {OP_HALO, CH_P}};
+// three reduction points per iteration (K3 is launched before ||S|| is known)
+const std::vector<Op> kIter = {{OP_HALO, CH_P}, ST(K1), {OP_GATHER, 0}, ST(K2), {OP_HALO, CH_S},
+                               ST(K3), {OP_GATHER, 0}, ST(K4), {OP_GATHER, 0}, ST(K5)};
+// exchange hidden behind the interior planes of K1/K3 (single-component slabs on a z-marching grid)
+const std::vector<Op> kIterOverlap = {{OP_HALO_START, CH_P}, ST(K1_INT), {OP_HALO_WAIT, CH_P}, ST(K1_BND), {OP_GATHER, 0},
+                                      ST(K2), {OP_HALO_START, CH_S}, ST(K3_INT), {OP_HALO_WAIT, CH_S}, ST(K3_BND),
+                                      {OP_GATHER, 0}, ST(K4), {OP_GATHER, 0}, ST(K5)};
+// the same from the producers' side (A-V slabs, any storage): K2/K5 boundary tiles first
+const std::vector<Op> kIterVsplit = {{OP_HALO_WAIT, CH_P}, ST(K1), {OP_GATHER, 0}, ST(K2_BND), {OP_HALO_START, CH_S},
+                                     ST(K2_INT), {OP_HALO_WAIT, CH_S}, ST(K3), {OP_GATHER, 0}, ST(K4), {OP_GATHER, 0},
+                                     ST(K5_BND), {OP_HALO_START, CH_P}, ST(K5_INT)};
+#undef ST
+
+struct Slab {
+    ec3d_ctx *c = nullptr;
+    int rank = 0, device = 0;
+    int32_t k0 = 0, k1 = 0, e0 = 0, e1 = 0; // owned planes [k0,k1), held planes [e0,e1)
+    double *lsum = nullptr;
+    bool lsum_fine = false;
+    const double **ptr_table = nullptr; // device: every rank's lsum
+    hipStream_t side = nullptr;
+    hipEvent_t ev_ready[3][RING] = {}, ev_halo[3][RING] = {}, ev_sum[RING] = {};
+    uint64_t seq[NCH] = {0, 0, 0, 0};
+    std::atomic<uint64_t> posted[NCH];
+    std::vector<Run> send_lo, recv_lo, send_hi, recv_hi; // towards rank-1 / rank+1, same order on both sides
+    std::vector<Copy> pull_lo, pull_hi;                  // my ghost rows <- neighbour's rows
+    bool split_ok = false;
+    int plan = 0; // 0 plain, 1 overlap (K1/K3 interior + boundary), 2 vsplit (K2/K5 boundary first)
+    int32_t *stop_pinned = nullptr;
+    hipEvent_t ev_stop[2] = {};
+    // A-V slab: local reference order [Ax_ext | Ay_ext | Az_ext | U_ext] <-> the global vector
+    int64_t nC_ext = 0, nU_ext = 0, n_local = 0;
+    std::vector<int32_t> u_glob;        // global U index of every held U unknown
+    int64_t own_lo[4] = {0}, own_hi[4] = {0}; // owned rows, local reference numbering
+    std::vector<double> io;             // staging for host <-> device copies of an A-V slab
+    std::string err;
+    Slab() { for (auto &p : posted) p.store(0); }
+};
+
+struct Pool {
+    std::vector<std::thread> th;
+    std::mutex m;
+    std::condition_variable cv, done_cv;
+    std::function<int(int)> job;
+    uint64_t gen = 0;
+    int pending = 0;
+    std::vector<int> rc;
+    bool quit = false;
+};
+} // namespace
+
+struct ec3d_multi {
+    int n = 0;
+    std::vector<std::unique_ptr<Slab>> slab;
+    Pool pool;
+    std::atomic<bool> abort{false};
+    int kind = 0; // 0: no matrix, 1: single component (ec3d_assemble_poisson), 2: A-V system
+    int32_t sdx = 0, sdy = 0, sdz = 0;
+    int64_t kdz = 0, nC_glob = 0, nU_glob = 0, n_glob = 0;
+    int64_t nnz = 0;
+};
+
+namespace {
+#define MHIP(call)                                                                             \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            ec3d_set_error(std::string(#call) + ": " + hipGetErrorString(e_));                 \
+            return 100;                                                                        \
+        }                                                                                      \
+    } while (0)
+
+void worker(ec3d_multi *m, int r)
+{
+    Pool &p = m->pool;
+    (void)hipSetDevice(m->slab[(size_t)r]->device);
+    uint64_t seen = 0;
+    for (;;) {
+        std::function<int(int)> job;
+        {
+            std::unique_lock<std::mutex> lk(p.m);
+            p.cv.wait(lk, [&] { return p.quit || p.gen != seen; });
+            if (p.quit) return;
+            seen = p.gen;
+            job = p.job;
+        }
+        int rc = job(r);
+        if (rc) {
+            m->slab[(size_t)r]->err = ec3d_last_error();
+            m->abort.store(true);
+        }
+        {
+            std::lock_guard<std::mutex> lk(p.m);
+            p.rc[(size_t)r] = rc;
+            if (--p.pending == 0) p.done_cv.notify_all();
+        }
+    }
+}
+
+// run fn(rank) on every slab's thread; first failure wins (its message becomes ec3d_last_error())
+int run_all(ec3d_multi *m, const std::function<int(int)> &fn)
+{
+    Pool &p = m->pool;
+    {
+        std::unique_lock<std::mutex> lk(p.m);
+        p.job = fn;
+        p.pending = m->n;
+        std::fill(p.rc.begin(), p.rc.end(), 0);
+        ++p.gen;
+        p.cv.notify_all();
+        p.done_cv.wait(lk, [&] { return p.pending == 0; });
+    }
+    int rc = 0;
+    for (int r = 0; r < m->n; ++r)
+        if (p.rc[(size_t)r]) {
+            // a rank that only gave up because another one failed reports 90
+            if (!rc || rc == 90) {
+                rc = p.rc[(size_t)r];
+                ec3d_set_error("rank " + std::to_string(r) + ": " + m->slab[(size_t)r]->err);
+            }
+        }
+    if (m->abort.load()) { // leave every stream idle and the channels aligned for the next call
+        for (auto &s : m->slab) {
+            (void)hipSetDevice(s->device);
+            (void)hipDeviceSynchronize();
+            for (int ch = 0; ch < NCH; ++ch) {
+                s->seq[ch] = 0;
+                s->posted[ch].store(0);
+            }
+        }
+        m->abort.store(false);
+    }
+    return rc;
+}
+
+int wait_posted(ec3d_multi *m, Slab &peer, int ch, uint64_t q)
+{
+    int spins = 0;
+    while (peer.posted[ch].load(std::memory_order_acquire) < q) {
+        if (m->abort.load(std::memory_order_relaxed)) {
+            ec3d_set_error("gave up: another rank failed");
+            return 90;
+        }
+        if (++spins > 256) std::this_thread::yield();
+    }
+    return 0;
+}
+
+int halo_start(ec3d_multi *m, Slab &s, int v)
+{
+    const uint64_t q = ++s.seq[v];
+    const int i = (int)(q % RING), vi = kVecOf[v];
+    MHIP(hipEventRecord(s.ev_ready[v][i], s.c->stream));
+    s.posted[v].store(q, std::memory_order_release);
+    // my own earlier readers of the ghost rows are behind this point of my compute stream
+    MHIP(hipStreamWaitEvent(s.side, s.ev_ready[v][i], 0));
+    for (int dir = -1; dir <= 1; dir += 2) {
+        const std::vector<Copy> &cp = dir < 0 ? s.pull_lo : s.pull_hi;
+        const int pr = s.rank + dir;
+        if (pr < 0 || pr >= m->n || cp.empty()) continue;
+        Slab &peer = *m->slab[(size_t)pr];
+        int rc = wait_posted(m, peer, v, q);
+        if (rc) return rc;
+        MHIP(hipStreamWaitEvent(s.side, peer.ev_ready[v][i], 0));
+        double *mine = s.c->vec[vi];
+        const double *theirs = peer.c->vec[vi];
+        for (const Copy &c : cp) {
+            if (peer.device == s.device)
+                MHIP(hipMemcpyAsync(mine + c.dst, theirs + c.src, (size_t)c.cnt * 8, hipMemcpyDeviceToDevice, s.side));
+            else
+                MHIP(hipMemcpyPeerAsync(mine + c.dst, s.device, theirs + c.src, peer.device, (size_t)c.cnt * 8, s.side));
+        }
+    }
+    MHIP(hipEventRecord(s.ev_halo[v][i], s.side));
+    return 0;
+}
+
+int halo_wait(Slab &s, int v)
+{
+    if (s.seq[v] == 0) return 0;
+    MHIP(hipStreamWaitEvent(s.c->stream, s.ev_halo[v][(int)(s.seq[v] % RING)], 0));
+    return 0;
+}
+
+// "gather": nothing moves -- my lsum is final behind this event; my next kernel may read everybody's
+int gather(ec3d_multi *m, Slab &s)
+{
+    const uint64_t q = ++s.seq[CH_SUM];
+    const int i = (int)(q % RING);
+    MHIP(hipEventRecord(s.ev_sum[i], s.c->stream));
+    s.posted[CH_SUM].store(q, std::memory_order_release);
+    for (int h = 0; h < m->n; ++h) {
+        if (h == s.rank) continue;
+        Slab &peer = *m->slab[(size_t)h];
+        int rc = wait_posted(m, peer, CH_SUM, q);
+        if (rc) return rc;
+        MHIP(hipStreamWaitEvent(s.c->stream, peer.ev_sum[i], 0));
+    }
+    return 0;
+}
+
+int unsplit_stage(int st)
+{
+    switch (st) {
+    case EC3D_STAGE_K2_BND: return EC3D_STAGE_K2;
+    case EC3D_STAGE_K5_BND: return EC3D_STAGE_K5;
+    case EC3D_STAGE_K2_INT:
+    case EC3D_STAGE_K5_INT: return -1;
+    default: return st;
+    }
+}
+
+// kernel (0..4 = K1..K5) a stage's time is booked under; -1: none
+int kernel_of_stage(int st)
+{
+    switch (st) {
+    case EC3D_STAGE_K1: case EC3D_STAGE_K1_INT: case EC3D_STAGE_K1_BND: return 0;
+    case EC3D_STAGE_K2: case EC3D_STAGE_K2_INT: case EC3D_STAGE_K2_BND: return 1;
+    case EC3D_STAGE_K3: case EC3D_STAGE_K3_INT: case EC3D_STAGE_K3_BND: return 2;
+    case EC3D_STAGE_K4: return 3;
+    case EC3D_STAGE_K5: case EC3D_STAGE_K5_INT: case EC3D_STAGE_K5_BND: return 4;
+    default: return -1;
+    }
+}
+
+struct StageTimer {
+    std::vector<hipEvent_t> ev; // pairs
+    std::vector<int> kern;
+};
+
+int run_plan(ec3d_multi *m, Slab &s, const std::vector<Op> &plan, int it, double tol, StageTimer *tm)
+{
+    int rc = 0;
+    for (const Op &op : plan) {
+        switch (op.kind) {
+        case OP_HALO:
+            if ((rc = halo_start(m, s, op.arg))) return rc;
+            if ((rc = halo_wait(s, op.arg))) return rc;
+            break;
+        case OP_HALO_START: if ((rc = halo_start(m, s, op.arg))) return rc; break;
+        case OP_HALO_WAIT: if ((rc = halo_wait(s, op.arg))) return rc; break;
+        case OP_GATHER: if ((rc = gather(m, s))) return rc; break;
+        default: {
+            const int st = (s.plan == 2 && !s.split_ok) ? unsplit_stage(op.arg) : op.arg;
+            if (st < 0) break;
+            const int k = tm ? kernel_of_stage(st) : -1;
+            if (k >= 0) {
+                hipEvent_t a, b;
+                MHIP(hipEventCreate(&a));
+                MHIP(hipEventCreate(&b));
+                MHIP(hipEventRecord(a, s.c->stream));
+                rc = ec3d_dist_step(s.c, st, it, tol);
+                MHIP(hipEventRecord(b, s.c->stream));
+                tm->ev.push_back(a);
+                tm->ev.push_back(b);
+                tm->kern.push_back(k);
+            } else {
+                rc = ec3d_dist_step(s.c, st, it, tol);
+            }
+            if (rc) return rc;
+        }
+        }
+    }
+    return 0;
+}
+
+const std::vector<Op> &begin_plan(const Slab &s) { return s.plan == 2 ? kBeginVsplit : kBegin; }
+const std::vector<Op> &iter_plan(const Slab &s) { return s.plan == 2 ? kIterVsplit : s.plan == 1 ? kIterOverlap : kIter; }
+
+int drain(Slab &s)
+{
+    MHIP(hipStreamSynchronize(s.side));
+    MHIP(hipStreamSynchronize(s.c->stream));
+    return 0;
+}
+
+void slab_bounds(int sdz, int rank, int world, int32_t &k0, int32_t &k1)
+{
+    const int base = sdz / world, rem = sdz % world;
+    k0 = rank * base + std::min(rank, rem);
+    k1 = k0 + base + (rank < rem ? 1 : 0);
+}
+
+// (re)create the per-slab context and the multi-rank plumbing around it
+int slab_reset(ec3d_multi *m, Slab &s)
+{
+    MHIP(hipSetDevice(s.device));
+    if (!s.c) {
+        int rc = ec3d_create(&s.c, s.device);
+        if (rc) return rc;
+        MHIP(hipStreamCreateWithFlags(&s.side, hipStreamNonBlocking));
+        for (int v = 0; v < 3; ++v)
+            for (int i = 0; i < RING; ++i) {
+                MHIP(hipEventCreateWithFlags(&s.ev_ready[v][i], hipEventDisableTiming));
+                MHIP(hipEventCreateWithFlags(&s.ev_halo[v][i], hipEventDisableTiming));
+            }
+        for (int i = 0; i < RING; ++i) MHIP(hipEventCreateWithFlags(&s.ev_sum[i], hipEventDisableTiming));
+        for (int i = 0; i < 2; ++i) MHIP(hipEventCreateWithFlags(&s.ev_stop[i], hipEventDisableTiming));
+        MHIP(hipHostMalloc(&s.stop_pinned, 2 * sizeof(int32_t), hipHostMallocDefault));
+        // the 8 sums every other GPU reads in place: fine-grained (coherent across devices) when the
+        // runtime offers it
+        if (hipExtMallocWithFlags((void **)&s.lsum, P_NSLOT * sizeof(double), hipDeviceMallocFinegrained) == hipSuccess) {
+            s.lsum_fine = true;
+        } else {
+            (void)hipGetLastError();
+            MHIP(hipMalloc(&s.lsum, P_NSLOT * sizeof(double)));
+        }
+        MHIP(hipMemset(s.lsum, 0, P_NSLOT * sizeof(double)));
+        MHIP(hipMalloc(&s.ptr_table, (size_t)m->n * sizeof(double *)));
+        // peer access to every other device that holds a slab
+        for (auto &o : m->slab) {
+            if (o->device == s.device) continue;
+            int can = 0;
+            MHIP(hipDeviceCanAccessPeer(&can, s.device, o->device));
+            if (!can) {
+                ec3d_set_error("ec3d_multi: device " + std::to_string(s.device) + " cannot access device " +
+                               std::to_string(o->device) + " (no peer path)");
+                return 104;
+            }
+            hipError_t e = hipDeviceEnablePeerAccess(o->device, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
+                ec3d_set_error(std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
+                return 100;
+            }
+            (void)hipGetLastError();
+        }
+    }
+    s.send_lo.clear(); s.recv_lo.clear(); s.send_hi.clear(); s.recv_hi.clear();
+    s.pull_lo.clear(); s.pull_hi.clear();
+    s.u_glob.clear();
+    s.split_ok = false;
+    s.plan = 0;
+    return 0;
+}
+
+// after every slab has its matrix: pointer tables, dist mode, halo copy lists, launch plans
+int finish_setup(ec3d_multi *m)
+{
+    // copy lists: my recv run i towards rank+1 <- rank+1's send run i towards me (and the mirror image)
+    auto pair_up = [&](const std::vector<Run> &recv, const std::vector<Run> &send, std::vector<Copy> &out) -> int {
+        out.clear();
+        if (recv.size() != send.size()) {
+            ec3d_set_error("ec3d_multi: neighbouring slabs disagree on the halo layout");
+            return 105;
+        }
+        for (size_t i = 0; i < recv.size(); ++i) {
+            const Run &r = recv[i], &t = send[i];
+            if (r.planes != t.planes || r.payload != t.payload) {
+                ec3d_set_error("ec3d_multi: neighbouring slabs disagree on the halo size");
+                return 105;
+            }
+            if (r.payload == 0) continue;
+            if (r.pitch == t.pitch || r.planes == 1) { // one contiguous piece (plane padding included)
+                const int64_t cnt = r.planes == 1 ? r.payload : (int64_t)r.planes * r.pitch;
+                out.push_back(Copy{r.start, t.start, cnt});
+            } else {
+                for (int p = 0; p < r.planes; ++p) out.push_back(Copy{r.start + p * r.pitch, t.start + p * t.pitch, r.payload});
+            }
+        }
+        return 0;
+    };
+    int rc = 0;
+    for (int g = 0; g < m->n; ++g) {
+        Slab &s = *m->slab[(size_t)g];
+        if (g + 1 < m->n && (rc = pair_up(s.recv_hi, m->slab[(size_t)g + 1]->send_lo, s.pull_hi))) return rc;
+        if (g > 0 && (rc = pair_up(s.recv_lo, m->slab[(size_t)g - 1]->send_hi, s.pull_lo))) return rc;
+    }
+    std::vector<const double *> tab((size_t)m->n);
+    for (int g = 0; g < m->n; ++g) tab[(size_t)g] = m->slab[(size_t)g]->lsum;
+    return run_all(m, [&](int r) -> int {
+        Slab &s = *m->slab[(size_t)r];
+        MHIP(hipMemcpy(s.ptr_table, tab.data(), tab.size() * sizeof(double *), hipMemcpyHostToDevice));
+        ec3d_ctx *c = s.c;
+        c->dist = true;
+        c->nranks = m->n;
+        c->lsum = s.lsum;
+        c->gsum = nullptr;
+        c->lsum_ptrs = s.ptr_table;
+        s.plan = 0;
+        s.split_ok = false;
+        if (m->kind == 1) {
+            s.plan = ec3d_can_overlap(c) ? 1 : 0;
+        } else if (m->n > 1) {
+            // the ORDER of exchanges is a property of the job: every A-V rank uses the producer-side
+            // plan; a rank whose slab is all boundary runs the whole kernels in that order
+            s.plan = 2;
+            std::vector<int64_t> lo, hi;
+            for (const std::vector<Run> *rs : {&s.send_lo, &s.recv_lo, &s.send_hi, &s.recv_hi})
+                for (const Run &r : *rs)
+                    if (r.payload > 0) {
+                        lo.push_back(r.lo());
+                        hi.push_back(r.hi());
+                    }
+            int32_t en = 0;
+            if (!lo.empty()) {
+                int rc2 = ec3d_dist_set_boundary_rows(c, (int32_t)lo.size(), lo.data(), hi.data(), &en);
+                if (rc2) return rc2;
+            }
+            s.split_ok = en != 0;
+        }
+        return 0;
+    });
+}
+
+// owned ranges (local reference numbering) and halo runs (DEVICE rows) of an A-V slab whose matrix is in place.
+// upl[p] = held conducting cells before held plane p (np + 1 entries).
+void av_layout(ec3d_multi *m, Slab &s, const std::vector<int64_t> &upl)
+{
+    const int H = 2;
+    ec3d_ctx *c = s.c;
+    const int64_t kdz = m->kdz, nC = s.nC_ext, mloc = s.nU_ext;
+    const int64_t p0 = s.k0 - s.e0, p1 = s.k1 - s.e0;
+    for (int d = 0; d < 3; ++d) {
+        s.own_lo[d] = d * nC + p0 * kdz;
+        s.own_hi[d] = d * nC + p1 * kdz;
+    }
+    s.own_lo[3] = 3 * nC + upl[(size_t)p0];
+    s.own_hi[3] = 3 * nC + upl[(size_t)p1];
+    // The 7-point stencil and the U rows read A one plane away; only the one-sided A-U stencils
+    // (src/EC3D.f90:697-706) reach two planes, and they read U
+    struct Blk { int64_t base, pitch, payload; int h; };
+    std::vector<Blk> blocks;
+    const bool structured = c->A.sav != 0;
+    if (structured) {
+        for (int d = 0; d < 4; ++d) blocks.push_back(Blk{d * c->nCd, c->pitch, kdz, d < 3 ? 1 : H});
+    } else {
+        for (int d = 0; d < 3; ++d) blocks.push_back(Blk{d * nC, kdz, kdz, 1});
+    }
+    if (s.e0 < s.k0) {
+        for (const Blk &b : blocks) {
+            s.send_lo.push_back(Run{b.base + p0 * b.pitch, b.pitch, b.payload, b.h});
+            s.recv_lo.push_back(Run{b.base + (p0 - b.h) * b.pitch, b.pitch, b.payload, b.h});
+        }
+        if (!structured) { // compact U block: the U cells of my first two owned planes / my lower halo planes
+            const int64_t ulo = upl[(size_t)p0], cnt_s = upl[(size_t)(p0 + H)] - ulo;
+            s.send_lo.push_back(Run{3 * nC + ulo, cnt_s, cnt_s, 1});
+            s.recv_lo.push_back(Run{3 * nC, ulo, ulo, 1});
+        }
+    }
+    if (s.k1 < s.e1) {
+        for (const Blk &b : blocks) {
+            s.send_hi.push_back(Run{b.base + (p1 - b.h) * b.pitch, b.pitch, b.payload, b.h});
+            s.recv_hi.push_back(Run{b.base + p1 * b.pitch, b.pitch, b.payload, b.h});
+        }
+        if (!structured) {
+            const int64_t uend = upl[(size_t)p1], cnt_s = uend - upl[(size_t)(p1 - H)], cnt_r = mloc - uend;
+            s.send_hi.push_back(Run{3 * nC + uend - cnt_s, cnt_s, cnt_s, 1});
+            s.recv_hi.push_back(Run{3 * nC + uend, cnt_r, cnt_r, 1});
+        }
+    }
+}
+
+int need(ec3d_multi *m, const char *who)
+{
+    if (!m || m->kind == 0) {
+        ec3d_set_error(std::string(who) + ": no matrix (call ec3d_multi_assemble* first)");
+        return 3;
+    }
+    return 0;
+}
+
+// host vector in the reference's global numbering -> this slab's work vector (owned AND halo entries)
+int slab_upload(ec3d_multi *m, Slab &s, int which, const double *glob)
+{
+    ec3d_ctx *c = s.c;
+    int rc = 0;
+    if (m->kind == 1) {
+        rc = ec3d_vec_h2d(c, c->vec[which], glob + (int64_t)s.k0 * m->kdz);
+    } else {
+        s.io.resize((size_t)s.n_local);
+        for (int d = 0; d < 3; ++d)
+            memcpy(s.io.data() + (size_t)d * s.nC_ext, glob + d * m->nC_glob + (int64_t)s.e0 * m->kdz,
+                   (size_t)s.nC_ext * sizeof(double));
+        double *u = s.io.data() + (size_t)3 * s.nC_ext;
+        const double *gu = glob + 3 * m->nC_glob;
+        for (int64_t q = 0; q < s.nU_ext; ++q) u[q] = gu[s.u_glob[(size_t)q]];
+        rc = ec3d_vec_h2d(c, c->vec[which], s.io.data());
+    }
+    if (rc) return rc;
+    MHIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// the OWNED entries of this slab's work vector -> the global host vector
+int slab_download(ec3d_multi *m, Slab &s, int which, double *glob)
+{
+    ec3d_ctx *c = s.c;
+    int rc = 0;
+    if (m->kind == 1) {
+        if ((rc = ec3d_vec_d2h(c, glob + (int64_t)s.k0 * m->kdz, c->vec[which]))) return rc;
+        MHIP(hipStreamSynchronize(c->stream));
+        return 0;
+    }
+    s.io.resize((size_t)s.n_local);
+    if ((rc = ec3d_vec_d2h(c, s.io.data(), c->vec[which]))) return rc;
+    MHIP(hipStreamSynchronize(c->stream));
+    for (int d = 0; d < 3; ++d)
+        memcpy(glob + d * m->nC_glob + (int64_t)s.k0 * m->kdz, s.io.data() + (size_t)s.own_lo[d],
+               (size_t)(s.own_hi[d] - s.own_lo[d]) * sizeof(double));
+    double *gu = glob + 3 * m->nC_glob;
+    for (int64_t q = s.own_lo[3]; q < s.own_hi[3]; ++q) gu[s.u_glob[(size_t)(q - 3 * s.nC_ext)]] = s.io[(size_t)q];
+    return 0;
+}
+
+// one reference solve on the resident slabs (src/solvers.f90:3-50); every rank returns the same iter
+int slab_solve(ec3d_multi *m, Slab &s, double tol, int32_t itmax, int32_t *iter_out, int *hit_itmax)
+{
+    ec3d_ctx *c = s.c;
+    const int64_t total = std::max<int64_t>(0, (int64_t)itmax + 1); // src/solvers.f90:25-29
+    int rc = run_plan(m, s, begin_plan(s), 0, tol, nullptr);
+    if (rc) return rc;
+    const double est_us = (double)c->A.n_pad * 264.0 / 4.0e6 + 12.0;
+    const int chunk = (int)std::min<double>(32.0, std::max<double>(1.0, 400.0 / est_us));
+    int64_t launched = 0;
+    int ci = 0;
+    bool stopped = false;
+    // every rank derives the same decisions from the same sums, so all see the flag at the same chunk and
+    // leave together; iterations enqueued past the exit return at once and touch nothing
+    while (launched < total && !stopped) {
+        const int64_t n = std::min<int64_t>(chunk, total - launched);
+        for (int64_t i = 0; i < n; ++i)
+            if ((rc = run_plan(m, s, iter_plan(s), (int)(++launched), 0.0, nullptr))) return rc;
+        if ((rc = ec3d_read_state_async(c, &s.stop_pinned[ci & 1]))) return rc;
+        MHIP(hipEventRecord(s.ev_stop[ci & 1], c->stream));
+        if (ci > 0) {
+            MHIP(hipEventSynchronize(s.ev_stop[(ci - 1) & 1]));
+            if (s.stop_pinned[(ci - 1) & 1] != INT_MAX) stopped = true;
+        }
+        ++ci;
+    }
+    if ((rc = drain(s))) return rc;
+    int32_t si = 0;
+    if ((rc = ec3d_read_state(c, &si, nullptr, nullptr))) return rc;
+    *iter_out = si >= 0 ? si : (int32_t)total;
+    *hit_itmax = si < 0;
+    return 0;
+}
+} // namespace
+
+// ---------------------------------------------------------------------------------------------
+extern "C" int ec3d_multi_create(ec3d_multi_handle *mh, int32_t nranks, const int32_t *devices)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        ec3d_set_error("ec3d_multi_create: no HIP device available (this library has no CPU path)");
+        return 101;
+    }
+    if (nranks < 1 || nranks > 64) {
+        ec3d_set_error("ec3d_multi_create: nranks must be 1..64");
+        return 2;
+    }
+    if (!devices && nranks > ndev) {
+        ec3d_set_error("ec3d_multi_create: needs " + std::to_string(nranks) + " devices, this machine has " +
+                       std::to_string(ndev));
+        return 103;
+    }
+    for (int r = 0; devices && r < nranks; ++r)
+        if (devices[r] < 0 || devices[r] >= ndev) {
+            ec3d_set_error("ec3d_multi_create: device ordinal " + std::to_string(devices[r]) + " out of range (" +
+                           std::to_string(ndev) + " devices)");
+            return 102;
+        }
+    ec3d_multi *m = new ec3d_multi();
+    m->n = nranks;
+    for (int r = 0; r < nranks; ++r) {
+        m->slab.emplace_back(new Slab());
+        m->slab.back()->rank = r;
+        m->slab.back()->device = devices ? devices[r] : r;
+    }
+    m->pool.rc.assign((size_t)nranks, 0);
+    for (int r = 0; r < nranks; ++r) m->pool.th.emplace_back(worker, m, r);
+    int rc = run_all(m, [&](int r) { return slab_reset(m, *m->slab[(size_t)r]); });
+    if (rc) {
+        std::string keep = ec3d_last_error();
+        ec3d_multi_destroy(m);
+        ec3d_set_error(keep);
+        return rc;
+    }
+    *mh = m;
+    return 0;
+}
+
+extern "C" int ec3d_multi_destroy(ec3d_multi_handle m)
+{
+    if (!m) return 0;
+    (void)run_all(m, [&](int r) -> int {
+        Slab &s = *m->slab[(size_t)r];
+        (void)hipSetDevice(s.device);
+        (void)hipDeviceSynchronize();
+        if (s.c) (void)ec3d_destroy(s.c);
+        s.c = nullptr;
+        if (s.side) (void)hipStreamDestroy(s.side);
+        for (int v = 0; v < 3; ++v)
+            for (int i = 0; i < RING; ++i) {
+                if (s.ev_ready[v][i]) (void)hipEventDestroy(s.ev_ready[v][i]);
+                if (s.ev_halo[v][i]) (void)hipEventDestroy(s.ev_halo[v][i]);
+            }
+        for (int i = 0; i < RING; ++i)
+            if (s.ev_sum[i]) (void)hipEventDestroy(s.ev_sum[i]);
+        for (int i = 0; i < 2; ++i)
+            if (s.ev_stop[i]) (void)hipEventDestroy(s.ev_stop[i]);
+        if (s.stop_pinned) (void)hipHostFree(s.stop_pinned);
+        if (s.lsum) (void)hipFree(s.lsum);
+        if (s.ptr_table) (void)hipFree(s.ptr_table);
+        return 0;
+    });
+    {
+        std::lock_guard<std::mutex> lk(m->pool.m);
+        m->pool.quit = true;
+        m->pool.cv.notify_all();
+    }
+    for (auto &t : m->pool.th) t.join();
+    delete m;
+    return 0;
+}
+
+extern "C" int ec3d_multi_ranks(ec3d_multi_handle m) { return m ? m->n : 0; }
+
+extern "C" int ec3d_multi_slab(ec3d_multi_handle m, int32_t rank, ec3d_handle *h, int32_t *k0, int32_t *k1)
+{
+    if (!m || rank < 0 || rank >= m->n) return 2;
+    Slab &s = *m->slab[(size_t)rank];
+    if (h) *h = s.c;
+    if (k0) *k0 = s.k0;
+    if (k1) *k1 = s.k1;
+    return 0;
+}
+
+extern "C" int ec3d_multi_set_format(ec3d_multi_handle m, int dictionary, int structured)
+{
+    if (!m) return 2;
+    for (auto &s : m->slab) {
+        if (dictionary >= 0) s->c->use_dict = dictionary != 0;
+        if (structured >= 0) s->c->use_sav = structured != 0;
+    }
+    return 0;
+}
+
+// ---- the single-component operator of BASELINE configs 2 and 4 (ec3d_assemble_poisson) on z-slabs -------
+extern "C" int ec3d_multi_assemble_poisson(ec3d_multi_handle m, int32_t sdx, int32_t sdy, int32_t sdz,
+                                           const double *BND, const double *delta)
+{
+    if (!m) return 2;
+    if (sdz < m->n) {
+        ec3d_set_error("ec3d_multi_assemble_poisson: fewer z-planes than ranks");
+        return 2;
+    }
+    m->kind = 0;
+    m->sdx = sdx; m->sdy = sdy; m->sdz = sdz;
+    m->kdz = (int64_t)sdx * sdy;
+    m->nC_glob = m->kdz * sdz;
+    m->nU_glob = 0;
+    m->n_glob = m->nC_glob;
+    int rc = run_all(m, [&](int r) -> int {
+        Slab &s = *m->slab[(size_t)r];
+        int rc2 = slab_reset(m, s);
+        if (rc2) return rc2;
+        slab_bounds(sdz, r, m->n, s.k0, s.k1);
+        s.e0 = s.k0;
+        s.e1 = s.k1;
+        rc2 = m->n == 1 ? ec3d_assemble_poisson(s.c, sdx, sdy, sdz, BND, delta)
+                        : ec3d_assemble_poisson_slab(s.c, sdx, sdy, sdz, s.k0, s.k1, BND, delta);
+        if (rc2) return rc2;
+        const int64_t kdz = m->kdz, n = (int64_t)(s.k1 - s.k0) * kdz;
+        s.n_local = n;
+        if (s.c->ghost < kdz && m->n > 1) {
+            ec3d_set_error("ec3d_multi: ghost zone smaller than a plane");
+            return 105;
+        }
+        if (r > 0) {
+            s.send_lo.push_back(Run{0, kdz, kdz, 1});
+            s.recv_lo.push_back(Run{-kdz, kdz, kdz, 1});
+        }
+        if (r + 1 < m->n) {
+            s.send_hi.push_back(Run{n - kdz, kdz, kdz, 1});
+            s.recv_hi.push_back(Run{n, kdz, kdz, 1});
+        }
+        return 0;
+    });
+    if (rc) return rc;
+    m->kind = 1;
+    m->nnz = 0;
+    for (auto &s : m->slab) m->nnz += s->c->A.nnz;
+    return finish_setup(m);
+}
+
+// ---- the full A-V system (ec3d_assemble, src/EC3D.f90:465-1049) on z-slabs: global tables in, the library
+//      cuts the extended slabs (two halo planes per interior side) and renumbers the U unknowns per slab
+extern "C" int ec3d_multi_assemble(ec3d_multi_handle m, int32_t sdx, int32_t sdy, int32_t sdz, const int8_t *geoPHYS,
+                                   const int32_t *geoPHYS_C, const double *valPHYS, int32_t nsub_glob,
+                                   const double *BND, const double *delta, double dt)
+{
+    if (!m) return 2;
+    const int H = 2;
+    if (m->n > 1 && sdz < H * m->n) {
+        ec3d_set_error("ec3d_multi_assemble: every rank needs at least two z-planes");
+        return 2;
+    }
+    m->kind = 0;
+    m->sdx = sdx; m->sdy = sdy; m->sdz = sdz;
+    m->kdz = (int64_t)sdx * sdy;
+    m->nC_glob = m->kdz * sdz;
+    int64_t nU = 0;
+    for (int64_t q = 0; q < m->nC_glob; ++q) nU += geoPHYS_C[q] != 0;
+    m->nU_glob = nU;
+    m->n_glob = 3 * m->nC_glob + nU;
+    for (int64_t q = 0; q < m->nC_glob; ++q)
+        if (geoPHYS_C[q] != 0 && (geoPHYS_C[q] <= 3 * m->nC_glob || geoPHYS_C[q] > m->n_glob)) {
+            ec3d_set_error("ec3d_multi_assemble: geoPHYS_C holds a U column id outside 3*nCells+1 .. n");
+            return 2;
+        }
+    int rc = run_all(m, [&](int r) -> int {
+        Slab &s = *m->slab[(size_t)r];
+        int rc2 = slab_reset(m, s);
+        if (rc2) return rc2;
+        slab_bounds(sdz, r, m->n, s.k0, s.k1);
+        s.e0 = std::max(0, s.k0 - H);
+        s.e1 = std::min(sdz, s.k1 + H);
+        const int64_t kdz = m->kdz, np = s.e1 - s.e0, nC = np * kdz;
+        const int8_t *geo = geoPHYS + (int64_t)s.e0 * kdz;
+        const int32_t *gc = geoPHYS_C + (int64_t)s.e0 * kdz;
+        std::vector<int32_t> gc_ext((size_t)nC, 0);
+        std::vector<int64_t> upl((size_t)np + 1, 0); // conducting cells before held plane p
+        int64_t mloc = 0;
+        for (int64_t p = 0; p < np; ++p) {
+            upl[(size_t)p] = mloc;
+            for (int64_t q = p * kdz; q < (p + 1) * kdz; ++q)
+                if (gc[q] != 0) {
+                    gc_ext[(size_t)q] = (int32_t)(3 * nC + 1 + mloc++);
+                    s.u_glob.push_back((int32_t)(gc[q] - 3 * m->nC_glob - 1));
+                }
+        }
+        upl[(size_t)np] = mloc;
+        s.nC_ext = nC;
+        s.nU_ext = mloc;
+        s.n_local = 3 * nC + mloc;
+        if (m->n == 1)
+            rc2 = ec3d_assemble(s.c, sdx, sdy, sdz, geo, gc_ext.data(), valPHYS, nsub_glob, BND, delta, dt);
+        else
+            rc2 = ec3d_assemble_slab(s.c, sdx, sdy, sdz, s.e0, s.e1, s.k0, s.k1, geo, gc_ext.data(), valPHYS, nsub_glob,
+                                     BND, delta, dt);
+        if (rc2) return rc2;
+        av_layout(m, s, upl);
+        return 0;
+    });
+    if (rc) return rc;
+    // neighbours must agree on the storage (a slab that fell back to bands + tail next to a structured one
+    // would exchange differently shaped blocks)
+    for (int g = 0; g + 1 < m->n; ++g)
+        if ((m->slab[(size_t)g]->c->A.sav != 0) != (m->slab[(size_t)g + 1]->c->A.sav != 0)) {
+            ec3d_set_error("ec3d_multi_assemble: slabs chose different storage formats; call "
+                           "ec3d_multi_set_format(h, -1, 0) to use bands + tail everywhere");
+            return 105;
+        }
+    m->kind = 2;
+    m->nnz = 0; // per-slab counts include inert halo rows: not summed
+    return finish_setup(m);
+}
+
+// ---- the reference's CSR triple (what sprsbcgstabwr_ receives): recognised as the A-V system on a grid
+//      (ec3d_sav_csr.cpp), then cut into slabs of the structured form -----------------------------------------
+extern "C" int ec3d_multi_set_matrix_csr(ec3d_multi_handle m, int32_t n, const double *valA, const int32_t *irow,
+                                         const int32_t *jcol)
+{
+    if (!m) return 2;
+    const int H = 2;
+    m->kind = 0;
+    SavHost G;
+    if (ec3d_csr_to_sav_host(n, valA, irow, jcol, G) != 0) {
+        ec3d_set_error("ec3d_multi_set_matrix_csr: the matrix is not recognised as the reference's A-V system on a "
+                       "grid (ec3d_probe_csr), so there are no z-planes to cut it along; use one GPU");
+        return 7;
+    }
+    const int64_t sdz = G.nCd / G.pitch;
+    if (m->n > 1 && sdz < (int64_t)H * m->n) {
+        ec3d_set_error("ec3d_multi_set_matrix_csr: every rank needs at least two z-planes");
+        return 2;
+    }
+    m->sdx = (int32_t)G.sdx; m->sdy = (int32_t)(G.plane / G.sdx); m->sdz = (int32_t)sdz;
+    m->kdz = G.plane;
+    m->nC_glob = G.plane * sdz;
+    m->nU_glob = (int64_t)G.cond_cell.size();
+    m->n_glob = n;
+    int rc = run_all(m, [&](int r) -> int {
+        Slab &s = *m->slab[(size_t)r];
+        int rc2 = slab_reset(m, s);
+        if (rc2) return rc2;
+        slab_bounds((int)sdz, r, m->n, s.k0, s.k1);
+        s.e0 = std::max(0, s.k0 - H);
+        s.e1 = std::min((int32_t)sdz, s.k1 + H);
+        const int64_t np = s.e1 - s.e0;
+        if (m->n == 1) {
+            if ((rc2 = ec3d_upload_sav(s.c, G))) return rc2;
+        } else {
+            SavHost L;
+            ec3d_sav_slice(G, s.e0, s.e1, s.k0, s.k1, L);
+            if ((rc2 = ec3d_upload_sav(s.c, L))) return rc2;
+        }
+        // held conducting cells: one contiguous run of the global scan-order list
+        std::vector<int64_t> upl((size_t)np + 1, 0);
+        int64_t first = -1, cnt = 0;
+        for (size_t q = 0; q < G.cond_cell.size(); ++q) {
+            const int64_t pl = G.cond_cell[q] / G.pitch;
+            if (pl < s.e0 || pl >= s.e1) continue;
+            if (first < 0) first = (int64_t)q;
+            ++cnt;
+            ++upl[(size_t)(pl - s.e0) + 1];
+        }
+        for (int64_t p = 0; p < np; ++p) upl[(size_t)p + 1] += upl[(size_t)p];
+        s.u_glob.resize((size_t)cnt);
+        for (int64_t q = 0; q < cnt; ++q) s.u_glob[(size_t)q] = (int32_t)(first + q);
+        s.nC_ext = np * G.plane;
+        s.nU_ext = cnt;
+        s.n_local = 3 * s.nC_ext + cnt;
+        av_layout(m, s, upl);
+        return 0;
+    });
+    if (rc) return rc;
+    m->kind = 2;
+    m->nnz = G.nnz;
+    return finish_setup(m);
+}
+
+extern "C" int ec3d_multi_upload(ec3d_multi_handle m, int which, const double *host)
+{
+    int rc = need(m, "ec3d_multi_upload");
+    if (rc) return rc;
+    if (which < 0 || which >= EC3D_NVEC) return 2;
+    return run_all(m, [&](int r) { return slab_upload(m, *m->slab[(size_t)r], which, host); });
+}
+
+extern "C" int ec3d_multi_download(ec3d_multi_handle m, int which, double *host)
+{
+    int rc = need(m, "ec3d_multi_download");
+    if (rc) return rc;
+    if (which < 0 || which >= EC3D_NVEC) return 2;
+    return run_all(m, [&](int r) { return slab_download(m, *m->slab[(size_t)r], which, host); });
+}
+
+extern "C" int ec3d_multi_size(ec3d_multi_handle m, int64_t *n)
+{
+    int rc = need(m, "ec3d_multi_size");
+    if (rc) return rc;
+    *n = m->n_glob;
+    return 0;
+}
+
+extern "C" int ec3d_multi_solve_resident(ec3d_multi_handle m, double tolerance, int32_t itmax, int32_t *iter)
+{
+    int rc = need(m, "ec3d_multi_solve_resident");
+    if (rc) return rc;
+    std::vector<int32_t> its((size_t)m->n, -1);
+    std::vector<int> hit((size_t)m->n, 0);
+    rc = run_all(m, [&](int r) {
+        return slab_solve(m, *m->slab[(size_t)r], tolerance, itmax, &its[(size_t)r], &hit[(size_t)r]);
+    });
+    if (rc) return rc;
+    for (int r = 1; r < m->n; ++r)
+        if (its[(size_t)r] != its[0]) {
+            ec3d_set_error("ec3d_multi_solve: ranks disagree on the iteration count (" + std::to_string(its[0]) + " vs " +
+                           std::to_string(its[(size_t)r]) + ")");
+            return 106;
+        }
+    *iter = its[0];
+    if (hit[0]) {
+        // itmax exit: the reference prints norm2(R) and returns (src/solvers.f90:25-28); ||R||^2 = the ranks'
+        // last R.R sums added in rank order
+        double s = 0.0;
+        for (auto &sl : m->slab) {
+            double v = 0.0;
+            (void)hipSetDevice(sl->device);
+            EC3D_HIP(hipMemcpy(&v, sl->lsum + P_RR, sizeof v, hipMemcpyDeviceToHost));
+            s += v;
+        }
+        printf(" %.17g\n", std::sqrt(s));
+        fflush(stdout);
+    }
+    return 0;
+}
+
+extern "C" int ec3d_multi_solve(ec3d_multi_handle m, const double *b, double *x, double tolerance, int32_t itmax,
+                                int32_t *iter)
+{
+    int rc = need(m, "ec3d_multi_solve");
+    if (rc) return rc;
+    if ((rc = run_all(m, [&](int r) -> int {
+             Slab &s = *m->slab[(size_t)r];
+             int rc2 = slab_upload(m, s, EC3D_VEC_B, b);
+             return rc2 ? rc2 : slab_upload(m, s, EC3D_VEC_X, x);
+         })))
+        return rc;
+    if ((rc = ec3d_multi_solve_resident(m, tolerance, itmax, iter))) return rc;
+    return run_all(m, [&](int r) { return slab_download(m, *m->slab[(size_t)r], EC3D_VEC_X, x); });
+}
+
+// ---- the time loop around the solve on slabs (src/EC3D.f90:275-404, :412-433; SlabSolver.rhs_step) ------
+extern "C" int ec3d_multi_rhs_step(ec3d_multi_handle m, int32_t moving, int32_t nsrc, const int32_t *src_index,
+                                   const double *src_value)
+{
+    int rc = need(m, "ec3d_multi_rhs_step");
+    if (rc) return rc;
+    if (m->kind != 2) {
+        ec3d_set_error("ec3d_multi_rhs_step: needs a matrix from ec3d_multi_assemble");
+        return 3;
+    }
+    return run_all(m, [&](int r) -> int {
+        Slab &s = *m->slab[(size_t)r];
+        // the U-row right-hand sides read A one plane away: refresh the X halo first
+        int rc2 = halo_start(m, s, CH_X);
+        if (rc2) return rc2;
+        if ((rc2 = halo_wait(s, CH_X))) return rc2;
+        // sources outside the held planes are dropped, the rest renumbered locally (1-based ids)
+        std::vector<int32_t> idx;
+        std::vector<double> val;
+        for (int32_t q = 0; q < nsrc; ++q) {
+            const int64_t g0 = (int64_t)src_index[q] - 1, d = g0 / m->nC_glob, cell = g0 % m->nC_glob;
+            const int64_t plane = cell / m->kdz;
+            if (d > 2 || plane < s.e0 || plane >= s.e1) continue;
+            idx.push_back((int32_t)(d * s.nC_ext + (cell - (int64_t)s.e0 * m->kdz) + 1));
+            val.push_back(src_value[q]);
+        }
+        int32_t dummy_i = 0;
+        double dummy_v = 0.0;
+        if ((rc2 = ec3d_rhs_step(s.c, moving, (int32_t)idx.size(), idx.empty() ? &dummy_i : idx.data(),
+                                 val.empty() ? &dummy_v : val.data())))
+            return rc2;
+        return drain(s);
+    });
+}
+
+extern "C" int ec3d_multi_post_update(ec3d_multi_handle m)
+{
+    int rc = need(m, "ec3d_multi_post_update");
+    if (rc) return rc;
+    return run_all(m, [&](int r) -> int {
+        Slab &s = *m->slab[(size_t)r];
+        int rc2 = ec3d_post_update(s.c);
+        return rc2 ? rc2 : drain(s);
+    });
+}
+
+extern "C" int ec3d_multi_vtk_fields(ec3d_multi_handle m, const double *delta, float *field_A, float *field_eddy,
+                                     float *field_source, float *field_B)
+{
+    int rc = need(m, "ec3d_multi_vtk_fields");
+    if (rc) return rc;
+    if (m->kind != 2) {
+        ec3d_set_error("ec3d_multi_vtk_fields: needs a matrix from ec3d_multi_assemble");
+        return 3;
+    }
+    if (field_eddy) memset(field_eddy, 0, (size_t)3 * m->nC_glob * sizeof(float)); // slabs without conductor skip it
+    return run_all(m, [&](int r) -> int {
+        Slab &s = *m->slab[(size_t)r];
+        int rc2 = halo_start(m, s, CH_X); // the curl reads the neighbours' planes
+        if (rc2) return rc2;
+        if ((rc2 = halo_wait(s, CH_X))) return rc2;
+        const size_t off = (size_t)3 * s.k0 * m->kdz;
+        if ((rc2 = ec3d_vtk_fields(s.c, delta, field_A + off, field_eddy ? field_eddy + off : nullptr, field_source + off,
+                                   field_B + off)))
+            return rc2;
+        return drain(s);
+    });
+}
+
+// ---- bench "steps": exits disabled, launches only ---------------------------------------------------------
+extern "C" int ec3d_multi_iterate_begin(ec3d_multi_handle m)
+{
+    int rc = need(m, "ec3d_multi_iterate_begin");
+    if (rc) return rc;
+    return run_all(m, [&](int r) -> int {
+        Slab &s = *m->slab[(size_t)r];
+        int rc2 = run_plan(m, s, begin_plan(s), 0, -1.0, nullptr);
+        return rc2 ? rc2 : drain(s);
+    });
+}
+
+extern "C" int ec3d_multi_iterate(ec3d_multi_handle m, int32_t first_iter, int32_t count, double *kernel_ms)
+{
+    int rc = need(m, "ec3d_multi_iterate");
+    if (rc) return rc;
+    return run_all(m, [&](int r) -> int {
+        Slab &s = *m->slab[(size_t)r];
+        StageTimer tm;
+        StageTimer *tp = (kernel_ms && r == 0) ? &tm : nullptr;
+        int rc2 = 0;
+        for (int it = first_iter; it < first_iter + count; ++it)
+            if ((rc2 = run_plan(m, s, iter_plan(s), it, 0.0, tp))) return rc2;
+        if (!kernel_ms) return 0; // asynchronous: ec3d_multi_synchronize() joins
+        if ((rc2 = drain(s))) return rc2;
+        if (tp) {
+            for (int k = 0; k < 5; ++k) kernel_ms[k] = 0.0;
+            for (size_t i = 0; i < tm.kern.size(); ++i) {
+                float ms = 0.f;
+                MHIP(hipEventElapsedTime(&ms, tm.ev[2 * i], tm.ev[2 * i + 1]));
+                kernel_ms[tm.kern[i]] += (double)ms / std::max(1, count);
+            }
+            for (hipEvent_t e : tm.ev) (void)hipEventDestroy(e);
+        }
+        return 0;
+    });
+}
+
+extern "C" int ec3d_multi_synchronize(ec3d_multi_handle m)
+{
+    if (!m) return 2;
+    return run_all(m, [&](int r) -> int {
+        Slab &s = *m->slab[(size_t)r];
+        if (!s.c) return 0;
+        MHIP(hipSetDevice(s.device));
+        return drain(s);
+    });
+}

@@ -198,3 +198,49 @@ int ec3d_csr_to_sav_host(int64_t n, const double *valA, const int32_t *irow, con
     S.n_dev = n_dev;
     return 0;
 }
+
+// One z-slab of a recognised system: the held planes [e0, e1) of each of the four blocks, same pitch, same
+// class table.  Rows of the halo planes (outside [k0, k1)) get the all-zero class: they only carry the
+// neighbours' values, exactly like the halo rows ec3d_assemble_slab produces natively.
+void ec3d_sav_slice(const SavHost &G, int64_t e0, int64_t e1, int64_t k0, int64_t k1, SavHost &L)
+{
+    L = SavHost();
+    const int64_t np = e1 - e0, pitch = G.pitch, nCd = np * pitch;
+    L.sdx = G.sdx;
+    L.plane = G.plane;
+    L.pitch = pitch;
+    L.nCd = nCd;
+    L.n_dev = 4 * nCd;
+    L.n_pad = round_up(L.n_dev, EC3D_TILE);
+    L.a0 = G.a0; L.u0 = G.u0; L.zero = G.zero; L.ncls = G.ncls;
+    L.table = G.table;
+    L.cls.assign((size_t)L.n_pad, (uint8_t)G.zero);
+    for (int d = 0; d < 4; ++d)
+        for (int64_t p = k0; p < k1; ++p)
+            memcpy(&L.cls[(size_t)(d * nCd + (p - e0) * pitch)], &G.cls[(size_t)(d * G.nCd + p * pitch)], (size_t)pitch);
+    L.tile_flag.assign((size_t)(L.n_pad / EC3D_TILE), 0);
+    for (int64_t r = 0; r < L.n_dev; ++r) {
+        const int c = L.cls[(size_t)r];
+        if (c >= L.a0 && c < L.zero) L.tile_flag[(size_t)(r / EC3D_TILE)] = 1;
+    }
+    L.ntiles_front = (3 * nCd + EC3D_TILE - 1) / EC3D_TILE;
+    for (int64_t tl = L.ntiles_front; tl < L.n_pad / EC3D_TILE; ++tl)
+        if (L.tile_flag[(size_t)tl]) L.ulist.push_back((int32_t)tl);
+    // held conducting cells: scan order is plane-major, so they are one contiguous run of the global list
+    const int64_t lo = e0 * pitch, hi = e1 * pitch;
+    bool first = true;
+    for (size_t m = 0; m < G.cond_cell.size(); ++m) {
+        const int64_t cell = G.cond_cell[m];
+        if (cell < lo || cell >= hi) continue;
+        if (first) { L.u_first = (int64_t)m; first = false; }
+        L.cond_cell.push_back((int32_t)(cell - lo));
+    }
+    L.n_ref = 3 * np * G.plane + (int64_t)L.cond_cell.size();
+    L.nnz = 0;
+    L.nown = 4;
+    for (int d = 0; d < 4; ++d) {
+        L.own_lo[d] = d * nCd + (k0 - e0) * pitch;
+        L.own_hi[d] = d * nCd + (k1 - e0) * pitch;
+    }
+    L.halo = pitch;
+}

@@ -21,15 +21,16 @@
 // vector kernels (sweep) -- every consumer reads slots of one producer class only.
 RedSrc ec3d_src_of(const ec3d_ctx *c, bool produced_by_spmv)
 {
-    if (c->dist) return RedSrc{c->gsum, c->nranks, P_NSLOT, 1};
-    return RedSrc{c->partials, produced_by_spmv ? c->sweep_s.nblk : c->sweep.nblk, 1, c->sweep.pstride};
+    if (c->dist && c->lsum_ptrs) return RedSrc{nullptr, c->nranks, 0, 0, c->lsum_ptrs};
+    if (c->dist) return RedSrc{c->gsum, c->nranks, P_NSLOT, 1, nullptr};
+    return RedSrc{c->partials, produced_by_spmv ? c->sweep_s.nblk : c->sweep.nblk, 1, c->sweep.pstride, nullptr};
 }
 RedSrc ec3d_part_of(const ec3d_ctx *c, bool produced_by_spmv, bool split)
 {
     const int cnt = !produced_by_spmv ? c->sweep.nblk
                     : split           ? c->sweep_int.nblk + c->sweep_bnd.nblk
                                       : c->sweep_s.nblk;
-    return RedSrc{c->partials, cnt, 1, c->sweep.pstride};
+    return RedSrc{c->partials, cnt, 1, c->sweep.pstride, nullptr};
 }
 
 // the five launches of one iteration; `k` selects one of them (1..5) or all (0)
@@ -67,7 +68,9 @@ int ec3d_launch_begin(ec3d_ctx *c, const MatView &A, double tol)
 
 int ec3d_single_rank_only(ec3d_ctx *c, const char *who)
 {
-    if (c->halo > 0 || c->nranks > 1) {
+    // c->dist alone (a full-grid handle configured with nranks = 1, the 1-rank rehearsal layout) must be
+    // refused as well: its kernels take their sums from gsum, which only the staged driver fills
+    if (c->halo > 0 || c->nranks > 1 || c->dist) {
         ec3d_set_error(std::string(who) + ": this handle holds one z-slab of a multi-rank problem; drive it "
                                           "with ec3d_dist_step (eddy_currents_3d_amd/dist.py)");
         return 4;

@@ -59,7 +59,12 @@ EXPORTS = ["sprsbcgstabwr_", "ec3d_invalidate", "ec3d_create", "ec3d_destroy", "
            "ec3d_dist_configure", "ec3d_dist_step", "ec3d_dist_set_boundary_rows", "ec3d_read_state_async", "ec3d_read_state", "ec3d_set_zmarch", "ec3d_can_overlap",
            "ec3d_rhs_step", "ec3d_post_update", "ec3d_assemble_slab", "ec3d_vtk_fields",
            "ec3d_set_structured", "ec3d_get_row_map", "ec3d_get_ulist", "ec3d_probe_csr",
-           "ec3d_device_synchronize"]
+           "ec3d_device_synchronize",
+           "ec3d_multi_create", "ec3d_multi_destroy", "ec3d_multi_ranks", "ec3d_multi_slab", "ec3d_multi_set_format",
+           "ec3d_multi_assemble_poisson", "ec3d_multi_assemble", "ec3d_multi_set_matrix_csr", "ec3d_multi_size",
+           "ec3d_multi_upload", "ec3d_multi_download", "ec3d_multi_solve", "ec3d_multi_solve_resident",
+           "ec3d_multi_rhs_step", "ec3d_multi_post_update", "ec3d_multi_vtk_fields", "ec3d_multi_iterate_begin",
+           "ec3d_multi_iterate", "ec3d_multi_synchronize"]
 
 _f64 = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
 _i32 = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
@@ -148,6 +153,26 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.ec3d_dist_step.argtypes = [hp, C.c_int32, C.c_int32, C.c_double]
     L.ec3d_read_state_async.argtypes = [hp, C.c_void_p]
     L.ec3d_read_state.argtypes = [hp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+    L.ec3d_multi_create.argtypes = [C.POINTER(hp), C.c_int32, hp]
+    L.ec3d_multi_destroy.argtypes = [hp]
+    L.ec3d_multi_ranks.argtypes = [hp]
+    L.ec3d_multi_slab.argtypes = [hp, C.c_int32, C.POINTER(hp), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.ec3d_multi_set_format.argtypes = [hp, C.c_int, C.c_int]
+    L.ec3d_multi_assemble_poisson.argtypes = [hp, C.c_int32, C.c_int32, C.c_int32, _f64, _f64]
+    L.ec3d_multi_assemble.argtypes = [hp, C.c_int32, C.c_int32, C.c_int32, _i8, _i32, _f64, C.c_int32, _f64,
+                                      _f64, C.c_double]
+    L.ec3d_multi_set_matrix_csr.argtypes = [hp, C.c_int32, _f64, _i32, _i32]
+    L.ec3d_multi_size.argtypes = [hp, C.POINTER(C.c_int64)]
+    L.ec3d_multi_upload.argtypes = [hp, C.c_int, _f64]
+    L.ec3d_multi_download.argtypes = [hp, C.c_int, _f64]
+    L.ec3d_multi_solve.argtypes = [hp, _f64, _f64, C.c_double, C.c_int32, C.POINTER(C.c_int32)]
+    L.ec3d_multi_solve_resident.argtypes = [hp, C.c_double, C.c_int32, C.POINTER(C.c_int32)]
+    L.ec3d_multi_rhs_step.argtypes = [hp, C.c_int32, C.c_int32, _i32, _f64]
+    L.ec3d_multi_post_update.argtypes = [hp]
+    L.ec3d_multi_vtk_fields.argtypes = [hp, _f64, hp, hp, hp, hp]
+    L.ec3d_multi_iterate_begin.argtypes = [hp]
+    L.ec3d_multi_iterate.argtypes = [hp, C.c_int32, C.c_int32, hp]
+    L.ec3d_multi_synchronize.argtypes = [hp]
     L.sprsbcgstabwr_.argtypes = [_f64, _i32, _i32, C.POINTER(C.c_int32), _f64, _f64,
                                  C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.sprsbcgstabwr_.restype = None
@@ -452,3 +477,144 @@ class EC3DSolver:
 
     def synchronize(self):
         _chk(self.L, self.L.ec3d_device_synchronize(self.h), "ec3d_device_synchronize")
+
+
+class _SlabView(EC3DSolver):
+    """A slab of an EC3DMulti as an EC3DSolver for introspection (geometry, info, read_state); the multi
+    handle owns it."""
+
+    def __init__(self, L, h):
+        self.L, self.h = L, h
+
+    def close(self):
+        self.h = C.c_void_p()
+
+    __del__ = close
+
+
+class EC3DMulti:
+    """N GPUs behind one handle (include/ec3d_hip.h section 2c): the library cuts the grid into z-slabs, keeps
+    one host thread per slab and moves halo planes and partial sums between the devices itself.  Host vectors
+    are in the reference's global numbering.  devices=None: GPUs 0 .. nranks-1 (raises "needs N devices" when
+    the machine has fewer); a list may name one GPU several times (several slabs on one card)."""
+
+    def __init__(self, nranks: int, devices=None, dictionary: bool | None = None, structured: bool | None = None):
+        self.L = load_library()
+        self.h = C.c_void_p()
+        dev = None if devices is None else np.ascontiguousarray(devices, np.int32)
+        if dev is not None and len(dev) != nranks:
+            raise ValueError("devices must name one device per rank")
+        _chk(self.L, self.L.ec3d_multi_create(C.byref(self.h), int(nranks), None if dev is None else dev.ctypes.data),
+             "ec3d_multi_create")
+        self.nranks = int(nranks)
+        if dictionary is not None or structured is not None:
+            _chk(self.L, self.L.ec3d_multi_set_format(self.h, -1 if dictionary is None else int(bool(dictionary)),
+                                                      -1 if structured is None else int(bool(structured))),
+                 "ec3d_multi_set_format")
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.L.ec3d_multi_destroy(self.h)
+            self.h = C.c_void_p()
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def assemble_poisson(self, sdx, sdy, sdz, delta=(0.00333, 0.00333, 0.00333), bnd=-0.95):
+        BND = np.full(6, float(bnd)) if np.isscalar(bnd) else np.ascontiguousarray(
+            np.asarray(bnd, np.float64).T).reshape(-1)
+        _chk(self.L, self.L.ec3d_multi_assemble_poisson(self.h, sdx, sdy, sdz, BND,
+                                                        np.ascontiguousarray(delta, np.float64)),
+             "ec3d_multi_assemble_poisson")
+
+    def assemble(self, geoPHYS, geoPHYS_C, valPHYS, BND, delta, dt):
+        """Same arguments as EC3DSolver.assemble (the GLOBAL tables)."""
+        sdz, sdy, sdx = geoPHYS.shape
+        vp = np.asarray(valPHYS, np.float64)
+        _chk(self.L, self.L.ec3d_multi_assemble(
+            self.h, sdx, sdy, sdz, np.ascontiguousarray(geoPHYS, np.int8).reshape(-1),
+            np.ascontiguousarray(geoPHYS_C, np.int32).reshape(-1),
+            np.ascontiguousarray(vp.T).reshape(-1), vp.shape[0],
+            np.ascontiguousarray(np.asarray(BND, np.float64).T).reshape(-1),
+            np.ascontiguousarray(delta, np.float64), float(dt)), "ec3d_multi_assemble")
+
+    def set_matrix_csr(self, valA, irow, jcol):
+        irow = np.ascontiguousarray(irow, np.int32)
+        _chk(self.L, self.L.ec3d_multi_set_matrix_csr(self.h, len(irow) - 1, np.ascontiguousarray(valA, np.float64),
+                                                      irow, np.ascontiguousarray(jcol, np.int32)),
+             "ec3d_multi_set_matrix_csr")
+
+    @property
+    def n(self) -> int:
+        n = C.c_int64(0)
+        _chk(self.L, self.L.ec3d_multi_size(self.h, C.byref(n)), "ec3d_multi_size")
+        return n.value
+
+    def slab(self, rank: int):
+        """(EC3DSolver view of rank's slab, k0, k1)."""
+        h, k0, k1 = C.c_void_p(), C.c_int32(0), C.c_int32(0)
+        _chk(self.L, self.L.ec3d_multi_slab(self.h, rank, C.byref(h), C.byref(k0), C.byref(k1)), "ec3d_multi_slab")
+        return _SlabView(self.L, h), k0.value, k1.value
+
+    def upload(self, which: str, a):
+        a = np.ascontiguousarray(a, np.float64)
+        if a.size != self.n:
+            raise ValueError(f"expected {self.n} entries (global numbering)")
+        _chk(self.L, self.L.ec3d_multi_upload(self.h, VEC[which], a), "ec3d_multi_upload")
+
+    def download(self, which: str):
+        a = np.zeros(self.n)
+        _chk(self.L, self.L.ec3d_multi_download(self.h, VEC[which], a), "ec3d_multi_download")
+        return a
+
+    def solve(self, b, x0, tolerance, itmax):
+        """One reference solve (src/solvers.f90:3-50) on all slabs.  Returns (x, iter)."""
+        x = np.array(x0, dtype=np.float64, copy=True)
+        it = C.c_int32(0)
+        _chk(self.L, self.L.ec3d_multi_solve(self.h, np.ascontiguousarray(b, np.float64), x, float(tolerance),
+                                             int(itmax), C.byref(it)), "ec3d_multi_solve")
+        return x, it.value
+
+    def solve_resident(self, tolerance, itmax):
+        it = C.c_int32(0)
+        _chk(self.L, self.L.ec3d_multi_solve_resident(self.h, float(tolerance), int(itmax), C.byref(it)),
+             "ec3d_multi_solve_resident")
+        return it.value
+
+    def rhs_step(self, src_index, src_value, moving: bool = False):
+        idx = np.ascontiguousarray(src_index, np.int32)
+        val = np.ascontiguousarray(src_value, np.float64)
+        _chk(self.L, self.L.ec3d_multi_rhs_step(self.h, int(bool(moving)), len(idx),
+                                                idx if len(idx) else np.zeros(1, np.int32),
+                                                val if len(val) else np.zeros(1)), "ec3d_multi_rhs_step")
+
+    def post_update(self):
+        _chk(self.L, self.L.ec3d_multi_post_update(self.h), "ec3d_multi_post_update")
+
+    def vtk_fields(self, delta, ncells: int, conducting: bool):
+        mk = lambda: np.empty((ncells, 3), np.float32)
+        fa, fs, fb = mk(), mk(), mk()
+        fe = mk() if conducting else None
+        _chk(self.L, self.L.ec3d_multi_vtk_fields(self.h, np.ascontiguousarray(delta, np.float64), fa.ctypes.data,
+                                                  fe.ctypes.data if conducting else None, fs.ctypes.data,
+                                                  fb.ctypes.data), "ec3d_multi_vtk_fields")
+        return dict(A=fa, eddy=fe, source=fs, B=fb)
+
+    def iterate_begin(self):
+        _chk(self.L, self.L.ec3d_multi_iterate_begin(self.h), "ec3d_multi_iterate_begin")
+
+    def iterate(self, first_iter: int, count: int, per_kernel: bool = False):
+        if not per_kernel:
+            _chk(self.L, self.L.ec3d_multi_iterate(self.h, first_iter, count, None), "ec3d_multi_iterate")
+            return None
+        ms = np.zeros(5)
+        _chk(self.L, self.L.ec3d_multi_iterate(self.h, first_iter, count, ms.ctypes.data), "ec3d_multi_iterate")
+        return dict(zip(("k1", "k2", "k3", "k4", "k5"), ms.tolist()))
+
+    def synchronize(self):
+        _chk(self.L, self.L.ec3d_multi_synchronize(self.h), "ec3d_multi_synchronize")

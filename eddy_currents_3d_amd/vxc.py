@@ -112,6 +112,26 @@ def refine(model: VxcModel, fx: int, fy: int, fz: int) -> VxcModel:
                     (model.adj[0] / fx, model.adj[1] / fy, model.adj[2] / fz), model.compression)
 
 
+def resample(model: VxcModel, sdx: int, sdy: int, sdz: int) -> VxcModel:
+    """The same geometry on an sdx x sdy x sdz grid (any size, not only integer multiples): new voxel i takes
+    the material of the old voxel that contains its centre, floor((i + 1/2) * old / new) per axis; the
+    physical size is kept (cell size * old / new).  This is how the inputs of BASELINE configs 3 and 5
+    (256x256x60 from the shipped 102x102x24, 384x192x128 from 176x32x22) are made.  For integer factors
+    it is refine()."""
+    oz, oy, ox = model.vox.shape
+    if min(sdx, sdy, sdz) < 1:
+        raise ValueError("resample: grid sizes must be positive")
+    # integer arithmetic: floor((2 i + 1) * old / (2 new)), exact for every size
+    ix = ((2 * np.arange(sdx, dtype=np.int64) + 1) * ox) // (2 * sdx)
+    iy = ((2 * np.arange(sdy, dtype=np.int64) + 1) * oy) // (2 * sdy)
+    iz = ((2 * np.arange(sdz, dtype=np.int64) + 1) * oz) // (2 * sdz)
+    vox = np.ascontiguousarray(model.vox[np.ix_(iz, iy, ix)])
+    # 12 significant digits: the reference reads these numbers through a 20-character field
+    # (src/utilites.f90:470-472), so the text written by write_vxc must round-trip within that
+    adj = tuple(float(f"{a * o / s:.12g}") for a, o, s in zip(model.adj, (ox, oy, oz), (sdx, sdy, sdz)))
+    return VxcModel(vox, list(model.names), model.lattice_dim, adj, model.compression)
+
+
 # -------------------------------------------------------------------------- palette mini-language
 _PREFIX = [("MEG", 1e6), ("PET", 1e15), ("M", 1e-3), ("K", 1e3), ("U", 1e-6), ("N", 1e-9), ("P", 1e-12),
            ("G", 1e9), ("T", 1e12), ("F", 1e-15), ("C", 1e-2), ("H", 1e2)]

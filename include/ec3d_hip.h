@@ -163,7 +163,9 @@ int ec3d_assemble_slab(ec3d_handle h, int32_t sdx, int32_t sdy, int32_t sdz, int
 int ec3d_vector_layout(ec3d_handle h, int64_t *ghost, int64_t *n, int64_t *n_pad, int64_t *halo);
 /* use caller-owned, zero-filled device memory (EC3D_NVEC * (2*ghost + n_pad) doubles) for the vectors */
 int ec3d_adopt_vectors(ec3d_handle h, double *device_base);
-/* reductions then come from gsum_device[nranks][8] (the all-gather of every rank's lsum_device[8]) */
+/* reductions then come from gsum_device[nranks][8] (the all-gather of every rank's lsum_device[8]); from then
+ * on the handle is driven stage by stage (ec3d_dist_step) and ec3d_solve / ec3d_iterate / ec3d_time_* refuse
+ * it.  ec3d_dist_configure(h, 1, NULL, NULL) leaves that mode again; so does a new matrix. */
 int ec3d_dist_configure(ec3d_handle h, int32_t nranks, double *lsum_device, double *gsum_device);
 enum { EC3D_STAGE_RESID = 0, /* R = B - A X, R0 = P = R; lsum <- B.B, R.R      src/solvers.f90:14-21 */
        EC3D_STAGE_SETUP = 1, /* Bnorm, rr0 from gsum                                            :21-23 */
@@ -200,6 +202,56 @@ int ec3d_can_overlap(ec3d_handle h);
 int ec3d_read_state_async(ec3d_handle h, int32_t *stop_iter_pinned);
 /* drain the stream and read the device-resident state; stop_iter = -1 while still running */
 int ec3d_read_state(ec3d_handle h, int32_t *stop_iter, int32_t *stop_kind, double *bnorm);
+
+/* ------------------------------------------------------------------------------------------
+ * 2c. Multi-GPU behind one handle: one process, N devices, invisible to the caller (SURVEY §8b
+ *     "Threading": the caller of src/EC3D.f90:408 is single-threaded and must not have to know).
+ *     The library cuts the grid into z-slabs (rank g owns planes [g*sdz/N, (g+1)*sdz/N), lower ranks
+ *     take the remainder), keeps one host thread per slab, pulls the halo planes of P and S from the
+ *     z-neighbours' memory over xGMI (peer access) while the interior planes compute, and lets every
+ *     kernel read the N ranks' partial sums in place, added in rank order -- the schedule of §2b and of
+ *     eddy_currents_3d_amd/dist.py, results bit-identical to it.  sprsbcgstabwr_ uses this path when the
+ *     environment says EC3D_NGPU=N (N > 1) and the matrix is recognised as the reference's A-V system.
+ *     devices == NULL: devices 0 .. nranks-1 (status 103 "needs N devices" when the machine has fewer);
+ *     an explicit list may name a device several times (several slabs on one GPU: tests, rehearsals).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct ec3d_multi *ec3d_multi_handle;
+int ec3d_multi_create(ec3d_multi_handle *mh, int32_t nranks, const int32_t *devices);
+int ec3d_multi_destroy(ec3d_multi_handle mh);
+int ec3d_multi_ranks(ec3d_multi_handle mh);
+/* the slab of one rank (an ordinary handle in multi-rank mode: introspection only) and its planes */
+int ec3d_multi_slab(ec3d_multi_handle mh, int32_t rank, ec3d_handle *h, int32_t *k0, int32_t *k1);
+/* as ec3d_set_format / ec3d_set_structured for every slab; -1 leaves a setting as it is */
+int ec3d_multi_set_format(ec3d_multi_handle mh, int dictionary, int structured);
+/* same arguments as ec3d_assemble_poisson / ec3d_assemble / ec3d_set_matrix_csr: GLOBAL tables in */
+int ec3d_multi_assemble_poisson(ec3d_multi_handle mh, int32_t sdx, int32_t sdy, int32_t sdz, const double *BND,
+                                const double *delta);
+int ec3d_multi_assemble(ec3d_multi_handle mh, int32_t sdx, int32_t sdy, int32_t sdz, const int8_t *geoPHYS,
+                        const int32_t *geoPHYS_C, const double *valPHYS, int32_t nsub_glob, const double *BND,
+                        const double *delta, double dt);
+/* CSR triple of the whole system (src/EC3D.f90:36-38): must be recognisable as the reference's A-V system
+ * on a grid (ec3d_probe_csr), which is then cut into slabs; status 7 otherwise (use one GPU) */
+int ec3d_multi_set_matrix_csr(ec3d_multi_handle mh, int32_t n, const double *valA, const int32_t *irow,
+                              const int32_t *jcol);
+/* host vectors in the reference's global numbering [Ax | Ay | Az | U], n unknowns (ec3d_multi_size) */
+int ec3d_multi_size(ec3d_multi_handle mh, int64_t *n);
+int ec3d_multi_upload(ec3d_multi_handle mh, int which, const double *host);
+int ec3d_multi_download(ec3d_multi_handle mh, int which, double *host);
+int ec3d_multi_solve(ec3d_multi_handle mh, const double *b, double *x, double tolerance, int32_t itmax,
+                     int32_t *iter);
+int ec3d_multi_solve_resident(ec3d_multi_handle mh, double tolerance, int32_t itmax, int32_t *iter);
+/* the time loop around the solve, as ec3d_rhs_step / ec3d_post_update / ec3d_vtk_fields (global ids,
+ * global output arrays); the X halo planes are refreshed inside */
+int ec3d_multi_rhs_step(ec3d_multi_handle mh, int32_t moving, int32_t nsrc, const int32_t *src_index,
+                        const double *src_value);
+int ec3d_multi_post_update(ec3d_multi_handle mh);
+int ec3d_multi_vtk_fields(ec3d_multi_handle mh, const double *delta, float *field_A, float *field_eddy,
+                          float *field_source, float *field_B);
+/* bench "steps" as ec3d_iterate_begin / ec3d_iterate: every rank's thread enqueues the iterations and
+ * returns; ec3d_multi_synchronize drains all devices.  kernel_ms (5 doubles): rank 0's stage averages. */
+int ec3d_multi_iterate_begin(ec3d_multi_handle mh);
+int ec3d_multi_iterate(ec3d_multi_handle mh, int32_t first_iter, int32_t count, double *kernel_ms);
+int ec3d_multi_synchronize(ec3d_multi_handle mh);
 
 /* ------------------------------------------------------------------------------------------
  * 3. Introspection / measurement

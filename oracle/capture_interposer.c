@@ -10,7 +10,9 @@
  * One file per call: $EC3D_CAPTURE_DIR/call_%04d.bin
  *   int64 n, nnz, itmax, iter_out; double tol, seconds;
  *   int32 irow[n+1]; int32 jcol[nnz]; double valA[nnz]; double b[n]; double x_in[n]; double x_out[n]
- * The matrix is written for call 0 only unless EC3D_CAPTURE_ALL_MATRICES is set (nnz = 0 otherwise).
+ * The matrix is written for call 0 only unless EC3D_CAPTURE_ALL_MATRICES is set (nnz = 0 otherwise);
+ * EC3D_CAPTURE_NO_MATRIX leaves it out of call 0 as well (full-size cases: irow alone gives nnz and the
+ * row-length histogram).
  */
 #define _POSIX_C_SOURCE 199309L
 #include <stdint.h>
@@ -45,7 +47,7 @@ void sprsbcgstabwr_(double *valA, int32_t *irow, int32_t *jcol, int32_t *n, doub
         snprintf(path, sizeof path, "%s/call_%04d.bin", dir, ncall);
         FILE *f = fopen(path, "wb");
         if (!f) { perror(path); exit(3); }
-        int with_matrix = (ncall == 0) || getenv("EC3D_CAPTURE_ALL_MATRICES");
+        int with_matrix = ((ncall == 0) || getenv("EC3D_CAPTURE_ALL_MATRICES")) && !getenv("EC3D_CAPTURE_NO_MATRIX");
         int64_t h[4] = {nn, with_matrix ? nnz : 0, *itmax, *iter};
         double d[2] = {*tol, sec};
         fwrite(h, 8, 4, f); fwrite(d, 8, 2, f);

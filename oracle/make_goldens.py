@@ -348,6 +348,68 @@ def case_g5():
              x=x if N <= 32 else x[::max(1, N ** 3 // 4096)], seconds=np.float64(sec))
 
 
+def vtk_vectors(blob):
+    """{name: float32 [npoints, 3]} of a field_N.vtk the reference wrote (src/utilites.f90:222-289)."""
+    out = {}
+    pos = 0
+    while True:
+        i = blob.find(b"VECTORS ", pos)
+        if i < 0:
+            return out
+        j = blob.index(b"\n", i)
+        name = blob[i:j].split()[1].decode()
+        npts = int(re.search(rb"POINT_DATA\s+(\d+)", blob).group(1))
+        out[name] = np.frombuffer(blob, ">f4", 3 * npts, j + 1).reshape(npts, 3).astype(np.float32)
+        pos = j + 1 + 12 * npts
+
+
+def case_g6(which=("ec_src_move_hole", "LIM"), max_calls=4):
+    """G6: BASELINE configs 3 and 5 at their full size -- the shipped geometries resampled (vxc.resample,
+    physical size kept) to 256x256x60 and 384x192x128 -- run through the UNMODIFIED reference for the first
+    `max_calls` time steps (hours for the whole runs on one core).  Too large to commit whole (100-240 MB per
+    vector): n, nnz, row-length histogram, per-step iter / ||b|| / ||x||, 200 probes of b and x per step,
+    and 200 probe points of every vector of the field_N.vtk files the reference wrote meanwhile.  The test
+    rebuilds the input from the g4 fixture's voxels with the same resampler."""
+    from eddy_currents_3d_amd import vxc
+    dims = {"ec_src_move_hole": (256, 256, 60), "LIM": (384, 192, 128)}
+    for stem in which:
+        g = np.load(os.path.join(GOLD, f"g4_{stem}.npz"))
+        model = vxc.VxcModel(g["vox"], [str(s) for s in g["names"]], float(str(g["lattice_dim"])),
+                             tuple(float(x) for x in g["adj"]))
+        big = vxc.resample(model, *dims[stem])
+        calls, log = run_reference(big.vox, big.names, repr(big.lattice_dim), tuple(repr(a) for a in big.adj),
+                                   max_calls=max_calls, extra_env={"EC3D_CAPTURE_NO_MATRIX": "1"})
+        echo = parse_log(log)   # empty when the run ends inside the interposer (_Exit drops Fortran's buffer)
+        for ax, key in enumerate(("deltaX", "deltaY", "deltaZ")):   # g10.3 echo: 3 digits is all it shows
+            if key in echo:
+                assert abs(echo[key] - big.delta[ax]) <= 2e-3 * big.delta[ax], (key, echo[key], big.delta[ax])
+        print(stem, "reference log tail:", log[-600:].replace("\n", " | "), flush=True)
+        n = calls[0]["n"]
+        rl = np.diff(calls[0]["irow"])
+        rng = np.random.Generator(np.random.PCG64(2025))
+        probes = np.sort(rng.choice(n, 200, replace=False)).astype(np.int64)
+        ncell = big.vox.size
+        pprobe = np.sort(rng.choice(ncell, 200, replace=False)).astype(np.int64)
+        d = dict(dims=np.array(dims[stem], np.int32), adj=np.array(big.adj), delta=big.delta,
+                 n=np.int64(n), nnz=np.int64(calls[0]["irow"][-1] - 1), rowlen_hist=np.bincount(rl, minlength=14),
+                 iters=np.array([c["iter"] for c in calls], np.int32), tol=np.float64(calls[0]["tol"]),
+                 itmax=np.int32(calls[0]["itmax"]),
+                 bnorm=np.array([np.linalg.norm(c["b"]) for c in calls]),
+                 xnorm=np.array([np.linalg.norm(c["x_out"]) for c in calls]),
+                 probes=probes, xprobe=np.stack([c["x_out"][probes] for c in calls]),
+                 bprobe=np.stack([c["b"][probes] for c in calls]),
+                 seconds=np.array([c["seconds"] for c in calls]), point_probes=pprobe)
+        for fn, blob in sorted(calls[0]["vtk"].items()):
+            if not fn.startswith("field_"):
+                continue
+            for name, v in vtk_vectors(blob).items():
+                d[f"vtk_{fn[:-4]}_{name}"] = v[pprobe]
+                d[f"vtk_{fn[:-4]}_{name}_norm"] = np.float64(np.linalg.norm(v.astype(np.float64)))
+        print(stem, dims[stem], "n", n, "iters", d["iters"], "bnorm", d["bnorm"], "xnorm", d["xnorm"],
+              "seconds", d["seconds"], "vtk", [k for k in d if k.startswith("vtk_") and not k.endswith("_norm")])
+        save("g6_" + stem + "_%dx%dx%d" % dims[stem], **d)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g2", "g2v", "g2i", "g3", "g4", "g5"]
     O.build()
@@ -358,3 +420,6 @@ if __name__ == "__main__":
     if "g3" in which: case_g3()
     if "g4" in which: case_g4()
     if "g5" in which: case_g5()
+    if "g6" in which: case_g6()
+    if "g6hole" in which: case_g6(("ec_src_move_hole",))
+    if "g6lim" in which: case_g6(("LIM",))

@@ -1,0 +1,271 @@
+"""Multi-GPU inside the library (include/ec3d_hip.h section 2c, csrc/ec3d_multi.hip): one process, N slabs, one
+host thread per slab, halo planes pulled over peer access, partial sums read in place.  On the one-GPU test
+box every slab sits on device 0 -- the same code path with local copies instead of xGMI ones.
+
+Bar: bit-identical to the staged drivers of eddy_currents_3d_amd/dist.py on the same slabs (same kernels, same
+rank-ordered sums), which in turn are pinned against the reference's captured solutions; plus the reference
+fixtures directly (src/solvers.f90:3-50 results within 10*tol, src/EC3D.f90:370-433 loop state bit for bit,
+field_N.vtk bytes)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REPO, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def E():
+    import eddy_currents_3d_amd as E
+    return E
+
+
+def _inprocess_poisson(sdx, sdy, sdz, world, b, tol, itmax):
+    from eddy_currents_3d_amd.dist import HipSlabOps, InProcessSlabs, slab_bounds
+    ops = []
+    for r in range(world):
+        k0, k1 = slab_bounds(sdz, r, world)
+        o = HipSlabOps(sdx, sdy, sdz, k0, k1, world)
+        o.set_vector("B", b.reshape(sdz, sdx * sdy)[k0:k1].reshape(-1))
+        ops.append(o)
+    drv = InProcessSlabs(ops)
+    it = drv.solve(tol, itmax)
+    x = drv.x()
+    for o in ops:
+        o.close()
+    return x, it
+
+
+@pytest.mark.parametrize("grid,world", [((64, 64, 40), 2), ((64, 64, 48), 3), ((64, 64, 40), 4),   # z-marching, overlap plan
+                                        ((24, 24, 24), 2), ((20, 20, 20), 3)])                      # plain plan
+def test_multi_poisson_bitwise_equals_staged_slabs(E, oracle, grid, world):
+    sdx, sdy, sdz = grid
+    tol = 1e-8
+    b = np.random.Generator(np.random.PCG64(5)).standard_normal(sdx * sdy * sdz)
+    x_ref, it_ref = _inprocess_poisson(sdx, sdy, sdz, world, b, tol, 5000)
+    with E.EC3DMulti(world, devices=[0] * world) as m:
+        m.assemble_poisson(sdx, sdy, sdz)
+        assert m.n == sdx * sdy * sdz
+        if sdx * sdy % 512 == 0:
+            assert all(m.slab(r)[0].can_overlap() for r in range(world))
+        x, it = m.solve(b, np.zeros(m.n), tol, 5000)
+        # a second solve on the same handle (warm start from the solution: converges at once or nearly)
+        x2, it2 = m.solve(b, x, tol, 5000)
+    valA, irow, jcol = oracle.poisson_csr(sdx, sdy, sdz)
+    res = np.linalg.norm(b - oracle.spmv_csr(valA, irow, jcol, x)) / np.linalg.norm(b)
+    print(f"{world} slabs of {sdx}x{sdy}x{sdz} in the library: iter {it} (staged driver {it_ref}), true residual {res:.2e}")
+    assert it == it_ref and np.array_equal(x, x_ref)
+    assert res < 5 * tol
+    assert it2 <= 2
+
+
+def test_multi_with_one_rank_equals_plain_handle(E, oracle):
+    N, tol = 24, 1e-8
+    b = oracle.bar_rhs(N)
+    with E.EC3DSolver() as s:
+        s.assemble_poisson(N, N, N)
+        x_ref, it_ref, _ = s.solve(b, np.zeros(N ** 3), tol, 10000)
+    with E.EC3DMulti(1) as m:
+        m.assemble_poisson(N, N, N)
+        x, it = m.solve(b, np.zeros(N ** 3), tol, 10000)
+    assert it == it_ref and np.array_equal(x, x_ref)
+
+
+@pytest.mark.parametrize("name,world", [("g2_conducting_hole_16x15x14", 2), ("g2_conducting_hole_16x15x14", 3),
+                                        ("g3_moving_coil_18x16x12", 2), ("g2v_conducting_moving_16x15x14", 4)])
+@pytest.mark.parametrize("structured", [True, False])
+def test_multi_av_slabs_match_staged_driver_and_reference(E, name, world, structured, plane_pitch):
+    """The full A-V system cut through the conductor; native assembly on slabs inside the library."""
+    from eddy_currents_3d_amd.dist import HipAVSlabOps, InProcessSlabs, slab_bounds
+    g = load_golden(name)
+    sdz = g["geoPHYS"].shape[0]
+    n = len(g["irow"]) - 1
+    tol, itmax = float(g["tol"]), int(g["itmax"])
+    with E.EC3DMulti(world, devices=[0] * world, structured=structured) as m:
+        m.assemble(g["geoPHYS"], g["geoPHYS_C"], g["valPHYS"], g["BND"], g["delta"], float(g["dt"]))
+        assert m.n == n
+        for k in (0, 1):
+            ops = []
+            for r in range(world):
+                k0, k1 = slab_bounds(sdz, r, world)
+                o = HipAVSlabOps(g["geoPHYS"], g["geoPHYS_C"], g["valPHYS"], g["BND"], g["delta"], float(g["dt"]),
+                                 k0, k1, world, structured=structured)
+                o.set_vector_global("B", g[f"b{k}"])
+                o.set_vector_global("X", g[f"xin{k}"])
+                ops.append(o)
+            drv = InProcessSlabs(ops, vsplit=True)
+            it_ref = drv.solve(tol, itmax)
+            x_ref = drv.x(n)
+            for o in ops:
+                o.close()
+            x, it = m.solve(g[f"b{k}"], g[f"xin{k}"], tol, itmax)
+            xr = g[f"xout{k}"]
+            rel = np.linalg.norm(x - xr) / np.linalg.norm(xr)
+            print(f"{name} in {world} slabs (library), step {k}: iter {it} / staged {it_ref} / reference "
+                  f"{int(g['iters'][k])}, rel diff vs reference {rel:.2e}")
+            assert it == it_ref and np.array_equal(x, x_ref)
+            assert rel <= 10 * tol
+            assert abs(it - int(g["iters"][k])) <= max(3, 0.15 * int(g["iters"][k]))
+
+
+@pytest.mark.parametrize("name,world", [("g2_conducting_hole_16x15x14", 2), ("g3_moving_coil_18x16x12", 3)])
+def test_multi_csr_route_equals_native_slabs(E, name, world, plane_pitch):
+    """What the drop-in receives (the reference's CSR triple) cut into slabs == the natively assembled slabs."""
+    g = load_golden(name)
+    tol, itmax = float(g["tol"]), int(g["itmax"])
+    with E.EC3DMulti(world, devices=[0] * world) as a, E.EC3DMulti(world, devices=[0] * world) as c:
+        a.assemble(g["geoPHYS"], g["geoPHYS_C"], g["valPHYS"], g["BND"], g["delta"], float(g["dt"]))
+        c.set_matrix_csr(g["valA"], g["irow"], g["jcol"])
+        assert a.n == c.n
+        for k in (0, 1):
+            xa, ita = a.solve(g[f"b{k}"], g[f"xin{k}"], tol, itmax)
+            xc, itc = c.solve(g[f"b{k}"], g[f"xin{k}"], tol, itmax)
+            assert ita == itc and np.array_equal(xa, xc)
+
+
+def test_multi_csr_route_refuses_a_matrix_without_a_grid(E):
+    n = 64
+    irow = np.arange(1, n + 2, dtype=np.int32)
+    with E.EC3DMulti(2, devices=[0, 0]) as m:
+        with pytest.raises(E.EC3DError, match="not recognised"):
+            m.set_matrix_csr(np.ones(n), irow, np.arange(1, n + 1, dtype=np.int32))
+
+
+@pytest.mark.parametrize("name,moving,world", [("g2_conducting_hole_16x15x14", False, 2),
+                                               ("g3_moving_coil_18x16x12", True, 3)])
+@pytest.mark.parametrize("structured", [True, False])
+def test_multi_time_loop_state_bitwise(E, name, moving, world, structured, plane_pitch):
+    """src/EC3D.f90:370-404 and :412-433 on the slabs of the multi handle: assembled b and post-updated x equal
+    the reference's loop state bit for bit."""
+    from test_gpu_timeloop import coil_sources
+    g = load_golden(name)
+    n = len(g["irow"]) - 1
+    with E.EC3DMulti(world, devices=[0] * world, structured=structured) as m:
+        m.assemble(g["geoPHYS"], g["geoPHYS_C"], g["valPHYS"], g["BND"], g["delta"], float(g["dt"]))
+        m.upload("X", np.zeros(n))
+        m.upload("B", np.zeros(n))
+        for k in range(len(g["iters"])):
+            if k > 0:
+                m.upload("X", g[f"xout{k - 1}"])
+                m.upload("B", g[f"b{k - 1}"])
+                m.post_update()
+                assert np.array_equal(m.download("X"), g[f"xin{k}"])
+            idx, val = coil_sources(g, k, moving)
+            m.rhs_step(idx, val, moving=moving)
+            assert np.array_equal(m.download("B"), g[f"b{k}"]), f"step {k}"
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_multi_fields_reproduce_reference_file(E, world, plane_pitch):
+    from eddy_currents_3d_amd.vtk import field_vtk_bytes
+    g = load_golden("g3_moving_coil_18x16x12")
+    sdz, sdy, sdx = g["geoPHYS"].shape
+    with E.EC3DMulti(world, devices=[0] * world) as m:
+        m.assemble(g["geoPHYS"], g["geoPHYS_C"], g["valPHYS"], g["BND"], g["delta"], float(g["dt"]))
+        for k in (1, 2):
+            m.upload("X", g[f"xout{k}"])
+            m.upload("B", g[f"b{k}"])
+            m.post_update()
+            f = m.vtk_fields(g["delta"], sdx * sdy * sdz, True)
+            assert field_vtk_bytes(sdx, sdy, sdz, g["delta"], f) == g[f"vtk_field_{k}"].tobytes()
+
+
+def test_multi_needs_the_devices_it_is_asked_for(E):
+    import torch
+    have = torch.cuda.device_count()
+    with pytest.raises(E.EC3DError, match=f"needs {have + 1} devices"):
+        E.EC3DMulti(have + 1)
+
+
+def test_multi_bench_steps_run_and_time(E):
+    with E.EC3DMulti(2, devices=[0, 0]) as m:
+        m.assemble_poisson(64, 64, 40)
+        m.upload("B", np.random.Generator(np.random.PCG64(1)).standard_normal(m.n))
+        m.upload("X", np.zeros(m.n))
+        m.iterate_begin()
+        m.iterate(1, 5)
+        m.synchronize()
+        ms = m.iterate(6, 5, per_kernel=True)
+    assert set(ms) == {"k1", "k2", "k3", "k4", "k5"} and all(v > 0 for v in ms.values())
+
+
+def test_dropin_symbol_uses_several_gpus_when_the_environment_says_so():
+    """sprsbcgstabwr_ (src/solvers.f90:3) with EC3D_NGPU=2: same call, same answer as one GPU to the solver
+    tolerance, the reference's iteration count within the slab bound; a child process because the switch is
+    read once."""
+    code = r"""
+import numpy as np, sys
+sys.path.insert(0, %r)
+import eddy_currents_3d_amd as E
+g = np.load(%r)
+tol, itmax = float(g["tol"]), int(g["itmax"])
+out = []
+for k in (0, 1):
+    x = g[f"xin{k}"].copy()
+    it = E.sprsBCGstabWR(g["valA"], g["irow"], g["jcol"], len(g["irow"]) - 1, g[f"b{k}"], x, tol, itmax)
+    xr = g[f"xout{k}"]
+    out.append((it, float(np.linalg.norm(x - xr) / np.linalg.norm(xr))))
+print("RESULT", out)
+""" % (REPO, os.path.join(REPO, "tests", "golden", "g2_conducting_hole_16x15x14.npz"))
+    g = load_golden("g2_conducting_hole_16x15x14")
+    res = {}
+    for ngpu in (1, 2):
+        env = dict(os.environ, EC3D_NGPU=str(ngpu), EC3D_DEVICES="0,0" if ngpu == 2 else "0")
+        if ngpu == 1:
+            env.pop("EC3D_DEVICES")
+        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stdout + p.stderr
+        res[ngpu] = eval([l for l in p.stdout.splitlines() if l.startswith("RESULT")][0][7:])
+    print(res)
+    tol = float(g["tol"])
+    for ngpu in (1, 2):
+        for k, (it, rel) in enumerate(res[ngpu]):
+            assert rel <= 10 * tol
+            assert abs(it - int(g["iters"][k])) <= max(3, 0.15 * int(g["iters"][k]))
+
+
+def test_teardown_with_torch_objects_gone_first():
+    """Pin of the round-1 teardown hang: the library must never touch an adopted torch stream that its owner has
+    already destroyed.  Destroy the torch side first, then the handle; must return (pytest-timeout guards)."""
+    import gc
+    import torch
+    from eddy_currents_3d_amd.dist import HipSlabOps
+    o = HipSlabOps(64, 64, 32, 0, 16, 2)
+    o.set_vector("B", np.ones(o.n))
+    o.step(0, 0, 1e-8)
+    o.synchronize()
+    local = o.local
+    o.local = None                  # keep close() from detaching politely
+    del o.store, o.lsum, o.gsum
+    o.stream = None
+    del o
+    gc.collect()
+    torch.cuda.empty_cache()
+    local.close()                   # ec3d_destroy with the adopted stream and vectors already gone
+
+
+def test_single_rank_entry_points_refuse_a_dist_configured_handle(E):
+    """a full-grid handle configured with nranks = 1 takes its sums from gsum, which only the staged
+    driver fills -- ec3d_solve / ec3d_iterate / ec3d_time_* must refuse it, and leaving dist mode restores them."""
+    import torch
+    N = 16
+    b = np.ones(N ** 3)
+    with E.EC3DSolver() as s:
+        s.assemble_poisson(N, N, N)
+        x_ref, it_ref, _ = s.solve(b, np.zeros(N ** 3), 1e-8, 1000)
+        lsum = torch.zeros(8, dtype=torch.float64, device="cuda")
+        gsum = torch.zeros(8, dtype=torch.float64, device="cuda")
+        s.dist_configure(1, lsum.data_ptr(), gsum.data_ptr())
+        with pytest.raises(E.EC3DError, match="multi-rank"):
+            s.solve(b, np.zeros(N ** 3), 1e-8, 1000)
+        with pytest.raises(E.EC3DError, match="multi-rank"):
+            s.time_iterations(2)
+        with pytest.raises(E.EC3DError, match="multi-rank"):
+            s.iterate(1, 1)
+        s.dist_configure(1, 0, 0)
+        x, it, _ = s.solve(b, np.zeros(N ** 3), 1e-8, 1000)
+        assert it == it_ref and np.array_equal(x, x_ref)
