@@ -25,6 +25,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <climits>
 #include <cmath>
 #include <condition_variable>
@@ -95,6 +96,10 @@ struct Slab {
     int64_t own_lo[4] = {0}, own_hi[4] = {0}; // owned rows, local reference numbering
     std::vector<double> io;             // staging for host <-> device copies of an A-V slab
     std::string err;
+    // where this slab's thread is (watchdog report): operation, stage / channel, iteration, sequence number
+    std::atomic<const char *> at{"idle"};
+    std::atomic<int> at_arg{0}, at_it{0};
+    std::atomic<uint64_t> at_seq{0};
     Slab() { for (auto &p : posted) p.store(0); }
 };
 
@@ -119,9 +124,14 @@ struct ec3d_multi {
     int32_t sdx = 0, sdy = 0, sdz = 0;
     int64_t kdz = 0, nC_glob = 0, nU_glob = 0, n_glob = 0;
     int64_t nnz = 0;
+    int chunk = 1; // iterations between two looks at the stop flag: ONE value for the job (ranks leave together)
 };
 
 namespace {
+// hipStreamWaitEvent on ANOTHER thread's event makes the runtime look into that thread's queue; two threads
+// doing that to each other at the same moment (every gather does) must not be able to wait for each other's
+// queue locks: one cross-queue wait at a time, process wide.  Launches and copies stay concurrent.
+std::mutex g_cross_wait;
 #define MHIP(call)                                                                             \
     do {                                                                                       \
         hipError_t e_ = (call);                                                                \
@@ -169,7 +179,40 @@ int run_all(ec3d_multi *m, const std::function<int(int)> &fn)
         std::fill(p.rc.begin(), p.rc.end(), 0);
         ++p.gen;
         p.cv.notify_all();
-        p.done_cv.wait(lk, [&] { return p.pending == 0; });
+        // watchdog: a job that makes no progress for EC3D_MULTI_WATCHDOG seconds (default 120; 0 = off) is a
+        // deadlock between the slabs' streams or threads.  Say where every rank stands, let the ranks that
+        // still can give up, and end the process if a thread stays stuck inside the runtime: there is no way
+        // to cancel it, and the interfaces this library stands behind have no channel for "hung".
+        static const int limit = getenv("EC3D_MULTI_WATCHDOG") ? atoi(getenv("EC3D_MULTI_WATCHDOG")) : 120;
+        auto report = [&]() {
+            std::string r;
+            for (auto &s : m->slab)
+                r += "  rank " + std::to_string(s->rank) + ": " + s->at.load() + " arg " + std::to_string(s->at_arg.load()) +
+                     " it " + std::to_string(s->at_it.load()) + " seq " + std::to_string(s->at_seq.load()) + " posted [" +
+                     std::to_string(s->posted[0].load()) + " " + std::to_string(s->posted[1].load()) + " " +
+                     std::to_string(s->posted[2].load()) + " " + std::to_string(s->posted[3].load()) + "]\n";
+            return r;
+        };
+        if (limit <= 0) {
+            p.done_cv.wait(lk, [&] { return p.pending == 0; });
+        } else {
+            std::string last;
+            for (;;) {
+                if (p.done_cv.wait_for(lk, std::chrono::seconds(limit), [&] { return p.pending == 0; })) break;
+                const std::string now = report();
+                if (now != last) { // still moving (a long solve): keep waiting
+                    last = now;
+                    continue;
+                }
+                fprintf(stderr, "libec3d_hip: multi-GPU job stalled for %d s:\n%s", limit, now.c_str());
+                fflush(stderr);
+                m->abort.store(true);
+                if (p.done_cv.wait_for(lk, std::chrono::seconds(10), [&] { return p.pending == 0; })) break;
+                fprintf(stderr, "libec3d_hip: a rank is stuck inside the HIP runtime; aborting the process\n");
+                fflush(stderr);
+                abort();
+            }
+        }
     }
     int rc = 0;
     for (int r = 0; r < m->n; ++r)
@@ -194,9 +237,12 @@ int run_all(ec3d_multi *m, const std::function<int(int)> &fn)
     return rc;
 }
 
-int wait_posted(ec3d_multi *m, Slab &peer, int ch, uint64_t q)
+int wait_posted(ec3d_multi *m, Slab &me, Slab &peer, int ch, uint64_t q)
 {
     int spins = 0;
+    me.at.store("wait_posted");
+    me.at_arg.store(ch * 100 + peer.rank);
+    me.at_seq.store(q);
     while (peer.posted[ch].load(std::memory_order_acquire) < q) {
         if (m->abort.load(std::memory_order_relaxed)) {
             ec3d_set_error("gave up: another rank failed");
@@ -207,10 +253,20 @@ int wait_posted(ec3d_multi *m, Slab &peer, int ch, uint64_t q)
     return 0;
 }
 
+int cross_wait(hipStream_t stream, hipEvent_t ev)
+{
+    std::lock_guard<std::mutex> lk(g_cross_wait);
+    MHIP(hipStreamWaitEvent(stream, ev, 0));
+    return 0;
+}
+
 int halo_start(ec3d_multi *m, Slab &s, int v)
 {
     const uint64_t q = ++s.seq[v];
     const int i = (int)(q % RING), vi = kVecOf[v];
+    s.at.store("halo_start:record");
+    s.at_arg.store(v);
+    s.at_seq.store(q);
     MHIP(hipEventRecord(s.ev_ready[v][i], s.c->stream));
     s.posted[v].store(q, std::memory_order_release);
     // my own earlier readers of the ghost rows are behind this point of my compute stream
@@ -220,9 +276,11 @@ int halo_start(ec3d_multi *m, Slab &s, int v)
         const int pr = s.rank + dir;
         if (pr < 0 || pr >= m->n || cp.empty()) continue;
         Slab &peer = *m->slab[(size_t)pr];
-        int rc = wait_posted(m, peer, v, q);
+        int rc = wait_posted(m, s, peer, v, q);
         if (rc) return rc;
-        MHIP(hipStreamWaitEvent(s.side, peer.ev_ready[v][i], 0));
+        s.at.store("halo_start:cross_wait");
+        if ((rc = cross_wait(s.side, peer.ev_ready[v][i]))) return rc;
+        s.at.store("halo_start:copy");
         double *mine = s.c->vec[vi];
         const double *theirs = peer.c->vec[vi];
         for (const Copy &c : cp) {
@@ -248,14 +306,17 @@ int gather(ec3d_multi *m, Slab &s)
 {
     const uint64_t q = ++s.seq[CH_SUM];
     const int i = (int)(q % RING);
+    s.at.store("gather:record");
+    s.at_seq.store(q);
     MHIP(hipEventRecord(s.ev_sum[i], s.c->stream));
     s.posted[CH_SUM].store(q, std::memory_order_release);
     for (int h = 0; h < m->n; ++h) {
         if (h == s.rank) continue;
         Slab &peer = *m->slab[(size_t)h];
-        int rc = wait_posted(m, peer, CH_SUM, q);
+        int rc = wait_posted(m, s, peer, CH_SUM, q);
         if (rc) return rc;
-        MHIP(hipStreamWaitEvent(s.c->stream, peer.ev_sum[i], 0));
+        s.at.store("gather:cross_wait");
+        if ((rc = cross_wait(s.c->stream, peer.ev_sum[i]))) return rc;
     }
     return 0;
 }
@@ -292,6 +353,7 @@ struct StageTimer {
 int run_plan(ec3d_multi *m, Slab &s, const std::vector<Op> &plan, int it, double tol, StageTimer *tm)
 {
     int rc = 0;
+    s.at_it.store(it);
     for (const Op &op : plan) {
         switch (op.kind) {
         case OP_HALO:
@@ -304,6 +366,8 @@ int run_plan(ec3d_multi *m, Slab &s, const std::vector<Op> &plan, int it, double
         default: {
             const int st = (s.plan == 2 && !s.split_ok) ? unsplit_stage(op.arg) : op.arg;
             if (st < 0) break;
+            s.at.store("stage");
+            s.at_arg.store(st);
             const int k = tm ? kernel_of_stage(st) : -1;
             if (k >= 0) {
                 hipEvent_t a, b;
@@ -330,8 +394,11 @@ const std::vector<Op> &iter_plan(const Slab &s) { return s.plan == 2 ? kIterVspl
 
 int drain(Slab &s)
 {
+    s.at.store("drain:side stream");
     MHIP(hipStreamSynchronize(s.side));
+    s.at.store("drain:compute stream");
     MHIP(hipStreamSynchronize(s.c->stream));
+    s.at.store("idle");
     return 0;
 }
 
@@ -428,6 +495,12 @@ int finish_setup(ec3d_multi *m)
     }
     std::vector<const double *> tab((size_t)m->n);
     for (int g = 0; g < m->n; ++g) tab[(size_t)g] = m->slab[(size_t)g]->lsum;
+    {   // about 0.4 ms of device work between two looks at the stop flag (as ec3d_solve.hip does)
+        int64_t big = 0;
+        for (auto &s : m->slab) big = std::max<int64_t>(big, s->c->A.n_pad);
+        const double est_us = (double)big * 264.0 / 4.0e6 + 12.0 + 20.0 * (m->n > 1);
+        m->chunk = (int)std::min<double>(32.0, std::max<double>(1.0, 400.0 / est_us));
+    }
     return run_all(m, [&](int r) -> int {
         Slab &s = *m->slab[(size_t)r];
         MHIP(hipMemcpy(s.ptr_table, tab.data(), tab.size() * sizeof(double *), hipMemcpyHostToDevice));
@@ -570,8 +643,9 @@ int slab_solve(ec3d_multi *m, Slab &s, double tol, int32_t itmax, int32_t *iter_
     const int64_t total = std::max<int64_t>(0, (int64_t)itmax + 1); // src/solvers.f90:25-29
     int rc = run_plan(m, s, begin_plan(s), 0, tol, nullptr);
     if (rc) return rc;
-    const double est_us = (double)c->A.n_pad * 264.0 / 4.0e6 + 12.0;
-    const int chunk = (int)std::min<double>(32.0, std::max<double>(1.0, 400.0 / est_us));
+    // every rank must look at the flag after the same iterations, so the chunk is a property of the job
+    // (finish_setup: from the largest slab), not of this slab
+    const int chunk = m->chunk;
     int64_t launched = 0;
     int ci = 0;
     bool stopped = false;
@@ -584,6 +658,7 @@ int slab_solve(ec3d_multi *m, Slab &s, double tol, int32_t itmax, int32_t *iter_
         if ((rc = ec3d_read_state_async(c, &s.stop_pinned[ci & 1]))) return rc;
         MHIP(hipEventRecord(s.ev_stop[ci & 1], c->stream));
         if (ci > 0) {
+            s.at.store("solve:wait for the previous chunk's stop flag");
             MHIP(hipEventSynchronize(s.ev_stop[(ci - 1) & 1]));
             if (s.stop_pinned[(ci - 1) & 1] != INT_MAX) stopped = true;
         }
