@@ -129,7 +129,7 @@ extern "C" int ec3d_dist_step(ec3d_handle c, int32_t stage, int32_t it, double t
     switch (stage) {
     case EC3D_STAGE_RESID:
         c->hist_cap = 0;
-        ec3d_launch_residual(A, c->sweep_s, v[EC3D_VEC_X], v[EC3D_VEC_B], v[EC3D_VEC_R], v[EC3D_VEC_R0],
+        ec3d_launch_residual(A, c->sweep_s, ec3d_cond_of(c, c->sweep_s), v[EC3D_VEC_X], v[EC3D_VEC_B], v[EC3D_VEC_R], v[EC3D_VEC_R0],
                              v[EC3D_VEC_P], c->partials, c->stream);
         fin(true, 1u << P_BB | 1u << P_RR_INIT);
         break;
@@ -141,22 +141,22 @@ extern "C" int ec3d_dist_step(ec3d_handle c, int32_t stage, int32_t it, double t
     case EC3D_STAGE_K5: ec3d_launch_stage(c, A, it, 5); break;
     case EC3D_STAGE_K1_INT:
         if (!need_split()) return 3;
-        ec3d_launch_k1(A, c->sweep_int, c->state, it, v[EC3D_VEC_P], v[EC3D_VEC_R0], v[EC3D_VEC_AP], c->partials,
+        ec3d_launch_k1(A, c->sweep_int, nullptr, c->state, it, v[EC3D_VEC_P], v[EC3D_VEC_R0], v[EC3D_VEC_AP], c->partials,
                        c->stream);
         break;
     case EC3D_STAGE_K1_BND:
         if (!need_split()) return 3;
-        ec3d_launch_k1(A, c->sweep_bnd, c->state, it, v[EC3D_VEC_P], v[EC3D_VEC_R0], v[EC3D_VEC_AP], c->partials,
+        ec3d_launch_k1(A, c->sweep_bnd, nullptr, c->state, it, v[EC3D_VEC_P], v[EC3D_VEC_R0], v[EC3D_VEC_AP], c->partials,
                        c->stream);
         fin(true, 1u << P_D1, true);
         break;
     case EC3D_STAGE_K3_INT:
         if (!need_split()) return 3;
-        ec3d_launch_k3(A, c->sweep_int, c->state, it, v[EC3D_VEC_S], v[EC3D_VEC_AS], c->partials, c->stream);
+        ec3d_launch_k3(A, c->sweep_int, nullptr, c->state, it, v[EC3D_VEC_S], v[EC3D_VEC_AS], c->partials, c->stream);
         break;
     case EC3D_STAGE_K3_BND:
         if (!need_split()) return 3;
-        ec3d_launch_k3(A, c->sweep_bnd, c->state, it, v[EC3D_VEC_S], v[EC3D_VEC_AS], c->partials, c->stream);
+        ec3d_launch_k3(A, c->sweep_bnd, nullptr, c->state, it, v[EC3D_VEC_S], v[EC3D_VEC_AS], c->partials, c->stream);
         fin(true, 1u << P_D2 | 1u << P_D3, true);
         break;
     case EC3D_STAGE_K2_BND:

@@ -91,7 +91,7 @@ extern "C" int ec3d_time_kernel(ec3d_handle c, int kernel, int32_t reps, double 
     ec3d_launch_iteration(c, A, 1); // populate every partial slot and the scalars
     auto one = [&]() {
         if (kernel == EC3D_K_SPMV)
-            ec3d_launch_spmv(A, c->sweep_s, v[EC3D_VEC_P], v[EC3D_VEC_AP], s);
+            ec3d_launch_spmv(A, c->sweep_s, ec3d_cond_of(c, c->sweep_s), v[EC3D_VEC_P], v[EC3D_VEC_AP], s);
         else
             ec3d_launch_stage(c, A, 2, kernel);
     };
@@ -107,3 +107,31 @@ extern "C" int ec3d_time_kernel(ec3d_handle c, int kernel, int32_t reps, double 
     return 0;
 }
 
+
+// ||B - A X|| / ||B|| of the resident vectors, computed on the device by the setup kernel of the solve
+// (src/solvers.f90:14-21: R = B - A X, partial sums of B.B and R.R), the workgroup partials added on the
+// host in workgroup order.  Overwrites the work vectors R, R0, P -- which the next solve rebuilds anyway.
+// What a caller uses to check a returned x independently of the iteration's own recurrence.
+extern "C" int ec3d_true_residual(ec3d_handle c, double *rel, double *bnorm)
+{
+    int rc = ec3d_need_matrix(c, "ec3d_true_residual");
+    if (rc) return rc;
+    if ((rc = ec3d_single_rank_only(c, "ec3d_true_residual"))) return rc;
+    double **v = c->vec;
+    ec3d_launch_residual(c->A.view(), c->sweep_s, ec3d_cond_of(c, c->sweep_s), v[EC3D_VEC_X], v[EC3D_VEC_B], v[EC3D_VEC_R], v[EC3D_VEC_R0],
+                         v[EC3D_VEC_P], c->partials, c->stream);
+    EC3D_HIP(hipGetLastError());
+    EC3D_HIP(hipStreamSynchronize(c->stream));
+    const int nb = ec3d_spmv_parts(c);
+    std::vector<double> part((size_t)nb);
+    double s[2] = {0.0, 0.0};
+    const int slot[2] = {P_BB, P_RR_INIT};
+    for (int k = 0; k < 2; ++k) {
+        EC3D_HIP(hipMemcpy(part.data(), c->partials + (size_t)slot[k] * c->sweep.pstride, part.size() * sizeof(double),
+                           hipMemcpyDeviceToHost));
+        for (int q = 0; q < nb; ++q) s[k] += part[(size_t)q];
+    }
+    if (bnorm) *bnorm = std::sqrt(s[0]);
+    *rel = s[0] > 0.0 ? std::sqrt(s[1] / s[0]) : std::sqrt(s[1]);
+    return 0;
+}

@@ -1146,3 +1146,34 @@ extern "C" int ec3d_multi_synchronize(ec3d_multi_handle m)
         return drain(s);
     });
 }
+
+// ||B - A X|| / ||B|| over all slabs (as ec3d_true_residual): X halo refreshed, the residual stage on every
+// slab, the ranks' two sums added on the host in rank order.
+extern "C" int ec3d_multi_true_residual(ec3d_multi_handle m, double *rel, double *bnorm)
+{
+    int rc = need(m, "ec3d_multi_true_residual");
+    if (rc) return rc;
+    std::vector<double> bb((size_t)m->n, 0.0), rr((size_t)m->n, 0.0);
+    rc = run_all(m, [&](int r) -> int {
+        Slab &s = *m->slab[(size_t)r];
+        int rc2 = halo_start(m, s, CH_X);
+        if (rc2) return rc2;
+        if ((rc2 = halo_wait(s, CH_X))) return rc2;
+        if ((rc2 = ec3d_dist_step(s.c, EC3D_STAGE_RESID, 0, 0.0))) return rc2;
+        if ((rc2 = drain(s))) return rc2;
+        double v[P_NSLOT];
+        MHIP(hipMemcpy(v, s.lsum, sizeof v, hipMemcpyDeviceToHost));
+        bb[(size_t)r] = v[P_BB];
+        rr[(size_t)r] = v[P_RR_INIT];
+        return 0;
+    });
+    if (rc) return rc;
+    double sb = 0.0, sr = 0.0;
+    for (int r = 0; r < m->n; ++r) {
+        sb += bb[(size_t)r];
+        sr += rr[(size_t)r];
+    }
+    if (bnorm) *bnorm = std::sqrt(sb);
+    *rel = sb > 0.0 ? std::sqrt(sr / sb) : std::sqrt(sr);
+    return 0;
+}

@@ -204,12 +204,14 @@ class SourceProgram:
 
 
 def run(model: vxc.VxcModel, solver, steps: int | None = None, out_dir: str | None = None, on_step=None,
-        on_rhs=None, on_solved=None):
+        on_rhs=None, on_solved=None, write_output=None):
     """The reference's run of ``model`` on ``solver`` (an EC3DSolver): assemble, then step until T >= stop (or
     ``steps`` steps).  Returns a list of per-step dicts (T, iter).  ``out_dir``: write ``field_N.vtk`` there at
     the reference's output cadence.  Hooks, all ``(k, solver, info)``: ``on_rhs`` when Jaf (B) of step k is
     built -- what the reference passes to its solver --, ``on_solved`` when Uaf (X) holds the solver's result,
-    ``on_step`` after the post-update."""
+    ``on_step`` after the post-update.  ``solver`` may be an EC3DMulti (N GPUs behind one handle) as well.
+    ``write_output(N) -> bool`` (default: always) says whether output step N's files go to disk; the fields are
+    computed on the device either way (``info["fields"]`` holds them when they are not written)."""
     t = vxc.domain_tables(model)
     if t["dt"] is None or t["time"] is None:
         raise ValueError("the model has no 'tran stop=... step=...' line")
@@ -243,9 +245,13 @@ def run(model: vxc.VxcModel, solver, steps: int | None = None, out_dir: str | No
             Npoint += 1
             if out_dir:
                 f = solver.vtk_fields(t["delta"], sdx * sdy * sdz, conducting)
-                write_field_vtk(os.path.join(out_dir, f"field_{Npoint}.vtk"), sdx, sdy, sdz, t["delta"], f)
-                if prog.groups:                          # :446  CALL writeVtk_src
-                    write_src_vtk(os.path.join(out_dir, f"src_{Npoint}.vtk"), sdx, sdy, sdz, t["delta"], prog.groups)
+                if write_output is None or write_output(Npoint):
+                    write_field_vtk(os.path.join(out_dir, f"field_{Npoint}.vtk"), sdx, sdy, sdz, t["delta"], f)
+                    if prog.groups:                      # :446  CALL writeVtk_src
+                        write_src_vtk(os.path.join(out_dir, f"src_{Npoint}.vtk"), sdx, sdy, sdz, t["delta"],
+                                      prog.groups)
+                else:
+                    info["fields"] = f
             info["output"] = Npoint
         log.append(info)
         if on_step is not None:

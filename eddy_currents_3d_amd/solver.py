@@ -64,7 +64,7 @@ EXPORTS = ["sprsbcgstabwr_", "ec3d_invalidate", "ec3d_create", "ec3d_destroy", "
            "ec3d_multi_assemble_poisson", "ec3d_multi_assemble", "ec3d_multi_set_matrix_csr", "ec3d_multi_size",
            "ec3d_multi_upload", "ec3d_multi_download", "ec3d_multi_solve", "ec3d_multi_solve_resident",
            "ec3d_multi_rhs_step", "ec3d_multi_post_update", "ec3d_multi_vtk_fields", "ec3d_multi_iterate_begin",
-           "ec3d_multi_iterate", "ec3d_multi_synchronize"]
+           "ec3d_multi_iterate", "ec3d_multi_synchronize", "ec3d_true_residual", "ec3d_multi_true_residual", "ec3d_get_visit_order"]
 
 _f64 = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
 _i32 = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
@@ -153,6 +153,9 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.ec3d_dist_step.argtypes = [hp, C.c_int32, C.c_int32, C.c_double]
     L.ec3d_read_state_async.argtypes = [hp, C.c_void_p]
     L.ec3d_read_state.argtypes = [hp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+    L.ec3d_get_visit_order.argtypes = [hp, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int64), hp, hp]
+    L.ec3d_true_residual.argtypes = [hp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.ec3d_multi_true_residual.argtypes = [hp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.ec3d_multi_create.argtypes = [C.POINTER(hp), C.c_int32, hp]
     L.ec3d_multi_destroy.argtypes = [hp]
     L.ec3d_multi_ranks.argtypes = [hp]
@@ -343,6 +346,18 @@ class EC3DSolver:
         _chk(self.L, self.L.ec3d_get_reduction_geometry(self.h, which, C.byref(g)), "ec3d_get_reduction_geometry")
         return g
 
+    def visit_order(self, which: int = 0):
+        """(offsets[nwg + 1], tiles): the 512-row tiles every workgroup of the vector kernels (0) / SpMV kernels
+        (1) visits, in order -- the summation order of the dot products."""
+        nwg, tot = C.c_int32(0), C.c_int64(0)
+        _chk(self.L, self.L.ec3d_get_visit_order(self.h, which, C.byref(nwg), C.byref(tot), None, None),
+             "ec3d_get_visit_order")
+        off = np.zeros(nwg.value + 1, np.int32)
+        tiles = np.zeros(max(tot.value, 1), np.int32)
+        _chk(self.L, self.L.ec3d_get_visit_order(self.h, which, C.byref(nwg), C.byref(tot), off.ctypes.data,
+                                                 tiles.ctypes.data), "ec3d_get_visit_order")
+        return off, tiles[:tot.value]
+
     def set_zmarch(self, on: bool):
         _chk(self.L, self.L.ec3d_set_zmarch(self.h, int(bool(on))), "ec3d_set_zmarch")
 
@@ -404,6 +419,12 @@ class EC3DSolver:
                                             fe.ctypes.data if conducting else None, fs.ctypes.data,
                                             fb.ctypes.data), "ec3d_vtk_fields")
         return dict(A=fa, eddy=fe, source=fs, B=fb)
+
+    def true_residual(self):
+        """(||B - A X|| / ||B||, ||B||) of the resident vectors, computed on the device."""
+        rel, bn = C.c_double(0), C.c_double(0)
+        _chk(self.L, self.L.ec3d_true_residual(self.h, C.byref(rel), C.byref(bn)), "ec3d_true_residual")
+        return rel.value, bn.value
 
     def spmv(self, x):
         y = np.empty(self.n)
@@ -580,11 +601,17 @@ class EC3DMulti:
                                              int(itmax), C.byref(it)), "ec3d_multi_solve")
         return x, it.value
 
-    def solve_resident(self, tolerance, itmax):
+    def solve_resident(self, tolerance, itmax, hist_cap: int = 0):
+        """Returns (iter, hist) like EC3DSolver.solve_resident; the history is not kept on slabs (empty)."""
         it = C.c_int32(0)
         _chk(self.L, self.L.ec3d_multi_solve_resident(self.h, float(tolerance), int(itmax), C.byref(it)),
              "ec3d_multi_solve_resident")
-        return it.value
+        return it.value, np.zeros((0, 2))
+
+    def true_residual(self):
+        rel, bn = C.c_double(0), C.c_double(0)
+        _chk(self.L, self.L.ec3d_multi_true_residual(self.h, C.byref(rel), C.byref(bn)), "ec3d_multi_true_residual")
+        return rel.value, bn.value
 
     def rhs_step(self, src_index, src_value, moving: bool = False):
         idx = np.ascontiguousarray(src_index, np.int32)

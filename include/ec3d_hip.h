@@ -111,6 +111,11 @@ int ec3d_post_update(ec3d_handle h);
 int ec3d_vtk_fields(ec3d_handle h, const double *delta, float *field_A, float *field_eddy,
                     float *field_source, float *field_B);
 
+/* ||B - A*X|| / ||B|| of the RESIDENT vectors, computed on the device by the solve's own setup kernel
+ * (src/solvers.f90:14-21); bnorm (may be NULL) receives ||B||.  The check of a returned x that does not rely
+ * on the iteration's recurrence for R.  Overwrites the work vectors R, R0, P (rebuilt by the next solve). */
+int ec3d_true_residual(ec3d_handle h, double *rel, double *bnorm);
+
 /* y = A*x through the device format (src/solvers.f90:54-61), host vectors.  Parity probe. */
 int ec3d_spmv(ec3d_handle h, const double *x, double *y);
 
@@ -245,6 +250,7 @@ int ec3d_multi_solve_resident(ec3d_multi_handle mh, double tolerance, int32_t it
 int ec3d_multi_rhs_step(ec3d_multi_handle mh, int32_t moving, int32_t nsrc, const int32_t *src_index,
                         const double *src_value);
 int ec3d_multi_post_update(ec3d_multi_handle mh);
+int ec3d_multi_true_residual(ec3d_multi_handle mh, double *rel, double *bnorm); /* as ec3d_true_residual */
 int ec3d_multi_vtk_fields(ec3d_multi_handle mh, const double *delta, float *field_A, float *field_eddy,
                           float *field_source, float *field_B);
 /* bench "steps" as ec3d_iterate_begin / ec3d_iterate: every rank's thread enqueues the iterations and
@@ -271,6 +277,12 @@ typedef struct {
 /* which = 0: vector kernels (dots S.S, R.R, R.R0); 1: SpMV kernels (B.B, initial R.R, AP.R0, AS.S, AS.AS) */
 int ec3d_get_reduction_geometry(ec3d_handle h, int which, ec3d_geom *g);
 int ec3d_get_ulist(ec3d_handle h, int32_t *tiles); /* ulist_n entries */
+/* The tiles (512 rows each) every workgroup of a launch visits, in order: workgroup w visits
+ * tiles[offsets[w] .. offsets[w+1]).  which as above; for which = 1 on the structured A-V form the list covers
+ * the plain pass followed by the conductor pass (two launches whose partial sums are added as one sequence).
+ * Each thread t of a workgroup owns rows tile*512 + 2t, 2t+1 and adds its products in this order -- the summation
+ * order the oracle's twin reproduces.  Two-pass: offsets == NULL -> *nwg and *total only. */
+int ec3d_get_visit_order(ec3d_handle h, int which, int32_t *nwg, int64_t *total, int32_t *offsets, int32_t *tiles);
 /* 1 (default): SpMV kernels walk the z direction per workgroup and keep x[r-kdz], x[r] in registers
  * when a grid plane is a whole number of 512-row tiles; 0: plain tile order. */
 int ec3d_set_zmarch(ec3d_handle h, int on);

@@ -150,21 +150,25 @@ static double block_tree(double *v, int threads)
 double oracle_dot_gpuorder(const oracle_gpu_geom *g, const double *a, const double *b, int64_t n)
 {
     int T = g->threads;
-    double *part = calloc((size_t)g->nblk, sizeof(double));
+    const int32_t nwg = g->visit_off ? g->visit_nwg : g->nblk;
+    double *part = calloc((size_t)(nwg > 0 ? nwg : 1), sizeof(double));
     double *acc = malloc((size_t)T * sizeof(double));
-    for (int32_t blk = 0; blk < g->nblk; ++blk) {
+    for (int32_t blk = 0; blk < nwg; ++blk) {
         for (int t = 0; t < T; ++t) acc[t] = 0.0;
         int64_t lst = -1; /* >= 0: walking the list of occupied U tiles (structured A-V form) */
         for (int64_t i = 0;; ++i) {
             int64_t tile = -1;
-            if (lst < 0) {
+            if (g->visit_off) { /* explicit account of the launch(es) */
+                if (g->visit_off[blk] + i >= g->visit_off[blk + 1]) break;
+                tile = g->visit[g->visit_off[blk] + i];
+            } else if (lst < 0) {
                 tile = oracle_gpu_tile_of(g, blk, i);
                 if (tile < 0) {
                     if (g->ulist_n == 0) break;
                     lst = blk;
                 }
             }
-            if (lst >= 0) {
+            if (!g->visit_off && lst >= 0) {
                 if (lst >= g->ulist_n) break;
                 tile = g->ulist[lst];
                 lst += g->nblk;
@@ -181,7 +185,7 @@ double oracle_dot_gpuorder(const oracle_gpu_geom *g, const double *a, const doub
     }
     for (int t = 0; t < T; ++t) {
         double s = 0.0;
-        for (int32_t i = t; i < g->nblk; i += T) s = s + part[i];
+        for (int32_t i = t; i < nwg; i += T) s = s + part[i];
         acc[t] = s;
     }
     double r = block_tree(acc, T);

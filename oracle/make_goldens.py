@@ -348,6 +348,22 @@ def case_g5():
              x=x if N <= 32 else x[::max(1, N ** 3 // 4096)], seconds=np.float64(sec))
 
 
+def case_g5_big(sizes=(128, 256)):
+    """BASELINE config 2 as stated: the reference solver alone on the 256^3 cube (and 128^3), bar RHS, x0 = 0,
+    tol 1e-8 -- about a quarter of an hour on one core.  Kept: iteration count, ||x||, ||b||, 64 probes of x."""
+    for N in sizes:
+        valA, irow, jcol = O.poisson_csr(N, N, N)
+        b = O.bar_rhs(N)
+        x, it, sec = O.solve_process("reference", valA, irow, jcol, b, np.zeros(N ** 3), 1e-8, 100000)
+        rng = np.random.Generator(np.random.PCG64(11))
+        probes = np.sort(rng.choice(N ** 3, 64, replace=False))
+        res = np.linalg.norm(b - O.spmv_csr(valA, irow, jcol, x)) / np.linalg.norm(b)
+        print(f"G5 N={N}: iter={it} ||x||={np.linalg.norm(x):.10e} true residual {res:.3e} t={sec:.1f}s", flush=True)
+        save(f"g5_cube{N}", N=np.int32(N), iter=np.int32(it), xnorm=np.linalg.norm(x), bnorm=np.linalg.norm(b),
+             probes=probes, xprobe=x[probes], true_residual=np.float64(res), seconds=np.float64(sec),
+             tol=np.float64(1e-8))
+
+
 def vtk_vectors(blob):
     """{name: float32 [npoints, 3]} of a field_N.vtk the reference wrote (src/utilites.f90:222-289)."""
     out = {}
@@ -398,6 +414,7 @@ def case_g6(which=("ec_src_move_hole", "LIM"), max_calls=4):
                  xnorm=np.array([np.linalg.norm(c["x_out"]) for c in calls]),
                  probes=probes, xprobe=np.stack([c["x_out"][probes] for c in calls]),
                  bprobe=np.stack([c["b"][probes] for c in calls]),
+                 xsketch=np.stack([O.count_sketch(c["x_out"]) for c in calls]),
                  seconds=np.array([c["seconds"] for c in calls]), point_probes=pprobe)
         for fn, blob in sorted(calls[0]["vtk"].items()):
             if not fn.startswith("field_"):
@@ -405,6 +422,7 @@ def case_g6(which=("ec_src_move_hole", "LIM"), max_calls=4):
             for name, v in vtk_vectors(blob).items():
                 d[f"vtk_{fn[:-4]}_{name}"] = v[pprobe]
                 d[f"vtk_{fn[:-4]}_{name}_norm"] = np.float64(np.linalg.norm(v.astype(np.float64)))
+                d[f"vtk_{fn[:-4]}_{name}_sketch"] = O.count_sketch(v.astype(np.float64))
         print(stem, dims[stem], "n", n, "iters", d["iters"], "bnorm", d["bnorm"], "xnorm", d["xnorm"],
               "seconds", d["seconds"], "vtk", [k for k in d if k.startswith("vtk_") and not k.endswith("_norm")])
         save("g6_" + stem + "_%dx%dx%d" % dims[stem], **d)
@@ -420,6 +438,7 @@ if __name__ == "__main__":
     if "g3" in which: case_g3()
     if "g4" in which: case_g4()
     if "g5" in which: case_g5()
+    if "g5big" in which: case_g5_big()
     if "g6" in which: case_g6()
     if "g6hole" in which: case_g6(("ec_src_move_hole",))
     if "g6lim" in which: case_g6(("LIM",))

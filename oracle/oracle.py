@@ -33,7 +33,8 @@ class GpuGeom(C.Structure):
     _fields_ = [("n_pad", C.c_int32), ("tile", C.c_int32), ("nblk", C.c_int32),
                 ("threads", C.c_int32), ("xcd_group", C.c_int32), ("zm_tpp", C.c_int32),
                 ("zm_pps", C.c_int32), ("ntiles_front", C.c_int32), ("ulist_n", C.c_int32),
-                ("ulist", C.POINTER(C.c_int32))]
+                ("ulist", C.POINTER(C.c_int32)), ("visit_nwg", C.c_int32),
+                ("visit_off", C.POINTER(C.c_int32)), ("visit", C.POINTER(C.c_int32))]
 
 
 def build(with_ref: bool = True) -> None:
@@ -125,6 +126,14 @@ def geoms_of(solver):
                      zm_tpp=g.zm_tpp, zm_pps=g.zm_pps, ntiles_front=g.ntiles_front, ulist_n=g.ulist_n,
                      ulist=ul.ctypes.data_as(C.POINTER(C.c_int32)))
         gg._keep = ul  # the struct only holds a pointer
+        if hasattr(solver, "visit_order"):   # the library's own account of its launches, tile by tile
+            off, tiles = solver.visit_order(which)
+            off = np.ascontiguousarray(off, np.int32)
+            tiles = np.ascontiguousarray(tiles if len(tiles) else np.zeros(1, np.int32), np.int32)
+            gg.visit_nwg = len(off) - 1
+            gg.visit_off = off.ctypes.data_as(C.POINTER(C.c_int32))
+            gg.visit = tiles.ctypes.data_as(C.POINTER(C.c_int32))
+            gg._keep_visit = (off, tiles)
         out.append(gg)
     return tuple(out)
 
@@ -252,6 +261,26 @@ def _unlimit_stack():
     except (ValueError, OSError):
         soft, hard = resource.getrlimit(resource.RLIMIT_STACK)
         resource.setrlimit(resource.RLIMIT_STACK, (hard, hard))
+
+
+def count_sketch(x, m=4096, seed=0x9E3779B97F4A7C15):
+    """Linear sketch of a long vector into m doubles: entry i goes to bucket h(i) with sign s(i) (splitmix64 of
+    the index).  ||sketch(x) - sketch(y)||_2 estimates ||x - y||_2 without bias, relative standard deviation
+    about sqrt(1/(2m)) (1.1 % at m = 4096): what lets a test state ||x_gpu - x_ref|| / ||x_ref|| for a vector far
+    too large to commit.  Pure index arithmetic: the same buckets here and on the GPU box."""
+    x = np.ascontiguousarray(x, np.float64).reshape(-1)
+    out = np.zeros(m)
+    step = 1 << 22
+    with np.errstate(over="ignore"):
+        for lo in range(0, x.size, step):
+            z = np.arange(lo, min(lo + step, x.size), dtype=np.uint64) + np.uint64(seed)
+            z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+            z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+            z = z ^ (z >> np.uint64(31))
+            bucket = ((z >> np.uint64(20)) % np.uint64(m)).astype(np.int64)
+            sign = 1.0 - 2.0 * ((z >> np.uint64(7)) & np.uint64(1)).astype(np.float64)
+            out += np.bincount(bucket, weights=sign * x[lo:lo + len(bucket)], minlength=m)
+    return out
 
 
 def solve_process(kind, valA, irow, jcol, b, x0, tol, itmax, nrep=1, capture_stdout=False):
