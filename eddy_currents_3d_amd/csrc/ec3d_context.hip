@@ -15,7 +15,6 @@ void ec3d_set_error(const std::string &msg) { g_err = msg; }
 extern "C" const char *ec3d_last_error(void) { return g_err.c_str(); }
 
 static int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
-static void free_walks(ec3d_ctx *c);
 
 MatView DevMatrix::view() const
 {
@@ -35,7 +34,6 @@ MatView DevMatrix::view() const
     v.sav_zero = sav_zero;
     v.sav_nC = sav_nC;
     for (int d = 0; d < 3; ++d) v.sav_step[d] = sav_step[d];
-    v.sav_T = sav_T;
     static const bool shuffle_off = getenv("EC3D_SHUFFLE") && atoi(getenv("EC3D_SHUFFLE")) == 0;
     v.pm1 = (nb == 7 && off[2] == -1 && off[4] == 1 && !shuffle_off) ? 1 : 0;
     v.has_tail = ntail > 0;
@@ -100,7 +98,6 @@ void ec3d_free_matrix(ec3d_ctx *c)
     if (A.cls) (void)hipFree(A.cls);
     if (A.table) (void)hipFree(A.table);
     A = DevMatrix();
-    free_walks(c);
     if (c->io_tmp) (void)hipFree(c->io_tmp);
     c->io_tmp = nullptr;
     if (c->vb_list) (void)hipFree(c->vb_list);
@@ -149,119 +146,6 @@ extern "C" int ec3d_destroy(ec3d_handle c)
     return 0;
 }
 
-// Structured form with whole tiles per block: find the conductor cell tiles (any of the four block tiles of
-// a cell tile holds a coupled row) -- the SpMV kernels then run as a plain pass over everything else plus a
-// conductor pass over these (MatView::sav_T).  EC3D_FUSE=0 keeps the couplings inline in one pass.
-static int build_conductor_tiles(ec3d_ctx *c)
-{
-    DevMatrix &A = c->A;
-    A.sav_T = 0;
-    A.n_cond_tiles = 0;
-    A.ctile_host.clear();
-    A.ulist_host.clear();
-    A.tile_flag_host.clear();
-    if (!A.sav) return 0;
-    const int64_t ntiles = A.n_pad / EC3D_TILE;
-    A.tile_flag_host.resize((size_t)ntiles);
-    EC3D_HIP(hipMemcpy(A.tile_flag_host.data(), A.tile_flag, (size_t)ntiles, hipMemcpyDeviceToHost));
-    A.ulist_host.resize((size_t)A.ulist_n);
-    if (A.ulist_n) EC3D_HIP(hipMemcpy(A.ulist_host.data(), A.ulist, (size_t)A.ulist_n * 4, hipMemcpyDeviceToHost));
-    bool fuse = A.sav_nC % EC3D_TILE == 0 && c->pitch % EC3D_TILE == 0;
-    if (const char *e = getenv("EC3D_FUSE")) fuse = fuse && atoi(e) != 0;
-    if (!fuse) return 0;
-    const int64_t T = A.sav_nC / EC3D_TILE;
-    A.ctile_host.assign((size_t)T, 0);
-    for (int64_t ct = 0; ct < T; ++ct) {
-        bool any = false;
-        for (int d = 0; d < 4; ++d) any = any || A.tile_flag_host[(size_t)(d * T + ct)] != 0;
-        A.ctile_host[(size_t)ct] = any;
-        A.n_cond_tiles += any;
-    }
-    A.sav_T = T;
-    return 0;
-}
-
-static void free_walks(ec3d_ctx *c)
-{
-    for (int i = 0; i < 2; ++i) {
-        if (c->walk_dev[i]) (void)hipFree(c->walk_dev[i]);
-        if (c->walk_off_dev[i]) (void)hipFree(c->walk_off_dev[i]);
-        c->walk_dev[i] = c->walk_off_dev[i] = nullptr;
-        c->walk_host[i].clear();
-        c->walk_off_host[i].clear();
-    }
-}
-
-// Walk lists of the two SpMV passes of a fused structured matrix.  Every xy position ("column", tpp of them)
-// contributes its tiles in z order -- the plain pass the A tiles of all three blocks that are not conductor
-// tiles, the conductor pass the conductor cell tiles --; a column's list is cut into runs of about equal
-// length so that `want` workgroups share the work evenly; columns are dealt to the 8 XCD labels
-// (blockIdx % 8) in contiguous groups, as in the z-marching map.
-static int build_walks(ec3d_ctx *c, int which, int want, Sweep &sw)
-{
-    const DevMatrix &A = c->A;
-    const int64_t T = A.sav_T, tpp = c->pitch / EC3D_TILE, np = T / tpp;
-    std::vector<std::vector<int32_t>> col((size_t)tpp);
-    int64_t total = 0;
-    for (int64_t cc = 0; cc < tpp; ++cc) {
-        auto &v = col[(size_t)cc];
-        if (which == 0) {
-            for (int blk = 0; blk < 3; ++blk)
-                for (int64_t k = 0; k < np; ++k)
-                    if (!A.ctile_host[(size_t)(k * tpp + cc)]) v.push_back((int32_t)((blk * np + k) * tpp + cc));
-        } else {
-            for (int64_t k = 0; k < np; ++k)
-                if (A.ctile_host[(size_t)(k * tpp + cc)]) v.push_back((int32_t)(k * tpp + cc));
-        }
-        total += (int64_t)v.size();
-    }
-    const int64_t len = std::max<int64_t>(1, (total + want - 1) / want); // entries per workgroup
-    const int64_t cpx = (tpp + 7) / 8;
-    std::vector<std::vector<std::pair<int32_t, int32_t>>> jobs(8); // per XCD label: (column, run) as (begin, end) into col[]
-    std::vector<std::vector<int32_t>> jobcol(8);
-    for (int64_t cc = 0; cc < tpp; ++cc) {
-        const int64_t n = (int64_t)col[(size_t)cc].size();
-        if (n == 0) continue;
-        const int64_t nseg = std::max<int64_t>(1, (n + len / 2) / len);
-        for (int64_t sg = 0; sg < nseg; ++sg) {
-            jobs[(size_t)(cc / cpx)].push_back({(int32_t)(sg * n / nseg), (int32_t)((sg + 1) * n / nseg)});
-            jobcol[(size_t)(cc / cpx)].push_back((int32_t)cc);
-        }
-    }
-    size_t per = 0;
-    for (auto &j : jobs) per = std::max(per, j.size());
-    const int nblk = (int)(8 * per);
-    auto &wl = c->walk_host[which];
-    auto &wo = c->walk_off_host[which];
-    wl.clear();
-    wo.assign((size_t)nblk + 1, 0);
-    for (int b = 0; b < nblk; ++b) {
-        const size_t lab = (size_t)(b & 7), j = (size_t)(b >> 3);
-        wo[(size_t)b] = (int32_t)wl.size();
-        if (j < jobs[lab].size()) {
-            const auto &v = col[(size_t)jobcol[lab][j]];
-            wl.insert(wl.end(), v.begin() + jobs[lab][j].first, v.begin() + jobs[lab][j].second);
-        }
-    }
-    wo[(size_t)nblk] = (int32_t)wl.size();
-    EC3D_HIP(hipMalloc(&c->walk_dev[which], std::max<size_t>(wl.size(), 1) * 4));
-    EC3D_HIP(hipMalloc(&c->walk_off_dev[which], wo.size() * 4));
-    if (!wl.empty()) EC3D_HIP(hipMemcpy(c->walk_dev[which], wl.data(), wl.size() * 4, hipMemcpyHostToDevice));
-    EC3D_HIP(hipMemcpy(c->walk_off_dev[which], wo.data(), wo.size() * 4, hipMemcpyHostToDevice));
-    sw.ntiles = 0;
-    sw.ulist = nullptr;
-    sw.ulist_n = 0;
-    sw.S = 0;
-    sw.zm_tpp = 0;
-    sw.walk = c->walk_dev[which];
-    sw.walk_off = c->walk_off_dev[which];
-    sw.walk_quad = which;
-    sw.walk_tpp = (int)tpp;
-    sw.c_T = T;
-    sw.nblk = nblk;
-    return 0;
-}
-
 // Launch geometry.  Vector kernels (K2, K4, K5): plain XCD-aware grid stride over 512-row tiles.
 // SpMV kernels: the same, or -- when a plane of the grid is a whole number of tiles -- the z-marching
 // map (one xy position per workgroup, consecutive planes per step; ec3d_tile_of in ec3d_kernels.hip).
@@ -296,32 +180,41 @@ static int choose_sweep(ec3d_ctx *c)
         if (atoi(e) == 0) sw.S = 0;
     sw.nblk = (int)nblk;
     sw.nt = c->nt_request >= 0 ? c->nt_request : (c->A.n_pad >= (4 << 20));
+    // K2 and K5 on grids of their own: the same map with another workgroup count
+    auto with_blocks = [&](int want_k) {
+        Sweep k = sw;
+        int64_t nb = std::min<int64_t>(sw.ntiles, want_k);
+        if (nb >= 8) {
+            nb -= nb % 8;
+            k.S = sw.S > 0 ? (int)(nb / 8) : 0;
+        } else {
+            k.S = 0;
+        }
+        k.nblk = (int)nb;
+        return k;
+    };
+    {
+        int w4 = want, w2 = want, w5 = want;
+        if (c->nblk_request <= 0) {
+            // K4 (5 reads + 2 writes) streams best from 2 workgroups per CU once the vectors are far beyond the
+            // caches: 512^3 1.31 vs 1.38 ms; at 256^3 3 per CU win (0.137 vs 0.147 ms); K2 and K5 prefer 3 per
+            // CU at both sizes (tools/vec_grid_sweep.sh)
+            if (c->A.n_pad >= ((int64_t)1 << 25)) w4 = 512; // 384^3: 0.498 vs 0.522 ms
+            if (const char *e = getenv("EC3D_NBLK_K4")) w4 = std::max(1, atoi(e));
+            if (const char *e = getenv("EC3D_NBLK_K2")) w2 = std::max(1, atoi(e));
+            if (const char *e = getenv("EC3D_NBLK_K5")) w5 = std::max(1, atoi(e));
+        }
+        if (w4 != want) sw = with_blocks(w4);
+        c->sweep_k2 = with_blocks(w2);
+        c->sweep_k5 = with_blocks(w5);
+    }
 
     Sweep &ss = c->sweep_s;
     ss = sw;
     const DevMatrix &A = c->A;
-    c->sweep_c = Sweep{};
-    free_walks(c);
-    bool walks = false;
-    if (A.sav_T > 0) {
-        // plain pass: the A tiles without a coupled row, by walk list (6 workgroups per CU, as the z-marching
-        // grids); conductor pass: the conductor cell tiles, four tiles each, 4 workgroups per CU
-        int want_s = c->nblk_request > 0 ? c->nblk_request : 1536;
-        if (const char *e = getenv("EC3D_NBLK_SPMV")) want_s = std::max(8, atoi(e));
-        int rc = build_walks(c, 0, want_s, ss);
-        if (rc) return rc;
-        if (A.n_cond_tiles > 0) {
-            Sweep &cw = c->sweep_c;
-            cw = sw;
-            int want_c = 1024;
-            if (const char *e = getenv("EC3D_NBLK_COND")) want_c = std::max(8, atoi(e));
-            if ((rc = build_walks(c, 1, want_c, cw))) return rc;
-        }
-        walks = true;
-    }
     int zm = c->zm_request;
     if (const char *e = getenv("EC3D_ZMARCH")) zm = atoi(e);
-    if (!walks && zm != 0 && A.nb == 7 && A.off[3] == 0 && A.off[0] == -A.off[6] && A.off[6] % EC3D_TILE == 0) {
+    if (zm != 0 && A.nb == 7 && A.off[3] == 0 && A.off[0] == -A.off[6] && A.off[6] % EC3D_TILE == 0) {
         const int64_t tpp = A.off[6] / EC3D_TILE;
         const int64_t nplanes = (sw.ntiles + tpp - 1) / tpp;
         if (tpp <= 4096 && nplanes >= 8) {
@@ -376,10 +269,11 @@ static int choose_sweep(ec3d_ctx *c)
             c->can_overlap = true;
         }
     }
-    c->sweep_c.part_off = ss.nblk; // the conductor pass's partials follow the plain pass's
     // room for a vector kernel in two launches as well (boundary list <= 256 workgroups)
-    const int ps = std::max(sw.nblk + 256, std::max(ss.nblk + c->sweep_c.nblk, parts));
-    sw.pstride = ss.pstride = c->sweep_int.pstride = c->sweep_bnd.pstride = c->sweep_c.pstride = ps;
+    const int vmax = std::max(sw.nblk, std::max(c->sweep_k2.nblk, c->sweep_k5.nblk));
+    const int ps = std::max(vmax + 256, std::max(ss.nblk, parts));
+    sw.pstride = ss.pstride = c->sweep_int.pstride = c->sweep_bnd.pstride = ps;
+    c->sweep_k2.pstride = c->sweep_k5.pstride = ps;
     return 0;
 }
 
@@ -387,10 +281,9 @@ static int choose_sweep(ec3d_ctx *c)
 int ec3d_prepare_vectors(ec3d_ctx *c)
 {
     free_vectors(c);
-    {
-        int rc = build_conductor_tiles(c);
-        if (rc) return rc;
-    }
+    c->A.ulist_host.resize((size_t)c->A.ulist_n);
+    if (c->A.ulist_n)
+        EC3D_HIP(hipMemcpy(c->A.ulist_host.data(), c->A.ulist, (size_t)c->A.ulist_n * 4, hipMemcpyDeviceToHost));
     int64_t maxoff = 0;
     for (int b = 0; b < c->A.nb; ++b) maxoff = std::max<int64_t>(maxoff, std::llabs(c->A.off[b]));
     if (c->A.sav) maxoff *= 2; // the one-sided A-U slots reach two planes
@@ -774,7 +667,7 @@ extern "C" int ec3d_get_reduction_geometry(ec3d_handle c, int which, ec3d_geom *
 {
     int rc = ec3d_need_matrix(c, "ec3d_get_reduction_geometry");
     if (rc) return rc;
-    const Sweep &sw = which == 1 ? c->sweep_s : c->sweep;
+    const Sweep &sw = which == 1 ? c->sweep_s : which == 2 ? c->sweep_k2 : c->sweep;
     g->n_pad = (int32_t)c->A.n_pad;
     g->tile = EC3D_TILE;
     g->nblk = sw.nblk;
@@ -792,39 +685,22 @@ extern "C" int ec3d_get_reduction_geometry(ec3d_handle c, int which, ec3d_geom *
 static void visit_of(const ec3d_ctx *c, const Sweep &sw, std::vector<std::vector<int32_t>> &out)
 {
     const DevMatrix &A = c->A;
-    const int which = &sw == &c->sweep_c ? 1 : 0;
+    std::vector<int32_t> ul;
+    if (sw.ulist_n > 0) {
+        if (sw.ulist == A.ulist) ul = A.ulist_host;
+        else { // a tile list made elsewhere (K2/K5 split sweeps)
+            ul.resize((size_t)sw.ulist_n);
+            (void)hipMemcpy(ul.data(), sw.ulist, ul.size() * 4, hipMemcpyDeviceToHost);
+        }
+    }
     for (int b = 0; b < sw.nblk; ++b) {
         std::vector<int32_t> v;
-        if (sw.walk) {
-            const auto &wl = c->walk_host[which];
-            const auto &wo = c->walk_off_host[which];
-            for (int32_t p = wo[(size_t)b]; p < wo[(size_t)b + 1]; ++p) {
-                if (!sw.walk_quad) {
-                    v.push_back(wl[(size_t)p]);
-                    continue;
-                }
-                for (int d = 0; d < 4; ++d) {
-                    const int64_t tile = d * sw.c_T + wl[(size_t)p];
-                    if (d == 3 && A.tile_flag_host[(size_t)tile] == 0) continue;
-                    v.push_back((int32_t)tile);
-                }
-            }
-        } else {
-            for (int64_t it = 0;; ++it) {
-                const int64_t tile = ec3d_tile_of(sw, b, it);
-                if (tile >= sw.ntiles) break;
-                v.push_back((int32_t)tile);
-            }
-            if (sw.ulist_n > 0) {
-                std::vector<int32_t> ul;
-                if (sw.ulist == A.ulist) ul = A.ulist_host;
-                else { // a tile list made elsewhere (K2/K5 split sweeps)
-                    ul.resize((size_t)sw.ulist_n);
-                    (void)hipMemcpy(ul.data(), sw.ulist, ul.size() * 4, hipMemcpyDeviceToHost);
-                }
-                for (int64_t l = b; l < sw.ulist_n; l += sw.nblk) v.push_back(ul[(size_t)l]);
-            }
+        for (int64_t it = 0;; ++it) {
+            const int64_t tile = ec3d_tile_of(sw, b, it);
+            if (tile >= sw.ntiles) break;
+            v.push_back((int32_t)tile);
         }
+        for (int64_t l = b; l < sw.ulist_n; l += sw.nblk) v.push_back(ul[(size_t)l]);
         out.push_back(std::move(v));
     }
 }
@@ -837,7 +713,8 @@ extern "C" int ec3d_get_visit_order(ec3d_handle c, int which, int32_t *nwg, int6
     std::vector<std::vector<int32_t>> v;
     if (which == 1) {
         visit_of(c, c->sweep_s, v);
-        if (c->sweep_c.nblk > 0) visit_of(c, c->sweep_c, v);
+    } else if (which == 2) {
+        visit_of(c, c->sweep_k2, v);
     } else {
         visit_of(c, c->sweep, v);
     }
@@ -1008,7 +885,7 @@ extern "C" int ec3d_spmv(ec3d_handle c, const double *x, double *y)
     if (rc) return rc;
     // P and AP serve as scratch
     if ((rc = ec3d_vec_h2d(c, c->vec[EC3D_VEC_P], x))) return rc;
-    ec3d_launch_spmv(c->A.view(), c->sweep_s, ec3d_cond_of(c, c->sweep_s), c->vec[EC3D_VEC_P], c->vec[EC3D_VEC_AP], c->stream);
+    ec3d_launch_spmv(c->A.view(), c->sweep_s, c->vec[EC3D_VEC_P], c->vec[EC3D_VEC_AP], c->stream);
     EC3D_HIP(hipGetLastError());
     if ((rc = ec3d_vec_d2h(c, y, c->vec[EC3D_VEC_AP]))) return rc;
     EC3D_HIP(hipStreamSynchronize(c->stream));

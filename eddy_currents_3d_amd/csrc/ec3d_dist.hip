@@ -119,8 +119,8 @@ extern "C" int ec3d_dist_step(ec3d_handle c, int32_t stage, int32_t it, double t
     }
     const MatView A = c->A.view();
     double **v = c->vec;
-    auto fin = [&](bool spmv_producer, unsigned mask, bool split = false) {
-        ec3d_launch_finalize(ec3d_part_of(c, spmv_producer, split), c->lsum, mask, c->stream);
+    auto fin = [&](int producer, unsigned mask, bool split = false) {
+        ec3d_launch_finalize(ec3d_part_of(c, producer, split), c->lsum, mask, c->stream);
     };
     auto need_split = [&]() {
         if (!c->can_overlap) ec3d_set_error("ec3d_dist_step: this slab cannot split K1/K3 (see ec3d_can_overlap)");
@@ -129,35 +129,35 @@ extern "C" int ec3d_dist_step(ec3d_handle c, int32_t stage, int32_t it, double t
     switch (stage) {
     case EC3D_STAGE_RESID:
         c->hist_cap = 0;
-        ec3d_launch_residual(A, c->sweep_s, ec3d_cond_of(c, c->sweep_s), v[EC3D_VEC_X], v[EC3D_VEC_B], v[EC3D_VEC_R], v[EC3D_VEC_R0],
+        ec3d_launch_residual(A, c->sweep_s, v[EC3D_VEC_X], v[EC3D_VEC_B], v[EC3D_VEC_R], v[EC3D_VEC_R0],
                              v[EC3D_VEC_P], c->partials, c->stream);
-        fin(true, 1u << P_BB | 1u << P_RR_INIT);
+        fin(EC3D_BY_SPMV, 1u << P_BB | 1u << P_RR_INIT);
         break;
-    case EC3D_STAGE_SETUP: ec3d_launch_setup(c->state, ec3d_src_of(c, true), tolerance, c->stream); break;
-    case EC3D_STAGE_K1: ec3d_launch_stage(c, A, it, 1); fin(true, 1u << P_D1); break;
-    case EC3D_STAGE_K2: ec3d_launch_stage(c, A, it, 2); fin(false, 1u << P_SS); break;
-    case EC3D_STAGE_K3: ec3d_launch_stage(c, A, it, 3); fin(true, 1u << P_D2 | 1u << P_D3); break;
-    case EC3D_STAGE_K4: ec3d_launch_stage(c, A, it, 4); fin(false, 1u << P_RR | 1u << P_RR0N); break;
+    case EC3D_STAGE_SETUP: ec3d_launch_setup(c->state, ec3d_src_of(c, EC3D_BY_SPMV), tolerance, c->stream); break;
+    case EC3D_STAGE_K1: ec3d_launch_stage(c, A, it, 1); fin(EC3D_BY_SPMV, 1u << P_D1); break;
+    case EC3D_STAGE_K2: ec3d_launch_stage(c, A, it, 2); fin(EC3D_BY_K2, 1u << P_SS); break;
+    case EC3D_STAGE_K3: ec3d_launch_stage(c, A, it, 3); fin(EC3D_BY_SPMV, 1u << P_D2 | 1u << P_D3); break;
+    case EC3D_STAGE_K4: ec3d_launch_stage(c, A, it, 4); fin(EC3D_BY_K4, 1u << P_RR | 1u << P_RR0N); break;
     case EC3D_STAGE_K5: ec3d_launch_stage(c, A, it, 5); break;
     case EC3D_STAGE_K1_INT:
         if (!need_split()) return 3;
-        ec3d_launch_k1(A, c->sweep_int, nullptr, c->state, it, v[EC3D_VEC_P], v[EC3D_VEC_R0], v[EC3D_VEC_AP], c->partials,
+        ec3d_launch_k1(A, c->sweep_int, c->state, it, v[EC3D_VEC_P], v[EC3D_VEC_R0], v[EC3D_VEC_AP], c->partials,
                        c->stream);
         break;
     case EC3D_STAGE_K1_BND:
         if (!need_split()) return 3;
-        ec3d_launch_k1(A, c->sweep_bnd, nullptr, c->state, it, v[EC3D_VEC_P], v[EC3D_VEC_R0], v[EC3D_VEC_AP], c->partials,
+        ec3d_launch_k1(A, c->sweep_bnd, c->state, it, v[EC3D_VEC_P], v[EC3D_VEC_R0], v[EC3D_VEC_AP], c->partials,
                        c->stream);
-        fin(true, 1u << P_D1, true);
+        fin(EC3D_BY_SPMV, 1u << P_D1, true);
         break;
     case EC3D_STAGE_K3_INT:
         if (!need_split()) return 3;
-        ec3d_launch_k3(A, c->sweep_int, nullptr, c->state, it, v[EC3D_VEC_S], v[EC3D_VEC_AS], c->partials, c->stream);
+        ec3d_launch_k3(A, c->sweep_int, c->state, it, v[EC3D_VEC_S], v[EC3D_VEC_AS], c->partials, c->stream);
         break;
     case EC3D_STAGE_K3_BND:
         if (!need_split()) return 3;
-        ec3d_launch_k3(A, c->sweep_bnd, nullptr, c->state, it, v[EC3D_VEC_S], v[EC3D_VEC_AS], c->partials, c->stream);
-        fin(true, 1u << P_D2 | 1u << P_D3, true);
+        ec3d_launch_k3(A, c->sweep_bnd, c->state, it, v[EC3D_VEC_S], v[EC3D_VEC_AS], c->partials, c->stream);
+        fin(EC3D_BY_SPMV, 1u << P_D2 | 1u << P_D3, true);
         break;
     case EC3D_STAGE_K2_BND:
     case EC3D_STAGE_K2_INT: {
@@ -166,7 +166,7 @@ extern "C" int ec3d_dist_step(ec3d_handle c, int32_t stage, int32_t it, double t
             return 3;
         }
         const bool bnd = stage == EC3D_STAGE_K2_BND;
-        ec3d_launch_k2(bnd ? c->sweep_vb : c->sweep_vi, ec3d_src_of(c, true), c->state, it, v[EC3D_VEC_R], v[EC3D_VEC_AP],
+        ec3d_launch_k2(bnd ? c->sweep_vb : c->sweep_vi, ec3d_src_of(c, EC3D_BY_SPMV), c->state, it, v[EC3D_VEC_R], v[EC3D_VEC_AP],
                        v[EC3D_VEC_S], c->partials, c->stream);
         if (!bnd)
             ec3d_launch_finalize(RedSrc{c->partials, c->sweep_vb.nblk + c->sweep_vi.nblk, 1, c->sweep.pstride, nullptr}, c->lsum,
@@ -179,7 +179,7 @@ extern "C" int ec3d_dist_step(ec3d_handle c, int32_t stage, int32_t it, double t
             ec3d_set_error("ec3d_dist_step: call ec3d_dist_set_boundary_rows first");
             return 3;
         }
-        ec3d_launch_k5(stage == EC3D_STAGE_K5_BND ? c->sweep_vb : c->sweep_vi, ec3d_src_of(c, false), c->state, it,
+        ec3d_launch_k5(stage == EC3D_STAGE_K5_BND ? c->sweep_vb : c->sweep_vi, ec3d_src_of(c, EC3D_BY_K4), c->state, it,
                        v[EC3D_VEC_R], v[EC3D_VEC_AP], v[EC3D_VEC_P], v[EC3D_VEC_R0], c->hist, c->hist_cap, c->stream);
         break;
     default: ec3d_set_error("ec3d_dist_step: unknown stage"); return 2;

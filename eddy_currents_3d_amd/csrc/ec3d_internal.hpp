@@ -45,12 +45,6 @@ struct MatView {
     int sav;
     int sav_a0, sav_u0, sav_zero;
     int64_t sav_nC, sav_step[3];
-    // Conductor cell tiles handled apart (sav_T > 0; needs whole tiles per block, sav_nC % EC3D_TILE == 0):
-    // cell tile ct = the tiles {d * sav_T + ct, d = 0..3} of the four blocks.  The plain pass (FMT_SAVP) walks
-    // the A tiles without a coupled row and knows no coupling; the conductor pass does the four tiles of a
-    // conductor cell tile back to back, column by column along z, so every coupling operand is an L1/L2 hit.
-    // Both passes follow explicit walk lists (Sweep::walk).
-    int64_t sav_T;
 };
 
 // where a kernel finds the partial sums it has to finish: value i of slot s is
@@ -92,27 +86,22 @@ struct Sweep {
     // everything else there is identically zero in every vector and stays so
     const int32_t *ulist;
     int ulist_n;
-    // walk lists (structured form with the conductor cell tiles apart): workgroup b visits the entries
-    // walk[walk_off[b] .. walk_off[b+1]) -- a run of one xy position ("column") along z, so that entries one
-    // plane (walk_tpp tiles) apart keep the z-march registers.  walk_quad: every entry is a CELL tile ct and
-    // stands for the tiles d * c_T + ct, d = 0..3 (d = 3 only when that U tile holds an unknown).
-    const int32_t *walk;
-    const int32_t *walk_off;
-    int walk_quad;
-    int walk_tpp;
-    int64_t c_T;
 };
 
 // blockIdx -> tile map of a sweep (host and device: ec3d_get_visit_order enumerates with the same function)
+// MODE: -1 = decide from the sweep's fields (host enumeration, vector kernels); 1 = the z-marching map is known to
+// apply (kernels instantiated with ZM = true are only ever launched on such sweeps); 0 = it is known not to.
+// Knowing it at compile time keeps the other maps' parameters out of the registers of the SpMV kernels.
+template <int MODE = -1>
 __host__ __device__ inline int64_t ec3d_tile_of(const Sweep &sw, int b, int64_t i)
 {
-    if (sw.bnd_last >= 0) {
+    if (MODE != 1 && sw.bnd_last >= 0) {
         // boundary launch of a z-slab: the first and the last owned plane, plain tile order
         const int64_t t = i * (int64_t)sw.nblk + b;
         if (t >= 2 * (int64_t)sw.zm_tpp) return sw.ntiles;
         return (t < sw.zm_tpp ? 0 : (int64_t)sw.bnd_last * sw.zm_tpp) + t % sw.zm_tpp;
     }
-    if (sw.zm_tpp > 0) {
+    if (MODE == 1 || (MODE == -1 && sw.zm_tpp > 0)) {
         // XCD label c owns zm_tpp/8 adjacent columns, so the +-sdx lines a column needs were fetched
         // by a neighbour on the same XCD one step earlier (L2 hit); plane k = pl0 + seg*pps + i
         const int cpx = (sw.zm_tpp + 7) >> 3, c = b & 7, s = b >> 3;
@@ -127,7 +116,6 @@ __host__ __device__ inline int64_t ec3d_tile_of(const Sweep &sw, int b, int64_t 
     }
     return i * (int64_t)sw.nblk + b;
 }
-
 struct SolverState {
     double rr0[2]; // R·R0 entering iteration it is rr0[it & 1]
     double alpha, omega;
@@ -189,11 +177,7 @@ struct DevMatrix {
     int sav = 0, sav_a0 = 0, sav_u0 = 0, sav_zero = 0;
     int32_t *ulist = nullptr; // tiles of the U block that hold at least one unknown
     int ulist_n = 0;
-    // conductor cell tiles (see MatView::sav_T): device arrays + host copies for the visit-order export
-    int64_t sav_T = 0;
-    int n_cond_tiles = 0;              // conductor cell tiles
-    std::vector<int32_t> ulist_host;
-    std::vector<uint8_t> tile_flag_host, ctile_host; // per tile / per cell tile (1: conductor cell tile)
+    std::vector<int32_t> ulist_host; // host copy for the visit-order export
     int64_t ntiles_front = 0; // tiles swept unconditionally
     int64_t sav_nC = 0, sav_step[3] = {0, 0, 0};
     int64_t bytes = 0;
@@ -209,13 +193,10 @@ struct ec3d_ctx {
     int64_t ghost = 0;     // zero halo (doubles) on both sides of every vector
     double *vec_base = nullptr;
     double *vec[8] = {nullptr};
-    Sweep sweep{};   // vector kernels (K2, K4, K5)
+    Sweep sweep{};   // vector kernels: K4's grid (and the geometry every other sweep is derived from)
+    Sweep sweep_k2{}, sweep_k5{}; // K2 (2 reads + 1 write) and K5 (3 + 1) like other workgroup counts than K4 (5 + 2)
     Sweep sweep_s{}; // SpMV kernels (K1, K3, residual, spmv)
     Sweep sweep_int{}, sweep_bnd{}; // z-slab: interior / boundary-plane launches of K1 and K3
-    Sweep sweep_c{};                // structured form: the conductor pass of the SpMV kernels (nblk 0: none)
-    // walk lists of the plain pass (sweep_s) and the conductor pass (sweep_c): device arrays + host copies
-    int32_t *walk_dev[2] = {nullptr, nullptr}, *walk_off_dev[2] = {nullptr, nullptr};
-    std::vector<int32_t> walk_host[2], walk_off_host[2];
     bool can_overlap = false;
     // K2/K5 as boundary + interior launches (ec3d_dist_set_boundary_rows): tile lists on the device
     Sweep sweep_vb{}, sweep_vi{};
@@ -319,25 +300,27 @@ int ec3d_vec_d2h(ec3d_ctx *c, double *host, const double *dev);
 // ec3d_context.hip
 int ec3d_need_matrix(ec3d_ctx *c, const char *who); // 0, or 3 + error text when the handle has no matrix
 // ec3d_solve.hip: where a consumer kernel finds its sums, and the launches of one iteration
-RedSrc ec3d_src_of(const ec3d_ctx *c, bool produced_by_spmv);
-RedSrc ec3d_part_of(const ec3d_ctx *c, bool produced_by_spmv, bool split = false);
+// who produced the partial sums a consumer needs: an SpMV-type stage (slots BB, RR_INIT, D1, D2, D3), K2 (SS)
+// or K4 (RR, RR0N)
+enum { EC3D_BY_K4 = 0, EC3D_BY_SPMV = 1, EC3D_BY_K2 = 2 };
+RedSrc ec3d_src_of(const ec3d_ctx *c, int producer);
+RedSrc ec3d_part_of(const ec3d_ctx *c, int producer, bool split = false);
 void ec3d_launch_stage(ec3d_ctx *c, const MatView &A, int it, int k); // k = 1..5, 0 = all five
 void ec3d_launch_iteration(ec3d_ctx *c, const MatView &A, int it);
 int ec3d_launch_begin(ec3d_ctx *c, const MatView &A, double tol);
 int ec3d_single_rank_only(ec3d_ctx *c, const char *who);
 
 // ec3d_kernels.hip — launchers (all asynchronous on `s`)
-// SpMV-type launchers: `cw` (may be null / nblk 0) is the conductor pass that follows the plain pass `sw`
-void ec3d_launch_spmv(const MatView &A, const Sweep &sw, const Sweep *cw, const double *x, double *y, hipStream_t s);
-void ec3d_launch_residual(const MatView &A, const Sweep &sw, const Sweep *cw, const double *x, const double *b, double *r,
+void ec3d_launch_spmv(const MatView &A, const Sweep &sw, const double *x, double *y, hipStream_t s);
+void ec3d_launch_residual(const MatView &A, const Sweep &sw, const double *x, const double *b, double *r,
                           double *r0, double *p, double *part, hipStream_t s);
 void ec3d_launch_finalize(const RedSrc &src, double *lsum, unsigned mask, hipStream_t s);
 void ec3d_launch_setup(SolverState *st, const RedSrc &src, double tol, hipStream_t s);
-void ec3d_launch_k1(const MatView &A, const Sweep &sw, const Sweep *cw, const SolverState *st, int it, const double *p,
+void ec3d_launch_k1(const MatView &A, const Sweep &sw, const SolverState *st, int it, const double *p,
                     const double *r0, double *ap, double *part, hipStream_t s);
 void ec3d_launch_k2(const Sweep &sw, const RedSrc &src, SolverState *st, int it, const double *r, const double *ap,
                     double *sv, double *part, hipStream_t s);
-void ec3d_launch_k3(const MatView &A, const Sweep &sw, const Sweep *cw, SolverState *st, int it, const double *sv, double *as,
+void ec3d_launch_k3(const MatView &A, const Sweep &sw, SolverState *st, int it, const double *sv, double *as,
                     double *part, hipStream_t s);
 void ec3d_launch_k4(const Sweep &sw, const RedSrc &src_ss, const RedSrc &src, SolverState *st, int it,
                     const double *p, const double *sv, const double *as, const double *r0, double *x, double *r,
@@ -363,11 +346,3 @@ int ec3d_build_dictionary_host(HostMatrix &M);
 void ec3d_free_rhs(ec3d_ctx *c);
 int ec3d_setup_rhs(ec3d_ctx *c, int64_t nCells, const int8_t *geoPHYS, const int32_t *geoPHYS_C,
                    const double *valPHYS, int32_t nsub_glob, double dt);
-
-// conductor pass to chain behind a launch with sweep `ss` (null: none)
-static inline const Sweep *ec3d_cond_of(const ec3d_ctx *c, const Sweep &ss)
-{
-    return (&ss == &c->sweep_s && c->sweep_c.nblk > 0) ? &c->sweep_c : nullptr;
-}
-// workgroups whose partial sums an SpMV-type stage leaves behind (plain pass + conductor pass)
-static inline int ec3d_spmv_parts(const ec3d_ctx *c) { return c->sweep_s.nblk + c->sweep_c.nblk; }

@@ -159,10 +159,7 @@ __device__ __forceinline__ double tail_add(const MatView &A, const V &x, int t, 
 //   FMT_DICT7    7 bands whose coefficient 7-tuples take <= 256 distinct values ("stencil classes"):
 //                one class byte per row + a table staged in LDS (17 B/row: 1 + x + y).  The values
 //                multiplied are the same doubles, so results are bit-identical to FMT_DIA7.
-//   FMT_SAV      structured A-V form, every row kind (couplings inline)
-//   FMT_SAVP     the same table, PLAIN rows only: the pass over the A blocks that leaves the conductor cell
-//                tiles (MatView::cskip) to the conductor pass -- a 7-point stencil and nothing else
-enum { FMT_GENERIC = 0, FMT_DIA7 = 7, FMT_DICT7 = 107, FMT_SAV = 207, FMT_SAVP = 307 };
+enum { FMT_GENERIC = 0, FMT_DIA7 = 7, FMT_DICT7 = 107, FMT_SAV = 207 };
 #define EC3D_SAV_STRIDE 16
 
 template <int FMT>
@@ -171,10 +168,6 @@ __device__ __forceinline__ void stage_table(const MatView &A, double *tbl)
     if (FMT == FMT_DICT7 || FMT == FMT_SAV) {
         const int cnt = A.ncls * (FMT == FMT_SAV ? EC3D_SAV_STRIDE : 7);
         for (int i = threadIdx.x; i < cnt; i += EC3D_THREADS) tbl[i] = A.table[i];
-        __syncthreads();
-    }
-    if (FMT == FMT_SAVP) { // the 7 band coefficients of every class, packed
-        for (int i = threadIdx.x; i < A.ncls * 7; i += EC3D_THREADS) tbl[i] = A.table[(i / 7) * EC3D_SAV_STRIDE + i % 7];
         __syncthreads();
     }
 }
@@ -245,7 +238,7 @@ __device__ __forceinline__ void spmv_pair(const MatView &A, const double *tbl, c
                                           bool first, ZRegs &z, double &s0, double &s1, d2 &ctr)
 {
     uint8_t tflag = 0; // per tile: any tail row (bands + tail) / any coupled row (structured form)
-    if (FMT == FMT_DIA7 || FMT == FMT_DICT7 || FMT == FMT_SAV || FMT == FMT_SAVP) {
+    if (FMT == FMT_DIA7 || FMT == FMT_DICT7 || FMT == FMT_SAV) {
         d2 xv[7];
         // the +-1 neighbours (bands 2 and 4 of the 7-point operator) are the centre pairs of the
         // adjacent lanes: take them by lane shuffle instead of two unaligned 16-byte loads; only the
@@ -255,7 +248,7 @@ __device__ __forceinline__ void spmv_pair(const MatView &A, const double *tbl, c
         // every load of the step is issued before the first use: class bytes, the two edge-lane
         // neighbours, then the band operands (one round trip per step instead of three)
         unsigned short cc = 0;
-        if (FMT == FMT_DICT7 || FMT == FMT_SAV || FMT == FMT_SAVP) cc = *reinterpret_cast<const unsigned short *>(A.cls + r);
+        if (FMT == FMT_DICT7 || FMT == FMT_SAV) cc = *reinterpret_cast<const unsigned short *>(A.cls + r);
         if (FMT == FMT_SAV || A.has_tail) tflag = A.tile_flag[tile];
         const int lane = threadIdx.x & 63;
         double left = 0.0, right = 0.0;
@@ -293,7 +286,7 @@ __device__ __forceinline__ void spmv_pair(const MatView &A, const double *tbl, c
                 s0 = s0 + c[b].x * xv[b].x;
                 s1 = s1 + c[b].y * xv[b].y;
             }
-        } else if (FMT == FMT_DICT7 || FMT == FMT_SAVP) {
+        } else if (FMT == FMT_DICT7) {
             const double *t0 = tbl + (cc & 0xFF) * 7, *t1 = tbl + (cc >> 8) * 7;
             s0 = t0[0] * xv[0].x;
             s1 = t1[0] * xv[0].y;
@@ -352,63 +345,33 @@ __device__ __forceinline__ void spmv_pair(const MatView &A, const double *tbl, c
 }
 
 // the SpMV grids are sized for 6 workgroups per CU (choose_sweep): keep the register count within that
-// (the kernels with the coupling code inline run as the small conductor pass, or on grids too small to care:
-// they get the registers they need -- 4 per CU -- instead of spilling)
-#define EC3D_SPMV_OCC __attribute__((amdgpu_waves_per_eu(FMT == FMT_SAV ? 4 : 6)))
-// TF(tile): does the U tile hold an unknown (conductor pass).  Walk lists are read one entry ahead, so
-// following them costs no memory round trip.
-#define EC3D_SWEEP_BEGIN_(TF)                                                                  \
+// (the structured form without z-marching only runs on grids too small for plane-aligned tiles: it takes the
+// registers it needs -- 5 per CU -- instead of spilling)
+#define EC3D_SPMV_OCC __attribute__((amdgpu_waves_per_eu((FMT == FMT_SAV && !ZM) ? 5 : 6)))
+#define EC3D_SWEEP_BEGIN_(MODE)                                                                \
     bool need_first_ = true;                                                                   \
     int64_t lst_ = -1; /* >= 0: walking the list of occupied U tiles */                        \
-    int wpos_ = 0, wend_ = 0, wnext_ = 0, cd_ = 0; /* walk list: position, end, entry read ahead, block */ \
-    int64_t prev_ = -(int64_t(1) << 40);                                                       \
-    if (sw.walk) {                                                                             \
-        wpos_ = sw.walk_off[blockIdx.x];                                                       \
-        wend_ = sw.walk_off[blockIdx.x + 1];                                                   \
-        if (wpos_ < wend_) wnext_ = sw.walk[wpos_];                                            \
-    }                                                                                          \
     for (int64_t it_ = 0;; ++it_) {                                                            \
         int64_t tile = 0;                                                                      \
-        if (sw.walk) {                                                                         \
-            if (wpos_ >= wend_) break;                                                         \
-            if (sw.walk_quad) {                                                                \
-                tile = (int64_t)cd_ * sw.c_T + wnext_;                                         \
-                const bool skip_u_ = cd_ == 3 && TF(tile) == 0;                                \
-                if (++cd_ == 4) {                                                              \
-                    cd_ = 0;                                                                   \
-                    if (++wpos_ < wend_) wnext_ = sw.walk[wpos_];                              \
-                }                                                                              \
-                if (skip_u_) continue;                                                         \
-                need_first_ = true;                                                            \
-            } else {                                                                           \
-                tile = wnext_;                                                                 \
-                if (tile != prev_ + sw.walk_tpp) need_first_ = true; /* not the plane above: z-march anew */ \
-                prev_ = tile;                                                                  \
-                if (++wpos_ < wend_) wnext_ = sw.walk[wpos_];                                  \
+        if (lst_ < 0) {                                                                        \
+            tile = ec3d_tile_of<MODE>(sw, blockIdx.x, it_);                                    \
+            if (tile >= sw.ntiles) {                                                           \
+                if (sw.ulist_n == 0) break;                                                    \
+                lst_ = blockIdx.x;                                                             \
             }                                                                                  \
-        } else {                                                                               \
-            if (lst_ < 0) {                                                                    \
-                tile = ec3d_tile_of(sw, blockIdx.x, it_);                                      \
-                if (tile >= sw.ntiles) {                                                       \
-                    if (sw.ulist_n == 0) break;                                                \
-                    lst_ = blockIdx.x;                                                         \
-                }                                                                              \
-            }                                                                                  \
-            if (lst_ >= 0) {                                                                   \
-                if (lst_ >= sw.ulist_n) break;                                                 \
-                tile = sw.ulist[lst_];                                                         \
-                lst_ += sw.nblk;                                                               \
-                need_first_ = true;                                                            \
-            }                                                                                  \
+        }                                                                                      \
+        if (lst_ >= 0) {                                                                       \
+            if (lst_ >= sw.ulist_n) break;                                                     \
+            tile = sw.ulist[lst_];                                                             \
+            lst_ += sw.nblk;                                                                   \
+            need_first_ = true;                                                                \
         }                                                                                      \
         const bool first_ = need_first_;                                                       \
         need_first_ = false;                                                                   \
         (void)first_;                                                                          \
         const int64_t r = tile * EC3D_TILE + 2 * (int64_t)threadIdx.x;
-#define EC3D_NO_TF(t) 1
-#define EC3D_A_TF(t) A.tile_flag[t]
-#define EC3D_SWEEP_BEGIN EC3D_SWEEP_BEGIN_(EC3D_NO_TF)     /* vector kernels */
-#define EC3D_SWEEP_BEGIN_A EC3D_SWEEP_BEGIN_(EC3D_A_TF)    /* SpMV-type kernels (matrix A in scope) */
+#define EC3D_SWEEP_BEGIN EC3D_SWEEP_BEGIN_(-1)             /* vector kernels */
+#define EC3D_SWEEP_BEGIN_A EC3D_SWEEP_BEGIN_((ZM ? 1 : 0)) /* SpMV-type kernels: ZM is a template parameter */
 #define EC3D_SWEEP_END }
 #define EC3D_TBL_DECL                                                                          \
     extern __shared__ double tbl[] /* the class table, sized at launch (EC3D_TBL_BYTES) */
@@ -703,7 +666,7 @@ __global__ __launch_bounds__(EC3D_THREADS) void k5_p_update(Sweep sw, RedSrc src
 // launchers
 static inline int fmt_of(const MatView &A)
 {
-    if (A.sav) return A.sav_T > 0 ? FMT_SAVP : FMT_SAV; // conductor cell tiles apart, or couplings inline
+    if (A.sav) return FMT_SAV;
     if (A.nb == 7 && A.ncls > 0) return FMT_DICT7;
     if (A.nb == 7) return FMT_DIA7;
     return FMT_GENERIC;
@@ -713,11 +676,10 @@ static inline bool nt_of(const Sweep &sw) { return sw.nt != 0; }
 // dynamic LDS: the class table only (a full 256-class table of the structured form would be 32 KiB and
 // cap the CU at 4 workgroups; real problems have ~100 classes)
 #define EC3D_TBL_BYTES(F)                                                                      \
-    (((F) == FMT_DICT7 || (F) == FMT_SAVP) ? (size_t)A.ncls * 7 * 8                            \
-                                           : ((F) == FMT_SAV ? (size_t)A.ncls * EC3D_SAV_STRIDE * 8 : 0))
+    ((F) == FMT_DICT7 ? (size_t)A.ncls * 7 * 8 : ((F) == FMT_SAV ? (size_t)A.ncls * EC3D_SAV_STRIDE * 8 : 0))
 #define EC3D_LAUNCH_FMT(F, KERNEL, ...)                                                        \
     do {                                                                                       \
-        const bool zm_ = (sw.zm_tpp > 0 || (sw.walk && !sw.walk_quad)) && sw.bnd_last < 0 && F != FMT_GENERIC; \
+        const bool zm_ = sw.zm_tpp > 0 && sw.bnd_last < 0 && F != FMT_GENERIC;                 \
         if (nt_of(sw) && zm_)                                                                  \
             KERNEL<F, true, (F != FMT_GENERIC)><<<sw.nblk, EC3D_THREADS, EC3D_TBL_BYTES(F), s>>>(__VA_ARGS__); \
         else if (nt_of(sw))                                                                    \
@@ -731,21 +693,9 @@ static inline bool nt_of(const Sweep &sw) { return sw.nt != 0; }
     do {                                                                                       \
         switch (fmt_of(A)) {                                                                   \
         case FMT_SAV: EC3D_LAUNCH_FMT(FMT_SAV, KERNEL, __VA_ARGS__); break;                    \
-        case FMT_SAVP: EC3D_LAUNCH_FMT(FMT_SAVP, KERNEL, __VA_ARGS__); break;                  \
         case FMT_DICT7: EC3D_LAUNCH_FMT(FMT_DICT7, KERNEL, __VA_ARGS__); break;                \
         case FMT_DIA7: EC3D_LAUNCH_FMT(FMT_DIA7, KERNEL, __VA_ARGS__); break;                  \
         default: EC3D_LAUNCH_FMT(FMT_GENERIC, KERNEL, __VA_ARGS__);                            \
-        }                                                                                      \
-    } while (0)
-// the conductor pass behind a plain pass: couplings inline, no z-march, its own (small) grid
-#define EC3D_LAUNCH_COND(KERNEL, ...)                                                          \
-    do {                                                                                       \
-        if (cw && cw->nblk > 0) {                                                              \
-            const Sweep &sw = *cw;                                                             \
-            if (nt_of(sw))                                                                     \
-                KERNEL<FMT_SAV, true, false><<<sw.nblk, EC3D_THREADS, EC3D_TBL_BYTES(FMT_SAV), s>>>(__VA_ARGS__); \
-            else                                                                               \
-                KERNEL<FMT_SAV, false, false><<<sw.nblk, EC3D_THREADS, EC3D_TBL_BYTES(FMT_SAV), s>>>(__VA_ARGS__);\
         }                                                                                      \
     } while (0)
 #define EC3D_LAUNCH_VEC(KERNEL, ...)                                                           \
@@ -756,17 +706,15 @@ static inline bool nt_of(const Sweep &sw) { return sw.nt != 0; }
             KERNEL<false><<<sw.nblk, EC3D_THREADS, 0, s>>>(__VA_ARGS__);                       \
     } while (0)
 
-void ec3d_launch_spmv(const MatView &A, const Sweep &sw, const Sweep *cw, const double *x, double *y, hipStream_t s)
+void ec3d_launch_spmv(const MatView &A, const Sweep &sw, const double *x, double *y, hipStream_t s)
 {
     EC3D_DISPATCH(A, k_spmv, A, sw, x, y);
-    EC3D_LAUNCH_COND(k_spmv, A, sw, x, y);
 }
 
-void ec3d_launch_residual(const MatView &A, const Sweep &sw, const Sweep *cw, const double *x, const double *b, double *r,
+void ec3d_launch_residual(const MatView &A, const Sweep &sw, const double *x, const double *b, double *r,
                           double *r0, double *p, double *part, hipStream_t s)
 {
     EC3D_DISPATCH(A, k_residual, A, sw, x, b, r, r0, p, part);
-    EC3D_LAUNCH_COND(k_residual, A, sw, x, b, r, r0, p, part);
 }
 
 void ec3d_launch_finalize(const RedSrc &src, double *lsum, unsigned mask, hipStream_t s)
@@ -779,11 +727,10 @@ void ec3d_launch_setup(SolverState *st, const RedSrc &src, double tol, hipStream
     k_setup<<<1, EC3D_THREADS, 0, s>>>(st, src, tol);
 }
 
-void ec3d_launch_k1(const MatView &A, const Sweep &sw, const Sweep *cw, const SolverState *st, int it, const double *p,
+void ec3d_launch_k1(const MatView &A, const Sweep &sw, const SolverState *st, int it, const double *p,
                     const double *r0, double *ap, double *part, hipStream_t s)
 {
     EC3D_DISPATCH(A, k1_spmv_dot, A, sw, st, it, p, r0, ap, part);
-    EC3D_LAUNCH_COND(k1_spmv_dot, A, sw, st, it, p, r0, ap, part);
 }
 
 void ec3d_launch_k2(const Sweep &sw, const RedSrc &src, SolverState *st, int it, const double *r, const double *ap,
@@ -792,11 +739,10 @@ void ec3d_launch_k2(const Sweep &sw, const RedSrc &src, SolverState *st, int it,
     EC3D_LAUNCH_VEC(k2_s_update, sw, src, st, it, r, ap, sv, part);
 }
 
-void ec3d_launch_k3(const MatView &A, const Sweep &sw, const Sweep *cw, SolverState *st, int it, const double *sv, double *as,
+void ec3d_launch_k3(const MatView &A, const Sweep &sw, SolverState *st, int it, const double *sv, double *as,
                     double *part, hipStream_t s)
 {
     EC3D_DISPATCH(A, k3_spmv_dots, A, sw, st, it, sv, as, part);
-    EC3D_LAUNCH_COND(k3_spmv_dots, A, sw, st, it, sv, as, part);
 }
 
 void ec3d_launch_k4(const Sweep &sw, const RedSrc &src_ss, const RedSrc &src, SolverState *st, int it,

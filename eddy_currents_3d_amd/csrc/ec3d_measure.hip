@@ -91,7 +91,7 @@ extern "C" int ec3d_time_kernel(ec3d_handle c, int kernel, int32_t reps, double 
     ec3d_launch_iteration(c, A, 1); // populate every partial slot and the scalars
     auto one = [&]() {
         if (kernel == EC3D_K_SPMV)
-            ec3d_launch_spmv(A, c->sweep_s, ec3d_cond_of(c, c->sweep_s), v[EC3D_VEC_P], v[EC3D_VEC_AP], s);
+            ec3d_launch_spmv(A, c->sweep_s, v[EC3D_VEC_P], v[EC3D_VEC_AP], s);
         else
             ec3d_launch_stage(c, A, 2, kernel);
     };
@@ -118,11 +118,11 @@ extern "C" int ec3d_true_residual(ec3d_handle c, double *rel, double *bnorm)
     if (rc) return rc;
     if ((rc = ec3d_single_rank_only(c, "ec3d_true_residual"))) return rc;
     double **v = c->vec;
-    ec3d_launch_residual(c->A.view(), c->sweep_s, ec3d_cond_of(c, c->sweep_s), v[EC3D_VEC_X], v[EC3D_VEC_B], v[EC3D_VEC_R], v[EC3D_VEC_R0],
+    ec3d_launch_residual(c->A.view(), c->sweep_s, v[EC3D_VEC_X], v[EC3D_VEC_B], v[EC3D_VEC_R], v[EC3D_VEC_R0],
                          v[EC3D_VEC_P], c->partials, c->stream);
     EC3D_HIP(hipGetLastError());
     EC3D_HIP(hipStreamSynchronize(c->stream));
-    const int nb = ec3d_spmv_parts(c);
+    const int nb = c->sweep_s.nblk;
     std::vector<double> part((size_t)nb);
     double s[2] = {0.0, 0.0};
     const int slot[2] = {P_BB, P_RR_INIT};

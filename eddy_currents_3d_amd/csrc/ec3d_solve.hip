@@ -19,18 +19,21 @@
 // Where a consumer finds the sums it needs.  Single GPU: the producer's per-workgroup partials; the
 // producers of slots BB, RR_INIT, D1, D2, D3 are SpMV-type kernels (sweep_s), those of SS, RR, RR0N
 // vector kernels (sweep) -- every consumer reads slots of one producer class only.
-RedSrc ec3d_src_of(const ec3d_ctx *c, bool produced_by_spmv)
+static int parts_of(const ec3d_ctx *c, int producer, bool split)
+{
+    if (producer == EC3D_BY_K2) return c->sweep_k2.nblk;
+    if (producer == EC3D_BY_K4) return c->sweep.nblk;
+    return split ? c->sweep_int.nblk + c->sweep_bnd.nblk : c->sweep_s.nblk;
+}
+RedSrc ec3d_src_of(const ec3d_ctx *c, int producer)
 {
     if (c->dist && c->lsum_ptrs) return RedSrc{nullptr, c->nranks, 0, 0, c->lsum_ptrs};
     if (c->dist) return RedSrc{c->gsum, c->nranks, P_NSLOT, 1, nullptr};
-    return RedSrc{c->partials, produced_by_spmv ? ec3d_spmv_parts(c) : c->sweep.nblk, 1, c->sweep.pstride, nullptr};
+    return RedSrc{c->partials, parts_of(c, producer, false), 1, c->sweep.pstride, nullptr};
 }
-RedSrc ec3d_part_of(const ec3d_ctx *c, bool produced_by_spmv, bool split)
+RedSrc ec3d_part_of(const ec3d_ctx *c, int producer, bool split)
 {
-    const int cnt = !produced_by_spmv ? c->sweep.nblk
-                    : split           ? c->sweep_int.nblk + c->sweep_bnd.nblk
-                                      : ec3d_spmv_parts(c);
-    return RedSrc{c->partials, cnt, 1, c->sweep.pstride, nullptr};
+    return RedSrc{c->partials, parts_of(c, producer, split), 1, c->sweep.pstride, nullptr};
 }
 
 // the five launches of one iteration; `k` selects one of them (1..5) or all (0)
@@ -40,17 +43,17 @@ void ec3d_launch_stage(ec3d_ctx *c, const MatView &A, int it, int k)
     const Sweep &sw = c->sweep, &ss = c->sweep_s;
     hipStream_t s = c->stream;
     if (k == 0 || k == 1)
-        ec3d_launch_k1(A, ss, ec3d_cond_of(c, ss), c->state, it, v[EC3D_VEC_P], v[EC3D_VEC_R0], v[EC3D_VEC_AP], c->partials, s);
+        ec3d_launch_k1(A, ss, c->state, it, v[EC3D_VEC_P], v[EC3D_VEC_R0], v[EC3D_VEC_AP], c->partials, s);
     if (k == 0 || k == 2)
-        ec3d_launch_k2(sw, ec3d_src_of(c, true), c->state, it, v[EC3D_VEC_R], v[EC3D_VEC_AP], v[EC3D_VEC_S], c->partials, s);
+        ec3d_launch_k2(c->sweep_k2, ec3d_src_of(c, EC3D_BY_SPMV), c->state, it, v[EC3D_VEC_R], v[EC3D_VEC_AP], v[EC3D_VEC_S], c->partials, s);
     if (k == 0 || k == 3)
-        ec3d_launch_k3(A, ss, ec3d_cond_of(c, ss), c->state, it, v[EC3D_VEC_S], v[EC3D_VEC_AS], c->partials, s);
+        ec3d_launch_k3(A, ss, c->state, it, v[EC3D_VEC_S], v[EC3D_VEC_AS], c->partials, s);
     if (k == 0 || k == 4)
-        ec3d_launch_k4(sw, ec3d_src_of(c, false), ec3d_src_of(c, true), c->state, it, v[EC3D_VEC_P], v[EC3D_VEC_S],
+        ec3d_launch_k4(sw, ec3d_src_of(c, EC3D_BY_K2), ec3d_src_of(c, EC3D_BY_SPMV), c->state, it, v[EC3D_VEC_P], v[EC3D_VEC_S],
                        v[EC3D_VEC_AS], v[EC3D_VEC_R0], v[EC3D_VEC_X], v[EC3D_VEC_R], c->partials, c->hist,
                        c->hist_cap, s);
     if (k == 0 || k == 5)
-        ec3d_launch_k5(sw, ec3d_src_of(c, false), c->state, it, v[EC3D_VEC_R], v[EC3D_VEC_AP], v[EC3D_VEC_P],
+        ec3d_launch_k5(c->sweep_k5, ec3d_src_of(c, EC3D_BY_K4), c->state, it, v[EC3D_VEC_R], v[EC3D_VEC_AP], v[EC3D_VEC_P],
                        v[EC3D_VEC_R0], c->hist, c->hist_cap, s);
 }
 
@@ -59,9 +62,9 @@ void ec3d_launch_iteration(ec3d_ctx *c, const MatView &A, int it) { ec3d_launch_
 int ec3d_launch_begin(ec3d_ctx *c, const MatView &A, double tol)
 {
     double **v = c->vec;
-    ec3d_launch_residual(A, c->sweep_s, ec3d_cond_of(c, c->sweep_s), v[EC3D_VEC_X], v[EC3D_VEC_B], v[EC3D_VEC_R], v[EC3D_VEC_R0], v[EC3D_VEC_P],
+    ec3d_launch_residual(A, c->sweep_s, v[EC3D_VEC_X], v[EC3D_VEC_B], v[EC3D_VEC_R], v[EC3D_VEC_R0], v[EC3D_VEC_P],
                          c->partials, c->stream);
-    ec3d_launch_setup(c->state, ec3d_src_of(c, true), tol, c->stream);
+    ec3d_launch_setup(c->state, ec3d_src_of(c, EC3D_BY_SPMV), tol, c->stream);
     EC3D_HIP(hipGetLastError());
     return 0;
 }
@@ -138,7 +141,7 @@ static int solve_core(ec3d_ctx *c, double tol, int32_t itmax, int32_t *iter, dou
                 EC3D_HIP(hipMemcpy(part.data(), c->partials + (size_t)P_RR_INIT * c->sweep.pstride,
                                    part.size() * sizeof(double), hipMemcpyDeviceToHost));
                 s = 0.0;
-                for (int q = 0; q < ec3d_spmv_parts(c); ++q) s += part[(size_t)q];
+                for (int q = 0; q < c->sweep_s.nblk; ++q) s += part[(size_t)q];
             }
             printf(" %.17g\n", std::sqrt(s));
             fflush(stdout);

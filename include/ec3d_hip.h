@@ -274,12 +274,11 @@ typedef struct {
     int32_t ulist_n;   /* structured A-V form: occupied tiles of the U block, visited afterwards,
                           workgroup b taking entries b, b+nblk, ... of ec3d_get_ulist()             */
 } ec3d_geom;
-/* which = 0: vector kernels (dots S.S, R.R, R.R0); 1: SpMV kernels (B.B, initial R.R, AP.R0, AS.S, AS.AS) */
+/* which = 0: K4 (dots R.R, R.R0); 1: SpMV kernels (B.B, initial R.R, AP.R0, AS.S, AS.AS); 2: K2 (dot S.S) */
 int ec3d_get_reduction_geometry(ec3d_handle h, int which, ec3d_geom *g);
 int ec3d_get_ulist(ec3d_handle h, int32_t *tiles); /* ulist_n entries */
 /* The tiles (512 rows each) every workgroup of a launch visits, in order: workgroup w visits
- * tiles[offsets[w] .. offsets[w+1]).  which as above; for which = 1 on the structured A-V form the list covers
- * the plain pass followed by the conductor pass (two launches whose partial sums are added as one sequence).
+ * tiles[offsets[w] .. offsets[w+1]).  which as above.
  * Each thread t of a workgroup owns rows tile*512 + 2t, 2t+1 and adds its products in this order -- the summation
  * order the oracle's twin reproduces.  Two-pass: offsets == NULL -> *nwg and *total only. */
 int ec3d_get_visit_order(ec3d_handle h, int which, int32_t *nwg, int64_t *total, int32_t *offsets, int32_t *tiles);

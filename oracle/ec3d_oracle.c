@@ -193,7 +193,22 @@ double oracle_dot_gpuorder(const oracle_gpu_geom *g, const double *a, const doub
     return r;
 }
 
+int oracle_bicgstab_wr_gpuorder3(const oracle_gpu_geom *gv, const oracle_gpu_geom *gs, const oracle_gpu_geom *gk2,
+                                 const double *valA, const int32_t *irow, const int32_t *jcol, int32_t n,
+                                 const double *b, double *x, double tolerance, int32_t itmax, int32_t *iter,
+                                 double *hist_s, double *hist_r, int32_t hist_cap);
 int oracle_bicgstab_wr_gpuorder(const oracle_gpu_geom *gv, const oracle_gpu_geom *gs, const double *valA,
+                                const int32_t *irow, const int32_t *jcol, int32_t n, const double *b,
+                                double *x, double tolerance, int32_t itmax, int32_t *iter, double *hist_s,
+                                double *hist_r, int32_t hist_cap)
+{
+    return oracle_bicgstab_wr_gpuorder3(gv, gs, gv, valA, irow, jcol, n, b, x, tolerance, itmax, iter, hist_s, hist_r,
+                                        hist_cap);
+}
+
+/* gk2: the geometry of K2 (S.S), which may run on a grid of its own */
+int oracle_bicgstab_wr_gpuorder3(const oracle_gpu_geom *gv, const oracle_gpu_geom *gs, const oracle_gpu_geom *gk2,
+                                 const double *valA,
                                 const int32_t *irow, const int32_t *jcol, int32_t n, const double *b,
                                 double *x, double tolerance, int32_t itmax, int32_t *iter, double *hist_s,
                                 double *hist_r, int32_t hist_cap)
@@ -218,7 +233,7 @@ int oracle_bicgstab_wr_gpuorder(const oracle_gpu_geom *gv, const oracle_gpu_geom
                            : oracle_dot_gpuorder(gv, R, R0, n);    /* K4 of the previous iteration */
         alpha = rr0 / oracle_dot_gpuorder(gs, AP, R0, n);         /* K1 */
         for (int32_t j = 0; j < n; ++j) S[j] = R[j] - alpha * AP[j];
-        nrm = sqrt(oracle_dot_gpuorder(gv, S, S, n));             /* K2 */
+        nrm = sqrt(oracle_dot_gpuorder(gk2, S, S, n));            /* K2 */
         if (hist_s && *iter <= hist_cap) hist_s[*iter - 1] = nrm;
         if (nrm / Bnorm < tolerance) {
             for (int32_t j = 0; j < n; ++j) x[j] = x[j] + alpha * P[j];

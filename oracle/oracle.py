@@ -71,6 +71,11 @@ def lib() -> C.CDLL:
                                                   C.POINTER(C.c_int32), C.c_void_p, C.c_void_p,
                                                   C.c_int32]
         L.oracle_bicgstab_wr_gpuorder.restype = C.c_int
+        L.oracle_bicgstab_wr_gpuorder3.argtypes = [C.POINTER(GpuGeom)] * 3 + [_f64p, _i32p, _i32p, C.c_int32,
+                                                                                _f64p, _f64p, C.c_double, C.c_int32,
+                                                                                C.POINTER(C.c_int32), C.c_void_p,
+                                                                                C.c_void_p, C.c_int32]
+        L.oracle_bicgstab_wr_gpuorder3.restype = C.c_int
         L.oracle_gen_sparse_matrix.argtypes = [C.c_int32, C.c_int32, C.c_int32, _i8p, _i32p, _f64p,
                                                C.c_int32, _f64p, _f64p, C.c_double, _i32p,
                                                C.c_void_p, C.c_void_p, C.POINTER(C.c_int64),
@@ -120,7 +125,7 @@ def geoms_of(solver):
     """(vector-kernel geometry, SpMV-kernel geometry) of an eddy_currents_3d_amd.EC3DSolver."""
     out = []
     ul = np.ascontiguousarray(solver.ulist(), np.int32)
-    for which in (0, 1):
+    for which in (0, 1, 2):   # K4's grid, the SpMV kernels', K2's
         g = solver.geometry(which)
         gg = GpuGeom(n_pad=g.n_pad, tile=g.tile, nblk=g.nblk, threads=g.threads, xcd_group=g.xcd_group,
                      zm_tpp=g.zm_tpp, zm_pps=g.zm_pps, ntiles_front=g.ntiles_front, ulist_n=g.ulist_n,
@@ -141,14 +146,15 @@ def geoms_of(solver):
 def bicgstab_wr_gpuorder(geom, valA, irow, jcol, b, x0, tol, itmax, hist_cap=0):
     """Same algorithm with the HIP kernels' summation order.  geom: (vector GpuGeom, SpMV GpuGeom)
     as returned by geoms_of(), or one GpuGeom used for both."""
-    gv, gs = geom if isinstance(geom, tuple) else (geom, geom)
+    gv, gs = (geom[0], geom[1]) if isinstance(geom, tuple) else (geom, geom)
+    gk2 = geom[2] if isinstance(geom, tuple) and len(geom) > 2 else gv
     n = len(irow) - 1
     x = np.array(x0, dtype=np.float64, copy=True)
     it = C.c_int32(0)
     hs, hr = _hist(hist_cap)
-    lib().oracle_bicgstab_wr_gpuorder(C.byref(gv), C.byref(gs), valA, irow, jcol, n,
-                                      np.ascontiguousarray(b, np.float64), x, tol, itmax,
-                                      C.byref(it), hs.ctypes.data, hr.ctypes.data, hist_cap)
+    lib().oracle_bicgstab_wr_gpuorder3(C.byref(gv), C.byref(gs), C.byref(gk2), valA, irow, jcol, n,
+                                       np.ascontiguousarray(b, np.float64), x, tol, itmax,
+                                       C.byref(it), hs.ctypes.data, hr.ctypes.data, hist_cap)
     return x, it.value, hs, hr
 
 
