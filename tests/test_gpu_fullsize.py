@@ -6,11 +6,15 @@
 
 The inputs are rebuilt here from the shipped voxels in tests/golden/g4_* with vxc.resample -- the same call
 oracle/make_goldens.py (case_g6) used when it ran the reference (src/EC3D.f90:241-455 through the capture
-interposer) for the first time steps: per-step iter, ||b||, ||x||, 200 probes of b and x at the solver call,
-and 200 probe points of every vector of the field_N.vtk files the reference wrote (src/utilites.f90:171-293).
+interposer) for the first time steps: per-step iter, ||b||, ||x||, 200 probes of b and x at the solver call, a
+4096-bucket count-sketch of every x (oracle.count_sketch: ||sketch(x) - sketch(y)|| estimates ||x - y||_2 to
+about 1 %, so the 2-norm distance of two 100-240 MB vectors can be stated from a 32 KB fixture), and the same for
+every vector of the field_N.vtk files the reference wrote (src/utilites.f90:171-293).
 
-Tolerances.  x and everything derived from it: 10*tol relative to the largest reference value -- both sides
-stop at a relative residual of tol = 5e-3 (src/solvers.f90:34, :43).  What is asserted strictly is what the
+Tolerances.  SURVEY section 8d: ||x_gpu - x_ref||_2 / ||x_ref||_2 <= 10*tol -- both sides stop at a relative
+residual of tol = 5e-3 (src/solvers.f90:34, :43), and fields derived from x inherit the bar.  Single entries
+may differ by more than that fraction of the largest entry (printed, not asserted: the bar is a 2-norm, and the
+systems are ill conditioned enough that two 5e-3 solutions differ visibly).  What is asserted strictly is what the
 algorithm promises: the TRUE residual ||b - A x|| / ||b|| of every GPU solution, computed on the device, is
 below tol.  Iteration counts are printed side by side; at these sizes unpreconditioned BiCGSTAB's path is not
 reproducible under re-association of the dot products (the reference's own
@@ -64,6 +68,7 @@ def test_first_steps_against_reference_held_numbers(case, tmp_path):
         pytest.skip("fixture not generated")
     import eddy_currents_3d_amd as E
     from eddy_currents_3d_amd import host
+    from oracle import oracle as O
     model, g = _model(case)
     probes, pp = g["probes"], g["point_probes"]
     tol = float(g["tol"])
@@ -77,6 +82,7 @@ def test_first_steps_against_reference_held_numbers(case, tmp_path):
     def on_solved(k, s, info):
         x = s.download("X")
         info["xnorm"], info["xprobe"] = float(np.linalg.norm(x)), x[probes]
+        info["xsketch"] = O.count_sketch(x)
         info["true_residual"] = s.true_residual()[0]          # on the device; before the post-update touches B
         seen.append(info)
 
@@ -86,20 +92,23 @@ def test_first_steps_against_reference_held_numbers(case, tmp_path):
         assert s.info.tail_rows == 0 and s.info.dict_classes > 0        # structured A-V form
     for k, info in enumerate(seen):
         it_ref = int(g["iters"][k])
-        print(f"{case} {tuple(g['dims'])} step {k}: iter {info['iter']} / reference {it_ref}; ||b|| {info['bnorm']:.9e} / "
-              f"{float(g['bnorm'][k]):.9e}; ||x|| {info['xnorm']:.6e} / {float(g['xnorm'][k]):.6e}; true residual "
+        rel2 = float(np.linalg.norm(info["xsketch"] - g["xsketch"][k]) / np.linalg.norm(g["xsketch"][k]))
+        print(f"{case} {tuple(int(v) for v in g['dims'])} step {k}: iter {info['iter']} / reference {it_ref}; ||b|| "
+              f"{info['bnorm']:.9e} / {float(g['bnorm'][k]):.9e}; ||x|| {info['xnorm']:.6e} / {float(g['xnorm'][k]):.6e}; "
+              f"||x - x_ref|| / ||x_ref|| = {rel2:.3e} (sketch; bar {10 * tol:g}); true residual "
               f"{info['true_residual']:.3e} (tol {tol:g}); probes of x: max diff "
               f"{np.abs(info['xprobe'] - g['xprobe'][k]).max() / np.abs(g['xprobe'][k]).max():.2e} of the largest")
+        assert rel2 <= 10 * tol
         assert info["true_residual"] < tol
         # step 0 has no history: b is the sources alone and matches to rounding; later steps carry the previous
         # solutions, each within the solver tolerance of the reference's
         assert info["bnorm"] == pytest.approx(float(g["bnorm"][k]), rel=1e-13 if k == 0 else 10 * tol)
         assert np.abs(info["bprobe"] - g["bprobe"][k]).max() <= (1e-13 if k == 0 else 10 * tol) * np.abs(g["bprobe"][k]).max()
         assert info["xnorm"] == pytest.approx(float(g["xnorm"][k]), rel=10 * tol)
-        assert np.abs(info["xprobe"] - g["xprobe"][k]).max() <= 10 * tol * np.abs(g["xprobe"][k]).max()
         assert 0.4 * it_ref <= info["iter"] <= 2.5 * it_ref
     # the files the reference wrote meanwhile: field_1 .. field_{nsteps-2} (the last step ends inside its solver call)
-    names = sorted({k.split("_", 3)[3] for k in g.files if k.startswith("vtk_field_") and not k.endswith("_norm")})
+    names = sorted({k.split("_", 3)[3] for k in g.files
+                    if k.startswith("vtk_field_") and not k.endswith(("_norm", "_sketch"))})
     for N in range(1, nsteps - 1):
         path = tmp_path / f"field_{N}.vtk"
         assert path.exists()
@@ -113,9 +122,12 @@ def test_first_steps_against_reference_held_numbers(case, tmp_path):
             our_norm = float(np.linalg.norm(ours[name].astype(np.float64)))
             # the source field does not depend on the solve: float32 rounding only
             bar = 1e-6 if name == "Vector_field_SOURCE" else 10 * tol
-            print(f"  field_{N}.vtk {name}: probes max diff {np.abs(got - ref).max() / max(scale, 1e-300):.2e} of the largest, "
-                  f"norm {our_norm:.6e} / {ref_norm:.6e}")
-            assert np.abs(got - ref).max() <= bar * scale + 1e-30
+            sk_ref = g[f"vtk_field_{N}_{name}_sketch"]
+            rel2 = float(np.linalg.norm(O.count_sketch(ours[name].astype(np.float64)) - sk_ref) /
+                         max(np.linalg.norm(sk_ref), 1e-300))
+            print(f"  field_{N}.vtk {name}: ||ours - ref|| / ||ref|| = {rel2:.3e} (sketch; bar {bar:g}), probes max diff "
+                  f"{np.abs(got - ref).max() / max(scale, 1e-300):.2e} of the largest, norm {our_norm:.6e} / {ref_norm:.6e}")
+            assert rel2 <= bar
             assert our_norm == pytest.approx(ref_norm, rel=bar)
 
 
