@@ -30,6 +30,7 @@ struct GridPar {
     double bnd[6];   // BND(d,s) column-major: [s*3+d]
     double dt;
     int nsub_glob;
+    int cond_dom;      // structured form: THE conducting domain (it allows one), 1 when there is none
     int64_t ncells0;
 };
 
@@ -332,11 +333,14 @@ void set_offsets(DevMatrix &A, const GridPar &g)
 struct SavIds {
     int a0, u0, zero, ncls;
 };
-__host__ __device__ inline SavIds sav_ids(int nsub_glob)
+// 27 box-position classes of a plain A row, 9 of a conducting A row (component x stencil pattern; the
+// structured form has ONE conducting domain, so the count does not grow with the number of air domains the
+// reference splits a large grid into, src/vxc2data.f90:316-333), 27 U-row patterns, the all-zero class: 64
+__host__ __device__ inline SavIds sav_ids()
 {
     SavIds s;
     s.a0 = 27;
-    s.u0 = 27 + 9 * nsub_glob;
+    s.u0 = 27 + 9;
     s.zero = s.u0 + 27;
     s.ncls = s.zero + 1;
     return s;
@@ -344,7 +348,7 @@ __host__ __device__ inline SavIds sav_ids(int nsub_glob)
 
 __global__ void k_build_table_sav(GridPar g, const double *__restrict__ valPHYS, double *table)
 {
-    const SavIds id = sav_ids(g.nsub_glob);
+    const SavIds id = sav_ids();
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= id.ncls) return;
     double t[16];
@@ -358,7 +362,7 @@ __global__ void k_build_table_sav(GridPar g, const double *__restrict__ valPHYS,
         a_row_bands(g, p[0], p[1], p[2], c, on_box);
         for (int b = 0; b < 7; ++b) t[b] = c[b];
     } else if (q < id.u0) {
-        const int e = q - 27, pat = e % 3 + 1, d = (e / 3) % 3, dom = e / 9 + 1;
+        const int e = q - 27, pat = e % 3 + 1, d = e / 3, dom = g.cond_dom;
         a_row_bands(g, 2, 2, 2, c, on_box);
         conductor_terms(g, valPHYS, dom, c);
         for (int b = 0; b < 7; ++b) t[b] = c[b];
@@ -407,7 +411,7 @@ __global__ __launch_bounds__(256) void k_assemble_sav(GridPar g, const int8_t *_
                                                       uint8_t *tile_flag, uint8_t *flags, int *err,
                                                       unsigned long long *nnz)
 {
-    const SavIds id = sav_ids(g.nsub_glob);
+    const SavIds id = sav_ids();
     const int64_t nn0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (nn0 >= g.nCells) return;
     const int kl = (int)(nn0 / g.kdz); // plane within the planes held
@@ -431,7 +435,6 @@ __global__ __launch_bounds__(256) void k_assemble_sav(GridPar g, const int8_t *_
         return;
     }
     if (on_box) { atomicMax(err, 3); return; }
-    const int dom = geo[nn0];
     const int64_t step[3] = {1, g.sdx, g.kdz};
     const int pos[3] = {i, j, k}, sd[3] = {g.sdx, g.sdy, g.sdz};
     int pu = 0, mul = 1;
@@ -452,7 +455,7 @@ __global__ __launch_bounds__(256) void k_assemble_sav(GridPar g, const int8_t *_
         if (pat != 1) fl |= (uint8_t)(1u << d);
         cnt += pat == 1 ? 2 : 3;
         const int64_t row = (int64_t)d * g.nCd + pc;
-        cls[row] = (uint8_t)(id.a0 + ((dom - 1) * 3 + d) * 3 + pat - 1);
+        cls[row] = (uint8_t)(id.a0 + d * 3 + pat - 1);
         tile_flag[row / EC3D_TILE] = 1;
         // U row: which neighbours are missing
         if (um == 0 && up == 0) { atomicMax(err, 1); return; } // the reference meets a zero column here
@@ -694,8 +697,8 @@ int ec3d_assemble_sav_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t sdz,
     const int32_t np = e1 - e0;           // planes held (a z-slab: owned planes + halo planes)
     g.nCells = g.kdz * np;
     const bool slab = !(e0 == 0 && e1 == sdz);
-    const SavIds id = sav_ids(nsub_glob);
-    if (id.ncls > 256 || sdx < 5 || sdy < 5 || sdz < 5) return -1;
+    const SavIds id = sav_ids();
+    if (sdx < 5 || sdy < 5 || sdz < 5) return -1;
     // conducting cells in scan order; one conducting domain only (U numbering = scan order)
     std::vector<int32_t> uidx((size_t)g.nCells, -1);
     int64_t nc0 = 0;
@@ -707,11 +710,12 @@ int ec3d_assemble_sav_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t sdz,
                 ec3d_set_error("ec3d_assemble: geoPHYS domain id out of range");
                 return 2;
             }
-            if (dom_seen && dom != dom_seen) return -1;
+            if (dom_seen && dom != dom_seen) return -1; // several conducting domains: bands + tail
             dom_seen = dom;
             if (geoPHYS_C[q] != 3 * g.nCells + nc0 + 1) return -1; // not scan-order numbering
             uidx[(size_t)q] = (int32_t)nc0++;
         }
+    g.cond_dom = dom_seen ? dom_seen : 1;
     // plane pitch: whole tiles per xy plane whenever that costs < 1/16 in rows
     // (EC3D_PITCH=0: never, 2: always -- the tests use it to cover the pitched layout on small grids)
     g.pitch = g.kdz;

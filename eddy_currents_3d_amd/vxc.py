@@ -73,8 +73,9 @@ def read_vxc(path) -> VxcModel:
             raise ValueError(f"{path}: layer {k} has {plane.size} voxels, expected {sdx * sdy}")
         vox[k] = plane.reshape(sdy, sdx)
     names = [s for s in re.findall(r"<Name>(.*?)</Name>", txt, flags=re.S)]
-    return VxcModel(vox, names, float(tag("Lattice_Dim")),
-                    (float(tag("X_Dim_Adj", "1")), float(tag("Y_Dim_Adj", "1")), float(tag("Z_Dim_Adj", "1"))),
+    num = lambda t: numeric(t[:10])   # CHARACTER(len=10) ch_e, src/vxc2data.f90:50: longer text is cut there
+    return VxcModel(vox, names, num(tag("Lattice_Dim")),
+                    (num(tag("X_Dim_Adj", "1")), num(tag("Y_Dim_Adj", "1")), num(tag("Z_Dim_Adj", "1"))),
                     comp)
 
 
@@ -83,6 +84,10 @@ def write_vxc(path, model: VxcModel, compression=None):
     sdz, sdy, sdx = model.vox.shape
     if max(sdx, sdy, sdz) > 999:
         raise ValueError("the reference reads the voxel counts with '(i3)': at most 999 per axis")
+    for v in (model.lattice_dim, *model.adj):
+        if len(repr(float(v))) > 10:
+            raise ValueError(f"{v!r}: the reference reads only the first 10 characters of the lattice numbers "
+                             "(src/vxc2data.f90:50); round it (vxc.resample does)")
     with open(path, "w", encoding="latin-1") as f:
         f.write('<?xml version="1.0" encoding="ISO-8859-1"?>\n<VXC Version="0.94">\n  <Lattice>\n')
         f.write(f"    <Lattice_Dim>{model.lattice_dim!r}</Lattice_Dim>\n")
@@ -126,9 +131,10 @@ def resample(model: VxcModel, sdx: int, sdy: int, sdz: int) -> VxcModel:
     iy = ((2 * np.arange(sdy, dtype=np.int64) + 1) * oy) // (2 * sdy)
     iz = ((2 * np.arange(sdz, dtype=np.int64) + 1) * oz) // (2 * sdz)
     vox = np.ascontiguousarray(model.vox[np.ix_(iz, iy, ix)])
-    # 12 significant digits: the reference reads these numbers through a 20-character field
-    # (src/utilites.f90:470-472), so the text written by write_vxc must round-trip within that
-    adj = tuple(float(f"{a * o / s:.12g}") for a, o, s in zip(model.adj, (ox, oy, oz), (sdx, sdy, sdz)))
+    # The reference keeps the text of Lattice_Dim and of the *_Dim_Adj values in a CHARACTER(len=10) variable
+    # (src/vxc2data.f90:50, :97, :104): whatever a file says, it reads the first 10 characters.  So the factors
+    # are cut to 10 characters here -- what write_vxc writes is then exactly what the reference reads.
+    adj = tuple(float(f"{a * o / s:.12g}"[:10]) for a, o, s in zip(model.adj, (ox, oy, oz), (sdx, sdy, sdz)))
     return VxcModel(vox, list(model.names), model.lattice_dim, adj, model.compression)
 
 

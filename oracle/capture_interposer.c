@@ -13,8 +13,13 @@
  * The matrix is written for call 0 only unless EC3D_CAPTURE_ALL_MATRICES is set (nnz = 0 otherwise);
  * EC3D_CAPTURE_NO_MATRIX leaves it out of call 0 as well (full-size cases: irow alone gives nnz and the
  * row-length histogram).
+ * EC3D_CAPTURE_PREFIX_ITERS=K (call 0 only): before the real solve, the same solver is run K times from the
+ * same x_in with itmax = k-1, k = 1..K -- it then returns after exactly k iterations (src/solvers.f90:25-29) --
+ * and $EC3D_CAPTURE_DIR/prefix_%02d.bin receives double ||b - A x_k||_2, double ||b||_2, then x_k[n]: the first
+ * K iterates of the unmodified reference on the full-size system.
  */
 #define _POSIX_C_SOURCE 199309L
+#include <math.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -35,6 +40,33 @@ void sprsbcgstabwr_(double *valA, int32_t *irow, int32_t *jcol, int32_t *n, doub
     int64_t nn = *n, nnz = irow[nn] - 1;
     double *x_in = NULL;
     if (dir) { x_in = malloc((size_t)nn * 8); memcpy(x_in, x, (size_t)nn * 8); }
+    const char *pk = getenv("EC3D_CAPTURE_PREFIX_ITERS");
+    if (dir && pk && ncall == 0) {
+        int K = atoi(pk);
+        double *xk = malloc((size_t)nn * 8);
+        for (int k = 1; k <= K; ++k) {
+            int32_t itk = k - 1, got = 0;
+            memcpy(xk, x_in, (size_t)nn * 8);
+            ref_sprsbcgstabwr_(valA, irow, jcol, n, b, xk, tol, &itk, &got);
+            double rr = 0.0, bb = 0.0;
+            for (int64_t r = 0; r < nn; ++r) { /* true residual of the k-th iterate */
+                double s = 0.0;
+                for (int64_t p = irow[r] - 1; p < irow[r + 1] - 1; ++p) s += valA[p] * xk[jcol[p] - 1];
+                rr += (b[r] - s) * (b[r] - s);
+                bb += b[r] * b[r];
+            }
+            double hd[2] = {sqrt(rr), sqrt(bb)};
+            char path[4096];
+            snprintf(path, sizeof path, "%s/prefix_%02d.bin", dir, k);
+            FILE *f = fopen(path, "wb");
+            if (!f) { perror(path); exit(3); }
+            fwrite(hd, 8, 2, f);
+            fwrite(xk, 8, (size_t)nn, f);
+            fclose(f);
+            fprintf(stderr, "[capture] prefix k=%d iter=%d ||b-Ax||/||b||=%.6e\n", k, got, hd[0] / hd[1]);
+        }
+        free(xk);
+    }
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
     ref_sprsbcgstabwr_(valA, irow, jcol, n, b, x, tol, itmax, iter);

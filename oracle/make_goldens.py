@@ -70,7 +70,7 @@ def read_shipped_vxc(path):
 
 
 def run_reference(vox, names, lattice_dim, adj=(1, 1, 1), max_calls=3, all_matrices=False, exe=None,
-                  extra_env=None):
+                  extra_env=None, before_cleanup=None):
     """Run EC3D_capture (or another build of the same program, e.g. _ref/EC3D_dropin) on the given
     case; returns the list of captured calls (dicts)."""
     td = tempfile.mkdtemp(prefix="ec3d_gold_")
@@ -113,6 +113,8 @@ def run_reference(vox, names, lattice_dim, adj=(1, 1, 1), max_calls=3, all_matri
                     with open(os.path.join(root, fn), "rb") as f:
                         vtk[fn] = f.read()
         calls[0]["vtk"] = vtk
+        if before_cleanup is not None:
+            before_cleanup(td)
         return calls, log
     finally:
         shutil.rmtree(td, ignore_errors=True)
@@ -364,6 +366,57 @@ def case_g5_big(sizes=(128, 256)):
              tol=np.float64(1e-8))
 
 
+def case_g6x(which=("ec_src_move_hole", "LIM"), K=16):
+    """G6X: two more facts about the full-size systems of case_g6, both for the first solver call (b = the
+    sources alone, x0 = 0), kept as sketches (oracle.count_sketch):
+      * the first K iterates of the UNMODIFIED solver (x_k and ||b - A x_k|| for k = 1..K: the solver run with
+        itmax = k-1) -- what a GPU run of exactly k iterations is compared with, before rounding differences
+        have had hundreds of iterations to grow;
+      * the reference against ITSELF under another summation order: the same program with only
+        src/solvers.f90 built -O3 -ffast-math (oracle/_ref/EC3D_capture_fast): iteration count and
+        ||x_fast - x_ref|| / ||x_ref|| at convergence -- the distance two runs of the reference's own algorithm
+        end up apart on this system, i.e. the floor under any parity bar for it."""
+    from eddy_currents_3d_amd import vxc
+    dims = {"ec_src_move_hole": (256, 256, 60), "LIM": (384, 192, 128)}
+    for stem in which:
+        g = np.load(os.path.join(GOLD, f"g4_{stem}.npz"))
+        model = vxc.VxcModel(g["vox"], [str(s) for s in g["names"]], float(str(g["lattice_dim"])),
+                             tuple(float(x) for x in g["adj"]))
+        big = vxc.resample(model, *dims[stem])
+        args = (big.vox, big.names, repr(big.lattice_dim), tuple(repr(a) for a in big.adj))
+        td_keep = {}
+
+        def grab(td):   # called before the scratch directory goes away
+            for k in range(1, K + 1):
+                with open(os.path.join(td, "cap", f"prefix_{k:02d}.bin"), "rb") as f:
+                    hd = np.fromfile(f, np.float64, 2)
+                    xk = np.fromfile(f, np.float64)
+                td_keep[k] = (hd, float(np.linalg.norm(xk)), O.count_sketch(xk, 1024))
+
+        calls, log = run_reference(*args, max_calls=1, extra_env={"EC3D_CAPTURE_NO_MATRIX": "1",
+                                                                   "EC3D_CAPTURE_PREFIX_ITERS": str(K)},
+                                   before_cleanup=grab)
+        x_ref, it_ref = calls[0]["x_out"], calls[0]["iter"]
+        fast, _ = run_reference(*args, max_calls=1, extra_env={"EC3D_CAPTURE_NO_MATRIX": "1"},
+                                exe=os.path.join(HERE, "_ref", "EC3D_capture_fast"))
+        x_fast, it_fast = fast[0]["x_out"], fast[0]["iter"]
+        assert np.array_equal(fast[0]["b"], calls[0]["b"])
+        d = dict(dims=np.array(dims[stem], np.int32), n=np.int64(calls[0]["n"]), tol=np.float64(calls[0]["tol"]),
+                 K=np.int32(K),
+                 prefix_rnorm=np.array([td_keep[k][0][0] for k in range(1, K + 1)]),
+                 bnorm=np.float64(td_keep[1][0][1]),
+                 prefix_xnorm=np.array([td_keep[k][1] for k in range(1, K + 1)]),
+                 prefix_xsketch=np.stack([td_keep[k][2] for k in range(1, K + 1)]),
+                 iter_ref=np.int32(it_ref), iter_fast=np.int32(it_fast),
+                 xnorm_ref=np.float64(np.linalg.norm(x_ref)), xnorm_fast=np.float64(np.linalg.norm(x_fast)),
+                 self_distance=np.float64(np.linalg.norm(x_fast - x_ref) / np.linalg.norm(x_ref)),
+                 xsketch_fast=O.count_sketch(x_fast))
+        print(stem, dims[stem], f"reference iter {it_ref}, -O3 -ffast-math build of the same solver iter {it_fast}, "
+              f"||x_fast - x_ref||/||x_ref|| = {float(d['self_distance']):.3e}; prefix residuals "
+              f"{d['prefix_rnorm'] / d['bnorm']}", flush=True)
+        save("g6x_" + stem + "_%dx%dx%d" % dims[stem], **d)
+
+
 def vtk_vectors(blob):
     """{name: float32 [npoints, 3]} of a field_N.vtk the reference wrote (src/utilites.f90:222-289)."""
     out = {}
@@ -440,5 +493,7 @@ if __name__ == "__main__":
     if "g5" in which: case_g5()
     if "g5big" in which: case_g5_big()
     if "g6" in which: case_g6()
+    if "g6xhole" in which: case_g6x(("ec_src_move_hole",))
+    if "g6xlim" in which: case_g6x(("LIM",))
     if "g6hole" in which: case_g6(("ec_src_move_hole",))
     if "g6lim" in which: case_g6(("LIM",))

