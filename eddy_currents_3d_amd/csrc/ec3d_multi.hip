@@ -39,7 +39,7 @@
 
 namespace {
 constexpr int RING = 4;
-enum { CH_P = 0, CH_S = 1, CH_X = 2, CH_SUM = 3, NCH = 4 };
+enum { CH_P = 0, CH_S = 1, CH_X = 2, CH_SUM = 3, CH_HUB = 4, NCH = 5 };
 const int kVecOf[3] = {EC3D_VEC_P, EC3D_VEC_S, EC3D_VEC_X};
 
 // a run of halo planes inside one work vector: `planes` pieces of `payload` doubles, `pitch` apart
@@ -81,8 +81,8 @@ struct Slab {
     bool lsum_fine = false;
     const double **ptr_table = nullptr; // device: every rank's lsum
     hipStream_t side = nullptr;
-    hipEvent_t ev_ready[3][RING] = {}, ev_halo[3][RING] = {}, ev_sum[RING] = {};
-    uint64_t seq[NCH] = {0, 0, 0, 0};
+    hipEvent_t ev_ready[3][RING] = {}, ev_halo[3][RING] = {}, ev_sum[RING] = {}, ev_hub[RING] = {};
+    uint64_t seq[NCH] = {0, 0, 0, 0, 0};
     std::atomic<uint64_t> posted[NCH];
     std::vector<Run> send_lo, recv_lo, send_hi, recv_hi; // towards rank-1 / rank+1, same order on both sides
     std::vector<Copy> pull_lo, pull_hi;                  // my ghost rows <- neighbour's rows
@@ -190,7 +190,8 @@ int run_all(ec3d_multi *m, const std::function<int(int)> &fn)
                 r += "  rank " + std::to_string(s->rank) + ": " + s->at.load() + " arg " + std::to_string(s->at_arg.load()) +
                      " it " + std::to_string(s->at_it.load()) + " seq " + std::to_string(s->at_seq.load()) + " posted [" +
                      std::to_string(s->posted[0].load()) + " " + std::to_string(s->posted[1].load()) + " " +
-                     std::to_string(s->posted[2].load()) + " " + std::to_string(s->posted[3].load()) + "]\n";
+                     std::to_string(s->posted[2].load()) + " " + std::to_string(s->posted[3].load()) + " " +
+                     std::to_string(s->posted[4].load()) + "]\n";
             return r;
         };
         if (limit <= 0) {
@@ -301,23 +302,34 @@ int halo_wait(Slab &s, int v)
     return 0;
 }
 
-// "gather": nothing moves -- my lsum is final behind this event; my next kernel may read everybody's
+// "gather": nothing moves -- my lsum is final behind my event; my next kernel may read everybody's once all
+// events are behind it.  All-to-all waits would cost N-1 cross-stream waits per rank and point (measured on
+// one card: 74 / 157 / 373 / 1022 us of enqueue time per iteration at 1 / 2 / 4 / 8 slabs); instead rank 0's
+// stream waits for everybody and records ONE event the others wait for: 2 (N-1) waits per point in all.
 int gather(ec3d_multi *m, Slab &s)
 {
     const uint64_t q = ++s.seq[CH_SUM];
     const int i = (int)(q % RING);
     s.at.store("gather:record");
     s.at_seq.store(q);
-    MHIP(hipEventRecord(s.ev_sum[i], s.c->stream));
-    s.posted[CH_SUM].store(q, std::memory_order_release);
-    for (int h = 0; h < m->n; ++h) {
-        if (h == s.rank) continue;
+    if (m->n == 1) return 0;
+    Slab &hub = *m->slab[0];
+    int rc = 0;
+    if (s.rank != 0) {
+        MHIP(hipEventRecord(s.ev_sum[i], s.c->stream));
+        s.posted[CH_SUM].store(q, std::memory_order_release);
+        if ((rc = wait_posted(m, s, hub, CH_HUB, q))) return rc;
+        s.at.store("gather:cross_wait hub");
+        return cross_wait(s.c->stream, hub.ev_hub[i]);
+    }
+    for (int h = 1; h < m->n; ++h) {
         Slab &peer = *m->slab[(size_t)h];
-        int rc = wait_posted(m, s, peer, CH_SUM, q);
-        if (rc) return rc;
+        if ((rc = wait_posted(m, s, peer, CH_SUM, q))) return rc;
         s.at.store("gather:cross_wait");
         if ((rc = cross_wait(s.c->stream, peer.ev_sum[i]))) return rc;
     }
+    MHIP(hipEventRecord(s.ev_hub[i], s.c->stream)); // behind rank 0's own sums and everybody else's
+    s.posted[CH_HUB].store(q, std::memory_order_release);
     return 0;
 }
 
@@ -423,6 +435,7 @@ int slab_reset(ec3d_multi *m, Slab &s)
                 MHIP(hipEventCreateWithFlags(&s.ev_halo[v][i], hipEventDisableTiming));
             }
         for (int i = 0; i < RING; ++i) MHIP(hipEventCreateWithFlags(&s.ev_sum[i], hipEventDisableTiming));
+        for (int i = 0; i < RING; ++i) MHIP(hipEventCreateWithFlags(&s.ev_hub[i], hipEventDisableTiming));
         for (int i = 0; i < 2; ++i) MHIP(hipEventCreateWithFlags(&s.ev_stop[i], hipEventDisableTiming));
         MHIP(hipHostMalloc(&s.stop_pinned, 2 * sizeof(int32_t), hipHostMallocDefault));
         // the 8 sums every other GPU reads in place: fine-grained (coherent across devices) when the
@@ -731,8 +744,10 @@ extern "C" int ec3d_multi_destroy(ec3d_multi_handle m)
                 if (s.ev_ready[v][i]) (void)hipEventDestroy(s.ev_ready[v][i]);
                 if (s.ev_halo[v][i]) (void)hipEventDestroy(s.ev_halo[v][i]);
             }
-        for (int i = 0; i < RING; ++i)
+        for (int i = 0; i < RING; ++i) {
             if (s.ev_sum[i]) (void)hipEventDestroy(s.ev_sum[i]);
+            if (s.ev_hub[i]) (void)hipEventDestroy(s.ev_hub[i]);
+        }
         for (int i = 0; i < 2; ++i)
             if (s.ev_stop[i]) (void)hipEventDestroy(s.ev_stop[i]);
         if (s.stop_pinned) (void)hipHostFree(s.stop_pinned);

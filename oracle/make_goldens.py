@@ -91,6 +91,8 @@ def run_reference(vox, names, lattice_dim, adj=(1, 1, 1), max_calls=3, all_matri
         log = p.stdout.decode(errors="replace") + p.stderr.decode(errors="replace")
         calls = []
         for fn in sorted(os.listdir(cap)):
+            if not fn.startswith("call_"):
+                continue
             with open(os.path.join(cap, fn), "rb") as f:
                 n, nnz, itmax, it = np.fromfile(f, np.int64, 4)
                 tol, sec = np.fromfile(f, np.float64, 2)
