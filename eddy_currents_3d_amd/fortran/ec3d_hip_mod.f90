@@ -14,7 +14,10 @@ module ec3d_hip
     public :: ec3d_create, ec3d_destroy, ec3d_assemble, ec3d_assemble_poisson, ec3d_set_matrix_csr, &
               ec3d_solve, ec3d_spmv, ec3d_get_cel_bnd, ec3d_error_text, ec3d_set_format, ec3d_set_structured, &
               ec3d_upload, ec3d_download, ec3d_solve_resident, ec3d_rhs_step, ec3d_post_update, &
-              ec3d_vtk_fields, EC3D_VEC_X, EC3D_VEC_B
+              ec3d_vtk_fields, EC3D_VEC_X, EC3D_VEC_B, ec3d_true_residual, &
+              ec3d_multi_create, ec3d_multi_destroy, ec3d_multi_assemble, ec3d_multi_set_matrix_csr, &
+              ec3d_multi_solve, ec3d_multi_upload, ec3d_multi_download, ec3d_multi_solve_resident, &
+              ec3d_multi_rhs_step, ec3d_multi_post_update, ec3d_multi_vtk_fields, ec3d_multi_true_residual
 
     integer(c_int), parameter :: EC3D_VEC_X = 0, EC3D_VEC_B = 1   ! Uaf, Jaf
 
@@ -133,6 +136,97 @@ module ec3d_hip
             integer(c_int), value :: which
             integer(c_int32_t), intent(out) :: count
             type(c_ptr), value :: list
+        end function
+        ! ||Jaf - A*Uaf|| / ||Jaf|| of the resident vectors, computed on the device
+        integer(c_int) function ec3d_true_residual(h, rel, bnorm) bind(C, name="ec3d_true_residual")
+            import :: c_ptr, c_int, c_double
+            type(c_ptr), value :: h
+            real(c_double), intent(out) :: rel, bnorm
+        end function
+        ! ---- N GPUs behind one handle (include/ec3d_hip.h section 2c): same arguments as the calls above, global
+        ! arrays in the reference's numbering; the library cuts z-slabs and keeps one host thread per GPU.
+        ! devices: c_null_ptr for GPUs 0 .. nranks-1, or c_loc of an INTEGER(c_int32_t) list.
+        integer(c_int) function ec3d_multi_create(mh, nranks, devices) bind(C, name="ec3d_multi_create")
+            import :: c_ptr, c_int, c_int32_t
+            type(c_ptr), intent(out) :: mh
+            integer(c_int32_t), value :: nranks
+            type(c_ptr), value :: devices
+        end function
+        integer(c_int) function ec3d_multi_destroy(mh) bind(C, name="ec3d_multi_destroy")
+            import :: c_ptr, c_int
+            type(c_ptr), value :: mh
+        end function
+        integer(c_int) function ec3d_multi_assemble(mh, sdx, sdy, sdz, geoPHYS, geoPHYS_C, valPHYS, nsub_glob, &
+                                                    BND, delta, dt) bind(C, name="ec3d_multi_assemble")
+            import :: c_ptr, c_int, c_int8_t, c_int32_t, c_double
+            type(c_ptr), value :: mh
+            integer(c_int32_t), value :: sdx, sdy, sdz, nsub_glob
+            integer(c_int8_t), intent(in) :: geoPHYS(*)
+            integer(c_int32_t), intent(in) :: geoPHYS_C(*)
+            real(c_double), intent(in) :: valPHYS(*), BND(*), delta(*)
+            real(c_double), value :: dt
+        end function
+        integer(c_int) function ec3d_multi_set_matrix_csr(mh, n, valA, irow, jcol) &
+                bind(C, name="ec3d_multi_set_matrix_csr")
+            import :: c_ptr, c_int, c_int32_t, c_double
+            type(c_ptr), value :: mh
+            integer(c_int32_t), value :: n
+            real(c_double), intent(in) :: valA(*)
+            integer(c_int32_t), intent(in) :: irow(*), jcol(*)
+        end function
+        ! replaces CALL sprsBCGstabwr(valA, irow, jcol, n, Jaf, Uaf, tolerance, itmax, iter)   (src/EC3D.f90:408)
+        integer(c_int) function ec3d_multi_solve(mh, b, x, tolerance, itmax, iter) bind(C, name="ec3d_multi_solve")
+            import :: c_ptr, c_int, c_int32_t, c_double
+            type(c_ptr), value :: mh
+            real(c_double), intent(in) :: b(*)
+            real(c_double), intent(inout) :: x(*)
+            real(c_double), value :: tolerance
+            integer(c_int32_t), value :: itmax
+            integer(c_int32_t), intent(out) :: iter
+        end function
+        integer(c_int) function ec3d_multi_upload(mh, which, host) bind(C, name="ec3d_multi_upload")
+            import :: c_ptr, c_int, c_double
+            type(c_ptr), value :: mh
+            integer(c_int), value :: which
+            real(c_double), intent(in) :: host(*)
+        end function
+        integer(c_int) function ec3d_multi_download(mh, which, host) bind(C, name="ec3d_multi_download")
+            import :: c_ptr, c_int, c_double
+            type(c_ptr), value :: mh
+            integer(c_int), value :: which
+            real(c_double), intent(out) :: host(*)
+        end function
+        integer(c_int) function ec3d_multi_solve_resident(mh, tolerance, itmax, iter) &
+                bind(C, name="ec3d_multi_solve_resident")
+            import :: c_ptr, c_int, c_int32_t, c_double
+            type(c_ptr), value :: mh
+            real(c_double), value :: tolerance
+            integer(c_int32_t), value :: itmax
+            integer(c_int32_t), intent(out) :: iter
+        end function
+        integer(c_int) function ec3d_multi_rhs_step(mh, moving, nsrc, src_index, src_value) &
+                bind(C, name="ec3d_multi_rhs_step")
+            import :: c_ptr, c_int, c_int32_t, c_double
+            type(c_ptr), value :: mh
+            integer(c_int32_t), value :: moving, nsrc
+            integer(c_int32_t), intent(in) :: src_index(*)
+            real(c_double), intent(in) :: src_value(*)
+        end function
+        integer(c_int) function ec3d_multi_post_update(mh) bind(C, name="ec3d_multi_post_update")
+            import :: c_ptr, c_int
+            type(c_ptr), value :: mh
+        end function
+        integer(c_int) function ec3d_multi_vtk_fields(mh, delta, fA, fEddy, fSource, fB) &
+                bind(C, name="ec3d_multi_vtk_fields")
+            import :: c_ptr, c_int, c_double, c_float
+            type(c_ptr), value :: mh
+            real(c_double), intent(in) :: delta(*)
+            real(c_float), intent(out) :: fA(*), fEddy(*), fSource(*), fB(*)   ! 3*nCells each, the WHOLE grid
+        end function
+        integer(c_int) function ec3d_multi_true_residual(mh, rel, bnorm) bind(C, name="ec3d_multi_true_residual")
+            import :: c_ptr, c_int, c_double
+            type(c_ptr), value :: mh
+            real(c_double), intent(out) :: rel, bnorm
         end function
         function ec3d_last_error_c() bind(C, name="ec3d_last_error") result(p)
             import :: c_ptr

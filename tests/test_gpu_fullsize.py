@@ -278,7 +278,9 @@ def test_first_iterations_track_the_reference_at_full_size(case, tmp_path):
         assert bn == pytest.approx(float(gx["bnorm"]), rel=1e-13)
         for kk in range(1, K + 1):
             s.upload("X", np.zeros(n))
-            it, _ = s.solve_resident(1e-300, kk - 1)       # exactly kk iterations (src/solvers.f90:25-29)
+            # exactly kk iterations (src/solvers.f90:25-29), at the input's own tolerance: the restart rule
+            # (:47-49) compares against it too, and the reference's prefix runs did restart
+            it, _ = s.solve_resident(float(gx["tol"]), kk - 1)
             assert it == kk
             res = s.true_residual()[0] * bn                 # ||b - A x_k|| from the device
             x = s.download("X")

@@ -47,7 +47,8 @@ def test_shipped_input_runs_like_the_reference(case, tmp_path):
         assert np.abs(info["bprobe"] - g["bprobe"][k]).max() <= (1e-14 if k == 0 else 10 * tol) * np.abs(g["bprobe"][k]).max()
         assert info["xnorm"] == pytest.approx(float(g["xnorm"][k]), rel=10 * tol)
         assert np.abs(info["xprobe"] - g["xprobe"][k]).max() <= 10 * tol * np.abs(g["xprobe"][k]).max()
-        assert abs(info["iter"] - it_ref) <= max(5, 0.3 * it_ref)
+        # 0.8 M / 0.4 M unknowns at tol 5e-3: the reference's own counts (173/160/80, 288/108/98, 70/36/36)
+        assert info["iter"] == it_ref
 
 
 def test_command_line_runs_a_vxc_file(tmp_path, capsys):

@@ -269,3 +269,81 @@ def test_single_rank_entry_points_refuse_a_dist_configured_handle(E):
         s.dist_configure(1, 0, 0)
         x, it, _ = s.solve(b, np.zeros(N ** 3), 1e-8, 1000)
         assert it == it_ref and np.array_equal(x, x_ref)
+
+
+# ---- a machine with at least two GPUs (skipped on the one-GPU test box; the driver's 8-GPU node runs them) ----
+def _two_devices():
+    import torch
+    return torch.cuda.device_count() >= 2
+
+
+def test_multi_on_two_real_devices_equals_two_slabs_on_one(E, oracle):
+    """Peer copies over xGMI, remote reads of the partial sums and cross-device event waits must give exactly what
+    the same two slabs give on one card."""
+    if not _two_devices():
+        pytest.skip("needs 2 GPUs")
+    sdx, sdy, sdz, tol = 64, 64, 48, 1e-8
+    b = np.random.Generator(np.random.PCG64(5)).standard_normal(sdx * sdy * sdz)
+    res = {}
+    for devs in ([0, 0], [0, 1]):
+        with E.EC3DMulti(2, devices=devs) as m:
+            m.assemble_poisson(sdx, sdy, sdz)
+            res[tuple(devs)] = m.solve(b, np.zeros(m.n), tol, 5000)
+    g = load_golden("g2_conducting_hole_16x15x14")
+    av = {}
+    for devs in ([0, 0], [0, 1]):
+        with E.EC3DMulti(2, devices=devs) as m:
+            m.assemble(g["geoPHYS"], g["geoPHYS_C"], g["valPHYS"], g["BND"], g["delta"], float(g["dt"]))
+            av[tuple(devs)] = m.solve(g["b0"], g["xin0"], float(g["tol"]), int(g["itmax"]))
+    for r in (res, av):
+        assert r[(0, 0)][1] == r[(0, 1)][1] and np.array_equal(r[(0, 0)][0], r[(0, 1)][0])
+
+
+def _nccl_worker(rank, world, port, out):
+    import sys
+    sys.path.insert(0, REPO)
+    import datetime
+    import torch
+    import torch.distributed as dist
+    from eddy_currents_3d_amd.dist import SlabSolver
+    from bench import bar_rhs
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120),
+                            device_id=torch.device("cuda", rank))
+    try:
+        s = SlabSolver.poisson_cube(64, rank, world, device=rank)
+        s.set_rhs(bar_rhs(64, s.k0, s.k1), np.zeros(s.n_local))
+        it = s.solve(1e-8, 20000)
+        x = s.gather_x()
+        if rank == 0:
+            np.save(out, np.concatenate([[it], x]))
+        s.ops.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_over_rccl_match_the_undivided_solve(E, tmp_path):
+    """one 2-rank nccl test -- in-place P2P on the ghost planes, all_gather on the adopted stream, the
+    halo_start / halo_wait overlap of dist.py -- against the single-GPU solve."""
+    if not _two_devices():
+        pytest.skip("needs 2 GPUs")
+    import socket
+    import torch.multiprocessing as mp
+    from bench import bar_rhs
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    out = str(tmp_path / "x.npy")
+    mp.spawn(_nccl_worker, args=(2, port, out), nprocs=2, join=True)
+    r = np.load(out)
+    it, x = int(r[0]), r[1:]
+    b = bar_rhs(64)
+    with E.EC3DSolver() as s:
+        s.assemble_poisson(64, 64, 64)
+        xr, itr, _ = s.solve(b, np.zeros(64 ** 3), 1e-8, 20000)
+        res = np.linalg.norm(b - s.spmv(x)) / np.linalg.norm(b)
+    print(f"2 ranks over RCCL: iter {it} / undivided {itr}, true residual {res:.2e}")
+    assert res < 5e-8
+    assert np.linalg.norm(x - xr) <= 1e-5 * np.linalg.norm(xr)

@@ -149,7 +149,14 @@ def test_solve_vs_reference_fixture(E, name):
             rel = np.linalg.norm(x - xr) / np.linalg.norm(xr)
             print(f"{name} step {k}: iter gpu {it} / reference {int(it_ref)}, rel diff {rel:.2e}")
             assert rel <= 10 * tol
-            assert abs(it - int(it_ref)) <= max(3, int(0.15 * int(it_ref)))
+            if name.startswith(("g2", "g3")):
+                # tol 5e-3 / 1e-3, 14-79 iterations: too few for the re-associated dot products to move a
+                # decision -- the count IS the reference's
+                assert it == int(it_ref)
+            else:
+                # g1 runs to tol 1e-6 (27-33 iterations with a residual plateau before the exit): the last
+                # step lands 2 iterations later than the reference today; bounded, as on the tol-1e-8 cubes
+                assert abs(it - int(it_ref)) <= max(3, int(0.15 * int(it_ref)))
 
 
 @pytest.mark.parametrize("N", [16, 32, 64])
