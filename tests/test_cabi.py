@@ -60,6 +60,8 @@ def test_fails_loudly_without_a_device(lib):
         pytest.skip("a GPU is present")
     with pytest.raises(E.EC3DError, match="no HIP device"):
         E.EC3DSolver()
+    with pytest.raises(E.EC3DError, match="no HIP device"):
+        E.EC3DMulti(2)                                      # N GPUs behind one handle: same rule
 
 
 def test_empty_system_is_answered_without_a_device(lib):

@@ -40,3 +40,25 @@ def test_reference_time_loop_on_gpu_solver(case, fixture):
         print(f"{case} step {k}: iter gpu {c['iter']} / reference {int(g['iters'][k])}, rel diff {rel:.2e}")
         assert rel <= 10 * tol
         assert abs(c["iter"] - int(g["iters"][k])) <= max(3, 0.15 * int(g["iters"][k]))
+
+
+@pytest.mark.skipif(not os.path.exists(EXE), reason="oracle/_ref/EC3D_dropin not built (needs /root/reference)")
+@pytest.mark.parametrize("case,fixture", [("g2", "g2_conducting_hole_16x15x14"), ("g3", "g3_moving_coil_18x16x12")])
+def test_reference_program_on_two_slabs_without_knowing(case, fixture):
+    """SURVEY section 8b "Threading": the same unmodified program, the same call at src/EC3D.f90:408, and
+    EC3D_NGPU=2 in the environment -- the library cuts the CSR matrix it is handed into two z-slabs (here both on
+    this GPU) and solves there.  The caller sees the reference's vectors and iteration counts."""
+    from oracle import make_goldens as G
+    inp = {"g2": G.inputs_g2, "g3": G.inputs_g3}[case]()
+    calls, log = G.run_reference(**inp, exe=EXE, extra_env={"EC3D_HIP_LIB": LIB, "EC3D_NGPU": "2",
+                                                            "EC3D_DEVICES": "0,0", "EC3D_MULTI_WATCHDOG": "30"})
+    g = load_golden(fixture)
+    assert len(calls) == len(g["iters"])
+    tol = float(g["tol"])
+    for k, c in enumerate(calls):
+        xr = g[f"xout{k}"]
+        rel = np.linalg.norm(c["x_out"] - xr) / np.linalg.norm(xr)
+        print(f"{case} step {k} on 2 slabs behind sprsbcgstabwr_: iter {c['iter']} / reference {int(g['iters'][k])}, "
+              f"rel diff {rel:.2e}")
+        assert rel <= 10 * tol
+        assert c["iter"] == int(g["iters"][k])

@@ -118,3 +118,30 @@ def test_gpu_order_dot_is_a_permutation_of_the_sum(oracle):
         d = oracle.dot_gpuorder(geom, a, b)
         assert d == oracle.dot_gpuorder(geom, a, b)
         assert d == pytest.approx(float(np.dot(a, b)), rel=1e-12)
+
+
+def test_count_sketch_is_linear_and_estimates_distances(oracle):
+    """oracle.count_sketch: what lets the full-size tests state ||x_gpu - x_ref|| / ||x_ref|| from a 32 KB fixture."""
+    rng = np.random.Generator(np.random.PCG64(9))
+    n = 1_500_000
+    x = rng.standard_normal(n)
+    y = x + 0.03 * rng.standard_normal(n) * np.linspace(0, 2, n)
+    sx, sy = oracle.count_sketch(x), oracle.count_sketch(y)
+    assert np.allclose(oracle.count_sketch(2.5 * x - y), 2.5 * sx - sy, rtol=0, atol=1e-9 * np.abs(sx).max())
+    est = np.linalg.norm(sx - sy) / np.linalg.norm(sx)
+    true = np.linalg.norm(x - y) / np.linalg.norm(x)
+    assert abs(est - true) <= 0.06 * true                    # ~1 % standard deviation at 4096 buckets
+    assert np.array_equal(sx, oracle.count_sketch(x))       # pure index arithmetic: reproducible anywhere
+
+
+def test_full_size_fixtures_hold_what_the_gpu_tests_read():
+    import os
+    from conftest import GOLDEN
+    for name in ("g6_ec_src_move_hole_256x256x60", "g6_LIM_384x192x128"):
+        if not os.path.exists(os.path.join(GOLDEN, name + ".npz")):
+            continue
+        g = load_golden(name)
+        k = len(g["iters"])
+        assert g["xsketch"].shape == (k, 4096) and g["xprobe"].shape == (k, 200) and g["bprobe"].shape == (k, 200)
+        assert int(g["n"]) == 3 * int(np.prod(g["dims"])) + (int(g["n"]) - 3 * int(np.prod(g["dims"])))
+        assert all(f"vtk_field_{N}_Field_A_sketch" in g.files for N in range(1, k - 1))
