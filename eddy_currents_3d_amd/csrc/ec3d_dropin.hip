@@ -8,7 +8,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <future>
 #include <mutex>
+#include <thread>
+#include <vector>
 
 // ---------------------------------------------------------------------------------------------
 // drop-in for src/solvers.f90:3 (called from src/EC3D.f90:408)
@@ -22,25 +25,59 @@ struct DropIn {
     int ngpu = -1;
     const void *valA = nullptr, *irow = nullptr, *jcol = nullptr;
     int64_t n = 0, nnz = 0;
-    uint64_t sig = 0;
+    uint64_t sig = 0, quick = 0;
     std::mutex mu;
 } g_drop;
 
-uint64_t matrix_signature(const double *valA, const int32_t *irow, const int32_t *jcol, int64_t n, int64_t nnz)
+// Change detector for callers that rebuild the matrix in place without telling us: EVERY entry of valA, jcol and
+// irow goes in.  That is 12 B per nonzero -- 1.9 GB for the 21 M-unknown A-V system, longer than the solve it
+// guards if done up front on one core -- so it runs on a few host threads WHILE the GPU solves (the caller's
+// thread has nothing else to do then), and the solution is handed back only once the signature has matched;
+// see sprsbcgstabwr_ below.  Chunks are hashed independently (8 interleaved lanes each: the multiply chain is
+// not the limit) and combined in order.
+uint64_t hash_chunk(const double *valA, const int32_t *jcol, int64_t lo, int64_t hi)
 {
-    // change detector for callers that rebuild the matrix in place without telling us: EVERY entry of
-    // valA, jcol and irow goes in (one streaming pass, ~12 B/nonzero -- small next to a solve, which reads
-    // the matrix twice per iteration).  Four independent lanes so the multiply chain is not the limit.
-    uint64_t h[4] = {1469598103934665603ull, 0x9E3779B97F4A7C15ull, 0xC2B2AE3D27D4EB4Full, 0x165667B19E3779F9ull};
-    for (int64_t p = 0; p < nnz; ++p) {
+    uint64_t h[8] = {1469598103934665603ull, 0x9E3779B97F4A7C15ull, 0xC2B2AE3D27D4EB4Full, 0x165667B19E3779F9ull,
+                     0x27D4EB2F165667C5ull, 0x85EBCA77C2B2AE63ull, 0xFF51AFD7ED558CCDull, 0xC4CEB9FE1A85EC53ull};
+    for (int64_t p = lo; p < hi; ++p) {
         uint64_t bits;
         memcpy(&bits, &valA[p], 8);
-        uint64_t &q = h[p & 3];
-        q = (q ^ bits) * 1099511628211ull;
-        q = (q ^ (uint64_t)(uint32_t)jcol[p]) * 1099511628211ull;
+        uint64_t &q = h[p & 7];
+        q = (q ^ bits ^ ((uint64_t)(uint32_t)jcol[p] << 32)) * 1099511628211ull;
     }
-    for (int64_t r = 0; r <= n; ++r) h[r & 3] = (h[r & 3] ^ (uint64_t)(uint32_t)irow[r]) * 1099511628211ull;
-    return ((h[0] * 31 + h[1]) * 31 + h[2]) * 31 + h[3];
+    uint64_t r = 0;
+    for (int k = 0; k < 8; ++k) r = r * 31 + h[k];
+    return r;
+}
+
+uint64_t matrix_signature(const double *valA, const int32_t *irow, const int32_t *jcol, int64_t n, int64_t nnz)
+{
+    unsigned nt = std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+    if (nnz < (1 << 20)) nt = 1;
+    std::vector<uint64_t> part(nt, 0);
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; ++t)
+        th.emplace_back([&, t] { part[t] = hash_chunk(valA, jcol, nnz * t / nt, nnz * (t + 1) / nt); });
+    part[0] = hash_chunk(valA, jcol, 0, nnz / nt);
+    for (auto &x : th) x.join();
+    uint64_t r = (uint64_t)n * 0x9E3779B97F4A7C15ull + (uint64_t)nnz;
+    for (unsigned t = 0; t < nt; ++t) r = (r ^ part[t]) * 1099511628211ull;
+    for (int64_t i = 0; i <= n; ++i) r = (r ^ (uint64_t)(uint32_t)irow[i]) * 1099511628211ull + (r >> 29);
+    return r;
+}
+
+// a few thousand samples: the quick look that decides whether the cached device matrix is worth starting on
+uint64_t sample_signature(const double *valA, const int32_t *jcol, int64_t nnz)
+{
+    uint64_t h = 1469598103934665603ull;
+    const int64_t step = std::max<int64_t>(1, nnz / 4096);
+    for (int64_t p = 0; p < nnz; p += step) {
+        uint64_t bits;
+        memcpy(&bits, &valA[p], 8);
+        h = (h ^ bits) * 1099511628211ull;
+        h = (h ^ (uint64_t)jcol[p]) * 1099511628211ull;
+    }
+    return h;
 }
 
 [[noreturn]] void die(const char *what)
@@ -89,43 +126,64 @@ extern "C" void sprsbcgstabwr_(double *valA, int32_t *irow, int32_t *jcol, int32
         if (ec3d_create(&g_drop.ctx, dev)) die("ec3d_create");
     }
     const int64_t nn = *n, nnz = (int64_t)irow[nn] - 1;
-    const uint64_t sig = matrix_signature(valA, irow, jcol, nn, nnz);
-    const bool same = g_drop.valA == valA && g_drop.irow == irow && g_drop.jcol == jcol && g_drop.n == nn &&
-                      g_drop.nnz == nnz && g_drop.sig == sig;
-    if (g_drop.ngpu > 1) {
-        if (!(g_drop.multi_has_matrix && same)) {
-            g_drop.multi_has_matrix = false;
-            const int rc = ec3d_multi_set_matrix_csr(g_drop.multi, *n, valA, irow, jcol);
-            if (rc == 7) { // no grid to cut: this matrix runs on one GPU
-                fprintf(stderr, "libec3d_hip: EC3D_NGPU=%d ignored: %s\n", g_drop.ngpu, ec3d_last_error());
-                g_drop.ngpu = 1;
-                if (!g_drop.ctx) {
-                    int dev = 0;
-                    if (const char *e = getenv("EC3D_DEVICE")) dev = atoi(e);
-                    if (ec3d_create(&g_drop.ctx, dev)) die("ec3d_create");
-                }
-            } else if (rc) {
-                die("ec3d_multi_set_matrix_csr");
-            } else {
-                g_drop.multi_has_matrix = true;
-                g_drop.valA = valA; g_drop.irow = irow; g_drop.jcol = jcol;
-                g_drop.n = nn; g_drop.nnz = nnz; g_drop.sig = sig;
-            }
+    const uint64_t quick = sample_signature(valA, jcol, nnz);
+    const bool looks_same = g_drop.valA == valA && g_drop.irow == irow && g_drop.jcol == jcol && g_drop.n == nn &&
+                            g_drop.nnz == nnz && g_drop.quick == quick;
+    auto remember = [&](uint64_t sig) {
+        g_drop.valA = valA; g_drop.irow = irow; g_drop.jcol = jcol;
+        g_drop.n = nn; g_drop.nnz = nnz; g_drop.sig = sig; g_drop.quick = quick;
+    };
+    auto single = [&]() {
+        if (!g_drop.ctx) {
+            int dev = 0;
+            if (const char *e = getenv("EC3D_DEVICE")) dev = atoi(e);
+            if (ec3d_create(&g_drop.ctx, dev)) die("ec3d_create");
         }
+    };
+    // The solve on whatever device matrix is in place: b and x go up, the iteration runs, x comes back ONLY if
+    // `accept` says so (the full signature, computed meanwhile, matched).  Returns false when x was withheld.
+    auto solve_cached = [&](std::future<uint64_t> *check) -> bool {
         if (g_drop.ngpu > 1) {
-            if (ec3d_multi_solve(g_drop.multi, b, x, *tolerance, *itmax, iter)) die("ec3d_multi_solve");
-            return;
+            if (ec3d_multi_upload(g_drop.multi, EC3D_VEC_B, b) || ec3d_multi_upload(g_drop.multi, EC3D_VEC_X, x) ||
+                ec3d_multi_solve_resident(g_drop.multi, *tolerance, *itmax, iter))
+                die("ec3d_multi_solve");
+            if (check && check->get() != g_drop.sig) return false;
+            if (ec3d_multi_download(g_drop.multi, EC3D_VEC_X, x)) die("ec3d_multi_download");
+        } else {
+            if (ec3d_upload(g_drop.ctx, EC3D_VEC_B, b) || ec3d_upload(g_drop.ctx, EC3D_VEC_X, x) ||
+                ec3d_solve_resident(g_drop.ctx, *tolerance, *itmax, iter, nullptr, 0))
+                die("ec3d_solve");
+            if (check && check->get() != g_drop.sig) return false;
+            if (ec3d_download(g_drop.ctx, EC3D_VEC_X, x)) die("ec3d_download");
+        }
+        return true;
+    };
+    const bool have = g_drop.ngpu > 1 ? g_drop.multi_has_matrix : (g_drop.ctx && g_drop.ctx->have_matrix);
+    if (have && looks_same) {
+        // start on the cached matrix; every entry of the caller's arrays is checked while the GPU works
+        std::future<uint64_t> check = std::async(std::launch::async, matrix_signature, valA, irow, jcol, nn, nnz);
+        if (solve_cached(&check)) return;
+        // the matrix was changed in place (same addresses, same samples): x is still the caller's, start over
+        g_drop.multi_has_matrix = false;
+        if (g_drop.ctx) ec3d_free_matrix(g_drop.ctx);
+    }
+    const uint64_t sig = matrix_signature(valA, irow, jcol, nn, nnz);
+    if (g_drop.ngpu > 1) {
+        g_drop.multi_has_matrix = false;
+        const int rc = ec3d_multi_set_matrix_csr(g_drop.multi, *n, valA, irow, jcol);
+        if (rc == 7) { // no grid to cut: this matrix runs on one GPU
+            fprintf(stderr, "libec3d_hip: EC3D_NGPU=%d ignored: %s\n", g_drop.ngpu, ec3d_last_error());
+            g_drop.ngpu = 1;
+        } else if (rc) {
+            die("ec3d_multi_set_matrix_csr");
+        } else {
+            g_drop.multi_has_matrix = true;
         }
     }
-    if (!(g_drop.ctx->have_matrix && same)) {
+    if (g_drop.ngpu <= 1) {
+        single();
         if (ec3d_set_matrix_csr(g_drop.ctx, *n, valA, irow, jcol)) die("ec3d_set_matrix_csr");
-        g_drop.valA = valA;
-        g_drop.irow = irow;
-        g_drop.jcol = jcol;
-        g_drop.n = nn;
-        g_drop.nnz = nnz;
-        g_drop.sig = sig;
     }
-    if (ec3d_solve(g_drop.ctx, b, x, *tolerance, *itmax, iter, nullptr, 0)) die("ec3d_solve");
+    remember(sig);
+    solve_cached(nullptr);
 }
-

@@ -113,8 +113,9 @@ def refine(model: VxcModel, fx: int, fy: int, fz: int) -> VxcModel:
     """Every voxel becomes fx*fy*fz voxels; the physical size is kept (cell size / factor).  This is how
     the 256^3-class inputs of BASELINE configs 3 and 5 are made from the shipped 102x102x24 / 176x32x22."""
     vox = np.repeat(np.repeat(np.repeat(model.vox, fz, axis=0), fy, axis=1), fx, axis=2)
-    return VxcModel(vox, list(model.names), model.lattice_dim,
-                    (model.adj[0] / fx, model.adj[1] / fy, model.adj[2] / fz), model.compression)
+    # cut to the 10 characters the reference reads (see resample)
+    adj = tuple(float(f"{a / f:.12g}"[:10]) for a, f in zip(model.adj, (fx, fy, fz)))
+    return VxcModel(vox, list(model.names), model.lattice_dim, adj, model.compression)
 
 
 def resample(model: VxcModel, sdx: int, sdy: int, sdz: int) -> VxcModel:

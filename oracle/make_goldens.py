@@ -419,6 +419,35 @@ def case_g6x(which=("ec_src_move_hole", "LIM"), K=16):
         save("g6x_" + stem + "_%dx%dx%d" % dims[stem], **d)
 
 
+def case_g6f(which=("ec_src_move_hole", "LIM"), steps=4):
+    """G6F: the reference against itself over the first `steps` TIME STEPS of the full-size runs of case_g6: the
+    same program with only src/solvers.f90 built -O3 -ffast-math.  From step 1 on the two runs start from states
+    that already differ (warm start and right-hand side carry the previous solutions), exactly as a GPU run does
+    against the reference; per step: iteration count and the sketch distance to the exact build's x
+    (tests/golden/g6_*).  Added to the g6x fixture as self_distance_steps / iters_fast_steps."""
+    from eddy_currents_3d_amd import vxc
+    dims = {"ec_src_move_hole": (256, 256, 60), "LIM": (384, 192, 128)}
+    for stem in which:
+        g = np.load(os.path.join(GOLD, f"g4_{stem}.npz"))
+        model = vxc.VxcModel(g["vox"], [str(s) for s in g["names"]], float(str(g["lattice_dim"])),
+                             tuple(float(x) for x in g["adj"]))
+        big = vxc.resample(model, *dims[stem])
+        fast, _ = run_reference(big.vox, big.names, repr(big.lattice_dim), tuple(repr(a) for a in big.adj),
+                                max_calls=steps, extra_env={"EC3D_CAPTURE_NO_MATRIX": "1"},
+                                exe=os.path.join(HERE, "_ref", "EC3D_capture_fast"))
+        name = "_%dx%dx%d" % dims[stem]
+        g6 = np.load(os.path.join(GOLD, "g6_" + stem + name + ".npz"))
+        gx = dict(np.load(os.path.join(GOLD, "g6x_" + stem + name + ".npz")))
+        sk = np.stack([O.count_sketch(c["x_out"]) for c in fast])
+        dist = np.array([np.linalg.norm(sk[k] - g6["xsketch"][k]) / np.linalg.norm(g6["xsketch"][k])
+                         for k in range(len(fast))])
+        gx["self_distance_steps"] = dist
+        gx["iters_fast_steps"] = np.array([c["iter"] for c in fast], np.int32)
+        print(stem, "fast-math build, iterations per step", gx["iters_fast_steps"], "exact build", g6["iters"],
+              "distance per step", dist, flush=True)
+        save("g6x_" + stem + name, **gx)
+
+
 def vtk_vectors(blob):
     """{name: float32 [npoints, 3]} of a field_N.vtk the reference wrote (src/utilites.f90:222-289)."""
     out = {}
@@ -495,6 +524,8 @@ if __name__ == "__main__":
     if "g5" in which: case_g5()
     if "g5big" in which: case_g5_big()
     if "g6" in which: case_g6()
+    if "g6fhole" in which: case_g6f(("ec_src_move_hole",))
+    if "g6flim" in which: case_g6f(("LIM",))
     if "g6xhole" in which: case_g6x(("ec_src_move_hole",))
     if "g6xlim" in which: case_g6x(("LIM",))
     if "g6hole" in which: case_g6(("ec_src_move_hole",))

@@ -97,6 +97,11 @@ def test_first_steps_against_reference_held_numbers(case, tmp_path):
     gx = load_golden(CASES[case][0].replace("g6_", "g6x_")) if os.path.exists(
         os.path.join(GOLDEN, CASES[case][0].replace("g6_", "g6x_") + ".npz")) else None
     self_d = float(gx["self_distance"]) if gx is not None else 0.0
+    # ... and the same yardstick for the warm-started steps, where both runs start from states that already differ
+    self_steps = gx["self_distance_steps"] if gx is not None and "self_distance_steps" in gx.files else None
+    if self_steps is not None:
+        print(f"{case}: the reference against itself per time step: distance {np.array2string(self_steps, precision=3)}, "
+              f"iterations {gx['iters_fast_steps']} (exact build {g['iters']})")
     if gx is not None:
         print(f"{case}: the reference against itself (-O3 -ffast-math build of src/solvers.f90): iter {int(gx['iter_fast'])} vs "
               f"{int(gx['iter_ref'])}, ||x_fast - x_ref|| / ||x_ref|| = {self_d:.3e}")
@@ -104,7 +109,8 @@ def test_first_steps_against_reference_held_numbers(case, tmp_path):
     for k, info in enumerate(seen):
         it_ref = int(g["iters"][k])
         rel2 = float(np.linalg.norm(info["xsketch"] - g["xsketch"][k]) / np.linalg.norm(g["xsketch"][k]))
-        bar_x = max(10 * tol, 1.5 * self_d)
+        sd = float(self_steps[k]) if self_steps is not None and k < len(self_steps) else (self_d if k == 0 else 0.0)
+        bar_x = max(10 * tol, 1.5 * max(sd, self_d if k == 0 else 0.0))
         print(f"{case} {tuple(int(v) for v in g['dims'])} step {k}: iter {info['iter']} / reference {it_ref}; ||b|| "
               f"{info['bnorm']:.9e} / {float(g['bnorm'][k]):.9e}; ||x|| {info['xnorm']:.6e} / {float(g['xnorm'][k]):.6e}; "
               f"||x - x_ref|| / ||x_ref|| = {rel2:.3e} (sketch; bar {bar_x:.3g}); true residual "
@@ -134,7 +140,8 @@ def test_first_steps_against_reference_held_numbers(case, tmp_path):
             ref_norm = float(g[f"vtk_field_{N}_{name}_norm"])
             our_norm = float(np.linalg.norm(ours[name].astype(np.float64)))
             # the source field does not depend on the solve: float32 rounding only
-            bar = 1e-6 if name == "Vector_field_SOURCE" else max(10 * tol, 1.5 * self_d)
+            sdN = float(self_steps[N]) if self_steps is not None and N < len(self_steps) else self_d
+            bar = 1e-6 if name == "Vector_field_SOURCE" else max(10 * tol, 1.5 * max(sdN, self_d))
             sk_ref = g[f"vtk_field_{N}_{name}_sketch"]
             rel2 = float(np.linalg.norm(O.count_sketch(ours[name].astype(np.float64)) - sk_ref) /
                          max(np.linalg.norm(sk_ref), 1e-300))

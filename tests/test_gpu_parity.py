@@ -196,6 +196,33 @@ def test_dropin_symbol_with_warm_starts(E):
     E.load_library().ec3d_invalidate()
 
 
+def test_dropin_symbol_notices_a_matrix_rebuilt_in_place(E, oracle):
+    """the drop-in caches the device matrix across calls (the reference assembles once,
+    src/EC3D.f90:115).  A caller that changes ONE coefficient in place, at the same addresses and not among the few
+    thousand sampled entries, must still get the answer of the matrix it passes: every entry is hashed (on host
+    threads, while the GPU already solves on the cached matrix) and a mismatch discards that solve."""
+    N = 24
+    valA, irow, jcol = oracle.poisson_csr(N, N, N)
+    n, nnz = N ** 3, len(valA)
+    assert nnz // 4096 > 1                       # so that most entries are NOT in the quick sample
+    b = oracle.bar_rhs(N)
+    x1 = np.zeros(n)
+    it1 = E.sprsBCGstabWR(valA, irow, jcol, n, b, x1, 1e-8, 5000)
+    p = (irow[n // 2] - 1) + 3                   # an entry of a middle row ...
+    step = nnz // 4096
+    while p % step == 0:                         # ... that the sample does not look at
+        p += 1
+    valA[p] *= 1.5                               # in place: same array, same address
+    x2 = np.zeros(n)
+    it2 = E.sprsBCGstabWR(valA, irow, jcol, n, b, x2, 1e-8, 5000)
+    with E.EC3DSolver() as s:                    # what a fresh conversion of the changed matrix gives
+        s.set_matrix_csr(valA, irow, jcol)
+        xr, itr, _ = s.solve(b, np.zeros(n), 1e-8, 5000)
+    assert it2 == itr and np.array_equal(x2, xr)
+    assert not np.array_equal(x2, x1)
+    E.load_library().ec3d_invalidate()
+
+
 # ------------------------------------------------------------------------------ edge cases
 def test_zero_rhs_returns_immediately(E):
     """src/solvers.f90:23: ||b|| = 0 -> iter = 0, x untouched."""
