@@ -76,6 +76,39 @@ __global__ __launch_bounds__(T) void k4like(int64_t ntiles, double alpha, double
     if ((threadIdx.x & 63) == 0) atomicAdd(&part[blockIdx.x], acc0);
 }
 
+// K4 shape with 4 CONSECUTIVE rows per thread (two adjacent 16-byte accesses per stream): a wave touches 2 KB of
+// every stream per pair of instructions instead of 1 KB
+template <int T, bool NTL, bool NTS>
+__global__ __launch_bounds__(T) void k4wide(int64_t ntiles, double alpha, double omega, const double *__restrict__ p,
+                                            const double *__restrict__ sv, const double *__restrict__ as,
+                                            const double *__restrict__ r0, double *__restrict__ x,
+                                            double *__restrict__ rv, double *part)
+{
+    double acc0 = 0.0, acc1 = 0.0;
+    const int64_t tile_rows = 4 * T;
+    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int64_t row = t * tile_rows + 4 * threadIdx.x;
+        d2 xv[2], pv[2], s[2], a[2], q[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            xv[h] = ld<NTL>(x + row + 2 * h); pv[h] = ld<NTL>(p + row + 2 * h); s[h] = ld<NTL>(sv + row + 2 * h);
+            a[h] = ld<NTL>(as + row + 2 * h); q[h] = ld<NTL>(r0 + row + 2 * h);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            d2 xn = d2{(xv[h].x + alpha * pv[h].x) + omega * s[h].x, (xv[h].y + alpha * pv[h].y) + omega * s[h].y};
+            d2 rn = d2{s[h].x - omega * a[h].x, s[h].y - omega * a[h].y};
+            st<NTS>(x + row + 2 * h, xn);
+            st<NTS>(rv + row + 2 * h, rn);
+            acc0 = acc0 + rn.x * rn.x; acc0 = acc0 + rn.y * rn.y;
+            acc1 = acc1 + rn.x * q[h].x; acc1 = acc1 + rn.y * q[h].y;
+        }
+    }
+    acc0 += acc1;
+    for (int off = 32; off > 0; off >>= 1) acc0 += __shfl_down(acc0, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&part[blockIdx.x], acc0);
+}
+
 // pure copy (float4-equivalent): the box's practical ceiling
 template <int T> __global__ __launch_bounds__(T) void copyk(int64_t ntiles, const double *__restrict__ a, double *__restrict__ b)
 {
@@ -137,6 +170,11 @@ int main(int argc, char **argv)
     RUN("k4 U2", 56, 256, (k4like<256, 2, false, false><<<g, 256>>>(ntiles, 0.5, 0.25, v[0], v[1], v[2], v[3], v[4], v[5], part)))
     RUN("k4 nt", 56, 256, (k4like<256, 1, true, true><<<g, 256>>>(ntiles, 0.5, 0.25, v[0], v[1], v[2], v[3], v[4], v[5], part)))
     RUN("k4 ntstore", 56, 256, (k4like<256, 1, false, true><<<g, 256>>>(ntiles, 0.5, 0.25, v[0], v[1], v[2], v[3], v[4], v[5], part)))
+    for (int g : grids) {
+        const int64_t ntiles = n / (4 * 256);
+        double ms = timeit([&] { k4wide<256, true, true><<<g, 256>>>(ntiles, 0.5, 0.25, v[0], v[1], v[2], v[3], v[4], v[5], part); });
+        printf("%-28s T=%d grid=%5d  %.3f ms  %.0f GB/s\n", "k4 wide4 nt", 256, g, ms, 56 * (double)n / ms / 1e6);
+    }
     RUN("k4 T512", 56, 512, (k4like<512, 1, false, false><<<g, 512>>>(ntiles, 0.5, 0.25, v[0], v[1], v[2], v[3], v[4], v[5], part)))
     return 0;
 }
