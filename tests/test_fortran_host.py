@@ -27,7 +27,7 @@ def build_demo(tmp, prog="ec3d_host_demo"):
 
 
 @pytest.mark.skipif(not os.path.exists(FC), reason="no Fortran compiler")
-@pytest.mark.parametrize("prog", ["ec3d_host_demo", "ec3d_timeloop_demo"])
+@pytest.mark.parametrize("prog", ["ec3d_host_demo", "ec3d_timeloop_demo", "ec3d_multi_demo"])
 def test_fortran_module_compiles_and_links(tmp_path, prog):
     exe = build_demo(str(tmp_path), prog)
     ldd = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
@@ -54,6 +54,39 @@ def test_fortran_host_assembles_and_solves(tmp_path):
         g["b0"].tofile(f)
         g["xin0"].tofile(f)
     subprocess.run([exe, fin, fout], check=True)
+    with open(fout, "rb") as f:
+        it = int(np.fromfile(f, np.int32, 1)[0])
+        x = np.fromfile(f, np.float64, n)
+    assert it == int(g["iters"][0])
+    assert np.linalg.norm(x - g["xout0"]) <= 10 * float(g["tol"]) * np.linalg.norm(g["xout0"])
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(FC), reason="no Fortran compiler")
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0"])
+def test_fortran_host_on_several_slabs(tmp_path, devices):
+    """examples/ec3d_multi_demo.f90: the same Fortran host through ec3d_multi_* -- global tables in, whole vectors
+    back, the reference's iteration count and solution."""
+    exe = build_demo(str(tmp_path), "ec3d_multi_demo")
+    g = load_golden("g2_conducting_hole_16x15x14")
+    sdz, sdy, sdx = g["geoPHYS"].shape
+    n = len(g["irow"]) - 1
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    with open(fin, "wb") as f:
+        np.array([sdx, sdy, sdz, g["valPHYS"].shape[0], int(g["itmax"])], np.int32).tofile(f)
+        np.array([float(g["dt"]), float(g["tol"])], np.float64).tofile(f)
+        np.asarray(g["delta"], np.float64).tofile(f)
+        np.ascontiguousarray(np.asarray(g["BND"], np.float64).T).tofile(f)
+        np.ascontiguousarray(g["geoPHYS"], np.int8).tofile(f)
+        np.ascontiguousarray(g["geoPHYS_C"], np.int32).tofile(f)
+        np.ascontiguousarray(np.asarray(g["valPHYS"], np.float64).T).tofile(f)
+        np.array([n], np.int32).tofile(f)
+        g["b0"].tofile(f)
+        g["xin0"].tofile(f)
+    r = subprocess.run([exe, fin, fout], env=dict(os.environ, EC3D_DEMO_DEVICES=devices, EC3D_MULTI_WATCHDOG="30"),
+                       capture_output=True, text=True)
+    print(r.stdout.strip())
+    assert r.returncode == 0, r.stdout + r.stderr
     with open(fout, "rb") as f:
         it = int(np.fromfile(f, np.int32, 1)[0])
         x = np.fromfile(f, np.float64, n)
