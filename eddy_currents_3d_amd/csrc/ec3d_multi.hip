@@ -256,8 +256,14 @@ int wait_posted(ec3d_multi *m, Slab &me, Slab &peer, int ch, uint64_t q)
 
 int cross_wait(hipStream_t stream, hipEvent_t ev)
 {
-    std::lock_guard<std::mutex> lk(g_cross_wait);
-    MHIP(hipStreamWaitEvent(stream, ev, 0));
+    // a precaution, not a measured need: EC3D_MULTI_SERIALIZE_WAITS=0 lets the threads issue them concurrently
+    static const bool serialize = !(getenv("EC3D_MULTI_SERIALIZE_WAITS") && atoi(getenv("EC3D_MULTI_SERIALIZE_WAITS")) == 0);
+    if (serialize) {
+        std::lock_guard<std::mutex> lk(g_cross_wait);
+        MHIP(hipStreamWaitEvent(stream, ev, 0));
+    } else {
+        MHIP(hipStreamWaitEvent(stream, ev, 0));
+    }
     return 0;
 }
 

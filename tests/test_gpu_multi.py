@@ -174,6 +174,27 @@ def test_multi_fields_reproduce_reference_file(E, world, plane_pitch):
             assert field_vtk_bytes(sdx, sdy, sdz, g["delta"], f) == g[f"vtk_field_{k}"].tobytes()
 
 
+def test_multi_refuses_what_it_cannot_cut(E):
+    """Edge cases of the decomposition: no matrix yet, fewer planes than ranks, A-V slabs thinner than the two
+    halo planes the one-sided A-U stencils need (src/EC3D.f90:697-706), a device ordinal that does not exist."""
+    g = load_golden("g2_conducting_hole_16x15x14")          # 14 planes
+    with E.EC3DMulti(2, devices=[0, 0]) as m:
+        with pytest.raises(E.EC3DError, match="no matrix"):
+            m.upload("B", np.zeros(8))
+        with pytest.raises(E.EC3DError, match="no matrix"):
+            m.solve_resident(1e-3, 10)
+    with E.EC3DMulti(4, devices=[0] * 4) as m:
+        with pytest.raises(E.EC3DError, match="fewer z-planes than ranks"):
+            m.assemble_poisson(8, 8, 3)
+    with E.EC3DMulti(8, devices=[0] * 8) as m:
+        with pytest.raises(E.EC3DError, match="at least two z-planes"):
+            m.assemble(g["geoPHYS"], g["geoPHYS_C"], g["valPHYS"], g["BND"], g["delta"], float(g["dt"]))
+    with pytest.raises(E.EC3DError, match="out of range"):
+        E.EC3DMulti(2, devices=[0, 99])
+    with pytest.raises(ValueError):
+        E.EC3DMulti(2, devices=[0])
+
+
 def test_multi_needs_the_devices_it_is_asked_for(E):
     import torch
     have = torch.cuda.device_count()
