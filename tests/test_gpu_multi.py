@@ -174,6 +174,21 @@ def test_multi_fields_reproduce_reference_file(E, world, plane_pitch):
             assert field_vtk_bytes(sdx, sdy, sdz, g["delta"], f) == g[f"vtk_field_{k}"].tobytes()
 
 
+def test_multi_csr_route_refuses_a_cube_read_as_three_blocks(E, oracle):
+    """A single-component cube whose plane count is a multiple of 3 passes the recogniser as "three blocks" (fine on
+    one GPU: the +-plane bands simply run across); cut into slabs block by block it would lose those couplings, so
+    the multi route must refuse it (status 7) and the drop-in then stays on one GPU."""
+    valA, irow, jcol = oracle.poisson_csr(16, 16, 24)
+    pr = E.probe_csr(valA, irow, jcol)
+    with E.EC3DMulti(2, devices=[0, 0]) as m:
+        if pr.structured:
+            with pytest.raises(E.EC3DError, match="couples across"):
+                m.set_matrix_csr(valA, irow, jcol)
+        else:
+            with pytest.raises(E.EC3DError, match="not recognised"):
+                m.set_matrix_csr(valA, irow, jcol)
+
+
 def test_multi_refuses_what_it_cannot_cut(E):
     """Edge cases of the decomposition: no matrix yet, fewer planes than ranks, A-V slabs thinner than the two
     halo planes the one-sided A-U stencils need (src/EC3D.f90:697-706), a device ordinal that does not exist."""
