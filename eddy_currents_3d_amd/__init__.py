@@ -5,6 +5,6 @@ The product is ``libec3d_hip.so`` (HIP, gfx950) behind the C ABI in ``include/ec
 this package is the thin Python host over it.  There is no CPU path: without the built library
 and a HIP device every call raises.
 """
-from .solver import EC3DSolver, EC3DMulti, EC3DError, sprsBCGstabWR, load_library, probe_csr  # noqa: F401
+from .solver import EC3DSolver, EC3DMulti, EC3DError, sprsBCGstabWR, load_library, probe_csr, probe_csr_multi  # noqa: F401
 
-__all__ = ["EC3DSolver", "EC3DMulti", "EC3DError", "sprsBCGstabWR", "load_library", "probe_csr"]
+__all__ = ["EC3DSolver", "EC3DMulti", "EC3DError", "sprsBCGstabWR", "load_library", "probe_csr", "probe_csr_multi"]

@@ -493,6 +493,22 @@ extern "C" int ec3d_probe_csr(int32_t n, const double *valA, const int32_t *irow
     return 0;
 }
 
+extern "C" int ec3d_probe_csr_multi(int32_t n, const double *valA, const int32_t *irow, const int32_t *jcol,
+                                    int32_t nranks, int32_t *cuttable)
+{
+    if (!cuttable || !valA || !irow || !jcol || nranks < 1) return 2;
+    *cuttable = 0;
+    SavHost S;
+    if (ec3d_csr_to_sav_host(n, valA, irow, jcol, S) != 0) {
+        ec3d_set_error("not recognised as the reference's A-V system on a grid: no z-planes to cut along");
+        return 0;
+    }
+    std::string why;
+    if (ec3d_sav_cuttable(S, nranks, why) == 0) *cuttable = 1;
+    else ec3d_set_error(why);
+    return 0;
+}
+
 extern "C" int ec3d_set_matrix_csr(ec3d_handle c, int32_t n, const double *valA, const int32_t *irow,
                                    const int32_t *jcol)
 {

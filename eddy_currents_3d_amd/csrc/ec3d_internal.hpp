@@ -284,6 +284,9 @@ void ec3d_host_matrix_to_csr(const HostMatrix &M, std::vector<int32_t> &irow, st
 
 // ec3d_sav_csr.cpp: 0, or -1 when the matrix does not have the structure
 int ec3d_csr_to_sav_host(int64_t n, const double *valA, const int32_t *irow, const int32_t *jcol, SavHost &S);
+// Can a recognised system be cut into `nranks` z-slabs?  0, or 2 (fewer than two planes per rank) / 7 (something
+// couples across the z faces of a component: not the reference's system on a box) with the reason in `why`.
+int ec3d_sav_cuttable(const SavHost &G, int nranks, std::string &why);
 // planes [e0, e1) of a recognised system as a slab that owns [k0, k1) (same pitch, classes and table)
 void ec3d_sav_slice(const SavHost &G, int64_t e0, int64_t e1, int64_t k0, int64_t k1, SavHost &L);
 

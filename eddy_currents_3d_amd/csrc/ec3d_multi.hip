@@ -929,25 +929,14 @@ extern "C" int ec3d_multi_set_matrix_csr(ec3d_multi_handle m, int32_t n, const d
         return 7;
     }
     const int64_t sdz = G.nCd / G.pitch;
-    if (m->n > 1 && sdz < (int64_t)H * m->n) {
-        ec3d_set_error("ec3d_multi_set_matrix_csr: every rank needs at least two z-planes");
-        return 2;
+    {
+        std::string why;
+        const int rc0 = ec3d_sav_cuttable(G, m->n, why);
+        if (rc0) {
+            ec3d_set_error("ec3d_multi_set_matrix_csr: " + why);
+            return rc0;
+        }
     }
-    // The four blocks are cut into slabs one by one, so nothing may couple ACROSS a block boundary through the
-    // +-plane bands: true for the reference's system (the first and last plane of a component are box-boundary
-    // rows, src/EC3D.f90:528-646), not for e.g. a single-component cube that the recogniser reads as three
-    // "blocks" of sdz/3 planes -- on one GPU that reading is harmless (bands simply run on), here it is not.
-    if (m->n > 1)
-        for (int d = 0; d < 4; ++d)
-            for (int side = 0; side < 2; ++side) {
-                const int64_t pl = side ? sdz - 1 : 0, base = d * G.nCd + pl * G.pitch;
-                for (int64_t q = 0; q < G.plane; ++q)
-                    if (G.table[(size_t)G.cls[(size_t)(base + q)] * 16 + (side ? 6 : 0)] != 0.0) {
-                        ec3d_set_error("ec3d_multi_set_matrix_csr: the matrix couples across what would be the z "
-                                       "faces of a component (not the reference's A-V system on a box); use one GPU");
-                        return 7;
-                    }
-            }
     m->sdx = (int32_t)G.sdx; m->sdy = (int32_t)(G.plane / G.sdx); m->sdz = (int32_t)sdz;
     m->kdz = G.plane;
     m->nC_glob = G.plane * sdz;

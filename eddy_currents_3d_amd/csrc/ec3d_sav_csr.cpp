@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <string>
 #include <unordered_map>
 
 namespace {
@@ -196,6 +197,31 @@ int ec3d_csr_to_sav_host(int64_t n, const double *valA, const int32_t *irow, con
     S.pitch = pitch;
     S.nCd = nCd;
     S.n_dev = n_dev;
+    return 0;
+}
+
+// The four blocks are cut into slabs one by one, so nothing may couple ACROSS a block boundary through the
+// +-plane bands: true for the reference's system (the first and last plane of a component are box-boundary
+// rows, src/EC3D.f90:528-646), not for e.g. a single-component cube that the recogniser reads as three
+// "blocks" of sdz/3 planes -- on one GPU that reading is harmless (bands simply run on), cut into slabs it is not.
+int ec3d_sav_cuttable(const SavHost &G, int nranks, std::string &why)
+{
+    const int64_t sdz = G.nCd / G.pitch;
+    if (nranks > 1 && sdz < 2 * (int64_t)nranks) {
+        why = "every rank needs at least two z-planes";
+        return 2;
+    }
+    if (nranks > 1)
+        for (int d = 0; d < 4; ++d)
+            for (int side = 0; side < 2; ++side) {
+                const int64_t pl = side ? sdz - 1 : 0, base = d * G.nCd + pl * G.pitch;
+                for (int64_t q = 0; q < G.plane; ++q)
+                    if (G.table[(size_t)G.cls[(size_t)(base + q)] * 16 + (side ? 6 : 0)] != 0.0) {
+                        why = "the matrix couples across what would be the z faces of a component (not the reference's "
+                              "A-V system on a box); use one GPU";
+                        return 7;
+                    }
+            }
     return 0;
 }
 

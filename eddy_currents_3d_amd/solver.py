@@ -64,7 +64,7 @@ EXPORTS = ["sprsbcgstabwr_", "ec3d_invalidate", "ec3d_create", "ec3d_destroy", "
            "ec3d_multi_assemble_poisson", "ec3d_multi_assemble", "ec3d_multi_set_matrix_csr", "ec3d_multi_size",
            "ec3d_multi_upload", "ec3d_multi_download", "ec3d_multi_solve", "ec3d_multi_solve_resident",
            "ec3d_multi_rhs_step", "ec3d_multi_post_update", "ec3d_multi_vtk_fields", "ec3d_multi_iterate_begin",
-           "ec3d_multi_iterate", "ec3d_multi_synchronize", "ec3d_true_residual", "ec3d_multi_true_residual", "ec3d_get_visit_order"]
+           "ec3d_multi_iterate", "ec3d_multi_synchronize", "ec3d_true_residual", "ec3d_multi_true_residual", "ec3d_get_visit_order", "ec3d_probe_csr_multi"]
 
 _f64 = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
 _i32 = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
@@ -144,6 +144,7 @@ def load_library(path: str | None = None) -> C.CDLL:
                                               np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS"),
                                               C.POINTER(C.c_int32)]
     L.ec3d_probe_csr.argtypes = [C.c_int32, _f64, _i32, _i32, C.POINTER(CsrProbe)]
+    L.ec3d_probe_csr_multi.argtypes = [C.c_int32, _f64, _i32, _i32, C.c_int32, C.POINTER(C.c_int32)]
     L.ec3d_get_ulist.argtypes = [hp, _i32]
     L.ec3d_set_stream.argtypes = [hp, hp]
     L.ec3d_assemble_poisson_slab.argtypes = [hp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f64, _f64]
@@ -201,6 +202,19 @@ def probe_csr(valA, irow, jcol):
     if rc:
         raise EC3DError(f"ec3d_probe_csr failed ({rc})")
     return out
+
+
+def probe_csr_multi(valA, irow, jcol, nranks: int):
+    """Host-only: (cuttable, reason) -- would the library cut this CSR matrix into `nranks` z-slabs
+    (EC3DMulti.set_matrix_csr, the drop-in symbol under EC3D_NGPU)?"""
+    L = load_library()
+    ok = C.c_int32(0)
+    irow = np.ascontiguousarray(irow, np.int32)
+    rc = L.ec3d_probe_csr_multi(len(irow) - 1, np.ascontiguousarray(valA, np.float64), irow,
+                                np.ascontiguousarray(jcol, np.int32), int(nranks), C.byref(ok))
+    if rc:
+        raise EC3DError(f"ec3d_probe_csr_multi failed ({rc})")
+    return bool(ok.value), ("" if ok.value else L.ec3d_last_error().decode())
 
 
 def sprsBCGstabWR(valA, irow, jcol, n, b, x, tolerance, itmax):

@@ -311,6 +311,12 @@ typedef struct {
 int ec3d_probe_csr(int32_t n, const double *valA, const int32_t *irow, const int32_t *jcol,
                    ec3d_csr_probe *out);
 
+/* Host-only as well: would ec3d_multi_set_matrix_csr / sprsbcgstabwr_ under EC3D_NGPU=nranks cut this matrix into
+ * nranks z-slabs?  *cuttable = 0 leaves the reason in ec3d_last_error(): not the structured form, fewer than two
+ * planes per rank, or couplings across the z faces of a component. */
+int ec3d_probe_csr_multi(int32_t n, const double *valA, const int32_t *irow, const int32_t *jcol, int32_t nranks,
+                         int32_t *cuttable);
+
 /* Time `reps` back-to-back launches of one kernel with hipEvents on the library's stream and
  * return the average per launch in milliseconds.  kernel: */
 enum { EC3D_K_SPMV = 0,   /* y = A p                        72 B/row             */

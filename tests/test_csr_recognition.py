@@ -79,3 +79,25 @@ def test_single_component_box_in_three_blocks(E):
     valA, irow, jcol = O.poisson_csr(8, 7, 15)
     p = E.probe_csr(valA, irow, jcol)
     assert p.structured == 1 and (p.sdx, p.sdy, p.sdz, p.n_cond) == (8, 7, 5, 0)
+
+
+def test_which_matrices_can_be_cut_into_z_slabs(oracle):
+    """ec3d_probe_csr_multi (host only): the decision the multi-GPU CSR route and the drop-in under EC3D_NGPU take.
+    The reference's captured A-V matrix (14 planes) can be cut into up to 7 slabs of two planes; a single-component
+    cube that the recogniser reads as three "blocks" couples across their faces and cannot; a matrix without a grid
+    has nothing to cut along."""
+    import eddy_currents_3d_amd as E
+    g = load_golden("g2_conducting_hole_16x15x14")
+    for nranks, want in ((1, True), (2, True), (7, True), (8, False)):
+        ok, why = E.probe_csr_multi(g["valA"], g["irow"], g["jcol"], nranks)
+        assert ok == want, (nranks, why)
+        if not want:
+            assert "two z-planes" in why
+    valA, irow, jcol = oracle.poisson_csr(16, 16, 24)
+    if E.probe_csr(valA, irow, jcol).structured:
+        assert E.probe_csr_multi(valA, irow, jcol, 1)[0]
+        ok, why = E.probe_csr_multi(valA, irow, jcol, 2)
+        assert not ok and "couples across" in why
+    n = 64
+    ok, why = E.probe_csr_multi(np.ones(n), np.arange(1, n + 2, dtype=np.int32), np.arange(1, n + 1, dtype=np.int32), 2)
+    assert not ok and "not recognised" in why
