@@ -1,0 +1,50 @@
+"""bench.py's contract with the driver: one JSON line with the agreed fields; `--gpus N` from a bare `python bench.py`
+starts by itself (in-library multi-GPU) and asks for the devices it needs before touching a GPU."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import REPO
+
+BENCH = os.path.join(REPO, "bench.py")
+REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline"]
+
+
+def _run(args, timeout=600, env=None):
+    return subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, timeout=timeout,
+                          env=dict(os.environ, **(env or {})))
+
+
+def test_more_gpus_than_the_machine_has_is_said_before_any_gpu_call():
+    import torch
+    have = torch.cuda.device_count()
+    r = _run(["--gpus", str(have + 1), "--steps", "2", "--warmup", "1"])
+    assert r.returncode != 0
+    assert f"needs {have + 1} devices, this machine has {have}" in (r.stdout + r.stderr)
+    assert "torch.distributed.run" not in (r.stdout + r.stderr)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args,ngpu", [(["--grid", "64", "--no-cpu-baseline"], 1),
+                                       (["--grid", "64", "--gpus", "2", "--devices", "0,0"], 2),
+                                       (["--grid", "64", "--force-dist", "--no-cpu-baseline"], 1)])
+def test_one_json_line_with_the_agreed_fields(args, ngpu):
+    r = _run(args + ["--steps", "4", "--warmup", "2"], env={"EC3D_MULTI_WATCHDOG": "30"})
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["n_gpus"] == ngpu and d["steps"] == 4 and d["warmup"] == 2 and d["dtype"] == "f64"
+    assert d["unit"] == "DOF*iters/s" and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["value"] == pytest.approx(64 ** 3 * 4 / (d["ms_per_step"] * 4e-3), rel=1e-6)
+    assert "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s"
+    assert rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"])
+    assert "traffic" in rf
