@@ -307,57 +307,71 @@ def test_single_rank_entry_points_refuse_a_dist_configured_handle(E):
         assert it == it_ref and np.array_equal(x, x_ref)
 
 
-# ---- a machine with at least two GPUs (skipped on the one-GPU test box; the driver's 8-GPU node runs them) ----
+# ---- a machine with at least two GPUs (skipped on the one-GPU test box).  Both run in CHILD processes with their
+# own time limits: nobody has run them on two devices yet, and a deadlock there must fail one test, not end the run
+# (the library's watchdog aborts a process whose threads are stuck inside the runtime).
 def _two_devices():
     import torch
     return torch.cuda.device_count() >= 2
 
 
-def test_multi_on_two_real_devices_equals_two_slabs_on_one(E, oracle):
+_TWO_DEVICE_SCRIPT = r"""
+import sys
+import numpy as np
+sys.path.insert(0, %(repo)r)
+import eddy_currents_3d_amd as E
+sdx, sdy, sdz, tol = 64, 64, 48, 1e-8
+b = np.random.Generator(np.random.PCG64(5)).standard_normal(sdx * sdy * sdz)
+res, av = {}, {}
+g = np.load(%(golden)r)
+for devs in ([0, 0], [0, 1]):
+    with E.EC3DMulti(2, devices=devs) as m:
+        m.assemble_poisson(sdx, sdy, sdz)
+        res[tuple(devs)] = m.solve(b, np.zeros(m.n), tol, 5000)
+    with E.EC3DMulti(2, devices=devs) as m:
+        m.assemble(g["geoPHYS"], g["geoPHYS_C"], g["valPHYS"], g["BND"], g["delta"], float(g["dt"]))
+        av[tuple(devs)] = m.solve(g["b0"], g["xin0"], float(g["tol"]), int(g["itmax"]))
+for r in (res, av):
+    assert r[(0, 0)][1] == r[(0, 1)][1] and np.array_equal(r[(0, 0)][0], r[(0, 1)][0]), "two devices differ from one"
+print("TWO_DEVICES_OK", res[(0, 1)][1], av[(0, 1)][1])
+"""
+
+
+def test_multi_on_two_real_devices_equals_two_slabs_on_one():
     """Peer copies over xGMI, remote reads of the partial sums and cross-device event waits must give exactly what
     the same two slabs give on one card."""
     if not _two_devices():
         pytest.skip("needs 2 GPUs")
-    sdx, sdy, sdz, tol = 64, 64, 48, 1e-8
-    b = np.random.Generator(np.random.PCG64(5)).standard_normal(sdx * sdy * sdz)
-    res = {}
-    for devs in ([0, 0], [0, 1]):
-        with E.EC3DMulti(2, devices=devs) as m:
-            m.assemble_poisson(sdx, sdy, sdz)
-            res[tuple(devs)] = m.solve(b, np.zeros(m.n), tol, 5000)
-    g = load_golden("g2_conducting_hole_16x15x14")
-    av = {}
-    for devs in ([0, 0], [0, 1]):
-        with E.EC3DMulti(2, devices=devs) as m:
-            m.assemble(g["geoPHYS"], g["geoPHYS_C"], g["valPHYS"], g["BND"], g["delta"], float(g["dt"]))
-            av[tuple(devs)] = m.solve(g["b0"], g["xin0"], float(g["tol"]), int(g["itmax"]))
-    for r in (res, av):
-        assert r[(0, 0)][1] == r[(0, 1)][1] and np.array_equal(r[(0, 0)][0], r[(0, 1)][0])
+    code = _TWO_DEVICE_SCRIPT % dict(repo=REPO, golden=os.path.join(REPO, "tests", "golden",
+                                                                    "g2_conducting_hole_16x15x14.npz"))
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, EC3D_MULTI_WATCHDOG="30"),
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "TWO_DEVICES_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
 
 
-def _nccl_worker(rank, world, port, out):
-    import sys
-    sys.path.insert(0, REPO)
-    import datetime
-    import torch
-    import torch.distributed as dist
-    from eddy_currents_3d_amd.dist import SlabSolver
-    from bench import bar_rhs
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    torch.cuda.set_device(rank)
-    dist.init_process_group("nccl", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120),
-                            device_id=torch.device("cuda", rank))
-    try:
-        s = SlabSolver.poisson_cube(64, rank, world, device=rank)
-        s.set_rhs(bar_rhs(64, s.k0, s.k1), np.zeros(s.n_local))
-        it = s.solve(1e-8, 20000)
-        x = s.gather_x()
-        if rank == 0:
-            np.save(out, np.concatenate([[it], x]))
-        s.ops.close()
-    finally:
-        dist.destroy_process_group()
+_NCCL_SCRIPT = r"""
+import os, sys, datetime
+import numpy as np
+sys.path.insert(0, %(repo)r)
+import torch
+import torch.distributed as dist
+from eddy_currents_3d_amd.dist import SlabSolver
+from bench import bar_rhs
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(rank)
+dist.init_process_group("nccl", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120),
+                        device_id=torch.device("cuda", rank))
+try:
+    s = SlabSolver.poisson_cube(64, rank, world, device=rank)
+    s.set_rhs(bar_rhs(64, s.k0, s.k1), np.zeros(s.n_local))
+    it = s.solve(1e-8, 20000)
+    x = s.gather_x()
+    if rank == 0:
+        np.save(%(out)r, np.concatenate([[it], x]))
+    s.ops.close()
+finally:
+    dist.destroy_process_group()
+"""
 
 
 def test_two_ranks_over_rccl_match_the_undivided_solve(E, tmp_path):
@@ -366,13 +380,25 @@ def test_two_ranks_over_rccl_match_the_undivided_solve(E, tmp_path):
     if not _two_devices():
         pytest.skip("needs 2 GPUs")
     import socket
-    import torch.multiprocessing as mp
     from bench import bar_rhs
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     out = str(tmp_path / "x.npy")
-    mp.spawn(_nccl_worker, args=(2, port, out), nprocs=2, join=True)
+    script = str(tmp_path / "rank.py")
+    open(script, "w").write(_NCCL_SCRIPT % dict(repo=REPO, out=out))
+    procs = [subprocess.Popen([sys.executable, script], env=dict(os.environ, RANK=str(r), WORLD_SIZE="2",
+                                                                 MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=300)[0])
+    except subprocess.TimeoutExpired:
+        for p in procs:
+            p.kill()
+        pytest.fail("two ranks over RCCL did not finish within 300 s")
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
     r = np.load(out)
     it, x = int(r[0]), r[1:]
     b = bar_rhs(64)
