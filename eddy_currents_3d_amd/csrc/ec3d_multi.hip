@@ -1202,3 +1202,23 @@ extern "C" int ec3d_multi_true_residual(ec3d_multi_handle m, double *rel, double
     *rel = sb > 0.0 ? std::sqrt(sr / sb) : std::sqrt(sr);
     return 0;
 }
+
+// y = A*x over the slabs (src/solvers.f90:54-61), host vectors in the global numbering: x goes to every slab's P
+// (owned and halo entries), the P halo planes are exchanged the way an iteration does it, every slab multiplies,
+// the owned parts of AP come back.  Parity probe of the slab operators and of the exchange together.
+extern "C" int ec3d_multi_spmv(ec3d_multi_handle m, const double *x, double *y)
+{
+    int rc = need(m, "ec3d_multi_spmv");
+    if (rc) return rc;
+    return run_all(m, [&](int r) -> int {
+        Slab &s = *m->slab[(size_t)r];
+        int rc2 = slab_upload(m, s, EC3D_VEC_P, x);
+        if (rc2) return rc2;
+        if ((rc2 = halo_start(m, s, CH_P))) return rc2;
+        if ((rc2 = halo_wait(s, CH_P))) return rc2;
+        ec3d_launch_spmv(s.c->A.view(), s.c->sweep_s, s.c->vec[EC3D_VEC_P], s.c->vec[EC3D_VEC_AP], s.c->stream);
+        MHIP(hipGetLastError());
+        if ((rc2 = drain(s))) return rc2;
+        return slab_download(m, s, EC3D_VEC_AP, y);
+    });
+}

@@ -64,7 +64,7 @@ EXPORTS = ["sprsbcgstabwr_", "ec3d_invalidate", "ec3d_create", "ec3d_destroy", "
            "ec3d_multi_assemble_poisson", "ec3d_multi_assemble", "ec3d_multi_set_matrix_csr", "ec3d_multi_size",
            "ec3d_multi_upload", "ec3d_multi_download", "ec3d_multi_solve", "ec3d_multi_solve_resident",
            "ec3d_multi_rhs_step", "ec3d_multi_post_update", "ec3d_multi_vtk_fields", "ec3d_multi_iterate_begin",
-           "ec3d_multi_iterate", "ec3d_multi_synchronize", "ec3d_true_residual", "ec3d_multi_true_residual", "ec3d_get_visit_order", "ec3d_probe_csr_multi"]
+           "ec3d_multi_iterate", "ec3d_multi_synchronize", "ec3d_true_residual", "ec3d_multi_true_residual", "ec3d_get_visit_order", "ec3d_probe_csr_multi", "ec3d_multi_spmv"]
 
 _f64 = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
 _i32 = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
@@ -173,6 +173,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.ec3d_multi_solve_resident.argtypes = [hp, C.c_double, C.c_int32, C.POINTER(C.c_int32)]
     L.ec3d_multi_rhs_step.argtypes = [hp, C.c_int32, C.c_int32, _i32, _f64]
     L.ec3d_multi_post_update.argtypes = [hp]
+    L.ec3d_multi_spmv.argtypes = [hp, _f64, _f64]
     L.ec3d_multi_vtk_fields.argtypes = [hp, _f64, hp, hp, hp, hp]
     L.ec3d_multi_iterate_begin.argtypes = [hp]
     L.ec3d_multi_iterate.argtypes = [hp, C.c_int32, C.c_int32, hp]
@@ -626,6 +627,11 @@ class EC3DMulti:
         rel, bn = C.c_double(0), C.c_double(0)
         _chk(self.L, self.L.ec3d_multi_true_residual(self.h, C.byref(rel), C.byref(bn)), "ec3d_multi_true_residual")
         return rel.value, bn.value
+
+    def spmv(self, x):
+        y = np.zeros(self.n)
+        _chk(self.L, self.L.ec3d_multi_spmv(self.h, np.ascontiguousarray(x, np.float64), y), "ec3d_multi_spmv")
+        return y
 
     def rhs_step(self, src_index, src_value, moving: bool = False):
         idx = np.ascontiguousarray(src_index, np.int32)

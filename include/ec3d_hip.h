@@ -250,6 +250,9 @@ int ec3d_multi_solve_resident(ec3d_multi_handle mh, double tolerance, int32_t it
 int ec3d_multi_rhs_step(ec3d_multi_handle mh, int32_t moving, int32_t nsrc, const int32_t *src_index,
                         const double *src_value);
 int ec3d_multi_post_update(ec3d_multi_handle mh);
+/* y = A*x over the slabs, host vectors in the global numbering (as ec3d_spmv): parity probe of the slab
+ * operators and of the halo exchange together */
+int ec3d_multi_spmv(ec3d_multi_handle mh, const double *x, double *y);
 int ec3d_multi_true_residual(ec3d_multi_handle mh, double *rel, double *bnorm); /* as ec3d_true_residual */
 int ec3d_multi_vtk_fields(ec3d_multi_handle mh, const double *delta, float *field_A, float *field_eddy,
                           float *field_source, float *field_B);
