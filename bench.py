@@ -13,7 +13,9 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W     -> one JSO
       - plain `python bench.py --gpus N`: ONE process, N devices, inside the library (include/ec3d_hip.h
         section 2c, csrc/ec3d_multi.hip): one host thread per slab, halo planes pulled over peer access
         (xGMI) behind the interior planes, partial sums read in place, rank-ordered.  Exits with
-        "needs N devices" before touching a GPU when the machine has fewer;
+        "needs N devices" before touching a GPU when the machine has fewer; before anything is timed, A*x over the
+        N devices is checked bit for bit against one device and the reductions through the true residual
+        (`verified` in the line; a broken transport ends the run without a number);
       - under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` (the driver's form):
         one process per GPU, torch.distributed (backend nccl = RCCL), halo planes by send/recv and the dot
         products by all_gather (eddy_currents_3d_amd/dist.py);
@@ -152,6 +154,8 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="use the z-slab/torch.distributed path even with one rank (rehearsal on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="in-library multi-GPU path: skip the A*x / reduction check against one device before timing")
     ap.add_argument("--cpu-grid", type=int, default=256, help="cube edge of the cpu_baseline sample")
     ap.add_argument("--cpu-iters", type=int, default=20, help="fixed iteration count of the cpu_baseline sample")
     ap.add_argument("--devices", type=str, default=None,
@@ -222,6 +226,36 @@ def main():
         else:
             s.assemble_poisson(N, N, N)
             s.upload("B", bar_rhs(N))
+        verified = None
+        if not args.no_verify:
+            # Before anything is timed: the transport between the devices must be RIGHT, not only fast.  A*x over the
+            # G slabs (slab operators + halo planes pulled over peer access) against one device, bit for bit, and the
+            # reduction path (every rank's sums read in place) through the true residual of (b, x).
+            xs = np.sin(0.37 * np.arange(n_global, dtype=np.float64))
+            y_multi = s.spmv(xs)
+            s.upload("X", xs)
+            res_multi = s.true_residual()
+            with E.EC3DSolver(device=(devices or [0])[0], dictionary=args.format == "dict") as one:
+                if args.workload == "av":
+                    one.assemble(geo, geoC, valPHYS, BND, delta, dt)
+                    one.upload("B", b)
+                else:
+                    one.assemble_poisson(N, N, N)
+                    one.upload("B", bar_rhs(N))
+                y_one = one.spmv(xs)
+                one.upload("X", xs)
+                res_one = one.true_residual()
+            if not np.array_equal(y_multi, y_one):
+                bad = int(np.count_nonzero(y_multi != y_one))
+                raise SystemExit(f"bench.py: A*x over {G} devices differs from one device in {bad} of {n_global} rows "
+                                 f"-- the halo exchange between the GPUs is broken; no number reported")
+            if abs(res_multi[0] - res_one[0]) > 1e-9 * abs(res_one[0]) or abs(res_multi[1] - res_one[1]) > 1e-9 * res_one[1]:
+                raise SystemExit(f"bench.py: reductions over {G} devices give {res_multi}, one device {res_one}; "
+                                 f"no number reported")
+            verified = (f"A*x over {G} devices == one device bit for bit ({n_global} rows); ||b - A x||/||b|| and ||b|| "
+                        f"equal to {abs(res_multi[0] - res_one[0]) / abs(res_one[0]):.1e} / "
+                        f"{abs(res_multi[1] - res_one[1]) / res_one[1]:.1e}")
+            del xs, y_multi, y_one
         s.upload("X", np.zeros(n_global))
         s.iterate_begin()
         s.iterate(1, W)
@@ -341,6 +375,8 @@ def main():
                          "algorithmic_bytes_per_launch": fmt_bytes[dom] * rows,
                          "avg_launch_ms": kernel_ms[dom]},
         }
+        if in_library and verified:
+            out["verified"] = verified
         if spmv_ms is not None:
             out["spmv"] = {"kernel": "k_spmv (y = A*x, 7 bands)", "ms": spmv_ms,
                            "survey_bytes_per_row": 72, "survey_GBps": 72 * rows / spmv_ms / 1e6,
