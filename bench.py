@@ -312,6 +312,36 @@ def main():
         s = SlabSolver.poisson_cube(N, rank, world, device=local_rank, dictionary=args.format == "dict")
         s.set_rhs(bar_rhs(N, s.k0, s.k1), np.zeros(s.n_local))
         s.iterate_begin()
+        verified = None
+        if not args.no_verify:
+            # Before anything is timed: this rank's part of A*x, with the halo planes coming from the z-neighbours
+            # over RCCL, against the undivided operator on this rank's own GPU, bit for bit; and ||b|| as every rank
+            # derives it from the all-gathered sums against the value computed on the host.
+            from eddy_currents_3d_amd.dist import K1
+            xs = np.sin(0.37 * np.arange(n_global, dtype=np.float64))
+            kd = N * N
+            with s.ops.context():
+                s.ops.set_vector("P", xs[s.k0 * kd:s.k1 * kd])
+                s.exchange("P")
+                s.ops.step(K1, 1, 0.0)                       # AP = A P on the slab (src/solvers.f90:30)
+            ap = s.ops.get_vector("AP")
+            with E.EC3DSolver(device=local_rank, dictionary=args.format == "dict") as one:
+                one.assemble_poisson(N, N, N)
+                y_one = one.spmv(xs)[s.k0 * kd:s.k1 * kd]
+            bad = int(np.count_nonzero(ap != y_one))
+            bn = s.local.read_state()[2]
+            bn_host = float(np.linalg.norm(bar_rhs(N)))
+            flag = torch.tensor([bad, int(abs(bn - bn_host) > 1e-12 * bn_host)], dtype=torch.int64, device="cuda")
+            dist.all_reduce(flag)
+            if int(flag[0]) or int(flag[1]):
+                raise SystemExit(f"bench.py rank {rank}: A*x over {world} ranks differs from one GPU in {bad} rows of this "
+                                 f"slab (all ranks: {int(flag[0])}), ||b|| {bn!r} vs {bn_host!r} -- the exchange over "
+                                 f"RCCL is broken; no number reported")
+            verified = (f"A*x over {world} ranks (halo planes over RCCL) == one GPU bit for bit on every slab; ||b|| from "
+                        f"the all-gathered sums equal to {abs(bn - bn_host) / bn_host:.1e}")
+            del xs, ap, y_one
+            s.set_rhs(bar_rhs(N, s.k0, s.k1), np.zeros(s.n_local))
+            s.iterate_begin()
         s.iterate(1, W)
         torch.cuda.synchronize()
         dist.barrier()
@@ -375,7 +405,7 @@ def main():
                          "algorithmic_bytes_per_launch": fmt_bytes[dom] * rows,
                          "avg_launch_ms": kernel_ms[dom]},
         }
-        if in_library and verified:
+        if (in_library or use_dist) and verified:
             out["verified"] = verified
         if spmv_ms is not None:
             out["spmv"] = {"kernel": "k_spmv (y = A*x, 7 bands)", "ms": spmv_ms,

@@ -49,5 +49,5 @@ def test_one_json_line_with_the_agreed_fields(args, ngpu):
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s"
     assert rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"])
     assert "traffic" in rf
-    if "--devices" in args:
+    if "--devices" in args or "--force-dist" in args:      # both multi-GPU paths check their transport before timing
         assert "bit for bit" in d["verified"]
