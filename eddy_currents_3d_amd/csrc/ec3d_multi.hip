@@ -290,8 +290,10 @@ int halo_start(ec3d_multi *m, Slab &s, int v)
         s.at.store("halo_start:copy");
         double *mine = s.c->vec[vi];
         const double *theirs = peer.c->vec[vi];
+        // EC3D_MULTI_FORCE_PEER_API=1: the peer-copy call also between slabs of ONE device (tests on a one-GPU box)
+        static const bool force_peer = getenv("EC3D_MULTI_FORCE_PEER_API") && atoi(getenv("EC3D_MULTI_FORCE_PEER_API")) != 0;
         for (const Copy &c : cp) {
-            if (peer.device == s.device)
+            if (peer.device == s.device && !force_peer)
                 MHIP(hipMemcpyAsync(mine + c.dst, theirs + c.src, (size_t)c.cnt * 8, hipMemcpyDeviceToDevice, s.side));
             else
                 MHIP(hipMemcpyPeerAsync(mine + c.dst, s.device, theirs + c.src, peer.device, (size_t)c.cnt * 8, s.side));
