@@ -166,6 +166,16 @@ static int choose_sweep(ec3d_ctx *c)
         sw.own_lo[q] = c->own_lo[q];
         sw.own_hi[q] = c->own_hi[q];
     }
+    // A slab of the structured form with tile-aligned planes: sweep the OWNED planes of every block only.  The
+    // halo planes carry the neighbours' values and are never computed, stored or counted (rows streamed per
+    // rank = rows owned), so no kernel needs the ownership ranges either.
+    if (c->A.sav && c->nown == 4 && c->pitch > 0 && c->pitch % EC3D_TILE == 0 && c->A.ulist) {
+        sw.win_blk = c->nCd / EC3D_TILE;
+        sw.win_t0 = c->own_lo[0] / EC3D_TILE;
+        sw.win_nt = (c->own_hi[0] - c->own_lo[0]) / EC3D_TILE;
+        sw.ntiles = 3 * sw.win_nt;
+        sw.nown = 0;
+    }
     // 256 CUs x 3 workgroups: measured best on 512^3 (whole multiples of the CU count matter;
     // 768 > 1024 > 512 > 2048)
     int want = c->nblk_request > 0 ? c->nblk_request : 768;
@@ -214,6 +224,9 @@ static int choose_sweep(ec3d_ctx *c)
     const DevMatrix &A = c->A;
     int zm = c->zm_request;
     if (const char *e = getenv("EC3D_ZMARCH")) zm = atoi(e);
+    // the z-marching kernels carry no ownership ranges: a slab whose owned rows are not a window of whole
+    // planes (bands + tail A-V slabs) keeps the plain map
+    if (sw.nown > 0) zm = 0;
     if (zm != 0 && A.nb == 7 && A.off[3] == 0 && A.off[0] == -A.off[6] && A.off[6] % EC3D_TILE == 0) {
         const int64_t tpp = A.off[6] / EC3D_TILE;
         const int64_t nplanes = (sw.ntiles + tpp - 1) / tpp;
@@ -713,7 +726,7 @@ static void visit_of(const ec3d_ctx *c, const Sweep &sw, std::vector<std::vector
         std::vector<int32_t> v;
         for (int64_t it = 0;; ++it) {
             const int64_t tile = ec3d_tile_of(sw, b, it);
-            if (tile >= sw.ntiles) break;
+            if (tile < 0) break;
             v.push_back((int32_t)tile);
         }
         for (int64_t l = b; l < sw.ulist_n; l += sw.nblk) v.push_back(ul[(size_t)l]);

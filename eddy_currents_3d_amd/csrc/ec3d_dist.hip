@@ -70,7 +70,7 @@ extern "C" int ec3d_dist_set_boundary_rows(ec3d_handle c, int32_t nranges, const
     // tiles the vector kernels visit: the front sweep and the occupied U tiles of the structured form
     const Sweep &sw = c->sweep;
     std::vector<int32_t> visit((size_t)sw.ntiles);
-    for (int64_t t = 0; t < sw.ntiles; ++t) visit[(size_t)t] = (int32_t)t;
+    for (int64_t t = 0; t < sw.ntiles; ++t) visit[(size_t)t] = (int32_t)ec3d_phys_tile(sw, t);
     if (sw.ulist_n) {
         std::vector<int32_t> ul((size_t)sw.ulist_n);
         EC3D_HIP(hipMemcpy(ul.data(), sw.ulist, ul.size() * 4, hipMemcpyDeviceToHost));

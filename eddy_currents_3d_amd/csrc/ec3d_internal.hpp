@@ -61,7 +61,7 @@ struct RedSrc {
 
 // blockIdx -> tile map (XCD aware when S > 0): see ec3d_tile_of() in ec3d_kernels.hip
 struct Sweep {
-    int64_t ntiles;
+    int64_t ntiles; // LOGICAL tiles of the front sweep (see win_* below); the U-block list comes behind them
     int64_t n; // rows owned; rows in [n, ntiles*EC3D_TILE) are padding
     int nblk;
     int S;
@@ -71,10 +71,17 @@ struct Sweep {
     // xy-plane ("column") and walks zm_pps consecutive planes, so x[r-kdz], x[r] stay in registers
     int zm_tpp;  // tiles per plane = kdz / 512
     int zm_pps;  // planes per z segment
-    // rows that count in the dot products when this handle holds an A-V slab on an extended grid
-    // (nown > 0): [Ax | Ay | Az | U] each contribute one owned index range
+    // rows that count in the dot products when this handle holds an A-V slab on an extended grid whose planes
+    // are NOT tile aligned (nown > 0; bands + tail, or the structured form on a small grid): [Ax | Ay | Az | U]
+    // each contribute one owned index range.  Tile-aligned structured slabs use the window below instead.
     int nown;
     int64_t own_lo[4], own_hi[4];
+    // Window (structured A-V slab with tile-aligned planes, win_nt > 0): a block of the device layout holds
+    // win_blk tiles (all held planes), of which the win_nt tiles from win_t0 on are OWNED; the halo planes'
+    // rows are read (neighbours' values) but never swept: no kernel computes or stores there and every swept
+    // row counts in the dot products.  Logical tile L of the front sweep is physical tile
+    // (L / win_nt) * win_blk + win_t0 + L % win_nt; the same in planes (tiles / zm_tpp) for the z-march.
+    int64_t win_nt, win_blk, win_t0;
     // split launches of the SpMV kernels in a z-slab, so the halo exchange overlaps the interior:
     // zm_pl0 > 0: z-march over planes [zm_pl0, zm_pl0 + zm_npl) only (interior launch);
     // bnd_last >= 0: the launch covers planes 0 and bnd_last only (boundary launch, plain tile order)
@@ -88,33 +95,46 @@ struct Sweep {
     int ulist_n;
 };
 
-// blockIdx -> tile map of a sweep (host and device: ec3d_get_visit_order enumerates with the same function)
+// logical -> physical tile of the front sweep (identity without a window)
+template <class SW>
+__host__ __device__ inline int64_t ec3d_phys_tile(const SW &sw, int64_t t)
+{
+    if (sw.win_nt <= 0) return t;
+    return (t / sw.win_nt) * sw.win_blk + sw.win_t0 + t % sw.win_nt;
+}
+
+// blockIdx -> tile map of a sweep (host and device: ec3d_get_visit_order enumerates with the same function).
+// Returns the PHYSICAL tile, or -1 when workgroup b has no i-th tile in the front sweep.
 // MODE: -1 = decide from the sweep's fields (host enumeration, vector kernels); 1 = the z-marching map is known to
-// apply (kernels instantiated with ZM = true are only ever launched on such sweeps); 0 = it is known not to.
-// Knowing it at compile time keeps the other maps' parameters out of the registers of the SpMV kernels.
-template <int MODE = -1>
-__host__ __device__ inline int64_t ec3d_tile_of(const Sweep &sw, int b, int64_t i)
+// apply; 0 = it is known not to.  (The z-marching SpMV kernels walk the same sequence incrementally,
+// EC3D_ZSWEEP in ec3d_kernels.hip: plane after plane of one column, restarting at every block of a windowed slab.)
+template <int MODE = -1, class SW = Sweep>
+__host__ __device__ inline int64_t ec3d_tile_of(const SW &sw, int b, int64_t i)
 {
     if (MODE != 1 && sw.bnd_last >= 0) {
         // boundary launch of a z-slab: the first and the last owned plane, plain tile order
         const int64_t t = i * (int64_t)sw.nblk + b;
-        if (t >= 2 * (int64_t)sw.zm_tpp) return sw.ntiles;
+        if (t >= 2 * (int64_t)sw.zm_tpp) return -1;
         return (t < sw.zm_tpp ? 0 : (int64_t)sw.bnd_last * sw.zm_tpp) + t % sw.zm_tpp;
     }
     if (MODE == 1 || (MODE == -1 && sw.zm_tpp > 0)) {
         // XCD label c owns zm_tpp/8 adjacent columns, so the +-sdx lines a column needs were fetched
-        // by a neighbour on the same XCD one step earlier (L2 hit); plane k = pl0 + seg*pps + i
+        // by a neighbour on the same XCD one step earlier (L2 hit); logical plane k = pl0 + seg*pps + i
         const int cpx = (sw.zm_tpp + 7) >> 3, c = b & 7, s = b >> 3;
         const int64_t col = c * cpx + s % cpx, seg = s / cpx;
         const int64_t pl = seg * sw.zm_pps + i;
-        if (col >= sw.zm_tpp || i >= sw.zm_pps || (sw.zm_npl > 0 && pl >= sw.zm_npl)) return sw.ntiles;
-        return (sw.zm_pl0 + pl) * sw.zm_tpp + col;
+        if (col >= sw.zm_tpp || i >= sw.zm_pps || (sw.zm_npl > 0 && pl >= sw.zm_npl)) return -1;
+        const int64_t t = (sw.zm_pl0 + pl) * sw.zm_tpp + col;
+        return t < sw.ntiles ? ec3d_phys_tile(sw, t) : -1;
     }
+    int64_t t;
     if (sw.S > 0) {
         int64_t c = b & 7, s = b >> 3;
-        return (i * 8 + c) * sw.S + s;
+        t = (i * 8 + c) * sw.S + s;
+    } else {
+        t = i * (int64_t)sw.nblk + b;
     }
-    return i * (int64_t)sw.nblk + b;
+    return t < sw.ntiles ? ec3d_phys_tile(sw, t) : -1;
 }
 struct SolverState {
     double rr0[2]; // R·R0 entering iteration it is rr0[it & 1]

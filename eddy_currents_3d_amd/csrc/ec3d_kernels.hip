@@ -78,6 +78,78 @@ __device__ __forceinline__ d2 load2(const double *__restrict__ p)
     return *reinterpret_cast<const d2 *>(p);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// What a kernel receives.  MatView / Sweep (ec3d_internal.hpp) describe a matrix and a launch for every format
+// and every map; passed by value they kept ~60 scalar registers busy in kernels that read a dozen of them, and the
+// SpMV kernels spilled 15-34 of them to vector lanes.  Each template instance now gets a view holding only the
+// fields it reads (made from MatView / Sweep by the launchers at the end of this file).
+struct TailDev {
+    const int32_t *tail_id;   // [n_pad]  -1 or index of the row's tail slot
+    const uint8_t *tile_flag; // [ntiles] 1 when any row of the tile has a tail
+    const int64_t *chunk_ptr; // [nchunk+1] entry offsets of the 64-row slices
+    const int32_t *tcol;
+    const double *tval;
+};
+// Matrix formats the row kernel is specialised for (template parameter FMT):
+//   FMT_GENERIC  any number of bands, one fp64 stream per band
+//   FMT_DIA7     7 bands, unrolled (72 B/row: 56 coefficients + x + y)
+//   FMT_DICT7    7 bands whose coefficient 7-tuples take <= 256 distinct values ("stencil classes"):
+//                one class byte per row + a table staged in LDS (17 B/row: 1 + x + y).  The values
+//                multiplied are the same doubles, so results are bit-identical to FMT_DIA7.
+//   FMT_SAV      the structured A-V form (MatView::sav): class byte per row, U on the grid, no tail
+enum { FMT_GENERIC = 0, FMT_DIA7 = 7, FMT_DICT7 = 107, FMT_SAV = 207 };
+#define EC3D_SAV_STRIDE 16
+
+template <int FMT> struct MatDev;
+template <> struct MatDev<FMT_GENERIC> {
+    const double *band[EC3D_MAXB];
+    int64_t off[EC3D_MAXB];
+    int nb;
+    TailDev t;
+    __device__ __forceinline__ int64_t boff(int b) const { return off[b]; }
+};
+template <> struct MatDev<FMT_DIA7> {
+    const double *band[7];
+    int64_t off[7];
+    int pm1;
+    TailDev t;
+    __device__ __forceinline__ int64_t boff(int b) const { return off[b]; }
+};
+template <> struct MatDev<FMT_DICT7> {
+    const uint8_t *cls;
+    const double *table;
+    int64_t off[7];
+    int ncls, pm1;
+    TailDev t;
+    __device__ __forceinline__ int64_t boff(int b) const { return off[b]; }
+};
+template <> struct MatDev<FMT_SAV> {
+    const uint8_t *cls;
+    const uint8_t *tile_flag; // 1: some row of the tile is coupled (uniform per tile)
+    const double *table;
+    int64_t nC, sdx, pitch; // rows per block; band offsets are (-pitch, -sdx, -1, 0, 1, sdx, pitch)
+    int ncls, pm1;
+    int a0, u0, zero; // class ranges (MatView); only the kernels for grids without tile-aligned planes read them
+    __device__ __forceinline__ int64_t boff(int b) const
+    {
+        return b == 0 ? -pitch : b == 1 ? -sdx : b == 2 ? -1 : b == 3 ? 0 : b == 4 ? 1 : b == 5 ? sdx : pitch;
+    }
+    __device__ __forceinline__ int64_t step(int d) const { return d == 0 ? 1 : d == 1 ? sdx : pitch; }
+};
+
+// the z-marching launch as its kernels see it
+struct SweepZ {
+    int64_t ntiles, n; // logical front tiles; rows >= n are padding
+    int tpp, pps, npl, pl0;
+    int pstride, part_off;
+    int ulist_n;
+    const int32_t *ulist;
+    int64_t win_npo, win_npb, win_p0; // window in planes (owned per block, held per block, first owned); npo = 0: none
+};
+template <bool ZM> struct SweepSel { typedef Sweep type; };
+template <> struct SweepSel<true> { typedef SweepZ type; };
+
 // rows >= n (padding up to the tile; in a z-slab they overlap the upper halo plane) are never
 // stored and contribute +0 to every dot product
 template <bool NT>
@@ -93,7 +165,8 @@ __device__ __forceinline__ void store2(double *__restrict__ v, int64_t r, int64_
     }
 }
 // rows that take part in the dot products: all rows < n, or -- for one z-slab of the A-V system held
-// on an extended grid (own planes + halo planes of every component) -- the owned index ranges only
+// on an extended grid whose planes are not tile aligned -- the owned index ranges only.  (Tile-aligned slabs
+// sweep owned tiles only: Sweep::win_*.)
 __device__ __forceinline__ bool row_owned(const Sweep &sw, int64_t r)
 {
     if (sw.nown == 0) return r < sw.n;
@@ -101,11 +174,91 @@ __device__ __forceinline__ bool row_owned(const Sweep &sw, int64_t r)
     for (int q = 0; q < sw.nown; ++q) o |= (r >= sw.own_lo[q]) & (r < sw.own_hi[q]);
     return o;
 }
+__device__ __forceinline__ bool row_owned(const SweepZ &sw, int64_t r) { return r < sw.n; }
 #define EC3D_MASK2(r, sw_, a, b)                                                               \
     do {                                                                                       \
         if (!row_owned(sw_, (r))) (a) = 0.0;                                                   \
         if (!row_owned(sw_, (r) + 1)) (b) = 0.0;                                               \
     } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// The tiles a workgroup visits, in order: the front sweep (ec3d_tile_of), then its share of the U-block list.
+// `first`: nothing is carried over from the previous tile (the z-march registers must be loaded).
+template <bool ZM> struct TileWalk;
+template <> struct TileWalk<false> {
+    const Sweep &sw;
+    int64_t it = 0, lst = -1;
+    __device__ __forceinline__ TileWalk(const Sweep &s) : sw(s) {}
+    template <int MODE = 0> __device__ __forceinline__ bool next(int64_t &tile, bool &first)
+    {
+        first = true;
+        if (lst < 0) {
+            tile = ec3d_tile_of<MODE>(sw, blockIdx.x, it++);
+            if (tile >= 0) return true;
+            if (sw.ulist_n == 0) return false;
+            lst = blockIdx.x;
+        }
+        if (lst >= sw.ulist_n) return false;
+        tile = sw.ulist[lst];
+        lst += sw.nblk;
+        return true;
+    }
+};
+// ec3d_tile_of<1> walked incrementally: one column, consecutive logical planes; in a windowed slab the physical
+// plane jumps over the halo planes at every block and the march starts afresh there
+template <> struct TileWalk<true> {
+    const SweepZ &sw;
+    int64_t lp, lend, pl, rem, lst = -1;
+    int col;
+    bool fresh = true;
+    __device__ __forceinline__ TileWalk(const SweepZ &s) : sw(s)
+    {
+        const int cpx = (sw.tpp + 7) >> 3, c = blockIdx.x & 7, sg = blockIdx.x >> 3;
+        col = c * cpx + sg % cpx;
+        const int64_t seg = sg / cpx;
+        lp = seg * sw.pps;
+        lend = lp + sw.pps;
+        if (sw.npl > 0 && lend > sw.npl) lend = sw.npl;
+        if (col >= sw.tpp) lend = lp;
+        const int64_t L = sw.pl0 + lp;
+        if (sw.win_npo > 0) {
+            rem = L % sw.win_npo;
+            pl = (L / sw.win_npo) * sw.win_npb + sw.win_p0 + rem;
+        } else {
+            rem = 1; // never 0: no block starts
+            pl = L;
+        }
+    }
+    template <int MODE = 1> __device__ __forceinline__ bool next(int64_t &tile, bool &first)
+    {
+        if (lst < 0) {
+            if (lp < lend && (sw.pl0 + lp) * sw.tpp + col < sw.ntiles) {
+                tile = pl * sw.tpp + col;
+                first = fresh || (sw.win_npo > 0 && rem == 0);
+                fresh = false;
+                ++lp;
+                ++pl;
+                if (sw.win_npo > 0 && ++rem == sw.win_npo) {
+                    rem = 0;
+                    pl += sw.win_npb - sw.win_npo;
+                }
+                return true;
+            }
+            if (sw.ulist_n == 0) return false;
+            lst = blockIdx.x;
+        }
+        if (lst >= sw.ulist_n) return false;
+        tile = sw.ulist[lst];
+        lst += gridDim.x;
+        first = true;
+        return true;
+    }
+};
+#define EC3D_WALK(SW_T, MODE)                                                                  \
+    int64_t tile;                                                                              \
+    bool first_;                                                                               \
+    for (SW_T walk_(sw); walk_.template next<MODE>(tile, first_);)
+#define EC3D_ROW const int64_t r = tile * EC3D_TILE + 2 * (int64_t)threadIdx.x
 
 // The vector a row kernel multiplies by, behind a small accessor (pair = two consecutive entries from
 // an 8-byte-aligned address, at = one gathered entry).
@@ -119,7 +272,7 @@ struct VecPlain {
 // order): a plain loop is a chain of two dependent global loads per entry, ~1-2 us each, and a 13-entry
 // U row then costs more than the whole banded part of the tile.
 template <int B, class V>
-__device__ __forceinline__ double tail_batch(const MatView &A, const V &x, int64_t e0, int cnt, double s)
+__device__ __forceinline__ double tail_batch(const TailDev &A, const V &x, int64_t e0, int cnt, double s)
 {
     double tv[B], xv[B];
     int tc[B];
@@ -138,7 +291,7 @@ __device__ __forceinline__ double tail_batch(const MatView &A, const V &x, int64
 }
 
 template <class V>
-__device__ __forceinline__ double tail_add(const MatView &A, const V &x, int t, double s)
+__device__ __forceinline__ double tail_add(const TailDev &A, const V &x, int t, double s)
 {
     const int64_t base = A.chunk_ptr[t >> 6], end = A.chunk_ptr[(t >> 6) + 1];
     int w = (int)((end - base) >> 6); // slots per row in this slice
@@ -153,40 +306,31 @@ __device__ __forceinline__ double tail_add(const MatView &A, const V &x, int t, 
     return s;
 }
 
-// Matrix formats the row kernel is specialised for (template parameter FMT):
-//   FMT_GENERIC  any number of bands, one fp64 stream per band
-//   FMT_DIA7     7 bands, unrolled (72 B/row: 56 coefficients + x + y)
-//   FMT_DICT7    7 bands whose coefficient 7-tuples take <= 256 distinct values ("stencil classes"):
-//                one class byte per row + a table staged in LDS (17 B/row: 1 + x + y).  The values
-//                multiplied are the same doubles, so results are bit-identical to FMT_DIA7.
-enum { FMT_GENERIC = 0, FMT_DIA7 = 7, FMT_DICT7 = 107, FMT_SAV = 207 };
-#define EC3D_SAV_STRIDE 16
-
 template <int FMT>
-__device__ __forceinline__ void stage_table(const MatView &A, double *tbl)
+__device__ __forceinline__ void stage_table(const MatDev<FMT> &A, double *tbl)
 {
-    if (FMT == FMT_DICT7 || FMT == FMT_SAV) {
+    if constexpr (FMT == FMT_DICT7 || FMT == FMT_SAV) {
         const int cnt = A.ncls * (FMT == FMT_SAV ? EC3D_SAV_STRIDE : 7);
         for (int i = threadIdx.x; i < cnt; i += EC3D_THREADS) tbl[i] = A.table[i];
         __syncthreads();
     }
 }
 
-// Structured A-V form: the coupling slots of rows r, r+1 (see MatView), added in slot order = ascending
-// column order = the reference's row-sum order.  A slot whose coefficient is zero is not an entry of the
-// reference's row: it is neither loaded nor added.  Both rows take their operands from one 16-byte load
-// per slot; most rows use 2 of the 5 (A rows) or 6 of the 9 (U rows) slots.
+// Structured A-V form, grids WITHOUT tile-aligned planes (small problems): the coupling slots of rows r, r+1
+// (see MatView), added in slot order = ascending column order = the reference's row-sum order.  A slot whose
+// coefficient is zero is not an entry of the reference's row: it is neither loaded nor added.  Both rows take
+// their operands from one 16-byte load per slot.
 // the two running sums are final here and no load moves across (register pressure, see the callers)
 #define EC3D_PIN(a, b) asm volatile("" : "+v"(a), "+v"(b)::"memory")
 template <class V>
-__device__ __forceinline__ void sav_u_pre(const MatView &A, const double *t0, const double *t1, const V &x,
+__device__ __forceinline__ void sav_u_pre(const MatDev<FMT_SAV> &A, const double *t0, const double *t1, const V &x,
                                           int64_t r, double &s0, double &s1)
 {
     // per component: the (up to) three loads first, then the adds in slot order -- a load inside the
     // add chain would cost one memory round trip per slot
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-        const int64_t base = r - (3 - d) * A.sav_nC;
+        const int64_t base = r - (3 - d) * A.nC;
         double v0[3], v1[3];
         d2 xx[3];
 #pragma unroll
@@ -194,7 +338,7 @@ __device__ __forceinline__ void sav_u_pre(const MatView &A, const double *t0, co
             v0[j] = t0[7 + 3 * d + j];
             v1[j] = t1[7 + 3 * d + j];
             xx[j] = d2{0.0, 0.0};
-            if (v0[j] != 0.0 || v1[j] != 0.0) xx[j] = x.pair(base + (j - 1) * A.sav_step[d]);
+            if (v0[j] != 0.0 || v1[j] != 0.0) xx[j] = x.pair(base + (j - 1) * A.step(d));
         }
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
@@ -205,10 +349,10 @@ __device__ __forceinline__ void sav_u_pre(const MatView &A, const double *t0, co
     }
 }
 template <class V>
-__device__ __forceinline__ void sav_a_post(const MatView &A, const double *t0, const double *t1, const V &x,
+__device__ __forceinline__ void sav_a_post(const MatDev<FMT_SAV> &A, const double *t0, const double *t1, const V &x,
                                            int64_t r, int d, double &s0, double &s1)
 {
-    const int64_t base = r + (3 - d) * A.sav_nC, step = A.sav_step[d];
+    const int64_t base = r + (3 - d) * A.nC, step = A.step(d);
     double v0[5], v1[5];
     d2 xx[5];
 #pragma unroll
@@ -230,15 +374,211 @@ struct ZRegs {
     d2 xm, xc;
 };
 
+// ---------------------------------------------------------------------------------------------
+// LDS staging of operands that would not fit the register budget while in flight: an LDS-DMA load
+// (global_load_lds_dwordx4) has no register destination.  Every thread fetches ITS OWN 16 bytes into its own
+// slot and reads nothing else back, so no barrier is involved -- LDS serves as spill space for loads in
+// flight.  One wave instruction writes 1 KiB at (wave-uniform base) + lane * 16.
+#define EC3D_NSTAGE 4 /* 16-byte slots per thread: 4 x 4 KiB per workgroup */
+__device__ __forceinline__ void stage_issue(const double *gp, double *stg, int k)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gp,
+                                     (__attribute__((address_space(3))) void *)(stg + k * EC3D_TILE +
+                                                                                (threadIdx.x >> 6) * 128),
+                                     16, 0, 0);
+}
+__device__ __forceinline__ d2 stage_read(const double *stg, int k)
+{
+    return *reinterpret_cast<const d2 *>(stg + k * EC3D_TILE + 2 * threadIdx.x);
+}
+// every vector-memory operation of this wave has landed (LDS-DMA included: it counts in vmcnt)
+#define EC3D_VM_DRAIN asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
+// Structured A-V form on a grid with tile-aligned planes (every grid worth timing): rows r, r+1 of A*x in a
+// tile that lies entirely in one block.  The operands of the coupling slots are requested TOGETHER with the band
+// operands -- one memory round trip per tile -- through the LDS staging slots, where the earlier version made
+// one dependent round trip per batch of slots (class byte -> table -> coefficient != 0 -> load; 2 round trips
+// in a coupled A tile, 4 in a U tile) because their operands had no registers to wait in:
+//   coupled A_d tile: U(cell + m*step_d), m = -1, 0, +1 (d = x: the aligned pairs at -2, 0, +2, which hold
+//                     every slot m = -2..2 of both rows); the outer slots m = -2, +2 of d = y, z occur on
+//                     conductor faces only and are fetched afterwards by the waves that meet one
+//   U tile:           A_x(cell - 1 .. cell + 2) from one register pair and two lane shuffles, A_y(cell -+ sdx),
+//                     A_z(cell -+ pitch) staged; the own-cell slots of y and z (conductor faces) afterwards
+// Same products, same order as before: bands ascending then U slots (A rows), A slots then bands (U rows) =
+// ascending columns = the reference's row sum (src/solvers.f90:59 after src/EC3D.f90:715); a slot whose
+// coefficient is zero is not an entry of the reference's row and is not added.
+// the 7-point part of a z-march step: operands of rows r, r+1 for the seven bands (as the single-component
+// kernels take them: plane below / centre from the registers, +-1 by lane shuffle).  Named registers, no
+// arrays: an operand array shared by the two tile kinds below ended up as one 32-register tuple in scratch.
+struct SavBand {
+    d2 zm, ym, c, yp, zp; // x[r - pitch], x[r - sdx], x[r], x[r + sdx], x[r + pitch]   (pairs r, r+1)
+    double left, right;   // x[r - 1], x[r + 2] on the wave's edge lanes
+};
+template <class V>
+__device__ __forceinline__ void sav_band_loads(const MatDev<FMT_SAV> &A, const V &x, int64_t r, bool first, ZRegs &z,
+                                               SavBand &o)
+{
+    const int lane = threadIdx.x & 63;
+    o.left = 0.0;
+    o.right = 0.0;
+    if (lane == 0) o.left = x.at(r - 1);
+    if (lane == 63) o.right = x.at(r + 2);
+    o.ym = x.pair(r - A.sdx);
+    o.yp = x.pair(r + A.sdx);
+    o.zp = x.pair(r + A.pitch);
+    if (first) {
+        o.zm = x.pair(r - A.pitch);
+        o.c = x.pair(r);
+    } else {
+        o.zm = z.xm;
+        o.c = z.xc;
+    }
+    z.xm = o.c;
+    z.xc = o.zp;
+}
+__device__ __forceinline__ void sav_band_sum(const double *t0, const double *t1, const SavBand &o, double &s0,
+                                             double &s1)
+{
+    const int lane = threadIdx.x & 63;
+    double left = o.left, right = o.right;
+    const double l = __shfl_up(o.c.y, 1, 64), rr = __shfl_down(o.c.x, 1, 64);
+    if (lane != 0) left = l;
+    if (lane != 63) right = rr;
+    s0 = s0 + t0[0] * o.zm.x;
+    s1 = s1 + t1[0] * o.zm.y;
+    s0 = s0 + t0[1] * o.ym.x;
+    s1 = s1 + t1[1] * o.ym.y;
+    s0 = s0 + t0[2] * left;
+    s1 = s1 + t1[2] * o.c.x;
+    s0 = s0 + t0[3] * o.c.x;
+    s1 = s1 + t1[3] * o.c.y;
+    s0 = s0 + t0[4] * o.c.y;
+    s1 = s1 + t1[4] * right;
+    s0 = s0 + t0[5] * o.yp.x;
+    s1 = s1 + t1[5] * o.yp.y;
+    s0 = s0 + t0[6] * o.zp.x;
+    s1 = s1 + t1[6] * o.zp.y;
+}
+
+template <class V>
+__device__ __forceinline__ void sav_pair_zm(const MatDev<FMT_SAV> &A, const double *tbl, double *stg, const V &x,
+                                            int64_t r, int64_t tile, bool first, ZRegs &z, double &s0, double &s1,
+                                            d2 &ctr)
+{
+    const int lane = threadIdx.x & 63;
+    const bool urow = r >= 3 * A.nC; // uniform: blocks are whole numbers of tiles here
+    const unsigned short cc = *reinterpret_cast<const unsigned short *>(A.cls + r);
+    const bool cpl = A.tile_flag[tile] != 0; // uniform
+    SavBand bo;
+    s0 = 0.0;
+    s1 = 0.0;
+    if (cpl && urow) {
+        // ---- a tile of the U block ----
+        const double *ay = x.x + r - 2 * A.nC, *az = x.x + r - A.nC;
+        stage_issue(ay - A.sdx, stg, 0);
+        stage_issue(ay + A.sdx, stg, 1);
+        stage_issue(az - A.pitch, stg, 2);
+        stage_issue(az + A.pitch, stg, 3);
+        const int64_t rx = r - 3 * A.nC;
+        d2 xa = x.pair(rx);
+        double xal = 0.0, xar = 0.0;
+        if (lane == 0) xal = x.at(rx - 1);
+        if (lane == 63) xar = x.at(rx + 2);
+        sav_band_loads(A, x, r, first, z, bo);
+        ctr = bo.c;
+        const double *t0 = tbl + (cc & 0xFF) * EC3D_SAV_STRIDE, *t1 = tbl + (cc >> 8) * EC3D_SAV_STRIDE;
+        EC3D_VM_DRAIN;
+        {   // A_x(cell - 1), A_x(cell), A_x(cell + 1)
+            const double l = __shfl_up(xa.y, 1, 64), rr = __shfl_down(xa.x, 1, 64);
+            if (lane != 0) xal = l;
+            if (lane != 63) xar = rr;
+            const double o0[3] = {xal, xa.x, xa.y}, o1[3] = {xa.x, xa.y, xar};
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const double v0 = t0[7 + j], v1 = t1[7 + j];
+                if (v0 != 0.0) s0 = s0 + v0 * o0[j];
+                if (v1 != 0.0) s1 = s1 + v1 * o1[j];
+            }
+        }
+        EC3D_PIN(s0, s1); // one group of coefficients and operands in registers at a time
+#pragma unroll
+        for (int dd = 1; dd < 3; ++dd) { // A_y, A_z
+            const double vm0 = t0[7 + 3 * dd], vm1 = t1[7 + 3 * dd], vc0 = t0[8 + 3 * dd], vc1 = t1[8 + 3 * dd],
+                         vp0 = t0[9 + 3 * dd], vp1 = t1[9 + 3 * dd];
+            d2 oc = d2{0.0, 0.0};
+            const bool want = vc0 != 0.0 || vc1 != 0.0; // own-cell slot: rows on a conductor face only
+            if (__any(want)) {
+                if (want) oc = x.pair(r - (3 - dd) * A.nC);
+            }
+            const d2 om = stage_read(stg, 2 * dd - 2), op = stage_read(stg, 2 * dd - 1);
+            if (vm0 != 0.0) s0 = s0 + vm0 * om.x;
+            if (vm1 != 0.0) s1 = s1 + vm1 * om.y;
+            if (vc0 != 0.0) s0 = s0 + vc0 * oc.x;
+            if (vc1 != 0.0) s1 = s1 + vc1 * oc.y;
+            if (vp0 != 0.0) s0 = s0 + vp0 * op.x;
+            if (vp1 != 0.0) s1 = s1 + vp1 * op.y;
+            EC3D_PIN(s0, s1);
+        }
+        sav_band_sum(t0, t1, bo, s0, s1);
+        return;
+    }
+    // ---- a tile of an A block ----
+    const int d = (r >= A.nC) + (r >= 2 * A.nC);
+    if (cpl) {
+        const double *u = x.x + r + (3 - d) * A.nC;
+        const int64_t st = d == 0 ? 2 : A.step(d);
+        stage_issue(u - st, stg, 0);
+        stage_issue(u, stg, 1);
+        stage_issue(u + st, stg, 2);
+    }
+    sav_band_loads(A, x, r, first, z, bo);
+    ctr = bo.c;
+    const double *t0 = tbl + (cc & 0xFF) * EC3D_SAV_STRIDE, *t1 = tbl + (cc >> 8) * EC3D_SAV_STRIDE;
+    sav_band_sum(t0, t1, bo, s0, s1);
+    if (cpl) {
+        EC3D_PIN(s0, s1); // the band operands are dead from here
+        EC3D_VM_DRAIN;
+        const d2 q0 = stage_read(stg, 0), q1 = stage_read(stg, 1), q2 = stage_read(stg, 2);
+        double o0[5], o1[5];
+        if (d == 0) { // cells r-2 .. r+3 lie in the three aligned pairs
+            o0[0] = q0.x; o0[1] = q0.y; o0[2] = q1.x; o0[3] = q1.y; o0[4] = q2.x;
+            o1[0] = q0.y; o1[1] = q1.x; o1[2] = q1.y; o1[3] = q2.x; o1[4] = q2.y;
+        } else {
+            o0[1] = q0.x; o0[2] = q1.x; o0[3] = q2.x;
+            o1[1] = q0.y; o1[2] = q1.y; o1[3] = q2.y;
+            // outer slots: one-sided stencils at a conductor face (src/EC3D.f90:667-676) only
+            const bool wlo = t0[7] != 0.0 || t1[7] != 0.0, whi = t0[11] != 0.0 || t1[11] != 0.0;
+            d2 qlo = d2{0.0, 0.0}, qhi = d2{0.0, 0.0};
+            if (__any(wlo || whi)) {
+                const int64_t base = r + (3 - d) * A.nC, st = A.step(d);
+                if (wlo) qlo = x.pair(base - 2 * st);
+                if (whi) qhi = x.pair(base + 2 * st);
+            }
+            o0[0] = qlo.x; o1[0] = qlo.y;
+            o0[4] = qhi.x; o1[4] = qhi.y;
+        }
+#pragma unroll
+        for (int m = 0; m < 5; ++m) {
+            const double v0 = t0[7 + m], v1 = t1[7 + m];
+            if (v0 != 0.0) s0 = s0 + v0 * o0[m];
+            if (v1 != 0.0) s1 = s1 + v1 * o1[m];
+        }
+    }
+}
+
 // rows r, r+1 of A*x (src/solvers.f90:58-59): bands in ascending column order, then the tail.
 // ZM: band 0 / 3 / 6 (offsets -kdz, 0, +kdz) come from / go to the registers `z`.
 // `ctr` returns x[r], x[r+1] (the centre band's operand).
-template <int FMT, bool ZM, class V>
-__device__ __forceinline__ void spmv_pair(const MatView &A, const double *tbl, const V &x, int64_t r, int64_t tile,
-                                          bool first, ZRegs &z, double &s0, double &s1, d2 &ctr)
+template <int FMT, bool ZM, bool TAIL, class V>
+__device__ __forceinline__ void spmv_pair(const MatDev<FMT> &A, const double *tbl, double *stg, const V &x, int64_t r,
+                                          int64_t tile, bool first, ZRegs &z, double &s0, double &s1, d2 &ctr)
 {
+    if constexpr (FMT == FMT_SAV && ZM) {
+        sav_pair_zm(A, tbl, stg, x, r, tile, first, z, s0, s1, ctr);
+        return;
+    }
     uint8_t tflag = 0; // per tile: any tail row (bands + tail) / any coupled row (structured form)
-    if (FMT == FMT_DIA7 || FMT == FMT_DICT7 || FMT == FMT_SAV) {
+    if constexpr (FMT == FMT_DIA7 || FMT == FMT_DICT7 || FMT == FMT_SAV) {
         d2 xv[7];
         // the +-1 neighbours (bands 2 and 4 of the 7-point operator) are the centre pairs of the
         // adjacent lanes: take them by lane shuffle instead of two unaligned 16-byte loads; only the
@@ -248,8 +588,9 @@ __device__ __forceinline__ void spmv_pair(const MatView &A, const double *tbl, c
         // every load of the step is issued before the first use: class bytes, the two edge-lane
         // neighbours, then the band operands (one round trip per step instead of three)
         unsigned short cc = 0;
-        if (FMT == FMT_DICT7 || FMT == FMT_SAV) cc = *reinterpret_cast<const unsigned short *>(A.cls + r);
-        if (FMT == FMT_SAV || A.has_tail) tflag = A.tile_flag[tile];
+        if constexpr (FMT == FMT_DICT7 || FMT == FMT_SAV) cc = *reinterpret_cast<const unsigned short *>(A.cls + r);
+        if constexpr (FMT == FMT_SAV) tflag = A.tile_flag[tile];
+        else if constexpr (TAIL) tflag = A.t.tile_flag[tile];
         const int lane = threadIdx.x & 63;
         double left = 0.0, right = 0.0;
         if (pm1) {
@@ -260,7 +601,7 @@ __device__ __forceinline__ void spmv_pair(const MatView &A, const double *tbl, c
         for (int b = 0; b < 7; ++b) {
             if (ZM && (b == 0 || b == 3) && !first) continue;
             if (pm1 && (b == 2 || b == 4)) continue;
-            xv[b] = x.pair(r + A.off[b]);
+            xv[b] = x.pair(r + A.boff(b));
         }
         if (ZM) {
             if (!first) { xv[0] = z.xm; xv[3] = z.xc; }
@@ -275,7 +616,7 @@ __device__ __forceinline__ void spmv_pair(const MatView &A, const double *tbl, c
             xv[2] = d2{left, ctr.x};
             xv[4] = d2{ctr.y, right};
         }
-        if (FMT == FMT_DIA7) {
+        if constexpr (FMT == FMT_DIA7) {
             d2 c[7];
 #pragma unroll
             for (int b = 0; b < 7; ++b) c[b] = *reinterpret_cast<const d2 *>(A.band[b] + r);
@@ -286,7 +627,7 @@ __device__ __forceinline__ void spmv_pair(const MatView &A, const double *tbl, c
                 s0 = s0 + c[b].x * xv[b].x;
                 s1 = s1 + c[b].y * xv[b].y;
             }
-        } else if (FMT == FMT_DICT7) {
+        } else if constexpr (FMT == FMT_DICT7) {
             const double *t0 = tbl + (cc & 0xFF) * 7, *t1 = tbl + (cc >> 8) * 7;
             s0 = t0[0] * xv[0].x;
             s1 = t1[0] * xv[0].y;
@@ -295,14 +636,14 @@ __device__ __forceinline__ void spmv_pair(const MatView &A, const double *tbl, c
                 s0 = s0 + t0[b] * xv[b].x;
                 s1 = s1 + t1[b] * xv[b].y;
             }
-        } else { // FMT_SAV: U rows take their A couplings first, A rows their U couplings last
+        } else { // FMT_SAV without tile-aligned planes: U rows take their A couplings first, A rows their U couplings last
             const int c0 = cc & 0xFF, c1 = cc >> 8;
             const double *t0 = tbl + c0 * EC3D_SAV_STRIDE, *t1 = tbl + c1 * EC3D_SAV_STRIDE;
             const bool cpl = tflag != 0; // any coupled row in this tile (uniform)
             // the coupling slots of an A class mean U columns, those of a U class A columns: a row of the
             // other kind goes through the all-zero class
-            const double *zt = tbl + A.sav_zero * EC3D_SAV_STRIDE;
-            const int64_t nA = 3 * A.sav_nC;
+            const double *zt = tbl + A.zero * EC3D_SAV_STRIDE;
+            const int64_t nA = 3 * A.nC;
             s0 = 0.0;
             s1 = 0.0;
             if (cpl && r + 1 >= nA) sav_u_pre(A, r >= nA ? t0 : zt, t1, x, r, s0, s1);
@@ -313,9 +654,9 @@ __device__ __forceinline__ void spmv_pair(const MatView &A, const double *tbl, c
             }
             if (cpl && r < nA) {
                 EC3D_PIN(s0, s1); // the band operands are dead from here: their registers take the slots'
-                const int d0 = (r >= A.sav_nC) + (r >= 2 * A.sav_nC);
-                const int d1 = (r + 1 >= A.sav_nC) + (r + 1 >= 2 * A.sav_nC);
-                const bool in0 = c0 >= A.sav_a0 && c0 < A.sav_u0, in1 = c1 >= A.sav_a0 && c1 < A.sav_u0 && r + 1 < nA;
+                const int d0 = (r >= A.nC) + (r >= 2 * A.nC);
+                const int d1 = (r + 1 >= A.nC) + (r + 1 >= 2 * A.nC);
+                const bool in0 = c0 >= A.a0 && c0 < A.u0, in1 = c1 >= A.a0 && c1 < A.u0 && r + 1 < nA;
                 if (d0 == d1) {
                     sav_a_post(A, in0 ? t0 : zt, in1 ? t1 : zt, x, r, d0, s0, s1);
                 } else { // the pair straddles two component blocks (odd block length)
@@ -335,12 +676,14 @@ __device__ __forceinline__ void spmv_pair(const MatView &A, const double *tbl, c
             s1 = s1 + c.y * xv.y;
         }
         ctr = x.pair(r);
-        if (A.has_tail) tflag = A.tile_flag[tile];
+        if constexpr (TAIL) tflag = A.t.tile_flag[tile];
     }
-    if (A.has_tail && tflag) {
-        i2 t = *reinterpret_cast<const i2 *>(A.tail_id + r);
-        if (t.x >= 0) s0 = tail_add(A, x, t.x, s0);
-        if (t.y >= 0) s1 = tail_add(A, x, t.y, s1);
+    if constexpr (TAIL && FMT != FMT_SAV) {
+        if (tflag) {
+            i2 t = *reinterpret_cast<const i2 *>(A.t.tail_id + r);
+            if (t.x >= 0) s0 = tail_add(A.t, x, t.x, s0);
+            if (t.y >= 0) s1 = tail_add(A.t, x, t.y, s1);
+        }
     }
 }
 
@@ -348,79 +691,65 @@ __device__ __forceinline__ void spmv_pair(const MatView &A, const double *tbl, c
 // (the structured form without z-marching only runs on grids too small for plane-aligned tiles: it takes the
 // registers it needs -- 5 per CU -- instead of spilling)
 #define EC3D_SPMV_OCC __attribute__((amdgpu_waves_per_eu((FMT == FMT_SAV && !ZM) ? 5 : 6)))
-#define EC3D_SWEEP_BEGIN_(MODE)                                                                \
-    bool need_first_ = true;                                                                   \
-    int64_t lst_ = -1; /* >= 0: walking the list of occupied U tiles */                        \
-    for (int64_t it_ = 0;; ++it_) {                                                            \
-        int64_t tile = 0;                                                                      \
-        if (lst_ < 0) {                                                                        \
-            tile = ec3d_tile_of<MODE>(sw, blockIdx.x, it_);                                    \
-            if (tile >= sw.ntiles) {                                                           \
-                if (sw.ulist_n == 0) break;                                                    \
-                lst_ = blockIdx.x;                                                             \
-            }                                                                                  \
-        }                                                                                      \
-        if (lst_ >= 0) {                                                                       \
-            if (lst_ >= sw.ulist_n) break;                                                     \
-            tile = sw.ulist[lst_];                                                             \
-            lst_ += sw.nblk;                                                                   \
-            need_first_ = true;                                                                \
-        }                                                                                      \
-        const bool first_ = need_first_;                                                       \
-        need_first_ = false;                                                                   \
-        (void)first_;                                                                          \
-        const int64_t r = tile * EC3D_TILE + 2 * (int64_t)threadIdx.x;
-#define EC3D_SWEEP_BEGIN EC3D_SWEEP_BEGIN_(-1)             /* vector kernels */
-#define EC3D_SWEEP_BEGIN_A EC3D_SWEEP_BEGIN_((ZM ? 1 : 0)) /* SpMV-type kernels: ZM is a template parameter */
-#define EC3D_SWEEP_END }
+#define EC3D_SPMV_T template <int FMT, bool NT, bool ZM, bool TAIL>
+#define EC3D_SWEEP_OF(ZM_) typename SweepSel<ZM_>::type
+// classes in the LDS table (0 for the formats without one)
+template <int FMT> __device__ __forceinline__ int ncls_of(const MatDev<FMT> &A)
+{
+    if constexpr (FMT == FMT_SAV || FMT == FMT_DICT7) return A.ncls;
+    return 0;
+}
 #define EC3D_TBL_DECL                                                                          \
-    extern __shared__ double tbl[] /* the class table, sized at launch (EC3D_TBL_BYTES) */
+    extern __shared__ double tbl[]; /* the class table, sized at launch (EC3D_TBL_BYTES) */    \
+    double *stg = tbl + (FMT == FMT_SAV ? ncls_of<FMT>(A) * EC3D_SAV_STRIDE : 0) /* staging slots (sav_pair_zm) */
 
 // ---------------------------------------------------------------------------------------------
 // plain y = A x  (src/solvers.f90:54-61)
-template <int FMT, bool NT, bool ZM>
-__global__ __launch_bounds__(EC3D_THREADS) EC3D_SPMV_OCC void k_spmv(MatView A, Sweep sw, const double *__restrict__ x,
-                                                       double *__restrict__ y)
+EC3D_SPMV_T __global__ __launch_bounds__(EC3D_THREADS) EC3D_SPMV_OCC void k_spmv(MatDev<FMT> A, EC3D_SWEEP_OF(ZM) sw,
+                                                                                   const double *__restrict__ x,
+                                                                                   double *__restrict__ y)
 {
     EC3D_TBL_DECL;
     stage_table<FMT>(A, tbl);
     ZRegs zr;
-    EC3D_SWEEP_BEGIN_A
-    double s0, s1;
-    d2 ctr;
-    spmv_pair<FMT, ZM>(A, tbl, VecPlain{x}, r, tile, first_, zr, s0, s1, ctr);
-    store2<NT>(y, r, sw.n, s0, s1);
-    EC3D_SWEEP_END
+    EC3D_WALK(TileWalk<ZM>, (ZM ? 1 : 0))
+    {
+        EC3D_ROW;
+        double s0, s1;
+        d2 ctr;
+        spmv_pair<FMT, ZM, TAIL>(A, tbl, stg, VecPlain{x}, r, tile, first_, zr, s0, s1, ctr);
+        store2<NT>(y, r, sw.n, s0, s1);
+    }
 }
 
 // setup: R = B - A X ; R0 = R ; P = R ; partials of B·B and R·R   (src/solvers.f90:14-21)
-template <int FMT, bool NT, bool ZM>
-__global__ __launch_bounds__(EC3D_THREADS) EC3D_SPMV_OCC void k_residual(MatView A, Sweep sw, const double *__restrict__ x,
-                                                           const double *__restrict__ b, double *__restrict__ rv,
-                                                           double *__restrict__ r0, double *__restrict__ p,
-                                                           double *__restrict__ part)
+EC3D_SPMV_T __global__ __launch_bounds__(EC3D_THREADS) EC3D_SPMV_OCC void k_residual(
+    MatDev<FMT> A, EC3D_SWEEP_OF(ZM) sw, const double *__restrict__ x, const double *__restrict__ b,
+    double *__restrict__ rv, double *__restrict__ r0, double *__restrict__ p, double *__restrict__ part)
 {
     __shared__ double lds[8];
     EC3D_TBL_DECL;
     stage_table<FMT>(A, tbl);
     ZRegs zr;
     double acc[2] = {0.0, 0.0};
-    EC3D_SWEEP_BEGIN_A
-    double s0, s1;
-    d2 ctr;
-    spmv_pair<FMT, ZM>(A, tbl, VecPlain{x}, r, tile, first_, zr, s0, s1, ctr);
-    d2 bv = load2<NT>(b + r);
-    double e0 = bv.x - s0, e1 = bv.y - s1, b0 = bv.x, b1 = bv.y;
-    store2<NT>(rv, r, sw.n, e0, e1);
-    store2<NT>(r0, r, sw.n, e0, e1);
-    store2<NT>(p, r, sw.n, e0, e1);
-    EC3D_MASK2(r, sw, e0, e1);
-    EC3D_MASK2(r, sw, b0, b1);
-    acc[0] = acc[0] + b0 * b0;
-    acc[0] = acc[0] + b1 * b1;
-    acc[1] = acc[1] + e0 * e0;
-    acc[1] = acc[1] + e1 * e1;
-    EC3D_SWEEP_END
+    EC3D_WALK(TileWalk<ZM>, (ZM ? 1 : 0))
+    {
+        EC3D_ROW;
+        double s0, s1;
+        d2 ctr;
+        spmv_pair<FMT, ZM, TAIL>(A, tbl, stg, VecPlain{x}, r, tile, first_, zr, s0, s1, ctr);
+        d2 bv = load2<NT>(b + r);
+        double e0 = bv.x - s0, e1 = bv.y - s1, b0 = bv.x, b1 = bv.y;
+        store2<NT>(rv, r, sw.n, e0, e1);
+        store2<NT>(r0, r, sw.n, e0, e1);
+        store2<NT>(p, r, sw.n, e0, e1);
+        EC3D_MASK2(r, sw, e0, e1);
+        EC3D_MASK2(r, sw, b0, b1);
+        acc[0] = acc[0] + b0 * b0;
+        acc[0] = acc[0] + b1 * b1;
+        acc[1] = acc[1] + e0 * e0;
+        acc[1] = acc[1] + e1 * e1;
+    }
     block_sum<2>(acc, lds);
     if (threadIdx.x == 0) {
         part[P_BB * sw.pstride + sw.part_off + blockIdx.x] = acc[0];
@@ -442,6 +771,32 @@ __global__ __launch_bounds__(EC3D_THREADS) void k_finalize(RedSrc src, double *l
     }
 }
 
+// The exit state travels as ONE 64-bit word: stop_iter in the low half, stop_kind in the high half
+// (SolverState keeps them adjacent and 8-byte aligned).  A reader never sees the iteration of one exit with
+// the kind of another, whoever wrote it and whenever: K5's entry test reads a pair that its own launch's lead
+// thread may be writing at that moment.
+__device__ __forceinline__ unsigned long long *stop_word(const SolverState *st)
+{
+    return reinterpret_cast<unsigned long long *>(const_cast<int *>(&st->stop_iter));
+}
+__device__ __forceinline__ void stop_publish(SolverState *st, int it, int kind)
+{
+    __hip_atomic_store(stop_word(st), (unsigned long long)(unsigned)it | ((unsigned long long)(unsigned)kind << 32),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void stop_read(const SolverState *st, int &it, int &kind)
+{
+    const unsigned long long w = __hip_atomic_load(stop_word(st), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    it = (int)(unsigned)(w & 0xFFFFFFFFull);
+    kind = (int)(unsigned)(w >> 32);
+}
+__device__ __forceinline__ int stop_iter_of(const SolverState *st)
+{
+    int it, kind;
+    stop_read(st, it, kind);
+    return it;
+}
+
 // Bnorm, rr0, "‖b‖ = 0 -> return" (src/solvers.f90:21-23); one workgroup
 __global__ __launch_bounds__(EC3D_THREADS) void k_setup(SolverState *st, RedSrc src, double tol)
 {
@@ -457,34 +812,33 @@ __global__ __launch_bounds__(EC3D_THREADS) void k_setup(SolverState *st, RedSrc 
         st->rr0[0] = 0.0;
         st->alpha = 0.0;
         st->omega = 0.0;
-        st->stop_kind = 0;
-        st->stop_iter = (bnorm == 0.0) ? 0 : INT_MAX;
+        stop_publish(st, (bnorm == 0.0) ? 0 : INT_MAX, 0);
     }
 }
 
 // K1: AP = A P ; partial AP·R0    (src/solvers.f90:30, :32 denominator)
-template <int FMT, bool NT, bool ZM>
-__global__ __launch_bounds__(EC3D_THREADS) EC3D_SPMV_OCC void k1_spmv_dot(MatView A, Sweep sw, const SolverState *st, int it,
-                                                            const double *__restrict__ p,
-                                                            const double *__restrict__ r0,
-                                                            double *__restrict__ ap, double *__restrict__ part)
+EC3D_SPMV_T __global__ __launch_bounds__(EC3D_THREADS) EC3D_SPMV_OCC void k1_spmv_dot(
+    MatDev<FMT> A, EC3D_SWEEP_OF(ZM) sw, const SolverState *st, int it, const double *__restrict__ p,
+    const double *__restrict__ r0, double *__restrict__ ap, double *__restrict__ part)
 {
     __shared__ double lds[4];
     EC3D_TBL_DECL;
-    if (st->stop_iter < it) return;
+    if (stop_iter_of(st) < it) return;
     stage_table<FMT>(A, tbl);
     ZRegs zr;
     double acc[1] = {0.0};
-    EC3D_SWEEP_BEGIN_A
-    double s0, s1;
-    d2 ctr;
-    spmv_pair<FMT, ZM>(A, tbl, VecPlain{p}, r, tile, first_, zr, s0, s1, ctr);
-    d2 q = load2<NT>(r0 + r);
-    store2<NT>(ap, r, sw.n, s0, s1);
-    EC3D_MASK2(r, sw, s0, s1);
-    acc[0] = acc[0] + s0 * q.x;
-    acc[0] = acc[0] + s1 * q.y;
-    EC3D_SWEEP_END
+    EC3D_WALK(TileWalk<ZM>, (ZM ? 1 : 0))
+    {
+        EC3D_ROW;
+        double s0, s1;
+        d2 ctr;
+        spmv_pair<FMT, ZM, TAIL>(A, tbl, stg, VecPlain{p}, r, tile, first_, zr, s0, s1, ctr);
+        d2 q = load2<NT>(r0 + r);
+        store2<NT>(ap, r, sw.n, s0, s1);
+        EC3D_MASK2(r, sw, s0, s1);
+        acc[0] = acc[0] + s0 * q.x;
+        acc[0] = acc[0] + s1 * q.y;
+    }
     block_sum<1>(acc, lds);
     if (threadIdx.x == 0) part[P_D1 * sw.pstride + sw.part_off + blockIdx.x] = acc[0];
 }
@@ -497,22 +851,24 @@ __global__ __launch_bounds__(EC3D_THREADS) void k2_s_update(Sweep sw, RedSrc src
                                                             double *__restrict__ part)
 {
     __shared__ double lds[4];
-    if (st->stop_iter < it) return;
+    if (stop_iter_of(st) < it) return;
     const int slot[1] = {P_D1};
     double d[1];
     reduce_partials<1>(src, slot, d, lds);
     const double alpha = st->rr0[it & 1] / d[0];
     if (blockIdx.x == 0 && threadIdx.x == 0) st->alpha = alpha;
     double acc[1] = {0.0};
-    EC3D_SWEEP_BEGIN
-    d2 a = load2<NT>(ap + r);
-    d2 q = load2<NT>(rv + r);
-    double s0 = q.x - alpha * a.x, s1 = q.y - alpha * a.y;
-    store2<NT>(sv, r, sw.n, s0, s1);
-    EC3D_MASK2(r, sw, s0, s1);
-    acc[0] = acc[0] + s0 * s0;
-    acc[0] = acc[0] + s1 * s1;
-    EC3D_SWEEP_END
+    EC3D_WALK(TileWalk<false>, -1)
+    {
+        EC3D_ROW;
+        d2 a = load2<NT>(ap + r);
+        d2 q = load2<NT>(rv + r);
+        double s0 = q.x - alpha * a.x, s1 = q.y - alpha * a.y;
+        store2<NT>(sv, r, sw.n, s0, s1);
+        EC3D_MASK2(r, sw, s0, s1);
+        acc[0] = acc[0] + s0 * s0;
+        acc[0] = acc[0] + s1 * s1;
+    }
     block_sum<1>(acc, lds);
     if (threadIdx.x == 0) part[P_SS * sw.pstride + sw.part_off + blockIdx.x] = acc[0];
 }
@@ -520,28 +876,29 @@ __global__ __launch_bounds__(EC3D_THREADS) void k2_s_update(Sweep sw, RedSrc src
 // K3: AS = A S ; partials AS·S and AS·AS (src/solvers.f90:39-40).  Launched before ‖S‖ is known
 // (one global reduction point less per iteration): when the ‖S‖ exit of :34-38 is then
 // taken by K4, AS is simply never used -- results are unchanged.
-template <int FMT, bool NT, bool ZM>
-__global__ __launch_bounds__(EC3D_THREADS) EC3D_SPMV_OCC void k3_spmv_dots(MatView A, Sweep sw, SolverState *st, int it,
-                                                             const double *__restrict__ sv,
-                                                             double *__restrict__ as, double *__restrict__ part)
+EC3D_SPMV_T __global__ __launch_bounds__(EC3D_THREADS) EC3D_SPMV_OCC void k3_spmv_dots(
+    MatDev<FMT> A, EC3D_SWEEP_OF(ZM) sw, SolverState *st, int it, const double *__restrict__ sv,
+    double *__restrict__ as, double *__restrict__ part)
 {
     __shared__ double lds[8];
     EC3D_TBL_DECL;
-    if (st->stop_iter < it) return;
+    if (stop_iter_of(st) < it) return;
     stage_table<FMT>(A, tbl);
     ZRegs zr;
     double acc[2] = {0.0, 0.0};
-    EC3D_SWEEP_BEGIN_A
-    double s0, s1;
-    d2 q;
-    spmv_pair<FMT, ZM>(A, tbl, VecPlain{sv}, r, tile, first_, zr, s0, s1, q);
-    store2<NT>(as, r, sw.n, s0, s1);
-    EC3D_MASK2(r, sw, s0, s1);
-    acc[0] = acc[0] + s0 * q.x;
-    acc[0] = acc[0] + s1 * q.y;
-    acc[1] = acc[1] + s0 * s0;
-    acc[1] = acc[1] + s1 * s1;
-    EC3D_SWEEP_END
+    EC3D_WALK(TileWalk<ZM>, (ZM ? 1 : 0))
+    {
+        EC3D_ROW;
+        double s0, s1;
+        d2 q;
+        spmv_pair<FMT, ZM, TAIL>(A, tbl, stg, VecPlain{sv}, r, tile, first_, zr, s0, s1, q);
+        store2<NT>(as, r, sw.n, s0, s1);
+        EC3D_MASK2(r, sw, s0, s1);
+        acc[0] = acc[0] + s0 * q.x;
+        acc[0] = acc[0] + s1 * q.y;
+        acc[1] = acc[1] + s0 * s0;
+        acc[1] = acc[1] + s1 * s1;
+    }
     block_sum<2>(acc, lds);
     if (threadIdx.x == 0) {
         part[P_D2 * sw.pstride + sw.part_off + blockIdx.x] = acc[0];
@@ -562,7 +919,7 @@ __global__ __launch_bounds__(EC3D_THREADS) void k4_x_r_update(Sweep sw, RedSrc s
                                                               double *hist, int64_t hist_cap)
 {
     __shared__ double lds[8];
-    if (st->stop_iter < it) return; // (this kernel is the one that may set stop_iter = it)
+    if (stop_iter_of(st) < it) return; // (this kernel is the one that may publish the exit (it, 1))
     const int slot_ss[1] = {P_SS};
     double ss[1];
     reduce_partials<1>(src_ss, slot_ss, ss, lds);
@@ -571,16 +928,17 @@ __global__ __launch_bounds__(EC3D_THREADS) void k4_x_r_update(Sweep sw, RedSrc s
     const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
     if (lead && hist && it <= hist_cap) hist[2 * (int64_t)(it - 1)] = snorm;
     if (snorm / st->bnorm < st->tol) {
-        EC3D_SWEEP_BEGIN
-        d2 xv = *reinterpret_cast<const d2 *>(x + r);
-        d2 pv = *reinterpret_cast<const d2 *>(p + r);
-        store2<false>(x, r, sw.n, xv.x + alpha * pv.x, xv.y + alpha * pv.y);
-        EC3D_SWEEP_END
-        if (lead) st->stop_kind = 1;
-        // every workgroup has read stop_iter above; K5 of this iteration tests stop_iter <= it.
-        // Written last and only by the lead thread; other workgroups of THIS launch may already
-        // have passed their entry test, which only compares against earlier iterations.
-        if (lead) st->stop_iter = it;
+        EC3D_WALK(TileWalk<false>, -1)
+        {
+            EC3D_ROW;
+            d2 xv = *reinterpret_cast<const d2 *>(x + r);
+            d2 pv = *reinterpret_cast<const d2 *>(p + r);
+            store2<false>(x, r, sw.n, xv.x + alpha * pv.x, xv.y + alpha * pv.y);
+        }
+        // every workgroup has read the exit word above; K5 of this iteration tests it again.  Published by the
+        // lead thread only; other workgroups of THIS launch may already have passed their entry test, which
+        // only compares against earlier iterations.
+        if (lead) stop_publish(st, it, 1);
         return;
     }
     const int slot[2] = {P_D2, P_D3};
@@ -589,21 +947,23 @@ __global__ __launch_bounds__(EC3D_THREADS) void k4_x_r_update(Sweep sw, RedSrc s
     const double omega = d[0] / d[1];
     if (lead) st->omega = omega;
     double acc[2] = {0.0, 0.0};
-    EC3D_SWEEP_BEGIN
-    d2 xv = load2<NT>(x + r);
-    d2 pv = load2<NT>(p + r);
-    d2 s = load2<NT>(sv + r);
-    d2 a = load2<NT>(as + r);
-    d2 q = load2<NT>(r0 + r);
-    store2<NT>(x, r, sw.n, (xv.x + alpha * pv.x) + omega * s.x, (xv.y + alpha * pv.y) + omega * s.y);
-    double e0 = s.x - omega * a.x, e1 = s.y - omega * a.y;
-    store2<NT>(rv, r, sw.n, e0, e1);
-    EC3D_MASK2(r, sw, e0, e1);
-    acc[0] = acc[0] + e0 * e0;
-    acc[0] = acc[0] + e1 * e1;
-    acc[1] = acc[1] + e0 * q.x;
-    acc[1] = acc[1] + e1 * q.y;
-    EC3D_SWEEP_END
+    EC3D_WALK(TileWalk<false>, -1)
+    {
+        EC3D_ROW;
+        d2 xv = load2<NT>(x + r);
+        d2 pv = load2<NT>(p + r);
+        d2 s = load2<NT>(sv + r);
+        d2 a = load2<NT>(as + r);
+        d2 q = load2<NT>(r0 + r);
+        store2<NT>(x, r, sw.n, (xv.x + alpha * pv.x) + omega * s.x, (xv.y + alpha * pv.y) + omega * s.y);
+        double e0 = s.x - omega * a.x, e1 = s.y - omega * a.y;
+        store2<NT>(rv, r, sw.n, e0, e1);
+        EC3D_MASK2(r, sw, e0, e1);
+        acc[0] = acc[0] + e0 * e0;
+        acc[0] = acc[0] + e1 * e1;
+        acc[1] = acc[1] + e0 * q.x;
+        acc[1] = acc[1] + e1 * q.y;
+    }
     block_sum<2>(acc, lds);
     if (threadIdx.x == 0) {
         part[P_RR * sw.pstride + sw.part_off + blockIdx.x] = acc[0];
@@ -620,14 +980,14 @@ __global__ __launch_bounds__(EC3D_THREADS) void k5_p_update(Sweep sw, RedSrc src
                                                             double *__restrict__ r0, double *hist, int64_t hist_cap)
 {
     __shared__ double lds[8];
-    // Only exits taken by EARLIER launches end this one: the ||S|| exit of this iteration's K4
-    // (stop_iter == it, kind 1) or anything before.  The lead thread of THIS launch writes stop_iter = it
-    // (kind 2) below while other workgroups may still be at this test; a wave that returned on seeing it
-    // would leave its workgroup's barriers in reduce_partials short of a wave.  Every workgroup reaches the
-    // same ||R|| decision from the same sums anyway.  (kind is written before stop_iter, by one thread.)
+    // Only exits taken by EARLIER launches end this one: the ||S|| exit of this iteration's K4 (it, kind 1) or
+    // anything before.  The lead thread of THIS launch publishes (it, 2) below while other workgroups may still
+    // be at this test; a wave that returned on seeing it would leave its workgroup's barriers in
+    // reduce_partials short of a wave.  The pair is one word (stop_publish), so (it, 1) is K4's and nothing else.
     {
-        const int si = st->stop_iter;
-        if (si < it || (si == it && st->stop_kind == 1)) return;
+        int si, kind;
+        stop_read(st, si, kind);
+        if (si < it || (si == it && kind == 1)) return;
     }
     const int slot[2] = {P_RR, P_RR0N};
     double d[2];
@@ -637,10 +997,7 @@ __global__ __launch_bounds__(EC3D_THREADS) void k5_p_update(Sweep sw, RedSrc src
     const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
     if (lead && hist && it <= hist_cap) hist[2 * (int64_t)(it - 1) + 1] = rnorm;
     if (rnorm / bnorm < tol) {
-        if (lead) {
-            st->stop_kind = 2;
-            st->stop_iter = it;
-        }
+        if (lead) stop_publish(st, it, 2);
         return;
     }
     const double rr0_new = d[1];
@@ -649,17 +1006,19 @@ __global__ __launch_bounds__(EC3D_THREADS) void k5_p_update(Sweep sw, RedSrc src
     const bool restart = fabs(rr0_new) / bnorm < tol;
     // next iteration's R·R0: after a restart R0 == R, so it is R·R in the same summation order
     if (lead) st->rr0[(it + 1) & 1] = restart ? d[0] : rr0_new;
-    EC3D_SWEEP_BEGIN
-    d2 q = load2<NT>(rv + r);
-    if (restart) {
-        store2<NT>(r0, r, sw.n, q.x, q.y);
-        store2<NT>(p, r, sw.n, q.x, q.y);
-    } else {
-        d2 pv = load2<NT>(p + r);
-        d2 a = load2<NT>(ap + r);
-        store2<NT>(p, r, sw.n, q.x + beta * (pv.x - omega * a.x), q.y + beta * (pv.y - omega * a.y));
+    EC3D_WALK(TileWalk<false>, -1)
+    {
+        EC3D_ROW;
+        d2 q = load2<NT>(rv + r);
+        if (restart) {
+            store2<NT>(r0, r, sw.n, q.x, q.y);
+            store2<NT>(p, r, sw.n, q.x, q.y);
+        } else {
+            d2 pv = load2<NT>(p + r);
+            d2 a = load2<NT>(ap + r);
+            store2<NT>(p, r, sw.n, q.x + beta * (pv.x - omega * a.x), q.y + beta * (pv.y - omega * a.y));
+        }
     }
-    EC3D_SWEEP_END
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -673,21 +1032,108 @@ static inline int fmt_of(const MatView &A)
 }
 // streaming policy: vectors of >= 32 MiB each (n_pad >= 4 Mi rows) cannot live in the caches
 static inline bool nt_of(const Sweep &sw) { return sw.nt != 0; }
-// dynamic LDS: the class table only (a full 256-class table of the structured form would be 32 KiB and
-// cap the CU at 4 workgroups; real problems have ~100 classes)
-#define EC3D_TBL_BYTES(F)                                                                      \
-    ((F) == FMT_DICT7 ? (size_t)A.ncls * 7 * 8 : ((F) == FMT_SAV ? (size_t)A.ncls * EC3D_SAV_STRIDE * 8 : 0))
+
+static inline TailDev tail_of(const MatView &A) { return TailDev{A.tail_id, A.tile_flag, A.chunk_ptr, A.tcol, A.tval}; }
+template <int FMT> static MatDev<FMT> mat_dev(const MatView &A);
+template <> MatDev<FMT_GENERIC> mat_dev<FMT_GENERIC>(const MatView &A)
+{
+    MatDev<FMT_GENERIC> m;
+    for (int b = 0; b < EC3D_MAXB; ++b) {
+        m.band[b] = A.band[b];
+        m.off[b] = A.off[b];
+    }
+    m.nb = A.nb;
+    m.t = tail_of(A);
+    return m;
+}
+template <> MatDev<FMT_DIA7> mat_dev<FMT_DIA7>(const MatView &A)
+{
+    MatDev<FMT_DIA7> m;
+    for (int b = 0; b < 7; ++b) {
+        m.band[b] = A.band[b];
+        m.off[b] = A.off[b];
+    }
+    m.pm1 = A.pm1;
+    m.t = tail_of(A);
+    return m;
+}
+template <> MatDev<FMT_DICT7> mat_dev<FMT_DICT7>(const MatView &A)
+{
+    MatDev<FMT_DICT7> m;
+    m.cls = A.cls;
+    m.table = A.table;
+    for (int b = 0; b < 7; ++b) m.off[b] = A.off[b];
+    m.ncls = A.ncls;
+    m.pm1 = A.pm1;
+    m.t = tail_of(A);
+    return m;
+}
+template <> MatDev<FMT_SAV> mat_dev<FMT_SAV>(const MatView &A)
+{
+    MatDev<FMT_SAV> m;
+    m.cls = A.cls;
+    m.tile_flag = A.tile_flag;
+    m.table = A.table;
+    m.nC = A.sav_nC;
+    m.sdx = A.sav_step[1];
+    m.pitch = A.sav_step[2];
+    m.ncls = A.ncls;
+    m.pm1 = A.pm1;
+    m.a0 = A.sav_a0;
+    m.u0 = A.sav_u0;
+    m.zero = A.sav_zero;
+    return m;
+}
+static inline SweepZ sweep_z(const Sweep &sw)
+{
+    SweepZ z;
+    z.ntiles = sw.ntiles;
+    z.n = sw.n;
+    z.tpp = sw.zm_tpp;
+    z.pps = sw.zm_pps;
+    z.npl = sw.zm_npl;
+    z.pl0 = sw.zm_pl0;
+    z.pstride = sw.pstride;
+    z.part_off = sw.part_off;
+    z.ulist_n = sw.ulist_n;
+    z.ulist = sw.ulist;
+    z.win_npo = sw.win_nt > 0 ? sw.win_nt / sw.zm_tpp : 0;
+    z.win_npb = sw.win_nt > 0 ? sw.win_blk / sw.zm_tpp : 0;
+    z.win_p0 = sw.win_nt > 0 ? sw.win_t0 / sw.zm_tpp : 0;
+    return z;
+}
+// dynamic LDS: the class table (a full 256-class table of the structured form would be 32 KiB and cap the CU
+// at 4 workgroups; real problems have 64 classes = 8 KiB) and, for the z-marching structured kernels, the
+// staging slots behind it (16 KiB): 24.6 KiB per workgroup, six of them fit a CU's 160 KiB
+static inline size_t tbl_bytes(const MatView &A, int F, bool zm)
+{
+    if (F == FMT_DICT7) return (size_t)A.ncls * 7 * 8;
+    if (F == FMT_SAV) return (size_t)A.ncls * EC3D_SAV_STRIDE * 8 + (zm ? (size_t)EC3D_NSTAGE * EC3D_TILE * 8 : 0);
+    return 0;
+}
+#define EC3D_LAUNCH_ZT(F, NT_, KERNEL, ...)                                                                         \
+    do {                                                                                                            \
+        const bool tail_ = F != FMT_SAV && A.has_tail;                                                              \
+        const size_t lds_ = tbl_bytes(A, F, zm_);                                                                   \
+        const MatDev<F> Ad = mat_dev<F>(A);                                                                         \
+        if constexpr (F != FMT_GENERIC) {                                                                           \
+            if (zm_) {                                                                                              \
+                const SweepZ swz = sweep_z(sw);                                                                     \
+                if (tail_) { if constexpr (F != FMT_SAV) KERNEL<F, NT_, true, true><<<sw.nblk, EC3D_THREADS, lds_, s>>>(Ad, swz, __VA_ARGS__); } \
+                else KERNEL<F, NT_, true, false><<<sw.nblk, EC3D_THREADS, lds_, s>>>(Ad, swz, __VA_ARGS__);          \
+                break;                                                                                              \
+            }                                                                                                       \
+        }                                                                                                           \
+        if (tail_) { if constexpr (F != FMT_SAV) KERNEL<F, NT_, false, true><<<sw.nblk, EC3D_THREADS, lds_, s>>>(Ad, sw, __VA_ARGS__); } \
+        else KERNEL<F, NT_, false, false><<<sw.nblk, EC3D_THREADS, lds_, s>>>(Ad, sw, __VA_ARGS__);                  \
+    } while (0)
 #define EC3D_LAUNCH_FMT(F, KERNEL, ...)                                                        \
     do {                                                                                       \
         const bool zm_ = sw.zm_tpp > 0 && sw.bnd_last < 0 && F != FMT_GENERIC;                 \
-        if (nt_of(sw) && zm_)                                                                  \
-            KERNEL<F, true, (F != FMT_GENERIC)><<<sw.nblk, EC3D_THREADS, EC3D_TBL_BYTES(F), s>>>(__VA_ARGS__); \
-        else if (nt_of(sw))                                                                    \
-            KERNEL<F, true, false><<<sw.nblk, EC3D_THREADS, EC3D_TBL_BYTES(F), s>>>(__VA_ARGS__);              \
-        else if (zm_)                                                                          \
-            KERNEL<F, false, (F != FMT_GENERIC)><<<sw.nblk, EC3D_THREADS, EC3D_TBL_BYTES(F), s>>>(__VA_ARGS__);\
+        if (nt_of(sw))                                                                         \
+            EC3D_LAUNCH_ZT(F, true, KERNEL, __VA_ARGS__);                                      \
         else                                                                                   \
-            KERNEL<F, false, false><<<sw.nblk, EC3D_THREADS, EC3D_TBL_BYTES(F), s>>>(__VA_ARGS__);             \
+            EC3D_LAUNCH_ZT(F, false, KERNEL, __VA_ARGS__);                                     \
     } while (0)
 #define EC3D_DISPATCH(A, KERNEL, ...)                                                          \
     do {                                                                                       \
@@ -708,13 +1154,13 @@ static inline bool nt_of(const Sweep &sw) { return sw.nt != 0; }
 
 void ec3d_launch_spmv(const MatView &A, const Sweep &sw, const double *x, double *y, hipStream_t s)
 {
-    EC3D_DISPATCH(A, k_spmv, A, sw, x, y);
+    EC3D_DISPATCH(A, k_spmv, x, y);
 }
 
 void ec3d_launch_residual(const MatView &A, const Sweep &sw, const double *x, const double *b, double *r,
                           double *r0, double *p, double *part, hipStream_t s)
 {
-    EC3D_DISPATCH(A, k_residual, A, sw, x, b, r, r0, p, part);
+    EC3D_DISPATCH(A, k_residual, x, b, r, r0, p, part);
 }
 
 void ec3d_launch_finalize(const RedSrc &src, double *lsum, unsigned mask, hipStream_t s)
@@ -730,7 +1176,7 @@ void ec3d_launch_setup(SolverState *st, const RedSrc &src, double tol, hipStream
 void ec3d_launch_k1(const MatView &A, const Sweep &sw, const SolverState *st, int it, const double *p,
                     const double *r0, double *ap, double *part, hipStream_t s)
 {
-    EC3D_DISPATCH(A, k1_spmv_dot, A, sw, st, it, p, r0, ap, part);
+    EC3D_DISPATCH(A, k1_spmv_dot, st, it, p, r0, ap, part);
 }
 
 void ec3d_launch_k2(const Sweep &sw, const RedSrc &src, SolverState *st, int it, const double *r, const double *ap,
@@ -742,7 +1188,7 @@ void ec3d_launch_k2(const Sweep &sw, const RedSrc &src, SolverState *st, int it,
 void ec3d_launch_k3(const MatView &A, const Sweep &sw, SolverState *st, int it, const double *sv, double *as,
                     double *part, hipStream_t s)
 {
-    EC3D_DISPATCH(A, k3_spmv_dots, A, sw, st, it, sv, as, part);
+    EC3D_DISPATCH(A, k3_spmv_dots, st, it, sv, as, part);
 }
 
 void ec3d_launch_k4(const Sweep &sw, const RedSrc &src_ss, const RedSrc &src, SolverState *st, int it,

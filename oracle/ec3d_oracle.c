@@ -584,3 +584,30 @@ int oracle_poisson_csr(int32_t sdx, int32_t sdy, int32_t sdz, const double *BND,
     if (nnz_out) *nnz_out = p;
     return 0;
 }
+
+/* The same operator for the z-planes [k0, k1) (0-based) only: local row pointers, GLOBAL 1-based columns, so
+ * oracle_spmv_csr over these rows with the whole vector gives those rows of A*x.  What a 512^3 check can afford
+ * (the full CSR triple is 11 GB): config 4's parity test compares a few planes' worth of rows.            */
+int oracle_poisson_csr_planes(int32_t sdx, int32_t sdy, int32_t sdz, const double *BND, const double *delta,
+                              int32_t k0, int32_t k1, int32_t *irow, int32_t *jcol, double *valA, int64_t *nnz_out)
+{
+    const int32_t kdz = sdx * sdy;
+    const double s3[3] = {1.0 / (delta[0] * delta[0]), 1.0 / (delta[1] * delta[1]),
+                          1.0 / (delta[2] * delta[2])};
+    int64_t p = 0;
+    int64_t row = 0;
+    irow[0] = 1;
+    for (int k = k0 + 1; k <= k1; ++k)
+    for (int j = 1; j <= sdy; ++j)
+    for (int i = 1; i <= sdx; ++i) {
+        int32_t col[10]; double val[10];
+        const int32_t nn = i + (j - 1) * sdx + (k - 1) * kdz;   /* src/EC3D.f90:524-525 */
+        int L = a_row_base(i, j, k, sdx, sdy, sdz, nn, kdz, BND, s3, col, val);
+        sort_row(col, val, L);
+        if (jcol) for (int m = 0; m < L; ++m) { jcol[p + m] = col[m]; valA[p + m] = val[m]; }
+        p += L;
+        irow[++row] = (int32_t)(p + 1);
+    }
+    if (nnz_out) *nnz_out = p;
+    return 0;
+}

@@ -84,6 +84,9 @@ def lib() -> C.CDLL:
         L.oracle_poisson_csr.argtypes = [C.c_int32, C.c_int32, C.c_int32, _f64p, _f64p, _i32p,
                                          C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
         L.oracle_poisson_csr.restype = C.c_int
+        L.oracle_poisson_csr_planes.argtypes = [C.c_int32, C.c_int32, C.c_int32, _f64p, _f64p, C.c_int32, C.c_int32,
+                                                _i32p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+        L.oracle_poisson_csr_planes.restype = C.c_int
         _lib = L
     return _lib
 
@@ -205,6 +208,26 @@ def poisson_csr(sdx, sdy, sdz, delta=(0.00333, 0.00333, 0.00333), bnd=-0.95):
     lib().oracle_poisson_csr(sdx, sdy, sdz, BND, d, irow, jcol.ctypes.data, valA.ctypes.data,
                              C.byref(nnz))
     return valA, irow, jcol
+
+
+def poisson_rows_times(sdx, sdy, sdz, k0, k1, x, delta=(0.00333, 0.00333, 0.00333), bnd=-0.95):
+    """Rows of the planes [k0, k1) (0-based) of poisson_csr(sdx, sdy, sdz) times the whole vector x: the CSR of
+    those planes only (global columns), summed by the same oracle_spmv_csr (src/solvers.f90:54-61)."""
+    BND = np.full(6, float(bnd)) if np.isscalar(bnd) else np.ascontiguousarray(bnd, np.float64)
+    d = np.ascontiguousarray(delta, np.float64)
+    rows = (k1 - k0) * sdx * sdy
+    irow = np.empty(rows + 1, np.int32)
+    nnz = C.c_int64(0)
+    L = lib()
+    L.oracle_poisson_csr_planes(sdx, sdy, sdz, BND, d, k0, k1, irow, None, None, C.byref(nnz))
+    jcol = np.empty(nnz.value, np.int32)
+    valA = np.empty(nnz.value, np.float64)
+    L.oracle_poisson_csr_planes(sdx, sdy, sdz, BND, d, k0, k1, irow, jcol.ctypes.data, valA.ctypes.data, C.byref(nnz))
+    x = np.ascontiguousarray(x, np.float64)
+    assert x.size == sdx * sdy * sdz
+    y = np.empty(rows)
+    L.oracle_spmv_csr(valA, irow, jcol, rows, x, y)
+    return y
 
 
 def bar_rhs(N):

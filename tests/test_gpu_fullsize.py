@@ -36,11 +36,15 @@ def _have(case):
     return os.path.exists(os.path.join(GOLDEN, CASES[case][0] + ".npz"))
 
 
-def _model(case):
+def _model(case, tol_text=None):
+    import re
     from eddy_currents_3d_amd import vxc
     g4 = load_golden("g4_" + case)
     g6 = load_golden(CASES[case][0])
-    small = vxc.VxcModel(g4["vox"], [str(s) for s in g4["names"]], float(str(g4["lattice_dim"])),
+    names = [str(s) for s in g4["names"]]
+    if tol_text is not None:      # the palette's "solver tol=" overridden, as oracle/make_goldens.py case_g6t does
+        names = [re.sub(r"\btol=\S+", "tol=" + tol_text, n) if re.search(r"\bsolver\b", n, re.I) else n for n in names]
+    small = vxc.VxcModel(g4["vox"], names, float(str(g4["lattice_dim"])),
                          tuple(float(x) for x in g4["adj"]))
     big = vxc.resample(small, *[int(v) for v in g6["dims"]])
     assert np.array_equal(big.delta, g6["delta"])          # the cell sizes the reference read from the file
@@ -307,3 +311,44 @@ def test_first_iterations_track_the_reference_at_full_size(case, tmp_path):
         assert dx <= (1e-10 if kk <= 8 else 1e-7)
         assert dr <= (1e-10 if kk <= 8 else 1e-7)
         worst = max(worst, dx)
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_converged_solution_within_ten_tol_of_the_reference(case):
+    """SURVEY section 8d's bar, unwidened: ||x_gpu - x_ref||_2 / ||x_ref||_2 <= 10*tol at full size, on a solve that
+    CONVERGES.  The shipped inputs stop at tol = 5e-3, where two summation orders of the same algorithm end 5-13 %
+    apart (the reference against its own -ffast-math build, g6x); with the palette's tolerance overridden to 5e-4
+    the unmodified reference (oracle/make_goldens.py case_g6t: first time step, b = the sources alone, x0 = 0;
+    666 iterations on config 3, 195 on config 5) and the GPU land on the same solution.  Also asserted: ||b|| to
+    rounding, the true residual from the device below tol, 200 probes of x within 10*tol of the largest entry."""
+    name = CASES[case][0].replace("g6_", "g6t_")
+    if not os.path.exists(os.path.join(GOLDEN, name + ".npz")):
+        pytest.skip("fixture not generated")
+    import eddy_currents_3d_amd as E
+    from eddy_currents_3d_amd import host
+    from oracle import oracle as O
+    gt = load_golden(name)
+    tol = float(gt["tol"])
+    model, _ = _model(case, tol_text=str(gt["tol_text"]))
+    out = {}
+
+    def on_solved(k, s, info):
+        x = s.download("X")
+        out.update(iter=info["iter"], res=s.true_residual(), xnorm=float(np.linalg.norm(x)), sketch=O.count_sketch(x),
+                   xprobe=x[gt["probes"]])
+
+    with E.EC3DSolver() as s:
+        host.run(model, s, steps=1, on_solved=on_solved)
+        assert s.n == int(gt["n"])
+    res, bnorm = out["res"]
+    rel = float(np.linalg.norm(out["sketch"] - gt["xsketch"]) / np.linalg.norm(gt["xsketch"]))
+    pmax = float(np.abs(out["xprobe"] - gt["xprobe"]).max() / np.abs(gt["xprobe"]).max())
+    print(f"{case} {tuple(int(v) for v in gt['dims'])} at tol {tol:g}: iter {out['iter']} / reference {int(gt['iter'])}; ||x|| "
+          f"{out['xnorm']:.8e} / {float(gt['xnorm']):.8e}; ||x - x_ref|| / ||x_ref|| = {rel:.3e} (bar 10*tol = {10 * tol:g}); "
+          f"true residual {res:.3e} (reference's own {float(gt['true_residual']):.3e}); probes max diff {pmax:.2e} of the largest")
+    assert bnorm == pytest.approx(float(gt["bnorm"]), rel=1e-13)
+    assert res < tol
+    assert rel <= 10 * tol                       # SURVEY 8d, no widening
+    assert pmax <= 10 * tol
+    assert out["xnorm"] == pytest.approx(float(gt["xnorm"]), rel=10 * tol)
+    assert 0.4 * int(gt["iter"]) <= out["iter"] <= 2.5 * int(gt["iter"])
