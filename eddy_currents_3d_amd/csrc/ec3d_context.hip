@@ -176,64 +176,69 @@ static int choose_sweep(ec3d_ctx *c)
         sw.ntiles = 3 * sw.win_nt;
         sw.nown = 0;
     }
-    // 256 CUs x 3 workgroups: measured best on 512^3 (whole multiples of the CU count matter;
-    // 768 > 1024 > 512 > 2048)
-    int want = c->nblk_request > 0 ? c->nblk_request : 768;
-    int64_t nblk = std::min<int64_t>(sw.ntiles, want);
-    if (nblk >= 8) {
-        nblk -= nblk % 8;
-        sw.S = (int)(nblk / 8);
-    } else {
-        sw.S = 0;
-    }
-    if (const char *e = getenv("EC3D_XCD_MAP"))
-        if (atoi(e) == 0) sw.S = 0;
-    sw.nblk = (int)nblk;
     sw.nt = c->nt_request >= 0 ? c->nt_request : (c->A.n_pad >= (4 << 20));
-    // K2 and K5 on grids of their own: the same map with another workgroup count
-    auto with_blocks = [&](int want_k) {
+    // Vector kernels (K2, K4, K5): each on a grid, a tile map and a batching depth of its own.
+    //   nblk  workgroups (whole multiples of the 256 CUs matter: 384 is far worse than 256 or 512)
+    //   map   1: XCD-aware moving window (label b % 8 owns S consecutive tiles of a window of nblk), 0: tile b, b + nblk, ...
+    //   depth tiles whose operands a wave requests before it finishes the first (walk_vec in ec3d_kernels.hip)
+    // Defaults are the measured optima (tools/vec_sweep.py, profiles/r03_vec_sweep_*); EC3D_NBLK_K*, EC3D_MAP_K*,
+    // EC3D_DEPTH_K* override one kernel, EC3D_XCD_MAP / EC3D_VEC_DEPTH all three, ec3d_set_workgroups every grid.
+    struct VecPlan { int nblk, map, depth; };
+    auto plan_of = [&](const char *k, VecPlan d) {
+        if (c->nblk_request > 0) d.nblk = c->nblk_request;
+        if (const char *e = getenv("EC3D_XCD_MAP")) d.map = atoi(e) != 0;
+        if (const char *e = getenv("EC3D_VEC_DEPTH")) d.depth = atoi(e);
+        if (c->nblk_request <= 0)
+            if (const char *e = getenv((std::string("EC3D_NBLK_") + k).c_str())) d.nblk = std::max(1, atoi(e));
+        if (const char *e = getenv((std::string("EC3D_MAP_") + k).c_str())) d.map = atoi(e) != 0;
+        if (const char *e = getenv((std::string("EC3D_DEPTH_") + k).c_str())) d.depth = atoi(e);
+        if (d.depth != 2 && d.depth != 4) d.depth = 1;
+        return d;
+    };
+    auto vec_sweep = [&](const VecPlan &pl) {
         Sweep k = sw;
-        int64_t nb = std::min<int64_t>(sw.ntiles, want_k);
+        int64_t nb = std::min<int64_t>(sw.ntiles, pl.nblk);
+        k.S = 0;
         if (nb >= 8) {
             nb -= nb % 8;
-            k.S = sw.S > 0 ? (int)(nb / 8) : 0;
-        } else {
-            k.S = 0;
+            if (pl.map) k.S = (int)(nb / 8);
         }
-        k.nblk = (int)nb;
+        k.nblk = (int)std::max<int64_t>(nb, 1);
+        k.vec_depth = pl.depth;
         return k;
     };
     {
-        int w4 = want, w2 = want, w5 = want;
-        if (c->nblk_request <= 0) {
-            // K4 (5 reads + 2 writes) streams best from 2 workgroups per CU once the vectors are far beyond the
-            // caches: 512^3 1.31 vs 1.38 ms; at 256^3 3 per CU win (0.137 vs 0.147 ms); K2 and K5 prefer 3 per
-            // CU at both sizes (tools/vec_grid_sweep.sh)
-            if (c->A.n_pad >= ((int64_t)1 << 25)) w4 = 512; // 384^3: 0.498 vs 0.522 ms
-            if (const char *e = getenv("EC3D_NBLK_K4")) w4 = std::max(1, atoi(e));
-            if (const char *e = getenv("EC3D_NBLK_K2")) w2 = std::max(1, atoi(e));
-            if (const char *e = getenv("EC3D_NBLK_K5")) w5 = std::max(1, atoi(e));
-        }
-        if (w4 != want) sw = with_blocks(w4);
-        c->sweep_k2 = with_blocks(w2);
-        c->sweep_k5 = with_blocks(w5);
+        const bool big = c->A.n_pad >= ((int64_t)1 << 25); // vectors of 256 MiB and more: nothing stays in a cache
+        const VecPlan p2 = plan_of("K2", big ? VecPlan{768, 0, 2} : VecPlan{768, 1, 1});
+        const VecPlan p4 = plan_of("K4", big ? VecPlan{256, 0, 2} : VecPlan{768, 1, 1});
+        const VecPlan p5 = plan_of("K5", big ? VecPlan{256, 0, 2} : VecPlan{768, 1, 1});
+        c->sweep_k2 = vec_sweep(p2);
+        c->sweep_k5 = vec_sweep(p5);
+        c->sweep_s = vec_sweep(plan_of("SPMV_PLAIN", VecPlan{768, 1, 1})); // SpMV kernels on grids without a z-march
+        sw = vec_sweep(p4);
     }
 
     Sweep &ss = c->sweep_s;
-    ss = sw;
     const DevMatrix &A = c->A;
     int zm = c->zm_request;
     if (const char *e = getenv("EC3D_ZMARCH")) zm = atoi(e);
     // the z-marching kernels carry no ownership ranges: a slab whose owned rows are not a window of whole
     // planes (bands + tail A-V slabs) keeps the plain map
     if (sw.nown > 0) zm = 0;
-    if (zm != 0 && A.nb == 7 && A.off[3] == 0 && A.off[0] == -A.off[6] && A.off[6] % EC3D_TILE == 0) {
+    if (zm != 0 && A.nb == 7 && A.off[3] == 0 && A.off[0] == -A.off[6] && A.off[6] % EC3D_TILE == 0 && A.off[2] == -1 &&
+        A.off[4] == 1 && A.off[1] == -A.off[5]) {
         const int64_t tpp = A.off[6] / EC3D_TILE;
         const int64_t nplanes = (sw.ntiles + tpp - 1) / tpp;
         if (tpp <= 4096 && nplanes >= 8) {
-            // the SpMV kernels like twice the workgroups of the vector kernels: 1536 (6 per CU) and 3072
-            // beat 1024 and 2048 at both 256^3 and 512^3
-            int want_s = c->nblk_request > 0 ? c->nblk_request : 1536;
+            // workgroups of the z-marching kernels (tools/vec_sweep.py, profiles/r03_sweep_*): the single-component
+            // kernels, 50-76 registers since they take per-format arguments, run best from 4 workgroups per CU once
+            // the vectors are far beyond the caches (512^3: K1/K3 619/487 us at 1024 against 654/508 at 1536) and
+            // from 3 per CU below that (256^3: 83.8/60.7 at 768 against 85.1/67.4); the structured A-V kernels, whose
+            // conductor columns are several times heavier than the others, want the finer grain of 6 per CU
+            // (21 M unknowns: 128/108 at 1472, 145/124 at 1104)
+            int want_s = c->nblk_request > 0 ? c->nblk_request
+                         : A.sav                 ? 1536
+                         : c->A.n_pad >= ((int64_t)1 << 25) ? 1024 : 768;
             if (const char *e = getenv("EC3D_NBLK_SPMV")) want_s = atoi(e);
             // columns are dealt to the 8 XCD labels in runs of cpx; with tpp % 8 != 0 the last run is short
             // and 8*cpx - tpp workgroups per segment stay idle

@@ -66,6 +66,7 @@ struct Sweep {
     int nblk;
     int S;
     int nt;      // nontemporal policy for once-touched streams (large problems)
+    int vec_depth; // vector kernels: tiles whose operands are requested together (1, 2, 4)
     int pstride; // doubles between two slots of the partial-sum buffer
     // z-marching map of the SpMV kernels (zm_tpp > 0): a workgroup owns one 512-row position of the
     // xy-plane ("column") and walks zm_pps consecutive planes, so x[r-kdz], x[r] stay in registers

@@ -20,6 +20,10 @@
 // reference's x86-64 object code does; the oracle's "GPU order" twin reproduces every bit.
 #include "ec3d_internal.hpp"
 
+#include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+
 typedef double d2 __attribute__((ext_vector_type(2)));
 typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
 typedef int i2 __attribute__((ext_vector_type(2)));
@@ -147,6 +151,19 @@ struct SweepZ {
     const int32_t *ulist;
     int64_t win_npo, win_npb, win_p0; // window in planes (owned per block, held per block, first owned); npo = 0: none
 };
+// the launch of a vector kernel (K2, K4, K5) as it sees it: logical tiles t0, t0 + stride, ... of the front sweep
+// (the XCD-aware map of ec3d_tile_of: t0 = (b % 8) * S + b / 8, stride = 8 S; or t0 = b, stride = nblk), then its
+// share of the tile list.  Passing the whole Sweep cost the loops a kernel-argument reload per tile.
+struct SweepV {
+    int64_t ntiles, n;
+    int S, nblk;
+    int pstride, part_off;
+    int ulist_n, two;
+    const int32_t *ulist;
+    int64_t win_nt, win_blk, win_t0;
+    int nown;
+    int64_t own_lo[4], own_hi[4];
+};
 template <bool ZM> struct SweepSel { typedef Sweep type; };
 template <> struct SweepSel<true> { typedef SweepZ type; };
 
@@ -175,6 +192,13 @@ __device__ __forceinline__ bool row_owned(const Sweep &sw, int64_t r)
     return o;
 }
 __device__ __forceinline__ bool row_owned(const SweepZ &sw, int64_t r) { return r < sw.n; }
+__device__ __forceinline__ bool row_owned(const SweepV &sw, int64_t r)
+{
+    if (sw.nown == 0) return r < sw.n;
+    bool o = false;
+    for (int q = 0; q < sw.nown; ++q) o |= (r >= sw.own_lo[q]) & (r < sw.own_hi[q]);
+    return o;
+}
 #define EC3D_MASK2(r, sw_, a, b)                                                               \
     do {                                                                                       \
         if (!row_owned(sw_, (r))) (a) = 0.0;                                                   \
@@ -183,81 +207,150 @@ __device__ __forceinline__ bool row_owned(const SweepZ &sw, int64_t r) { return 
 
 // ---------------------------------------------------------------------------------------------
 // The tiles a workgroup visits, in order: the front sweep (ec3d_tile_of), then its share of the U-block list.
-// `first`: nothing is carried over from the previous tile (the z-march registers must be loaded).
-template <bool ZM> struct TileWalk;
-template <> struct TileWalk<false> {
-    const Sweep &sw;
-    int64_t it = 0, lst = -1;
-    __device__ __forceinline__ TileWalk(const Sweep &s) : sw(s) {}
-    template <int MODE = 0> __device__ __forceinline__ bool next(int64_t &tile, bool &first)
-    {
-        first = true;
-        if (lst < 0) {
-            tile = ec3d_tile_of<MODE>(sw, blockIdx.x, it++);
-            if (tile >= 0) return true;
-            if (sw.ulist_n == 0) return false;
-            lst = blockIdx.x;
-        }
-        if (lst >= sw.ulist_n) return false;
-        tile = sw.ulist[lst];
-        lst += sw.nblk;
-        return true;
+// body(tile, first): `first` (a compile-time constant at every call site, so the loop bodies are specialised and
+// branch free) says that nothing is carried over from the previous tile -- the z-march registers must be loaded.
+typedef std::integral_constant<bool, true> TrueC;
+typedef std::integral_constant<bool, false> FalseC;
+
+// plain maps (vector kernels: MODE -1; SpMV kernels on grids without a z-march and boundary launches: MODE 0)
+template <int MODE, class BODY>
+__device__ __forceinline__ void walk_plain(const Sweep &sw, BODY &&body)
+{
+    for (int64_t it = 0;; ++it) {
+        const int64_t tile = ec3d_tile_of<MODE>(sw, blockIdx.x, it);
+        if (tile < 0) break;
+        body(tile, TrueC());
     }
-};
-// ec3d_tile_of<1> walked incrementally: one column, consecutive logical planes; in a windowed slab the physical
-// plane jumps over the halo planes at every block and the march starts afresh there
-template <> struct TileWalk<true> {
-    const SweepZ &sw;
-    int64_t lp, lend, pl, rem, lst = -1;
-    int col;
-    bool fresh = true;
-    __device__ __forceinline__ TileWalk(const SweepZ &s) : sw(s)
-    {
-        const int cpx = (sw.tpp + 7) >> 3, c = blockIdx.x & 7, sg = blockIdx.x >> 3;
-        col = c * cpx + sg % cpx;
-        const int64_t seg = sg / cpx;
-        lp = seg * sw.pps;
-        lend = lp + sw.pps;
-        if (sw.npl > 0 && lend > sw.npl) lend = sw.npl;
-        if (col >= sw.tpp) lend = lp;
-        const int64_t L = sw.pl0 + lp;
-        if (sw.win_npo > 0) {
-            rem = L % sw.win_npo;
-            pl = (L / sw.win_npo) * sw.win_npb + sw.win_p0 + rem;
-        } else {
-            rem = 1; // never 0: no block starts
-            pl = L;
+    for (int64_t lst = blockIdx.x; lst < sw.ulist_n; lst += sw.nblk) body((int64_t)sw.ulist[lst], TrueC());
+}
+// vector kernels: the same sequence as ec3d_tile_of<-1> gives for their sweeps, walked by a stride.
+// load(tile) requests a tile's operands and returns them; fin(tile, operands) computes, stores and accumulates.
+// With sw.two the operands of TWO tiles are requested before the first is finished (twice the bytes in flight
+// per wave); tiles are finished in the order of the one-tile walk, so the sums are the same sums.
+template <class LOAD, class FIN>
+__device__ __forceinline__ void walk_vec(const SweepV &sw, LOAD &&load, FIN &&fin)
+{
+    const int b = blockIdx.x;
+    const int64_t t0 = sw.S > 0 ? (int64_t)(b & 7) * sw.S + (b >> 3) : b;
+    const int64_t stride = sw.S > 0 ? (int64_t)8 * sw.S : sw.nblk;
+    if (sw.win_nt > 0) {
+        for (int64_t t = t0; t < sw.ntiles; t += stride) {
+            const int64_t p = (t / sw.win_nt) * sw.win_blk + sw.win_t0 + t % sw.win_nt;
+            auto a = load(p);
+            fin(p, a);
+        }
+    } else if (sw.two == 4) {
+        int64_t t = t0;
+        for (; t + 3 * stride < sw.ntiles; t += 4 * stride) {
+            auto a = load(t);
+            auto c = load(t + stride);
+            auto d = load(t + 2 * stride);
+            auto e = load(t + 3 * stride);
+            fin(t, a);
+            fin(t + stride, c);
+            fin(t + 2 * stride, d);
+            fin(t + 3 * stride, e);
+        }
+        for (; t < sw.ntiles; t += stride) {
+            auto a = load(t);
+            fin(t, a);
+        }
+    } else if (sw.two == 2) {
+        int64_t t = t0;
+        for (; t + stride < sw.ntiles; t += 2 * stride) {
+            auto a = load(t);
+            auto c = load(t + stride);
+            fin(t, a);
+            fin(t + stride, c);
+        }
+        if (t < sw.ntiles) {
+            auto a = load(t);
+            fin(t, a);
+        }
+    } else {
+        for (int64_t t = t0; t < sw.ntiles; t += stride) {
+            auto a = load(t);
+            fin(t, a);
         }
     }
-    template <int MODE = 1> __device__ __forceinline__ bool next(int64_t &tile, bool &first)
-    {
-        if (lst < 0) {
-            if (lp < lend && (sw.pl0 + lp) * sw.tpp + col < sw.ntiles) {
+    for (int64_t lst = b; lst < sw.ulist_n; lst += sw.nblk) {
+        const int64_t p = sw.ulist[lst];
+        auto a = load(p);
+        fin(p, a);
+    }
+}
+// ec3d_tile_of<1> walked incrementally: one column, runs of consecutive planes.  A run ends where the segment
+// ends or -- in a windowed slab -- where the owned planes of a block end: the physical plane then jumps over the
+// halo planes and the march starts afresh in the next block.
+template <bool SPEC, class BODY>
+__device__ __forceinline__ void walk_zm(const SweepZ &sw, BODY &&body)
+{
+    const int cpx = (sw.tpp + 7) >> 3, c = blockIdx.x & 7, sg = blockIdx.x >> 3;
+    const int col = c * cpx + sg % cpx;
+    int64_t lp = (int64_t)(sg / cpx) * sw.pps; // logical plane, relative to pl0
+    int64_t lend = lp + sw.pps;
+    if (sw.npl > 0 && lend > sw.npl) lend = sw.npl;
+    {   // logical planes whose tile of this column exists: (pl0 + lp) * tpp + col < ntiles
+        const int64_t nlp = (sw.ntiles - col + sw.tpp - 1) / sw.tpp - sw.pl0;
+        if (lend > nlp) lend = nlp;
+    }
+    if (col >= sw.tpp) lend = lp;
+    const bool win = sw.win_npo > 0;
+    int64_t rem = 0, pl = sw.pl0 + lp;
+    if (win && lp < lend) {
+        rem = pl % sw.win_npo;
+        pl = (pl / sw.win_npo) * sw.win_npb + sw.win_p0 + rem;
+    }
+    if constexpr (SPEC) { // two copies of the body in the front sweep, each without the test
+        while (lp < lend) {
+            int64_t run = lend - lp;
+            if (win && run > sw.win_npo - rem) run = sw.win_npo - rem;
+            int64_t tile = pl * sw.tpp + col;
+            body(tile, TrueC());
+            for (int64_t q = 1; q < run; ++q) {
+                tile += sw.tpp;
+                body(tile, FalseC());
+            }
+            lp += run;
+            pl += run + (sw.win_npb - sw.win_npo); // next block's first owned plane (windowed slab only)
+            rem = 0;
+        }
+        for (int64_t lst = blockIdx.x; lst < sw.ulist_n; lst += gridDim.x) body((int64_t)sw.ulist[lst], TrueC());
+    } else {
+        // a body too large to have three times (structured form: two copies already cost 25-45 spilled
+        // registers): ONE loop over the front sweep and the list, `first` a run-time flag
+        bool fresh = true;
+        int64_t lst = -1;
+        for (;;) {
+            int64_t tile;
+            bool first;
+            if (lst < 0 && lp < lend) {
                 tile = pl * sw.tpp + col;
-                first = fresh || (sw.win_npo > 0 && rem == 0);
+                first = fresh || (win && rem == 0);
                 fresh = false;
                 ++lp;
                 ++pl;
-                if (sw.win_npo > 0 && ++rem == sw.win_npo) {
+                if (win && ++rem == sw.win_npo) {
                     rem = 0;
                     pl += sw.win_npb - sw.win_npo;
                 }
-                return true;
+            } else {
+                if (lst < 0) lst = blockIdx.x;
+                if (lst >= sw.ulist_n) break;
+                tile = sw.ulist[lst];
+                lst += gridDim.x;
+                first = true;
             }
-            if (sw.ulist_n == 0) return false;
-            lst = blockIdx.x;
+            body(tile, first);
         }
-        if (lst >= sw.ulist_n) return false;
-        tile = sw.ulist[lst];
-        lst += gridDim.x;
-        first = true;
-        return true;
     }
-};
-#define EC3D_WALK(SW_T, MODE)                                                                  \
-    int64_t tile;                                                                              \
-    bool first_;                                                                               \
-    for (SW_T walk_(sw); walk_.template next<MODE>(tile, first_);)
+}
+template <bool ZM, bool SPEC, class SW, class BODY>
+__device__ __forceinline__ void walk_spmv(const SW &sw, BODY &&body)
+{
+    if constexpr (ZM) walk_zm<SPEC>(sw, body);
+    else walk_plain<0>(sw, body);
+}
 #define EC3D_ROW const int64_t r = tile * EC3D_TILE + 2 * (int64_t)threadIdx.x
 
 // The vector a row kernel multiplies by, behind a small accessor (pair = two consecutive entries from
@@ -569,7 +662,7 @@ __device__ __forceinline__ void sav_pair_zm(const MatDev<FMT_SAV> &A, const doub
 // rows r, r+1 of A*x (src/solvers.f90:58-59): bands in ascending column order, then the tail.
 // ZM: band 0 / 3 / 6 (offsets -kdz, 0, +kdz) come from / go to the registers `z`.
 // `ctr` returns x[r], x[r+1] (the centre band's operand).
-template <int FMT, bool ZM, bool TAIL, class V>
+template <int FMT, bool ZM, bool TAIL, bool NTB, class V>
 __device__ __forceinline__ void spmv_pair(const MatDev<FMT> &A, const double *tbl, double *stg, const V &x, int64_t r,
                                           int64_t tile, bool first, ZRegs &z, double &s0, double &s1, d2 &ctr)
 {
@@ -584,7 +677,7 @@ __device__ __forceinline__ void spmv_pair(const MatDev<FMT> &A, const double *tb
         // adjacent lanes: take them by lane shuffle instead of two unaligned 16-byte loads; only the
         // first/last lane of a wave reads its outer neighbour from memory.  The SpMV kernels are
         // bound by L1/TA load issue, not by HBM, so 3 full-wave loads per step instead of 5 matter.
-        const bool pm1 = A.pm1 != 0;
+        const bool pm1 = ZM ? true : A.pm1 != 0; // a z-marching grid is the 7-point one (choose_sweep)
         // every load of the step is issued before the first use: class bytes, the two edge-lane
         // neighbours, then the band operands (one round trip per step instead of three)
         unsigned short cc = 0;
@@ -619,7 +712,7 @@ __device__ __forceinline__ void spmv_pair(const MatDev<FMT> &A, const double *tb
         if constexpr (FMT == FMT_DIA7) {
             d2 c[7];
 #pragma unroll
-            for (int b = 0; b < 7; ++b) c[b] = *reinterpret_cast<const d2 *>(A.band[b] + r);
+            for (int b = 0; b < 7; ++b) c[b] = load2<NTB>(A.band[b] + r); // coefficients: touched once per launch
             s0 = c[0].x * xv[0].x;
             s1 = c[0].y * xv[0].y;
 #pragma unroll
@@ -712,14 +805,13 @@ EC3D_SPMV_T __global__ __launch_bounds__(EC3D_THREADS) EC3D_SPMV_OCC void k_spmv
     EC3D_TBL_DECL;
     stage_table<FMT>(A, tbl);
     ZRegs zr;
-    EC3D_WALK(TileWalk<ZM>, (ZM ? 1 : 0))
-    {
+    walk_spmv<ZM, FMT != FMT_SAV>(sw, [&](int64_t tile, auto fc) {
         EC3D_ROW;
         double s0, s1;
         d2 ctr;
-        spmv_pair<FMT, ZM, TAIL>(A, tbl, stg, VecPlain{x}, r, tile, first_, zr, s0, s1, ctr);
+        spmv_pair<FMT, ZM, TAIL, NT>(A, tbl, stg, VecPlain{x}, r, tile, (bool)fc, zr, s0, s1, ctr);
         store2<NT>(y, r, sw.n, s0, s1);
-    }
+    });
 }
 
 // setup: R = B - A X ; R0 = R ; P = R ; partials of B·B and R·R   (src/solvers.f90:14-21)
@@ -732,12 +824,11 @@ EC3D_SPMV_T __global__ __launch_bounds__(EC3D_THREADS) EC3D_SPMV_OCC void k_resi
     stage_table<FMT>(A, tbl);
     ZRegs zr;
     double acc[2] = {0.0, 0.0};
-    EC3D_WALK(TileWalk<ZM>, (ZM ? 1 : 0))
-    {
+    walk_spmv<ZM, FMT != FMT_SAV>(sw, [&](int64_t tile, auto fc) {
         EC3D_ROW;
         double s0, s1;
         d2 ctr;
-        spmv_pair<FMT, ZM, TAIL>(A, tbl, stg, VecPlain{x}, r, tile, first_, zr, s0, s1, ctr);
+        spmv_pair<FMT, ZM, TAIL, NT>(A, tbl, stg, VecPlain{x}, r, tile, (bool)fc, zr, s0, s1, ctr);
         d2 bv = load2<NT>(b + r);
         double e0 = bv.x - s0, e1 = bv.y - s1, b0 = bv.x, b1 = bv.y;
         store2<NT>(rv, r, sw.n, e0, e1);
@@ -749,7 +840,7 @@ EC3D_SPMV_T __global__ __launch_bounds__(EC3D_THREADS) EC3D_SPMV_OCC void k_resi
         acc[0] = acc[0] + b1 * b1;
         acc[1] = acc[1] + e0 * e0;
         acc[1] = acc[1] + e1 * e1;
-    }
+    });
     block_sum<2>(acc, lds);
     if (threadIdx.x == 0) {
         part[P_BB * sw.pstride + sw.part_off + blockIdx.x] = acc[0];
@@ -786,7 +877,10 @@ __device__ __forceinline__ void stop_publish(SolverState *st, int it, int kind)
 }
 __device__ __forceinline__ void stop_read(const SolverState *st, int &it, int &kind)
 {
-    const unsigned long long w = __hip_atomic_load(stop_word(st), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // one indivisible 64-bit load with the ordinary cache policy: agent scope (sc1) sends every wave of the launch
+    // to the same L2 line past its L1 -- measured +35..80 us per kernel at 512^3.  A value from the L1 is at worst
+    // an OLDER pair, which the entry tests treat like "not yet published".
+    const unsigned long long w = __hip_atomic_load(stop_word(st), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     it = (int)(unsigned)(w & 0xFFFFFFFFull);
     kind = (int)(unsigned)(w >> 32);
 }
@@ -827,25 +921,24 @@ EC3D_SPMV_T __global__ __launch_bounds__(EC3D_THREADS) EC3D_SPMV_OCC void k1_spm
     stage_table<FMT>(A, tbl);
     ZRegs zr;
     double acc[1] = {0.0};
-    EC3D_WALK(TileWalk<ZM>, (ZM ? 1 : 0))
-    {
+    walk_spmv<ZM, FMT != FMT_SAV>(sw, [&](int64_t tile, auto fc) {
         EC3D_ROW;
         double s0, s1;
         d2 ctr;
-        spmv_pair<FMT, ZM, TAIL>(A, tbl, stg, VecPlain{p}, r, tile, first_, zr, s0, s1, ctr);
+        spmv_pair<FMT, ZM, TAIL, NT>(A, tbl, stg, VecPlain{p}, r, tile, (bool)fc, zr, s0, s1, ctr);
         d2 q = load2<NT>(r0 + r);
         store2<NT>(ap, r, sw.n, s0, s1);
         EC3D_MASK2(r, sw, s0, s1);
         acc[0] = acc[0] + s0 * q.x;
         acc[0] = acc[0] + s1 * q.y;
-    }
+    });
     block_sum<1>(acc, lds);
     if (threadIdx.x == 0) part[P_D1 * sw.pstride + sw.part_off + blockIdx.x] = acc[0];
 }
 
 // K2: alpha = rr0 / (AP·R0) ; S = R - alpha*AP ; partial S·S   (src/solvers.f90:31-34)
 template <bool NT>
-__global__ __launch_bounds__(EC3D_THREADS) void k2_s_update(Sweep sw, RedSrc src, SolverState *st, int it,
+__global__ __launch_bounds__(EC3D_THREADS) void k2_s_update(SweepV sw, RedSrc src, SolverState *st, int it,
                                                             const double *__restrict__ rv,
                                                             const double *__restrict__ ap, double *__restrict__ sv,
                                                             double *__restrict__ part)
@@ -858,17 +951,19 @@ __global__ __launch_bounds__(EC3D_THREADS) void k2_s_update(Sweep sw, RedSrc src
     const double alpha = st->rr0[it & 1] / d[0];
     if (blockIdx.x == 0 && threadIdx.x == 0) st->alpha = alpha;
     double acc[1] = {0.0};
-    EC3D_WALK(TileWalk<false>, -1)
-    {
+    struct Ops { d2 a, q; };
+    walk_vec(sw, [&](int64_t tile) {
         EC3D_ROW;
-        d2 a = load2<NT>(ap + r);
-        d2 q = load2<NT>(rv + r);
+        return Ops{load2<NT>(ap + r), load2<NT>(rv + r)};
+    }, [&](int64_t tile, const Ops &o) {
+        EC3D_ROW;
+        const d2 a = o.a, q = o.q;
         double s0 = q.x - alpha * a.x, s1 = q.y - alpha * a.y;
         store2<NT>(sv, r, sw.n, s0, s1);
         EC3D_MASK2(r, sw, s0, s1);
         acc[0] = acc[0] + s0 * s0;
         acc[0] = acc[0] + s1 * s1;
-    }
+    });
     block_sum<1>(acc, lds);
     if (threadIdx.x == 0) part[P_SS * sw.pstride + sw.part_off + blockIdx.x] = acc[0];
 }
@@ -886,19 +981,18 @@ EC3D_SPMV_T __global__ __launch_bounds__(EC3D_THREADS) EC3D_SPMV_OCC void k3_spm
     stage_table<FMT>(A, tbl);
     ZRegs zr;
     double acc[2] = {0.0, 0.0};
-    EC3D_WALK(TileWalk<ZM>, (ZM ? 1 : 0))
-    {
+    walk_spmv<ZM, FMT != FMT_SAV>(sw, [&](int64_t tile, auto fc) {
         EC3D_ROW;
         double s0, s1;
         d2 q;
-        spmv_pair<FMT, ZM, TAIL>(A, tbl, stg, VecPlain{sv}, r, tile, first_, zr, s0, s1, q);
+        spmv_pair<FMT, ZM, TAIL, NT>(A, tbl, stg, VecPlain{sv}, r, tile, (bool)fc, zr, s0, s1, q);
         store2<NT>(as, r, sw.n, s0, s1);
         EC3D_MASK2(r, sw, s0, s1);
         acc[0] = acc[0] + s0 * q.x;
         acc[0] = acc[0] + s1 * q.y;
         acc[1] = acc[1] + s0 * s0;
         acc[1] = acc[1] + s1 * s1;
-    }
+    });
     block_sum<2>(acc, lds);
     if (threadIdx.x == 0) {
         part[P_D2 * sw.pstride + sw.part_off + blockIdx.x] = acc[0];
@@ -910,7 +1004,7 @@ EC3D_SPMV_T __global__ __launch_bounds__(EC3D_THREADS) EC3D_SPMV_OCC void k3_spm
 //     omega = (AS·S)/(AS·AS) ; X = X + alpha*P + omega*S ; R = S - omega*AS ;
 //     partials R·R and R·R0   (:40-44)
 template <bool NT>
-__global__ __launch_bounds__(EC3D_THREADS) void k4_x_r_update(Sweep sw, RedSrc src_ss, RedSrc src, SolverState *st,
+__global__ __launch_bounds__(EC3D_THREADS) void k4_x_r_update(SweepV sw, RedSrc src_ss, RedSrc src, SolverState *st,
                                                               int it, const double *__restrict__ p,
                                                               const double *__restrict__ sv,
                                                               const double *__restrict__ as,
@@ -928,13 +1022,14 @@ __global__ __launch_bounds__(EC3D_THREADS) void k4_x_r_update(Sweep sw, RedSrc s
     const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
     if (lead && hist && it <= hist_cap) hist[2 * (int64_t)(it - 1)] = snorm;
     if (snorm / st->bnorm < st->tol) {
-        EC3D_WALK(TileWalk<false>, -1)
-        {
+        struct OpsX { d2 xv, pv; };
+        walk_vec(sw, [&](int64_t tile) {
             EC3D_ROW;
-            d2 xv = *reinterpret_cast<const d2 *>(x + r);
-            d2 pv = *reinterpret_cast<const d2 *>(p + r);
-            store2<false>(x, r, sw.n, xv.x + alpha * pv.x, xv.y + alpha * pv.y);
-        }
+            return OpsX{*reinterpret_cast<const d2 *>(x + r), *reinterpret_cast<const d2 *>(p + r)};
+        }, [&](int64_t tile, const OpsX &o) {
+            EC3D_ROW;
+            store2<false>(x, r, sw.n, o.xv.x + alpha * o.pv.x, o.xv.y + alpha * o.pv.y);
+        });
         // every workgroup has read the exit word above; K5 of this iteration tests it again.  Published by the
         // lead thread only; other workgroups of THIS launch may already have passed their entry test, which
         // only compares against earlier iterations.
@@ -947,14 +1042,13 @@ __global__ __launch_bounds__(EC3D_THREADS) void k4_x_r_update(Sweep sw, RedSrc s
     const double omega = d[0] / d[1];
     if (lead) st->omega = omega;
     double acc[2] = {0.0, 0.0};
-    EC3D_WALK(TileWalk<false>, -1)
-    {
+    struct Ops { d2 xv, pv, s, a, q; };
+    walk_vec(sw, [&](int64_t tile) {
         EC3D_ROW;
-        d2 xv = load2<NT>(x + r);
-        d2 pv = load2<NT>(p + r);
-        d2 s = load2<NT>(sv + r);
-        d2 a = load2<NT>(as + r);
-        d2 q = load2<NT>(r0 + r);
+        return Ops{load2<NT>(x + r), load2<NT>(p + r), load2<NT>(sv + r), load2<NT>(as + r), load2<NT>(r0 + r)};
+    }, [&](int64_t tile, const Ops &o) {
+        EC3D_ROW;
+        const d2 xv = o.xv, pv = o.pv, s = o.s, a = o.a, q = o.q;
         store2<NT>(x, r, sw.n, (xv.x + alpha * pv.x) + omega * s.x, (xv.y + alpha * pv.y) + omega * s.y);
         double e0 = s.x - omega * a.x, e1 = s.y - omega * a.y;
         store2<NT>(rv, r, sw.n, e0, e1);
@@ -963,7 +1057,7 @@ __global__ __launch_bounds__(EC3D_THREADS) void k4_x_r_update(Sweep sw, RedSrc s
         acc[0] = acc[0] + e1 * e1;
         acc[1] = acc[1] + e0 * q.x;
         acc[1] = acc[1] + e1 * q.y;
-    }
+    });
     block_sum<2>(acc, lds);
     if (threadIdx.x == 0) {
         part[P_RR * sw.pstride + sw.part_off + blockIdx.x] = acc[0];
@@ -974,7 +1068,7 @@ __global__ __launch_bounds__(EC3D_THREADS) void k4_x_r_update(Sweep sw, RedSrc s
 // K5: if ‖R‖/Bnorm < tol exit (src/solvers.f90:43) ; beta = (alpha/omega)*rr0_new/rr0 (:45) ;
 //     P = R + beta*(P - omega*AP) (:46) ; restart R0 = R, P = R when |rr0_new|/Bnorm < tol (:47-49)
 template <bool NT>
-__global__ __launch_bounds__(EC3D_THREADS) void k5_p_update(Sweep sw, RedSrc src, SolverState *st, int it,
+__global__ __launch_bounds__(EC3D_THREADS) void k5_p_update(SweepV sw, RedSrc src, SolverState *st, int it,
                                                             const double *__restrict__ rv,
                                                             const double *__restrict__ ap, double *__restrict__ p,
                                                             double *__restrict__ r0, double *hist, int64_t hist_cap)
@@ -1006,18 +1100,25 @@ __global__ __launch_bounds__(EC3D_THREADS) void k5_p_update(Sweep sw, RedSrc src
     const bool restart = fabs(rr0_new) / bnorm < tol;
     // next iteration's R·R0: after a restart R0 == R, so it is R·R in the same summation order
     if (lead) st->rr0[(it + 1) & 1] = restart ? d[0] : rr0_new;
-    EC3D_WALK(TileWalk<false>, -1)
-    {
-        EC3D_ROW;
-        d2 q = load2<NT>(rv + r);
-        if (restart) {
+    if (restart) {
+        walk_vec(sw, [&](int64_t tile) {
+            EC3D_ROW;
+            return load2<NT>(rv + r);
+        }, [&](int64_t tile, const d2 &q) {
+            EC3D_ROW;
             store2<NT>(r0, r, sw.n, q.x, q.y);
             store2<NT>(p, r, sw.n, q.x, q.y);
-        } else {
-            d2 pv = load2<NT>(p + r);
-            d2 a = load2<NT>(ap + r);
+        });
+    } else {
+        struct Ops { d2 q, pv, a; };
+        walk_vec(sw, [&](int64_t tile) {
+            EC3D_ROW;
+            return Ops{load2<NT>(rv + r), load2<NT>(p + r), load2<NT>(ap + r)};
+        }, [&](int64_t tile, const Ops &o) {
+            EC3D_ROW;
+            const d2 q = o.q, pv = o.pv, a = o.a;
             store2<NT>(p, r, sw.n, q.x + beta * (pv.x - omega * a.x), q.y + beta * (pv.y - omega * a.y));
-        }
+        });
     }
 }
 
@@ -1144,12 +1245,35 @@ static inline size_t tbl_bytes(const MatView &A, int F, bool zm)
         default: EC3D_LAUNCH_FMT(FMT_GENERIC, KERNEL, __VA_ARGS__);                            \
         }                                                                                      \
     } while (0)
+static inline SweepV sweep_v(const Sweep &sw)
+{
+    SweepV v;
+    v.ntiles = sw.ntiles;
+    v.n = sw.n;
+    v.S = sw.S;
+    v.nblk = sw.nblk;
+    v.pstride = sw.pstride;
+    v.part_off = sw.part_off;
+    v.ulist_n = sw.ulist_n;
+    v.two = sw.vec_depth;
+    v.ulist = sw.ulist;
+    v.win_nt = sw.win_nt;
+    v.win_blk = sw.win_blk;
+    v.win_t0 = sw.win_t0;
+    v.nown = sw.nown;
+    for (int q = 0; q < 4; ++q) {
+        v.own_lo[q] = sw.own_lo[q];
+        v.own_hi[q] = sw.own_hi[q];
+    }
+    return v;
+}
 #define EC3D_LAUNCH_VEC(KERNEL, ...)                                                           \
     do {                                                                                       \
+        const SweepV swv = sweep_v(sw);                                                        \
         if (nt_of(sw))                                                                         \
-            KERNEL<true><<<sw.nblk, EC3D_THREADS, 0, s>>>(__VA_ARGS__);                        \
+            KERNEL<true><<<sw.nblk, EC3D_THREADS, 0, s>>>(swv, __VA_ARGS__);                   \
         else                                                                                   \
-            KERNEL<false><<<sw.nblk, EC3D_THREADS, 0, s>>>(__VA_ARGS__);                       \
+            KERNEL<false><<<sw.nblk, EC3D_THREADS, 0, s>>>(swv, __VA_ARGS__);                  \
     } while (0)
 
 void ec3d_launch_spmv(const MatView &A, const Sweep &sw, const double *x, double *y, hipStream_t s)
@@ -1182,7 +1306,7 @@ void ec3d_launch_k1(const MatView &A, const Sweep &sw, const SolverState *st, in
 void ec3d_launch_k2(const Sweep &sw, const RedSrc &src, SolverState *st, int it, const double *r, const double *ap,
                     double *sv, double *part, hipStream_t s)
 {
-    EC3D_LAUNCH_VEC(k2_s_update, sw, src, st, it, r, ap, sv, part);
+    EC3D_LAUNCH_VEC(k2_s_update, src, st, it, r, ap, sv, part);
 }
 
 void ec3d_launch_k3(const MatView &A, const Sweep &sw, SolverState *st, int it, const double *sv, double *as,
@@ -1195,11 +1319,11 @@ void ec3d_launch_k4(const Sweep &sw, const RedSrc &src_ss, const RedSrc &src, So
                     const double *p, const double *sv, const double *as, const double *r0, double *x, double *r,
                     double *part, double *hist, int64_t hist_cap, hipStream_t s)
 {
-    EC3D_LAUNCH_VEC(k4_x_r_update, sw, src_ss, src, st, it, p, sv, as, r0, x, r, part, hist, hist_cap);
+    EC3D_LAUNCH_VEC(k4_x_r_update, src_ss, src, st, it, p, sv, as, r0, x, r, part, hist, hist_cap);
 }
 
 void ec3d_launch_k5(const Sweep &sw, const RedSrc &src, SolverState *st, int it, const double *r, const double *ap,
                     double *p, double *r0, double *hist, int64_t hist_cap, hipStream_t s)
 {
-    EC3D_LAUNCH_VEC(k5_p_update, sw, src, st, it, r, ap, p, r0, hist, hist_cap);
+    EC3D_LAUNCH_VEC(k5_p_update, src, st, it, r, ap, p, r0, hist, hist_cap);
 }

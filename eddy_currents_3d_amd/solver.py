@@ -19,7 +19,7 @@ import os
 import numpy as np
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIBPATH = os.path.join(PKG, "libec3d_hip.so")
+LIBPATH = os.environ.get("EC3D_LIB") or os.path.join(PKG, "libec3d_hip.so")   # EC3D_LIB: another build (A/B timing)
 
 
 class EC3DError(RuntimeError):

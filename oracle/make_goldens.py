@@ -544,6 +544,31 @@ def case_g6t(which=("ec_src_move_hole",), tol="0.5m"):
         save("g6t_" + stem + "_%dx%dx%d" % dims[stem], **d)
 
 
+def case_g6tf(which=("ec_src_move_hole",), tol="0.5m"):
+    """G6TF: the yardstick for case_g6t -- the reference against ITSELF at the same overridden tolerance: the same
+    program with only src/solvers.f90 built -O3 -ffast-math (oracle/_ref/EC3D_capture_fast), first time step.
+    Added to the g6t fixture: iter_fast, self_distance = ||x_fast - x_ref|| / ||x_ref|| by the sketches."""
+    from eddy_currents_3d_amd import vxc
+    dims = {"ec_src_move_hole": (256, 256, 60), "LIM": (384, 192, 128)}
+    for stem in which:
+        g = np.load(os.path.join(GOLD, f"g4_{stem}.npz"))
+        names = [re.sub(r"\btol=\S+", "tol=" + tol, str(s)) if re.search(r"\bsolver\b", str(s), re.I) else str(s)
+                 for s in g["names"]]
+        model = vxc.VxcModel(g["vox"], names, float(str(g["lattice_dim"])), tuple(float(x) for x in g["adj"]))
+        big = vxc.resample(model, *dims[stem])
+        fast, _ = run_reference(big.vox, big.names, repr(big.lattice_dim), tuple(repr(a) for a in big.adj),
+                                max_calls=1, extra_env={"EC3D_CAPTURE_NO_MATRIX": "1"},
+                                exe=os.path.join(HERE, "_ref", "EC3D_capture_fast"))
+        name = "g6t_" + stem + "_%dx%dx%d" % dims[stem]
+        gt = dict(np.load(os.path.join(GOLD, name + ".npz")))
+        sk = O.count_sketch(fast[0]["x_out"])
+        gt["iter_fast"] = np.int32(fast[0]["iter"])
+        gt["self_distance"] = np.float64(np.linalg.norm(sk - gt["xsketch"]) / np.linalg.norm(gt["xsketch"]))
+        print(stem, f"tol {tol}: -O3 -ffast-math build of the same solver: iter {fast[0]['iter']} (exact build "
+              f"{int(gt['iter'])}), ||x_fast - x_ref|| / ||x_ref|| = {float(gt['self_distance']):.3e}", flush=True)
+        save(name, **gt)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g2", "g2v", "g2i", "g3", "g4", "g5"]
     O.build()
@@ -564,3 +589,5 @@ if __name__ == "__main__":
     if "g6lim" in which: case_g6(("LIM",))
     if "g6thole" in which: case_g6t(("ec_src_move_hole",))
     if "g6tlim" in which: case_g6t(("LIM",))
+    if "g6tfhole" in which: case_g6tf(("ec_src_move_hole",))
+    if "g6tflim" in which: case_g6tf(("LIM",))

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Same-box A/B timing: per-kernel averages INSIDE the iteration (hipEvents on the library's stream, as bench.py
+measures them) and the bare SpMV, for one workload.  Boxes differ by up to 10 %, so variants are only ever compared
+within one gpurun call; EC3D_LIB selects another build of the library, the other knobs are environment variables
+read by the library.   usage: ab_perf.py cube512|cube256|dia512|av3 [label]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import eddy_currents_3d_amd as E
+
+wl = sys.argv[1] if len(sys.argv) > 1 else "cube512"
+label = sys.argv[2] if len(sys.argv) > 2 else ""
+import bench
+with E.EC3DSolver(dictionary=not wl.startswith("dia")) as s:
+    if wl == "av3":
+        geo, geoC, valPHYS, BND, delta, dt, b = bench.av_system(3)
+        s.assemble(geo, geoC, valPHYS, BND, delta, dt)
+        n = len(b)
+    else:
+        N = int(wl[-3:])
+        s.assemble_poisson(N, N, N)
+        n = N ** 3
+        b = bench.bar_rhs(N)
+    s.upload("B", b)
+    s.upload("X", np.zeros(n))
+    s.iterate_begin()
+    s.iterate(1, 5)
+    s.synchronize()
+    K = 40
+    ms = s.iterate(6, K, per_kernel=True)
+    ms2 = s.iterate(6 + K, K, per_kernel=True)
+    sp = s.time_kernel("spmv", 30)
+    tot = sum(ms2.values())
+    print(f"{wl:8s} {label:28s} " + " ".join(f"{k}={1e3 * min(ms[k], ms2[k]):7.1f}" for k in ("k1", "k2", "k3", "k4", "k5")) +
+          f" sum={1e3 * tot:7.1f} spmv={1e3 * sp:7.1f} us  wg={s.geometry(0).nblk}/{s.geometry(1).nblk}", flush=True)
