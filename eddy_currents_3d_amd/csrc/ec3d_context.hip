@@ -11,6 +11,7 @@
 #include <mutex>
 
 static thread_local std::string g_err;
+thread_local double *ec3d_itmax_print_hold = nullptr;
 void ec3d_set_error(const std::string &msg) { g_err = msg; }
 extern "C" const char *ec3d_last_error(void) { return g_err.c_str(); }
 

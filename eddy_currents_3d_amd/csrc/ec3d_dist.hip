@@ -188,6 +188,16 @@ extern "C" int ec3d_dist_step(ec3d_handle c, int32_t stage, int32_t it, double t
     return 0;
 }
 
+// kernel launches ec3d_dist_step issues for a stage (the stage's kernel and, where it produces sums, k_finalize)
+int ec3d_dist_launches(int stage)
+{
+    switch (stage) {
+    case EC3D_STAGE_SETUP: case EC3D_STAGE_K5: case EC3D_STAGE_K1_INT: case EC3D_STAGE_K3_INT: case EC3D_STAGE_K2_BND:
+    case EC3D_STAGE_K5_BND: case EC3D_STAGE_K5_INT: return 1;
+    default: return 2;
+    }
+}
+
 extern "C" int ec3d_can_overlap(ec3d_handle c) { return c && c->have_matrix && c->can_overlap ? 1 : 0; }
 
 extern "C" int ec3d_read_state_async(ec3d_handle c, int32_t *stop_iter_pinned)

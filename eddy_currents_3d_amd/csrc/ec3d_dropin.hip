@@ -111,7 +111,14 @@ extern "C" void sprsbcgstabwr_(double *valA, int32_t *irow, int32_t *jcol, int32
         std::vector<int32_t> devs;
         if (const char *e = getenv("EC3D_DEVICES"))
             for (const char *p = e; *p;) {
-                devs.push_back((int32_t)strtol(p, const_cast<char **>(&p), 10));
+                char *end = nullptr;
+                const long d = strtol(p, &end, 10);
+                if (end == p) { // not a number: strtol does not advance, the loop would never end
+                    ec3d_set_error(std::string("EC3D_DEVICES=\"") + e + "\": expected device ordinals separated by commas");
+                    die("EC3D_DEVICES");
+                }
+                devs.push_back((int32_t)d);
+                p = end;
                 while (*p == ',' || *p == ' ') ++p;
             }
         if (!devs.empty() && (int)devs.size() != g_drop.ngpu) {
@@ -142,18 +149,38 @@ extern "C" void sprsbcgstabwr_(double *valA, int32_t *irow, int32_t *jcol, int32
     };
     // The solve on whatever device matrix is in place: b and x go up, the iteration runs, x comes back ONLY if
     // `accept` says so (the full signature, computed meanwhile, matched).  Returns false when x was withheld.
+    // the reference prints norm2(R) on the itmax exit (src/solvers.f90:25-28); a solve whose result is withheld
+    // below must not have printed it, so the line is held back until the result is accepted
+    double held_rnorm = 0.0;
+    bool held = false;
+    uint64_t fresh_sig = 0; // signature of the caller's arrays as they are NOW, once a check has computed it
+    bool have_fresh = false;
     auto solve_cached = [&](std::future<uint64_t> *check) -> bool {
+        ec3d_itmax_print_hold = &held_rnorm;
+        held_rnorm = -1.0;
+        struct Release {
+            ~Release() { ec3d_itmax_print_hold = nullptr; }
+        } release;
+        auto accept = [&]() {
+            held = held_rnorm >= 0.0;
+            if (held) {
+                printf(" %.17g\n", held_rnorm);
+                fflush(stdout);
+            }
+        };
         if (g_drop.ngpu > 1) {
             if (ec3d_multi_upload(g_drop.multi, EC3D_VEC_B, b) || ec3d_multi_upload(g_drop.multi, EC3D_VEC_X, x) ||
                 ec3d_multi_solve_resident(g_drop.multi, *tolerance, *itmax, iter))
                 die("ec3d_multi_solve");
-            if (check && check->get() != g_drop.sig) return false;
+            if (check && (fresh_sig = check->get()) != g_drop.sig) return false;
+            accept();
             if (ec3d_multi_download(g_drop.multi, EC3D_VEC_X, x)) die("ec3d_multi_download");
         } else {
             if (ec3d_upload(g_drop.ctx, EC3D_VEC_B, b) || ec3d_upload(g_drop.ctx, EC3D_VEC_X, x) ||
                 ec3d_solve_resident(g_drop.ctx, *tolerance, *itmax, iter, nullptr, 0))
                 die("ec3d_solve");
-            if (check && check->get() != g_drop.sig) return false;
+            if (check && (fresh_sig = check->get()) != g_drop.sig) return false;
+            accept();
             if (ec3d_download(g_drop.ctx, EC3D_VEC_X, x)) die("ec3d_download");
         }
         return true;
@@ -163,17 +190,21 @@ extern "C" void sprsbcgstabwr_(double *valA, int32_t *irow, int32_t *jcol, int32
         // start on the cached matrix; every entry of the caller's arrays is checked while the GPU works
         std::future<uint64_t> check = std::async(std::launch::async, matrix_signature, valA, irow, jcol, nn, nnz);
         if (solve_cached(&check)) return;
-        // the matrix was changed in place (same addresses, same samples): x is still the caller's, start over
+        // the matrix was changed in place (same addresses, same samples): x is still the caller's, start over --
+        // with the signature the check has just computed over every entry, not a second pass over 12 B per nonzero
+        have_fresh = true;
         g_drop.multi_has_matrix = false;
         if (g_drop.ctx) ec3d_free_matrix(g_drop.ctx);
     }
-    const uint64_t sig = matrix_signature(valA, irow, jcol, nn, nnz);
+    const uint64_t sig = have_fresh ? fresh_sig : matrix_signature(valA, irow, jcol, nn, nnz);
     if (g_drop.ngpu > 1) {
         g_drop.multi_has_matrix = false;
         const int rc = ec3d_multi_set_matrix_csr(g_drop.multi, *n, valA, irow, jcol);
         if (rc == 7) { // no grid to cut: this matrix runs on one GPU
             fprintf(stderr, "libec3d_hip: EC3D_NGPU=%d ignored: %s\n", g_drop.ngpu, ec3d_last_error());
             g_drop.ngpu = 1;
+            (void)ec3d_multi_destroy(g_drop.multi); // N contexts, streams and worker threads nobody will use
+            g_drop.multi = nullptr;
         } else if (rc) {
             die("ec3d_multi_set_matrix_csr");
         } else {

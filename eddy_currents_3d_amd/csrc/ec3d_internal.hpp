@@ -277,6 +277,9 @@ struct ec3d_ctx {
 enum { P_BB = 0, P_RR_INIT = 1, P_D1 = 2, P_SS = 3, P_D2 = 4, P_D3 = 5, P_RR = 6, P_RR0N = 7, P_NSLOT = 8 };
 
 void ec3d_set_error(const std::string &msg);
+// itmax exit: the reference prints norm2(R) (src/solvers.f90:25-28).  When this points somewhere, the solve entry
+// points store the value there instead of printing it (the drop-in prints it once its result is accepted).
+extern thread_local double *ec3d_itmax_print_hold;
 #define EC3D_HIP(call)                                                                         \
     do {                                                                                       \
         hipError_t e_ = (call);                                                                \
@@ -333,6 +336,7 @@ void ec3d_launch_stage(ec3d_ctx *c, const MatView &A, int it, int k); // k = 1..
 void ec3d_launch_iteration(ec3d_ctx *c, const MatView &A, int it);
 int ec3d_launch_begin(ec3d_ctx *c, const MatView &A, double tol);
 int ec3d_single_rank_only(ec3d_ctx *c, const char *who);
+int ec3d_dist_launches(int stage); // ec3d_dist.hip
 
 // ec3d_kernels.hip — launchers (all asynchronous on `s`)
 void ec3d_launch_spmv(const MatView &A, const Sweep &sw, const double *x, double *y, hipStream_t s);

@@ -79,6 +79,7 @@ struct Slab {
     int32_t k0 = 0, k1 = 0, e0 = 0, e1 = 0; // owned planes [k0,k1), held planes [e0,e1)
     double *lsum = nullptr;
     bool lsum_fine = false;
+    uint64_t api_calls = 0, api_iters = 0; // runtime calls / iterations of the last ec3d_multi_iterate (this rank)
     const double **ptr_table = nullptr; // device: every rank's lsum
     hipStream_t side = nullptr;
     hipEvent_t ev_ready[3][RING] = {}, ev_halo[3][RING] = {}, ev_sum[RING] = {}, ev_hub[RING] = {};
@@ -132,8 +133,11 @@ namespace {
 // doing that to each other at the same moment (every gather does) must not be able to wait for each other's
 // queue locks: one cross-queue wait at a time, process wide.  Launches and copies stay concurrent.
 std::mutex g_cross_wait;
+// HIP runtime calls issued by the slab threads (launches are counted in run_plan): what the host pays per iteration
+thread_local uint64_t t_api_calls = 0;
 #define MHIP(call)                                                                             \
     do {                                                                                       \
+        ++t_api_calls;                                                                         \
         hipError_t e_ = (call);                                                                \
         if (e_ != hipSuccess) {                                                                \
             ec3d_set_error(std::string(#call) + ": " + hipGetErrorString(e_));                 \
@@ -169,7 +173,9 @@ void worker(ec3d_multi *m, int r)
 }
 
 // run fn(rank) on every slab's thread; first failure wins (its message becomes ec3d_last_error())
-int run_all(ec3d_multi *m, const std::function<int(int)> &fn)
+// `watch`: the job makes the slabs wait for each other (halo pulls, reduction points), so a stall is possible and the
+// watchdog is armed; jobs that only work on their own slab (assembly, uploads, creation) may take as long as they need.
+int run_all(ec3d_multi *m, const std::function<int(int)> &fn, bool watch = false)
 {
     Pool &p = m->pool;
     {
@@ -183,7 +189,8 @@ int run_all(ec3d_multi *m, const std::function<int(int)> &fn)
         // deadlock between the slabs' streams or threads.  Say where every rank stands, let the ranks that
         // still can give up, and end the process if a thread stays stuck inside the runtime: there is no way
         // to cancel it, and the interfaces this library stands behind have no channel for "hung".
-        static const int limit = getenv("EC3D_MULTI_WATCHDOG") ? atoi(getenv("EC3D_MULTI_WATCHDOG")) : 120;
+        static const int limit_env = getenv("EC3D_MULTI_WATCHDOG") ? atoi(getenv("EC3D_MULTI_WATCHDOG")) : 120;
+        const int limit = watch ? limit_env : 0;
         auto report = [&]() {
             std::string r;
             for (auto &s : m->slab)
@@ -209,9 +216,12 @@ int run_all(ec3d_multi *m, const std::function<int(int)> &fn)
                 fflush(stderr);
                 m->abort.store(true);
                 if (p.done_cv.wait_for(lk, std::chrono::seconds(10), [&] { return p.pending == 0; })) break;
-                fprintf(stderr, "libec3d_hip: a rank is stuck inside the HIP runtime; aborting the process\n");
+                // no signal, no core dump of a 100 GB process, an exit status the caller's shell can read; never a
+                // re-exec (the process has touched the GPU)
+                fprintf(stderr, "libec3d_hip: a rank is stuck inside the HIP runtime; ending the process (exit status 86)\n");
                 fflush(stderr);
-                abort();
+                fflush(stdout);
+                _Exit(86);
             }
         }
     }
@@ -402,6 +412,7 @@ int run_plan(ec3d_multi *m, Slab &s, const std::vector<Op> &plan, int it, double
             } else {
                 rc = ec3d_dist_step(s.c, st, it, tol);
             }
+            t_api_calls += (uint64_t)ec3d_dist_launches(st); // the kernel launches of the stage
             if (rc) return rc;
         }
         }
@@ -429,6 +440,31 @@ void slab_bounds(int sdz, int rank, int world, int32_t &k0, int32_t &k1)
     k1 = k0 + base + (rank < rem ? 1 : 0);
 }
 
+// Peer access from this slab's device to every other device that holds a slab.  Runs on every slab's thread BEFORE
+// anything is allocated (ec3d_multi_create), so that every allocation a peer will touch -- the work vectors the
+// halo planes are pulled from, lsum, which the peers' kernels dereference -- is made with the mappings in place.
+int enable_peers(ec3d_multi *m, Slab &s)
+{
+    MHIP(hipSetDevice(s.device));
+    for (auto &o : m->slab) {
+        if (o->device == s.device) continue;
+        int can = 0;
+        MHIP(hipDeviceCanAccessPeer(&can, s.device, o->device));
+        if (!can) {
+            ec3d_set_error("ec3d_multi: device " + std::to_string(s.device) + " cannot access device " +
+                           std::to_string(o->device) + " (no peer path)");
+            return 104;
+        }
+        hipError_t e = hipDeviceEnablePeerAccess(o->device, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
+            ec3d_set_error(std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
+            return 100;
+        }
+        (void)hipGetLastError();
+    }
+    return 0;
+}
+
 // (re)create the per-slab context and the multi-rank plumbing around it
 int slab_reset(ec3d_multi *m, Slab &s)
 {
@@ -446,33 +482,27 @@ int slab_reset(ec3d_multi *m, Slab &s)
         for (int i = 0; i < RING; ++i) MHIP(hipEventCreateWithFlags(&s.ev_hub[i], hipEventDisableTiming));
         for (int i = 0; i < 2; ++i) MHIP(hipEventCreateWithFlags(&s.ev_stop[i], hipEventDisableTiming));
         MHIP(hipHostMalloc(&s.stop_pinned, 2 * sizeof(int32_t), hipHostMallocDefault));
-        // the 8 sums every other GPU reads in place: fine-grained (coherent across devices) when the
-        // runtime offers it
+        // The 8 sums every other GPU's kernels read in place, launch after launch: fine-grained (coherent across
+        // devices) memory.  Peer access between all the devices involved was enabled BEFORE this allocation
+        // (enable_peers, ec3d_multi_create).  Plain hipMalloc memory is only good enough when every slab sits
+        // on this same device (rehearsals on a one-GPU box); across devices there is no silent fallback.
+        bool several_devices = false;
+        for (auto &o : m->slab) several_devices |= o->device != s.device;
         if (hipExtMallocWithFlags((void **)&s.lsum, P_NSLOT * sizeof(double), hipDeviceMallocFinegrained) == hipSuccess) {
             s.lsum_fine = true;
         } else {
             (void)hipGetLastError();
+            if (several_devices) {
+                ec3d_set_error("ec3d_multi: device " + std::to_string(s.device) + " cannot allocate fine-grained memory "
+                               "(hipExtMallocWithFlags, hipDeviceMallocFinegrained) for the partial sums the other GPUs "
+                               "read in place; coarse-grained memory is not coherent across devices -- refusing to run "
+                               "on several devices without it");
+                return 107;
+            }
             MHIP(hipMalloc(&s.lsum, P_NSLOT * sizeof(double)));
         }
         MHIP(hipMemset(s.lsum, 0, P_NSLOT * sizeof(double)));
         MHIP(hipMalloc(&s.ptr_table, (size_t)m->n * sizeof(double *)));
-        // peer access to every other device that holds a slab
-        for (auto &o : m->slab) {
-            if (o->device == s.device) continue;
-            int can = 0;
-            MHIP(hipDeviceCanAccessPeer(&can, s.device, o->device));
-            if (!can) {
-                ec3d_set_error("ec3d_multi: device " + std::to_string(s.device) + " cannot access device " +
-                               std::to_string(o->device) + " (no peer path)");
-                return 104;
-            }
-            hipError_t e = hipDeviceEnablePeerAccess(o->device, 0);
-            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
-                ec3d_set_error(std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
-                return 100;
-            }
-            (void)hipGetLastError();
-        }
     }
     s.send_lo.clear(); s.recv_lo.clear(); s.send_hi.clear(); s.recv_hi.clear();
     s.pull_lo.clear(); s.pull_hi.clear();
@@ -605,6 +635,32 @@ void av_layout(ec3d_multi *m, Slab &s, const std::vector<int64_t> &upl)
     }
 }
 
+__global__ void k_fill(double *p, int64_t n, double v)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// NaN into every row of work vector `vi` that the halo exchange is about to fill (the recv runs), on the slab's
+// compute stream: a pull that comes late, copies the wrong rows or never happens then shows in the result instead
+// of leaving behind whatever was uploaded there.  Only rows the exchange WRITES are touched: halo rows no owned row
+// reads (the outer halo plane of the A blocks) keep their finite values, since a band coefficient of zero still
+// multiplies its operand.
+int poison_recv_rows(Slab &s, int vi)
+{
+    double *v = s.c->vec[vi];
+    const double nan = std::nan("");
+    for (const std::vector<Run> *rs : {&s.recv_lo, &s.recv_hi})
+        for (const Run &r : *rs)
+            for (int p = 0; p < r.planes; ++p) {
+                if (r.payload <= 0) continue;
+                k_fill<<<(unsigned)((r.payload + 255) / 256), 256, 0, s.c->stream>>>(v + r.start + (int64_t)p * r.pitch,
+                                                                                        r.payload, nan);
+                MHIP(hipGetLastError());
+            }
+    return 0;
+}
+
 int need(ec3d_multi *m, const char *who)
 {
     if (!m || m->kind == 0) {
@@ -726,7 +782,8 @@ extern "C" int ec3d_multi_create(ec3d_multi_handle *mh, int32_t nranks, const in
     }
     m->pool.rc.assign((size_t)nranks, 0);
     for (int r = 0; r < nranks; ++r) m->pool.th.emplace_back(worker, m, r);
-    int rc = run_all(m, [&](int r) { return slab_reset(m, *m->slab[(size_t)r]); });
+    int rc = run_all(m, [&](int r) { return enable_peers(m, *m->slab[(size_t)r]); }); // all of them, then allocate
+    if (!rc) rc = run_all(m, [&](int r) { return slab_reset(m, *m->slab[(size_t)r]); });
     if (rc) {
         std::string keep = ec3d_last_error();
         ec3d_multi_destroy(m);
@@ -1016,7 +1073,7 @@ extern "C" int ec3d_multi_solve_resident(ec3d_multi_handle m, double tolerance, 
     std::vector<int> hit((size_t)m->n, 0);
     rc = run_all(m, [&](int r) {
         return slab_solve(m, *m->slab[(size_t)r], tolerance, itmax, &its[(size_t)r], &hit[(size_t)r]);
-    });
+    }, true);
     if (rc) return rc;
     for (int r = 1; r < m->n; ++r)
         if (its[(size_t)r] != its[0]) {
@@ -1035,8 +1092,12 @@ extern "C" int ec3d_multi_solve_resident(ec3d_multi_handle m, double tolerance, 
             EC3D_HIP(hipMemcpy(&v, sl->lsum + P_RR, sizeof v, hipMemcpyDeviceToHost));
             s += v;
         }
-        printf(" %.17g\n", std::sqrt(s));
-        fflush(stdout);
+        if (ec3d_itmax_print_hold) {
+            *ec3d_itmax_print_hold = std::sqrt(s);
+        } else {
+            printf(" %.17g\n", std::sqrt(s));
+            fflush(stdout);
+        }
     }
     return 0;
 }
@@ -1088,7 +1149,7 @@ extern "C" int ec3d_multi_rhs_step(ec3d_multi_handle m, int32_t moving, int32_t 
                                  val.empty() ? &dummy_v : val.data())))
             return rc2;
         return drain(s);
-    });
+    }, true);
 }
 
 extern "C" int ec3d_multi_post_update(ec3d_multi_handle m)
@@ -1122,7 +1183,7 @@ extern "C" int ec3d_multi_vtk_fields(ec3d_multi_handle m, const double *delta, f
                                    field_B + off)))
             return rc2;
         return drain(s);
-    });
+    }, true);
 }
 
 // ---- bench "steps": exits disabled, launches only ---------------------------------------------------------
@@ -1134,7 +1195,7 @@ extern "C" int ec3d_multi_iterate_begin(ec3d_multi_handle m)
         Slab &s = *m->slab[(size_t)r];
         int rc2 = run_plan(m, s, begin_plan(s), 0, -1.0, nullptr);
         return rc2 ? rc2 : drain(s);
-    });
+    }, true);
 }
 
 extern "C" int ec3d_multi_iterate(ec3d_multi_handle m, int32_t first_iter, int32_t count, double *kernel_ms)
@@ -1146,8 +1207,11 @@ extern "C" int ec3d_multi_iterate(ec3d_multi_handle m, int32_t first_iter, int32
         StageTimer tm;
         StageTimer *tp = (kernel_ms && r == 0) ? &tm : nullptr;
         int rc2 = 0;
+        const uint64_t calls0 = t_api_calls;
         for (int it = first_iter; it < first_iter + count; ++it)
             if ((rc2 = run_plan(m, s, iter_plan(s), it, 0.0, tp))) return rc2;
+        s.api_calls = t_api_calls - calls0;
+        s.api_iters = (uint64_t)std::max(0, count);
         if (!kernel_ms) return 0; // asynchronous: ec3d_multi_synchronize() joins
         if ((rc2 = drain(s))) return rc2;
         if (tp) {
@@ -1160,7 +1224,17 @@ extern "C" int ec3d_multi_iterate(ec3d_multi_handle m, int32_t first_iter, int32
             for (hipEvent_t e : tm.ev) (void)hipEventDestroy(e);
         }
         return 0;
-    });
+    }, true);
+}
+
+// HIP runtime calls (launches, event records / waits, copies) rank `rank`'s thread issued per iteration in the last
+// ec3d_multi_iterate: the host-side price of an iteration, which has to stay below its device time
+extern "C" int ec3d_multi_api_calls(ec3d_multi_handle m, int32_t rank, double *per_iteration)
+{
+    if (!m || rank < 0 || rank >= m->n || !per_iteration) return 2;
+    const Slab &s = *m->slab[(size_t)rank];
+    *per_iteration = s.api_iters ? (double)s.api_calls / (double)s.api_iters : 0.0;
+    return 0;
 }
 
 extern "C" int ec3d_multi_synchronize(ec3d_multi_handle m)
@@ -1193,7 +1267,7 @@ extern "C" int ec3d_multi_true_residual(ec3d_multi_handle m, double *rel, double
         bb[(size_t)r] = v[P_BB];
         rr[(size_t)r] = v[P_RR_INIT];
         return 0;
-    });
+    }, true);
     if (rc) return rc;
     double sb = 0.0, sr = 0.0;
     for (int r = 0; r < m->n; ++r) {
@@ -1205,9 +1279,10 @@ extern "C" int ec3d_multi_true_residual(ec3d_multi_handle m, double *rel, double
     return 0;
 }
 
-// y = A*x over the slabs (src/solvers.f90:54-61), host vectors in the global numbering: x goes to every slab's P
-// (owned and halo entries), the P halo planes are exchanged the way an iteration does it, every slab multiplies,
-// the owned parts of AP come back.  Parity probe of the slab operators and of the exchange together.
+// y = A*x over the slabs (src/solvers.f90:54-61), host vectors in the global numbering: x goes to every slab's P,
+// the rows the halo exchange fills are set to NaN, the P halo planes are exchanged the way an iteration does it,
+// every slab multiplies, the owned parts of AP come back.  Parity probe of the slab operators AND of the exchange:
+// a result equal to the undivided operator's means every halo row arrived, in time, from the right place.
 extern "C" int ec3d_multi_spmv(ec3d_multi_handle m, const double *x, double *y)
 {
     int rc = need(m, "ec3d_multi_spmv");
@@ -1216,11 +1291,13 @@ extern "C" int ec3d_multi_spmv(ec3d_multi_handle m, const double *x, double *y)
         Slab &s = *m->slab[(size_t)r];
         int rc2 = slab_upload(m, s, EC3D_VEC_P, x);
         if (rc2) return rc2;
+        // the probe must depend on the transport: what the exchange is to deliver is NaN until it does
+        if (m->n > 1 && (rc2 = poison_recv_rows(s, EC3D_VEC_P))) return rc2;
         if ((rc2 = halo_start(m, s, CH_P))) return rc2;
         if ((rc2 = halo_wait(s, CH_P))) return rc2;
         ec3d_launch_spmv(s.c->A.view(), s.c->sweep_s, s.c->vec[EC3D_VEC_P], s.c->vec[EC3D_VEC_AP], s.c->stream);
         MHIP(hipGetLastError());
         if ((rc2 = drain(s))) return rc2;
         return slab_download(m, s, EC3D_VEC_AP, y);
-    });
+    }, true);
 }

@@ -143,8 +143,12 @@ static int solve_core(ec3d_ctx *c, double tol, int32_t itmax, int32_t *iter, dou
                 s = 0.0;
                 for (int q = 0; q < c->sweep_s.nblk; ++q) s += part[(size_t)q];
             }
-            printf(" %.17g\n", std::sqrt(s));
-            fflush(stdout);
+            if (ec3d_itmax_print_hold) {
+                *ec3d_itmax_print_hold = std::sqrt(s);
+            } else {
+                printf(" %.17g\n", std::sqrt(s));
+                fflush(stdout);
+            }
         }
     }
     if (hist_host && c->hist_cap > 0)

@@ -64,7 +64,7 @@ EXPORTS = ["sprsbcgstabwr_", "ec3d_invalidate", "ec3d_create", "ec3d_destroy", "
            "ec3d_multi_assemble_poisson", "ec3d_multi_assemble", "ec3d_multi_set_matrix_csr", "ec3d_multi_size",
            "ec3d_multi_upload", "ec3d_multi_download", "ec3d_multi_solve", "ec3d_multi_solve_resident",
            "ec3d_multi_rhs_step", "ec3d_multi_post_update", "ec3d_multi_vtk_fields", "ec3d_multi_iterate_begin",
-           "ec3d_multi_iterate", "ec3d_multi_synchronize", "ec3d_true_residual", "ec3d_multi_true_residual", "ec3d_get_visit_order", "ec3d_probe_csr_multi", "ec3d_multi_spmv"]
+           "ec3d_multi_iterate", "ec3d_multi_synchronize", "ec3d_true_residual", "ec3d_multi_true_residual", "ec3d_get_visit_order", "ec3d_probe_csr_multi", "ec3d_multi_spmv", "ec3d_multi_api_calls"]
 
 _f64 = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
 _i32 = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
@@ -178,6 +178,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.ec3d_multi_iterate_begin.argtypes = [hp]
     L.ec3d_multi_iterate.argtypes = [hp, C.c_int32, C.c_int32, hp]
     L.ec3d_multi_synchronize.argtypes = [hp]
+    L.ec3d_multi_api_calls.argtypes = [hp, C.c_int32, C.POINTER(C.c_double)]
     L.sprsbcgstabwr_.argtypes = [_f64, _i32, _i32, C.POINTER(C.c_int32), _f64, _f64,
                                  C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.sprsbcgstabwr_.restype = None
@@ -665,3 +666,9 @@ class EC3DMulti:
 
     def synchronize(self):
         _chk(self.L, self.L.ec3d_multi_synchronize(self.h), "ec3d_multi_synchronize")
+
+    def api_calls(self, rank: int) -> float:
+        """HIP runtime calls per iteration rank `rank`'s host thread issued in the last iterate()."""
+        v = C.c_double(0.0)
+        _chk(self.L, self.L.ec3d_multi_api_calls(self.h, rank, C.byref(v)), "ec3d_multi_api_calls")
+        return v.value

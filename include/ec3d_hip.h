@@ -251,7 +251,7 @@ int ec3d_multi_rhs_step(ec3d_multi_handle mh, int32_t moving, int32_t nsrc, cons
                         const double *src_value);
 int ec3d_multi_post_update(ec3d_multi_handle mh);
 /* y = A*x over the slabs, host vectors in the global numbering (as ec3d_spmv): parity probe of the slab
- * operators and of the halo exchange together */
+ * operators and of the halo exchange together -- the rows the exchange is to fill hold NaN until it has */
 int ec3d_multi_spmv(ec3d_multi_handle mh, const double *x, double *y);
 int ec3d_multi_true_residual(ec3d_multi_handle mh, double *rel, double *bnorm); /* as ec3d_true_residual */
 int ec3d_multi_vtk_fields(ec3d_multi_handle mh, const double *delta, float *field_A, float *field_eddy,
@@ -261,6 +261,9 @@ int ec3d_multi_vtk_fields(ec3d_multi_handle mh, const double *delta, float *fiel
 int ec3d_multi_iterate_begin(ec3d_multi_handle mh);
 int ec3d_multi_iterate(ec3d_multi_handle mh, int32_t first_iter, int32_t count, double *kernel_ms);
 int ec3d_multi_synchronize(ec3d_multi_handle mh);
+/* HIP runtime calls (kernel launches, event records and waits, copies) that rank `rank`'s host thread issued per
+ * iteration during the last ec3d_multi_iterate: the host-side price of one pass of src/solvers.f90:24-50 on N GPUs */
+int ec3d_multi_api_calls(ec3d_multi_handle mh, int32_t rank, double *per_iteration);
 
 /* ------------------------------------------------------------------------------------------
  * 3. Introspection / measurement

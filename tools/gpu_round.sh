@@ -13,7 +13,7 @@ run() { # name, seconds, command...
     if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "timed out: stopping" | tee -a $out/progress.log; exit $rc; fi
     return $rc
 }
-run pytest 900 python -m pytest tests -m gpu -q -x -rs -rP -rx "$@"
+run pytest 900 python -m pytest tests -m gpu -q -x -rsPx "$@"
 tail -n 5 $out/pytest.log
 run bench_cube 300 python bench.py --no-cpu-baseline
 tail -n 1 $out/bench_cube.log | cut -c1-600

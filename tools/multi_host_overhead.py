@@ -43,9 +43,11 @@ def main():
             m.synchronize()
             t2 = time.perf_counter()
             plan = "overlap" if m.slab(0)[0].can_overlap() else "plain"
+            calls = [m.api_calls(r) for r in range(n)]
         print(f"N={n}: enqueue {1e6 * (t1 - t0) / args.iters:7.1f} us/iteration per rank thread (all threads in parallel), "
               f"until drained {1e6 * (t2 - t0) / args.iters:7.1f} us/iteration, plan {plan}, rows per slab "
-              f"{args.edge * args.edge * args.planes_per_slab}")
+              f"{args.edge * args.edge * args.planes_per_slab}; HIP runtime calls per iteration and rank: "
+              f"{' '.join(f'{c:.0f}' for c in calls)}")
 
 
 if __name__ == "__main__":
