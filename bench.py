@@ -142,7 +142,8 @@ def latest_traffic(grid, fmt, workload, n_gpus):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=300,
+                    help="timed iterations (default 300: the GPU leg then lasts about a second at 512^3)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--grid", type=int, default=512, help="cube edge N (512 = headline, 256 = config 2)")
     ap.add_argument("--format", choices=["dict", "dia"], default="dict",
@@ -154,6 +155,7 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="use the z-slab/torch.distributed path even with one rank (rehearsal on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-spmv-dia", action="store_true", help="skip the plain-DIA SpMV figure after the timed region")
     ap.add_argument("--no-verify", action="store_true",
                     help="in-library multi-GPU path: skip the A*x / reduction check against one device before timing")
     ap.add_argument("--cpu-grid", type=int, default=256, help="cube edge of the cpu_baseline sample")
@@ -301,8 +303,8 @@ def main():
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         elapsed = t1 - t0
-        # instrumented pass of the same K iterations: hipEvents around every launch, library stream
-        kernel_ms = s.iterate(W + K + 1, K, per_kernel=True)
+        # instrumented pass of the same iterations (at most 50 of them: six hipEvents each), library stream
+        kernel_ms = s.iterate(W + K + 1, min(K, 50), per_kernel=True)
         spmv_ms = s.time_kernel("spmv", 20)
         geom = {"vector": int(s.geometry(0).nblk), "spmv": int(s.geometry(1).nblk)}
         info = s.info
@@ -361,6 +363,24 @@ def main():
         info = s.local.info
         parallelism = f"z-slab x{world} (halo send/recv + all_gather of dot products, RCCL)"
 
+    # The north-star SpMV figure in the driver-run line: the plain 7-band DIA SpMV (56 B of coefficients + x + y =
+    # 72 B/row) at the same grid, timed after the headline region on a handle of its own (the
+    # default format's handle is closed first: 7.5 GB of bands + 8.6 GB of vectors), 20 launches back to back.
+    spmv_dia = None
+    if rank == 0 and not use_dist and not in_library and args.workload == "cube" and args.format == "dict" \
+            and not args.no_spmv_dia:
+        s.close()
+        with E.EC3DSolver(device=local_rank, dictionary=False) as sd:
+            sd.assemble_poisson(N, N, N)
+            sd.upload("B", bar_rhs(N))
+            sd.upload("X", np.zeros(n_global))
+            ms_d = sd.time_kernel("spmv", 20)
+            spmv_dia = {"kernel": "k_spmv, plain DIA (7 fp64 coefficient streams + x + y)", "ms": ms_d,
+                        "bytes_per_row": 72, "GBps": 72 * n_global / ms_d / 1e6,
+                        "frac": 72 * n_global / ms_d / 1e6 / PEAK_HBM_GBS, "workgroups": int(sd.geometry(1).nblk),
+                        "note": "20 launches back to back after the timed region; run-to-run the same binary gives "
+                                "either ~1.8 or ~2.0 ms at 512^3 (profiles/r03_dia_bimodal_*.log)"}
+
     if rank == 0:
         ms_per_step = elapsed * 1e3 / K
         value = n_global * K / elapsed
@@ -412,6 +432,8 @@ def main():
                            "survey_bytes_per_row": 72, "survey_GBps": 72 * rows / spmv_ms / 1e6,
                            "frac_of_peak_survey_model": 72 * rows / spmv_ms / 1e6 / PEAK_HBM_GBS,
                            "bytes_per_row": fmt_bytes["spmv"], "GBps": fmt_bytes["spmv"] * rows / spmv_ms / 1e6}
+        if spmv_dia is not None:
+            out["spmv_dia"] = spmv_dia
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.cpu_grid, args.cpu_iters)

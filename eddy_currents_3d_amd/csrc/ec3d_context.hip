@@ -177,7 +177,11 @@ static int choose_sweep(ec3d_ctx *c)
         sw.ntiles = 3 * sw.win_nt;
         sw.nown = 0;
     }
-    sw.nt = c->nt_request >= 0 ? c->nt_request : (c->A.n_pad >= (4 << 20));
+    {
+        int ntreq = c->nt_request;
+        if (const char *e = getenv("EC3D_NT")) ntreq = atoi(e); // read here too: sweeps of launch knobs in one process
+        sw.nt = ntreq >= 0 ? ntreq : (c->A.n_pad >= (4 << 20));
+    }
     // Vector kernels (K2, K4, K5): each on a grid, a tile map and a batching depth of its own.
     //   nblk  workgroups (whole multiples of the 256 CUs matter: 384 is far worse than 256 or 512)
     //   map   1: XCD-aware moving window (label b % 8 owns S consecutive tiles of a window of nblk), 0: tile b, b + nblk, ...

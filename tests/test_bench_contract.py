@@ -49,5 +49,8 @@ def test_one_json_line_with_the_agreed_fields(args, ngpu):
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s"
     assert rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"])
     assert "traffic" in rf
+    if ngpu == 1 and "--force-dist" not in args:           # the north-star SpMV figure travels in the driver-run line
+        sd = d["spmv_dia"]
+        assert sd["bytes_per_row"] == 72 and sd["ms"] > 0 and sd["frac"] == pytest.approx(sd["GBps"] / 8000.0)
     if "--devices" in args or "--force-dist" in args:      # both multi-GPU paths check their transport before timing
         assert "bit for bit" in d["verified"]
