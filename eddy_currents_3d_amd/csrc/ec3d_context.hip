@@ -235,15 +235,25 @@ static int choose_sweep(ec3d_ctx *c)
         const int64_t tpp = A.off[6] / EC3D_TILE;
         const int64_t nplanes = (sw.ntiles + tpp - 1) / tpp;
         if (tpp <= 4096 && nplanes >= 8) {
-            // workgroups of the z-marching kernels (tools/vec_sweep.py, profiles/r03_sweep_*): the single-component
-            // kernels, 50-76 registers since they take per-format arguments, run best from 4 workgroups per CU once
-            // the vectors are far beyond the caches (512^3: K1/K3 619/487 us at 1024 against 654/508 at 1536) and
-            // from 3 per CU below that (256^3: 83.8/60.7 at 768 against 85.1/67.4); the structured A-V kernels, whose
-            // conductor columns are several times heavier than the others, want the finer grain of 6 per CU
-            // (21 M unknowns: 128/108 at 1472, 145/124 at 1104)
-            int want_s = c->nblk_request > 0 ? c->nblk_request
-                         : A.sav                 ? 1536
-                         : c->A.n_pad >= ((int64_t)1 << 25) ? 1024 : 768;
+            // 2-D tiles (EC3D_PX x EC3D_PY patches, patch_pair in ec3d_kernels.hip) for the single-component operator in
+            // the dictionary format on a grid that divides into them: the +-sdx neighbours come from the workgroup's
+            // own rows through LDS.  Not for plain DIA: its seven coefficient streams are 56 of the 72 B per row, and
+            // reading them in 1 KiB pieces per patch row instead of 4 KiB runs costs more than the x loads save
+            // (512^3: K1/K3 2154/1964 us with patches, 2066/1847 without).
+            const int64_t sdx = A.off[5];
+            int patch = 1;
+            if (const char *e = getenv("EC3D_PATCH")) patch = atoi(e);
+            const bool use_patch = patch && !A.sav && A.ntail == 0 && A.ncls > 0 && sdx % EC3D_PX == 0 && A.off[6] % sdx == 0 &&
+                                   (A.off[6] / sdx) % EC3D_PY == 0 && c->A.n == nplanes * A.off[6];
+            // workgroups of the z-marching kernels (tools/vec_sweep.py, profiles/r03_sweep_*, r03_patch_*): the
+            // single-component kernels, 50-76 registers since they take per-format arguments, run best from 4
+            // workgroups per CU once the vectors are far beyond the caches (512^3: K1/K3 619/487 us at 1024 against
+            // 654/508 at 1536; with 2-D tiles 594/433 against 585/447) and below that from 3 per CU (256^3: 84/61 at
+            // 768 against 85/67) or, with 2-D tiles, 6 per CU (76/59 at 1536 against 89/65 at 768); the structured
+            // A-V kernels, whose conductor columns are several times heavier than the others, want the finer grain
+            // of 6 per CU (21 M unknowns: 128/108 at 1472, 145/124 at 1104, 137/116 at 1288)
+            const bool big = c->A.n_pad >= ((int64_t)1 << 25);
+            int want_s = c->nblk_request > 0 ? c->nblk_request : A.sav ? 1536 : big ? 1024 : use_patch ? 1536 : 768;
             if (const char *e = getenv("EC3D_NBLK_SPMV")) want_s = atoi(e);
             // columns are dealt to the 8 XCD labels in runs of cpx; with tpp % 8 != 0 the last run is short
             // and 8*cpx - tpp workgroups per segment stay idle
@@ -266,6 +276,10 @@ static int choose_sweep(ec3d_ctx *c)
             ss.zm_pps = (int)((nplanes + nseg - 1) / nseg);
             ss.nblk = (int)(cols * nseg);
             ss.S = 0;
+            if (use_patch) {
+                ss.patch_npx = (int)(sdx / EC3D_PX);
+                ss.patch_sdx = sdx;
+            }
         }
     }
     // z-slab of the single-component operator on a z-marching grid: K1/K3 can be split into an interior
@@ -286,6 +300,7 @@ static int choose_sweep(ec3d_ctx *c)
             si.nblk = (int)(cols * nseg);
             si.part_off = 0;
             sb.bnd_last = (int)(np - 1);
+            sb.patch_npx = 0; // the boundary planes go through the plain kernels: 512 consecutive cells per tile
             sb.nblk = (int)std::min<int64_t>(2 * tpp, 768);
             sb.part_off = si.nblk;
             parts = si.nblk + sb.nblk;
@@ -716,6 +731,9 @@ extern "C" int ec3d_get_reduction_geometry(ec3d_handle c, int which, ec3d_geom *
     g->zm_pps = sw.zm_pps;
     g->ntiles_front = (int32_t)sw.ntiles;
     g->ulist_n = sw.ulist_n;
+    g->patch_x = sw.patch_npx > 0 ? EC3D_PX : 0;
+    g->patch_y = sw.patch_npx > 0 ? EC3D_PY : 0;
+    g->patch_sdx = sw.patch_npx > 0 ? (int32_t)sw.patch_sdx : 0;
     return 0;
 }
 

@@ -13,6 +13,10 @@
 #define EC3D_TILE 512 /* rows per tile: every thread owns 2 consecutive rows (one 16-B access) */
 #define EC3D_MAXB 16  /* DIA bands */
 #define EC3D_CHUNK 64 /* sliced-ELL slice height = one wavefront */
+#ifndef EC3D_PX
+#define EC3D_PX 128   /* 2-D tile (patch) of the z-marching kernels: cells along x (one wave = one patch row) ... */
+#endif
+#define EC3D_PY (EC3D_TILE / EC3D_PX) /* ... and along y */
 
 // ---------------------------------------------------------------------------------------------
 // Device format.  Rows [0, n_pad).  Row r of A is
@@ -72,6 +76,12 @@ struct Sweep {
     // xy-plane ("column") and walks zm_pps consecutive planes, so x[r-kdz], x[r] stay in registers
     int zm_tpp;  // tiles per plane = kdz / 512
     int zm_pps;  // planes per z segment
+    // 2-D tiles of the z-marching single-component kernels (patch_npx > 0): a tile is a patch of EC3D_PX x EC3D_PY
+    // cells of the xy plane instead of 512 consecutive cells; tile q of a plane is patch (q % patch_npx, q / patch_npx),
+    // thread t owns cells 2 (t % (EC3D_PX/2)) and the next one of the patch's row t / (EC3D_PX/2).  See patch_pair in
+    // ec3d_kernels.hip.
+    int patch_npx;  // patches per grid row = sdx / EC3D_PX
+    int64_t patch_sdx;
     // rows that count in the dot products when this handle holds an A-V slab on an extended grid whose planes
     // are NOT tile aligned (nown > 0; bands + tail, or the structured form on a small grid): [Ax | Ay | Az | U]
     // each contribute one owned index range.  Tile-aligned structured slabs use the window below instead.
@@ -95,6 +105,17 @@ struct Sweep {
     const int32_t *ulist;
     int ulist_n;
 };
+
+// first of the two consecutive rows thread t of a workgroup owns in `tile`
+template <class SW>
+__host__ __device__ inline int64_t ec3d_row_of(const SW &sw, int64_t tile, int t)
+{
+    if (sw.patch_npx <= 0) return tile * EC3D_TILE + 2 * (int64_t)t;
+    const int64_t plane = tile / sw.zm_tpp, q = tile % sw.zm_tpp;
+    const int64_t py = q / sw.patch_npx, px = q % sw.patch_npx;
+    return plane * (int64_t)sw.zm_tpp * EC3D_TILE + (py * EC3D_PY + t / (EC3D_PX / 2)) * sw.patch_sdx + px * EC3D_PX +
+           2 * (int64_t)(t % (EC3D_PX / 2));
+}
 
 // logical -> physical tile of the front sweep (identity without a window)
 template <class SW>

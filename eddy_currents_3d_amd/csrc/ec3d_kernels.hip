@@ -150,6 +150,9 @@ struct SweepZ {
     int ulist_n;
     const int32_t *ulist;
     int64_t win_npo, win_npb, win_p0; // window in planes (owned per block, held per block, first owned); npo = 0: none
+    int patch_npx;                    // 2-D tiles (Sweep::patch_npx); zm_tpp doubles as tpp for ec3d_row_of
+    int64_t patch_sdx;
+    int zm_tpp;
 };
 // the launch of a vector kernel (K2, K4, K5) as it sees it: logical tiles t0, t0 + stride, ... of the front sweep
 // (the XCD-aware map of ec3d_tile_of: t0 = (b % 8) * S + b / 8, stride = 8 S; or t0 = b, stride = nblk), then its
@@ -352,6 +355,7 @@ __device__ __forceinline__ void walk_spmv(const SW &sw, BODY &&body)
     else walk_plain<0>(sw, body);
 }
 #define EC3D_ROW const int64_t r = tile * EC3D_TILE + 2 * (int64_t)threadIdx.x
+#define EC3D_ROW_S const int64_t r = PATCH ? ec3d_row_of(sw, tile, (int)threadIdx.x) : tile * EC3D_TILE + 2 * (int64_t)threadIdx.x
 
 // The vector a row kernel multiplies by, behind a small accessor (pair = two consecutive entries from
 // an 8-byte-aligned address, at = one gathered entry).
@@ -659,15 +663,110 @@ __device__ __forceinline__ void sav_pair_zm(const MatDev<FMT_SAV> &A, const doub
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 2-D tiles for the single-component 7-point operator (north_star: "LDS-staged neighbour stencils").  A workgroup
+// owns a patch of EC3D_PX x EC3D_PY = 64 x 8 cells of the xy plane and marches in z: thread t holds cells
+// (2q, 2q+1), q = t % 32, of patch row y = t / 32 (a wave = two patch rows).  Per step and thread ONE 16-byte global
+// load brings the plane above; the plane below and the centre are the z-march registers; +-1 are lane shuffles inside
+// the row (its two end lanes read the neighbouring patch); and +-sdx -- the patch rows above and below, which the
+// 512-consecutive-cells tile had to fetch with two more global loads per thread -- are the centre values the
+// workgroup's other threads hold, passed through LDS: when a thread's plane-above pair arrives it is stored to the
+// buffer the NEXT step reads (two buffers, one barrier per step).  Only the patch's first and last row go to memory
+// for their outer neighbour.  Global loads per wave and step: 1 full + at most half a wave of rim + 4 lanes of edge,
+// where the linear tile issues 3 full + 2 lanes.  Same products in the same order: A*x is bit-identical; the dot
+// products are summed in this thread -> cell assignment, which ec3d_geom::patch_x tells the oracle's twin.
+template <int FMT, bool NTB, class V>
+__device__ __forceinline__ void patch_pair(const MatDev<FMT> &A, const double *tbl, double *pbuf, int step, const V &x,
+                                           int64_t r, bool first, ZRegs &z, double &s0, double &s1, d2 &ctr)
+{
+    constexpr int HX = EC3D_PX / 2; // lanes per patch row
+    const int t = threadIdx.x, y = t / HX, q = t % HX;
+    const int64_t sdx = A.off[5], kdz = A.off[6];
+    double *cur = pbuf + (step & 1) * EC3D_TILE, *nxt = pbuf + ((step + 1) & 1) * EC3D_TILE;
+    unsigned short cc = 0;
+    if constexpr (FMT == FMT_DICT7) cc = *reinterpret_cast<const unsigned short *>(A.cls + r);
+    d2 c[7];
+    if constexpr (FMT == FMT_DIA7) {
+#pragma unroll
+        for (int b = 0; b < 7; ++b) c[b] = load2<NTB>(A.band[b] + r);
+    }
+    // every global load of the step first
+    const d2 zp = x.pair(r + kdz);
+    double left = 0.0, right = 0.0;
+    if (q == 0) left = x.at(r - 1);
+    if (q == HX - 1) right = x.at(r + 2);
+    d2 ym = d2{0.0, 0.0}, yp = d2{0.0, 0.0};
+    if (y == 0) ym = x.pair(r - sdx);
+    if (y == EC3D_PY - 1) yp = x.pair(r + sdx);
+    d2 zm, cx;
+    if (first) { // nothing carried over: plane below and centre from memory, centre into this step's buffer
+        zm = x.pair(r - kdz);
+        cx = x.pair(r);
+        *reinterpret_cast<d2 *>(cur + 2 * t) = cx;
+    } else {
+        zm = z.xm;
+        cx = z.xc;
+    }
+    __syncthreads(); // this step's buffer is complete (written at the end of the previous step, or just now)
+    if (y > 0) ym = *reinterpret_cast<const d2 *>(cur + 2 * (t - HX));
+    if (y < EC3D_PY - 1) yp = *reinterpret_cast<const d2 *>(cur + 2 * (t + HX));
+    ctr = cx;
+    {
+        const double l = __shfl_up(cx.y, 1, 64), rr = __shfl_down(cx.x, 1, 64);
+        if (q != 0) left = l;
+        if (q != HX - 1) right = rr;
+    }
+    if constexpr (FMT == FMT_DIA7) {
+        s0 = c[0].x * zm.x;
+        s1 = c[0].y * zm.y;
+        s0 = s0 + c[1].x * ym.x;
+        s1 = s1 + c[1].y * ym.y;
+        s0 = s0 + c[2].x * left;
+        s1 = s1 + c[2].y * cx.x;
+        s0 = s0 + c[3].x * cx.x;
+        s1 = s1 + c[3].y * cx.y;
+        s0 = s0 + c[4].x * cx.y;
+        s1 = s1 + c[4].y * right;
+        s0 = s0 + c[5].x * yp.x;
+        s1 = s1 + c[5].y * yp.y;
+        s0 = s0 + c[6].x * zp.x;
+        s1 = s1 + c[6].y * zp.y;
+    } else {
+        const double *t0 = tbl + (cc & 0xFF) * 7, *t1 = tbl + (cc >> 8) * 7;
+        s0 = t0[0] * zm.x;
+        s1 = t1[0] * zm.y;
+        s0 = s0 + t0[1] * ym.x;
+        s1 = s1 + t1[1] * ym.y;
+        s0 = s0 + t0[2] * left;
+        s1 = s1 + t1[2] * cx.x;
+        s0 = s0 + t0[3] * cx.x;
+        s1 = s1 + t1[3] * cx.y;
+        s0 = s0 + t0[4] * cx.y;
+        s1 = s1 + t1[4] * right;
+        s0 = s0 + t0[5] * yp.x;
+        s1 = s1 + t1[5] * yp.y;
+        s0 = s0 + t0[6] * zp.x;
+        s1 = s1 + t1[6] * zp.y;
+    }
+    // the plane above is the next step's centre: into the other buffer (nobody reads that one before the next barrier)
+    *reinterpret_cast<d2 *>(nxt + 2 * t) = zp;
+    z.xm = cx;
+    z.xc = zp;
+}
+
 // rows r, r+1 of A*x (src/solvers.f90:58-59): bands in ascending column order, then the tail.
 // ZM: band 0 / 3 / 6 (offsets -kdz, 0, +kdz) come from / go to the registers `z`.
 // `ctr` returns x[r], x[r+1] (the centre band's operand).
-template <int FMT, bool ZM, bool TAIL, bool NTB, class V>
-__device__ __forceinline__ void spmv_pair(const MatDev<FMT> &A, const double *tbl, double *stg, const V &x, int64_t r,
-                                          int64_t tile, bool first, ZRegs &z, double &s0, double &s1, d2 &ctr)
+template <int FMT, bool ZM, bool TAIL, bool NTB, bool PATCH, class V>
+__device__ __forceinline__ void spmv_pair(const MatDev<FMT> &A, const double *tbl, double *stg, int &step, const V &x,
+                                          int64_t r, int64_t tile, bool first, ZRegs &z, double &s0, double &s1, d2 &ctr)
 {
     if constexpr (FMT == FMT_SAV && ZM) {
         sav_pair_zm(A, tbl, stg, x, r, tile, first, z, s0, s1, ctr);
+        return;
+    }
+    if constexpr (PATCH && (FMT == FMT_DIA7 || FMT == FMT_DICT7)) {
+        patch_pair<FMT, NTB>(A, tbl, stg, step++, x, r, first, z, s0, s1, ctr);
         return;
     }
     uint8_t tflag = 0; // per tile: any tail row (bands + tail) / any coupled row (structured form)
@@ -784,7 +883,7 @@ __device__ __forceinline__ void spmv_pair(const MatDev<FMT> &A, const double *tb
 // (the structured form without z-marching only runs on grids too small for plane-aligned tiles: it takes the
 // registers it needs -- 5 per CU -- instead of spilling)
 #define EC3D_SPMV_OCC __attribute__((amdgpu_waves_per_eu((FMT == FMT_SAV && !ZM) ? 5 : 6)))
-#define EC3D_SPMV_T template <int FMT, bool NT, bool ZM, bool TAIL>
+#define EC3D_SPMV_T template <int FMT, bool NT, bool ZM, bool TAIL, bool PATCH>
 #define EC3D_SWEEP_OF(ZM_) typename SweepSel<ZM_>::type
 // classes in the LDS table (0 for the formats without one)
 template <int FMT> __device__ __forceinline__ int ncls_of(const MatDev<FMT> &A)
@@ -794,7 +893,7 @@ template <int FMT> __device__ __forceinline__ int ncls_of(const MatDev<FMT> &A)
 }
 #define EC3D_TBL_DECL                                                                          \
     extern __shared__ double tbl[]; /* the class table, sized at launch (EC3D_TBL_BYTES) */    \
-    double *stg = tbl + (FMT == FMT_SAV ? ncls_of<FMT>(A) * EC3D_SAV_STRIDE : 0) /* staging slots (sav_pair_zm) */
+    double *stg = tbl + (FMT == FMT_SAV ? ncls_of<FMT>(A) * EC3D_SAV_STRIDE : ((ncls_of<FMT>(A) * 7 + 1) & ~1)) /* staging slots (sav_pair_zm) / centre-plane buffers (patch_pair) behind the table */
 
 // ---------------------------------------------------------------------------------------------
 // plain y = A x  (src/solvers.f90:54-61)
@@ -805,11 +904,12 @@ EC3D_SPMV_T __global__ __launch_bounds__(EC3D_THREADS) EC3D_SPMV_OCC void k_spmv
     EC3D_TBL_DECL;
     stage_table<FMT>(A, tbl);
     ZRegs zr;
+    int pstep = 0; // steps taken (2-D tiles: which of the two LDS buffers holds the centre plane)
     walk_spmv<ZM, FMT != FMT_SAV>(sw, [&](int64_t tile, auto fc) {
-        EC3D_ROW;
+        EC3D_ROW_S;
         double s0, s1;
         d2 ctr;
-        spmv_pair<FMT, ZM, TAIL, NT>(A, tbl, stg, VecPlain{x}, r, tile, (bool)fc, zr, s0, s1, ctr);
+        spmv_pair<FMT, ZM, TAIL, NT, PATCH>(A, tbl, stg, pstep, VecPlain{x}, r, tile, (bool)fc, zr, s0, s1, ctr);
         store2<NT>(y, r, sw.n, s0, s1);
     });
 }
@@ -823,12 +923,13 @@ EC3D_SPMV_T __global__ __launch_bounds__(EC3D_THREADS) EC3D_SPMV_OCC void k_resi
     EC3D_TBL_DECL;
     stage_table<FMT>(A, tbl);
     ZRegs zr;
+    int pstep = 0; // steps taken (2-D tiles: which of the two LDS buffers holds the centre plane)
     double acc[2] = {0.0, 0.0};
     walk_spmv<ZM, FMT != FMT_SAV>(sw, [&](int64_t tile, auto fc) {
-        EC3D_ROW;
+        EC3D_ROW_S;
         double s0, s1;
         d2 ctr;
-        spmv_pair<FMT, ZM, TAIL, NT>(A, tbl, stg, VecPlain{x}, r, tile, (bool)fc, zr, s0, s1, ctr);
+        spmv_pair<FMT, ZM, TAIL, NT, PATCH>(A, tbl, stg, pstep, VecPlain{x}, r, tile, (bool)fc, zr, s0, s1, ctr);
         d2 bv = load2<NT>(b + r);
         double e0 = bv.x - s0, e1 = bv.y - s1, b0 = bv.x, b1 = bv.y;
         store2<NT>(rv, r, sw.n, e0, e1);
@@ -920,12 +1021,13 @@ EC3D_SPMV_T __global__ __launch_bounds__(EC3D_THREADS) EC3D_SPMV_OCC void k1_spm
     if (stop_iter_of(st) < it) return;
     stage_table<FMT>(A, tbl);
     ZRegs zr;
+    int pstep = 0; // steps taken (2-D tiles: which of the two LDS buffers holds the centre plane)
     double acc[1] = {0.0};
     walk_spmv<ZM, FMT != FMT_SAV>(sw, [&](int64_t tile, auto fc) {
-        EC3D_ROW;
+        EC3D_ROW_S;
         double s0, s1;
         d2 ctr;
-        spmv_pair<FMT, ZM, TAIL, NT>(A, tbl, stg, VecPlain{p}, r, tile, (bool)fc, zr, s0, s1, ctr);
+        spmv_pair<FMT, ZM, TAIL, NT, PATCH>(A, tbl, stg, pstep, VecPlain{p}, r, tile, (bool)fc, zr, s0, s1, ctr);
         d2 q = load2<NT>(r0 + r);
         store2<NT>(ap, r, sw.n, s0, s1);
         EC3D_MASK2(r, sw, s0, s1);
@@ -980,12 +1082,13 @@ EC3D_SPMV_T __global__ __launch_bounds__(EC3D_THREADS) EC3D_SPMV_OCC void k3_spm
     if (stop_iter_of(st) < it) return;
     stage_table<FMT>(A, tbl);
     ZRegs zr;
+    int pstep = 0; // steps taken (2-D tiles: which of the two LDS buffers holds the centre plane)
     double acc[2] = {0.0, 0.0};
     walk_spmv<ZM, FMT != FMT_SAV>(sw, [&](int64_t tile, auto fc) {
-        EC3D_ROW;
+        EC3D_ROW_S;
         double s0, s1;
         d2 q;
-        spmv_pair<FMT, ZM, TAIL, NT>(A, tbl, stg, VecPlain{sv}, r, tile, (bool)fc, zr, s0, s1, q);
+        spmv_pair<FMT, ZM, TAIL, NT, PATCH>(A, tbl, stg, pstep, VecPlain{sv}, r, tile, (bool)fc, zr, s0, s1, q);
         store2<NT>(as, r, sw.n, s0, s1);
         EC3D_MASK2(r, sw, s0, s1);
         acc[0] = acc[0] + s0 * q.x;
@@ -1201,13 +1304,17 @@ static inline SweepZ sweep_z(const Sweep &sw)
     z.win_npo = sw.win_nt > 0 ? sw.win_nt / sw.zm_tpp : 0;
     z.win_npb = sw.win_nt > 0 ? sw.win_blk / sw.zm_tpp : 0;
     z.win_p0 = sw.win_nt > 0 ? sw.win_t0 / sw.zm_tpp : 0;
+    z.patch_npx = sw.patch_npx;
+    z.patch_sdx = sw.patch_sdx;
+    z.zm_tpp = sw.zm_tpp;
     return z;
 }
 // dynamic LDS: the class table (a full 256-class table of the structured form would be 32 KiB and cap the CU
 // at 4 workgroups; real problems have 64 classes = 8 KiB) and, for the z-marching structured kernels, the
 // staging slots behind it (16 KiB): 24.6 KiB per workgroup, six of them fit a CU's 160 KiB
-static inline size_t tbl_bytes(const MatView &A, int F, bool zm)
+static inline size_t tbl_bytes(const MatView &A, int F, bool zm, bool patch)
 {
+    if (patch) return (size_t)((F == FMT_DICT7 ? A.ncls * 7 + 1 : 0) & ~1) * 8 + (size_t)2 * EC3D_TILE * 8;
     if (F == FMT_DICT7) return (size_t)A.ncls * 7 * 8;
     if (F == FMT_SAV) return (size_t)A.ncls * EC3D_SAV_STRIDE * 8 + (zm ? (size_t)EC3D_NSTAGE * EC3D_TILE * 8 : 0);
     return 0;
@@ -1215,18 +1322,20 @@ static inline size_t tbl_bytes(const MatView &A, int F, bool zm)
 #define EC3D_LAUNCH_ZT(F, NT_, KERNEL, ...)                                                                         \
     do {                                                                                                            \
         const bool tail_ = F != FMT_SAV && A.has_tail;                                                              \
-        const size_t lds_ = tbl_bytes(A, F, zm_);                                                                   \
+        const bool patch_ = zm_ && !tail_ && sw.patch_npx > 0 && (F == FMT_DIA7 || F == FMT_DICT7);                 \
+        const size_t lds_ = tbl_bytes(A, F, zm_, patch_);                                                           \
         const MatDev<F> Ad = mat_dev<F>(A);                                                                         \
         if constexpr (F != FMT_GENERIC) {                                                                           \
             if (zm_) {                                                                                              \
                 const SweepZ swz = sweep_z(sw);                                                                     \
-                if (tail_) { if constexpr (F != FMT_SAV) KERNEL<F, NT_, true, true><<<sw.nblk, EC3D_THREADS, lds_, s>>>(Ad, swz, __VA_ARGS__); } \
-                else KERNEL<F, NT_, true, false><<<sw.nblk, EC3D_THREADS, lds_, s>>>(Ad, swz, __VA_ARGS__);          \
+                if (patch_) { if constexpr (F == FMT_DIA7 || F == FMT_DICT7) KERNEL<F, NT_, true, false, true><<<sw.nblk, EC3D_THREADS, lds_, s>>>(Ad, swz, __VA_ARGS__); } \
+                else if (tail_) { if constexpr (F != FMT_SAV) KERNEL<F, NT_, true, true, false><<<sw.nblk, EC3D_THREADS, lds_, s>>>(Ad, swz, __VA_ARGS__); } \
+                else KERNEL<F, NT_, true, false, false><<<sw.nblk, EC3D_THREADS, lds_, s>>>(Ad, swz, __VA_ARGS__);   \
                 break;                                                                                              \
             }                                                                                                       \
         }                                                                                                           \
-        if (tail_) { if constexpr (F != FMT_SAV) KERNEL<F, NT_, false, true><<<sw.nblk, EC3D_THREADS, lds_, s>>>(Ad, sw, __VA_ARGS__); } \
-        else KERNEL<F, NT_, false, false><<<sw.nblk, EC3D_THREADS, lds_, s>>>(Ad, sw, __VA_ARGS__);                  \
+        if (tail_) { if constexpr (F != FMT_SAV) KERNEL<F, NT_, false, true, false><<<sw.nblk, EC3D_THREADS, lds_, s>>>(Ad, sw, __VA_ARGS__); } \
+        else KERNEL<F, NT_, false, false, false><<<sw.nblk, EC3D_THREADS, lds_, s>>>(Ad, sw, __VA_ARGS__);           \
     } while (0)
 #define EC3D_LAUNCH_FMT(F, KERNEL, ...)                                                        \
     do {                                                                                       \

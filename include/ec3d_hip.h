@@ -279,14 +279,18 @@ typedef struct {
     int32_t ntiles_front; /* tiles swept by the map above (all of them unless structured A-V form)  */
     int32_t ulist_n;   /* structured A-V form: occupied tiles of the U block, visited afterwards,
                           workgroup b taking entries b, b+nblk, ... of ec3d_get_ulist()             */
+    int32_t patch_x, patch_y; /* > 0: a tile of this sweep is a patch of patch_x x patch_y grid cells (2-D tiles of   */
+    int32_t patch_sdx;        /* the z-marching SpMV kernels on a grid with rows of patch_sdx cells): tile q of a plane
+                                 is patch (q % (patch_sdx/patch_x), q / (patch_sdx/patch_x)); thread t owns the cells
+                                 2 (t % (patch_x/2)) and the next one of the patch's row t / (patch_x/2)               */
 } ec3d_geom;
 /* which = 0: K4 (dots R.R, R.R0); 1: SpMV kernels (B.B, initial R.R, AP.R0, AS.S, AS.AS); 2: K2 (dot S.S) */
 int ec3d_get_reduction_geometry(ec3d_handle h, int which, ec3d_geom *g);
 int ec3d_get_ulist(ec3d_handle h, int32_t *tiles); /* ulist_n entries */
 /* The tiles (512 rows each) every workgroup of a launch visits, in order: workgroup w visits
  * tiles[offsets[w] .. offsets[w+1]).  which as above.
- * Each thread t of a workgroup owns rows tile*512 + 2t, 2t+1 and adds its products in this order -- the summation
- * order the oracle's twin reproduces.  Two-pass: offsets == NULL -> *nwg and *total only. */
+ * Each thread t of a workgroup owns rows tile*512 + 2t, 2t+1 (or the two cells of a patch, ec3d_geom::patch_x) and
+ * adds its products in this order -- the summation order the oracle's twin reproduces.  Two-pass: offsets == NULL -> *nwg and *total only. */
 int ec3d_get_visit_order(ec3d_handle h, int which, int32_t *nwg, int64_t *total, int32_t *offsets, int32_t *tiles);
 /* 1 (default): SpMV kernels walk the z direction per workgroup and keep x[r-kdz], x[r] in registers
  * when a grid plane is a whole number of 512-row tiles; 0: plain tile order. */

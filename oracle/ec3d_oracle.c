@@ -147,6 +147,15 @@ static double block_tree(double *v, int threads)
     return tot;
 }
 
+/* first of the two consecutive rows thread t owns in `tile` (ec3d_row_of in the HIP source) */
+static int64_t gpu_row_of(const oracle_gpu_geom *g, int64_t tile, int t)
+{
+    if (g->patch_x <= 0) return tile * g->tile + 2 * (int64_t)t;
+    const int64_t npx = g->patch_sdx / g->patch_x, hx = g->patch_x / 2;
+    const int64_t plane = tile / g->zm_tpp, q = tile % g->zm_tpp, py = q / npx, px = q % npx;
+    return plane * (int64_t)g->zm_tpp * g->tile + (py * g->patch_y + t / hx) * g->patch_sdx + px * g->patch_x + 2 * (t % hx);
+}
+
 double oracle_dot_gpuorder(const oracle_gpu_geom *g, const double *a, const double *b, int64_t n)
 {
     int T = g->threads;
@@ -174,7 +183,7 @@ double oracle_dot_gpuorder(const oracle_gpu_geom *g, const double *a, const doub
                 lst += g->nblk;
             }
             for (int t = 0; t < T; ++t) {
-                int64_t r = tile * g->tile + 2 * (int64_t)t;
+                int64_t r = gpu_row_of(g, tile, t);
                 double p0 = r < n ? a[r] * b[r] : 0.0;
                 double p1 = r + 1 < n ? a[r + 1] * b[r + 1] : 0.0;
                 acc[t] = acc[t] + p0;

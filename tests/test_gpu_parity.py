@@ -305,11 +305,45 @@ def test_full_size_256_spmv_bitwise_vs_oracle(E, oracle):
         assert np.array_equal(s.spmv(x), oracle.spmv_csr(valA, irow, jcol, x))
 
 
-def test_large_grid_768_formats_bitwise(E):
+@pytest.mark.parametrize("grid", [(128, 16, 12), (256, 8, 9), (128, 12, 10)])
+def test_two_dimensional_tiles_bitwise(E, oracle, grid, monkeypatch):
+    """The 2-D tiles of the z-marching dictionary kernels (patch_pair in csrc/ec3d_kernels.hip: a workgroup owns a
+    128 x 4 patch of the xy plane, the +-sdx neighbours travel through LDS): A*x equals the oracle's CSR SpMV bit for
+    bit (src/solvers.f90:54-61), the solve equals the oracle's GPU-order twin bit for bit -- x, iter and the whole
+    residual history -- with the thread -> cell assignment the library reports (ec3d_geom::patch_x), and the same
+    system on 512-consecutive-cell tiles (EC3D_PATCH=0) gives the same A*x bit for bit and the same solution to
+    rounding growth.  Grids: two patch rows of 4 / one patch column; a 256-wide grid (two patch columns); 12 rows."""
+    sdx, sdy, sdz = grid
+    n = sdx * sdy * sdz
+    valA, irow, jcol = oracle.poisson_csr(sdx, sdy, sdz)
+    rng = np.random.Generator(np.random.PCG64(2026))
+    x0 = rng.standard_normal(n)
+    b = rng.standard_normal(n)
+    tol = 1e-9
+    res = {}
+    for patch in ("1", "0"):
+        monkeypatch.setenv("EC3D_PATCH", patch)
+        with E.EC3DSolver() as s:
+            s.assemble_poisson(sdx, sdy, sdz)
+            g = s.geometry(1)
+            assert g.zm_tpp == sdx * sdy // 512
+            assert (g.patch_x, g.patch_y, g.patch_sdx) == ((128, 4, sdx) if patch == "1" else (0, 0, 0))
+            assert np.array_equal(s.spmv(x0), oracle.spmv_csr(valA, irow, jcol, x0))
+            x, it, hist = s.solve(b, np.zeros(n), tol, 5000, hist_cap=64)
+            xo, ito, hs, hr = oracle.twin_solve(s, valA, irow, jcol, b, np.zeros(n), tol, 5000, hist_cap=64)
+            m = min(it, 64)
+            assert it == ito and np.array_equal(x, xo)
+            assert np.array_equal(hist[:m, 0], hs[:m]) and np.array_equal(hist[:m - 1, 1], hr[:m - 1])
+            res[patch] = (x, it)
+    assert np.linalg.norm(res["1"][0] - res["0"][0]) <= 1e-6 * np.linalg.norm(res["0"][0])
+
+
+def test_large_grid_768_formats_bitwise(E, monkeypatch):
     """Well beyond the benchmark size (768^3, n = 452 984 832, 3.2e9 nonzeros > 2^31): plain DIA streams
     (25 GB) and the dictionary form give bit-identical iterates after 6 iterations -- a size-independent
     check that the large-index paths (64-bit row arithmetic, z-marching map with 2 z-segments, 3
     workgroups per CU) agree.  x of the two runs is compared on the device side via checksums."""
+    monkeypatch.setenv("EC3D_PATCH", "0")     # same tiles for both formats: the dictionary's 2-D tiles sum the dots in another order
     N = 768
     n = N ** 3
     rng = np.random.Generator(np.random.PCG64(99))

@@ -1,6 +1,8 @@
 #!/bin/bash
 tag=${1:-ab}; out=gpurun_out/$tag; mkdir -p $out
-for wl in av3 cube256 cube512; do
-timeout -k 10 300 python tools/vec_sweep.py $wl ";NT=0;NT=1;" > $out/nt_$wl.log 2>> $out/sweep.err
-cat $out/nt_$wl.log
+timeout -k 10 800 python -m pytest tests/test_gpu_parity.py tests/test_gpu_formats_dist.py tests/test_gpu_edge_cases.py tests/test_gpu_multi.py tests/test_gpu_config4.py -m gpu -q -x > $out/pytest.log 2>&1 || { tail -n 40 $out/pytest.log; echo "tests failed: no timing"; exit 1; }
+tail -n 2 $out/pytest.log
+for wl in cube512 cube256; do
+timeout -k 10 300 python tools/vec_sweep.py $wl ";PATCH=0;" > $out/patch_$wl.log 2>> $out/sweep.err
+cat $out/patch_$wl.log
 done
