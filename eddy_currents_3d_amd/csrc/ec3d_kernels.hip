@@ -1027,8 +1027,12 @@ EC3D_SPMV_T __global__ __launch_bounds__(EC3D_THREADS) EC3D_SPMV_OCC void k1_spm
         EC3D_ROW_S;
         double s0, s1;
         d2 ctr;
+        // R0's pair: requested before the step's own loads in the structured kernels (A-V K1 128 -> 124 us; their
+        // steps wait on LDS-DMA slots), after them elsewhere (2-D tiles: 593 vs 603 us at 512^3, 76 vs 80 at 256^3)
+        d2 q;
+        if constexpr (FMT == FMT_SAV) q = load2<NT>(r0 + r);
         spmv_pair<FMT, ZM, TAIL, NT, PATCH>(A, tbl, stg, pstep, VecPlain{p}, r, tile, (bool)fc, zr, s0, s1, ctr);
-        d2 q = load2<NT>(r0 + r);
+        if constexpr (FMT != FMT_SAV) q = load2<NT>(r0 + r);
         store2<NT>(ap, r, sw.n, s0, s1);
         EC3D_MASK2(r, sw, s0, s1);
         acc[0] = acc[0] + s0 * q.x;
