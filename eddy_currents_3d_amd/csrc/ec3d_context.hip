@@ -224,6 +224,7 @@ static int choose_sweep(ec3d_ctx *c)
     }
 
     Sweep &ss = c->sweep_s;
+    c->fuse23_ok = false;
     const DevMatrix &A = c->A;
     int zm = c->zm_request;
     if (const char *e = getenv("EC3D_ZMARCH")) zm = atoi(e);
@@ -279,6 +280,12 @@ static int choose_sweep(ec3d_ctx *c)
             if (use_patch) {
                 ss.patch_npx = (int)(sdx / EC3D_PX);
                 ss.patch_sdx = sdx;
+                // K2 inside K3 (k23_s_spmv_dots): pays where nothing stays in a cache -- 512^3: K2 + K3 539 + 435 us
+                // -> 856 us, iteration 3530 -> 3435 us; 256^3: 131 -> 154 us and K4 130 -> 165 us behind it (431 ->
+                // 476 us).  EC3D_FUSE23=0 never, 2 on every grid with 2-D tiles (tests).
+                int fuse = 1;
+                if (const char *e = getenv("EC3D_FUSE23")) fuse = atoi(e);
+                c->fuse23_ok = fuse == 2 || (fuse == 1 && big);
             }
         }
     }
@@ -721,7 +728,7 @@ extern "C" int ec3d_get_reduction_geometry(ec3d_handle c, int which, ec3d_geom *
 {
     int rc = ec3d_need_matrix(c, "ec3d_get_reduction_geometry");
     if (rc) return rc;
-    const Sweep &sw = which == 1 ? c->sweep_s : which == 2 ? c->sweep_k2 : c->sweep;
+    const Sweep &sw = which == 1 ? c->sweep_s : which == 2 ? (ec3d_fused23(c) ? c->sweep_s : c->sweep_k2) : c->sweep;
     g->n_pad = (int32_t)c->A.n_pad;
     g->tile = EC3D_TILE;
     g->nblk = sw.nblk;
@@ -770,8 +777,8 @@ extern "C" int ec3d_get_visit_order(ec3d_handle c, int which, int32_t *nwg, int6
     std::vector<std::vector<int32_t>> v;
     if (which == 1) {
         visit_of(c, c->sweep_s, v);
-    } else if (which == 2) {
-        visit_of(c, c->sweep_k2, v);
+    } else if (which == 2) { // who sums S.S: K2, or the SpMV kernel it runs inside of
+        visit_of(c, ec3d_fused23(c) ? c->sweep_s : c->sweep_k2, v);
     } else {
         visit_of(c, c->sweep, v);
     }

@@ -240,6 +240,7 @@ struct ec3d_ctx {
     Sweep sweep_s{}; // SpMV kernels (K1, K3, residual, spmv)
     Sweep sweep_int{}, sweep_bnd{}; // z-slab: interior / boundary-plane launches of K1 and K3
     bool can_overlap = false;
+    bool fuse23_ok = false; // 2-D tiles: K2 may run inside K3 (single rank only, see ec3d_fused23)
     // K2/K5 as boundary + interior launches (ec3d_dist_set_boundary_rows): tile lists on the device
     Sweep sweep_vb{}, sweep_vi{};
     int32_t *vb_list = nullptr, *vi_list = nullptr;
@@ -354,6 +355,7 @@ enum { EC3D_BY_K4 = 0, EC3D_BY_SPMV = 1, EC3D_BY_K2 = 2 };
 RedSrc ec3d_src_of(const ec3d_ctx *c, int producer);
 RedSrc ec3d_part_of(const ec3d_ctx *c, int producer, bool split = false);
 void ec3d_launch_stage(ec3d_ctx *c, const MatView &A, int it, int k); // k = 1..5, 0 = all five
+inline bool ec3d_fused23(const ec3d_ctx *c) { return c->fuse23_ok && !c->dist && c->halo == 0; }
 void ec3d_launch_iteration(ec3d_ctx *c, const MatView &A, int it);
 int ec3d_launch_begin(ec3d_ctx *c, const MatView &A, double tol);
 int ec3d_single_rank_only(ec3d_ctx *c, const char *who);
@@ -371,6 +373,8 @@ void ec3d_launch_k2(const Sweep &sw, const RedSrc &src, SolverState *st, int it,
                     double *sv, double *part, hipStream_t s);
 void ec3d_launch_k3(const MatView &A, const Sweep &sw, SolverState *st, int it, const double *sv, double *as,
                     double *part, hipStream_t s);
+void ec3d_launch_k23(const MatView &A, const Sweep &sw, const RedSrc &src, SolverState *st, int it, const double *r,
+                     const double *ap, double *sv, double *as, double *part, hipStream_t s);
 void ec3d_launch_k4(const Sweep &sw, const RedSrc &src_ss, const RedSrc &src, SolverState *st, int it,
                     const double *p, const double *sv, const double *as, const double *r0, double *x, double *r,
                     double *part, double *hist, int64_t hist_cap, hipStream_t s);

@@ -364,6 +364,19 @@ struct VecPlain {
     __device__ __forceinline__ d2 pair(int64_t i) const { return *reinterpret_cast<const d2u *>(x + i); }
     __device__ __forceinline__ double at(int64_t i) const { return x[i]; }
 };
+// S = R - alpha*AP formed where it is read (K2 fused into K3, src/solvers.f90:33 inside :39): every value is the same
+// expression, rounded the same way, whichever thread forms it -- the owner that stores it or a neighbour that needs it
+struct VecFused {
+    const double *__restrict__ rv;
+    const double *__restrict__ ap;
+    double alpha;
+    __device__ __forceinline__ d2 pair(int64_t i) const
+    {
+        const d2 q = *reinterpret_cast<const d2u *>(rv + i), a = *reinterpret_cast<const d2u *>(ap + i);
+        return d2{q.x - alpha * a.x, q.y - alpha * a.y};
+    }
+    __device__ __forceinline__ double at(int64_t i) const { return rv[i] - alpha * ap[i]; }
+};
 // Tail of one row: s += tval[e] * x[tcol[e]] over the row's slots of its 64-row slice, in stored order.
 // The loads are issued in batches (all values/columns of a batch, then all gathers, then the adds in
 // order): a plain loop is a chain of two dependent global loads per entry, ~1-2 us each, and a 13-entry
@@ -1107,6 +1120,52 @@ EC3D_SPMV_T __global__ __launch_bounds__(EC3D_THREADS) EC3D_SPMV_OCC void k3_spm
     }
 }
 
+// K2 + K3 in one launch (2-D tiles only, single rank): alpha = rr0 / (AP.R0); S = R - alpha*AP formed per plane where
+// the stencil needs it (VecFused: the plane above from two loads instead of one, the +-sdx rows through LDS as before,
+// rim and edge values recomputed by the lanes that need them) and stored by its owner; AS = A S; partials S.S, AS.S,
+// AS.AS -- all three in the SpMV kernels' thread -> cell assignment.  Saves the 8 B per row S costs to re-read and one
+// launch; the products, their order and every stored value are those of K2 followed by K3 (src/solvers.f90:31-40).
+EC3D_SPMV_T __global__ __launch_bounds__(EC3D_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void k23_s_spmv_dots(
+    MatDev<FMT> A, EC3D_SWEEP_OF(ZM) sw, RedSrc src, SolverState *st, int it, const double *__restrict__ rv,
+    const double *__restrict__ ap, double *__restrict__ sv, double *__restrict__ as, double *__restrict__ part)
+{
+    __shared__ double lds[12];
+    EC3D_TBL_DECL;
+    if (stop_iter_of(st) < it) return;
+    const int slot[1] = {P_D1};
+    double d[1];
+    reduce_partials<1>(src, slot, d, lds);
+    const double alpha = st->rr0[it & 1] / d[0];
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->alpha = alpha;
+    stage_table<FMT>(A, tbl);
+    ZRegs zr;
+    int pstep = 0;
+    double acc[3] = {0.0, 0.0, 0.0};
+    walk_spmv<ZM, FMT != FMT_SAV>(sw, [&](int64_t tile, auto fc) {
+        EC3D_ROW_S;
+        double s0, s1;
+        d2 q; // S[r], S[r+1]
+        spmv_pair<FMT, ZM, TAIL, NT, PATCH>(A, tbl, stg, pstep, VecFused{rv, ap, alpha}, r, tile, (bool)fc, zr, s0, s1, q);
+        store2<NT>(sv, r, sw.n, q.x, q.y);
+        store2<NT>(as, r, sw.n, s0, s1);
+        double q0 = q.x, q1 = q.y;
+        EC3D_MASK2(r, sw, q0, q1);
+        EC3D_MASK2(r, sw, s0, s1);
+        acc[0] = acc[0] + q0 * q0;
+        acc[0] = acc[0] + q1 * q1;
+        acc[1] = acc[1] + s0 * q.x;
+        acc[1] = acc[1] + s1 * q.y;
+        acc[2] = acc[2] + s0 * s0;
+        acc[2] = acc[2] + s1 * s1;
+    });
+    block_sum<3>(acc, lds);
+    if (threadIdx.x == 0) {
+        part[P_SS * sw.pstride + sw.part_off + blockIdx.x] = acc[0];
+        part[P_D2 * sw.pstride + sw.part_off + blockIdx.x] = acc[1];
+        part[P_D3 * sw.pstride + sw.part_off + blockIdx.x] = acc[2];
+    }
+}
+
 // K4: if ‖S‖/Bnorm < tol: X += alpha*P, exit (src/solvers.f90:34-38); else
 //     omega = (AS·S)/(AS·AS) ; X = X + alpha*P + omega*S ; R = S - omega*AS ;
 //     partials R·R and R·R0   (:40-44)
@@ -1426,6 +1485,19 @@ void ec3d_launch_k3(const MatView &A, const Sweep &sw, SolverState *st, int it, 
                     double *part, hipStream_t s)
 {
     EC3D_DISPATCH(A, k3_spmv_dots, st, it, sv, as, part);
+}
+
+void ec3d_launch_k23(const MatView &A, const Sweep &sw, const RedSrc &src, SolverState *st, int it, const double *r,
+                     const double *ap, double *sv, double *as, double *part, hipStream_t s)
+{
+    // the 2-D-tile dictionary kernels only (ec3d_fused23): one instantiation per cache policy
+    const MatDev<FMT_DICT7> Ad = mat_dev<FMT_DICT7>(A);
+    const SweepZ swz = sweep_z(sw);
+    const size_t lds = tbl_bytes(A, FMT_DICT7, true, true);
+    if (nt_of(sw))
+        k23_s_spmv_dots<FMT_DICT7, true, true, false, true><<<sw.nblk, EC3D_THREADS, lds, s>>>(Ad, swz, src, st, it, r, ap, sv, as, part);
+    else
+        k23_s_spmv_dots<FMT_DICT7, false, true, false, true><<<sw.nblk, EC3D_THREADS, lds, s>>>(Ad, swz, src, st, it, r, ap, sv, as, part);
 }
 
 void ec3d_launch_k4(const Sweep &sw, const RedSrc &src_ss, const RedSrc &src, SolverState *st, int it,

@@ -21,7 +21,7 @@
 // vector kernels (sweep) -- every consumer reads slots of one producer class only.
 static int parts_of(const ec3d_ctx *c, int producer, bool split)
 {
-    if (producer == EC3D_BY_K2) return c->sweep_k2.nblk;
+    if (producer == EC3D_BY_K2) return ec3d_fused23(c) ? c->sweep_s.nblk : c->sweep_k2.nblk; // fused: S.S comes from K23
     if (producer == EC3D_BY_K4) return c->sweep.nblk;
     return split ? c->sweep_int.nblk + c->sweep_bnd.nblk : c->sweep_s.nblk;
 }
@@ -44,9 +44,13 @@ void ec3d_launch_stage(ec3d_ctx *c, const MatView &A, int it, int k)
     hipStream_t s = c->stream;
     if (k == 0 || k == 1)
         ec3d_launch_k1(A, ss, c->state, it, v[EC3D_VEC_P], v[EC3D_VEC_R0], v[EC3D_VEC_AP], c->partials, s);
-    if (k == 0 || k == 2)
+    const bool fused = ec3d_fused23(c); // K2 inside K3 (2-D tiles, single rank): stage 2 is empty, stage 3 is K23
+    if ((k == 0 || k == 2) && !fused)
         ec3d_launch_k2(c->sweep_k2, ec3d_src_of(c, EC3D_BY_SPMV), c->state, it, v[EC3D_VEC_R], v[EC3D_VEC_AP], v[EC3D_VEC_S], c->partials, s);
-    if (k == 0 || k == 3)
+    if ((k == 0 || k == 3) && fused)
+        ec3d_launch_k23(A, ss, ec3d_src_of(c, EC3D_BY_SPMV), c->state, it, v[EC3D_VEC_R], v[EC3D_VEC_AP], v[EC3D_VEC_S],
+                        v[EC3D_VEC_AS], c->partials, s);
+    if ((k == 0 || k == 3) && !fused)
         ec3d_launch_k3(A, ss, c->state, it, v[EC3D_VEC_S], v[EC3D_VEC_AS], c->partials, s);
     if (k == 0 || k == 4)
         ec3d_launch_k4(sw, ec3d_src_of(c, EC3D_BY_K2), ec3d_src_of(c, EC3D_BY_SPMV), c->state, it, v[EC3D_VEC_P], v[EC3D_VEC_S],

@@ -305,14 +305,18 @@ def test_full_size_256_spmv_bitwise_vs_oracle(E, oracle):
         assert np.array_equal(s.spmv(x), oracle.spmv_csr(valA, irow, jcol, x))
 
 
+@pytest.mark.parametrize("fuse", ["0", "2"])
 @pytest.mark.parametrize("grid", [(128, 16, 12), (256, 8, 9), (128, 12, 10)])
-def test_two_dimensional_tiles_bitwise(E, oracle, grid, monkeypatch):
+def test_two_dimensional_tiles_bitwise(E, oracle, grid, fuse, monkeypatch):
     """The 2-D tiles of the z-marching dictionary kernels (patch_pair in csrc/ec3d_kernels.hip: a workgroup owns a
     128 x 4 patch of the xy plane, the +-sdx neighbours travel through LDS): A*x equals the oracle's CSR SpMV bit for
     bit (src/solvers.f90:54-61), the solve equals the oracle's GPU-order twin bit for bit -- x, iter and the whole
     residual history -- with the thread -> cell assignment the library reports (ec3d_geom::patch_x), and the same
     system on 512-consecutive-cell tiles (EC3D_PATCH=0) gives the same A*x bit for bit and the same solution to
-    rounding growth.  Grids: two patch rows of 4 / one patch column; a 256-wide grid (two patch columns); 12 rows."""
+    rounding growth.  Grids: two patch rows of 4 / one patch column; a 256-wide grid (two patch columns); 12 rows.
+    fuse = 2: K2 inside K3 (k23_s_spmv_dots, the default from 32 Mi rows, forced here): S.S is then summed in the SpMV
+    kernels' order, which the library reports as geometry 2 -- the twin must still match bit for bit."""
+    monkeypatch.setenv("EC3D_FUSE23", fuse)
     sdx, sdy, sdz = grid
     n = sdx * sdy * sdz
     valA, irow, jcol = oracle.poisson_csr(sdx, sdy, sdz)
@@ -328,6 +332,7 @@ def test_two_dimensional_tiles_bitwise(E, oracle, grid, monkeypatch):
             g = s.geometry(1)
             assert g.zm_tpp == sdx * sdy // 512
             assert (g.patch_x, g.patch_y, g.patch_sdx) == ((128, 4, sdx) if patch == "1" else (0, 0, 0))
+            assert (s.geometry(2).nblk == g.nblk and s.geometry(2).patch_x == 128) == (patch == "1" and fuse == "2")
             assert np.array_equal(s.spmv(x0), oracle.spmv_csr(valA, irow, jcol, x0))
             x, it, hist = s.solve(b, np.zeros(n), tol, 5000, hist_cap=64)
             xo, ito, hs, hr = oracle.twin_solve(s, valA, irow, jcol, b, np.zeros(n), tol, 5000, hist_cap=64)
