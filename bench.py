@@ -395,6 +395,13 @@ def main():
             fmt_bytes["k3"] += fmt_bytes.pop("k2") - 8
             survey_bytes["k3"] += survey_bytes.pop("k2") - 8
             names["k3"] = "k23_s_spmv_dots (S = R - alpha*AP inside AS = A*S; S.S, AS.S, AS.AS)"
+        if "k1" in kernel_ms and kernel_ms["k1"] < 0.05 * kernel_ms["k5"]:
+            # K5 runs inside the NEXT iteration's K1 (k51_p_spmv_dot): stage 1 is empty after the first iteration,
+            # stage 5 forms P where the stencil of AP = A*P reads it -- P is written once and not read back
+            kernel_ms["k5"] += kernel_ms.pop("k1")
+            fmt_bytes["k5"] += fmt_bytes.pop("k1") - 8
+            survey_bytes["k5"] += survey_bytes.pop("k1") - 8
+            names["k5"] = "k51_p_spmv_dot (P = R + beta*(P - omega*AP) inside the next AP = A*P; AP.R0)"
         dom = max(kernel_ms, key=kernel_ms.get)   # dominant kernel by measured share
         tr = latest_traffic(N, args.format, args.workload, world)
         use_tr = bool(tr)

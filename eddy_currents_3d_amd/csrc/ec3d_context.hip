@@ -81,6 +81,8 @@ static void free_vectors(ec3d_ctx *c)
     if (c->vec_base && c->own_vectors) (void)hipFree(c->vec_base);
     c->own_vectors = true;
     if (c->partials) (void)hipFree(c->partials);
+    if (c->pp_base) (void)hipFree(c->pp_base);
+    c->pp_base = nullptr;
     c->vec_base = nullptr;
     c->partials = nullptr;
     for (auto &v : c->vec) v = nullptr;
@@ -225,6 +227,7 @@ static int choose_sweep(ec3d_ctx *c)
 
     Sweep &ss = c->sweep_s;
     c->fuse23_ok = false;
+    c->fuse51_ok = false;
     const DevMatrix &A = c->A;
     int zm = c->zm_request;
     if (const char *e = getenv("EC3D_ZMARCH")) zm = atoi(e);
@@ -286,6 +289,10 @@ static int choose_sweep(ec3d_ctx *c)
                 int fuse = 1;
                 if (const char *e = getenv("EC3D_FUSE23")) fuse = atoi(e);
                 c->fuse23_ok = fuse == 2 || (fuse == 1 && big);
+                // K5 inside the next iteration's K1 (k51_p_spmv_dot): K1 + K5 593 + 700 us -> 1225 us at 512^3
+                int fuse5 = 1;
+                if (const char *e = getenv("EC3D_FUSE51")) fuse5 = atoi(e);
+                c->fuse51_ok = fuse5 == 2 || (fuse5 == 1 && big);
             }
         }
     }
@@ -347,6 +354,28 @@ int ec3d_prepare_vectors(ec3d_ctx *c)
     EC3D_HIP(hipMalloc(&c->partials, (size_t)P_NSLOT * c->sweep.pstride * sizeof(double)));
     EC3D_HIP(hipMemsetAsync(c->partials, 0, (size_t)P_NSLOT * c->sweep.pstride * sizeof(double), c->stream));
     EC3D_HIP(hipStreamSynchronize(c->stream));
+    return ec3d_spare_pair(c);
+}
+
+// the second buffers of P and AP for K5-in-K1 (ec3d_fused51): only handles that own their vectors
+int ec3d_spare_pair(ec3d_ctx *c)
+{
+    c->pbuf[1] = c->vec[EC3D_VEC_P];
+    c->apbuf[1] = c->vec[EC3D_VEC_AP];
+    if (!c->fuse51_ok || !c->own_vectors) {
+        if (c->pp_base) (void)hipFree(c->pp_base);
+        c->pp_base = nullptr;
+        c->pbuf[0] = c->apbuf[0] = nullptr;
+        return 0;
+    }
+    const int64_t len = c->ghost + c->A.n_pad + c->ghost;
+    if (!c->pp_base) {
+        EC3D_HIP(hipMalloc(&c->pp_base, (size_t)len * 2 * sizeof(double)));
+        EC3D_HIP(hipMemsetAsync(c->pp_base, 0, (size_t)len * 2 * sizeof(double), c->stream));
+        EC3D_HIP(hipStreamSynchronize(c->stream));
+    }
+    c->pbuf[0] = c->pp_base + c->ghost;
+    c->apbuf[0] = c->pp_base + len + c->ghost;
     return 0;
 }
 
@@ -365,6 +394,7 @@ extern "C" int ec3d_set_workgroups(ec3d_handle c, int32_t nblk)
         if (c->partials) (void)hipFree(c->partials);
         EC3D_HIP(hipMalloc(&c->partials, (size_t)P_NSLOT * c->sweep.pstride * sizeof(double)));
         EC3D_HIP(hipMemset(c->partials, 0, (size_t)P_NSLOT * c->sweep.pstride * sizeof(double)));
+        return ec3d_spare_pair(c);
     }
     return 0;
 }

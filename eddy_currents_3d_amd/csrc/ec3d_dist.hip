@@ -37,7 +37,7 @@ extern "C" int ec3d_adopt_vectors(ec3d_handle c, double *base)
     c->vec_base = base;
     c->own_vectors = false;
     for (int v = 0; v < EC3D_NVEC; ++v) c->vec[v] = base + (size_t)v * len + c->ghost;
-    return 0;
+    return ec3d_spare_pair(c); // adopted vectors: no spare pair, the kernels of an iteration stay unfused
 }
 
 extern "C" int ec3d_dist_configure(ec3d_handle c, int32_t nranks, double *lsum_device, double *gsum_device)

@@ -241,6 +241,12 @@ struct ec3d_ctx {
     Sweep sweep_int{}, sweep_bnd{}; // z-slab: interior / boundary-plane launches of K1 and K3
     bool can_overlap = false;
     bool fuse23_ok = false; // 2-D tiles: K2 may run inside K3 (single rank only, see ec3d_fused23)
+    bool fuse51_ok = false; // 2-D tiles: K5 may run inside the next iteration's K1 (ec3d_fused51)
+    // K5-in-K1 reads the previous iteration's P and AP while it writes the new ones (neighbouring workgroups read the
+    // old values of cells this one owns), so both vectors alternate between two buffers: P(it) lives in
+    // pbuf[it & 1], AP(it) in apbuf[it & 1]; index 1 is vec[EC3D_VEC_P] / vec[EC3D_VEC_AP], index 0 the spare pair
+    double *pp_base = nullptr;
+    double *pbuf[2] = {nullptr, nullptr}, *apbuf[2] = {nullptr, nullptr};
     // K2/K5 as boundary + interior launches (ec3d_dist_set_boundary_rows): tile lists on the device
     Sweep sweep_vb{}, sweep_vi{};
     int32_t *vb_list = nullptr, *vi_list = nullptr;
@@ -342,6 +348,7 @@ int ec3d_upload_matrix(ec3d_ctx *c, const HostMatrix &M);
 int ec3d_download_matrix(ec3d_ctx *c, HostMatrix &M);
 void ec3d_free_matrix(ec3d_ctx *c);
 int ec3d_prepare_vectors(ec3d_ctx *c);
+int ec3d_spare_pair(ec3d_ctx *c);
 // host vector (reference numbering, n_ref entries) <-> device vector (device numbering)
 int ec3d_vec_h2d(ec3d_ctx *c, double *dev, const double *host);
 int ec3d_vec_d2h(ec3d_ctx *c, double *host, const double *dev);
@@ -356,6 +363,7 @@ RedSrc ec3d_src_of(const ec3d_ctx *c, int producer);
 RedSrc ec3d_part_of(const ec3d_ctx *c, int producer, bool split = false);
 void ec3d_launch_stage(ec3d_ctx *c, const MatView &A, int it, int k); // k = 1..5, 0 = all five
 inline bool ec3d_fused23(const ec3d_ctx *c) { return c->fuse23_ok && !c->dist && c->halo == 0; }
+inline bool ec3d_fused51(const ec3d_ctx *c) { return c->fuse51_ok && !c->dist && c->halo == 0 && c->pp_base != nullptr; }
 void ec3d_launch_iteration(ec3d_ctx *c, const MatView &A, int it);
 int ec3d_launch_begin(ec3d_ctx *c, const MatView &A, double tol);
 int ec3d_single_rank_only(ec3d_ctx *c, const char *who);
@@ -375,6 +383,9 @@ void ec3d_launch_k3(const MatView &A, const Sweep &sw, SolverState *st, int it, 
                     double *part, hipStream_t s);
 void ec3d_launch_k23(const MatView &A, const Sweep &sw, const RedSrc &src, SolverState *st, int it, const double *r,
                      const double *ap, double *sv, double *as, double *part, hipStream_t s);
+void ec3d_launch_k51(const MatView &A, const Sweep &sw, const RedSrc &src, SolverState *st, int it, const double *r,
+                     const double *p_old, const double *ap_old, double *p_new, double *ap_new, double *r0, double *part,
+                     double *hist, int64_t hist_cap, hipStream_t s);
 void ec3d_launch_k4(const Sweep &sw, const RedSrc &src_ss, const RedSrc &src, SolverState *st, int it,
                     const double *p, const double *sv, const double *as, const double *r0, double *x, double *r,
                     double *part, double *hist, int64_t hist_cap, hipStream_t s);

@@ -377,6 +377,28 @@ struct VecFused {
     }
     __device__ __forceinline__ double at(int64_t i) const { return rv[i] - alpha * ap[i]; }
 };
+// P = R + beta*(P - omega*AP) formed where it is read (K5 fused into the next iteration's K1, src/solvers.f90:46 inside
+// :30), or P = R after a restart (:47-49); reads the PREVIOUS iteration's P and AP, which live in other buffers than
+// the ones this launch writes (neighbouring workgroups read them too)
+struct VecFusedP {
+    const double *__restrict__ rv;
+    const double *__restrict__ p;
+    const double *__restrict__ ap;
+    double beta, omega;
+    bool restart;
+    __device__ __forceinline__ d2 pair(int64_t i) const
+    {
+        const d2 q = *reinterpret_cast<const d2u *>(rv + i);
+        if (restart) return q;
+        const d2 pv = *reinterpret_cast<const d2u *>(p + i), a = *reinterpret_cast<const d2u *>(ap + i);
+        return d2{q.x + beta * (pv.x - omega * a.x), q.y + beta * (pv.y - omega * a.y)};
+    }
+    __device__ __forceinline__ double at(int64_t i) const
+    {
+        if (restart) return rv[i];
+        return rv[i] + beta * (p[i] - omega * ap[i]);
+    }
+};
 // Tail of one row: s += tval[e] * x[tcol[e]] over the row's slots of its 64-row slice, in stored order.
 // The loads are issued in batches (all values/columns of a batch, then all gathers, then the adds in
 // order): a plain loop is a chain of two dependent global loads per entry, ~1-2 us each, and a 13-entry
@@ -1166,6 +1188,62 @@ EC3D_SPMV_T __global__ __launch_bounds__(EC3D_THREADS) __attribute__((amdgpu_wav
     }
 }
 
+// K5 + the next iteration's K1 in one launch (2-D tiles only, single rank): the exits and the restart rule of K5
+// (src/solvers.f90:43-49), then P = R + beta*(P - omega*AP) formed per plane where the stencil of AP = A P needs it
+// (VecFusedP) and stored by its owner, AP.R0 for iteration it + 1 (:30-32).  P and AP of iteration `it` are read from
+// (p_old, ap_old) and those of it + 1 written to (p_new, ap_new): other workgroups read the old values of cells this
+// one owns (rim, edge, the planes at a segment's ends), so the update cannot be in place.  Saves the 8 B per row P
+// costs to re-read and one launch; every stored value and every product is K5's followed by K1's.
+EC3D_SPMV_T __global__ __launch_bounds__(EC3D_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void k51_p_spmv_dot(
+    MatDev<FMT> A, EC3D_SWEEP_OF(ZM) sw, RedSrc src, SolverState *st, int it, const double *__restrict__ rv,
+    const double *__restrict__ p_old, const double *__restrict__ ap_old, double *__restrict__ p_new,
+    double *__restrict__ ap_new, double *__restrict__ r0, double *__restrict__ part, double *hist, int64_t hist_cap)
+{
+    __shared__ double lds[8];
+    EC3D_TBL_DECL;
+    {
+        int si, kind;
+        stop_read(st, si, kind);
+        if (si < it || (si == it && kind == 1)) return;
+    }
+    const int slot[2] = {P_RR, P_RR0N};
+    double d[2];
+    reduce_partials<2>(src, slot, d, lds);
+    const double rnorm = sqrt(d[0]);
+    const double bnorm = st->bnorm, tol = st->tol;
+    const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+    if (lead && hist && it <= hist_cap) hist[2 * (int64_t)(it - 1) + 1] = rnorm;
+    if (rnorm / bnorm < tol) {
+        if (lead) stop_publish(st, it, 2);
+        return;
+    }
+    const double rr0_new = d[1];
+    const double alpha = st->alpha, omega = st->omega;
+    const double beta = (alpha / omega) * rr0_new / st->rr0[it & 1];
+    const bool restart = fabs(rr0_new) / bnorm < tol;
+    if (lead) st->rr0[(it + 1) & 1] = restart ? d[0] : rr0_new;
+    stage_table<FMT>(A, tbl);
+    ZRegs zr;
+    int pstep = 0;
+    double acc[1] = {0.0};
+    walk_spmv<ZM, FMT != FMT_SAV>(sw, [&](int64_t tile, auto fc) {
+        EC3D_ROW_S;
+        double s0, s1;
+        d2 pc; // the new P[r], P[r+1]
+        spmv_pair<FMT, ZM, TAIL, NT, PATCH>(A, tbl, stg, pstep, VecFusedP{rv, p_old, ap_old, beta, omega, restart}, r, tile,
+                                            (bool)fc, zr, s0, s1, pc);
+        d2 q = restart ? pc : load2<NT>(r0 + r); // after a restart R0 = R = the new P
+        store2<NT>(p_new, r, sw.n, pc.x, pc.y);
+        if (restart) store2<NT>(r0, r, sw.n, pc.x, pc.y);
+        store2<NT>(ap_new, r, sw.n, s0, s1);
+        EC3D_MASK2(r, sw, s0, s1);
+        acc[0] = acc[0] + s0 * q.x;
+        acc[0] = acc[0] + s1 * q.y;
+    });
+    block_sum<1>(acc, lds);
+    if (threadIdx.x == 0) part[P_D1 * sw.pstride + sw.part_off + blockIdx.x] = acc[0];
+}
+
 // K4: if ‖S‖/Bnorm < tol: X += alpha*P, exit (src/solvers.f90:34-38); else
 //     omega = (AS·S)/(AS·AS) ; X = X + alpha*P + omega*S ; R = S - omega*AS ;
 //     partials R·R and R·R0   (:40-44)
@@ -1498,6 +1576,19 @@ void ec3d_launch_k23(const MatView &A, const Sweep &sw, const RedSrc &src, Solve
         k23_s_spmv_dots<FMT_DICT7, true, true, false, true><<<sw.nblk, EC3D_THREADS, lds, s>>>(Ad, swz, src, st, it, r, ap, sv, as, part);
     else
         k23_s_spmv_dots<FMT_DICT7, false, true, false, true><<<sw.nblk, EC3D_THREADS, lds, s>>>(Ad, swz, src, st, it, r, ap, sv, as, part);
+}
+
+void ec3d_launch_k51(const MatView &A, const Sweep &sw, const RedSrc &src, SolverState *st, int it, const double *r,
+                     const double *p_old, const double *ap_old, double *p_new, double *ap_new, double *r0, double *part,
+                     double *hist, int64_t hist_cap, hipStream_t s)
+{
+    const MatDev<FMT_DICT7> Ad = mat_dev<FMT_DICT7>(A);
+    const SweepZ swz = sweep_z(sw);
+    const size_t lds = tbl_bytes(A, FMT_DICT7, true, true);
+    if (nt_of(sw))
+        k51_p_spmv_dot<FMT_DICT7, true, true, false, true><<<sw.nblk, EC3D_THREADS, lds, s>>>(Ad, swz, src, st, it, r, p_old, ap_old, p_new, ap_new, r0, part, hist, hist_cap);
+    else
+        k51_p_spmv_dot<FMT_DICT7, false, true, false, true><<<sw.nblk, EC3D_THREADS, lds, s>>>(Ad, swz, src, st, it, r, p_old, ap_old, p_new, ap_new, r0, part, hist, hist_cap);
 }
 
 void ec3d_launch_k4(const Sweep &sw, const RedSrc &src_ss, const RedSrc &src, SolverState *st, int it,

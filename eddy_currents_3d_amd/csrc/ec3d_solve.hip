@@ -36,29 +36,40 @@ RedSrc ec3d_part_of(const ec3d_ctx *c, int producer, bool split)
     return RedSrc{c->partials, parts_of(c, producer, split), 1, c->sweep.pstride, nullptr};
 }
 
-// the five launches of one iteration; `k` selects one of them (1..5) or all (0)
+// the five launches of one iteration; `k` selects one of them (1..5) or all (0).
+// With the fusions of the 2-D-tile kernels (single rank, vectors beyond the caches) an iteration is THREE launches:
+//   stage 1: K1 -- only in iteration 1 (afterwards AP = A P was produced by the previous iteration's stage 5)
+//   stage 2: empty, stage 3: K23 (S = R - alpha*AP inside AS = A S)
+//   stage 4: K4
+//   stage 5: K51 (the exits and the P update of K5, then the NEXT iteration's K1 on the new P)
+// P(it) and AP(it) then live in pbuf[it & 1] / apbuf[it & 1] (ec3d_ctx).
 void ec3d_launch_stage(ec3d_ctx *c, const MatView &A, int it, int k)
 {
     double **v = c->vec;
     const Sweep &sw = c->sweep, &ss = c->sweep_s;
     hipStream_t s = c->stream;
-    if (k == 0 || k == 1)
-        ec3d_launch_k1(A, ss, c->state, it, v[EC3D_VEC_P], v[EC3D_VEC_R0], v[EC3D_VEC_AP], c->partials, s);
     const bool fused = ec3d_fused23(c); // K2 inside K3 (2-D tiles, single rank): stage 2 is empty, stage 3 is K23
+    const bool f51 = ec3d_fused51(c);
+    double *P = f51 ? c->pbuf[it & 1] : v[EC3D_VEC_P], *AP = f51 ? c->apbuf[it & 1] : v[EC3D_VEC_AP];
+    if ((k == 0 || k == 1) && (!f51 || it == 1))
+        ec3d_launch_k1(A, ss, c->state, it, P, v[EC3D_VEC_R0], AP, c->partials, s);
     if ((k == 0 || k == 2) && !fused)
-        ec3d_launch_k2(c->sweep_k2, ec3d_src_of(c, EC3D_BY_SPMV), c->state, it, v[EC3D_VEC_R], v[EC3D_VEC_AP], v[EC3D_VEC_S], c->partials, s);
+        ec3d_launch_k2(c->sweep_k2, ec3d_src_of(c, EC3D_BY_SPMV), c->state, it, v[EC3D_VEC_R], AP, v[EC3D_VEC_S], c->partials, s);
     if ((k == 0 || k == 3) && fused)
-        ec3d_launch_k23(A, ss, ec3d_src_of(c, EC3D_BY_SPMV), c->state, it, v[EC3D_VEC_R], v[EC3D_VEC_AP], v[EC3D_VEC_S],
+        ec3d_launch_k23(A, ss, ec3d_src_of(c, EC3D_BY_SPMV), c->state, it, v[EC3D_VEC_R], AP, v[EC3D_VEC_S],
                         v[EC3D_VEC_AS], c->partials, s);
     if ((k == 0 || k == 3) && !fused)
         ec3d_launch_k3(A, ss, c->state, it, v[EC3D_VEC_S], v[EC3D_VEC_AS], c->partials, s);
     if (k == 0 || k == 4)
-        ec3d_launch_k4(sw, ec3d_src_of(c, EC3D_BY_K2), ec3d_src_of(c, EC3D_BY_SPMV), c->state, it, v[EC3D_VEC_P], v[EC3D_VEC_S],
+        ec3d_launch_k4(sw, ec3d_src_of(c, EC3D_BY_K2), ec3d_src_of(c, EC3D_BY_SPMV), c->state, it, P, v[EC3D_VEC_S],
                        v[EC3D_VEC_AS], v[EC3D_VEC_R0], v[EC3D_VEC_X], v[EC3D_VEC_R], c->partials, c->hist,
                        c->hist_cap, s);
-    if (k == 0 || k == 5)
-        ec3d_launch_k5(c->sweep_k5, ec3d_src_of(c, EC3D_BY_K4), c->state, it, v[EC3D_VEC_R], v[EC3D_VEC_AP], v[EC3D_VEC_P],
+    if ((k == 0 || k == 5) && !f51)
+        ec3d_launch_k5(c->sweep_k5, ec3d_src_of(c, EC3D_BY_K4), c->state, it, v[EC3D_VEC_R], AP, P,
                        v[EC3D_VEC_R0], c->hist, c->hist_cap, s);
+    if ((k == 0 || k == 5) && f51)
+        ec3d_launch_k51(A, ss, ec3d_src_of(c, EC3D_BY_K4), c->state, it, v[EC3D_VEC_R], P, AP, c->pbuf[(it + 1) & 1],
+                        c->apbuf[(it + 1) & 1], v[EC3D_VEC_R0], c->partials, c->hist, c->hist_cap, s);
 }
 
 void ec3d_launch_iteration(ec3d_ctx *c, const MatView &A, int it) { ec3d_launch_stage(c, A, it, 0); }

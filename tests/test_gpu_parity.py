@@ -317,6 +317,7 @@ def test_two_dimensional_tiles_bitwise(E, oracle, grid, fuse, monkeypatch):
     fuse = 2: K2 inside K3 (k23_s_spmv_dots, the default from 32 Mi rows, forced here): S.S is then summed in the SpMV
     kernels' order, which the library reports as geometry 2 -- the twin must still match bit for bit."""
     monkeypatch.setenv("EC3D_FUSE23", fuse)
+    monkeypatch.setenv("EC3D_FUSE51", fuse)      # and K5 inside the next K1 (k51_p_spmv_dot), P / AP alternating buffers
     sdx, sdy, sdz = grid
     n = sdx * sdy * sdz
     valA, irow, jcol = oracle.poisson_csr(sdx, sdy, sdz)

@@ -10,7 +10,7 @@ import bench
 wl = sys.argv[1]
 configs = sys.argv[2].split(";") if len(sys.argv) > 2 else [""]
 KN = ("EC3D_NBLK_K2", "EC3D_NBLK_K4", "EC3D_NBLK_K5", "EC3D_NBLK_SPMV", "EC3D_XCD_MAP", "EC3D_VEC_DEPTH", "EC3D_NT",
-      "EC3D_PATCH", "EC3D_FUSE23", "EC3D_MAP_K2", "EC3D_MAP_K4", "EC3D_MAP_K5", "EC3D_DEPTH_K2", "EC3D_DEPTH_K4", "EC3D_DEPTH_K5")
+      "EC3D_PATCH", "EC3D_FUSE23", "EC3D_FUSE51", "EC3D_MAP_K2", "EC3D_MAP_K4", "EC3D_MAP_K5", "EC3D_DEPTH_K2", "EC3D_DEPTH_K4", "EC3D_DEPTH_K5")
 with E.EC3DSolver(dictionary=not wl.startswith("dia")) as s:
     if wl == "av3":
         geo, geoC, valPHYS, BND, delta, dt, b = bench.av_system(3)
