@@ -2,10 +2,13 @@
 //
 // Reference arithmetic restated (src/solvers.f90:3-61, see the per-kernel notes) with these
 // MI355X-first choices:
-//   * matrix = DIA bands (SoA, one fp64 stream per band) + sliced-ELL tail; no column indices
-//     on the band part, every stream is read with 16-byte accesses, one tile = 512 rows;
-//   * one iteration = 5 launches (K1..K5); every vector op is fused into the kernel that
-//     produces its operand, every dot product into the kernel that produces its vector;
+//   * matrix = one class byte per row + a coefficient table in LDS (dictionary / structured A-V form), or DIA bands
+//     (SoA, one fp64 stream per band) + sliced-ELL tail; no column indices on the band part, every stream is read
+//     with 16-byte accesses, one tile = 512 rows -- consecutive ones, or a 128 x 4 patch of the xy plane whose
+//     +-sdx neighbours travel through LDS (patch_pair);
+//   * one iteration = 5 launches (K1..K5), every vector op fused into the kernel that produces its operand, every
+//     dot product into the kernel that produces its vector -- or 3 launches on large single-rank problems, where
+//     S and P are formed inside the SpMV kernels that read them (k23_s_spmv_dots, k51_p_spmv_dot);
 //   * reductions are deterministic: per-thread sequential over its tiles, 64-lane shuffle tree,
 //     4 wave sums left to right, one partial per workgroup; the NEXT kernel's workgroups each
 //     re-reduce the partials in the same order (a few KB from L2), so there is no atomics, no
@@ -13,9 +16,10 @@
 //     in a device-resident SolverState;
 //   * convergence is decided on the device: an exit writes stop_iter, later launches become
 //     no-ops, the host polls asynchronously (ec3d_solve.hip);
-//   * blockIdx -> tile map is XCD aware: the 8 XCD labels (blockIdx % 8) sweep disjoint
-//     contiguous groups of S tiles of one moving window, so x[r ± sdx] re-reads hit the L2 of
-//     the XCD that fetched them and the window's planes stay in the Infinity Cache.
+//   * the SpMV kernels march in z (one xy position per workgroup, the planes below and at the row in registers);
+//     their columns are dealt to the 8 XCD labels (blockIdx % 8) in contiguous runs, so what a neighbour column
+//     fetched is in the same XCD's L2; the vector kernels take the grid, tile order and batching depth measured
+//     best for each (choose_sweep in ec3d_context.hip).
 // Built with -ffp-contract=off: products and sums are rounded separately, exactly as the
 // reference's x86-64 object code does; the oracle's "GPU order" twin reproduces every bit.
 #include "ec3d_internal.hpp"

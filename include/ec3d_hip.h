@@ -345,7 +345,10 @@ int ec3d_time_iterations(ec3d_handle h, int32_t iters, double *ms_total);
  * ec3d_iterate_begin sets up R, R0, P from the resident b/x with exits disabled; ec3d_iterate
  * enqueues iterations first_iter .. first_iter+count-1 and returns without synchronising.
  * With kernel_ms != NULL (5 doubles, K1..K5) it brackets every launch with hipEvents on the
- * library's stream, synchronises, and returns each kernel's average duration in ms. */
+ * library's stream, synchronises, and returns each kernel's average duration in ms.
+ * On large single-rank problems with 2-D tiles an iteration is three launches: K2 runs inside K3 and K5 inside
+ * the NEXT iteration's K1; stages 1 (after the first iteration) and 2 are then empty and report ~0 ms, stage 3 is
+ * K2 + K3, stage 5 is K5 + K1 (EC3D_FUSE23=0 EC3D_FUSE51=0 restore five launches). */
 int ec3d_iterate_begin(ec3d_handle h);
 int ec3d_iterate(ec3d_handle h, int32_t first_iter, int32_t count, double *kernel_ms);
 
