@@ -341,6 +341,15 @@ def test_two_dimensional_tiles_bitwise(E, oracle, grid, fuse, monkeypatch):
             assert it == ito and np.array_equal(x, xo)
             assert np.array_equal(hist[:m, 0], hs[:m]) and np.array_equal(hist[:m - 1, 1], hr[:m - 1])
             res[patch] = (x, it)
+            # the same handle again: a warm start that runs into itmax (src/solvers.f90:25-29: 8 iterations), then a
+            # solve from the converged x (exits at once) -- the alternating P / AP buffers of the fused iteration
+            # must start every solve in the same state
+            xw, itw, hw = s.solve(b, 0.5 * x, tol, 7, hist_cap=16)
+            xwo, itwo, hws, hwr = oracle.twin_solve(s, valA, irow, jcol, b, 0.5 * x, tol, 7, hist_cap=16)
+            assert itw == itwo == 8 and np.array_equal(xw, xwo) and np.array_equal(hw[:8, 0], hws[:8])
+            xc, itc, _ = s.solve(b, x, tol, 5000)
+            xco, itco, _, _ = oracle.twin_solve(s, valA, irow, jcol, b, x, tol, 5000)
+            assert itc == itco and np.array_equal(xc, xco)
     assert np.linalg.norm(res["1"][0] - res["0"][0]) <= 1e-6 * np.linalg.norm(res["0"][0])
 
 
