@@ -746,7 +746,10 @@ __device__ __forceinline__ void patch_pair(const MatDev<FMT> &A, const double *t
         zm = z.xm;
         cx = z.xc;
     }
-    __syncthreads(); // this step's buffer is complete (written at the end of the previous step, or just now)
+    // this step's buffer is complete (written at the end of the previous step, or just now).  A raw barrier behind a
+    // wait for the LDS writes only: __syncthreads() also drains every global load in flight (vmcnt(0)) before the
+    // barrier, which would put the LDS exchange BEHIND the arrival of the plane above instead of beside it
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (y > 0) ym = *reinterpret_cast<const d2 *>(cur + 2 * (t - HX));
     if (y < EC3D_PY - 1) yp = *reinterpret_cast<const d2 *>(cur + 2 * (t + HX));
     ctr = cx;
