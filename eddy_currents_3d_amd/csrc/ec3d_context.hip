@@ -409,10 +409,11 @@ static int up(T *&dst, const std::vector<T> &src, int64_t &bytes, hipStream_t s)
     return 0;
 }
 
-int ec3d_upload_matrix(ec3d_ctx *c, const HostMatrix &M)
+int ec3d_upload_matrix(ec3d_ctx *c, const HostMatrix &M, int64_t halo)
 {
     EC3D_HIP(hipSetDevice(c->device));
     ec3d_free_matrix(c);
+    c->halo = halo;
     DevMatrix &A = c->A;
     A.n = M.n;
     A.n_pad = M.n_pad;
@@ -574,13 +575,20 @@ extern "C" int ec3d_probe_csr_multi(int32_t n, const double *valA, const int32_t
     if (!cuttable || !valA || !irow || !jcol || nranks < 1) return 2;
     *cuttable = 0;
     SavHost S;
-    if (ec3d_csr_to_sav_host(n, valA, irow, jcol, S) != 0) {
-        ec3d_set_error("not recognised as the reference's A-V system on a grid: no z-planes to cut along");
+    std::string why = "not recognised as the reference's A-V system on a grid nor as a single-component 7-point "
+                      "operator on one: no z-planes to cut along";
+    const bool sav = ec3d_csr_to_sav_host(n, valA, irow, jcol, S) == 0;
+    if (sav && ec3d_sav_cuttable(S, nranks, why) == 0) {
+        *cuttable = 1;
         return 0;
     }
-    std::string why;
-    if (ec3d_sav_cuttable(S, nranks, why) == 0) *cuttable = 1;
-    else ec3d_set_error(why);
+    HostMatrix M; // a cube (configs 2 and 4 arriving as CSR) cuts plane by plane
+    int64_t sdx = 0, kdz = 0;
+    if (ec3d_csr_to_host_matrix(n, valA, irow, jcol, M) == 0 && ec3d_host_matrix_is_cube(M, sdx, kdz)) {
+        if ((int64_t)n / kdz >= nranks) *cuttable = 1;
+        else why = "fewer z-planes than ranks";
+    }
+    if (!*cuttable) ec3d_set_error(why);
     return 0;
 }
 

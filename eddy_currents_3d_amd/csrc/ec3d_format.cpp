@@ -191,3 +191,14 @@ void ec3d_host_matrix_to_csr(const HostMatrix &M, std::vector<int32_t> &irow, st
         irow[r + 1] = (int32_t)(jcol.size() + 1);
     }
 }
+
+bool ec3d_host_matrix_is_cube(const HostMatrix &M, int64_t &sdx, int64_t &kdz)
+{
+    if (M.ntail != 0 || M.nb != 7 || M.off[3] != 0 || M.off[2] != -1 || M.off[4] != 1 || M.off[1] != -M.off[5] ||
+        M.off[0] != -M.off[6] || M.off[5] < 2 || M.off[6] <= M.off[5] || M.off[6] % M.off[5] != 0 ||
+        M.n % M.off[6] != 0)
+        return false;
+    sdx = M.off[5];
+    kdz = M.off[6];
+    return true;
+}

@@ -338,13 +338,18 @@ void ec3d_host_matrix_to_csr(const HostMatrix &M, std::vector<int32_t> &irow, st
 int ec3d_csr_to_sav_host(int64_t n, const double *valA, const int32_t *irow, const int32_t *jcol, SavHost &S);
 // Can a recognised system be cut into `nranks` z-slabs?  0, or 2 (fewer than two planes per rank) / 7 (something
 // couples across the z faces of a component: not the reference's system on a box) with the reason in `why`.
+// seven bands at (-kdz, -sdx, -1, 0, 1, sdx, kdz), no tail, n a whole number of planes of kdz rows (kdz a whole
+// number of sdx lines): a single-component 7-point operator on a grid, which can be cut along z plane by plane
+bool ec3d_host_matrix_is_cube(const HostMatrix &M, int64_t &sdx, int64_t &kdz);
 int ec3d_sav_cuttable(const SavHost &G, int nranks, std::string &why);
 // planes [e0, e1) of a recognised system as a slab that owns [k0, k1) (same pitch, classes and table)
 void ec3d_sav_slice(const SavHost &G, int64_t e0, int64_t e1, int64_t k0, int64_t k1, SavHost &L);
 
 // ec3d_context.hip
 int ec3d_upload_sav(ec3d_ctx *c, const SavHost &S);
-int ec3d_upload_matrix(ec3d_ctx *c, const HostMatrix &M);
+// halo > 0: the matrix is a z-slab of a single-component operator whose planes hold `halo` rows (the ghost zones of
+// the vectors then carry the neighbours' planes, ec3d_assemble_poisson_slab does the same natively)
+int ec3d_upload_matrix(ec3d_ctx *c, const HostMatrix &M, int64_t halo = 0);
 int ec3d_download_matrix(ec3d_ctx *c, HostMatrix &M);
 void ec3d_free_matrix(ec3d_ctx *c);
 int ec3d_prepare_vectors(ec3d_ctx *c);

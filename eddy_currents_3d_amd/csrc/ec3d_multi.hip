@@ -973,6 +973,70 @@ extern "C" int ec3d_multi_assemble(ec3d_multi_handle m, int32_t sdx, int32_t sdy
     return finish_setup(m);
 }
 
+// ---- a single-component 7-point operator that arrives as CSR (BASELINE configs 2 and 4 through the drop-in symbol):
+//      seven bands at (-kdz, -sdx, -1, 0, 1, sdx, kdz) and nothing else, n a whole number of planes.  Every rank takes
+//      the band rows of its planes (same coefficients, same order), the ghost zones carry the neighbours' planes -- the
+//      layout of ec3d_multi_assemble_poisson.  Returns -1 when the matrix is not of that kind.
+static int multi_set_cube_csr(ec3d_multi *m, int32_t n, const double *valA, const int32_t *irow, const int32_t *jcol)
+{
+    HostMatrix M;
+    if (ec3d_csr_to_host_matrix(n, valA, irow, jcol, M) != 0) return -1;
+    int64_t sdx = 0, kdz = 0;
+    if (!ec3d_host_matrix_is_cube(M, sdx, kdz)) return -1;
+    const int64_t sdz = (int64_t)n / kdz;
+    if (sdz < m->n) {
+        ec3d_set_error("ec3d_multi_set_matrix_csr: fewer z-planes than ranks");
+        return 2;
+    }
+    m->sdx = (int32_t)sdx; m->sdy = (int32_t)(kdz / sdx); m->sdz = (int32_t)sdz;
+    m->kdz = kdz;
+    m->nC_glob = (int64_t)n;
+    m->nU_glob = 0;
+    m->n_glob = (int64_t)n;
+    int rc = run_all(m, [&](int r) -> int {
+        Slab &s = *m->slab[(size_t)r];
+        int rc2 = slab_reset(m, s);
+        if (rc2) return rc2;
+        slab_bounds((int)sdz, r, m->n, s.k0, s.k1);
+        s.e0 = s.k0;
+        s.e1 = s.k1;
+        const int64_t rows = (int64_t)(s.k1 - s.k0) * kdz, r0 = (int64_t)s.k0 * kdz;
+        HostMatrix S;
+        S.n = rows;
+        S.n_pad = (rows + EC3D_TILE - 1) / EC3D_TILE * EC3D_TILE;
+        S.nb = 7;
+        for (int b = 0; b < 7; ++b) S.off[b] = M.off[b];
+        S.bands.assign((size_t)7 * S.n_pad, 0.0);
+        for (int b = 0; b < 7; ++b)
+            memcpy(&S.bands[(size_t)b * S.n_pad], &M.bands[(size_t)b * M.n_pad + r0], (size_t)rows * sizeof(double));
+        S.tail_id.assign((size_t)S.n_pad, -1);
+        S.tile_flag.assign((size_t)(S.n_pad / EC3D_TILE), 0);
+        S.chunk_ptr.assign(1, 0);
+        S.nnz = 0;
+        for (int64_t q = r0; q < r0 + rows; ++q) S.nnz += irow[q + 1] - irow[q];
+        if (s.c->use_dict) ec3d_build_dictionary_host(S);
+        if ((rc2 = ec3d_upload_matrix(s.c, S, m->n > 1 ? kdz : 0))) return rc2;
+        s.n_local = rows;
+        if (s.c->ghost < kdz && m->n > 1) {
+            ec3d_set_error("ec3d_multi: ghost zone smaller than a plane");
+            return 105;
+        }
+        if (r > 0) {
+            s.send_lo.push_back(Run{0, kdz, kdz, 1});
+            s.recv_lo.push_back(Run{-kdz, kdz, kdz, 1});
+        }
+        if (r + 1 < m->n) {
+            s.send_hi.push_back(Run{rows - kdz, kdz, kdz, 1});
+            s.recv_hi.push_back(Run{rows, kdz, kdz, 1});
+        }
+        return 0;
+    });
+    if (rc) return rc;
+    m->kind = 1;
+    m->nnz = M.nnz;
+    return finish_setup(m);
+}
+
 // ---- the reference's CSR triple (what sprsbcgstabwr_ receives): recognised as the A-V system on a grid
 //      (ec3d_sav_csr.cpp), then cut into slabs of the structured form -----------------------------------------
 extern "C" int ec3d_multi_set_matrix_csr(ec3d_multi_handle m, int32_t n, const double *valA, const int32_t *irow,
@@ -983,14 +1047,21 @@ extern "C" int ec3d_multi_set_matrix_csr(ec3d_multi_handle m, int32_t n, const d
     m->kind = 0;
     SavHost G;
     if (ec3d_csr_to_sav_host(n, valA, irow, jcol, G) != 0) {
+        const int rc1 = multi_set_cube_csr(m, n, valA, irow, jcol); // a single-component 7-point operator?
+        if (rc1 >= 0) return rc1;
         ec3d_set_error("ec3d_multi_set_matrix_csr: the matrix is not recognised as the reference's A-V system on a "
-                       "grid (ec3d_probe_csr), so there are no z-planes to cut it along; use one GPU");
+                       "grid (ec3d_probe_csr) nor as a single-component 7-point operator on one, so there are no "
+                       "z-planes to cut it along; use one GPU");
         return 7;
     }
     const int64_t sdz = G.nCd / G.pitch;
     {
         std::string why;
         const int rc0 = ec3d_sav_cuttable(G, m->n, why);
+        if (rc0 == 7) { // e.g. a cube whose plane count is a multiple of 3, read as three blocks
+            const int rc1 = multi_set_cube_csr(m, n, valA, irow, jcol);
+            if (rc1 >= 0) return rc1;
+        }
         if (rc0) {
             ec3d_set_error("ec3d_multi_set_matrix_csr: " + why);
             return rc0;

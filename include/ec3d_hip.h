@@ -235,7 +235,9 @@ int ec3d_multi_assemble(ec3d_multi_handle mh, int32_t sdx, int32_t sdy, int32_t 
                         const int32_t *geoPHYS_C, const double *valPHYS, int32_t nsub_glob, const double *BND,
                         const double *delta, double dt);
 /* CSR triple of the whole system (src/EC3D.f90:36-38): must be recognisable as the reference's A-V system
- * on a grid (ec3d_probe_csr), which is then cut into slabs; status 7 otherwise (use one GPU) */
+ * on a grid (ec3d_probe_csr) or as a single-component 7-point operator on one (seven bands at -kdz, -sdx, -1, 0,
+ * 1, sdx, kdz and nothing else: src/EC3D.f90:528-654 without conducting cells), which is then cut into slabs;
+ * status 7 otherwise (use one GPU) */
 int ec3d_multi_set_matrix_csr(ec3d_multi_handle mh, int32_t n, const double *valA, const int32_t *irow,
                               const int32_t *jcol);
 /* host vectors in the reference's global numbering [Ax | Ay | Az | U], n unknowns (ec3d_multi_size) */
@@ -322,8 +324,8 @@ int ec3d_probe_csr(int32_t n, const double *valA, const int32_t *irow, const int
                    ec3d_csr_probe *out);
 
 /* Host-only as well: would ec3d_multi_set_matrix_csr / sprsbcgstabwr_ under EC3D_NGPU=nranks cut this matrix into
- * nranks z-slabs?  *cuttable = 0 leaves the reason in ec3d_last_error(): not the structured form, fewer than two
- * planes per rank, or couplings across the z faces of a component. */
+ * nranks z-slabs?  *cuttable = 0 leaves the reason in ec3d_last_error(): neither the structured A-V form nor a
+ * single-component 7-point operator, fewer than two planes per rank (A-V) or fewer planes than ranks. */
 int ec3d_probe_csr_multi(int32_t n, const double *valA, const int32_t *irow, const int32_t *jcol, int32_t nranks,
                          int32_t *cuttable);
 

@@ -84,8 +84,8 @@ def test_single_component_box_in_three_blocks(E):
 def test_which_matrices_can_be_cut_into_z_slabs(oracle):
     """ec3d_probe_csr_multi (host only): the decision the multi-GPU CSR route and the drop-in under EC3D_NGPU take.
     The reference's captured A-V matrix (14 planes) can be cut into up to 7 slabs of two planes; a single-component
-    cube that the recogniser reads as three "blocks" couples across their faces and cannot; a matrix without a grid
-    has nothing to cut along."""
+    cube (whether or not the A-V recogniser reads it as three "blocks" that couple across their faces) is cut plane
+    by plane as seven bands on a grid; a matrix without a grid has nothing to cut along."""
     import eddy_currents_3d_amd as E
     g = load_golden("g2_conducting_hole_16x15x14")
     for nranks, want in ((1, True), (2, True), (7, True), (8, False)):
@@ -94,10 +94,12 @@ def test_which_matrices_can_be_cut_into_z_slabs(oracle):
         if not want:
             assert "two z-planes" in why
     valA, irow, jcol = oracle.poisson_csr(16, 16, 24)
-    if E.probe_csr(valA, irow, jcol).structured:
-        assert E.probe_csr_multi(valA, irow, jcol, 1)[0]
-        ok, why = E.probe_csr_multi(valA, irow, jcol, 2)
-        assert not ok and "couples across" in why
+    for nranks, want in ((1, True), (2, True), (24, True), (25, False)):
+        ok, why = E.probe_csr_multi(valA, irow, jcol, nranks)
+        assert ok == want, (nranks, why)
+    assert "fewer z-planes" in E.probe_csr_multi(valA, irow, jcol, 25)[1]
+    valA, irow, jcol = oracle.poisson_csr(9, 7, 5)
+    assert E.probe_csr_multi(valA, irow, jcol, 5)[0]
     n = 64
     ok, why = E.probe_csr_multi(np.ones(n), np.arange(1, n + 2, dtype=np.int32), np.arange(1, n + 1, dtype=np.int32), 2)
     assert not ok and "not recognised" in why

@@ -155,7 +155,7 @@ def test_multi_spmv_of_the_cube_bitwise(E, oracle):
         assert np.array_equal(m.spmv(x), oracle.spmv_csr(valA, irow, jcol, x))
 
 
-def test_multi_csr_route_refuses_a_matrix_without_a_grid(E):
+def test_multi_csr_route_refuses_a_matrix_without_a_grid(E, oracle):
     n = 64
     irow = np.arange(1, n + 2, dtype=np.int32)
     with E.EC3DMulti(2, devices=[0, 0]) as m:
@@ -202,19 +202,42 @@ def test_multi_fields_reproduce_reference_file(E, world, plane_pitch):
             assert field_vtk_bytes(sdx, sdy, sdz, g["delta"], f) == g[f"vtk_field_{k}"].tobytes()
 
 
-def test_multi_csr_route_refuses_a_cube_read_as_three_blocks(E, oracle):
-    """A single-component cube whose plane count is a multiple of 3 passes the recogniser as "three blocks" (fine on
-    one GPU: the +-plane bands simply run across); cut into slabs block by block it would lose those couplings, so
-    the multi route must refuse it (status 7) and the drop-in then stays on one GPU."""
-    valA, irow, jcol = oracle.poisson_csr(16, 16, 24)
-    pr = E.probe_csr(valA, irow, jcol)
+@pytest.mark.parametrize("dims,world", [((16, 16, 24), 2), ((16, 16, 24), 3), ((20, 12, 10), 4), ((64, 64, 40), 2)])
+def test_multi_csr_route_cuts_a_single_component_cube(E, oracle, dims, world):
+    """BASELINE configs 2 and 4 as the drop-in symbol receives them: the CSR triple of the single-component 7-point
+    operator (src/EC3D.f90:528-654 with no conducting cell).  A plane count that is a multiple of 3 passes the A-V
+    recogniser as "three blocks" whose faces couple -- the multi route then, and whenever the A-V recogniser says
+    no, reads the matrix as seven bands on a grid and cuts it plane by plane: A*x bit-identical to the oracle's CSR
+    row sums, the solve bit-identical to the natively assembled slabs (same coefficients, same slabs)."""
+    sdx, sdy, sdz = dims
+    valA, irow, jcol = oracle.poisson_csr(sdx, sdy, sdz)
+    n = sdx * sdy * sdz
+    x = np.random.Generator(np.random.PCG64(77)).standard_normal(n)
+    b = np.random.Generator(np.random.PCG64(78)).standard_normal(n)
+    assert E.probe_csr_multi(valA, irow, jcol, world)[0]
+    with E.EC3DMulti(world, devices=[0] * world) as m:
+        m.set_matrix_csr(valA, irow, jcol)
+        assert m.n == n
+        y = m.spmv(x)
+        xs, its = m.solve(b, np.zeros(n), 1e-9, 2000)
+    assert np.array_equal(y, oracle.spmv_csr(valA, irow, jcol, x))
+    with E.EC3DMulti(world, devices=[0] * world) as m:
+        m.assemble_poisson(sdx, sdy, sdz)
+        xa, ita = m.solve(b, np.zeros(n), 1e-9, 2000)
+    assert its == ita and np.array_equal(xs, xa)
+    r = b - oracle.spmv_csr(valA, irow, jcol, xs)
+    assert np.linalg.norm(r) <= 1e-7 * np.linalg.norm(b)
+
+
+def test_multi_csr_route_refuses_a_matrix_without_a_grid(E, oracle):
+    n = 64
     with E.EC3DMulti(2, devices=[0, 0]) as m:
-        if pr.structured:
-            with pytest.raises(E.EC3DError, match="couples across"):
-                m.set_matrix_csr(valA, irow, jcol)
-        else:
-            with pytest.raises(E.EC3DError, match="not recognised"):
-                m.set_matrix_csr(valA, irow, jcol)
+        with pytest.raises(E.EC3DError, match="not recognised"):
+            m.set_matrix_csr(np.ones(n), np.arange(1, n + 2, dtype=np.int32), np.arange(1, n + 1, dtype=np.int32))
+    valA, irow, jcol = oracle.poisson_csr(8, 8, 3)
+    with E.EC3DMulti(4, devices=[0] * 4) as m:
+        with pytest.raises(E.EC3DError, match="fewer z-planes than ranks"):
+            m.set_matrix_csr(valA, irow, jcol)
 
 
 def test_multi_refuses_what_it_cannot_cut(E):
@@ -290,6 +313,42 @@ print("RESULT", out)
         for k, (it, rel) in enumerate(res[ngpu]):
             assert rel <= 10 * tol
             assert abs(it - int(g["iters"][k])) <= max(3, 0.15 * int(g["iters"][k]))
+
+
+def test_dropin_symbol_cuts_a_cube_csr_over_two_gpus(oracle, tmp_path):
+    """BASELINE config 2's matrix handed to sprsbcgstabwr_ (src/solvers.f90:3) as CSR with EC3D_NGPU=2: the library
+    cuts it plane by plane (stderr must not say the switch was ignored) and returns the one-GPU answer to the solver
+    tolerance."""
+    sdx, sdy, sdz = 24, 20, 18
+    valA, irow, jcol = oracle.poisson_csr(sdx, sdy, sdz)
+    n = sdx * sdy * sdz
+    b = np.random.Generator(np.random.PCG64(5)).standard_normal(n)
+    f = str(tmp_path / "cube.npz")
+    np.savez(f, valA=valA, irow=irow, jcol=jcol, b=b)
+    code = r"""
+import numpy as np, sys
+sys.path.insert(0, %r)
+import eddy_currents_3d_amd as E
+g = np.load(%r)
+x = np.zeros(len(g["b"]))
+it = E.sprsBCGstabWR(g["valA"], g["irow"], g["jcol"], len(g["irow"]) - 1, g["b"], x, 1e-10, 5000)
+np.save(sys.argv[1], x)
+print("RESULT", it)
+""" % (REPO, f)
+    xs = {}
+    for ngpu in (1, 2):
+        env = dict(os.environ, EC3D_NGPU=str(ngpu))
+        env.pop("EC3D_DEVICES", None)
+        if ngpu == 2:
+            env["EC3D_DEVICES"] = "0,0"
+        out = str(tmp_path / f"x{ngpu}.npy")
+        p = subprocess.run([sys.executable, "-c", code, out], env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stdout + p.stderr
+        assert "ignored" not in p.stderr, p.stderr
+        xs[ngpu] = np.load(out)
+    for x in xs.values():
+        assert np.linalg.norm(b - oracle.spmv_csr(valA, irow, jcol, x)) <= 1e-8 * np.linalg.norm(b)
+    assert np.linalg.norm(xs[2] - xs[1]) <= 1e-7 * np.linalg.norm(xs[1])
 
 
 def test_teardown_with_torch_objects_gone_first():
