@@ -592,8 +592,8 @@ int ec3d_assemble_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t sdz, int
     }
     EC3D_HIP(hipMalloc(&A.tail_id, (size_t)A.n_pad * 4));
     EC3D_HIP(hipMemsetAsync(A.tail_id, 0xFF, (size_t)A.n_pad * 4, c->stream));
-    EC3D_HIP(hipMalloc(&A.tile_flag, (size_t)(A.n_pad / EC3D_TILE)));
-    EC3D_HIP(hipMemsetAsync(A.tile_flag, 0, (size_t)(A.n_pad / EC3D_TILE), c->stream));
+    EC3D_HIP(hipMalloc(&A.tile_flag, (size_t)(A.n_pad / EC3D_TILE) + 4)); // + 4: read by dwords (sav_tile_coupled)
+    EC3D_HIP(hipMemsetAsync(A.tile_flag, 0, (size_t)(A.n_pad / EC3D_TILE) + 4, c->stream));
     EC3D_HIP(hipMalloc(&A.chunk_ptr, cp.size() * 8));
     EC3D_HIP(hipMemcpyAsync(A.chunk_ptr, cp.data(), cp.size() * 8, hipMemcpyHostToDevice, c->stream));
     EC3D_HIP(hipMalloc(&A.tcol, te * 4));
@@ -751,8 +751,8 @@ int ec3d_assemble_sav_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t sdz,
     EC3D_HIP(hipMalloc(&A.tval, 8));
     EC3D_HIP(hipMalloc(&A.cls, (size_t)A.n_pad));
     EC3D_HIP(hipMemsetAsync(A.cls, id.zero, (size_t)A.n_pad, c->stream));
-    EC3D_HIP(hipMalloc(&A.tile_flag, (size_t)(A.n_pad / EC3D_TILE)));
-    EC3D_HIP(hipMemsetAsync(A.tile_flag, 0, (size_t)(A.n_pad / EC3D_TILE), c->stream));
+    EC3D_HIP(hipMalloc(&A.tile_flag, (size_t)(A.n_pad / EC3D_TILE) + 4)); // + 4: read by dwords (sav_tile_coupled)
+    EC3D_HIP(hipMemsetAsync(A.tile_flag, 0, (size_t)(A.n_pad / EC3D_TILE) + 4, c->stream));
     EC3D_HIP(hipMalloc(&A.table, (size_t)id.ncls * 16 * sizeof(double)));
     A.bytes = A.n_pad + A.n_pad / EC3D_TILE + id.ncls * 128;
 

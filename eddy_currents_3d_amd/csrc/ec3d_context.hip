@@ -106,6 +106,8 @@ void ec3d_free_matrix(ec3d_ctx *c)
     if (c->vb_list) (void)hipFree(c->vb_list);
     if (c->vi_list) (void)hipFree(c->vi_list);
     c->vb_list = c->vi_list = nullptr;
+    if (c->us_list) (void)hipFree(c->us_list);
+    c->us_list = nullptr;
     c->can_vsplit = false;
     c->n_ref = 0;
     c->plane = c->pitch = c->nCd = 0;
@@ -294,6 +296,41 @@ static int choose_sweep(ec3d_ctx *c)
                 if (const char *e = getenv("EC3D_FUSE51")) fuse5 = atoi(e);
                 c->fuse51_ok = fuse5 == 2 || (fuse5 == 1 && big);
             }
+        }
+    }
+    // Structured form, U tiles of the z-marching SpMV kernels.  A U tile reads eleven tile-sized operands (its own three
+    // planes and +-sdx lines, A_x, three of A_y, three of A_z) and nothing is carried between U tiles; dealt round robin
+    // (entry b, b + nblk, ...) the neighbours of a tile run on other XCDs or at other times and every one of those
+    // operands comes from HBM (measured: the U tiles are 5.5 of the 16.9 B per row the SpMV kernels read on the 21 M
+    // system).  So the list is re-ordered for these kernels: the tiles, sorted by column, are cut into eight equal
+    // shares, one per XCD label; a share is taken plane by plane, consecutive tiles by consecutive workgroups of that
+    // XCD at the same time, so in-plane and plane-to-plane neighbours meet in that XCD's L2.  Holes (-1) end a
+    // workgroup's list.  The vector kernels keep the plain list (they read nothing twice).
+    if (c->us_list) (void)hipFree(c->us_list);
+    c->us_list = nullptr;
+    {
+        int local = 1;
+        if (const char *e = getenv("EC3D_ULIST_XCD")) local = atoi(e);
+        if (local && A.sav && ss.zm_tpp > 0 && ss.ulist_n > 0 && ss.nblk % 8 == 0 &&
+            (int)c->A.ulist_host.size() == ss.ulist_n && ss.ulist == c->A.ulist) {
+            const int64_t tpp = ss.zm_tpp, G = ss.nblk, Gx = G / 8, L = ss.ulist_n;
+            std::vector<int32_t> byc(c->A.ulist_host);
+            std::stable_sort(byc.begin(), byc.end(), [&](int32_t a, int32_t b) { return a % tpp < b % tpp; });
+            int64_t K = 0;
+            std::vector<std::vector<int32_t>> share(8);
+            for (int x = 0; x < 8; ++x) {
+                share[x].assign(byc.begin() + L * x / 8, byc.begin() + L * (x + 1) / 8);
+                std::sort(share[x].begin(), share[x].end()); // tile id ascending = plane by plane, column by column
+                K = std::max<int64_t>(K, ((int64_t)share[x].size() + Gx - 1) / Gx);
+            }
+            std::vector<int32_t> perm((size_t)(K * G), -1);
+            for (int x = 0; x < 8; ++x)
+                for (size_t i = 0; i < share[x].size(); ++i)
+                    perm[(size_t)(((int64_t)i / Gx) * G + ((int64_t)i % Gx) * 8 + x)] = share[x][i];
+            EC3D_HIP(hipMalloc(&c->us_list, perm.size() * 4));
+            EC3D_HIP(hipMemcpy(c->us_list, perm.data(), perm.size() * 4, hipMemcpyHostToDevice));
+            ss.ulist = c->us_list;
+            ss.ulist_n = (int)perm.size();
         }
     }
     // z-slab of the single-component operator on a z-marching grid: K1/K3 can be split into an interior
@@ -524,7 +561,7 @@ int ec3d_upload_sav(ec3d_ctx *c, const SavHost &S)
     EC3D_HIP(hipMalloc(&A.tcol, 8));
     EC3D_HIP(hipMalloc(&A.tval, 8));
     EC3D_HIP(hipMalloc(&A.cls, S.cls.size()));
-    EC3D_HIP(hipMalloc(&A.tile_flag, S.tile_flag.size()));
+    EC3D_HIP(hipMalloc(&A.tile_flag, S.tile_flag.size() + 4)); // + 4: read by dwords (sav_tile_coupled)
     EC3D_HIP(hipMalloc(&A.table, S.table.size() * 8));
     EC3D_HIP(hipMalloc(&A.ulist, std::max<size_t>(S.ulist.size(), 1) * 4));
     EC3D_HIP(hipMemcpy(A.cls, S.cls.data(), S.cls.size(), hipMemcpyHostToDevice));
@@ -775,7 +812,7 @@ extern "C" int ec3d_get_reduction_geometry(ec3d_handle c, int which, ec3d_geom *
     g->zm_tpp = sw.zm_tpp;
     g->zm_pps = sw.zm_pps;
     g->ntiles_front = (int32_t)sw.ntiles;
-    g->ulist_n = sw.ulist_n;
+    g->ulist_n = (c->us_list && sw.ulist == c->us_list) ? c->A.ulist_n : sw.ulist_n; // tiles, not list slots
     g->patch_x = sw.patch_npx > 0 ? EC3D_PX : 0;
     g->patch_y = sw.patch_npx > 0 ? EC3D_PY : 0;
     g->patch_sdx = sw.patch_npx > 0 ? (int32_t)sw.patch_sdx : 0;
@@ -802,7 +839,8 @@ static void visit_of(const ec3d_ctx *c, const Sweep &sw, std::vector<std::vector
             if (tile < 0) break;
             v.push_back((int32_t)tile);
         }
-        for (int64_t l = b; l < sw.ulist_n; l += sw.nblk) v.push_back(ul[(size_t)l]);
+        // a hole (-1) of the XCD-local list ends the workgroup's share
+        for (int64_t l = b; l < sw.ulist_n && ul[(size_t)l] >= 0; l += sw.nblk) v.push_back(ul[(size_t)l]);
         out.push_back(std::move(v));
     }
 }

@@ -250,6 +250,7 @@ struct ec3d_ctx {
     // K2/K5 as boundary + interior launches (ec3d_dist_set_boundary_rows): tile lists on the device
     Sweep sweep_vb{}, sweep_vi{};
     int32_t *vb_list = nullptr, *vi_list = nullptr;
+    int32_t *us_list = nullptr; // structured form: the U tiles in the order the z-marching SpMV kernels take them (choose_sweep)
     bool can_vsplit = false;
     int nown = 0;    // ownership ranges of an A-V slab (see Sweep)
     int64_t own_lo[4] = {0}, own_hi[4] = {0};

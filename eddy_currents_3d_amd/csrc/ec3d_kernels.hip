@@ -345,6 +345,7 @@ __device__ __forceinline__ void walk_zm(const SweepZ &sw, BODY &&body)
                 if (lst < 0) lst = blockIdx.x;
                 if (lst >= sw.ulist_n) break;
                 tile = sw.ulist[lst];
+                if (tile < 0) break; // a hole of the XCD-local list (choose_sweep) ends this workgroup's share
                 lst += gridDim.x;
                 first = true;
             }
@@ -528,7 +529,14 @@ __device__ __forceinline__ d2 stage_read(const double *stg, int k)
     return *reinterpret_cast<const d2 *>(stg + k * EC3D_TILE + 2 * threadIdx.x);
 }
 // every vector-memory operation of this wave has landed (LDS-DMA included: it counts in vmcnt)
-#define EC3D_VM_DRAIN asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+// (the instruction through the builtin, so that the compiler's own wait-count bookkeeping sees it -- behind an inline
+// asm it kept every load of the step for outstanding and put a vmcnt(0) of its own in front of the next step's first
+// write to one of their registers; the empty asm keeps LDS reads from moving above)
+#define EC3D_VM_DRAIN                                                                                                  \
+    do {                                                                                                               \
+        __builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0), expcnt and lgkmcnt left alone (gfx9 encoding) */              \
+        asm volatile("" ::: "memory");                                                                                 \
+    } while (0)
 
 // Structured A-V form on a grid with tile-aligned planes (every grid worth timing): rows r, r+1 of A*x in a
 // tile that lies entirely in one block.  The operands of the coupling slots are requested TOGETHER with the band
@@ -555,10 +563,12 @@ __device__ __forceinline__ void sav_band_loads(const MatDev<FMT_SAV> &A, const V
                                                SavBand &o)
 {
     const int lane = threadIdx.x & 63;
-    o.left = 0.0;
-    o.right = 0.0;
-    if (lane == 0) o.left = x.at(r - 1);
-    if (lane == 63) o.right = x.at(r + 2);
+    // the wave's two outer neighbours in ONE predicated load: two separate ifs compiled to an if/else whose else
+    // branch (every wave has lanes 1..62) began with s_waitcnt vmcnt(0) -- a memory round trip before the band loads
+    double edge = 0.0;
+    if (lane == 0 || lane == 63) edge = x.at(lane == 0 ? r - 1 : r + 2);
+    o.left = edge;
+    o.right = edge;
     o.ym = x.pair(r - A.sdx);
     o.yp = x.pair(r + A.sdx);
     o.zp = x.pair(r + A.pitch);
@@ -596,33 +606,64 @@ __device__ __forceinline__ void sav_band_sum(const double *t0, const double *t1,
     s1 = s1 + t1[6] * o.zp.y;
 }
 
+// tile_flag[tile] through the scalar unit: the dword that holds the byte (gfx9 has no scalar byte load; the array is
+// allocated with 4 bytes to spare)
+__device__ __forceinline__ bool sav_tile_coupled(const MatDev<FMT_SAV> &A, int64_t tile)
+{
+    const int t = __builtin_amdgcn_readfirstlane((int)tile);
+    // constant address space: the flags are written by no kernel of this library's solve, and only a load the
+    // compiler knows to be unclobbered goes through the scalar unit (s_load_dword, its own counter: no vmcnt wait)
+    typedef const __attribute__((address_space(4))) unsigned *cptr;
+    const unsigned w = ((cptr)(uintptr_t)A.tile_flag)[t >> 2];
+    return ((w >> ((t & 3) * 8)) & 0xFFu) != 0;
+}
 template <class V>
 __device__ __forceinline__ void sav_pair_zm(const MatDev<FMT_SAV> &A, const double *tbl, double *stg, const V &x,
                                             int64_t r, int64_t tile, bool first, ZRegs &z, double &s0, double &s1,
                                             d2 &ctr)
 {
     const int lane = threadIdx.x & 63;
-    const bool urow = r >= 3 * A.nC; // uniform: blocks are whole numbers of tiles here
+    // which block the tile lies in, decided on the scalar unit from the tile number (blocks are whole numbers of tiles
+    // here): taken from the lanes' rows the tests are vector compares, the branches below run under exec masks and
+    // the compiler protects registers both sides write with waits for every load in flight
+    const int64_t trow = (int64_t)__builtin_amdgcn_readfirstlane((int)tile) * EC3D_TILE;
+    const bool urow = trow >= 3 * A.nC;
     const unsigned short cc = *reinterpret_cast<const unsigned short *>(A.cls + r);
-    const bool cpl = A.tile_flag[tile] != 0; // uniform
+    // coupled? (uniform)  A U tile that is visited holds an unknown, so it is; an A tile's flag comes through the
+    // scalar unit (read as a byte it was a vector load, and a wait on vmcnt, in front of the step's loads)
+    const bool cpl = urow ? true : sav_tile_coupled(A, tile);
     SavBand bo;
     s0 = 0.0;
     s1 = 0.0;
-    if (cpl && urow) {
-        // ---- a tile of the U block ----
+    // EVERY load of the step is requested before the first value is looked at (the class bytes included: with the
+    // two tile kinds requesting their operands in branches of their own, the compiler hoisted the classes' first use
+    // above the branch and the step began with a wait for them)
+    const int d = (trow >= A.nC) + (trow >= 2 * A.nC); // component of an A tile
+    d2 xa;      // U tile only (left unset elsewhere: a value to set is a register to protect with a wait)
+    double xae;
+    if (urow) {
+        xae = 0.0;
         const double *ay = x.x + r - 2 * A.nC, *az = x.x + r - A.nC;
         stage_issue(ay - A.sdx, stg, 0);
         stage_issue(ay + A.sdx, stg, 1);
         stage_issue(az - A.pitch, stg, 2);
         stage_issue(az + A.pitch, stg, 3);
         const int64_t rx = r - 3 * A.nC;
-        d2 xa = x.pair(rx);
-        double xal = 0.0, xar = 0.0;
-        if (lane == 0) xal = x.at(rx - 1);
-        if (lane == 63) xar = x.at(rx + 2);
-        sav_band_loads(A, x, r, first, z, bo);
-        ctr = bo.c;
-        const double *t0 = tbl + (cc & 0xFF) * EC3D_SAV_STRIDE, *t1 = tbl + (cc >> 8) * EC3D_SAV_STRIDE;
+        xa = x.pair(rx);
+        if (lane == 0 || lane == 63) xae = x.at(lane == 0 ? rx - 1 : rx + 2); // one predicated load (see sav_band_loads)
+    } else if (cpl) {
+        const double *u = x.x + r + (3 - d) * A.nC;
+        const int64_t st = d == 0 ? 2 : A.step(d);
+        stage_issue(u - st, stg, 0);
+        stage_issue(u, stg, 1);
+        stage_issue(u + st, stg, 2);
+    }
+    sav_band_loads(A, x, r, first, z, bo);
+    ctr = bo.c;
+    const double *t0 = tbl + (cc & 0xFF) * EC3D_SAV_STRIDE, *t1 = tbl + (cc >> 8) * EC3D_SAV_STRIDE;
+    if (urow) {
+        // ---- a tile of the U block ----
+        double xal = xae, xar = xae;
         EC3D_VM_DRAIN;
         {   // A_x(cell - 1), A_x(cell), A_x(cell + 1)
             const double l = __shfl_up(xa.y, 1, 64), rr = __shfl_down(xa.x, 1, 64);
@@ -659,17 +700,6 @@ __device__ __forceinline__ void sav_pair_zm(const MatDev<FMT_SAV> &A, const doub
         return;
     }
     // ---- a tile of an A block ----
-    const int d = (r >= A.nC) + (r >= 2 * A.nC);
-    if (cpl) {
-        const double *u = x.x + r + (3 - d) * A.nC;
-        const int64_t st = d == 0 ? 2 : A.step(d);
-        stage_issue(u - st, stg, 0);
-        stage_issue(u, stg, 1);
-        stage_issue(u + st, stg, 2);
-    }
-    sav_band_loads(A, x, r, first, z, bo);
-    ctr = bo.c;
-    const double *t0 = tbl + (cc & 0xFF) * EC3D_SAV_STRIDE, *t1 = tbl + (cc >> 8) * EC3D_SAV_STRIDE;
     sav_band_sum(t0, t1, bo, s0, s1);
     if (cpl) {
         EC3D_PIN(s0, s1); // the band operands are dead from here
