@@ -376,6 +376,7 @@ int ec3d_prepare_vectors(ec3d_ctx *c)
     int64_t maxoff = 0;
     for (int b = 0; b < c->A.nb; ++b) maxoff = std::max<int64_t>(maxoff, std::llabs(c->A.off[b]));
     if (c->A.sav) maxoff *= 2; // the one-sided A-U slots reach two planes
+    else if (c->A.nb == 7) maxoff += std::llabs(c->A.off[5]); // 2-D tiles ask for the row beside the plane above (patch_pair)
     int64_t galign = 64;
     if (const char *e = getenv("EC3D_GHOST_ALIGN")) galign = std::max<int64_t>(2, atoll(e));
     c->ghost = round_up(maxoff + 2, galign);

@@ -509,6 +509,7 @@ __device__ __forceinline__ void sav_a_post(const MatDev<FMT_SAV> &A, const doubl
 // x values of the planes below / at the current row, carried across the steps of a z-march
 struct ZRegs {
     d2 xm, xc;
+    d2 rim; // 2-D tiles: the outer neighbour row of the NEXT step's centre plane (first / last patch row only)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -764,9 +765,20 @@ __device__ __forceinline__ void patch_pair(const MatDev<FMT> &A, const double *t
     double left = 0.0, right = 0.0;
     if (q == 0) left = x.at(r - 1);
     if (q == HX - 1) right = x.at(r + 2);
-    d2 ym = d2{0.0, 0.0}, yp = d2{0.0, 0.0};
-    if (y == 0) ym = x.pair(r - sdx);
-    if (y == EC3D_PY - 1) yp = x.pair(r + sdx);
+    // The patch's first and last row take their outer neighbour from memory -- one plane AHEAD: the row asked for now
+    // is the one beside the plane above, i.e. the lines the neighbouring patch is asking for at this very step as ITS
+    // plane above, so the two requests meet in the L2.  Asked for a step later (beside the centre plane, as the stencil
+    // reads it) the lines had to survive a whole step of every workgroup of the XCD: with the three operand vectors of
+    // K5-in-K1 they did not (PMC 56.3 B/row against 49; 52.3 now).  The vectors' ghost zones cover the row beside the plane
+    // above the last one (ec3d_prepare_vectors); it is never used.
+    const bool rimrow = y == 0 || y == EC3D_PY - 1;
+    const int64_t roff = y == 0 ? -sdx : sdx;
+    d2 rimc = d2{0.0, 0.0};
+    if (rimrow) {
+        rimc = first ? x.pair(r + roff) : z.rim;
+        z.rim = x.pair(r + kdz + roff);
+    }
+    d2 ym = rimc, yp = rimc;
     d2 zm, cx;
     if (first) { // nothing carried over: plane below and centre from memory, centre into this step's buffer
         zm = x.pair(r - kdz);

@@ -1,8 +1,13 @@
 #!/bin/bash
-tag=${1:-ab}; out=gpurun_out/$tag; mkdir -p $out
-timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_config4.py -m gpu -q -x > $out/pytest.log 2>&1 || { tail -n 60 $out/pytest.log; echo "tests failed: no timing"; exit 1; }
-tail -n 2 $out/pytest.log
-timeout -k 10 300 python tools/vec_sweep.py cube512 ";FUSE51=0,FUSE23=0;NBLK_SPMV=512;NBLK_SPMV=1536;FUSE51=0,FUSE23=0,NBLK_SPMV=1536;" > $out/ahead_512.log 2>> $out/err.log
-cat $out/ahead_512.log
-timeout -k 10 300 python tools/vec_sweep.py cube256 ";NBLK_SPMV=768;NBLK_SPMV=1024;NBLK_SPMV=1280" > $out/ahead_256.log 2>> $out/err.log
-cat $out/ahead_256.log
+# scratch A/B (one gpurun call): 2-D tiles, rim rows one plane ahead
+set -e
+python -m pytest tests/test_gpu_parity.py tests/test_gpu_formats_dist.py tests/test_gpu_multi.py -x -q > gpurun_out/ab_pytest.log 2>&1 || { tail -20 gpurun_out/ab_pytest.log; exit 1; }
+tail -2 gpurun_out/ab_pytest.log
+for rep in 1 2; do
+  EC3D_LIB=tools/ab/libec3d_hip_rim0.so python3 tools/ab_perf.py cube512 rim_now
+  python3 tools/ab_perf.py cube512 rim_ahead
+done
+EC3D_LIB=tools/ab/libec3d_hip_rim0.so EC3D_FUSE23=0 EC3D_FUSE51=0 python3 tools/ab_perf.py cube512 rim_now_5launch
+EC3D_FUSE23=0 EC3D_FUSE51=0 python3 tools/ab_perf.py cube512 rim_ahead_5launch
+EC3D_LIB=tools/ab/libec3d_hip_rim0.so python3 tools/ab_perf.py cube256 rim_now
+python3 tools/ab_perf.py cube256 rim_ahead
