@@ -378,8 +378,10 @@ def main():
             spmv_dia = {"kernel": "k_spmv, plain DIA (7 fp64 coefficient streams + x + y)", "ms": ms_d,
                         "bytes_per_row": 72, "GBps": 72 * n_global / ms_d / 1e6,
                         "frac": 72 * n_global / ms_d / 1e6 / PEAK_HBM_GBS, "workgroups": int(sd.geometry(1).nblk),
-                        "note": "20 launches back to back after the timed region; run-to-run the same binary gives "
-                                "either ~1.8 or ~2.0 ms at 512^3 (profiles/r03_dia_bimodal_*.log)"}
+                        "note": "20 launches back to back after the timed region; the time depends on where the driver "
+                                "put the 7.5 GB of band streams (1.68 ... 2.0 ms at 512^3 from one allocation to the "
+                                "next), so the library looks at up to 8 placements at set-up and keeps the fastest "
+                                "(DESIGN.md section 4, profiles/r03_dia_placement.log)"}
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / K
