@@ -58,6 +58,26 @@ def test_undivided_rows_equal_the_oracle_csr_row_sums(oracle, xvec, undivided):
     print(f"512^3: {checked} rows on {len(cuts)} planes bit-identical to the oracle's CSR row sums")
 
 
+def test_plain_band_streams_equal_the_dictionary_form(E, xvec, undivided, capfd):
+    """The north-star SpMV figure's storage (seven fp64 coefficient streams, 7.5 GB at this size) multiplies the same
+    doubles in the same order as the class-coded form, wherever the library's set-up probe (place_bands: up to 8
+    placements of the streams timed, the fastest kept) ends up putting them."""
+    import os
+    y, _ = undivided
+    os.environ["EC3D_PLACE_VERBOSE"] = "1"
+    try:
+        with E.EC3DSolver(dictionary=False) as s:
+            s.assemble_poisson(N, N, N)
+            yd = s.spmv(xvec)
+    finally:
+        del os.environ["EC3D_PLACE_VERBOSE"]
+    err = capfd.readouterr().err
+    tried = [l for l in err.splitlines() if "band placement" in l]
+    print("\n".join(tried))
+    assert 1 <= len(tried) <= 8
+    assert np.array_equal(yd, y)
+
+
 def test_eight_slabs_on_one_card_spmv_equals_undivided(E, xvec, undivided):
     y, _ = undivided
     with E.EC3DMulti(WORLD, devices=[0] * WORLD) as m:

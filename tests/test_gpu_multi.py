@@ -202,8 +202,9 @@ def test_multi_fields_reproduce_reference_file(E, world, plane_pitch):
             assert field_vtk_bytes(sdx, sdy, sdz, g["delta"], f) == g[f"vtk_field_{k}"].tobytes()
 
 
+@pytest.mark.parametrize("dictionary", [True, False])
 @pytest.mark.parametrize("dims,world", [((16, 16, 24), 2), ((16, 16, 24), 3), ((20, 12, 10), 4), ((64, 64, 40), 2)])
-def test_multi_csr_route_cuts_a_single_component_cube(E, oracle, dims, world):
+def test_multi_csr_route_cuts_a_single_component_cube(E, oracle, dims, world, dictionary):
     """BASELINE configs 2 and 4 as the drop-in symbol receives them: the CSR triple of the single-component 7-point
     operator (src/EC3D.f90:528-654 with no conducting cell).  A plane count that is a multiple of 3 passes the A-V
     recogniser as "three blocks" whose faces couple -- the multi route then, and whenever the A-V recogniser says
@@ -215,13 +216,13 @@ def test_multi_csr_route_cuts_a_single_component_cube(E, oracle, dims, world):
     x = np.random.Generator(np.random.PCG64(77)).standard_normal(n)
     b = np.random.Generator(np.random.PCG64(78)).standard_normal(n)
     assert E.probe_csr_multi(valA, irow, jcol, world)[0]
-    with E.EC3DMulti(world, devices=[0] * world) as m:
+    with E.EC3DMulti(world, devices=[0] * world, dictionary=dictionary) as m:
         m.set_matrix_csr(valA, irow, jcol)
         assert m.n == n
         y = m.spmv(x)
         xs, its = m.solve(b, np.zeros(n), 1e-9, 2000)
     assert np.array_equal(y, oracle.spmv_csr(valA, irow, jcol, x))
-    with E.EC3DMulti(world, devices=[0] * world) as m:
+    with E.EC3DMulti(world, devices=[0] * world, dictionary=dictionary) as m:
         m.assemble_poisson(sdx, sdy, sdz)
         xa, ita = m.solve(b, np.zeros(n), 1e-9, 2000)
     assert its == ita and np.array_equal(xs, xa)
