@@ -204,10 +204,11 @@ def test_whole_run_with_true_residual_every_step(case, tmp_path):
           f"largest true residual {worst[0]:.3e} (tol {tol:g})")
 
 
-def test_config3_on_two_slabs_inside_the_library(tmp_path):
-    """The same run driven through the multi-GPU handle (2 slabs, here both on this GPU): the slabs reproduce the
-    undivided run's right-hand sides to the solver tolerance and every solution's true residual is below tol."""
-    case = "ec_src_move_hole"
+@pytest.mark.parametrize("case,world", [("ec_src_move_hole", 2), ("LIM", 8)])
+def test_full_size_on_slabs_inside_the_library(case, world, tmp_path):
+    """The same run driven through the multi-GPU handle -- config 3 on 2 slabs, config 5 (LIM at 384x192x128, the case
+    BASELINE names for 8 GPUs) on 8 slabs of 16 planes, here all on this GPU: the slabs reproduce the undivided run's
+    right-hand sides to the solver tolerance and every solution's true residual is below tol."""
     if not _have(case):
         pytest.skip("fixture not generated")
     import eddy_currents_3d_amd as E
@@ -223,12 +224,12 @@ def test_config3_on_two_slabs_inside_the_library(tmp_path):
         info["true_residual"] = s.true_residual()[0]
         res.append(info)
 
-    with E.EC3DMulti(2, devices=[0, 0]) as m:
+    with E.EC3DMulti(world, devices=[0] * world) as m:
         log = host.run(model, m, steps=3, out_dir=str(tmp_path), on_rhs=on_rhs, on_solved=on_solved)
         assert m.n == int(g["n"])
     assert len(log) == 3
     for k, info in enumerate(res):
-        print(f"config 3 on 2 slabs, step {k}: iter {info['iter']} / reference {int(g['iters'][k])}; ||b|| {info['bnorm']:.9e} / "
+        print(f"{case} on {world} slabs, step {k}: iter {info['iter']} / reference {int(g['iters'][k])}; ||b|| {info['bnorm']:.9e} / "
               f"{float(g['bnorm'][k]):.9e}; true residual {info['true_residual']:.3e}")
         assert info["true_residual"] < tol
         assert info["bnorm"] == pytest.approx(float(g["bnorm"][k]), rel=1e-13 if k == 0 else 10 * tol)
