@@ -1,13 +1,9 @@
 #!/bin/bash
 set -e
-python -m pytest tests/test_gpu_parity.py tests/test_gpu_formats_dist.py -x -q > gpurun_out/ab_pytest.log 2>&1 || { tail -20 gpurun_out/ab_pytest.log; exit 1; }
+python -m pytest tests/test_gpu_parity.py tests/test_gpu_edge_cases.py -x -q > gpurun_out/ab_pytest.log 2>&1 || { tail -20 gpurun_out/ab_pytest.log; exit 1; }
 tail -2 gpurun_out/ab_pytest.log
 for rep in 1 2; do
-  EC3D_LIB=tools/ab/libec3d_hip_r0late.so python3 tools/ab_perf.py cube512 before
-  python3 tools/ab_perf.py cube512 raw_then_form
+  EC3D_KEEP_S=1 python3 tools/ab_perf.py cube512 S_stored
+  python3 tools/ab_perf.py cube512 S_formed_again
 done
-EC3D_LIB=tools/ab/libec3d_hip_r0late.so EC3D_FUSE23=0 EC3D_FUSE51=0 python3 tools/ab_perf.py cube512 before_5launch
-EC3D_FUSE23=0 EC3D_FUSE51=0 python3 tools/ab_perf.py cube512 raw_5launch
-EC3D_LIB=tools/ab/libec3d_hip_r0late.so python3 tools/ab_perf.py cube256 before
-python3 tools/ab_perf.py cube256 raw_then_form
-EC3D_FUSE23=2 EC3D_FUSE51=2 python3 tools/ab_perf.py cube256 raw_fused
+for cfg in "256 0 2" "256 0 4" "512 0 2" "256 0 1" "768 0 2" "256 1 2"; do set -- $cfg; EC3D_NBLK_K4=$1 EC3D_MAP_K4=$2 EC3D_DEPTH_K4=$3 python3 tools/ab_perf.py cube512 "k4 nblk=$1 map=$2 depth=$3"; done
