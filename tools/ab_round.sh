@@ -1,9 +1,18 @@
 #!/bin/bash
 set -e
-python -m pytest tests/test_gpu_parity.py tests/test_gpu_edge_cases.py -x -q > gpurun_out/ab_pytest.log 2>&1 || { tail -20 gpurun_out/ab_pytest.log; exit 1; }
-tail -2 gpurun_out/ab_pytest.log
-for rep in 1 2; do
-  EC3D_KEEP_S=1 python3 tools/ab_perf.py cube512 S_stored
-  python3 tools/ab_perf.py cube512 S_formed_again
-done
-for cfg in "256 0 2" "256 0 4" "512 0 2" "256 0 1" "768 0 2" "256 1 2"; do set -- $cfg; EC3D_NBLK_K4=$1 EC3D_MAP_K4=$2 EC3D_DEPTH_K4=$3 python3 tools/ab_perf.py cube512 "k4 nblk=$1 map=$2 depth=$3"; done
+python3 tools/air_box.py 64 64 8 tiny
+python3 tools/air_box.py 128 128 16 small
+python3 tools/air_box.py 256 256 32 mid
+python3 tools/air_box.py 306 306 72 full
+python3 - <<'PY'
+import sys, numpy as np
+sys.path.insert(0, '.')
+import eddy_currents_3d_amd as E
+for N in (64, 128, 256):
+    with E.EC3DSolver() as s:
+        s.assemble_poisson(N, N, N)
+        s.upload("B", np.ones(N**3)); s.upload("X", np.zeros(N**3))
+        s.iterate_begin(); s.iterate(1, 5); s.synchronize()
+        ms = s.iterate(6, 40, per_kernel=True)
+        print(f"cube {N}: " + " ".join(f"{k}={1e3*v:7.1f}" for k, v in ms.items()), f"wg={s.geometry(0).nblk}/{s.geometry(1).nblk}", flush=True)
+PY
