@@ -1512,13 +1512,13 @@ static inline size_t tbl_bytes(const MatView &A, int F, bool zm, bool patch)
 #define EC3D_LAUNCH_ZT(F, NT_, KERNEL, ...)                                                                         \
     do {                                                                                                            \
         const bool tail_ = F != FMT_SAV && A.has_tail;                                                              \
-        const bool patch_ = zm_ && !tail_ && sw.patch_npx > 0 && (F == FMT_DIA7 || F == FMT_DICT7);                 \
+        const bool patch_ = zm_ && !tail_ && sw.patch_npx > 0 && F == FMT_DICT7; /* choose_sweep: dictionary only */ \
         const size_t lds_ = tbl_bytes(A, F, zm_, patch_);                                                           \
         const MatDev<F> Ad = mat_dev<F>(A);                                                                         \
         if constexpr (F != FMT_GENERIC) {                                                                           \
             if (zm_) {                                                                                              \
                 const SweepZ swz = sweep_z(sw);                                                                     \
-                if (patch_) { if constexpr (F == FMT_DIA7 || F == FMT_DICT7) KERNEL<F, NT_, true, false, true><<<sw.nblk, EC3D_THREADS, lds_, s>>>(Ad, swz, __VA_ARGS__); } \
+                if (patch_) { if constexpr (F == FMT_DICT7) KERNEL<F, NT_, true, false, true><<<sw.nblk, EC3D_THREADS, lds_, s>>>(Ad, swz, __VA_ARGS__); } \
                 else if (tail_) { if constexpr (F != FMT_SAV) KERNEL<F, NT_, true, true, false><<<sw.nblk, EC3D_THREADS, lds_, s>>>(Ad, swz, __VA_ARGS__); } \
                 else KERNEL<F, NT_, true, false, false><<<sw.nblk, EC3D_THREADS, lds_, s>>>(Ad, swz, __VA_ARGS__);   \
                 break;                                                                                              \
