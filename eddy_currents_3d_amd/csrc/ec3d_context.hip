@@ -184,7 +184,19 @@ static int choose_sweep(ec3d_ctx *c)
     {
         int ntreq = c->nt_request;
         if (const char *e = getenv("EC3D_NT")) ntreq = atoi(e); // read here too: sweeps of launch knobs in one process
-        sw.nt = ntreq >= 0 ? ntreq : (c->A.n_pad >= (4 << 20));
+        sw.nt = (ntreq >= 0 ? ntreq : (c->A.n_pad >= (4 << 20))) & 1;
+        // Between the sizes where everything lives in a cache (< 4 Mi rows: no nontemporal streams at all) and those
+        // where nothing does (>= 32 Mi rows), a vector or two fit the 256 MiB Infinity Cache: the output of a kernel
+        // that the NEXT kernel reads first is stored cacheable although the launch's other streams are nontemporal
+        // (bits above bit 0 of Sweep::nt, EC3D_KEEP_* in ec3d_kernels.hip).  tools/keep_sweep.py, cubes of 32 ... 240 MiB
+        // per vector, iteration time against all-nontemporal: AP (K1 -> K2) and R (K4 -> K5) -1.7 ... -4.1 % at every
+        // size; S (K2 -> K3) on top of them -2.4 ... -5.0 % up to 128 MiB per vector, a loss above 200; P (K5 -> K1)
+        // and AS (K3 -> K4) gain nothing or push out what K4 finds there today.  21 M-unknown A-V system: -2.8 %.
+        // At 512^3 any of them costs 2-4 %.  EC3D_KEEP=<bits> overrides (1 AP, 2 S, 8 R, 32 P).
+        int keep = 0;
+        if (c->A.n_pad < ((int64_t)1 << 25)) keep = 1 | 8 | (c->A.n_pad * 8 <= ((int64_t)136 << 20) ? 2 : 0);
+        if (const char *e = getenv("EC3D_KEEP")) keep = atoi(e);
+        if (sw.nt) sw.nt |= keep << 1;
     }
     // Vector kernels (K2, K4, K5): each on a grid, a tile map and a batching depth of its own.
     //   nblk  workgroups (whole multiples of the 256 CUs matter: 384 is far worse than 256 or 512)

@@ -157,6 +157,7 @@ struct SweepZ {
     int patch_npx;                    // 2-D tiles (Sweep::patch_npx); zm_tpp doubles as tpp for ec3d_row_of
     int64_t patch_sdx;
     int zm_tpp;
+    int keep; // producers whose output stays cacheable (EC3D_KEEP_*)
 };
 // the launch of a vector kernel (K2, K4, K5) as it sees it: logical tiles t0, t0 + stride, ... of the front sweep
 // (the XCD-aware map of ec3d_tile_of: t0 = (b % 8) * S + b / 8, stride = 8 S; or t0 = b, stride = nblk), then its
@@ -170,7 +171,12 @@ struct SweepV {
     int64_t win_nt, win_blk, win_t0;
     int nown;
     int64_t own_lo[4], own_hi[4];
+    int keep; // producers whose output stays cacheable (EC3D_KEEP_*)
 };
+// the policy bits travel in Sweep::nt above bit 0 (bit 0: nontemporal streams)
+__device__ __forceinline__ int keep_of(const Sweep &sw) { return sw.nt >> 1; }
+__device__ __forceinline__ int keep_of(const SweepZ &sw) { return sw.keep; }
+__device__ __forceinline__ int keep_of(const SweepV &sw) { return sw.keep; }
 template <bool ZM> struct SweepSel { typedef Sweep type; };
 template <> struct SweepSel<true> { typedef SweepZ type; };
 
@@ -187,6 +193,18 @@ __device__ __forceinline__ void store2(double *__restrict__ v, int64_t r, int64_
     } else if (r < n) {
         v[r] = a;
     }
+}
+// A producer's output at sizes where the NEXT kernel can find it in the 256 MiB Infinity Cache: `keep` (uniform, from
+// the launch's policy bits, see choose_sweep) stores it cacheable although the launch's streams are nontemporal.
+#define EC3D_KEEP_AP 1  /* K1's AP  -> K2 */
+#define EC3D_KEEP_S 2   /* K2's S   -> K3 */
+#define EC3D_KEEP_R 8   /* K4's R   -> K5, K1's dot */
+#define EC3D_KEEP_P 32  /* K5's P   -> K1 */
+template <bool NT>
+__device__ __forceinline__ void store2k(double *__restrict__ v, int64_t r, int64_t n, double a, double b, bool keep)
+{
+    if (NT && keep) store2<false>(v, r, n, a, b);
+    else store2<NT>(v, r, n, a, b);
 }
 // rows that take part in the dot products: all rows < n, or -- for one z-slab of the A-V system held
 // on an extended grid whose planes are not tile aligned -- the owned index ranges only.  (Tile-aligned slabs
@@ -1117,7 +1135,7 @@ EC3D_SPMV_T __global__ __launch_bounds__(EC3D_THREADS) EC3D_SPMV_OCC void k1_spm
         if constexpr (FMT == FMT_SAV) q = load2<NT>(r0 + r);
         spmv_pair<FMT, ZM, TAIL, NT, PATCH>(A, tbl, stg, pstep, VecPlain{p}, r, tile, (bool)fc, zr, s0, s1, ctr);
         if constexpr (FMT != FMT_SAV) q = load2<NT>(r0 + r);
-        store2<NT>(ap, r, sw.n, s0, s1);
+        store2k<NT>(ap, r, sw.n, s0, s1, keep_of(sw) & EC3D_KEEP_AP);
         EC3D_MASK2(r, sw, s0, s1);
         acc[0] = acc[0] + s0 * q.x;
         acc[0] = acc[0] + s1 * q.y;
@@ -1149,7 +1167,7 @@ __global__ __launch_bounds__(EC3D_THREADS) void k2_s_update(SweepV sw, RedSrc sr
         EC3D_ROW;
         const d2 a = o.a, q = o.q;
         double s0 = q.x - alpha * a.x, s1 = q.y - alpha * a.y;
-        store2<NT>(sv, r, sw.n, s0, s1);
+        store2k<NT>(sv, r, sw.n, s0, s1, keep_of(sw) & EC3D_KEEP_S);
         EC3D_MASK2(r, sw, s0, s1);
         acc[0] = acc[0] + s0 * s0;
         acc[0] = acc[0] + s1 * s1;
@@ -1344,7 +1362,7 @@ __global__ __launch_bounds__(EC3D_THREADS) void k4_x_r_update(SweepV sw, RedSrc 
         const d2 xv = o.xv, pv = o.pv, s = o.s, a = o.a, q = o.q;
         store2<NT>(x, r, sw.n, (xv.x + alpha * pv.x) + omega * s.x, (xv.y + alpha * pv.y) + omega * s.y);
         double e0 = s.x - omega * a.x, e1 = s.y - omega * a.y;
-        store2<NT>(rv, r, sw.n, e0, e1);
+        store2k<NT>(rv, r, sw.n, e0, e1, keep_of(sw) & EC3D_KEEP_R);
         EC3D_MASK2(r, sw, e0, e1);
         acc[0] = acc[0] + e0 * e0;
         acc[0] = acc[0] + e1 * e1;
@@ -1410,7 +1428,7 @@ __global__ __launch_bounds__(EC3D_THREADS) void k5_p_update(SweepV sw, RedSrc sr
         }, [&](int64_t tile, const Ops &o) {
             EC3D_ROW;
             const d2 q = o.q, pv = o.pv, a = o.a;
-            store2<NT>(p, r, sw.n, q.x + beta * (pv.x - omega * a.x), q.y + beta * (pv.y - omega * a.y));
+            store2k<NT>(p, r, sw.n, q.x + beta * (pv.x - omega * a.x), q.y + beta * (pv.y - omega * a.y), keep_of(sw) & EC3D_KEEP_P);
         });
     }
 }
@@ -1425,7 +1443,7 @@ static inline int fmt_of(const MatView &A)
     return FMT_GENERIC;
 }
 // streaming policy: vectors of >= 32 MiB each (n_pad >= 4 Mi rows) cannot live in the caches
-static inline bool nt_of(const Sweep &sw) { return sw.nt != 0; }
+static inline bool nt_of(const Sweep &sw) { return (sw.nt & 1) != 0; }
 
 static inline TailDev tail_of(const MatView &A) { return TailDev{A.tail_id, A.tile_flag, A.chunk_ptr, A.tcol, A.tval}; }
 template <int FMT> static MatDev<FMT> mat_dev(const MatView &A);
@@ -1497,6 +1515,7 @@ static inline SweepZ sweep_z(const Sweep &sw)
     z.patch_npx = sw.patch_npx;
     z.patch_sdx = sw.patch_sdx;
     z.zm_tpp = sw.zm_tpp;
+    z.keep = sw.nt >> 1;
     return z;
 }
 // dynamic LDS: the class table (a full 256-class table of the structured form would be 32 KiB and cap the CU
@@ -1560,6 +1579,7 @@ static inline SweepV sweep_v(const Sweep &sw)
     v.win_blk = sw.win_blk;
     v.win_t0 = sw.win_t0;
     v.nown = sw.nown;
+    v.keep = sw.nt >> 1;
     for (int q = 0; q < 4; ++q) {
         v.own_lo[q] = sw.own_lo[q];
         v.own_hi[q] = sw.own_hi[q];

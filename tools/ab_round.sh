@@ -1,18 +1,14 @@
 #!/bin/bash
 set -e
-python3 tools/air_box.py 64 64 8 tiny
-python3 tools/air_box.py 128 128 16 small
-python3 tools/air_box.py 256 256 32 mid
-python3 tools/air_box.py 306 306 72 full
-python3 - <<'PY'
-import sys, numpy as np
-sys.path.insert(0, '.')
-import eddy_currents_3d_amd as E
-for N in (64, 128, 256):
-    with E.EC3DSolver() as s:
-        s.assemble_poisson(N, N, N)
-        s.upload("B", np.ones(N**3)); s.upload("X", np.zeros(N**3))
-        s.iterate_begin(); s.iterate(1, 5); s.synchronize()
-        ms = s.iterate(6, 40, per_kernel=True)
-        print(f"cube {N}: " + " ".join(f"{k}={1e3*v:7.1f}" for k, v in ms.items()), f"wg={s.geometry(0).nblk}/{s.geometry(1).nblk}", flush=True)
-PY
+python -m pytest tests/test_gpu_parity.py tests/test_gpu_multi.py tests/test_gpu_formats_dist.py tests/test_gpu_timeloop.py tests/test_gpu_two_process.py -x -q > gpurun_out/ab_pytest.log 2>&1 || { tail -20 gpurun_out/ab_pytest.log; exit 1; }
+tail -2 gpurun_out/ab_pytest.log
+for rep in 1 2; do
+ for wl in cube256 av3; do
+  EC3D_KEEP=0 python3 tools/ab_perf.py $wl all_nontemporal
+  python3 tools/ab_perf.py $wl policy
+ done
+done
+EC3D_KEEP=0 python3 tools/ab_perf.py cube512 all_nontemporal
+python3 tools/ab_perf.py cube512 policy
+python3 bench.py --grid 256 --no-cpu-baseline --no-spmv-dia 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bench 256', d['value'], d['ms_per_step'])"
+python3 bench.py --workload av --no-cpu-baseline 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bench av', d['value'], d['ms_per_step'])"
