@@ -184,7 +184,9 @@ static int choose_sweep(ec3d_ctx *c)
     {
         int ntreq = c->nt_request;
         if (const char *e = getenv("EC3D_NT")) ntreq = atoi(e); // read here too: sweeps of launch knobs in one process
-        sw.nt = (ntreq >= 0 ? ntreq : (c->A.n_pad >= (4 << 20))) & 1;
+        // nontemporal streams from 4.5 Mi rows (tools/keep_sweep.py: at 4 Mi rows = 32 MiB per vector plain caching is
+        // still 8 % faster than any nontemporal policy, at 5.2 M rows it is 1.5 % slower than the policy below)
+        sw.nt = (ntreq >= 0 ? ntreq : (c->A.n_pad >= (9 << 19))) & 1;
         // Between the sizes where everything lives in a cache (< 4 Mi rows: no nontemporal streams at all) and those
         // where nothing does (>= 32 Mi rows), a vector or two fit the 256 MiB Infinity Cache: the output of a kernel
         // that the NEXT kernel reads first is stored cacheable although the launch's other streams are nontemporal

@@ -11,7 +11,12 @@ for (sx, sy, sz) in dims:
     n = sx * sy * sz
     row = []
     for m in masks:
-        os.environ["EC3D_KEEP"] = str(m)
+        os.environ.pop("EC3D_NT", None)
+        os.environ.pop("EC3D_KEEP", None)
+        if m == -1:
+            os.environ["EC3D_NT"] = "0"     # no nontemporal streams at all
+        elif m != -2:                       # -2: the library's own policy
+            os.environ["EC3D_KEEP"] = str(m)
         with E.EC3DSolver() as s:
             s.assemble_poisson(sx, sy, sz)
             s.upload("B", np.ones(n)); s.upload("X", np.zeros(n))
