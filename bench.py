@@ -139,6 +139,96 @@ def latest_traffic(grid, fmt, workload, n_gpus):
     return None
 
 
+def stage_table(s, info, kernel_ms):
+    """Per-stage records of one handle's iteration: which launches it is made of (asked of the library,
+    ec3d_get_fusion), each stage's algorithmic bytes per row under this format's and the SURVEY's byte model, its
+    measured average and the rate that gives.  Returns (kernels, names, fmt_bytes, dominant stage)."""
+    rows = int(info.n)
+    fmt_bytes = dict(DICT_BYTES if info.dict_classes > 0 else SURVEY_BYTES)
+    survey_bytes = dict(SURVEY_BYTES)
+    names = dict(KERNEL_NAMES)
+    kernel_ms = dict(kernel_ms)
+    k2_in_k3, k5_in_k1 = s.fusion() if hasattr(s, "fusion") else (0, 0)
+    if k2_in_k3:
+        # K2 runs inside K3 (k23_s_spmv_dots: 2-D tiles, vectors beyond the caches): stage 2 is empty, stage 3
+        # forms S = R - alpha*AP where the stencil reads it -- S is written once and not read back: 8 B/row less
+        kernel_ms["k3"] += kernel_ms.pop("k2")
+        fmt_bytes["k3"] += fmt_bytes.pop("k2") - 8
+        survey_bytes["k3"] += survey_bytes.pop("k2") - 8
+        names["k3"] = "k23_s_spmv_dots (S = R - alpha*AP inside AS = A*S; S.S, AS.S, AS.AS)"
+    if k5_in_k1:
+        # K5 runs inside the NEXT iteration's K1 (k51_p_spmv_dot): stage 1 is empty after the first iteration,
+        # stage 5 forms P where the stencil of AP = A*P reads it -- P is written once and not read back
+        kernel_ms["k5"] += kernel_ms.pop("k1")
+        fmt_bytes["k5"] += fmt_bytes.pop("k1") - 8
+        survey_bytes["k5"] += survey_bytes.pop("k1") - 8
+        names["k5"] = "k51_p_spmv_dot (P = R + beta*(P - omega*AP) inside the next AP = A*P; AP.R0)"
+    total = sum(kernel_ms.values())
+    kernels = {}
+    for k, ms in kernel_ms.items():
+        kernels[k] = {"name": names[k], "ms": ms, "share": ms / total,
+                      "bytes_per_row": fmt_bytes[k], "GBps": fmt_bytes[k] * rows / ms / 1e6,
+                      "survey_bytes_per_row": survey_bytes[k],
+                      "survey_GBps": survey_bytes[k] * rows / ms / 1e6}
+    dom = max(kernel_ms, key=kernel_ms.get)   # dominant kernel by measured share
+    return kernels, names, fmt_bytes, dom
+
+
+def side_workload(E, name, device, K=200, W=5):
+    """A driver-timed figure for a workload other than the headline one, on a fresh handle, AFTER the headline's
+    timed region: the same measurement (W warm-up iterations, K timed between two synchronisations, then an
+    instrumented pass with hipEvents at every kernel boundary), condensed to one sub-record.
+      av       the full A-V system [Ax | Ay | Az | U] (the matrix src/EC3D.f90:408 solves) of the shipped
+               compare_to_Elmer geometry refined x3 per axis: 306 x 306 x 72, n = 21.4 M
+      cube256  the 256^3 cube of BASELINE config 2"""
+    import numpy as np
+    import torch
+    t_wall = time.perf_counter()
+    with E.EC3DSolver(device=device) as s:
+        if name == "av":
+            geo, geoC, valPHYS, BND, delta, dt, b = av_system(3)
+            s.assemble(geo, geoC, valPHYS, BND, delta, dt)
+            n = len(b)
+            what = (f"full A-V system of the shipped compare_to_Elmer geometry refined x3: grid "
+                    f"{geo.shape[2]}x{geo.shape[1]}x{geo.shape[0]}, {int(np.count_nonzero(geoC))} conducting cells, "
+                    f"coil RHS, x0=0, exits disabled")
+        else:
+            N = 256
+            s.assemble_poisson(N, N, N)
+            n = N ** 3
+            b = bar_rhs(N)
+            what = "synthetic 256^3 7-pt operator (BASELINE config 2 grid), bar RHS, x0=0, exits disabled"
+        s.upload("B", b)
+        s.upload("X", np.zeros(n))
+        s.iterate_begin()
+        s.iterate(1, W)
+        s.synchronize()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        s.iterate(W + 1, K)
+        s.synchronize()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        kernel_ms = s.iterate(W + K + 1, 50, per_kernel=True)
+        spmv_ms = s.time_kernel("spmv", 20)
+        info = s.info
+        kernels, names, fmt_bytes, dom = stage_table(s, info, kernel_ms)
+        geom = {"vector": int(s.geometry(0).nblk), "spmv": int(s.geometry(1).nblk)}
+    rows = int(info.n)
+    achieved = fmt_bytes[dom] * rows / (kernels[dom]["ms"] * 1e-3) / 1e9
+    per_iter = sum(fmt_bytes[k] for k in kernels)
+    return {"workload": what, "n": n, "value": n * K / elapsed, "unit": "DOF*iters/s", "steps": K, "warmup": W,
+            "ms_per_step": elapsed * 1e3 / K, "workgroups": geom,
+            "bytes_per_dof_iter": per_iter, "iter_hbm_frac": per_iter * n * K / elapsed / 1e9 / PEAK_HBM_GBS,
+            "kernels": {k: {"ms": v["ms"], "bytes_per_row": v["bytes_per_row"], "GBps": v["GBps"],
+                            "frac": v["GBps"] / PEAK_HBM_GBS} for k, v in kernels.items()},
+            "dominant": {"kernel": names[dom], "bytes_per_row": fmt_bytes[dom], "avg_launch_ms": kernels[dom]["ms"],
+                         "achieved": achieved, "frac": achieved / PEAK_HBM_GBS},
+            "spmv": {"ms": spmv_ms, "bytes_per_row": fmt_bytes["spmv"], "GBps": fmt_bytes["spmv"] * rows / spmv_ms / 1e6,
+                     "frac": fmt_bytes["spmv"] * rows / spmv_ms / 1e6 / PEAK_HBM_GBS},
+            "wall_s": time.perf_counter() - t_wall}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -156,6 +246,8 @@ def main():
                     help="use the z-slab/torch.distributed path even with one rank (rehearsal on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-spmv-dia", action="store_true", help="skip the plain-DIA SpMV figure after the timed region")
+    ap.add_argument("--no-side-workloads", action="store_true",
+                    help="skip the A-V (refine 3) and 256^3 sub-records timed after the headline region")
     ap.add_argument("--no-verify", action="store_true",
                     help="in-library multi-GPU path: skip the A*x / reduction check against one device before timing")
     ap.add_argument("--cpu-grid", type=int, default=256, help="cube edge of the cpu_baseline sample")
@@ -308,6 +400,7 @@ def main():
         spmv_ms = s.time_kernel("spmv", 20)
         geom = {"vector": int(s.geometry(0).nblk), "spmv": int(s.geometry(1).nblk)}
         info = s.info
+        fusion_state = s.fusion()
         parallelism = "single GPU"
     else:
         from eddy_currents_3d_amd.dist import SlabSolver
@@ -363,6 +456,14 @@ def main():
         info = s.local.info
         parallelism = f"z-slab x{world} (halo send/recv + all_gather of dot products, RCCL)"
 
+    class _Fusion:       # the headline handle's launches per iteration (multi-rank slabs always run five)
+        def __init__(self, st):
+            self.st = st
+
+        def fusion(self):
+            return self.st
+    fusion_of = _Fusion(fusion_state if (not use_dist and not in_library) else (0, 0))
+
     # The north-star SpMV figure in the driver-run line: the plain 7-band DIA SpMV (56 B of coefficients + x + y =
     # 72 B/row) at the same grid, timed after the headline region on a handle of its own (the
     # default format's handle is closed first: 7.5 GB of bands + 8.6 GB of vectors), 20 launches back to back.
@@ -383,36 +484,25 @@ def main():
                                 "next), so the library looks at up to 8 placements at set-up and keeps the fastest "
                                 "(DESIGN.md section 4, profiles/r03_dia_placement.log)"}
 
+    # Driver-timed figures for the reference's own system and for config 2's grid: the headline
+    # handle is gone by now, each runs on a fresh handle, config.workload stays the 512^3 cube.
+    side = {}
+    if rank == 0 and not use_dist and not in_library and args.workload == "cube" and args.format == "dict" \
+            and N == 512 and not args.no_side_workloads:
+        for name in ("av", "cube256"):
+            try:
+                side[name] = side_workload(E, name, local_rank)
+            except Exception as e:     # reporting only: the headline number does not depend on it
+                side[name] = {"error": repr(e)}
+
     if rank == 0:
         ms_per_step = elapsed * 1e3 / K
         value = n_global * K / elapsed
         rows = int(info.n)                       # rows one launch processes on this rank
-        fmt_bytes = dict(DICT_BYTES if info.dict_classes > 0 else SURVEY_BYTES)
-        survey_bytes = dict(SURVEY_BYTES)
-        names = dict(KERNEL_NAMES)
-        if "k2" in kernel_ms and kernel_ms["k2"] < 0.05 * kernel_ms["k3"]:
-            # K2 runs inside K3 (k23_s_spmv_dots: 2-D tiles, vectors beyond the caches): stage 2 is empty, stage 3
-            # forms S = R - alpha*AP where the stencil reads it -- S is written once and not read back: 8 B/row less
-            kernel_ms["k3"] += kernel_ms.pop("k2")
-            fmt_bytes["k3"] += fmt_bytes.pop("k2") - 8
-            survey_bytes["k3"] += survey_bytes.pop("k2") - 8
-            names["k3"] = "k23_s_spmv_dots (S = R - alpha*AP inside AS = A*S; S.S, AS.S, AS.AS)"
-        if "k1" in kernel_ms and kernel_ms["k1"] < 0.05 * kernel_ms["k5"]:
-            # K5 runs inside the NEXT iteration's K1 (k51_p_spmv_dot): stage 1 is empty after the first iteration,
-            # stage 5 forms P where the stencil of AP = A*P reads it -- P is written once and not read back
-            kernel_ms["k5"] += kernel_ms.pop("k1")
-            fmt_bytes["k5"] += fmt_bytes.pop("k1") - 8
-            survey_bytes["k5"] += survey_bytes.pop("k1") - 8
-            names["k5"] = "k51_p_spmv_dot (P = R + beta*(P - omega*AP) inside the next AP = A*P; AP.R0)"
-        dom = max(kernel_ms, key=kernel_ms.get)   # dominant kernel by measured share
+        kernels, names, fmt_bytes, dom = stage_table(fusion_of, info, kernel_ms)
+        kernel_ms = {k: v["ms"] for k, v in kernels.items()}
         tr = latest_traffic(N, args.format, args.workload, world)
         use_tr = bool(tr)
-        kernels = {}
-        for k, ms in kernel_ms.items():
-            kernels[k] = {"name": names[k], "ms": ms, "share": ms / sum(kernel_ms.values()),
-                          "bytes_per_row": fmt_bytes[k], "GBps": fmt_bytes[k] * rows / ms / 1e6,
-                          "survey_bytes_per_row": survey_bytes[k],
-                          "survey_GBps": survey_bytes[k] * rows / ms / 1e6}
         achieved = fmt_bytes[dom] * rows / (kernel_ms[dom] * 1e-3) / 1e9
         traffic = tr["kernels"].get(dom, {}).get("hbm_bytes") if use_tr else None
         out = {
@@ -451,6 +541,8 @@ def main():
                            "bytes_per_row": fmt_bytes["spmv"], "GBps": fmt_bytes["spmv"] * rows / spmv_ms / 1e6}
         if spmv_dia is not None:
             out["spmv_dia"] = spmv_dia
+        for name, rec in side.items():
+            out[name] = rec
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.cpu_grid, args.cpu_iters)

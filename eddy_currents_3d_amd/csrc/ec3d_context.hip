@@ -1067,6 +1067,14 @@ extern "C" int ec3d_get_row_map(ec3d_handle c, int32_t *ref_to_dev)
     return 0;
 }
 
+// P and AP alternate between two buffers while K5 runs inside K1 (ec3d_fused51): the pair the last launch wrote
+static double *cur_vec(ec3d_ctx *c, int which)
+{
+    if (ec3d_fused51(c) && which == EC3D_VEC_P) return c->pbuf[c->pcur & 1];
+    if (ec3d_fused51(c) && which == EC3D_VEC_AP) return c->apbuf[c->pcur & 1];
+    return c->vec[which];
+}
+
 extern "C" int ec3d_upload(ec3d_handle c, int which, const double *host)
 {
     int rc = ec3d_need_matrix(c, "ec3d_upload");
@@ -1082,7 +1090,7 @@ extern "C" int ec3d_download(ec3d_handle c, int which, double *host)
     int rc = ec3d_need_matrix(c, "ec3d_download");
     if (rc) return rc;
     if (which < 0 || which >= EC3D_NVEC) return 2;
-    if ((rc = ec3d_vec_d2h(c, host, c->vec[which]))) return rc;
+    if ((rc = ec3d_vec_d2h(c, host, cur_vec(c, which)))) return rc;
     EC3D_HIP(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -1092,7 +1100,7 @@ extern "C" int ec3d_device_vector(ec3d_handle c, int which, double **device_ptr,
     int rc = ec3d_need_matrix(c, "ec3d_device_vector");
     if (rc) return rc;
     if (which < 0 || which >= EC3D_NVEC) return 2;
-    *device_ptr = c->vec[which];
+    *device_ptr = cur_vec(c, which);
     *n = c->A.n;
     return 0;
 }

@@ -221,3 +221,15 @@ extern "C" int ec3d_read_state(ec3d_handle c, int32_t *stop_iter, int32_t *stop_
     return 0;
 }
 
+// how often the restart rule of src/solvers.f90:47-49 fired in the last solve (counted by K5's lead thread)
+extern "C" int ec3d_get_restart_count(ec3d_handle c, int32_t *count)
+{
+    if (!c || !c->state || !count) return 2;
+    EC3D_HIP(hipSetDevice(c->device));
+    EC3D_HIP(hipStreamSynchronize(c->stream));
+    SolverState st;
+    EC3D_HIP(hipMemcpy(&st, c->state, sizeof st, hipMemcpyDeviceToHost));
+    *count = st.restarts;
+    return 0;
+}
+

@@ -164,6 +164,8 @@ struct SolverState {
     double bnorm, tol;
     int stop_iter; // INT_MAX while running; iteration at which an exit was taken
     int stop_kind; // 1: ‖S‖ exit (solvers.f90:34-38), 2: ‖R‖ exit (:43), 0: none / ‖b‖ = 0
+    int restarts;  // times the restart R0 = R, P = R (solvers.f90:47-49) fired in this solve (ec3d_get_restart_count)
+    int pad_;
 };
 
 // host-side image of the format (CSR conversion / export)
@@ -247,6 +249,8 @@ struct ec3d_ctx {
     // pbuf[it & 1], AP(it) in apbuf[it & 1]; index 1 is vec[EC3D_VEC_P] / vec[EC3D_VEC_AP], index 0 the spare pair
     double *pp_base = nullptr;
     double *pbuf[2] = {nullptr, nullptr}, *apbuf[2] = {nullptr, nullptr};
+    int pcur = 1;          // which pair holds the CURRENT P / AP (what ec3d_download and ec3d_device_vector hand out)
+    int ap_valid_for = 0;  // K5-in-K1: the iteration whose AP = A P the last K51 launch already produced (0: none)
     // K2/K5 as boundary + interior launches (ec3d_dist_set_boundary_rows): tile lists on the device
     Sweep sweep_vb{}, sweep_vi{};
     int32_t *vb_list = nullptr, *vi_list = nullptr;

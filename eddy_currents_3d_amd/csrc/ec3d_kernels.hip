@@ -1109,6 +1109,7 @@ __global__ __launch_bounds__(EC3D_THREADS) void k_setup(SolverState *st, RedSrc 
         st->rr0[0] = 0.0;
         st->alpha = 0.0;
         st->omega = 0.0;
+        st->restarts = 0;
         stop_publish(st, (bnorm == 0.0) ? 0 : INT_MAX, 0);
     }
 }
@@ -1289,6 +1290,7 @@ EC3D_SPMV_T __global__ __launch_bounds__(EC3D_THREADS) __attribute__((amdgpu_wav
     const double beta = (alpha / omega) * rr0_new / st->rr0[it & 1];
     const bool restart = fabs(rr0_new) / bnorm < tol;
     if (lead) st->rr0[(it + 1) & 1] = restart ? d[0] : rr0_new;
+    if (lead && restart) st->restarts = st->restarts + 1;
     stage_table<FMT>(A, tbl);
     ZRegs zr;
     int pstep = 0;
@@ -1411,6 +1413,7 @@ __global__ __launch_bounds__(EC3D_THREADS) void k5_p_update(SweepV sw, RedSrc sr
     const bool restart = fabs(rr0_new) / bnorm < tol;
     // next iteration's R·R0: after a restart R0 == R, so it is R·R in the same summation order
     if (lead) st->rr0[(it + 1) & 1] = restart ? d[0] : rr0_new;
+    if (lead && restart) st->restarts = st->restarts + 1;
     if (restart) {
         walk_vec(sw, [&](int64_t tile) {
             EC3D_ROW;

@@ -41,6 +41,16 @@ extern "C" int ec3d_iterate_begin(ec3d_handle c)
     return ec3d_launch_begin(c, c->A.view(), -1.0);
 }
 
+// the fusions in force on this handle: what stages 2 and 1 of ec3d_iterate's kernel_ms mean
+extern "C" int ec3d_get_fusion(ec3d_handle c, int32_t *k2_in_k3, int32_t *k5_in_k1)
+{
+    int rc = ec3d_need_matrix(c, "ec3d_get_fusion");
+    if (rc) return rc;
+    if (k2_in_k3) *k2_in_k3 = ec3d_fused23(c) ? 1 : 0;
+    if (k5_in_k1) *k5_in_k1 = ec3d_fused51(c) ? 1 : 0;
+    return 0;
+}
+
 extern "C" int ec3d_iterate(ec3d_handle c, int32_t first_iter, int32_t count, double *kernel_ms)
 {
     int rc = ec3d_need_matrix(c, "ec3d_iterate");
@@ -87,13 +97,25 @@ extern "C" int ec3d_time_kernel(ec3d_handle c, int kernel, int32_t reps, double 
     double **v = c->vec;
     hipStream_t s = c->stream;
     c->hist_cap = 0;
+    if (kernel < EC3D_K_SPMV || kernel > EC3D_K5) {
+        ec3d_set_error("ec3d_time_kernel: unknown kernel");
+        return 2;
+    }
+    if (kernel == EC3D_K2 && ec3d_fused23(c)) { // stage 2 launches nothing on this handle: no time to report
+        ec3d_set_error("ec3d_time_kernel: K2 runs inside K3 on this handle (ec3d_get_fusion); time EC3D_K3 instead");
+        return 5;
+    }
     if ((rc = ec3d_launch_begin(c, A, -1.0))) return rc;
     ec3d_launch_iteration(c, A, 1); // populate every partial slot and the scalars
     auto one = [&]() {
         if (kernel == EC3D_K_SPMV)
             ec3d_launch_spmv(A, c->sweep_s, v[EC3D_VEC_P], v[EC3D_VEC_AP], s);
-        else
+        else {
+            // K5-in-K1 handles: EC3D_K1 times the plain K1 of iteration 2 (on the AP buffer the fused launch filled),
+            // EC3D_K5 the fused K5 + K1 launch
+            if (kernel == EC3D_K1) c->ap_valid_for = 0;
             ec3d_launch_stage(c, A, 2, kernel);
+        }
     };
     one(); // warm
     EC3D_HIP(hipEventRecord(c->t0, s));

@@ -129,9 +129,7 @@ struct ec3d_multi {
 };
 
 namespace {
-// hipStreamWaitEvent on ANOTHER thread's event makes the runtime look into that thread's queue; two threads
-// doing that to each other at the same moment (every gather does) must not be able to wait for each other's
-// queue locks: one cross-queue wait at a time, process wide.  Launches and copies stay concurrent.
+// only taken under EC3D_MULTI_SERIALIZE_WAITS=1 (see cross_wait)
 std::mutex g_cross_wait;
 // HIP runtime calls issued by the slab threads (launches are counted in run_plan): what the host pays per iteration
 thread_local uint64_t t_api_calls = 0;
@@ -266,8 +264,12 @@ int wait_posted(ec3d_multi *m, Slab &me, Slab &peer, int ch, uint64_t q)
 
 int cross_wait(hipStream_t stream, hipEvent_t ev)
 {
-    // a precaution, not a measured need: EC3D_MULTI_SERIALIZE_WAITS=0 lets the threads issue them concurrently
-    static const bool serialize = !(getenv("EC3D_MULTI_SERIALIZE_WAITS") && atoi(getenv("EC3D_MULTI_SERIALIZE_WAITS")) == 0);
+    // hipStreamWaitEvent is thread safe like every HIP entry point and the threads issue these waits concurrently.
+    // Rounds 2 and 3 took a process-wide mutex around every one of them by default -- "a precaution, not a measured
+    // need": eight rank threads then queued up behind it at every reduction point and exchange.  It protected against
+    // nothing that was ever observed (tools/multi_stress.py, 2-8 slabs on one card, runs with it off), so it is now
+    // off; EC3D_MULTI_SERIALIZE_WAITS=1 brings it back for a run that wants to rule the runtime out.
+    static const bool serialize = getenv("EC3D_MULTI_SERIALIZE_WAITS") && atoi(getenv("EC3D_MULTI_SERIALIZE_WAITS")) != 0;
     if (serialize) {
         std::lock_guard<std::mutex> lk(g_cross_wait);
         MHIP(hipStreamWaitEvent(stream, ev, 0));
@@ -322,8 +324,12 @@ int halo_wait(Slab &s, int v)
 
 // "gather": nothing moves -- my lsum is final behind my event; my next kernel may read everybody's once all
 // events are behind it.  All-to-all waits would cost N-1 cross-stream waits per rank and point (measured on
-// one card: 74 / 157 / 373 / 1022 us of enqueue time per iteration at 1 / 2 / 4 / 8 slabs); instead rank 0's
-// stream waits for everybody and records ONE event the others wait for: 2 (N-1) waits per point in all.
+// one card: 74 / 157 / 373 / 1022 us of enqueue time per iteration at 1 / 2 / 4 / 8 slabs).  Instead the "final"
+// events are folded up a binomial tree: rank r waits for its children r + 2^j (every j with r % 2^(j+1) == 0 and
+// r + 2^j < N; a child's event is recorded behind the child's own waits, so it covers the child's whole subtree),
+// records its own event, and rank 0 -- behind its log2(N) children -- records ONE event every other rank waits
+// for.  Waits per reduction point: N - 1 going up (at most ceil(log2 N) on any one rank: 3 on rank 0 at N = 8, where
+// a flat hub issued 7) plus N - 1 going down.  EC3D_MULTI_FLAT_HUB=1 restores the flat hub.
 int gather(ec3d_multi *m, Slab &s)
 {
     const uint64_t q = ++s.seq[CH_SUM];
@@ -331,20 +337,27 @@ int gather(ec3d_multi *m, Slab &s)
     s.at.store("gather:record");
     s.at_seq.store(q);
     if (m->n == 1) return 0;
+    static const bool flat = getenv("EC3D_MULTI_FLAT_HUB") && atoi(getenv("EC3D_MULTI_FLAT_HUB")) != 0;
     Slab &hub = *m->slab[0];
     int rc = 0;
+    // children of this rank in the tree (flat hub: every other rank is a child of rank 0)
+    for (int step = 1; step < m->n; step <<= 1) {
+        if (flat ? s.rank != 0 : (s.rank & (2 * step - 1)) != 0) break;
+        const int lo = flat ? 1 : s.rank + step, hi = flat ? m->n : std::min(m->n, lo + 1);
+        for (int h = lo; h < hi; ++h) {
+            Slab &peer = *m->slab[(size_t)h];
+            if ((rc = wait_posted(m, s, peer, CH_SUM, q))) return rc;
+            s.at.store("gather:cross_wait");
+            if ((rc = cross_wait(s.c->stream, peer.ev_sum[i]))) return rc;
+        }
+        if (flat) break;
+    }
     if (s.rank != 0) {
-        MHIP(hipEventRecord(s.ev_sum[i], s.c->stream));
+        MHIP(hipEventRecord(s.ev_sum[i], s.c->stream)); // behind my sums and my subtree's
         s.posted[CH_SUM].store(q, std::memory_order_release);
         if ((rc = wait_posted(m, s, hub, CH_HUB, q))) return rc;
         s.at.store("gather:cross_wait hub");
         return cross_wait(s.c->stream, hub.ev_hub[i]);
-    }
-    for (int h = 1; h < m->n; ++h) {
-        Slab &peer = *m->slab[(size_t)h];
-        if ((rc = wait_posted(m, s, peer, CH_SUM, q))) return rc;
-        s.at.store("gather:cross_wait");
-        if ((rc = cross_wait(s.c->stream, peer.ev_sum[i]))) return rc;
     }
     MHIP(hipEventRecord(s.ev_hub[i], s.c->stream)); // behind rank 0's own sums and everybody else's
     s.posted[CH_HUB].store(q, std::memory_order_release);
@@ -1058,7 +1071,9 @@ extern "C" int ec3d_multi_set_matrix_csr(ec3d_multi_handle m, int32_t n, const d
     {
         std::string why;
         const int rc0 = ec3d_sav_cuttable(G, m->n, why);
-        if (rc0 == 7) { // e.g. a cube whose plane count is a multiple of 3, read as three blocks
+        if (rc0) { // e.g. a cube whose plane count is a multiple of 3, read as three blocks of planes / 3 (too few planes
+                   // per rank for that reading, or coupled across the blocks' faces): as ec3d_probe_csr_multi, any
+                   // refusal of the A-V reading is followed by the single-component one
             const int rc1 = multi_set_cube_csr(m, n, valA, irow, jcol);
             if (rc1 >= 0) return rc1;
         }
@@ -1311,12 +1326,14 @@ extern "C" int ec3d_multi_api_calls(ec3d_multi_handle m, int32_t rank, double *p
 extern "C" int ec3d_multi_synchronize(ec3d_multi_handle m)
 {
     if (!m) return 2;
+    // watched: this is where the asynchronous ec3d_multi_iterate (bench.py's timed region) is joined -- every rank sits
+    // in hipStreamSynchronize behind cross-slab event waits, the very stall the watchdog exists for
     return run_all(m, [&](int r) -> int {
         Slab &s = *m->slab[(size_t)r];
         if (!s.c) return 0;
         MHIP(hipSetDevice(s.device));
         return drain(s);
-    });
+    }, true);
 }
 
 // ||B - A X|| / ||B|| over all slabs (as ec3d_true_residual): X halo refreshed, the residual stage on every

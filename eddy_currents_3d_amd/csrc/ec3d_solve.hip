@@ -51,7 +51,9 @@ void ec3d_launch_stage(ec3d_ctx *c, const MatView &A, int it, int k)
     const bool fused = ec3d_fused23(c); // K2 inside K3 (2-D tiles, single rank): stage 2 is empty, stage 3 is K23
     const bool f51 = ec3d_fused51(c);
     double *P = f51 ? c->pbuf[it & 1] : v[EC3D_VEC_P], *AP = f51 ? c->apbuf[it & 1] : v[EC3D_VEC_AP];
-    if ((k == 0 || k == 1) && (!f51 || it == 1))
+    // fused: AP(it) was produced by the previous iteration's K51 -- unless this call does not continue that
+    // iteration (iteration 1, ec3d_iterate from another first_iter, ec3d_time_kernel): then K1 runs on its own
+    if ((k == 0 || k == 1) && (!f51 || it == 1 || c->ap_valid_for != it))
         ec3d_launch_k1(A, ss, c->state, it, P, v[EC3D_VEC_R0], AP, c->partials, s);
     if ((k == 0 || k == 2) && !fused)
         ec3d_launch_k2(c->sweep_k2, ec3d_src_of(c, EC3D_BY_SPMV), c->state, it, v[EC3D_VEC_R], AP, v[EC3D_VEC_S], c->partials, s);
@@ -67,9 +69,12 @@ void ec3d_launch_stage(ec3d_ctx *c, const MatView &A, int it, int k)
     if ((k == 0 || k == 5) && !f51)
         ec3d_launch_k5(c->sweep_k5, ec3d_src_of(c, EC3D_BY_K4), c->state, it, v[EC3D_VEC_R], AP, P,
                        v[EC3D_VEC_R0], c->hist, c->hist_cap, s);
-    if ((k == 0 || k == 5) && f51)
+    if ((k == 0 || k == 5) && f51) {
         ec3d_launch_k51(A, ss, ec3d_src_of(c, EC3D_BY_K4), c->state, it, v[EC3D_VEC_R], P, AP, c->pbuf[(it + 1) & 1],
                         c->apbuf[(it + 1) & 1], v[EC3D_VEC_R0], c->partials, c->hist, c->hist_cap, s);
+        c->ap_valid_for = it + 1;
+        c->pcur = (it + 1) & 1;
+    }
 }
 
 void ec3d_launch_iteration(ec3d_ctx *c, const MatView &A, int it) { ec3d_launch_stage(c, A, it, 0); }
@@ -80,6 +85,8 @@ int ec3d_launch_begin(ec3d_ctx *c, const MatView &A, double tol)
     ec3d_launch_residual(A, c->sweep_s, v[EC3D_VEC_X], v[EC3D_VEC_B], v[EC3D_VEC_R], v[EC3D_VEC_R0], v[EC3D_VEC_P],
                          c->partials, c->stream);
     ec3d_launch_setup(c->state, ec3d_src_of(c, EC3D_BY_SPMV), tol, c->stream);
+    c->pcur = 1; // P = R went to vec[P] = pbuf[1]
+    c->ap_valid_for = 0;
     EC3D_HIP(hipGetLastError());
     return 0;
 }

@@ -207,6 +207,9 @@ int ec3d_can_overlap(ec3d_handle h);
 int ec3d_read_state_async(ec3d_handle h, int32_t *stop_iter_pinned);
 /* drain the stream and read the device-resident state; stop_iter = -1 while still running */
 int ec3d_read_state(ec3d_handle h, int32_t *stop_iter, int32_t *stop_kind, double *bnorm);
+/* how often the restart rule R0 = R, P = R (src/solvers.f90:47-49) fired during the last solve on this handle
+ * (drains the stream): lets a test assert that a parity case really went through the restart branch */
+int ec3d_get_restart_count(ec3d_handle h, int32_t *count);
 
 /* ------------------------------------------------------------------------------------------
  * 2c. Multi-GPU behind one handle: one process, N devices, invisible to the caller (SURVEY §8b
@@ -353,6 +356,12 @@ int ec3d_time_iterations(ec3d_handle h, int32_t iters, double *ms_total);
  * K2 + K3, stage 5 is K5 + K1 (EC3D_FUSE23=0 EC3D_FUSE51=0 restore five launches). */
 int ec3d_iterate_begin(ec3d_handle h);
 int ec3d_iterate(ec3d_handle h, int32_t first_iter, int32_t count, double *kernel_ms);
+/* which of the two fusions this handle runs (decided by size and tile shape when the matrix is set): *k2_in_k3 = 1:
+ * stage 2 launches nothing and stage 3 is K2 + K3 (ec3d_time_kernel(EC3D_K2) then fails with status 5); *k5_in_k1 = 1:
+ * stage 5 is K5 + the next iteration's K1 and stage 1 launches K1 only where the previous launch was not the
+ * preceding iteration's stage 5; P / AP then alternate between two buffers and ec3d_download / ec3d_device_vector
+ * hand out the current one. */
+int ec3d_get_fusion(ec3d_handle h, int32_t *k2_in_k3, int32_t *k5_in_k1);
 
 int ec3d_device_synchronize(ec3d_handle h);
 

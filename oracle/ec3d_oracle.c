@@ -206,6 +206,7 @@ int oracle_bicgstab_wr_gpuorder3(const oracle_gpu_geom *gv, const oracle_gpu_geo
                                  const double *valA, const int32_t *irow, const int32_t *jcol, int32_t n,
                                  const double *b, double *x, double tolerance, int32_t itmax, int32_t *iter,
                                  double *hist_s, double *hist_r, int32_t hist_cap);
+static int oracle_restarts_ = 0;
 int oracle_bicgstab_wr_gpuorder(const oracle_gpu_geom *gv, const oracle_gpu_geom *gs, const double *valA,
                                 const int32_t *irow, const int32_t *jcol, int32_t n, const double *b,
                                 double *x, double tolerance, int32_t itmax, int32_t *iter, double *hist_s,
@@ -228,6 +229,7 @@ int oracle_bicgstab_wr_gpuorder3(const oracle_gpu_geom *gv, const oracle_gpu_geo
     double alpha, beta, omega, rr0, rr0_new, Bnorm, nrm;
     int hit_itmax = 0;
     *iter = 0;
+    oracle_restarts_ = 0;
     oracle_spmv_csr(valA, irow, jcol, n, x, R);
     for (int32_t j = 0; j < n; ++j) R[j] = b[j] - R[j];
     memcpy(R0, R, nb);
@@ -261,12 +263,17 @@ int oracle_bicgstab_wr_gpuorder3(const oracle_gpu_geom *gv, const oracle_gpu_geo
         if (fabs(rr0_new) / Bnorm < tolerance) {
             memcpy(R0, R, nb);
             memcpy(P, R, nb);
+            ++oracle_restarts_;
         }
     }
 done:
     free(R); free(R0); free(P); free(AP); free(S); free(AS);
     return hit_itmax;
 }
+
+/* restarts (src/solvers.f90:47-49) taken by the last GPU-order solve of this process: what a test compares with the
+ * device's own count (ec3d_get_restart_count) to know that a parity case went through the restart branch */
+int oracle_last_restart_count(void) { return oracle_restarts_; }
 
 /* ------------------------------------------------------------------------------------ */
 /* src/utilites.f90:477-498 full_sort(a,b,n,1,1): ascending by column; columns are distinct */

@@ -77,6 +77,8 @@ def lib() -> C.CDLL:
                                                                                 C.POINTER(C.c_int32), C.c_void_p,
                                                                                 C.c_void_p, C.c_int32]
         L.oracle_bicgstab_wr_gpuorder3.restype = C.c_int
+        L.oracle_last_restart_count.argtypes = []
+        L.oracle_last_restart_count.restype = C.c_int
         L.oracle_gen_sparse_matrix.argtypes = [C.c_int32, C.c_int32, C.c_int32, _i8p, _i32p, _f64p,
                                                C.c_int32, _f64p, _f64p, C.c_double, _i32p,
                                                C.c_void_p, C.c_void_p, C.POINTER(C.c_int64),
@@ -190,6 +192,11 @@ def twin_solve(solver, valA, irow, jcol, b, x0, tol, itmax, hist_cap=0):
     xo, it, hs, hr = bicgstab_wr_gpuorder(geoms_of(solver), vd, ird, jcd, bd, xd, tol, itmax, hist_cap=hist_cap)
     assert np.all(np.delete(xo, rm) == 0.0)
     return xo[rm], it, hs, hr
+
+
+def last_restart_count():
+    """Restarts (src/solvers.f90:47-49) the last twin solve took."""
+    return int(lib().oracle_last_restart_count())
 
 
 def dot_gpuorder(geom, a, b):

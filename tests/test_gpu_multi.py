@@ -155,14 +155,6 @@ def test_multi_spmv_of_the_cube_bitwise(E, oracle):
         assert np.array_equal(m.spmv(x), oracle.spmv_csr(valA, irow, jcol, x))
 
 
-def test_multi_csr_route_refuses_a_matrix_without_a_grid(E, oracle):
-    n = 64
-    irow = np.arange(1, n + 2, dtype=np.int32)
-    with E.EC3DMulti(2, devices=[0, 0]) as m:
-        with pytest.raises(E.EC3DError, match="not recognised"):
-            m.set_matrix_csr(np.ones(n), irow, np.arange(1, n + 1, dtype=np.int32))
-
-
 @pytest.mark.parametrize("name,moving,world", [("g2_conducting_hole_16x15x14", False, 2),
                                                ("g3_moving_coil_18x16x12", True, 3)])
 @pytest.mark.parametrize("structured", [True, False])
@@ -203,7 +195,10 @@ def test_multi_fields_reproduce_reference_file(E, world, plane_pitch):
 
 
 @pytest.mark.parametrize("dictionary", [True, False])
-@pytest.mark.parametrize("dims,world", [((16, 16, 24), 2), ((16, 16, 24), 3), ((20, 12, 10), 4), ((64, 64, 40), 2)])
+@pytest.mark.parametrize("dims,world", [((16, 16, 24), 2), ((16, 16, 24), 3), ((20, 12, 10), 4), ((64, 64, 40), 2),
+                                        # 24 planes read as three blocks of 8: fewer than two planes per rank for the
+                                        # A-V reading (status 2), yet 24 planes cut six or eight ways as a cube
+                                        ((16, 16, 24), 6), ((16, 16, 24), 8)])
 def test_multi_csr_route_cuts_a_single_component_cube(E, oracle, dims, world, dictionary):
     """BASELINE configs 2 and 4 as the drop-in symbol receives them: the CSR triple of the single-component 7-point
     operator (src/EC3D.f90:528-654 with no conducting cell).  A plane count that is a multiple of 3 passes the A-V

@@ -117,10 +117,31 @@ def test_assembly_rejects_what_the_reference_cannot_index(E):
 
 
 # ----------------------------------------------------------------------------------- solve
+# Cache policies of the kernels' streams (choose_sweep in csrc/ec3d_context.hip).  The library picks one by size --
+# plain caching below 4.5 Mi rows, nontemporal streams with the next kernel's operand kept cacheable (AP, S, R = 11;
+# without S = 9) up to 32 Mi rows, everything nontemporal above -- so on the small captured systems only the first
+# would ever run.  EC3D_NT / EC3D_KEEP force each template instance (NT = true loads / stores, store2k's keep bits)
+# onto them: every instance that ships by default meets the bitwise contract here, not only at sizes no twin can
+# follow.  43 = 11 + P kept as well (a policy the sweeps of round 3 tried; it must stay correct while it is selectable).
+POLICIES = [("0", None), ("1", "0"), ("1", "9"), ("1", "11"), ("1", "43")]
+
+
+def set_policy(monkeypatch, policy):
+    nt, keep = policy
+    monkeypatch.setenv("EC3D_NT", nt)
+    if keep is None:
+        monkeypatch.delenv("EC3D_KEEP", raising=False)
+    else:
+        monkeypatch.setenv("EC3D_KEEP", keep)
+
+
+@pytest.mark.parametrize("policy", POLICIES, ids=lambda p: f"nt{p[0]}-keep{p[1]}")
 @pytest.mark.parametrize("name", CAPTURED)
-def test_solve_bitwise_vs_gpu_order_oracle(E, oracle, name):
+def test_solve_bitwise_vs_gpu_order_oracle(E, oracle, name, policy, plane_pitch, monkeypatch):
     """Every captured call (warm starts included): x, iter and the whole residual history are
-    bit-identical to the oracle run with the kernels' summation order."""
+    bit-identical to the oracle run with the kernels' summation order -- under every cache policy the
+    library can select, on the default and on the pitched (z-marching) structured form."""
+    set_policy(monkeypatch, policy)
     g = load_golden(name)
     tol, itmax = float(g["tol"]), int(g["itmax"])
     with E.EC3DSolver() as s:
@@ -271,6 +292,7 @@ def test_restart_rule_is_exercised(E, oracle):
         xo, ito, _, _ = oracle.twin_solve(s, g["valA"], g["irow"], g["jcol"], g["b0"], g["xin0"],
                                                     tol, 1000)
         assert it == ito and np.array_equal(x, xo)
+        assert s.restart_count() == oracle.last_restart_count() > 0
 
 
 # ----------------------------------------------------------------- full-size, size-independent
@@ -305,9 +327,10 @@ def test_full_size_256_spmv_bitwise_vs_oracle(E, oracle):
         assert np.array_equal(s.spmv(x), oracle.spmv_csr(valA, irow, jcol, x))
 
 
+@pytest.mark.parametrize("policy", POLICIES, ids=lambda p: f"nt{p[0]}-keep{p[1]}")
 @pytest.mark.parametrize("fuse", ["0", "2"])
 @pytest.mark.parametrize("grid", [(128, 16, 12), (256, 8, 9), (128, 12, 10)])
-def test_two_dimensional_tiles_bitwise(E, oracle, grid, fuse, monkeypatch):
+def test_two_dimensional_tiles_bitwise(E, oracle, grid, fuse, policy, monkeypatch):
     """The 2-D tiles of the z-marching dictionary kernels (patch_pair in csrc/ec3d_kernels.hip: a workgroup owns a
     128 x 4 patch of the xy plane, the +-sdx neighbours travel through LDS): A*x equals the oracle's CSR SpMV bit for
     bit (src/solvers.f90:54-61), the solve equals the oracle's GPU-order twin bit for bit -- x, iter and the whole
@@ -318,6 +341,9 @@ def test_two_dimensional_tiles_bitwise(E, oracle, grid, fuse, monkeypatch):
     kernels' order, which the library reports as geometry 2 -- the twin must still match bit for bit."""
     monkeypatch.setenv("EC3D_FUSE23", fuse)
     monkeypatch.setenv("EC3D_FUSE51", fuse)      # and K5 inside the next K1 (k51_p_spmv_dot), P / AP alternating buffers
+    if policy != POLICIES[0] and grid != (256, 8, 9):
+        pytest.skip("cache policies: one grid is enough (the policy does not depend on the grid)")
+    set_policy(monkeypatch, policy)
     sdx, sdy, sdz = grid
     n = sdx * sdy * sdz
     valA, irow, jcol = oracle.poisson_csr(sdx, sdy, sdz)
@@ -340,6 +366,9 @@ def test_two_dimensional_tiles_bitwise(E, oracle, grid, fuse, monkeypatch):
             m = min(it, 64)
             assert it == ito and np.array_equal(x, xo)
             assert np.array_equal(hist[:m, 0], hs[:m]) and np.array_equal(hist[:m - 1, 1], hr[:m - 1])
+            # the restart R0 = R, P = R (src/solvers.f90:47-49) fired -- with fuse = 2 inside k51_p_spmv_dot, which then
+            # rewrites R0 in the SpMV kernel -- as often as in the twin (counted by the device / by the oracle)
+            assert s.restart_count() == oracle.last_restart_count() > 0
             res[patch] = (x, it)
             # the same handle again: a warm start that runs into itmax (src/solvers.f90:25-29: 8 iterations), then a
             # solve from the converged x (exits at once) -- the alternating P / AP buffers of the fused iteration

@@ -2,7 +2,7 @@
 """Same-box A/B timing: per-kernel averages INSIDE the iteration (hipEvents on the library's stream, as bench.py
 measures them) and the bare SpMV, for one workload.  Boxes differ by up to 10 %, so variants are only ever compared
 within one gpurun call; EC3D_LIB selects another build of the library, the other knobs are environment variables
-read by the library.   usage: ab_perf.py cube512|cube256|dia512|av3 [label]"""
+read by the library.   usage: ab_perf.py cube512|cube256|dia512|av1|av3|lim|hole [label]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -12,10 +12,20 @@ wl = sys.argv[1] if len(sys.argv) > 1 else "cube512"
 label = sys.argv[2] if len(sys.argv) > 2 else ""
 import bench
 with E.EC3DSolver(dictionary=not wl.startswith("dia")) as s:
-    if wl == "av3":
-        geo, geoC, valPHYS, BND, delta, dt, b = bench.av_system(3)
+    if wl.startswith("av"):          # av1 = the shipped compare_to_Elmer grid (0.79 M unknowns), av3 = refined x3
+        geo, geoC, valPHYS, BND, delta, dt, b = bench.av_system(int(wl[2:]))
         s.assemble(geo, geoC, valPHYS, BND, delta, dt)
         n = len(b)
+    elif wl in ("lim", "hole"):      # BASELINE configs 5 / 3: LIM at 384x192x128, ec_src_move_hole at 256x256x60
+        from eddy_currents_3d_amd import vxc
+        case, dims = ("LIM", (384, 192, 128)) if wl == "lim" else ("ec_src_move_hole", (256, 256, 60))
+        g = np.load(os.path.join(os.path.dirname(bench.__file__), "tests", "golden", f"g4_{case}.npz"))
+        model = vxc.resample(vxc.VxcModel(g["vox"], [str(x) for x in g["names"]], float(str(g["lattice_dim"])),
+                                          tuple(float(x) for x in g["adj"])), *dims)
+        t = vxc.domain_tables(model)
+        s.assemble(t["geoPHYS"], t["geoPHYS_C"], t["valPHYS"], t["BND"], t["delta"], t["dt"])
+        n = s.n
+        b = np.random.Generator(np.random.PCG64(7)).standard_normal(n)
     else:
         N = int(wl[-3:])
         s.assemble_poisson(N, N, N)
