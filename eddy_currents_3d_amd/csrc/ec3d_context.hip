@@ -119,6 +119,7 @@ void ec3d_free_matrix(ec3d_ctx *c)
     c->lsum = c->gsum = nullptr;
     c->lsum_ptrs = nullptr;
     ec3d_free_rhs(c);
+    ec3d_free_output(c);
     c->have_matrix = false;
     free_vectors(c);
     for (auto &l : c->cel_bnd) l.clear();

@@ -304,6 +304,16 @@ struct ec3d_ctx {
     int32_t *src_idx = nullptr;    // per-step source scatter staging
     double *src_val = nullptr;
     int64_t src_cap = 0;
+    // field output (ec3d_output.hip): device scratch for the four float32 vectors, the conductor mask, and -- for
+    // output overlapped with the next time step -- a side stream with two pinned host buffers
+    float *out_dev = nullptr;
+    int64_t out_cells = 0;
+    int32_t *out_mask = nullptr;
+    float *out_pinned[2] = {nullptr, nullptr};
+    hipStream_t out_stream = nullptr;
+    hipEvent_t out_ev_fields = nullptr, out_ev_free = nullptr, out_ev_copied[2] = {nullptr, nullptr};
+    int out_next = 0;
+    bool out_busy = false;
 };
 
 // partial-sum slots inside ctx->partials (each nblk doubles)
@@ -416,6 +426,8 @@ int ec3d_assemble_poisson_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t 
                                  const double *BND, const double *delta);
 // ec3d_format.cpp / ec3d_context.hip: dictionary compression of the bands
 int ec3d_build_dictionary_host(HostMatrix &M);
+// ec3d_output.hip
+void ec3d_free_output(ec3d_ctx *c);
 // ec3d_rhs.hip
 void ec3d_free_rhs(ec3d_ctx *c);
 int ec3d_setup_rhs(ec3d_ctx *c, int64_t nCells, const int8_t *geoPHYS, const int32_t *geoPHYS_C,

@@ -203,15 +203,82 @@ class SourceProgram:
         return np.concatenate(idx).astype(np.int32), np.concatenate(val), self.moving
 
 
+class _OutputPipeline:
+    """field_N.vtk / src_N.vtk of output step N written on a host thread while step N+1 is solved.
+
+    The reference writes the files inside its time loop (src/EC3D.f90:436-444) and the solver waits; here
+    ``ec3d_vtk_fields_begin`` puts the field kernel behind the post-update on the solver's stream and the copy of
+    the four vectors (already in the file's big-endian byte order) into one of two pinned buffers on a side stream,
+    the loop goes on, and this thread waits for the copy, hands the views to ``on_fields`` and writes the bytes as
+    they are.  At most two outputs are in flight (two pinned buffers): before output N is started, output N-2 must
+    have left its buffer."""
+
+    def __init__(self, solver, dims, delta, out_dir, on_fields):
+        import queue
+        import threading
+        self.solver, self.dims, self.delta, self.out_dir, self.on_fields = solver, dims, delta, out_dir, on_fields
+        self.jobs = queue.Queue()
+        self.done = []                  # one threading.Event per started output, in order
+        self.error = None
+        self._Event = threading.Event
+        self.thread = threading.Thread(target=self._work, name="ec3d-output", daemon=True)
+        self.thread.start()
+
+    def start(self, N, groups, write, info):
+        if len(self.done) >= 2:
+            self.done[-2].wait()        # the buffer this output is going to use is free again
+        self._raise()
+        slot = self.solver.vtk_fields_begin(self.delta, big_endian=True)
+        ev = self._Event()
+        self.done.append(ev)
+        self.jobs.put((slot, N, groups, write, info, ev))
+
+    def _work(self):
+        sdx, sdy, sdz = self.dims
+        while True:
+            job = self.jobs.get()
+            if job is None:
+                return
+            slot, N, groups, write, info, ev = job
+            try:
+                f = self.solver.vtk_fields_wait(slot, big_endian=True)      # views of the pinned buffer
+                if self.on_fields is not None:
+                    self.on_fields(N, f, info)
+                if write:
+                    write_field_vtk(os.path.join(self.out_dir, f"field_{N}.vtk"), sdx, sdy, sdz, self.delta, f)
+                    if groups:                                              # src/EC3D.f90:446  CALL writeVtk_src
+                        write_src_vtk(os.path.join(self.out_dir, f"src_{N}.vtk"), sdx, sdy, sdz, self.delta, groups)
+            except BaseException as e:  # reported by the loop's thread at its next output, or at the end
+                self.error = e
+            finally:
+                ev.set()
+
+    def _raise(self):
+        if self.error is not None:
+            e, self.error = self.error, None
+            raise e
+
+    def finish(self):
+        self.jobs.put(None)
+        self.thread.join()
+        self._raise()
+
+
 def run(model: vxc.VxcModel, solver, steps: int | None = None, out_dir: str | None = None, on_step=None,
-        on_rhs=None, on_solved=None, write_output=None):
+        on_rhs=None, on_solved=None, write_output=None, overlap_output: bool = True, on_fields=None):
     """The reference's run of ``model`` on ``solver`` (an EC3DSolver): assemble, then step until T >= stop (or
     ``steps`` steps).  Returns a list of per-step dicts (T, iter).  ``out_dir``: write ``field_N.vtk`` there at
     the reference's output cadence.  Hooks, all ``(k, solver, info)``: ``on_rhs`` when Jaf (B) of step k is
     built -- what the reference passes to its solver --, ``on_solved`` when Uaf (X) holds the solver's result,
     ``on_step`` after the post-update.  ``solver`` may be an EC3DMulti (N GPUs behind one handle) as well.
     ``write_output(N) -> bool`` (default: always) says whether output step N's files go to disk; the fields are
-    computed on the device either way (``info["fields"]`` holds them when they are not written)."""
+    computed on the device and brought to the host either way.
+
+    ``overlap_output`` (default, single-device handles): the field output of step N runs beside step N+1 -- field
+    kernel and device-to-host copy asynchronously, formatting-free writing on a host thread (_OutputPipeline); the
+    files are the same bytes.  ``on_fields(N, fields, info)`` is then called on that thread with views of the pinned
+    buffer (valid during the call).  Without overlap the fields are fetched synchronously after the post-update,
+    ``on_fields`` is called in the loop and ``info["fields"]`` holds them when they are not written."""
     t = vxc.domain_tables(model)
     if t["dt"] is None or t["time"] is None:
         raise ValueError("the model has no 'tran stop=... step=...' line")
@@ -228,6 +295,22 @@ def run(model: vxc.VxcModel, solver, steps: int | None = None, out_dir: str | No
     T, Ntime, Nprint, Npoint = 0.0, 0, Nout, 0           # src/EC3D.f90:137-144
     if out_dir:
         os.makedirs(out_dir, exist_ok=True)
+    pipe = None
+    if out_dir and overlap_output and hasattr(solver, "vtk_fields_begin"):
+        pipe = _OutputPipeline(solver, (sdx, sdy, sdz), t["delta"], out_dir, on_fields)
+    log = []
+    try:
+        log = _time_loop(solver, t, prog, (sdx, sdy, sdz), conducting, out_dir, pipe, steps, on_step, on_rhs, on_solved,
+                         write_output, on_fields, DT, Time, Nout, T, Ntime, Nprint, Npoint)
+    finally:
+        if pipe is not None:
+            pipe.finish()
+    return log
+
+
+def _time_loop(solver, t, prog, dims, conducting, out_dir, pipe, steps, on_step, on_rhs, on_solved, write_output,
+               on_fields, DT, Time, Nout, T, Ntime, Nprint, Npoint):
+    sdx, sdy, sdz = dims
     log = []
     while True:
         idx, val, moving = prog.step(T)
@@ -243,8 +326,12 @@ def run(model: vxc.VxcModel, solver, steps: int | None = None, out_dir: str | No
         if Ntime >= Nprint and Ntime != 0:               # :437-446
             Nprint = Ntime + Nout
             Npoint += 1
-            if out_dir:
+            if out_dir and pipe is not None:
+                pipe.start(Npoint, list(prog.groups), write_output is None or bool(write_output(Npoint)), info)
+            elif out_dir:
                 f = solver.vtk_fields(t["delta"], sdx * sdy * sdz, conducting)
+                if on_fields is not None:
+                    on_fields(Npoint, f, info)
                 if write_output is None or write_output(Npoint):
                     write_field_vtk(os.path.join(out_dir, f"field_{Npoint}.vtk"), sdx, sdy, sdz, t["delta"], f)
                     if prog.groups:                      # :446  CALL writeVtk_src

@@ -13,35 +13,58 @@ def _i8(*vals):
     return " ".join("%8d" % v for v in vals).strip()
 
 
-def field_vtk_bytes(sdx, sdy, sdz, delta, fields) -> bytes:
+_POINTS = {}   # (sdx, sdy, sdz, delta) -> the big-endian POINTS block: the same bytes in every file of a run
+
+
+def _points_block(sdx, sdy, sdz, delta) -> bytes:
+    key = (sdx, sdy, sdz, tuple(float(d) for d in delta))
+    if key not in _POINTS:
+        # REAL(k,8)*delta - delta, then REAL(.,4)   (utilites.f90:210-219)
+        x = (np.arange(1, sdx + 1, dtype=np.float64) * delta[0] - delta[0]).astype(np.float32)
+        y = (np.arange(1, sdy + 1, dtype=np.float64) * delta[1] - delta[1]).astype(np.float32)
+        z = (np.arange(1, sdz + 1, dtype=np.float64) * delta[2] - delta[2]).astype(np.float32)
+        pts = np.empty((sdz, sdy, sdx, 3), ">f4")
+        pts[..., 0] = x[None, None, :]
+        pts[..., 1] = y[None, :, None]
+        pts[..., 2] = z[:, None, None]
+        _POINTS.clear()                      # one grid at a time: the block is 12 bytes per cell
+        _POINTS[key] = pts.tobytes()
+    return _POINTS[key]
+
+
+def field_vtk_pieces(sdx, sdy, sdz, delta, fields):
+    """The file as a list of bytes-like pieces, in order.  Vectors that already are big-endian float32 (dtype '>f4':
+    what EC3DSolver.vtk_fields_wait hands out, swapped on the device) go out as views -- no copy, no conversion."""
     n = sdx * sdy * sdz
     out = [b"# vtk DataFile Version 3.0\nout data result\nBINARY\n",
            ("DATASET STRUCTURED_GRID\nDIMENSIONS %s\n" % _i8(sdx, sdy, sdz)).encode(),
-           ("POINTS %s float\n" % _i8(n)).encode()]
-    # REAL(k,8)*delta - delta, then REAL(.,4)   (utilites.f90:210-219)
-    x = (np.arange(1, sdx + 1, dtype=np.float64) * delta[0] - delta[0]).astype(np.float32)
-    y = (np.arange(1, sdy + 1, dtype=np.float64) * delta[1] - delta[1]).astype(np.float32)
-    z = (np.arange(1, sdz + 1, dtype=np.float64) * delta[2] - delta[2]).astype(np.float32)
-    pts = np.empty((sdz, sdy, sdx, 3), np.float32)
-    pts[..., 0] = x[None, None, :]
-    pts[..., 1] = y[None, :, None]
-    pts[..., 2] = z[:, None, None]
-    out += [pts.astype(">f4").tobytes(), b"\n", ("POINT_DATA %s\n" % _i8(n)).encode()]
+           ("POINTS %s float\n" % _i8(n)).encode(),
+           _points_block(sdx, sdy, sdz, delta), b"\n", ("POINT_DATA %s\n" % _i8(n)).encode()]
 
     def vec(name, a):
-        return [("VECTORS %s float\n" % name).encode(), np.ascontiguousarray(a).astype(">f4").tobytes(), b"\n"]
+        a = np.ascontiguousarray(a)
+        if a.dtype != np.dtype(">f4"):
+            a = a.astype(">f4")
+        return [("VECTORS %s float\n" % name).encode(), memoryview(a).cast("B"), b"\n"]
 
     out += vec("Field_A", fields["A"])
     if fields.get("eddy") is not None:
         out += vec("Vector_field_eddy", fields["eddy"])
     out += vec("Vector_field_SOURCE", fields["source"])
     out += vec("Vector_field_B", fields["B"])
-    return b"".join(out)
+    return out
+
+
+def field_vtk_bytes(sdx, sdy, sdz, delta, fields) -> bytes:
+    return b"".join(bytes(p) for p in field_vtk_pieces(sdx, sdy, sdz, delta, fields))
 
 
 def write_field_vtk(path, sdx, sdy, sdz, delta, fields):
-    with open(path, "wb") as f:
-        f.write(field_vtk_bytes(sdx, sdy, sdz, delta, fields))
+    with open(path, "wb", buffering=0) as f:       # unbuffered: the pieces are 100 MB views, not to be copied again
+        for p in field_vtk_pieces(sdx, sdy, sdz, delta, fields):
+            mv = memoryview(p).cast("B")
+            while len(mv):
+                mv = mv[f.write(mv):]
 
 
 def src_vtk_bytes(sdx, sdy, sdz, delta, groups) -> bytes:

@@ -184,15 +184,18 @@ def test_whole_run_with_true_residual_every_step(case, tmp_path):
         iters.append(info["iter"])
         assert info["true_residual"] < tol, (k, info)
 
-    def on_step(k, s, info):
-        f = info.pop("fields", None)      # computed, not written: finite everywhere
-        if f is not None:
-            assert all(np.isfinite(v).all() for v in f.values() if v is not None)
+    checked = []
+
+    def on_fields(N, f, info):            # on the output thread, while the next step is being solved: the views of the
+        if N % 10 == 0 or N in keep:      # pinned buffer (big-endian float32, as the file holds them), finite everywhere
+            assert all(np.isfinite(v.astype(np.float32)).all() for v in f.values() if v is not None), N
+            checked.append(N)
 
     keep = {1, steps // 2, steps - 1}
     with E.EC3DSolver() as s:
-        log = host.run(model, s, steps=steps, out_dir=str(tmp_path), on_solved=on_solved, on_step=on_step,
+        log = host.run(model, s, steps=steps, out_dir=str(tmp_path), on_solved=on_solved, on_fields=on_fields,
                        write_output=lambda N: N in keep)
+    assert set(checked) >= keep
     assert len(log) == steps and [i.get("output") for i in log] == [None] + list(range(1, steps))
     written = sorted(f for f in os.listdir(tmp_path) if f.startswith("field_"))
     assert written == sorted(f"field_{N}.vtk" for N in keep)

@@ -51,6 +51,32 @@ def test_shipped_input_runs_like_the_reference(case, tmp_path):
         assert info["iter"] == it_ref
 
 
+def test_overlapped_output_writes_the_same_files(tmp_path):
+    """Field output beside the next step's solve (host._OutputPipeline over ec3d_vtk_fields_begin / _wait: field
+    kernel behind the post-update, bytes swapped on the device, pinned double buffer, a host thread that writes) must
+    leave exactly the files the synchronous path writes -- the moving-coil LIM input, 6 steps, 5 outputs, so both
+    pinned buffers are reused while the loop runs ahead."""
+    import filecmp
+    import eddy_currents_3d_amd as E
+    from eddy_currents_3d_amd import host, vxc
+    g = load_golden("g4_LIM")
+    model = vxc.VxcModel(g["vox"], [str(s) for s in g["names"]], float(str(g["lattice_dim"])),
+                         tuple(float(x) for x in g["adj"]))
+    logs = {}
+    for mode in (True, False):
+        d = tmp_path / ("overlap" if mode else "sync")
+        seen = []
+        with E.EC3DSolver() as s:
+            logs[mode] = host.run(model, s, steps=6, out_dir=str(d), overlap_output=mode,
+                                  on_fields=lambda N, f, info: seen.append((N, float(np.abs(f["A"].astype(np.float32)).max()))))
+        assert [n for n, _ in seen] == [1, 2, 3, 4, 5] and all(a > 0 for _, a in seen)
+    assert [i["iter"] for i in logs[True]] == [i["iter"] for i in logs[False]]
+    names = sorted(os.listdir(tmp_path / "sync"))
+    assert names == sorted(f"{k}_{n}.vtk" for k in ("field", "src") for n in range(1, 6))
+    match, mismatch, errors = filecmp.cmpfiles(tmp_path / "sync", tmp_path / "overlap", names, shallow=False)
+    assert sorted(match) == names and not mismatch and not errors
+
+
 def test_command_line_runs_a_vxc_file(tmp_path, capsys):
     """python -m eddy_currents_3d_amd.run: a ZLIB-compressed .vxc file in, the reference's output files out."""
     from eddy_currents_3d_amd import run, vxc

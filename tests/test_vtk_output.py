@@ -60,6 +60,16 @@ def test_device_fields_and_curl_reproduce_reference_file(name, steps, plane_pitc
             s.post_update()
             f = s.vtk_fields(g["delta"], ncell, conducting)
             assert field_vtk_bytes(sdx, sdy, sdz, g["delta"], f) == g[f"vtk_field_{k}"].tobytes()
+            # the overlapped path (ec3d_vtk_fields_begin / _wait: side stream, pinned buffer, bytes swapped on the
+            # device): the same file, from views that are written as they are
+            slot = s.vtk_fields_begin(g["delta"], big_endian=True)
+            fo = s.vtk_fields_wait(slot, big_endian=True)
+            assert all(v is None or v.dtype == np.dtype(">f4") for v in fo.values())
+            assert field_vtk_bytes(sdx, sdy, sdz, g["delta"], fo) == g[f"vtk_field_{k}"].tobytes()
+            slot = s.vtk_fields_begin(g["delta"], big_endian=False)           # the other buffer, host byte order
+            fn = s.vtk_fields_wait(slot, big_endian=False)
+            assert all(np.array_equal(fn[key], f[key]) for key in ("A", "source", "B"))
+            assert (fn["eddy"] is None) == (f["eddy"] is None) and (f["eddy"] is None or np.array_equal(fn["eddy"], f["eddy"]))
 
 
 @pytest.mark.gpu
