@@ -98,6 +98,7 @@ void ec3d_free_matrix(ec3d_ctx *c)
     if (A.tcol) (void)hipFree(A.tcol);
     if (A.tval) (void)hipFree(A.tval);
     if (A.ulist) (void)hipFree(A.ulist);
+    if (A.rp_flag) (void)hipFree(A.rp_flag);
     if (A.cls) (void)hipFree(A.cls);
     if (A.table) (void)hipFree(A.table);
     A = DevMatrix();
@@ -108,6 +109,7 @@ void ec3d_free_matrix(ec3d_ctx *c)
     c->vb_list = c->vi_list = nullptr;
     if (c->us_list) (void)hipFree(c->us_list);
     c->us_list = nullptr;
+    c->us_host.clear();
     c->can_vsplit = false;
     c->n_ref = 0;
     c->plane = c->pitch = c->nCd = 0;
@@ -149,6 +151,74 @@ extern "C" int ec3d_destroy(ec3d_handle c)
     if (c->t1) (void)hipEventDestroy(c->t1);
     if (c->own_stream_obj) (void)hipStreamDestroy(c->own_stream_obj);
     delete c;
+    return 0;
+}
+
+// Runtime-shaped 2-D tiles for the structured A-V form (sav_patch_step in ec3d_kernels.hip): the patch shape for a
+// grid of sdx x sdy cells per plane.  px must be even (a thread owns two consecutive cells) and divide sdx (no
+// ragged patch columns), px * py <= 512, py >= 2; the last patch ROW may be ragged.  Score = the share of the 512
+// thread-cells of a tile that are real cells; at least 32 cells per patch row (256-byte pieces of a vector) unless
+// the grid itself is narrower; ties go to the px nearest 128 (the shape the cube kernels were tuned on).
+static double pick_patch_shape(int64_t sdx, int64_t sdy, int &px_out, int &py_out)
+{
+    double best = 0.0;
+    px_out = py_out = 0;
+    if (sdx % 2) return 0.0;
+    for (int64_t px = 4; px <= std::min<int64_t>(sdx, 256); px += 2) {
+        if (sdx % px) continue;
+        if (px < 32 && px != sdx) continue;
+        const int64_t py = EC3D_TILE / px;
+        if (py < 2) continue;
+        const int64_t npy = (sdy + py - 1) / py;
+        const double eff = (double)(px * py) / EC3D_TILE * (double)sdy / (double)(npy * py);
+        const bool better = eff > best + 1e-9 ||
+                            (eff > best - 1e-9 && std::llabs(px - 128) < std::llabs((int64_t)px_out - 128));
+        if (better) {
+            best = std::max(best, eff);
+            px_out = (int)px;
+            py_out = (int)py;
+        }
+    }
+    return best;
+}
+
+// per patch tile of the three A blocks: does it hold a coupled row?  and the patch tiles of the U block that hold an
+// unknown (ascending): from the class bytes, once per matrix and shape
+static int build_patch_tables(ec3d_ctx *c, int px, int py)
+{
+    DevMatrix &A = c->A;
+    if (A.rp_px == px && A.rp_py == py && A.rp_flag) return 0;
+    if (A.rp_flag) (void)hipFree(A.rp_flag);
+    A.rp_flag = nullptr;
+    const int64_t sdx = A.sav_step[1], pitch = A.sav_step[2], planes = A.sav_nC / pitch, sdy = c->plane / sdx;
+    const int64_t npx = sdx / px, npy = (sdy + py - 1) / py, tpp = npx * npy;
+    std::vector<uint8_t> cls((size_t)A.n_pad);
+    EC3D_HIP(hipStreamSynchronize(c->stream));
+    EC3D_HIP(hipMemcpy(cls.data(), A.cls, cls.size(), hipMemcpyDeviceToHost));
+    std::vector<uint8_t> flag((size_t)(3 * planes * tpp) + 4, 0); // + 4: read by dwords
+    A.rp_ulist_host.clear();
+    for (int64_t P = 0; P < 4 * planes; ++P)
+        for (int64_t q = 0; q < tpp; ++q) {
+            const int64_t pyi = q / npx, pxi = q % npx;
+            bool any = false;
+            for (int64_t y = pyi * py; y < std::min<int64_t>(sdy, (pyi + 1) * py) && !any; ++y) {
+                const uint8_t *row = &cls[(size_t)(P * pitch + y * sdx + pxi * px)];
+                for (int x = 0; x < px; ++x) {
+                    const int k = row[x];
+                    if (P < 3 * planes ? (k >= A.sav_a0 && k < A.sav_u0) : (k >= A.sav_u0 && k < A.sav_zero)) {
+                        any = true;
+                        break;
+                    }
+                }
+            }
+            if (!any) continue;
+            if (P < 3 * planes) flag[(size_t)(P * tpp + q)] = 1;
+            else A.rp_ulist_host.push_back((int32_t)(P * tpp + q));
+        }
+    EC3D_HIP(hipMalloc(&A.rp_flag, flag.size()));
+    EC3D_HIP(hipMemcpy(A.rp_flag, flag.data(), flag.size(), hipMemcpyHostToDevice));
+    A.rp_px = px;
+    A.rp_py = py;
     return 0;
 }
 
@@ -266,6 +336,30 @@ static int choose_sweep(ec3d_ctx *c)
             if (const char *e = getenv("EC3D_PATCH")) patch = atoi(e);
             const bool use_patch = patch && !A.sav && A.ntail == 0 && A.ncls > 0 && sdx % EC3D_PX == 0 && A.off[6] % sdx == 0 &&
                                    (A.off[6] / sdx) % EC3D_PY == 0 && c->A.n == nplanes * A.off[6];
+            // The structured A-V form on runtime-shaped 2-D tiles (sav_patch_step): a single-rank handle whose planes are
+            // tile aligned, from a shape that keeps >= 90 % of a tile's thread-cells busy.  EC3D_SAV_PATCH=0 never,
+            // 2 whenever a shape exists (tests: the small fixture grids).
+            int rp_px = 0, rp_py = 0;
+            if (A.sav && c->halo == 0 && c->nown == 0 && sw.win_nt == 0 && c->plane > 0 && c->plane % sdx == 0) {
+                // Off unless asked for: measured against the linear tiles on the A-V systems of BASELINE configs 3 and 5
+                // and on the 21 M-unknown refinement of the shipped geometry, the 2-D tiles change K1 / K3 by -3 ... +4 %
+                // (iteration within 1 %), and K2-in-K3 / K5-in-K1 on them LOSE 4 ... 20 % at every size these systems
+                // reach on one GPU (profiles/r04_sav_patch_*.log).  EC3D_SAV_PATCH=1: when a shape
+                // keeps >= 90 % of the threads busy; 2: whenever a shape exists.
+                int want = 0;
+                if (const char *e = getenv("EC3D_SAV_PATCH")) want = atoi(e);
+                const double eff = want ? pick_patch_shape(sdx, c->plane / sdx, rp_px, rp_py) : 0.0;
+                if (!(rp_px > 0 && (want == 2 || eff >= 0.9))) rp_px = rp_py = 0;
+                if (const char *e = getenv("EC3D_SAV_PATCH_PX")) { // tests: a given shape (px cells per patch row)
+                    const int px = atoi(e);
+                    if (want && px >= 4 && px % 2 == 0 && px <= 256 && sdx % px == 0) {
+                        rp_px = px;
+                        rp_py = EC3D_TILE / px;
+                    }
+                }
+                if (rp_px > 0 && build_patch_tables(c, rp_px, rp_py) != 0) return 100;
+            }
+            const bool sav_patch = rp_px > 0;
             // workgroups of the z-marching kernels (tools/vec_sweep.py, profiles/r03_sweep_*, r03_patch_*): the
             // single-component kernels, 50-76 registers since they take per-format arguments, run best from 4
             // workgroups per CU once the vectors are far beyond the caches (512^3: K1/K3 619/487 us at 1024 against
@@ -276,16 +370,30 @@ static int choose_sweep(ec3d_ctx *c)
             const bool big = c->A.n_pad >= ((int64_t)1 << 25);
             int want_s = c->nblk_request > 0 ? c->nblk_request : A.sav ? 1536 : big ? 1024 : use_patch ? 1536 : 768;
             if (const char *e = getenv("EC3D_NBLK_SPMV")) want_s = atoi(e);
+            // tiles per plane and logical tiles of the front sweep as the SpMV kernels count them
+            int64_t tpp_s = tpp, ntiles_s = sw.ntiles;
+            if (sav_patch) {
+                const int64_t sdy = c->plane / sdx;
+                tpp_s = (sdx / rp_px) * ((sdy + rp_py - 1) / rp_py);
+                ntiles_s = 3 * (c->nCd / c->pitch) * tpp_s;
+            }
             // columns are dealt to the 8 XCD labels in runs of cpx; with tpp % 8 != 0 the last run is short
             // and 8*cpx - tpp workgroups per segment stay idle
-            const int64_t cols = (tpp + 7) / 8 * 8;
+            const int64_t cols = (tpp_s + 7) / 8 * 8;
             // z segments per column.  6 workgroups per CU are resident (want_s = 6 * 256): a grid just above
             // that leaves a second, nearly empty round (2048 at 512^3: +5 %, 1600 at 640^3: +30 % on K1), a
             // grid well below it wastes latency hiding.  So: the fewest segments that fill one round to
             // >= 5/6 as full as the columns allow, or else >= 1.5 rounds, where the hardware's dynamic dispatch
             // evens things out (2400 at 640^3, 3072 at 512^3 are as good as an exact fit).
             int64_t nseg = 1;
-            const int64_t max_seg = std::max<int64_t>(1, nplanes / 8);
+            // planes per z segment: at least 2.  (Rounds 1-3 kept 8, so that the two extra loads of a segment's first
+            // plane were spread over 8 steps; on a problem that fits the caches that left the shipped 102 x 102 x 24
+            // system with 216 workgroups of 8 DEPENDENT steps each, under one workgroup per CU and a memory round trip per
+            // step: K1 / K3 20.4 / 20.9 us against 12.4 / 13.1 us on 864 workgroups of 2 steps; 128^3: 84.8 -> 81.4 us
+            // per iteration; no difference from 4 M rows up, where the grid is full either way.  EC3D_MIN_PPS overrides.)
+            int64_t min_pps = 2;
+            if (const char *e = getenv("EC3D_MIN_PPS")) min_pps = std::max(1, atoi(e));
+            const int64_t max_seg = std::max<int64_t>(1, nplanes / min_pps);
             if (c->nblk_request > 0 || getenv("EC3D_NBLK_SPMV")) {
                 nseg = std::max<int64_t>(1, (want_s + cols / 2) / cols); // explicit request: nearest
             } else {
@@ -293,23 +401,46 @@ static int choose_sweep(ec3d_ctx *c)
                 nseg = (fit >= 1 && 6 * cols * fit >= 5 * want_s) ? fit : (3 * want_s + 2 * cols - 1) / (2 * cols);
             }
             nseg = std::min<int64_t>(nseg, max_seg);
-            ss.zm_tpp = (int)tpp;
+            ss.zm_tpp = (int)tpp_s;
             ss.zm_pps = (int)((nplanes + nseg - 1) / nseg);
             ss.nblk = (int)(cols * nseg);
             ss.S = 0;
+            ss.ntiles = ntiles_s;
+            if (sav_patch) {
+                const int64_t sdy = c->plane / sdx;
+                ss.rp_px = rp_px;
+                ss.rp_py = rp_py;
+                ss.rp_npx = (int)(sdx / rp_px);
+                ss.rp_sdy = (int)sdy;
+                ss.rp_sdx = sdx;
+                ss.rp_pitch = c->pitch;
+                ss.rp_flag = A.rp_flag;
+                // K2 inside K3, K5 inside the next K1 on these tiles as on the cube's (same rule: vectors beyond the
+                // caches; EC3D_FUSE23 / EC3D_FUSE51 = 0 never, 2 always)
+                int fuse = 1, fuse5 = 1;
+                if (const char *e = getenv("EC3D_FUSE23")) fuse = atoi(e);
+                if (const char *e = getenv("EC3D_FUSE51")) fuse5 = atoi(e);
+                const bool fuse_big = c->A.n_pad >= ((int64_t)1 << 26); // the cube's rule (below)
+                c->fuse23_ok = fuse == 2 || (fuse == 1 && fuse_big);
+                c->fuse51_ok = fuse5 == 2 || (fuse5 == 1 && fuse_big);
+            }
             if (use_patch) {
                 ss.patch_npx = (int)(sdx / EC3D_PX);
                 ss.patch_sdx = sdx;
                 // K2 inside K3 (k23_s_spmv_dots): pays where nothing stays in a cache -- 512^3: K2 + K3 539 + 435 us
                 // -> 856 us, iteration 3530 -> 3435 us; 256^3: 131 -> 154 us and K4 130 -> 165 us behind it (431 ->
                 // 476 us).  EC3D_FUSE23=0 never, 2 on every grid with 2-D tiles (tests).
+                // Round 4 measured where the three-launch iteration starts to pay (same box, five against three launches,
+                // us per iteration): 512 x 512 x 128 (32 Mi rows) 841 / 848, 384^3 (54 Mi) 1484 / 1530, 512 x 512 x 256
+                // (64 Mi) 1704 / 1678, 512 x 512 x 384 (96 Mi) 2577 / 2472, 512^3 (128 Mi) -3 ... -4.5 %: from 64 Mi rows.
+                const bool fuse_big = c->A.n_pad >= ((int64_t)1 << 26);
                 int fuse = 1;
                 if (const char *e = getenv("EC3D_FUSE23")) fuse = atoi(e);
-                c->fuse23_ok = fuse == 2 || (fuse == 1 && big);
+                c->fuse23_ok = fuse == 2 || (fuse == 1 && fuse_big);
                 // K5 inside the next iteration's K1 (k51_p_spmv_dot): K1 + K5 593 + 700 us -> 1225 us at 512^3
                 int fuse5 = 1;
                 if (const char *e = getenv("EC3D_FUSE51")) fuse5 = atoi(e);
-                c->fuse51_ok = fuse5 == 2 || (fuse5 == 1 && big);
+                c->fuse51_ok = fuse5 == 2 || (fuse5 == 1 && fuse_big);
             }
         }
     }
@@ -323,13 +454,19 @@ static int choose_sweep(ec3d_ctx *c)
     // workgroup's list.  The vector kernels keep the plain list (they read nothing twice).
     if (c->us_list) (void)hipFree(c->us_list);
     c->us_list = nullptr;
+    c->us_host.clear();
     {
         int local = 1;
         if (const char *e = getenv("EC3D_ULIST_XCD")) local = atoi(e);
-        if (local && A.sav && ss.zm_tpp > 0 && ss.ulist_n > 0 && ss.nblk % 8 == 0 &&
-            (int)c->A.ulist_host.size() == ss.ulist_n && ss.ulist == c->A.ulist) {
+        // on runtime-shaped 2-D tiles the list holds PATCH tiles of the U block (build_patch_tables); there is no plain
+        // form of it on the device, so the XCD-local order is always taken
+        const bool rp = ss.rp_px > 0;
+        const std::vector<int32_t> &src = rp ? c->A.rp_ulist_host : c->A.ulist_host;
+        if (rp) ss.ulist_n = (int)src.size();
+        if ((local || rp) && A.sav && ss.zm_tpp > 0 && ss.ulist_n > 0 && ss.nblk % 8 == 0 &&
+            (int)src.size() == ss.ulist_n && (rp || ss.ulist == c->A.ulist)) {
             const int64_t tpp = ss.zm_tpp, G = ss.nblk, Gx = G / 8, L = ss.ulist_n;
-            std::vector<int32_t> byc(c->A.ulist_host);
+            std::vector<int32_t> byc(src);
             std::stable_sort(byc.begin(), byc.end(), [&](int32_t a, int32_t b) { return a % tpp < b % tpp; });
             int64_t K = 0;
             std::vector<std::vector<int32_t>> share(8);
@@ -346,6 +483,14 @@ static int choose_sweep(ec3d_ctx *c)
             EC3D_HIP(hipMemcpy(c->us_list, perm.data(), perm.size() * 4, hipMemcpyHostToDevice));
             ss.ulist = c->us_list;
             ss.ulist_n = (int)perm.size();
+            c->us_host = perm;
+        } else if (rp) { // (a grid of fewer than 8 workgroups: the list as it is)
+            if (!src.empty()) {
+                EC3D_HIP(hipMalloc(&c->us_list, src.size() * 4));
+                EC3D_HIP(hipMemcpy(c->us_list, src.data(), src.size() * 4, hipMemcpyHostToDevice));
+            }
+            ss.ulist = c->us_list;
+            c->us_host = src;
         }
     }
     // z-slab of the single-component operator on a z-marching grid: K1/K3 can be split into an interior
@@ -902,6 +1047,16 @@ extern "C" int ec3d_get_reduction_geometry(ec3d_handle c, int which, ec3d_geom *
     g->patch_x = sw.patch_npx > 0 ? EC3D_PX : 0;
     g->patch_y = sw.patch_npx > 0 ? EC3D_PY : 0;
     g->patch_sdx = sw.patch_npx > 0 ? (int32_t)sw.patch_sdx : 0;
+    g->patch_pitch = sw.patch_npx > 0 ? sw.zm_tpp * EC3D_TILE : 0;
+    g->patch_sdy = sw.patch_npx > 0 ? (int32_t)(sw.zm_tpp * (int64_t)EC3D_TILE / sw.patch_sdx) : 0;
+    if (sw.rp_px > 0) { // runtime-shaped 2-D tiles of the structured kernels
+        g->patch_x = sw.rp_px;
+        g->patch_y = sw.rp_py;
+        g->patch_sdx = (int32_t)sw.rp_sdx;
+        g->patch_pitch = (int32_t)sw.rp_pitch;
+        g->patch_sdy = sw.rp_sdy;
+        g->ulist_n = (int32_t)c->A.rp_ulist_host.size();
+    }
     return 0;
 }
 
@@ -913,6 +1068,7 @@ static void visit_of(const ec3d_ctx *c, const Sweep &sw, std::vector<std::vector
     std::vector<int32_t> ul;
     if (sw.ulist_n > 0) {
         if (sw.ulist == A.ulist) ul = A.ulist_host;
+        else if (sw.ulist == c->us_list && !c->us_host.empty()) ul = c->us_host; // the SpMV kernels' own order of the U tiles
         else { // a tile list made elsewhere (K2/K5 split sweeps)
             ul.resize((size_t)sw.ulist_n);
             (void)hipMemcpy(ul.data(), sw.ulist, ul.size() * 4, hipMemcpyDeviceToHost);

@@ -82,6 +82,16 @@ struct Sweep {
     // ec3d_kernels.hip.
     int patch_npx;  // patches per grid row = sdx / EC3D_PX
     int64_t patch_sdx;
+    // Runtime-shaped 2-D tiles of the z-marching STRUCTURED A-V kernels (rp_px > 0; sav_patch_step in
+    // ec3d_kernels.hip): a tile is a patch of rp_px x rp_py cells (rp_px even, a divisor of the grid's sdx,
+    // rp_px * rp_py <= 512) of one xy plane of one block; zm_tpp = rp_npx * ceil(rp_sdy / rp_py) patches per plane,
+    // patch q of a plane is (q % rp_npx, q / rp_npx); thread t owns cells 2t, 2t + 1 of the patch in row-major order
+    // (threads with 2t >= rp_px * rp_py, and rows beyond rp_sdy in the last patch row, idle).  A plane of a block
+    // starts every rp_pitch device rows (the structured form's plane pitch), so tile T = P * zm_tpp + q lies in
+    // plane P of the four stacked blocks.  rp_flag[T]: some row of the A-block patch T is coupled to U.
+    int rp_px, rp_py, rp_npx, rp_sdy;
+    int64_t rp_sdx, rp_pitch;
+    const uint8_t *rp_flag;
     // rows that count in the dot products when this handle holds an A-V slab on an extended grid whose planes
     // are NOT tile aligned (nown > 0; bands + tail, or the structured form on a small grid): [Ax | Ay | Az | U]
     // each contribute one owned index range.  Tile-aligned structured slabs use the window below instead.
@@ -222,6 +232,10 @@ struct DevMatrix {
     int32_t *ulist = nullptr; // tiles of the U block that hold at least one unknown
     int ulist_n = 0;
     std::vector<int32_t> ulist_host; // host copy for the visit-order export
+    // the same for runtime-shaped 2-D tiles (Sweep::rp_*), made by choose_sweep for the shape it picked
+    int rp_px = 0, rp_py = 0;
+    uint8_t *rp_flag = nullptr;            // per patch tile of the three A blocks: coupled
+    std::vector<int32_t> rp_ulist_host;    // patch tiles of the U block that hold an unknown, ascending
     int64_t ntiles_front = 0; // tiles swept unconditionally
     int64_t sav_nC = 0, sav_step[3] = {0, 0, 0};
     int64_t bytes = 0;
@@ -255,6 +269,7 @@ struct ec3d_ctx {
     Sweep sweep_vb{}, sweep_vi{};
     int32_t *vb_list = nullptr, *vi_list = nullptr;
     int32_t *us_list = nullptr; // structured form: the U tiles in the order the z-marching SpMV kernels take them (choose_sweep)
+    std::vector<int32_t> us_host; // host copy (visit-order export)
     bool can_vsplit = false;
     int nown = 0;    // ownership ranges of an A-V slab (see Sweep)
     int64_t own_lo[4] = {0}, own_hi[4] = {0};

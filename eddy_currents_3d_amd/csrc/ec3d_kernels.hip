@@ -75,6 +75,59 @@ __device__ __forceinline__ void reduce_partials(const RedSrc &src, const int (&s
     block_sum<NV>(out, lds);
 }
 
+// The same in two halves, so that a kernel can REQUEST the producer's partials together with everything else it
+// needs before its first tile -- the exit word, the scalars of SolverState, the class table -- and wait once: each
+// of these used to be a dependent memory round trip of its own (exit word -> partials -> scalars -> table -> first
+// tile), which is what a launch costs on a problem that fits the caches (the reference's shipped inputs: 0.4-0.8 M
+// unknowns, where a kernel's whole sweep is one or two more round trips).  partials_request issues the loads of
+// the first EC3D_PMAX values a thread adds (1536 partials cover every default grid) and uses none of them;
+// partials_finish adds them in the order of reduce_partials -- the same sums -- and loads what is left, if anything.
+#define EC3D_PMAX 6
+template <int NV> struct PartialsEarly { double v[NV][EC3D_PMAX]; };
+template <int NV>
+__device__ __forceinline__ void partials_request(const RedSrc &src, const int (&slot)[NV], PartialsEarly<NV> &e)
+{
+    // branch free: an index beyond the count reads entry 0 (always there) and its value is dropped -- a load behind a
+    // branch of its own is waited for at the end of that branch, and the requests would go out one by one again
+    if (src.ptrs) { // one value per rank, each in that rank's own memory
+#pragma unroll
+        for (int j = 0; j < EC3D_PMAX; ++j) {
+            const int i = (int)threadIdx.x + j * EC3D_THREADS;
+            const double *q = src.ptrs[i < src.count ? i : 0];
+#pragma unroll
+            for (int k = 0; k < NV; ++k) e.v[k][j] = q[slot[k]];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const double *p = src.base + (int64_t)slot[k] * src.slot_mul;
+#pragma unroll
+            for (int j = 0; j < EC3D_PMAX; ++j) {
+                const int i = (int)threadIdx.x + j * EC3D_THREADS;
+                e.v[k][j] = p[(int64_t)(i < src.count ? i : 0) * src.stride];
+            }
+        }
+    }
+}
+template <int NV>
+__device__ __forceinline__ void partials_finish(const RedSrc &src, const int (&slot)[NV], const PartialsEarly<NV> &e,
+                                                double (&out)[NV], double *lds)
+{
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        double a = 0.0;
+#pragma unroll
+        for (int j = 0; j < EC3D_PMAX; ++j) // (a value beyond the count enters as +0.0, which changes no sum)
+            a = a + ((int)threadIdx.x + j * EC3D_THREADS < src.count ? e.v[k][j] : 0.0);
+        for (int i = (int)threadIdx.x + EC3D_PMAX * EC3D_THREADS; i < src.count; i += EC3D_THREADS) {
+            if (src.ptrs) a = a + src.ptrs[i][slot[k]];
+            else a = a + src.base[(int64_t)slot[k] * src.slot_mul + (int64_t)i * src.stride];
+        }
+        out[k] = a;
+    }
+    block_sum<NV>(out, lds);
+}
+
 // Streams that are touched once per launch use the nontemporal (streaming) cache policy when the
 // vectors are far larger than the 256 MiB Infinity Cache (NT = true): on a 512^3 grid that is worth
 // +10..25 % on the pure vector stages (tools/stream_bench.hip).  Small problems keep the default
@@ -137,6 +190,7 @@ template <> struct MatDev<FMT_SAV> {
     const uint8_t *tile_flag; // 1: some row of the tile is coupled (uniform per tile)
     const double *table;
     int64_t nC, sdx, pitch; // rows per block; band offsets are (-pitch, -sdx, -1, 0, 1, sdx, pitch)
+    int64_t planes;         // xy planes per block = nC / pitch
     int ncls, pm1;
     int a0, u0, zero; // class ranges (MatView); only the kernels for grids without tile-aligned planes read them
     __device__ __forceinline__ int64_t boff(int b) const
@@ -158,6 +212,8 @@ struct SweepZ {
     int64_t patch_sdx;
     int zm_tpp;
     int keep; // producers whose output stays cacheable (EC3D_KEEP_*)
+    int rp_px, rp_py, rp_npx, rp_sdy; // runtime-shaped 2-D tiles of the structured kernels (Sweep::rp_*)
+    const uint8_t *rp_flag;
 };
 // the launch of a vector kernel (K2, K4, K5) as it sees it: logical tiles t0, t0 + stride, ... of the front sweep
 // (the XCD-aware map of ec3d_tile_of: t0 = (b % 8) * S + b / 8, stride = 8 S; or t0 = b, stride = nblk), then its
@@ -371,14 +427,86 @@ __device__ __forceinline__ void walk_zm(const SweepZ &sw, BODY &&body)
         }
     }
 }
-template <bool ZM, bool SPEC, class SW, class BODY>
-__device__ __forceinline__ void walk_spmv(const SW &sw, BODY &&body)
+// Where a thread of a runtime-shaped patch sweep (structured A-V kernels, Sweep::rp_*) stands: set by the walker
+// before every step.  An idle thread (its cells lie beyond the patch, or beyond the grid's last row in a ragged patch
+// row) goes through the step like everybody else -- the workgroup meets at a barrier every step -- on the plane's
+// first row, whose loads are all valid; it stores nothing and adds +0.0 to every sum.
+struct PatchPos {
+    int64_t P;  // plane over the four stacked blocks
+    int q;      // patch within the plane
+    int64_t r;  // first of the thread's two rows
+    bool live;
+    int tx, ty; // the thread's cells (tx, tx + 1) of patch row ty: fixed for the launch
+};
+template <class BODY>
+__device__ __forceinline__ void walk_zm_rt(const SweepZ &sw, int64_t pitch, int64_t sdx, PatchPos &pp, BODY &&body)
 {
-    if constexpr (ZM) walk_zm<SPEC>(sw, body);
+    const int t2 = 2 * (int)threadIdx.x;
+    pp.ty = t2 / sw.rp_px;
+    pp.tx = t2 - pp.ty * sw.rp_px;
+    const bool inpatch = pp.ty < sw.rp_py;
+    int64_t po = 0; // the thread's first cell within a plane
+    auto place = [&](int q) {
+        const int pyi = q / sw.rp_npx, pxi = q - pyi * sw.rp_npx;
+        const int gy = pyi * sw.rp_py + pp.ty;
+        pp.q = q;
+        pp.live = inpatch && gy < sw.rp_sdy;
+        po = pp.live ? (int64_t)gy * sdx + (int64_t)pxi * sw.rp_px + pp.tx : 0;
+    };
+    // the front sweep: one column (patch position), consecutive planes of the three A blocks (walk_zm without windows)
+    const int cpx = (sw.tpp + 7) >> 3, c = blockIdx.x & 7, sg = blockIdx.x >> 3;
+    const int col = c * cpx + sg % cpx;
+    int64_t lp = (int64_t)(sg / cpx) * sw.pps;
+    int64_t lend = lp + sw.pps;
+    if (sw.npl > 0 && lend > sw.npl) lend = sw.npl;
+    {
+        const int64_t nlp = (sw.ntiles - col + sw.tpp - 1) / sw.tpp - sw.pl0;
+        if (lend > nlp) lend = nlp;
+    }
+    if (col >= sw.tpp) lend = lp;
+    if (lp < lend) place(col);
+    bool fresh = true;
+    int64_t lst = -1;
+    for (;;) {
+        bool first;
+        if (lst < 0 && lp < lend) {
+            pp.P = sw.pl0 + lp;
+            first = fresh;
+            fresh = false;
+            ++lp;
+        } else {
+            if (lst < 0) lst = blockIdx.x;
+            if (lst >= sw.ulist_n) break;
+            const int T = sw.ulist[lst];
+            if (T < 0) break; // a hole of the XCD-local list ends this workgroup's share
+            lst += gridDim.x;
+            pp.P = T / sw.tpp;
+            place(T - (int)pp.P * sw.tpp);
+            first = true;
+        }
+        pp.r = pp.P * pitch + po;
+        body(pp.P * sw.tpp + pp.q, first);
+    }
+}
+template <int FMT, bool ZM, bool SPEC, bool PATCH, class SW, class AD, class BODY>
+__device__ __forceinline__ void walk_spmv(const AD &A, const SW &sw, PatchPos &pp, BODY &&body)
+{
+    if constexpr (FMT == 207 /* FMT_SAV */ && ZM && PATCH) walk_zm_rt(sw, A.pitch, A.sdx, pp, body);
+    else if constexpr (ZM) walk_zm<SPEC>(sw, body);
     else walk_plain<0>(sw, body);
 }
 #define EC3D_ROW const int64_t r = tile * EC3D_TILE + 2 * (int64_t)threadIdx.x
-#define EC3D_ROW_S const int64_t r = PATCH ? ec3d_row_of(sw, tile, (int)threadIdx.x) : tile * EC3D_TILE + 2 * (int64_t)threadIdx.x
+// SpMV kernels: the thread's first row in `tile`, whether it owns rows there at all (runtime-shaped patches have idle
+// threads), and the row count its stores compare with (0 for an idle thread: nothing is stored)
+#define EC3D_ROW_S                                                                                                     \
+    const int64_t r = (FMT == FMT_SAV && PATCH) ? pp.r                                                                 \
+                      : PATCH ? ec3d_row_of(sw, tile, (int)threadIdx.x) : tile * EC3D_TILE + 2 * (int64_t)threadIdx.x; \
+    const bool live_ = (FMT == FMT_SAV && PATCH) ? pp.live : true;                                                     \
+    const int64_t nst = live_ ? sw.n : 0
+#define EC3D_IDLE2(a, b)                                                                                               \
+    do {                                                                                                               \
+        if (!live_) { (a) = 0.0; (b) = 0.0; }                                                                          \
+    } while (0)
 
 // The vector a row kernel multiplies by, behind a small accessor (pair = two consecutive entries from
 // an 8-byte-aligned address, at = one gathered entry).
@@ -467,6 +595,35 @@ __device__ __forceinline__ void stage_table(const MatDev<FMT> &A, double *tbl)
     if constexpr (FMT == FMT_DICT7 || FMT == FMT_SAV) {
         const int cnt = A.ncls * (FMT == FMT_SAV ? EC3D_SAV_STRIDE : 7);
         for (int i = threadIdx.x; i < cnt; i += EC3D_THREADS) tbl[i] = A.table[i];
+        __syncthreads();
+    }
+}
+// the same in two halves (see partials_request): the first four entries a thread copies -- 1024 doubles, the 64
+// classes of a natively assembled structured system -- are requested early, stored behind the exit test
+struct TableEarly { double v[4]; };
+template <int FMT>
+__device__ __forceinline__ void table_request(const MatDev<FMT> &A, TableEarly &e)
+{
+    if constexpr (FMT == FMT_DICT7 || FMT == FMT_SAV) {
+        const int cnt = A.ncls * (FMT == FMT_SAV ? EC3D_SAV_STRIDE : 7);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = (int)threadIdx.x + j * EC3D_THREADS;
+            e.v[j] = A.table[i < cnt ? i : 0]; // branch free (see partials_request)
+        }
+    }
+}
+template <int FMT>
+__device__ __forceinline__ void table_store(const MatDev<FMT> &A, const TableEarly &e, double *tbl)
+{
+    if constexpr (FMT == FMT_DICT7 || FMT == FMT_SAV) {
+        const int cnt = A.ncls * (FMT == FMT_SAV ? EC3D_SAV_STRIDE : 7);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = (int)threadIdx.x + j * EC3D_THREADS;
+            if (i < cnt) tbl[i] = e.v[j];
+        }
+        for (int i = (int)threadIdx.x + 4 * EC3D_THREADS; i < cnt; i += EC3D_THREADS) tbl[i] = A.table[i];
         __syncthreads();
     }
 }
@@ -752,6 +909,228 @@ __device__ __forceinline__ void sav_pair_zm(const MatDev<FMT_SAV> &A, const doub
 }
 
 // ---------------------------------------------------------------------------------------------
+// Structured A-V form on runtime-shaped 2-D tiles (round 4).  What patch_pair below does for the single-component
+// cube -- a workgroup owns a patch of the xy plane and marches in z; the plane above is ONE 16-byte global load per
+// thread, the plane below and the centre are carried in registers, and the in-plane neighbours are the centre values
+// the workgroup's other threads hold, exchanged through LDS (two 4 KiB buffers, one barrier per step) -- for the
+// reference's own system [Ax | Ay | Az | U] on ANY grid with an even sdx: the patch is rp_px x rp_py cells with rp_px
+// a divisor of sdx chosen when the matrix is set (choose_sweep: 102 x 5 on the 306-wide refinement of the shipped
+// geometry, 128 x 4 on 256- and 384-wide grids), threads own cells 2t, 2t + 1 of the patch in row-major order, so a
+// wave is no longer a patch row and the +-1 neighbours come out of the LDS buffer as well (two 8-byte reads where
+// patch_pair shuffles lanes); only the patch's rim (first / last row, requested a plane ahead like patch_pair's, and
+// the first / last cell of every row) goes to memory.  Global loads per step: 1 full-wave load + rim, where the linear
+// tile (sav_pair_zm) issues 3.  The coupling operands of a coupled A tile / a U tile are requested with the band
+// operands as in sav_pair_zm: two through LDS-DMA staging slots (16 KiB of slots would cost the sixth workgroup per
+// CU: table 8 + exchange 8 + slots 8 = 24 KiB), the others into registers; when the operand vector is FORMED where it
+// is read (K2 inside K3, K5 inside K1: V is not VecPlain) all of them go through registers.  Same products, same
+// order as sav_pair_zm (bands ascending then U slots for A rows, A slots then bands for U rows = ascending columns =
+// the reference's row sum, src/solvers.f90:59 after src/EC3D.f90:715): A*x is bit-identical; the dot products are
+// summed in this thread -> cell assignment, which ec3d_geom::patch_* tells the oracle's twin.
+#define EC3D_NSTAGE_RT 2
+template <class V>
+__device__ __forceinline__ void sav_patch_step(const MatDev<FMT_SAV> &A, const SweepZ &sw, const double *tbl,
+                                               double *lds, int step, const V &x, const PatchPos &pp, bool first,
+                                               ZRegs &z, double &s0, double &s1, d2 &ctr)
+{
+    constexpr bool STAGED = std::is_same<V, VecPlain>::value;
+    const int t = threadIdx.x, tx = pp.tx, ty = pp.ty;
+    const int px = sw.rp_px, py = sw.rp_py, hx = px >> 1;
+    const int64_t r = pp.r, sdx = A.sdx, pitch = A.pitch;
+    double *cur = lds + (step & 1) * EC3D_TILE, *nxt = lds + ((step + 1) & 1) * EC3D_TILE;
+    double *stg = lds + 2 * EC3D_TILE; // the staging slots behind the two exchange buffers
+    // which block the plane lies in: uniform, from the plane number
+    const int64_t P = pp.P;
+    const bool urow = P >= 3 * A.planes;
+    const int d = (P >= A.planes) + (P >= 2 * A.planes);
+    bool cpl = true; // a visited U tile holds an unknown; an A tile's flag comes through the scalar unit
+    if (!urow) {
+        typedef const __attribute__((address_space(4))) unsigned *cptr;
+        const int T = __builtin_amdgcn_readfirstlane((int)(P * sw.tpp + pp.q));
+        const unsigned w = ((cptr)(uintptr_t)sw.rp_flag)[T >> 2];
+        cpl = ((w >> ((T & 3) * 8)) & 0xFFu) != 0;
+    }
+    s0 = 0.0;
+    s1 = 0.0;
+    // ---- every load of the step is requested before the first value is looked at ----
+    const unsigned short cc = *reinterpret_cast<const unsigned short *>(A.cls + r);
+    d2 c0v, c1v, c2v, c3v; // coupling operands in registers (which ones depends on the tile kind and on STAGED)
+    d2 xlo, xhi;           // U tile: A_x(cell - 1, cell), A_x(cell + 1, cell + 2)
+    if (urow) {
+        const int64_t rx = r - 3 * A.nC, ry = r - 2 * A.nC, rz = r - A.nC;
+        if constexpr (STAGED) {
+            stage_issue(x.x + ry - sdx, stg, 0);
+            stage_issue(x.x + ry + sdx, stg, 1);
+        } else {
+            c0v = x.pair(ry - sdx);
+            c1v = x.pair(ry + sdx);
+        }
+        c2v = x.pair(rz - pitch);
+        c3v = x.pair(rz + pitch);
+        xlo = x.pair(rx - 1);
+        xhi = x.pair(rx + 1);
+    } else if (cpl) {
+        const int64_t u = r + (3 - d) * A.nC, st = d == 0 ? 2 : A.step(d);
+        if constexpr (STAGED) {
+            stage_issue(x.x + u - st, stg, 0);
+            stage_issue(x.x + u + st, stg, 1);
+        } else {
+            c0v = x.pair(u - st);
+            c1v = x.pair(u + st);
+        }
+        c2v = x.pair(u);
+    }
+    // the band operands: plane above, the row's two outer cells, the patch's outer rows one plane ahead
+    const d2 zp = x.pair(r + pitch);
+    // the row's outer neighbour of its first / last thread in ONE predicated load (px >= 4: never both)
+    double edge = 0.0;
+    if (tx == 0 || tx == px - 2) edge = x.at(tx == 0 ? r - 1 : r + 2);
+    const bool rimrow = ty == 0 || ty == py - 1;
+    const int64_t roff = ty == 0 ? -sdx : sdx;
+    d2 rimc = d2{0.0, 0.0};
+    if constexpr (STAGED) {
+        // beside the centre plane, where the stencil reads it: the unfused kernels' traffic did not change when
+        // patch_pair's rim moved a plane ahead (PMC 25.5 / 17.4 B per row either way), and the carried pair is four
+        // registers these instances do not have
+        if (rimrow) rimc = x.pair(r + roff);
+    } else if (rimrow) { // K2-in-K3 / K5-in-K1 (two or three operand vectors per step): a plane ahead, see patch_pair
+        rimc = first ? x.pair(r + roff) : z.rim;
+        z.rim = x.pair(r + pitch + roff);
+    }
+    d2 zm;
+    if (first) { // nothing carried over: plane below and centre from memory, centre into this step's buffer
+        zm = x.pair(r - pitch);
+        *reinterpret_cast<d2 *>(cur + 2 * t) = x.pair(r);
+    } else {
+        zm = z.xm;
+    }
+    // this step's buffer is complete (written at the end of the previous step, or just now): a raw barrier behind a
+    // wait for the LDS writes only, so the loads above stay in flight across it (see patch_pair)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const double *t0 = tbl + (cc & 0xFF) * EC3D_SAV_STRIDE, *t1 = tbl + (cc >> 8) * EC3D_SAV_STRIDE;
+    // The in-plane band operands (and the centre pair itself, the thread's own slot: it is not carried in registers)
+    // are read from the exchange buffer only where the row sum reaches the bands -- in a U tile behind the A slots,
+    // whose operands then do not share the register file with them (these kernels sit at the budget of six
+    // workgroups per CU).
+    d2 ym, yp, cx;
+    double left, right;
+    auto bands = [&]() {
+        asm volatile("" ::: "memory"); // no LDS read moves above this point
+        ym = rimc;
+        yp = rimc;
+        if (ty > 0) ym = *reinterpret_cast<const d2 *>(cur + 2 * (t - hx));
+        if (ty < py - 1) yp = *reinterpret_cast<const d2 *>(cur + 2 * (t + hx));
+        left = edge;
+        right = edge;
+        if (tx > 0) left = cur[2 * t - 1];
+        if (tx < px - 2 && ty < py) right = cur[2 * t + 2];
+        cx = *reinterpret_cast<const d2 *>(cur + 2 * t);
+        s0 = s0 + t0[0] * zm.x;
+        s1 = s1 + t1[0] * zm.y;
+        s0 = s0 + t0[1] * ym.x;
+        s1 = s1 + t1[1] * ym.y;
+        s0 = s0 + t0[2] * left;
+        s1 = s1 + t1[2] * cx.x;
+        s0 = s0 + t0[3] * cx.x;
+        s1 = s1 + t1[3] * cx.y;
+        s0 = s0 + t0[4] * cx.y;
+        s1 = s1 + t1[4] * right;
+        s0 = s0 + t0[5] * yp.x;
+        s1 = s1 + t1[5] * yp.y;
+        s0 = s0 + t0[6] * zp.x;
+        s1 = s1 + t1[6] * zp.y;
+    };
+    if (urow) {
+        // ---- a tile of the U block: the A slots first (A_x, A_y, A_z: the lower columns), then the bands ----
+        if constexpr (STAGED) EC3D_VM_DRAIN;
+        {
+            const double o0[3] = {xlo.x, xlo.y, xhi.x}, o1[3] = {xlo.y, xhi.x, xhi.y};
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const double v0 = t0[7 + j], v1 = t1[7 + j];
+                if (v0 != 0.0) s0 = s0 + v0 * o0[j];
+                if (v1 != 0.0) s1 = s1 + v1 * o1[j];
+            }
+        }
+        EC3D_PIN(s0, s1);
+#pragma unroll
+        for (int dd = 1; dd < 3; ++dd) { // A_y, A_z
+            const double vm0 = t0[7 + 3 * dd], vm1 = t1[7 + 3 * dd], vc0 = t0[8 + 3 * dd], vc1 = t1[8 + 3 * dd],
+                         vp0 = t0[9 + 3 * dd], vp1 = t1[9 + 3 * dd];
+            d2 oc = d2{0.0, 0.0};
+            const bool want = vc0 != 0.0 || vc1 != 0.0; // own-cell slot: rows on a conductor face only
+            if (__any(want)) {
+                if (want) oc = x.pair(r - (3 - dd) * A.nC);
+            }
+            d2 om, op;
+            if (dd == 1) {
+                if constexpr (STAGED) {
+                    om = stage_read(stg, 0);
+                    op = stage_read(stg, 1);
+                } else {
+                    om = c0v;
+                    op = c1v;
+                }
+            } else {
+                om = c2v;
+                op = c3v;
+            }
+            if (vm0 != 0.0) s0 = s0 + vm0 * om.x;
+            if (vm1 != 0.0) s1 = s1 + vm1 * om.y;
+            if (vc0 != 0.0) s0 = s0 + vc0 * oc.x;
+            if (vc1 != 0.0) s1 = s1 + vc1 * oc.y;
+            if (vp0 != 0.0) s0 = s0 + vp0 * op.x;
+            if (vp1 != 0.0) s1 = s1 + vp1 * op.y;
+            EC3D_PIN(s0, s1);
+        }
+        bands();
+    } else {
+        // ---- a tile of an A block: the bands, then the U slots m = -2 .. 2 ----
+        bands();
+        if (cpl) {
+            EC3D_PIN(s0, s1);
+            d2 q0, q2;
+            if constexpr (STAGED) {
+                EC3D_VM_DRAIN;
+                q0 = stage_read(stg, 0);
+                q2 = stage_read(stg, 1);
+            } else {
+                q0 = c0v;
+                q2 = c1v;
+            }
+            const d2 q1 = c2v;
+            double o0[5], o1[5];
+            if (d == 0) { // cells r-2 .. r+3 lie in the three aligned pairs
+                o0[0] = q0.x; o0[1] = q0.y; o0[2] = q1.x; o0[3] = q1.y; o0[4] = q2.x;
+                o1[0] = q0.y; o1[1] = q1.x; o1[2] = q1.y; o1[3] = q2.x; o1[4] = q2.y;
+            } else {
+                o0[1] = q0.x; o0[2] = q1.x; o0[3] = q2.x;
+                o1[1] = q0.y; o1[2] = q1.y; o1[3] = q2.y;
+                // outer slots: one-sided stencils at a conductor face (src/EC3D.f90:667-676) only
+                const bool wlo = t0[7] != 0.0 || t1[7] != 0.0, whi = t0[11] != 0.0 || t1[11] != 0.0;
+                d2 qlo = d2{0.0, 0.0}, qhi = d2{0.0, 0.0};
+                if (__any(wlo || whi)) {
+                    const int64_t base = r + (3 - d) * A.nC, st = A.step(d);
+                    if (wlo) qlo = x.pair(base - 2 * st);
+                    if (whi) qhi = x.pair(base + 2 * st);
+                }
+                o0[0] = qlo.x; o1[0] = qlo.y;
+                o0[4] = qhi.x; o1[4] = qhi.y;
+            }
+#pragma unroll
+            for (int m = 0; m < 5; ++m) {
+                const double v0 = t0[7 + m], v1 = t1[7 + m];
+                if (v0 != 0.0) s0 = s0 + v0 * o0[m];
+                if (v1 != 0.0) s1 = s1 + v1 * o1[m];
+            }
+        }
+    }
+    // the plane above is the next step's centre: into the other buffer (nobody reads that one before the next barrier)
+    *reinterpret_cast<d2 *>(nxt + 2 * t) = zp;
+    ctr = cx;
+    z.xm = cx;
+}
+
+// ---------------------------------------------------------------------------------------------
 // 2-D tiles for the single-component 7-point operator (north_star: "LDS-staged neighbour stencils").  A workgroup
 // owns a patch of EC3D_PX x EC3D_PY = 64 x 8 cells of the xy plane and marches in z: thread t holds cells
 // (2q, 2q+1), q = t % 32, of patch row y = t / 32 (a wave = two patch rows).  Per step and thread ONE 16-byte global
@@ -859,12 +1238,17 @@ __device__ __forceinline__ void patch_pair(const MatDev<FMT> &A, const double *t
 // rows r, r+1 of A*x (src/solvers.f90:58-59): bands in ascending column order, then the tail.
 // ZM: band 0 / 3 / 6 (offsets -kdz, 0, +kdz) come from / go to the registers `z`.
 // `ctr` returns x[r], x[r+1] (the centre band's operand).
-template <int FMT, bool ZM, bool TAIL, bool NTB, bool PATCH, class V>
-__device__ __forceinline__ void spmv_pair(const MatDev<FMT> &A, const double *tbl, double *stg, int &step, const V &x,
-                                          int64_t r, int64_t tile, bool first, ZRegs &z, double &s0, double &s1, d2 &ctr)
+template <int FMT, bool ZM, bool TAIL, bool NTB, bool PATCH, class V, class SW>
+__device__ __forceinline__ void spmv_pair(const MatDev<FMT> &A, const SW &sw, const PatchPos &pp, const double *tbl,
+                                          double *stg, int &step, const V &x, int64_t r, int64_t tile, bool first,
+                                          ZRegs &z, double &s0, double &s1, d2 &ctr)
 {
-    if constexpr (FMT == FMT_SAV && ZM) {
-        sav_pair_zm(A, tbl, stg, x, r, tile, first, z, s0, s1, ctr);
+    if constexpr (FMT == FMT_SAV && ZM && PATCH) {
+        sav_patch_step(A, sw, tbl, stg, step++, x, pp, first, z, s0, s1, ctr);
+        return;
+    }
+    if constexpr (FMT == FMT_SAV && ZM && !PATCH) {
+        if constexpr (std::is_same<V, VecPlain>::value) sav_pair_zm(A, tbl, stg, x, r, tile, first, z, s0, s1, ctr);
         return;
     }
     if constexpr (PATCH && (FMT == FMT_DIA7 || FMT == FMT_DICT7)) {
@@ -1006,13 +1390,14 @@ EC3D_SPMV_T __global__ __launch_bounds__(EC3D_THREADS) EC3D_SPMV_OCC void k_spmv
     EC3D_TBL_DECL;
     stage_table<FMT>(A, tbl);
     ZRegs zr;
+    PatchPos pp{};
     int pstep = 0; // steps taken (2-D tiles: which of the two LDS buffers holds the centre plane)
-    walk_spmv<ZM, FMT != FMT_SAV>(sw, [&](int64_t tile, auto fc) {
+    walk_spmv<FMT, ZM, FMT != FMT_SAV, PATCH>(A, sw, pp, [&](int64_t tile, auto fc) {
         EC3D_ROW_S;
         double s0, s1;
         d2 ctr;
-        spmv_pair<FMT, ZM, TAIL, NT, PATCH>(A, tbl, stg, pstep, VecPlain{x}, r, tile, (bool)fc, zr, s0, s1, ctr);
-        store2<NT>(y, r, sw.n, s0, s1);
+        spmv_pair<FMT, ZM, TAIL, NT, PATCH>(A, sw, pp, tbl, stg, pstep, VecPlain{x}, r, tile, (bool)fc, zr, s0, s1, ctr);
+        store2<NT>(y, r, nst, s0, s1);
     });
 }
 
@@ -1025,20 +1410,23 @@ EC3D_SPMV_T __global__ __launch_bounds__(EC3D_THREADS) EC3D_SPMV_OCC void k_resi
     EC3D_TBL_DECL;
     stage_table<FMT>(A, tbl);
     ZRegs zr;
+    PatchPos pp{};
     int pstep = 0; // steps taken (2-D tiles: which of the two LDS buffers holds the centre plane)
     double acc[2] = {0.0, 0.0};
-    walk_spmv<ZM, FMT != FMT_SAV>(sw, [&](int64_t tile, auto fc) {
+    walk_spmv<FMT, ZM, FMT != FMT_SAV, PATCH>(A, sw, pp, [&](int64_t tile, auto fc) {
         EC3D_ROW_S;
         double s0, s1;
         d2 ctr;
-        spmv_pair<FMT, ZM, TAIL, NT, PATCH>(A, tbl, stg, pstep, VecPlain{x}, r, tile, (bool)fc, zr, s0, s1, ctr);
+        spmv_pair<FMT, ZM, TAIL, NT, PATCH>(A, sw, pp, tbl, stg, pstep, VecPlain{x}, r, tile, (bool)fc, zr, s0, s1, ctr);
         d2 bv = load2<NT>(b + r);
         double e0 = bv.x - s0, e1 = bv.y - s1, b0 = bv.x, b1 = bv.y;
-        store2<NT>(rv, r, sw.n, e0, e1);
-        store2<NT>(r0, r, sw.n, e0, e1);
-        store2<NT>(p, r, sw.n, e0, e1);
+        store2<NT>(rv, r, nst, e0, e1);
+        store2<NT>(r0, r, nst, e0, e1);
+        store2<NT>(p, r, nst, e0, e1);
         EC3D_MASK2(r, sw, e0, e1);
+        EC3D_IDLE2(e0, e1);
         EC3D_MASK2(r, sw, b0, b1);
+        EC3D_IDLE2(b0, b1);
         acc[0] = acc[0] + b0 * b0;
         acc[0] = acc[0] + b1 * b1;
         acc[1] = acc[1] + e0 * e0;
@@ -1087,6 +1475,9 @@ __device__ __forceinline__ void stop_read(const SolverState *st, int &it, int &k
     it = (int)(unsigned)(w & 0xFFFFFFFFull);
     kind = (int)(unsigned)(w >> 32);
 }
+// everything requested above this line stays above it (the compiler would otherwise sink a load to its first use,
+// behind the exit test -- and the requests would go out one after the other again)
+#define EC3D_REQUESTS_OUT asm volatile("" ::: "memory")
 __device__ __forceinline__ int stop_iter_of(const SolverState *st)
 {
     int it, kind;
@@ -1121,23 +1512,29 @@ EC3D_SPMV_T __global__ __launch_bounds__(EC3D_THREADS) EC3D_SPMV_OCC void k1_spm
 {
     __shared__ double lds[4];
     EC3D_TBL_DECL;
-    if (stop_iter_of(st) < it) return;
-    stage_table<FMT>(A, tbl);
+    TableEarly te;
+    table_request<FMT>(A, te); // with the exit word: one round trip before the first tile instead of two
+    const int stop_it = stop_iter_of(st);
+    EC3D_REQUESTS_OUT;
+    if (stop_it < it) return;
+    table_store<FMT>(A, te, tbl);
     ZRegs zr;
+    PatchPos pp{};
     int pstep = 0; // steps taken (2-D tiles: which of the two LDS buffers holds the centre plane)
     double acc[1] = {0.0};
-    walk_spmv<ZM, FMT != FMT_SAV>(sw, [&](int64_t tile, auto fc) {
+    walk_spmv<FMT, ZM, FMT != FMT_SAV, PATCH>(A, sw, pp, [&](int64_t tile, auto fc) {
         EC3D_ROW_S;
         double s0, s1;
         d2 ctr;
         // R0's pair: requested before the step's own loads in the structured kernels (A-V K1 128 -> 124 us; their
         // steps wait on LDS-DMA slots), after them elsewhere (2-D tiles: 593 vs 603 us at 512^3, 76 vs 80 at 256^3)
         d2 q;
-        if constexpr (FMT == FMT_SAV) q = load2<NT>(r0 + r);
-        spmv_pair<FMT, ZM, TAIL, NT, PATCH>(A, tbl, stg, pstep, VecPlain{p}, r, tile, (bool)fc, zr, s0, s1, ctr);
-        if constexpr (FMT != FMT_SAV) q = load2<NT>(r0 + r);
-        store2k<NT>(ap, r, sw.n, s0, s1, keep_of(sw) & EC3D_KEEP_AP);
+        if constexpr (FMT == FMT_SAV && !PATCH) q = load2<NT>(r0 + r);
+        spmv_pair<FMT, ZM, TAIL, NT, PATCH>(A, sw, pp, tbl, stg, pstep, VecPlain{p}, r, tile, (bool)fc, zr, s0, s1, ctr);
+        if constexpr (FMT != FMT_SAV || PATCH) q = load2<NT>(r0 + r);
+        store2k<NT>(ap, r, nst, s0, s1, keep_of(sw) & EC3D_KEEP_AP);
         EC3D_MASK2(r, sw, s0, s1);
+        EC3D_IDLE2(s0, s1);
         acc[0] = acc[0] + s0 * q.x;
         acc[0] = acc[0] + s1 * q.y;
     });
@@ -1153,11 +1550,16 @@ __global__ __launch_bounds__(EC3D_THREADS) void k2_s_update(SweepV sw, RedSrc sr
                                                             double *__restrict__ part)
 {
     __shared__ double lds[4];
-    if (stop_iter_of(st) < it) return;
     const int slot[1] = {P_D1};
+    PartialsEarly<1> pe;
+    partials_request<1>(src, slot, pe); // exit word, partials and rr0 in one round trip (see partials_request)
+    const double rr0 = st->rr0[it & 1];
+    const int stop_it = stop_iter_of(st);
+    EC3D_REQUESTS_OUT;
+    if (stop_it < it) return;
     double d[1];
-    reduce_partials<1>(src, slot, d, lds);
-    const double alpha = st->rr0[it & 1] / d[0];
+    partials_finish<1>(src, slot, pe, d, lds);
+    const double alpha = rr0 / d[0];
     if (blockIdx.x == 0 && threadIdx.x == 0) st->alpha = alpha;
     double acc[1] = {0.0};
     struct Ops { d2 a, q; };
@@ -1186,18 +1588,24 @@ EC3D_SPMV_T __global__ __launch_bounds__(EC3D_THREADS) EC3D_SPMV_OCC void k3_spm
 {
     __shared__ double lds[8];
     EC3D_TBL_DECL;
-    if (stop_iter_of(st) < it) return;
-    stage_table<FMT>(A, tbl);
+    TableEarly te;
+    table_request<FMT>(A, te);
+    const int stop_it = stop_iter_of(st);
+    EC3D_REQUESTS_OUT;
+    if (stop_it < it) return;
+    table_store<FMT>(A, te, tbl);
     ZRegs zr;
+    PatchPos pp{};
     int pstep = 0; // steps taken (2-D tiles: which of the two LDS buffers holds the centre plane)
     double acc[2] = {0.0, 0.0};
-    walk_spmv<ZM, FMT != FMT_SAV>(sw, [&](int64_t tile, auto fc) {
+    walk_spmv<FMT, ZM, FMT != FMT_SAV, PATCH>(A, sw, pp, [&](int64_t tile, auto fc) {
         EC3D_ROW_S;
         double s0, s1;
         d2 q;
-        spmv_pair<FMT, ZM, TAIL, NT, PATCH>(A, tbl, stg, pstep, VecPlain{sv}, r, tile, (bool)fc, zr, s0, s1, q);
-        store2<NT>(as, r, sw.n, s0, s1);
+        spmv_pair<FMT, ZM, TAIL, NT, PATCH>(A, sw, pp, tbl, stg, pstep, VecPlain{sv}, r, tile, (bool)fc, zr, s0, s1, q);
+        store2<NT>(as, r, nst, s0, s1);
         EC3D_MASK2(r, sw, s0, s1);
+        EC3D_IDLE2(s0, s1);
         acc[0] = acc[0] + s0 * q.x;
         acc[0] = acc[0] + s1 * q.y;
         acc[1] = acc[1] + s0 * s0;
@@ -1221,26 +1629,36 @@ EC3D_SPMV_T __global__ __launch_bounds__(EC3D_THREADS) __attribute__((amdgpu_wav
 {
     __shared__ double lds[12];
     EC3D_TBL_DECL;
-    if (stop_iter_of(st) < it) return;
     const int slot[1] = {P_D1};
+    PartialsEarly<1> pe;
+    partials_request<1>(src, slot, pe);
+    const double rr0 = st->rr0[it & 1];
+    TableEarly te;
+    table_request<FMT>(A, te);
+    const int stop_it = stop_iter_of(st);
+    EC3D_REQUESTS_OUT;
+    if (stop_it < it) return;
     double d[1];
-    reduce_partials<1>(src, slot, d, lds);
-    const double alpha = st->rr0[it & 1] / d[0];
+    partials_finish<1>(src, slot, pe, d, lds);
+    const double alpha = rr0 / d[0];
     if (blockIdx.x == 0 && threadIdx.x == 0) st->alpha = alpha;
-    stage_table<FMT>(A, tbl);
+    table_store<FMT>(A, te, tbl);
     ZRegs zr;
+    PatchPos pp{};
     int pstep = 0;
     double acc[3] = {0.0, 0.0, 0.0};
-    walk_spmv<ZM, FMT != FMT_SAV>(sw, [&](int64_t tile, auto fc) {
+    walk_spmv<FMT, ZM, FMT != FMT_SAV, PATCH>(A, sw, pp, [&](int64_t tile, auto fc) {
         EC3D_ROW_S;
         double s0, s1;
         d2 q; // S[r], S[r+1]
-        spmv_pair<FMT, ZM, TAIL, NT, PATCH>(A, tbl, stg, pstep, VecFused{rv, ap, alpha}, r, tile, (bool)fc, zr, s0, s1, q);
-        store2<NT>(sv, r, sw.n, q.x, q.y);
-        store2<NT>(as, r, sw.n, s0, s1);
+        spmv_pair<FMT, ZM, TAIL, NT, PATCH>(A, sw, pp, tbl, stg, pstep, VecFused{rv, ap, alpha}, r, tile, (bool)fc, zr, s0, s1, q);
+        store2<NT>(sv, r, nst, q.x, q.y);
+        store2<NT>(as, r, nst, s0, s1);
         double q0 = q.x, q1 = q.y;
         EC3D_MASK2(r, sw, q0, q1);
+        EC3D_IDLE2(q0, q1);
         EC3D_MASK2(r, sw, s0, s1);
+        EC3D_IDLE2(s0, s1);
         acc[0] = acc[0] + q0 * q0;
         acc[0] = acc[0] + q1 * q1;
         acc[1] = acc[1] + s0 * q.x;
@@ -1269,16 +1687,21 @@ EC3D_SPMV_T __global__ __launch_bounds__(EC3D_THREADS) __attribute__((amdgpu_wav
 {
     __shared__ double lds[8];
     EC3D_TBL_DECL;
+    const int slot[2] = {P_RR, P_RR0N};
+    PartialsEarly<2> pe;
+    partials_request<2>(src, slot, pe);
+    const double bnorm = st->bnorm, tol = st->tol, alpha = st->alpha, omega = st->omega, rr0 = st->rr0[it & 1];
+    TableEarly te;
+    table_request<FMT>(A, te);
     {
         int si, kind;
         stop_read(st, si, kind);
+        EC3D_REQUESTS_OUT;
         if (si < it || (si == it && kind == 1)) return;
     }
-    const int slot[2] = {P_RR, P_RR0N};
     double d[2];
-    reduce_partials<2>(src, slot, d, lds);
+    partials_finish<2>(src, slot, pe, d, lds);
     const double rnorm = sqrt(d[0]);
-    const double bnorm = st->bnorm, tol = st->tol;
     const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
     if (lead && hist && it <= hist_cap) hist[2 * (int64_t)(it - 1) + 1] = rnorm;
     if (rnorm / bnorm < tol) {
@@ -1286,26 +1709,27 @@ EC3D_SPMV_T __global__ __launch_bounds__(EC3D_THREADS) __attribute__((amdgpu_wav
         return;
     }
     const double rr0_new = d[1];
-    const double alpha = st->alpha, omega = st->omega;
-    const double beta = (alpha / omega) * rr0_new / st->rr0[it & 1];
+    const double beta = (alpha / omega) * rr0_new / rr0;
     const bool restart = fabs(rr0_new) / bnorm < tol;
     if (lead) st->rr0[(it + 1) & 1] = restart ? d[0] : rr0_new;
     if (lead && restart) st->restarts = st->restarts + 1;
-    stage_table<FMT>(A, tbl);
+    table_store<FMT>(A, te, tbl);
     ZRegs zr;
+    PatchPos pp{};
     int pstep = 0;
     double acc[1] = {0.0};
-    walk_spmv<ZM, FMT != FMT_SAV>(sw, [&](int64_t tile, auto fc) {
+    walk_spmv<FMT, ZM, FMT != FMT_SAV, PATCH>(A, sw, pp, [&](int64_t tile, auto fc) {
         EC3D_ROW_S;
         double s0, s1;
         d2 pc; // the new P[r], P[r+1]
-        spmv_pair<FMT, ZM, TAIL, NT, PATCH>(A, tbl, stg, pstep, VecFusedP{rv, p_old, ap_old, beta, omega, restart}, r, tile,
+        spmv_pair<FMT, ZM, TAIL, NT, PATCH>(A, sw, pp, tbl, stg, pstep, VecFusedP{rv, p_old, ap_old, beta, omega, restart}, r, tile,
                                             (bool)fc, zr, s0, s1, pc);
         d2 q = restart ? pc : load2<NT>(r0 + r); // after a restart R0 = R = the new P
-        store2<NT>(p_new, r, sw.n, pc.x, pc.y);
-        if (restart) store2<NT>(r0, r, sw.n, pc.x, pc.y);
-        store2<NT>(ap_new, r, sw.n, s0, s1);
+        store2<NT>(p_new, r, nst, pc.x, pc.y);
+        if (restart) store2<NT>(r0, r, nst, pc.x, pc.y);
+        store2<NT>(ap_new, r, nst, s0, s1);
         EC3D_MASK2(r, sw, s0, s1);
+        EC3D_IDLE2(s0, s1);
         acc[0] = acc[0] + s0 * q.x;
         acc[0] = acc[0] + s1 * q.y;
     });
@@ -1326,15 +1750,23 @@ __global__ __launch_bounds__(EC3D_THREADS) void k4_x_r_update(SweepV sw, RedSrc 
                                                               double *hist, int64_t hist_cap)
 {
     __shared__ double lds[8];
-    if (stop_iter_of(st) < it) return; // (this kernel is the one that may publish the exit (it, 1))
+    // S.S (from K2 or K2-in-K3), AS.S and AS.AS (from K3), the scalars and the exit word: one round trip
     const int slot_ss[1] = {P_SS};
+    const int slot[2] = {P_D2, P_D3};
+    PartialsEarly<1> pss;
+    PartialsEarly<2> pd;
+    partials_request<1>(src_ss, slot_ss, pss);
+    partials_request<2>(src, slot, pd);
+    const double alpha = st->alpha, bnorm = st->bnorm, tol = st->tol;
+    const int stop_it = stop_iter_of(st);
+    EC3D_REQUESTS_OUT;
+    if (stop_it < it) return; // (this kernel is the one that may publish the exit (it, 1))
     double ss[1];
-    reduce_partials<1>(src_ss, slot_ss, ss, lds);
+    partials_finish<1>(src_ss, slot_ss, pss, ss, lds);
     const double snorm = sqrt(ss[0]);
-    const double alpha = st->alpha;
     const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
     if (lead && hist && it <= hist_cap) hist[2 * (int64_t)(it - 1)] = snorm;
-    if (snorm / st->bnorm < st->tol) {
+    if (snorm / bnorm < tol) {
         struct OpsX { d2 xv, pv; };
         walk_vec(sw, [&](int64_t tile) {
             EC3D_ROW;
@@ -1349,9 +1781,8 @@ __global__ __launch_bounds__(EC3D_THREADS) void k4_x_r_update(SweepV sw, RedSrc 
         if (lead) stop_publish(st, it, 1);
         return;
     }
-    const int slot[2] = {P_D2, P_D3};
     double d[2];
-    reduce_partials<2>(src, slot, d, lds);
+    partials_finish<2>(src, slot, pd, d, lds);
     const double omega = d[0] / d[1];
     if (lead) st->omega = omega;
     double acc[2] = {0.0, 0.0};
@@ -1391,16 +1822,19 @@ __global__ __launch_bounds__(EC3D_THREADS) void k5_p_update(SweepV sw, RedSrc sr
     // anything before.  The lead thread of THIS launch publishes (it, 2) below while other workgroups may still
     // be at this test; a wave that returned on seeing it would leave its workgroup's barriers in
     // reduce_partials short of a wave.  The pair is one word (stop_publish), so (it, 1) is K4's and nothing else.
+    const int slot[2] = {P_RR, P_RR0N};
+    PartialsEarly<2> pe;
+    partials_request<2>(src, slot, pe);
+    const double bnorm = st->bnorm, tol = st->tol, alpha = st->alpha, omega = st->omega, rr0 = st->rr0[it & 1];
     {
         int si, kind;
         stop_read(st, si, kind);
+        EC3D_REQUESTS_OUT;
         if (si < it || (si == it && kind == 1)) return;
     }
-    const int slot[2] = {P_RR, P_RR0N};
     double d[2];
-    reduce_partials<2>(src, slot, d, lds);
+    partials_finish<2>(src, slot, pe, d, lds);
     const double rnorm = sqrt(d[0]);
-    const double bnorm = st->bnorm, tol = st->tol;
     const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
     if (lead && hist && it <= hist_cap) hist[2 * (int64_t)(it - 1) + 1] = rnorm;
     if (rnorm / bnorm < tol) {
@@ -1408,8 +1842,7 @@ __global__ __launch_bounds__(EC3D_THREADS) void k5_p_update(SweepV sw, RedSrc sr
         return;
     }
     const double rr0_new = d[1];
-    const double alpha = st->alpha, omega = st->omega;
-    const double beta = (alpha / omega) * rr0_new / st->rr0[it & 1];
+    const double beta = (alpha / omega) * rr0_new / rr0;
     const bool restart = fabs(rr0_new) / bnorm < tol;
     // next iteration's R·R0: after a restart R0 == R, so it is R·R in the same summation order
     if (lead) st->rr0[(it + 1) & 1] = restart ? d[0] : rr0_new;
@@ -1492,6 +1925,7 @@ template <> MatDev<FMT_SAV> mat_dev<FMT_SAV>(const MatView &A)
     m.nC = A.sav_nC;
     m.sdx = A.sav_step[1];
     m.pitch = A.sav_step[2];
+    m.planes = A.sav_step[2] > 0 ? A.sav_nC / A.sav_step[2] : 0;
     m.ncls = A.ncls;
     m.pm1 = A.pm1;
     m.a0 = A.sav_a0;
@@ -1519,6 +1953,11 @@ static inline SweepZ sweep_z(const Sweep &sw)
     z.patch_sdx = sw.patch_sdx;
     z.zm_tpp = sw.zm_tpp;
     z.keep = sw.nt >> 1;
+    z.rp_px = sw.rp_px;
+    z.rp_py = sw.rp_py;
+    z.rp_npx = sw.rp_npx;
+    z.rp_sdy = sw.rp_sdy;
+    z.rp_flag = sw.rp_flag;
     return z;
 }
 // dynamic LDS: the class table (a full 256-class table of the structured form would be 32 KiB and cap the CU
@@ -1526,6 +1965,8 @@ static inline SweepZ sweep_z(const Sweep &sw)
 // staging slots behind it (16 KiB): 24.6 KiB per workgroup, six of them fit a CU's 160 KiB
 static inline size_t tbl_bytes(const MatView &A, int F, bool zm, bool patch)
 {
+    // structured form on runtime-shaped 2-D tiles: table, two exchange buffers, two staging slots (sav_patch_step)
+    if (patch && F == FMT_SAV) return (size_t)A.ncls * EC3D_SAV_STRIDE * 8 + (size_t)(2 + EC3D_NSTAGE_RT) * EC3D_TILE * 8;
     if (patch) return (size_t)((F == FMT_DICT7 ? A.ncls * 7 + 1 : 0) & ~1) * 8 + (size_t)2 * EC3D_TILE * 8;
     if (F == FMT_DICT7) return (size_t)A.ncls * 7 * 8;
     if (F == FMT_SAV) return (size_t)A.ncls * EC3D_SAV_STRIDE * 8 + (zm ? (size_t)EC3D_NSTAGE * EC3D_TILE * 8 : 0);
@@ -1534,13 +1975,13 @@ static inline size_t tbl_bytes(const MatView &A, int F, bool zm, bool patch)
 #define EC3D_LAUNCH_ZT(F, NT_, KERNEL, ...)                                                                         \
     do {                                                                                                            \
         const bool tail_ = F != FMT_SAV && A.has_tail;                                                              \
-        const bool patch_ = zm_ && !tail_ && sw.patch_npx > 0 && F == FMT_DICT7; /* choose_sweep: dictionary only */ \
+        const bool patch_ = zm_ && !tail_ && ((sw.patch_npx > 0 && F == FMT_DICT7) || (sw.rp_px > 0 && F == FMT_SAV)); /* choose_sweep */ \
         const size_t lds_ = tbl_bytes(A, F, zm_, patch_);                                                           \
         const MatDev<F> Ad = mat_dev<F>(A);                                                                         \
         if constexpr (F != FMT_GENERIC) {                                                                           \
             if (zm_) {                                                                                              \
                 const SweepZ swz = sweep_z(sw);                                                                     \
-                if (patch_) { if constexpr (F == FMT_DICT7) KERNEL<F, NT_, true, false, true><<<sw.nblk, EC3D_THREADS, lds_, s>>>(Ad, swz, __VA_ARGS__); } \
+                if (patch_) { if constexpr (F == FMT_DICT7 || F == FMT_SAV) KERNEL<F, NT_, true, false, true><<<sw.nblk, EC3D_THREADS, lds_, s>>>(Ad, swz, __VA_ARGS__); } \
                 else if (tail_) { if constexpr (F != FMT_SAV) KERNEL<F, NT_, true, true, false><<<sw.nblk, EC3D_THREADS, lds_, s>>>(Ad, swz, __VA_ARGS__); } \
                 else KERNEL<F, NT_, true, false, false><<<sw.nblk, EC3D_THREADS, lds_, s>>>(Ad, swz, __VA_ARGS__);   \
                 break;                                                                                              \
@@ -1640,9 +2081,18 @@ void ec3d_launch_k3(const MatView &A, const Sweep &sw, SolverState *st, int it, 
 void ec3d_launch_k23(const MatView &A, const Sweep &sw, const RedSrc &src, SolverState *st, int it, const double *r,
                      const double *ap, double *sv, double *as, double *part, hipStream_t s)
 {
-    // the 2-D-tile dictionary kernels only (ec3d_fused23): one instantiation per cache policy
-    const MatDev<FMT_DICT7> Ad = mat_dev<FMT_DICT7>(A);
+    // the 2-D-tile kernels only (ec3d_fused23): dictionary cube and structured A-V form, one instance per cache policy
     const SweepZ swz = sweep_z(sw);
+    if (A.sav) {
+        const MatDev<FMT_SAV> Ad = mat_dev<FMT_SAV>(A);
+        const size_t lds = tbl_bytes(A, FMT_SAV, true, true);
+        if (nt_of(sw))
+            k23_s_spmv_dots<FMT_SAV, true, true, false, true><<<sw.nblk, EC3D_THREADS, lds, s>>>(Ad, swz, src, st, it, r, ap, sv, as, part);
+        else
+            k23_s_spmv_dots<FMT_SAV, false, true, false, true><<<sw.nblk, EC3D_THREADS, lds, s>>>(Ad, swz, src, st, it, r, ap, sv, as, part);
+        return;
+    }
+    const MatDev<FMT_DICT7> Ad = mat_dev<FMT_DICT7>(A);
     const size_t lds = tbl_bytes(A, FMT_DICT7, true, true);
     if (nt_of(sw))
         k23_s_spmv_dots<FMT_DICT7, true, true, false, true><<<sw.nblk, EC3D_THREADS, lds, s>>>(Ad, swz, src, st, it, r, ap, sv, as, part);
@@ -1654,8 +2104,17 @@ void ec3d_launch_k51(const MatView &A, const Sweep &sw, const RedSrc &src, Solve
                      const double *p_old, const double *ap_old, double *p_new, double *ap_new, double *r0, double *part,
                      double *hist, int64_t hist_cap, hipStream_t s)
 {
-    const MatDev<FMT_DICT7> Ad = mat_dev<FMT_DICT7>(A);
     const SweepZ swz = sweep_z(sw);
+    if (A.sav) {
+        const MatDev<FMT_SAV> Ad = mat_dev<FMT_SAV>(A);
+        const size_t lds = tbl_bytes(A, FMT_SAV, true, true);
+        if (nt_of(sw))
+            k51_p_spmv_dot<FMT_SAV, true, true, false, true><<<sw.nblk, EC3D_THREADS, lds, s>>>(Ad, swz, src, st, it, r, p_old, ap_old, p_new, ap_new, r0, part, hist, hist_cap);
+        else
+            k51_p_spmv_dot<FMT_SAV, false, true, false, true><<<sw.nblk, EC3D_THREADS, lds, s>>>(Ad, swz, src, st, it, r, p_old, ap_old, p_new, ap_new, r0, part, hist, hist_cap);
+        return;
+    }
+    const MatDev<FMT_DICT7> Ad = mat_dev<FMT_DICT7>(A);
     const size_t lds = tbl_bytes(A, FMT_DICT7, true, true);
     if (nt_of(sw))
         k51_p_spmv_dot<FMT_DICT7, true, true, false, true><<<sw.nblk, EC3D_THREADS, lds, s>>>(Ad, swz, src, st, it, r, p_old, ap_old, p_new, ap_new, r0, part, hist, hist_cap);

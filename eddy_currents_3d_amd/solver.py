@@ -30,7 +30,8 @@ class Geom(C.Structure):
     _fields_ = [("n_pad", C.c_int32), ("tile", C.c_int32), ("nblk", C.c_int32),
                 ("threads", C.c_int32), ("xcd_group", C.c_int32), ("zm_tpp", C.c_int32),
                 ("zm_pps", C.c_int32), ("ntiles_front", C.c_int32), ("ulist_n", C.c_int32),
-                ("patch_x", C.c_int32), ("patch_y", C.c_int32), ("patch_sdx", C.c_int32)]
+                ("patch_x", C.c_int32), ("patch_y", C.c_int32), ("patch_sdx", C.c_int32),
+                ("patch_pitch", C.c_int32), ("patch_sdy", C.c_int32)]
 
 
 class MatrixInfo(C.Structure):

@@ -299,7 +299,12 @@ typedef struct {
     int32_t patch_x, patch_y; /* > 0: a tile of this sweep is a patch of patch_x x patch_y grid cells (2-D tiles of   */
     int32_t patch_sdx;        /* the z-marching SpMV kernels on a grid with rows of patch_sdx cells): tile q of a plane
                                  is patch (q % (patch_sdx/patch_x), q / (patch_sdx/patch_x)); thread t owns the cells
-                                 2 (t % (patch_x/2)) and the next one of the patch's row t / (patch_x/2)               */
+                                 2t, 2t + 1 of the patch in row-major order (idle when 2t >= patch_x * patch_y)       */
+    int32_t patch_pitch;      /* device rows from one xy plane to the next (>= patch_sdx * patch_sdy) and grid rows   */
+    int32_t patch_sdy;        /* per plane: rows of the last patch row beyond patch_sdy do not exist (idle threads);
+                                 tile T lies in plane T / zm_tpp, first row of thread t =
+                                 (T / zm_tpp) * patch_pitch + (py * patch_y + 2t / patch_x) * patch_sdx + px * patch_x
+                                 + 2t % patch_x, (px, py) = the patch's position in the plane                          */
 } ec3d_geom;
 /* which = 0: K4 (dots R.R, R.R0); 1: SpMV kernels (B.B, initial R.R, AP.R0, AS.S, AS.AS); 2: K2 (dot S.S) */
 int ec3d_get_reduction_geometry(ec3d_handle h, int which, ec3d_geom *g);

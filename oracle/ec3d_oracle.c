@@ -148,12 +148,17 @@ static double block_tree(double *v, int threads)
 }
 
 /* first of the two consecutive rows thread t owns in `tile` (ec3d_row_of in the HIP source) */
+/* -1: the thread owns no rows of this tile (runtime-shaped patches: beyond the patch or beyond the grid's last row) */
 static int64_t gpu_row_of(const oracle_gpu_geom *g, int64_t tile, int t)
 {
     if (g->patch_x <= 0) return tile * g->tile + 2 * (int64_t)t;
-    const int64_t npx = g->patch_sdx / g->patch_x, hx = g->patch_x / 2;
+    const int64_t npx = g->patch_sdx / g->patch_x;
     const int64_t plane = tile / g->zm_tpp, q = tile % g->zm_tpp, py = q / npx, px = q % npx;
-    return plane * (int64_t)g->zm_tpp * g->tile + (py * g->patch_y + t / hx) * g->patch_sdx + px * g->patch_x + 2 * (t % hx);
+    const int64_t c0 = 2 * (int64_t)t, ty = c0 / g->patch_x, tx = c0 % g->patch_x;
+    const int64_t pitch = g->patch_pitch > 0 ? g->patch_pitch : (int64_t)g->zm_tpp * g->tile;
+    if (ty >= g->patch_y) return -1;
+    if (g->patch_sdy > 0 && py * g->patch_y + ty >= g->patch_sdy) return -1;
+    return plane * pitch + (py * g->patch_y + ty) * g->patch_sdx + px * g->patch_x + tx;
 }
 
 double oracle_dot_gpuorder(const oracle_gpu_geom *g, const double *a, const double *b, int64_t n)
@@ -184,6 +189,7 @@ double oracle_dot_gpuorder(const oracle_gpu_geom *g, const double *a, const doub
             }
             for (int t = 0; t < T; ++t) {
                 int64_t r = gpu_row_of(g, tile, t);
+                if (r < 0) continue; /* an idle thread adds nothing (the kernels add +0.0, which changes no sum) */
                 double p0 = r < n ? a[r] * b[r] : 0.0;
                 double p1 = r + 1 < n ? a[r + 1] * b[r + 1] : 0.0;
                 acc[t] = acc[t] + p0;

@@ -35,7 +35,8 @@ class GpuGeom(C.Structure):
                 ("zm_pps", C.c_int32), ("ntiles_front", C.c_int32), ("ulist_n", C.c_int32),
                 ("ulist", C.POINTER(C.c_int32)), ("visit_nwg", C.c_int32),
                 ("visit_off", C.POINTER(C.c_int32)), ("visit", C.POINTER(C.c_int32)),
-                ("patch_x", C.c_int32), ("patch_y", C.c_int32), ("patch_sdx", C.c_int32)]
+                ("patch_x", C.c_int32), ("patch_y", C.c_int32), ("patch_sdx", C.c_int32),
+                ("patch_pitch", C.c_int32), ("patch_sdy", C.c_int32)]
 
 
 def build(with_ref: bool = True) -> None:
@@ -136,7 +137,8 @@ def geoms_of(solver):
         gg = GpuGeom(n_pad=g.n_pad, tile=g.tile, nblk=g.nblk, threads=g.threads, xcd_group=g.xcd_group,
                      zm_tpp=g.zm_tpp, zm_pps=g.zm_pps, ntiles_front=g.ntiles_front, ulist_n=g.ulist_n,
                      ulist=ul.ctypes.data_as(C.POINTER(C.c_int32)), patch_x=g.patch_x, patch_y=g.patch_y,
-                     patch_sdx=g.patch_sdx)
+                     patch_sdx=g.patch_sdx, patch_pitch=getattr(g, "patch_pitch", 0),
+                     patch_sdy=getattr(g, "patch_sdy", 0))
         gg._keep = ul  # the struct only holds a pointer
         if hasattr(solver, "visit_order"):   # the library's own account of its launches, tile by tile
             off, tiles = solver.visit_order(which)

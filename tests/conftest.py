@@ -37,3 +37,15 @@ def plane_pitch(request, monkeypatch):
     else:
         monkeypatch.delenv("EC3D_PITCH", raising=False)
     return request.param
+
+
+@pytest.fixture(params=["linear", "patch", "patch-fused"])
+def sav_tiles(request, monkeypatch):
+    """Tiles of the z-marching structured A-V kernels: 512 consecutive cells (sav_pair_zm), runtime-shaped 2-D
+    patches (sav_patch_step, forced on the small fixture grids, where the library would not pick them), and the
+    patches with K2 inside K3 and K5 inside the next K1 (three launches per iteration)."""
+    monkeypatch.setenv("EC3D_SAV_PATCH", "0" if request.param == "linear" else "2")
+    fuse = "2" if request.param == "patch-fused" else "0"
+    monkeypatch.setenv("EC3D_FUSE23", fuse)
+    monkeypatch.setenv("EC3D_FUSE51", fuse)
+    return request.param

@@ -2,8 +2,9 @@
 GPU-order twin, bit for bit.
 
 choose_sweep (csrc/ec3d_context.hip) switches by size: nontemporal streams from 4.5 Mi rows, the next kernel's operand
-kept cacheable up to 32 Mi rows, and from 32 Mi rows on 2-D tiles the three-launch iteration (K2 inside K3, K5 inside
-the next K1, P / AP in alternating buffers) with the vector kernels on 256 workgroups, two tiles in flight.  The small
+kept cacheable up to 32 Mi rows, from 32 Mi rows the vector kernels on 256 workgroups with two tiles in flight, and from
+64 Mi rows on 2-D tiles the three-launch iteration (K2 inside K3, K5 inside the next K1, P / AP in alternating
+buffers).  The small
 parity cases force those instances through EC3D_NT / EC3D_KEEP / EC3D_FUSE* (tests/test_gpu_parity.py); here NOTHING is
 forced -- the handle is built the way bench.py builds it and the twin follows the launch geometry the library reports
 (ec3d_get_visit_order), for the first iterations of src/solvers.f90:24-50 (the itmax exit of :25-29 ends the run; the
@@ -28,12 +29,14 @@ def no_knobs(monkeypatch):
         monkeypatch.delenv(k, raising=False)
 
 
-@pytest.mark.parametrize("dims, fused, iters", [((256, 256, 80), False, 8), ((512, 512, 128), True, 6)],
-                         ids=["5Mi-rows-nt-keep", "32Mi-rows-three-launches"])
+@pytest.mark.parametrize("dims, fused, iters", [((256, 256, 80), False, 8), ((512, 512, 128), False, 6),
+                                                ((512, 512, 256), True, 4)],
+                         ids=["5Mi-rows-nt-keep", "32Mi-rows-all-nontemporal", "64Mi-rows-three-launches"])
 def test_cube_at_the_default_policy_bitwise(E, oracle, dims, fused, iters, monkeypatch):
     """Single-component operator (BASELINE configs 2 / 4 family).  256 x 256 x 80 = 5.2 M rows: nontemporal streams,
-    AP / S / R kept cacheable, 2-D tiles, five launches.  512 x 512 x 128 = 2^25 rows: the size from which fusion and
-    the all-nontemporal policy switch on by themselves -- the configuration of the headline 512^3 run."""
+    AP / S / R kept cacheable, 2-D tiles, five launches.  512 x 512 x 128 = 2^25 rows: everything nontemporal, the
+    vector kernels on 256 workgroups with two tiles in flight.  512 x 512 x 256 = 2^26 rows: the size from which K2 runs
+    inside K3 and K5 inside the next K1 by themselves -- the configuration of the headline 512^3 run."""
     no_knobs(monkeypatch)
     sdx, sdy, sdz = dims
     n = sdx * sdy * sdz

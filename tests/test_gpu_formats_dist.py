@@ -152,7 +152,7 @@ def test_zmarch_spmv_and_solve_bitwise(E, oracle, dims, dic):
     with E.EC3DSolver(dictionary=dic) as s:
         s.assemble_poisson(sdx, sdy, sdz)
         gs = s.geometry(1)
-        assert gs.zm_tpp == sdx * sdy // 512 and gs.zm_pps >= 8
+        assert gs.zm_tpp == sdx * sdy // 512 and gs.zm_pps >= 2
         assert np.array_equal(s.spmv(x), oracle.spmv_csr(valA, irow, jcol, x))
         xs, it, hist = s.solve(b, np.zeros(n), 1e-9, 5000, hist_cap=64)
         xo, ito, hs, hr = oracle.twin_solve(s, valA, irow, jcol, b, np.zeros(n), 1e-9,
@@ -279,10 +279,13 @@ def test_split_spmv_is_the_same_operator(E, oracle):
 # ------------------------------------------------------------------------- structured A-V form
 @pytest.mark.parametrize("name", ["g2_conducting_hole_16x15x14", "g2v_conducting_moving_16x15x14",
                                   "g3_moving_coil_18x16x12", "g2i_itmax_exit_16x15x14"])
-def test_structured_av_form(E, oracle, name, plane_pitch):
+def test_structured_av_form(E, oracle, name, plane_pitch, sav_tiles):
     """ec3d_assemble's default storage for the A-V system: U embedded in the grid, every coupling a
     class-coded stencil slot, no tail.  The operator is the reference's (exported CSR and SpMV bit-identical)
-    and the solve is bit-identical to the oracle's twin run on the system in device numbering."""
+    and the solve is bit-identical to the oracle's twin run on the system in device numbering -- on linear tiles,
+    on runtime-shaped 2-D tiles and with the fused three-launch iteration on them."""
+    if sav_tiles != "linear" and plane_pitch != "pitched":
+        pytest.skip("2-D tiles need the z-marching (pitched) layout")
     g = load_golden(name)
     n = len(g["irow"]) - 1
     tol, itmax = float(g["tol"]), int(g["itmax"])
@@ -296,6 +299,8 @@ def test_structured_av_form(E, oracle, name, plane_pitch):
         nC_dev = g["geoPHYS"].size if plane_pitch == "auto" else sdz * (-(-sdx * sdy // 512) * 512)
         assert rm.max() < 4 * nC_dev and np.all(np.diff(rm) > 0)
         assert (s.geometry(1).zm_tpp > 0) == (plane_pitch == "pitched")
+        assert (s.geometry(1).patch_x > 0) == (sav_tiles != "linear")
+        assert s.fusion() == ((1, 1) if sav_tiles == "patch-fused" else (0, 0))
         va, ir, jc = s.export_csr()
         assert np.array_equal(ir, g["irow"]) and np.array_equal(jc, g["jcol"]) and np.array_equal(va, g["valA"])
         assert np.array_equal(s.spmv(x), oracle.spmv_csr(g["valA"], g["irow"], g["jcol"], x))
@@ -314,10 +319,12 @@ def test_structured_av_form(E, oracle, name, plane_pitch):
 
 
 @pytest.mark.parametrize("name", ["g2_conducting_hole_16x15x14", "g3_moving_coil_18x16x12", "g1_nonconducting_8x7x6"])
-def test_structured_form_recognised_in_csr(E, oracle, name, plane_pitch):
+def test_structured_form_recognised_in_csr(E, oracle, name, plane_pitch, sav_tiles):
     """The drop-in route: the reference's CSR goes in, the structure is recognised entry by entry
     (ec3d_sav_csr.cpp) and the handle ends up in the same class-coded form ec3d_assemble builds natively --
     same row map, same operator bit for bit, same solve."""
+    if sav_tiles != "linear" and plane_pitch != "pitched":
+        pytest.skip("2-D tiles need the z-marching (pitched) layout")
     g = load_golden(name)
     n = len(g["irow"]) - 1
     tol, itmax = float(g["tol"]), int(g["itmax"])
@@ -337,6 +344,86 @@ def test_structured_form_recognised_in_csr(E, oracle, name, plane_pitch):
         assert it == ito and np.array_equal(xs, xo) and np.array_equal(hist[:min(it, 64), 0], hs[:min(it, 64)])
         xn, itn, _ = nat.solve(g["b0"], g["xin0"], tol, itmax)
         assert itn == it and np.array_equal(xn, xs)
+
+
+def synthetic_av(sdx, sdy, sdz, block, hole=None):
+    """A small A-V system on any grid: one conducting block (i0, i1, j0, j1, k0, k1; 0-based, end exclusive) with an
+    optional hole through it, air elsewhere; arrays as ec3d_assemble takes them (src/m_vxc2data.f90:43-52)."""
+    mu0 = 0.12566370964050292e-05
+    geo = np.full((sdz, sdy, sdx), 2, np.int8)
+    i0, i1, j0, j1, k0, k1 = block
+    geo[k0:k1, j0:j1, i0:i1] = 1
+    if hole:
+        a0, a1, b0, b1 = hole
+        geo[k0:k1, b0:b1, a0:a1] = 2
+    flat = geo.reshape(-1)
+    geoC = np.zeros(flat.size, np.int32)
+    idx = np.flatnonzero(flat == 1)
+    geoC[idx] = 3 * flat.size + 1 + np.arange(idx.size)
+    valPHYS = np.zeros((2, 5))
+    valPHYS[:, 0] = 1.0
+    valPHYS[0, 1] = mu0 * 35.26e6
+    valPHYS[0, 2:5] = (0.3, -0.2, 0.1)          # a moving conductor: the advection terms of src/EC3D.f90:657-662
+    return geo, geoC.reshape(geo.shape), valPHYS, np.array([[-0.95, -0.9], [-0.85, -0.8], [-0.75, -0.7]]), \
+        np.array([0.004, 0.005, 0.003]), 1e-3
+
+
+@pytest.mark.parametrize("fuse", ["0", "2"])
+@pytest.mark.parametrize("dims,px,block,hole", [
+    ((64, 22, 12), "32", (9, 52, 4, 19, 3, 9), (28, 36, 9, 14)),    # 2 patch columns of 32 x 16, ragged second patch row
+    ((96, 21, 10), "48", (5, 90, 3, 18, 2, 8), (40, 60, 8, 13)),    # 48 x 10 (480-cell patches: idle threads), ragged rows
+    ((102, 23, 9), None, (7, 95, 4, 20, 2, 7), (50, 56, 10, 14)),   # the picker's own shape for a 102-wide grid: 102 x 5
+])
+def test_structured_form_on_runtime_shaped_tiles(E, oracle, dims, px, block, hole, fuse, monkeypatch):
+    """sav_patch_step on shapes the captured fixtures cannot reach: several patch columns, patches of fewer than 512
+    cells (threads beyond the patch idle), a ragged last patch row (rows beyond the grid idle), a conductor -- with a
+    hole, so every one-sided A-U stencil and Neumann-mirrored U row occurs -- that crosses patch boundaries in x and y.
+    A*x == the oracle's CSR row sums of the matrix the oracle's gen_sparse_matrix builds (src/EC3D.f90:465-1049), the
+    solve == the twin, bit for bit, with and without the fused launches; and the linear tiles give the same A*x."""
+    sdx, sdy, sdz = dims
+    geo, geoC, valPHYS, BND, delta, dt = synthetic_av(sdx, sdy, sdz, block, hole)
+    m = oracle.gen_sparse_matrix(geo, geoC, valPHYS, BND, delta, dt)
+    n = m["n"]
+    rng = np.random.Generator(np.random.PCG64(606))
+    x = rng.standard_normal(n)
+    b = rng.standard_normal(n)
+    monkeypatch.setenv("EC3D_PITCH", "2")
+    monkeypatch.setenv("EC3D_FUSE23", fuse)
+    monkeypatch.setenv("EC3D_FUSE51", fuse)
+    ys = {}
+    for tiles in ("2", "0"):
+        monkeypatch.setenv("EC3D_SAV_PATCH", tiles)
+        if px and tiles == "2":
+            monkeypatch.setenv("EC3D_SAV_PATCH_PX", px)
+        else:
+            monkeypatch.delenv("EC3D_SAV_PATCH_PX", raising=False)
+        with E.EC3DSolver() as s:
+            s.assemble(geo, geoC, valPHYS, BND, delta, dt)
+            g1 = s.geometry(1)
+            if tiles == "2":
+                want_px = int(px) if px else 102
+                assert (g1.patch_x, g1.patch_y, g1.patch_sdx, g1.patch_sdy) == (want_px, 512 // want_px, sdx, sdy)
+                assert g1.zm_tpp == (sdx // want_px) * -(-sdy // (512 // want_px))
+                assert s.fusion() == ((1, 1) if fuse == "2" else (0, 0))
+            else:
+                assert g1.patch_x == 0 and g1.zm_tpp > 0
+            va, ir, jc = s.export_csr()
+            assert np.array_equal(ir, m["irow"]) and np.array_equal(jc, m["jcol"]) and np.array_equal(va, m["valA"])
+            ys[tiles] = s.spmv(x)
+            assert np.array_equal(ys[tiles], oracle.spmv_csr(m["valA"], m["irow"], m["jcol"], x))
+            # unpreconditioned BiCGSTAB stagnates on these little systems with a random right-hand side (the reference's
+            # own solver does: itmax exit); parity does not need convergence -- 150 iterations through the itmax exit
+            # (src/solvers.f90:25-29), every ||S||, ||R|| of the history and x against the twin
+            xs, it, hist = s.solve(b, np.zeros(n), 1e-12, 149, hist_cap=150)
+            xo, ito, hs, hr = oracle.twin_solve(s, m["valA"], m["irow"], m["jcol"], b, np.zeros(n), 1e-12, 149, hist_cap=150)
+            assert it == ito == 150 and np.array_equal(xs, xo)
+            assert np.array_equal(hist[:150, 0], hs[:150]) and np.array_equal(hist[:150, 1], hr[:150])
+            assert s.restart_count() == oracle.last_restart_count()
+            # a warm start on the same handle: the alternating P / AP buffers of the fused iteration start clean
+            xw, itw, _ = s.solve(b, 0.5 * xs, 1e-12, 5)
+            xwo, itwo, _, _ = oracle.twin_solve(s, m["valA"], m["irow"], m["jcol"], b, 0.5 * xs, 1e-12, 5)
+            assert itw == itwo == 6 and np.array_equal(xw, xwo)
+    assert np.array_equal(ys["2"], ys["0"])
 
 
 def test_structured_form_needs_the_reference_row_order(E, oracle):

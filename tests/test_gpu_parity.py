@@ -157,6 +157,31 @@ def test_solve_bitwise_vs_gpu_order_oracle(E, oracle, name, policy, plane_pitch,
                 assert np.array_equal(hist[:it - 1, 1], hr[:it - 1])
 
 
+@pytest.mark.parametrize("policy", POLICIES[1:], ids=lambda p: f"nt{p[0]}-keep{p[1]}")
+@pytest.mark.parametrize("name", ["g2_conducting_hole_16x15x14", "g3_moving_coil_18x16x12"])
+def test_structured_two_dimensional_tiles_every_policy(E, oracle, name, policy, sav_tiles, monkeypatch):
+    """The structured A-V kernels on runtime-shaped 2-D tiles (sav_patch_step), unfused and with K2 inside K3 / K5
+    inside the next K1, under the nontemporal policies their sizes run with by default: every captured call bit-identical
+    to the twin."""
+    if sav_tiles == "linear":
+        pytest.skip("covered by test_solve_bitwise_vs_gpu_order_oracle")
+    set_policy(monkeypatch, policy)
+    monkeypatch.setenv("EC3D_PITCH", "2")
+    g = load_golden(name)
+    tol, itmax = float(g["tol"]), int(g["itmax"])
+    with E.EC3DSolver() as s:
+        s.set_matrix_csr(g["valA"], g["irow"], g["jcol"])
+        assert s.geometry(1).patch_x > 0 and s.fusion() == ((1, 1) if sav_tiles == "patch-fused" else (0, 0))
+        for k in range(len(g["iters"])):
+            x, it, hist = s.solve(g[f"b{k}"], g[f"xin{k}"], tol, itmax, hist_cap=400)
+            xo, ito, hs, hr = oracle.twin_solve(s, g["valA"], g["irow"], g["jcol"], g[f"b{k}"], g[f"xin{k}"], tol, itmax,
+                                                hist_cap=400)
+            assert it == ito and np.array_equal(x, xo)
+            assert np.array_equal(hist[:it, 0], hs[:it])
+            if it > 1:
+                assert np.array_equal(hist[:it - 1, 1], hr[:it - 1])
+
+
 @pytest.mark.parametrize("name", CAPTURED)
 def test_solve_vs_reference_fixture(E, name):
     """Against the unmodified reference's outputs: fields within 10*tol, iterations side by side."""
