@@ -13,6 +13,7 @@
 #define EC3D_TILE 512 /* rows per tile: every thread owns 2 consecutive rows (one 16-B access) */
 #define EC3D_MAXB 16  /* DIA bands */
 #define EC3D_CHUNK 64 /* sliced-ELL slice height = one wavefront */
+#define EC3D_OUT_SLOTS 3 /* pinned host buffers of the overlapped field output (ec3d_vtk_fields_begin) */
 #ifndef EC3D_PX
 #define EC3D_PX 128   /* 2-D tile (patch) of the z-marching kernels: cells along x (one wave = one patch row) ... */
 #endif
@@ -319,14 +320,15 @@ struct ec3d_ctx {
     int32_t *src_idx = nullptr;    // per-step source scatter staging
     double *src_val = nullptr;
     int64_t src_cap = 0;
+    std::vector<uint64_t> src_seen; // host: one bit per A unknown, all zero between calls (repeat check of ec3d_rhs_step)
     // field output (ec3d_output.hip): device scratch for the four float32 vectors, the conductor mask, and -- for
     // output overlapped with the next time step -- a side stream with two pinned host buffers
     float *out_dev = nullptr;
     int64_t out_cells = 0;
     int32_t *out_mask = nullptr;
-    float *out_pinned[2] = {nullptr, nullptr};
+    float *out_pinned[EC3D_OUT_SLOTS] = {nullptr, nullptr, nullptr};
     hipStream_t out_stream = nullptr;
-    hipEvent_t out_ev_fields = nullptr, out_ev_free = nullptr, out_ev_copied[2] = {nullptr, nullptr};
+    hipEvent_t out_ev_fields = nullptr, out_ev_free = nullptr, out_ev_copied[EC3D_OUT_SLOTS] = {nullptr, nullptr, nullptr};
     int out_next = 0;
     bool out_busy = false;
 };

@@ -101,7 +101,7 @@ int output_prepare(ec3d_ctx *c, bool pinned)
         EC3D_HIP(hipStreamCreateWithFlags(&c->out_stream, hipStreamNonBlocking));
         EC3D_HIP(hipEventCreateWithFlags(&c->out_ev_fields, hipEventDisableTiming));
         EC3D_HIP(hipEventCreateWithFlags(&c->out_ev_free, hipEventDisableTiming));
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < EC3D_OUT_SLOTS; ++i) {
             EC3D_HIP(hipEventCreateWithFlags(&c->out_ev_copied[i], hipEventDisableTiming));
             EC3D_HIP(hipHostMalloc(&c->out_pinned[i], (size_t)12 * nOwn * sizeof(float), hipHostMallocDefault));
         }
@@ -137,7 +137,7 @@ void ec3d_free_output(ec3d_ctx *c)
     c->out_dev = nullptr;
     c->out_mask = nullptr;
     c->out_cells = 0;
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < EC3D_OUT_SLOTS; ++i) {
         if (c->out_pinned[i]) (void)hipHostFree(c->out_pinned[i]);
         c->out_pinned[i] = nullptr;
         if (c->out_ev_copied[i]) (void)hipEventDestroy(c->out_ev_copied[i]);
@@ -178,14 +178,14 @@ extern "C" int ec3d_vtk_fields(ec3d_handle c, const double *delta, float *field_
 // Field output overlapped with the next time step (the reference writes field_N.vtk every output step,
 // src/EC3D.f90:436-444 -> src/utilites.f90:171-293, while nothing else happens; here the next step's right-hand side
 // and solve run meanwhile).  _begin enqueues the field kernel on the compute stream -- so it sees exactly the X and B
-// the synchronous call would -- and the copy of the four vectors into one of two PINNED host buffers on a side stream,
+// the synchronous call would -- and the copy of the four vectors into one of EC3D_OUT_SLOTS (3) PINNED host buffers on a side stream,
 // and returns at once; _wait blocks (on the copy's event only) and hands out the buffer.
 extern "C" int ec3d_vtk_fields_begin(ec3d_handle c, const double *delta, int32_t big_endian, int32_t *slot)
 {
     int rc = output_prepare(c, true);
     if (rc) return rc;
     if (!slot) return 2;
-    const int i = c->out_next & 1;
+    const int i = c->out_next % EC3D_OUT_SLOTS;
     // the device buffer is written again only once the previous copy has read it (one buffer on the device: the copy
     // takes ~10 ms of a time step that lasts several times that)
     if (c->out_busy) EC3D_HIP(hipStreamWaitEvent(c->stream, c->out_ev_free, 0));
@@ -197,7 +197,7 @@ extern "C" int ec3d_vtk_fields_begin(ec3d_handle c, const double *delta, int32_t
     EC3D_HIP(hipEventRecord(c->out_ev_copied[i], c->out_stream));
     EC3D_HIP(hipEventRecord(c->out_ev_free, c->out_stream));
     c->out_busy = true;
-    c->out_next = i ^ 1;
+    c->out_next = (i + 1) % EC3D_OUT_SLOTS;
     *slot = i;
     return 0;
 }
@@ -205,7 +205,7 @@ extern "C" int ec3d_vtk_fields_begin(ec3d_handle c, const double *delta, int32_t
 extern "C" int ec3d_vtk_fields_wait(ec3d_handle c, int32_t slot, const float **field_A, const float **field_eddy,
                                     const float **field_source, const float **field_B, int64_t *ncells)
 {
-    if (!c || slot < 0 || slot > 1 || !c->out_pinned[slot]) {
+    if (!c || slot < 0 || slot >= EC3D_OUT_SLOTS || !c->out_pinned[slot]) {
         ec3d_set_error("ec3d_vtk_fields_wait: no such slot (call ec3d_vtk_fields_begin first)");
         return 2;
     }

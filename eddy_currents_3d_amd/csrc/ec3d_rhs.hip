@@ -189,14 +189,27 @@ extern "C" int ec3d_rhs_step(ec3d_handle c, int32_t moving, int32_t nsrc, const 
         std::vector<int32_t> idx;
         std::vector<double> val;
         bool dup = false;
-        for (int32_t q = 0; q < nsrc; ++q) {
+        for (int32_t q = 0; q < nsrc; ++q)
             if (src_index[q] < 1 || src_index[q] > 3 * nCells) {
                 ec3d_set_error("ec3d_rhs_step: source index out of range (sources act on Ax, Ay, Az)");
                 return 2;
             }
-            dup |= !last.emplace(src_index[q], src_value[q]).second;
-            last[src_index[q]] = src_value[q];
+        {   // Does a cell appear twice?  One bit per A unknown, set on the way in and cleared again on the way out: the
+            // coils of config 5 are 317 088 cells per step, and the hash map that used to answer this question for every
+            // step cost more host time than the step's other calls together (it is still what resolves a real repeat).
+            const size_t words = (size_t)(3 * nCells + 63) / 64 + 1;
+            if (c->src_seen.size() != words) c->src_seen.assign(words, 0);
+            uint64_t *seen = c->src_seen.data();
+            for (int32_t q = 0; q < nsrc; ++q) {
+                const uint32_t id = (uint32_t)src_index[q];
+                const uint64_t bit = 1ull << (id & 63);
+                dup |= (seen[id >> 6] & bit) != 0;
+                seen[id >> 6] |= bit;
+            }
+            for (int32_t q = 0; q < nsrc; ++q) seen[(uint32_t)src_index[q] >> 6] = 0;
         }
+        if (dup)
+            for (int32_t q = 0; q < nsrc; ++q) last[src_index[q]] = src_value[q];
         auto dev_of = [&](int32_t id1) { // 1-based reference id of an A unknown -> device row
             const int64_t r0 = (int64_t)id1 - 1;
             return (int32_t)((r0 / nCells) * nCd + c->dev_cell(r0 % nCells));

@@ -210,28 +210,43 @@ class _OutputPipeline:
     ``ec3d_vtk_fields_begin`` puts the field kernel behind the post-update on the solver's stream and the copy of
     the four vectors (already in the file's big-endian byte order) into one of two pinned buffers on a side stream,
     the loop goes on, and this thread waits for the copy, hands the views to ``on_fields`` and writes the bytes as
-    they are.  At most two outputs are in flight (two pinned buffers): before output N is started, output N-2 must
-    have left its buffer."""
+    they are.  As many outputs are in flight as the library has pinned buffers (three; one writer thread each, since
+    one write() stream fills the page cache at 3-4 GB/s and a 9 M-cell step is 566 MB): before output N is started,
+    output N-3 must have left its buffer.  src_N.vtk needs nothing from the device and goes through threads of its own."""
 
-    def __init__(self, solver, dims, delta, out_dir, on_fields):
+    def __init__(self, solver, dims, delta, out_dir, on_fields, on_written=None):
         import queue
         import threading
         self.solver, self.dims, self.delta, self.out_dir, self.on_fields = solver, dims, delta, out_dir, on_fields
+        self.on_written = on_written
         self.jobs = queue.Queue()
         self.done = []                  # one threading.Event per started output, in order
         self.error = None
         self._Event = threading.Event
-        self.thread = threading.Thread(target=self._work, name="ec3d-output", daemon=True)
-        self.thread.start()
+        # src_N.vtk needs nothing from the device: it is formatted and written on a thread of its own from the moment
+        # the step's sources are known (81 MB of corner coordinates per step on config 5)
+        from concurrent.futures import ThreadPoolExecutor
+        self.src_pool = ThreadPoolExecutor(max_workers=2, thread_name_prefix="ec3d-src")
+        from .solver import VTK_SLOTS
+        self.slots = VTK_SLOTS
+        self.threads = [threading.Thread(target=self._work, name=f"ec3d-output-{i}", daemon=True)
+                        for i in range(self.slots)]
+        for th in self.threads:
+            th.start()
 
     def start(self, N, groups, write, info):
-        if len(self.done) >= 2:
-            self.done[-2].wait()        # the buffer this output is going to use is free again
+        if len(self.done) >= self.slots:
+            self.done[-self.slots].wait()   # the buffer this output is going to use is free again
         self._raise()
         slot = self.solver.vtk_fields_begin(self.delta, big_endian=True)
         ev = self._Event()
         self.done.append(ev)
-        self.jobs.put((slot, N, groups, write, info, ev))
+        src = None
+        if write and groups:                                                # src/EC3D.f90:446  CALL writeVtk_src
+            sdx, sdy, sdz = self.dims
+            src = self.src_pool.submit(write_src_vtk, os.path.join(self.out_dir, f"src_{N}.vtk"), sdx, sdy, sdz,
+                                       self.delta, groups)
+        self.jobs.put((slot, N, src, write, info, ev))
 
     def _work(self):
         sdx, sdy, sdz = self.dims
@@ -239,15 +254,19 @@ class _OutputPipeline:
             job = self.jobs.get()
             if job is None:
                 return
-            slot, N, groups, write, info, ev = job
+            slot, N, src, write, info, ev = job
             try:
                 f = self.solver.vtk_fields_wait(slot, big_endian=True)      # views of the pinned buffer
                 if self.on_fields is not None:
                     self.on_fields(N, f, info)
                 if write:
-                    write_field_vtk(os.path.join(self.out_dir, f"field_{N}.vtk"), sdx, sdy, sdz, self.delta, f)
-                    if groups:                                              # src/EC3D.f90:446  CALL writeVtk_src
-                        write_src_vtk(os.path.join(self.out_dir, f"src_{N}.vtk"), sdx, sdy, sdz, self.delta, groups)
+                    paths = [os.path.join(self.out_dir, f"field_{N}.vtk")]
+                    write_field_vtk(paths[0], sdx, sdy, sdz, self.delta, f)
+                    if src is not None:
+                        src.result()
+                        paths.append(os.path.join(self.out_dir, f"src_{N}.vtk"))
+                    if self.on_written is not None:
+                        self.on_written(N, paths)
             except BaseException as e:  # reported by the loop's thread at its next output, or at the end
                 self.error = e
             finally:
@@ -259,13 +278,52 @@ class _OutputPipeline:
             raise e
 
     def finish(self):
-        self.jobs.put(None)
-        self.thread.join()
+        for _ in self.threads:
+            self.jobs.put(None)
+        for th in self.threads:
+            th.join()
+        self.src_pool.shutdown(wait=True)
         self._raise()
 
 
+class _SourcesAhead:
+    """The source program of the NEXT time steps evaluated while the GPU solves this one.  Sources and their motion
+    are functions of time alone (src/EC3D.f90:245-340 never reads the solution), so step k + 1's (unknown id, value)
+    list -- 317 088 moving cells on config 5, 18 ms of numpy per step -- does not have to wait for solve k: a thread
+    walks the same sequence T = 0, T + DT, ... (same floating-point accumulation as the loop) at most two steps ahead."""
+
+    def __init__(self, prog, T, DT, Time, steps):
+        import queue
+        import threading
+        self.q = queue.Queue(maxsize=2)
+        self.error = None
+
+        def work():
+            try:
+                t, k = T, 0
+                while True:
+                    idx, val, moving = prog.step(t)
+                    self.q.put((t, idx, val, moving, list(prog.groups)))
+                    k += 1
+                    t = t + DT
+                    if not t < Time or (steps is not None and k >= steps):
+                        break
+            except BaseException as e:
+                self.error = e
+                self.q.put(None)
+        self.thread = threading.Thread(target=work, name="ec3d-sources", daemon=True)
+        self.thread.start()
+
+    def next(self, T):
+        item = self.q.get()
+        if item is None:
+            raise self.error
+        assert item[0] == T
+        return item[1:]
+
+
 def run(model: vxc.VxcModel, solver, steps: int | None = None, out_dir: str | None = None, on_step=None,
-        on_rhs=None, on_solved=None, write_output=None, overlap_output: bool = True, on_fields=None):
+        on_rhs=None, on_solved=None, write_output=None, overlap_output: bool = True, on_fields=None, on_written=None):
     """The reference's run of ``model`` on ``solver`` (an EC3DSolver): assemble, then step until T >= stop (or
     ``steps`` steps).  Returns a list of per-step dicts (T, iter).  ``out_dir``: write ``field_N.vtk`` there at
     the reference's output cadence.  Hooks, all ``(k, solver, info)``: ``on_rhs`` when Jaf (B) of step k is
@@ -278,7 +336,9 @@ def run(model: vxc.VxcModel, solver, steps: int | None = None, out_dir: str | No
     kernel and device-to-host copy asynchronously, formatting-free writing on a host thread (_OutputPipeline); the
     files are the same bytes.  ``on_fields(N, fields, info)`` is then called on that thread with views of the pinned
     buffer (valid during the call).  Without overlap the fields are fetched synchronously after the post-update,
-    ``on_fields`` is called in the loop and ``info["fields"]`` holds them when they are not written."""
+    ``on_fields`` is called in the loop and ``info["fields"]`` holds them when they are not written.
+    ``on_written(N, paths)``: after output step N's files are complete (a run of hundreds of 500 MB files may want
+    to move them away)."""
     t = vxc.domain_tables(model)
     if t["dt"] is None or t["time"] is None:
         raise ValueError("the model has no 'tran stop=... step=...' line")
@@ -297,11 +357,11 @@ def run(model: vxc.VxcModel, solver, steps: int | None = None, out_dir: str | No
         os.makedirs(out_dir, exist_ok=True)
     pipe = None
     if out_dir and overlap_output and hasattr(solver, "vtk_fields_begin"):
-        pipe = _OutputPipeline(solver, (sdx, sdy, sdz), t["delta"], out_dir, on_fields)
+        pipe = _OutputPipeline(solver, (sdx, sdy, sdz), t["delta"], out_dir, on_fields, on_written)
     log = []
     try:
         log = _time_loop(solver, t, prog, (sdx, sdy, sdz), conducting, out_dir, pipe, steps, on_step, on_rhs, on_solved,
-                         write_output, on_fields, DT, Time, Nout, T, Ntime, Nprint, Npoint)
+                         write_output, on_fields, on_written, DT, Time, Nout, T, Ntime, Nprint, Npoint)
     finally:
         if pipe is not None:
             pipe.finish()
@@ -309,11 +369,12 @@ def run(model: vxc.VxcModel, solver, steps: int | None = None, out_dir: str | No
 
 
 def _time_loop(solver, t, prog, dims, conducting, out_dir, pipe, steps, on_step, on_rhs, on_solved, write_output,
-               on_fields, DT, Time, Nout, T, Ntime, Nprint, Npoint):
+               on_fields, on_written, DT, Time, Nout, T, Ntime, Nprint, Npoint):
     sdx, sdy, sdz = dims
     log = []
+    ahead = _SourcesAhead(prog, T, DT, Time, steps)
     while True:
-        idx, val, moving = prog.step(T)
+        idx, val, moving, groups = ahead.next(T)
         info = dict(T=T, nsrc=len(idx))
         solver.rhs_step(idx, val, moving=moving)
         if on_rhs is not None:
@@ -327,16 +388,19 @@ def _time_loop(solver, t, prog, dims, conducting, out_dir, pipe, steps, on_step,
             Nprint = Ntime + Nout
             Npoint += 1
             if out_dir and pipe is not None:
-                pipe.start(Npoint, list(prog.groups), write_output is None or bool(write_output(Npoint)), info)
+                pipe.start(Npoint, groups, write_output is None or bool(write_output(Npoint)), info)
             elif out_dir:
                 f = solver.vtk_fields(t["delta"], sdx * sdy * sdz, conducting)
                 if on_fields is not None:
                     on_fields(Npoint, f, info)
                 if write_output is None or write_output(Npoint):
-                    write_field_vtk(os.path.join(out_dir, f"field_{Npoint}.vtk"), sdx, sdy, sdz, t["delta"], f)
-                    if prog.groups:                      # :446  CALL writeVtk_src
-                        write_src_vtk(os.path.join(out_dir, f"src_{Npoint}.vtk"), sdx, sdy, sdz, t["delta"],
-                                      prog.groups)
+                    paths = [os.path.join(out_dir, f"field_{Npoint}.vtk")]
+                    write_field_vtk(paths[0], sdx, sdy, sdz, t["delta"], f)
+                    if groups:                           # :446  CALL writeVtk_src
+                        paths.append(os.path.join(out_dir, f"src_{Npoint}.vtk"))
+                        write_src_vtk(paths[1], sdx, sdy, sdz, t["delta"], groups)
+                    if on_written is not None:
+                        on_written(Npoint, paths)
                 else:
                     info["fields"] = f
             info["output"] = Npoint

@@ -47,6 +47,7 @@ class CsrProbe(C.Structure):
 
 
 VEC = dict(X=0, B=1, R=2, R0=3, P=4, AP=5, S=6, AS=7)
+VTK_SLOTS = 3   # EC3D_VTK_SLOTS of include/ec3d_hip.h: pinned buffers of the overlapped field output
 KERNEL = dict(spmv=0, k1=1, k2=2, k3=3, k4=4, k5=5)
 # algorithmic bytes per row of each kernel with 7 bands
 KERNEL_BYTES_PER_ROW = dict(spmv=72, k1=80, k2=24, k3=72, k4=56, k5=32)
@@ -471,8 +472,8 @@ class EC3DSolver:
 
     def vtk_fields_wait(self, slot: int, big_endian: bool = True):
         """Block until slot's copy has landed; dict(A, eddy (None without conductors), source, B) of (ncells, 3)
-        arrays that VIEW the library's pinned buffer (dtype '>f4' when big_endian): valid until the second
-        vtk_fields_begin after the one that returned this slot."""
+        arrays that VIEW the library's pinned buffer (dtype '>f4' when big_endian): valid until the third
+        vtk_fields_begin after the one that returned this slot (VTK_SLOTS buffers, taken in turn)."""
         p = [C.POINTER(C.c_float)() for _ in range(4)]
         n = C.c_int64(0)
         _chk(self.L, self.L.ec3d_vtk_fields_wait(self.h, slot, C.byref(p[0]), C.byref(p[1]), C.byref(p[2]), C.byref(p[3]),

@@ -113,12 +113,13 @@ int ec3d_vtk_fields(ec3d_handle h, const double *delta, float *field_A, float *f
 
 /* The same, overlapped with the next time step (the reference's loop writes field_N.vtk every output step and does
  * nothing else meanwhile, src/EC3D.f90:436-444).  _begin enqueues the field kernel on the handle's stream -- it sees
- * the X and B of this step -- and the copy of the four vectors into one of two pinned host buffers on a side stream,
+ * the X and B of this step -- and the copy of the four vectors into one of three pinned host buffers (taken in turn) on a side stream,
  * and returns without waiting: the caller goes on with ec3d_rhs_step / ec3d_solve_resident of the next step.
  * big_endian != 0: the floats arrive in the byte order of the reference's BINARY legacy-VTK file (swapped on the
  * device), ready to be written as they are.  _wait blocks until that slot's copy has landed and returns pointers into
- * the pinned buffer (field_eddy = NULL without conductors), valid until the second ec3d_vtk_fields_begin after this
- * one; *ncells = cells per vector (3 floats each). */
+ * the pinned buffer (field_eddy = NULL without conductors), valid until the third ec3d_vtk_fields_begin after this
+ * one (EC3D_VTK_SLOTS buffers); *ncells = cells per vector (3 floats each). */
+#define EC3D_VTK_SLOTS 3
 int ec3d_vtk_fields_begin(ec3d_handle h, const double *delta, int32_t big_endian, int32_t *slot);
 int ec3d_vtk_fields_wait(ec3d_handle h, int32_t slot, const float **field_A, const float **field_eddy,
                          const float **field_source, const float **field_B, int64_t *ncells);
