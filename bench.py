@@ -476,7 +476,9 @@ def main():
             sd.upload("B", bar_rhs(N))
             sd.upload("X", np.zeros(n_global))
             ms_d = sd.time_kernel("spmv", 20)
+            cand_us, kept = sd.band_placement() if hasattr(sd, "band_placement") else ([], -1)
             spmv_dia = {"kernel": "k_spmv, plain DIA (7 fp64 coefficient streams + x + y)", "ms": ms_d,
+                        "placement": {"candidate_us": [round(v, 1) for v in cand_us], "kept": kept},
                         "bytes_per_row": 72, "GBps": 72 * n_global / ms_d / 1e6,
                         "frac": 72 * n_global / ms_d / 1e6 / PEAK_HBM_GBS, "workgroups": int(sd.geometry(1).nblk),
                         "note": "20 launches back to back after the timed region; the time depends on where the driver "

@@ -522,7 +522,10 @@ int ec3d_assemble_poisson_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t 
         k_assemble_poisson<<<(unsigned)nblk, 256, 0, c->stream>>>(g, nullptr, A.cls);
     } else {
         const size_t bb = (size_t)7 * A.n_pad * sizeof(double);
-        EC3D_HIP(hipMalloc(&A.bands, bb));
+        {
+            const int rcb = ec3d_alloc_bands(c, &A.bands, bb); // the placement a probe chose for this size, if any
+            if (rcb) return rcb;
+        }
         EC3D_HIP(hipMemsetAsync(A.bands, 0, bb, c->stream));
         A.bytes = (int64_t)bb;
         k_assemble_poisson<<<(unsigned)nblk, 256, 0, c->stream>>>(g, A.bands, nullptr);

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <mutex>
 
 static thread_local std::string g_err;
@@ -91,7 +92,14 @@ static void free_vectors(ec3d_ctx *c)
 void ec3d_free_matrix(ec3d_ctx *c)
 {
     DevMatrix &A = c->A;
-    if (A.bands) (void)hipFree(A.bands);
+    if (A.bands && c->bands_placed) { // keep the placement the probe chose for the next matrix of this size
+        if (c->placed_bands && c->placed_bands != A.bands) (void)hipFree(c->placed_bands);
+        c->placed_bands = A.bands;
+        c->placed_bytes = (size_t)A.nb * A.n_pad * sizeof(double);
+    } else if (A.bands) {
+        (void)hipFree(A.bands);
+    }
+    c->bands_placed = false;
     if (A.tail_id) (void)hipFree(A.tail_id);
     if (A.tile_flag) (void)hipFree(A.tile_flag);
     if (A.chunk_ptr) (void)hipFree(A.chunk_ptr);
@@ -142,6 +150,8 @@ extern "C" int ec3d_destroy(ec3d_handle c)
         (void)hipStreamSynchronize(c->stream);
     c->stream = c->own_stream_obj;
     ec3d_free_matrix(c);
+    if (c->placed_bands) (void)hipFree(c->placed_bands);
+    c->placed_bands = nullptr;
     if (c->hist) (void)hipFree(c->hist);
     if (c->state) (void)hipFree(c->state);
     if (c->state_pinned) (void)hipHostFree(c->state_pinned);
@@ -536,12 +546,35 @@ static int choose_sweep(ec3d_ctx *c)
 // after EC3D_PLACE candidates (default 8; 0 or 1: off) -- about 15 ms each at 512^3.  Only from 32 Mi rows (below that
 // the streams partly live in the Infinity Cache and the spread is gone) and only while the device has room for a
 // second copy.  Results do not depend on it.
+int ec3d_alloc_bands(ec3d_ctx *c, double **bands, size_t bytes)
+{
+    if (c->placed_bands && c->placed_bytes == bytes) { // the placement found for this size earlier: no new probe
+        *bands = c->placed_bands;
+        c->placed_bands = nullptr;
+        c->bands_placed = true;
+        return 0;
+    }
+    if (c->placed_bands) (void)hipFree(c->placed_bands); // another size now: the kept copy is of no use
+    c->placed_bands = nullptr;
+    c->bands_placed = false;
+    EC3D_HIP(hipMalloc(bands, bytes));
+    return 0;
+}
+
 static int place_bands(ec3d_ctx *c)
 {
     DevMatrix &A = c->A;
     int cand = 8;
     if (const char *e = getenv("EC3D_PLACE")) cand = atoi(e);
+    // once per handle and size (the chosen allocation survives a change of matrix: ec3d_alloc_bands); not for a z-slab
+    // (its neighbours may sit on the same device and hold spare copies of their own at the same moment)
+    if (c->bands_placed || c->halo > 0) return 0;
     if (!A.bands || A.sav || A.cls || A.nb <= 0 || A.n_pad < ((int64_t)1 << 25) || cand < 2 || !c->vec[EC3D_VEC_P]) return 0;
+    c->place_us.clear();
+    c->place_kept = 0;
+    const auto t_begin = std::chrono::steady_clock::now();
+    double budget_ms = 400.0; // the whole search: a candidate costs a 7.5 GB device copy and three launches (~15 ms at 512^3)
+    if (const char *e = getenv("EC3D_PLACE_BUDGET_MS")) budget_ms = atof(e);
     const size_t bb = (size_t)A.nb * A.n_pad * sizeof(double);
     const bool verbose = getenv("EC3D_PLACE_VERBOSE") != nullptr;
     hipEvent_t e0, e1;
@@ -560,8 +593,10 @@ static int place_bands(ec3d_ctx *c)
     float best = 0.f;
     int rc = time_it(best);
     float worst = best;
+    c->place_us.push_back(500.f * best);
     if (verbose) fprintf(stderr, "libec3d_hip: band placement 0: %.1f us per SpMV\n", 500.0 * best);
     for (int k = 1; k < cand && !rc && best > 0.95f * worst; ++k) {
+        if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count() > budget_ms) break;
         size_t fr = 0, tot = 0;
         if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < bb + ((size_t)1 << 30)) break;
         double *other = nullptr;
@@ -578,9 +613,11 @@ static int place_bands(ec3d_ctx *c)
         float ms = 0.f;
         rc = time_it(ms);
         if (verbose) fprintf(stderr, "libec3d_hip: band placement %d: %.1f us per SpMV\n", k, 500.0 * ms);
+        c->place_us.push_back(500.f * ms);
         worst = std::max(worst, ms);
         if (!rc && ms < best) {
             best = ms;
+            c->place_kept = k;
         } else {
             std::swap(other, A.bands);
         }
@@ -588,6 +625,7 @@ static int place_bands(ec3d_ctx *c)
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    c->bands_placed = rc == 0;
     // AP held A*0 = 0 before and after
     return rc;
 }
@@ -647,6 +685,16 @@ int ec3d_spare_pair(ec3d_ctx *c)
     return 0;
 }
 
+// what the placement probe of the plain band streams found on this handle (bench.py prints it with the SpMV figure)
+extern "C" int ec3d_get_band_placement(ec3d_handle c, int32_t cap, double *candidate_us, int32_t *tried, int32_t *kept)
+{
+    if (!c || !tried || !kept) return 2;
+    *tried = (int32_t)c->place_us.size();
+    *kept = c->place_kept;
+    for (int32_t i = 0; candidate_us && i < cap && i < *tried; ++i) candidate_us[i] = c->place_us[(size_t)i];
+    return 0;
+}
+
 extern "C" int ec3d_set_workgroups(ec3d_handle c, int32_t nblk)
 {
     c->nblk_request = nblk;
@@ -696,8 +744,12 @@ int ec3d_upload_matrix(ec3d_ctx *c, const HostMatrix &M, int64_t halo)
         A.ncls = M.ncls;
         if ((rc = up(A.cls, M.cls, A.bytes, c->stream))) return rc;
         if ((rc = up(A.table, M.table, A.bytes, c->stream))) return rc;
-    } else if ((rc = up(A.bands, M.bands, A.bytes, c->stream))) {
-        return rc;
+    } else {
+        const size_t nbytes = std::max<size_t>(M.bands.size(), 1) * sizeof(double);
+        if ((rc = ec3d_alloc_bands(c, &A.bands, nbytes))) return rc;
+        if (!M.bands.empty())
+            EC3D_HIP(hipMemcpyAsync(A.bands, M.bands.data(), M.bands.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        A.bytes += (int64_t)nbytes;
     }
     if ((rc = up(A.tail_id, M.tail_id, A.bytes, c->stream))) return rc;
     if ((rc = up(A.tile_flag, M.tile_flag, A.bytes, c->stream))) return rc;

@@ -320,6 +320,13 @@ struct ec3d_ctx {
     int32_t *src_idx = nullptr;    // per-step source scatter staging
     double *src_val = nullptr;
     int64_t src_cap = 0;
+    // plain band streams whose placement was probed (place_bands): kept across a change of matrix of the same size, so
+    // the probe runs once per handle and size, and what it found (candidate times in us, the one kept)
+    double *placed_bands = nullptr;
+    size_t placed_bytes = 0;
+    bool bands_placed = false;
+    std::vector<float> place_us;
+    int place_kept = -1;
     std::vector<uint64_t> src_seen; // host: one bit per A unknown, all zero between calls (repeat check of ec3d_rhs_step)
     // field output (ec3d_output.hip): device scratch for the four float32 vectors, the conductor mask, and -- for
     // output overlapped with the next time step -- a side stream with two pinned host buffers
@@ -385,6 +392,8 @@ int ec3d_upload_matrix(ec3d_ctx *c, const HostMatrix &M, int64_t halo = 0);
 int ec3d_download_matrix(ec3d_ctx *c, HostMatrix &M);
 void ec3d_free_matrix(ec3d_ctx *c);
 int ec3d_prepare_vectors(ec3d_ctx *c);
+// device memory for the plain band streams: the allocation a placement probe chose earlier, when the size fits
+int ec3d_alloc_bands(ec3d_ctx *c, double **bands, size_t bytes);
 int ec3d_spare_pair(ec3d_ctx *c);
 // host vector (reference numbering, n_ref entries) <-> device vector (device numbering)
 int ec3d_vec_h2d(ec3d_ctx *c, double *dev, const double *host);

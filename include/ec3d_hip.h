@@ -330,6 +330,13 @@ typedef struct {
 } ec3d_matrix_info;
 int ec3d_get_matrix_info(ec3d_handle h, ec3d_matrix_info *info);
 
+/* Plain band streams of >= 32 Mi rows: where the driver puts them decides how fast the SpMV runs (1.70 ... 2.01 ms at
+ * 512^3 from one allocation to the next), so the library looks at up to 8 placements when such a matrix is first set
+ * on a handle (at most ~0.4 s; once per handle and size: the chosen allocation is kept across ec3d_set_matrix_csr /
+ * ec3d_assemble_poisson calls of the same size) and keeps the fastest.  This reports what it saw: *tried candidates,
+ * their SpMV times in microseconds (the first `cap` of them), and which one was kept; *tried = 0: no probe ran. */
+int ec3d_get_band_placement(ec3d_handle h, int32_t cap, double *candidate_us, int32_t *tried, int32_t *kept);
+
 /* Host-only check (no GPU needed, no handle): would ec3d_set_matrix_csr / sprsbcgstabwr_ store this
  * matrix in the structured A-V form?  structured = 0 means bands + tail (still exact, slower on the U
  * couplings).  The test is the one the library runs: every entry of the matrix gen_sparse_matrix builds
