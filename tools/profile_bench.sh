@@ -6,7 +6,7 @@ TAG=${1:-r01}; GRID=${2:-512}; FMT=${3:-dict}; WL=${4:-cube}; REF=${5:-3}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
-ARGS="--grid $GRID --no-cpu-baseline --format $FMT --workload $WL --refine $REF"
+ARGS="--grid $GRID --no-cpu-baseline --no-side-workloads --format $FMT --workload $WL --refine $REF"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py $ARGS --steps 30 --warmup 5 > $OUT/bench_trace.json 2> $OUT/trace.err || { tail -20 $OUT/trace.err; exit 1; }
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/bench.py $ARGS --no-spmv-dia --steps 4 --warmup 1 > $OUT/bench_fetch.json 2> $OUT/fetch.err || { tail -20 $OUT/fetch.err; exit 1; }
