@@ -164,7 +164,7 @@ extern "C" void sprsbcgstabwr_(double *valA, int32_t *irow, int32_t *jcol, int32
         auto accept = [&]() {
             held = held_rnorm >= 0.0;
             if (held) {
-                printf(" %.17g\n", held_rnorm);
+                ec3d_print_rnorm(held_rnorm);
                 fflush(stdout);
             }
         };

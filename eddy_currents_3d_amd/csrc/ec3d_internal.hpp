@@ -5,6 +5,7 @@
 #include "../../include/ec3d_hip.h"
 
 #include <climits>
+#include <cstdio>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -344,6 +345,16 @@ struct ec3d_ctx {
 enum { P_BB = 0, P_RR_INIT = 1, P_D1 = 2, P_SS = 3, P_D2 = 4, P_D3 = 5, P_RR = 6, P_RR0N = 7, P_NSLOT = 8 };
 
 void ec3d_set_error(const std::string &msg);
+// a REAL(8) as the reference's `print*` writes it (src/solvers.f90:27, flang's list-directed output); buf >= 40
+void ec3d_format_list_directed(double v, char *buf);
+// the itmax exit's line: norm2(R) on stdout, as the reference prints it
+inline void ec3d_print_rnorm(double rnorm)
+{
+    char line[48];
+    ec3d_format_list_directed(rnorm, line);
+    printf("%s\n", line);
+    fflush(stdout);
+}
 // itmax exit: the reference prints norm2(R) (src/solvers.f90:25-28).  When this points somewhere, the solve entry
 // points store the value there instead of printing it (the drop-in prints it once its result is accepted).
 extern thread_local double *ec3d_itmax_print_hold;

@@ -1132,14 +1132,14 @@ __device__ __forceinline__ void sav_patch_step(const MatDev<FMT_SAV> &A, const S
 
 // ---------------------------------------------------------------------------------------------
 // 2-D tiles for the single-component 7-point operator (north_star: "LDS-staged neighbour stencils").  A workgroup
-// owns a patch of EC3D_PX x EC3D_PY = 64 x 8 cells of the xy plane and marches in z: thread t holds cells
-// (2q, 2q+1), q = t % 32, of patch row y = t / 32 (a wave = two patch rows).  Per step and thread ONE 16-byte global
+// owns a patch of EC3D_PX x EC3D_PY = 128 x 4 cells of the xy plane and marches in z: thread t holds cells
+// (2q, 2q+1), q = t % 64, of patch row y = t / 64 (a wave = one patch row).  Per step and thread ONE 16-byte global
 // load brings the plane above; the plane below and the centre are the z-march registers; +-1 are lane shuffles inside
 // the row (its two end lanes read the neighbouring patch); and +-sdx -- the patch rows above and below, which the
 // 512-consecutive-cells tile had to fetch with two more global loads per thread -- are the centre values the
 // workgroup's other threads hold, passed through LDS: when a thread's plane-above pair arrives it is stored to the
 // buffer the NEXT step reads (two buffers, one barrier per step).  Only the patch's first and last row go to memory
-// for their outer neighbour.  Global loads per wave and step: 1 full + at most half a wave of rim + 4 lanes of edge,
+// for their outer neighbour.  Global loads per wave and step: 1 full + the rim (two of the four waves) + 2 lanes of edge,
 // where the linear tile issues 3 full + 2 lanes.  Same products in the same order: A*x is bit-identical; the dot
 // products are summed in this thread -> cell assignment, which ec3d_geom::patch_x tells the oracle's twin.
 template <int FMT, bool NTB, class V>

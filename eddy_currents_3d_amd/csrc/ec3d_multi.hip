@@ -1181,7 +1181,7 @@ extern "C" int ec3d_multi_solve_resident(ec3d_multi_handle m, double tolerance, 
         if (ec3d_itmax_print_hold) {
             *ec3d_itmax_print_hold = std::sqrt(s);
         } else {
-            printf(" %.17g\n", std::sqrt(s));
+            ec3d_print_rnorm(std::sqrt(s));
             fflush(stdout);
         }
     }

@@ -168,7 +168,7 @@ static int solve_core(ec3d_ctx *c, double tol, int32_t itmax, int32_t *iter, dou
             if (ec3d_itmax_print_hold) {
                 *ec3d_itmax_print_hold = std::sqrt(s);
             } else {
-                printf(" %.17g\n", std::sqrt(s));
+                ec3d_print_rnorm(std::sqrt(s));
                 fflush(stdout);
             }
         }

@@ -62,7 +62,7 @@ EXPORTS = ["sprsbcgstabwr_", "ec3d_invalidate", "ec3d_create", "ec3d_destroy", "
            "ec3d_dist_configure", "ec3d_dist_step", "ec3d_dist_set_boundary_rows", "ec3d_read_state_async", "ec3d_read_state", "ec3d_get_restart_count", "ec3d_set_zmarch", "ec3d_can_overlap",
            "ec3d_rhs_step", "ec3d_post_update", "ec3d_assemble_slab", "ec3d_vtk_fields", "ec3d_vtk_fields_begin", "ec3d_vtk_fields_wait",
            "ec3d_set_structured", "ec3d_get_row_map", "ec3d_get_ulist", "ec3d_probe_csr",
-           "ec3d_device_synchronize",
+           "ec3d_device_synchronize", "ec3d_format_real8",
            "ec3d_multi_create", "ec3d_multi_destroy", "ec3d_multi_ranks", "ec3d_multi_slab", "ec3d_multi_set_format",
            "ec3d_multi_assemble_poisson", "ec3d_multi_assemble", "ec3d_multi_set_matrix_csr", "ec3d_multi_size",
            "ec3d_multi_upload", "ec3d_multi_download", "ec3d_multi_solve", "ec3d_multi_solve_resident",
@@ -158,6 +158,8 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.ec3d_time_kernel.argtypes = [hp, C.c_int, C.c_int32, C.POINTER(C.c_double)]
     L.ec3d_time_iterations.argtypes = [hp, C.c_int32, C.POINTER(C.c_double)]
     L.ec3d_device_synchronize.argtypes = [hp]
+    L.ec3d_format_real8.argtypes = [C.c_double, C.c_char_p]
+    L.ec3d_format_real8.restype = None
     L.ec3d_iterate_begin.argtypes = [hp]
     L.ec3d_iterate.argtypes = [hp, C.c_int32, C.c_int32, hp]
     L.ec3d_get_fusion.argtypes = [hp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]

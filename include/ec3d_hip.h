@@ -390,6 +390,11 @@ int ec3d_get_fusion(ec3d_handle h, int32_t *k2_in_k3, int32_t *k5_in_k1);
 
 int ec3d_device_synchronize(ec3d_handle h);
 
+/* How the library writes the one number the reference prints: norm2(R) on the itmax exit (`print*, norm2(R)`,
+ * src/solvers.f90:27), in the list-directed format of the toolchain the reference is built with in this image (flang):
+ * leading blank, shortest digits, " .5813987794206226" / " 16.27049629976871" / " 9.87654321E-03".  buf >= 40 bytes. */
+void ec3d_format_real8(double v, char *buf);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,6 +12,84 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* One REAL(8) as the reference's `print*, norm2(R)` (src/solvers.f90:27) writes it when the program is built with the
+ * toolchain of this image (amdflang / flang's runtime, list-directed output): a leading blank; then the digits flang's
+ * binary-to-decimal "minimize" step picks -- of the decimal strings with the FEWEST digits that lie strictly between
+ * the midpoints to the neighbouring doubles, the middle one (rounded down: candidates 861 ... 866 give 863), which is
+ * not always the one nearest to the value --; F form without a leading zero and with a bare trailing point
+ * (" .5813987794206226", " 16.27049629976871", " 500.") when the value rounded to ONE significant digit is 0.d x 10^e with
+ * 0 <= e <= 15, otherwise d.dddE+ee with at least two exponent digits (" 9.87654321E-03", " 1.E+16", " 1.E-300").  Checked
+ * against random doubles printed by a program compiled with amdflang (a sample: tests/test_oracle_golden.py).  buf >= 40. */
+void oracle_format_list_directed(double v, char *buf)
+{
+    char big[64], ds[24], cand[48];
+    int e10, nd = 0, k;
+    unsigned long long pick = 0;
+    long double mlo, mhi;
+    char *o = buf;
+    *o++ = ' ';
+    if (v != v) { strcpy(o, "NaN"); return; }
+    if (v < 0.0 || (v == 0.0 && 1.0 / v < 0.0)) { *o++ = '-'; v = -v; }
+    if (v > 1.7976931348623157e308) { strcpy(o, "Inf"); return; }
+    if (v == 0.0) { strcpy(o, "0."); return; }
+    mlo = ((long double)nextafter(v, 0.0) + (long double)v) / 2;       /* exact in the 64-bit significand */
+    mhi = ((long double)nextafter(v, INFINITY) + (long double)v) / 2;
+    if (v >= 1.7976931348623157e308) mhi = (long double)v + ((long double)v - mlo); /* the largest double: mirror the lower half */
+    snprintf(big, sizeof big, "%.29e", v); /* d.ddd...(29)e+XX: the exact expansion, far beyond what a double resolves */
+    e10 = atoi(strchr(big, 'e') + 1);
+    for (nd = 1; nd <= 17; ++nd) {
+        unsigned long long fl = (unsigned long long)(big[0] - '0'), klo, khi;
+        const int sc = e10 - nd + 1; /* a candidate is k x 10^sc */
+        int in_f, in_c;
+        for (k = 1; k < nd; ++k) fl = fl * 10 + (unsigned long long)(big[1 + k] - '0'); /* (big[1] is the point) */
+#define EC3D_CAND(kk) (snprintf(cand, sizeof cand, "%llue%d", (unsigned long long)(kk), sc), strtold(cand, NULL))
+        in_f = EC3D_CAND(fl) > mlo;      /* the exact value cut off after nd digits: below v, above the lower midpoint? */
+        in_c = EC3D_CAND(fl + 1) < mhi;  /* the next one up: above v, below the upper midpoint? */
+        if (!in_f && !in_c) continue;
+        klo = in_f ? fl : fl + 1;
+        khi = in_c ? fl + 1 : fl;
+        {   /* a double's rounding interval holds at most ~23 strings of 17 digits: bounded walks */
+            int guard;
+            for (guard = 0; guard < 32 && klo > 1 && EC3D_CAND(klo - 1) > mlo; ++guard) --klo;
+            for (guard = 0; guard < 32 && EC3D_CAND(khi + 1) < mhi; ++guard) ++khi;
+        }
+#undef EC3D_CAND
+        pick = klo + (khi - klo) / 2;
+        break;
+    }
+    snprintf(ds, sizeof ds, "%llu", pick);
+    e10 += (int)strlen(ds) - nd; /* 99..9 + 1 carried into one more digit */
+    nd = (int)strlen(ds);
+    while (nd > 1 && ds[nd - 1] == '0') ds[--nd] = 0;
+    {   /* exponent of the value rounded to one significant digit, as 0.d x 10^e1 */
+        char one[16];
+        int e1;
+        snprintf(one, sizeof one, "%.0e", v);
+        e1 = atoi(strchr(one, 'e') + 1) + 1;
+        if (e1 < 0 || e1 > 15) { /* E editing, scale factor 1 */
+            const int ea = e10 < 0 ? -e10 : e10;
+            *o++ = ds[0];
+            *o++ = '.';
+            for (k = 1; k < nd; ++k) *o++ = ds[k];
+            sprintf(o, "E%c%02d", e10 < 0 ? '-' : '+', ea);
+            return;
+        }
+    }
+    {   /* F editing: the point after e10 + 1 digits */
+        const int ip = e10 + 1; /* digits before the point (<= 0: zeros behind it first) */
+        if (ip <= 0) {
+            *o++ = '.';
+            for (k = 0; k < -ip; ++k) *o++ = '0';
+            for (k = 0; k < nd; ++k) *o++ = ds[k];
+        } else {
+            for (k = 0; k < ip; ++k) *o++ = k < nd ? ds[k] : '0';
+            *o++ = '.';
+            for (k = ip; k < nd; ++k) *o++ = ds[k];
+        }
+        *o = 0;
+    }
+}
+
 /* ------------------------------------------------------------------------------------ */
 /* src/solvers.f90:54-61                                                                 */
 void oracle_spmv_csr(const double *valA, const int32_t *irow, const int32_t *jcol, int32_t n,
@@ -74,7 +152,11 @@ int oracle_bicgstab_wr(const double *valA, const int32_t *irow, const int32_t *j
     if (Bnorm == 0.0) goto done;                        /* :23 */
     for (;;) {
         if (*iter > itmax) { /* :25-28 */
-            printf(" %.17g\n", oracle_norm2(R, n));
+            {
+                char line[48];
+                oracle_format_list_directed(oracle_norm2(R, n), line);
+                printf("%s\n", line);
+            }
             hit_itmax = 1;
             break;
         }

@@ -145,3 +145,24 @@ def test_full_size_fixtures_hold_what_the_gpu_tests_read():
         assert g["xsketch"].shape == (k, 4096) and g["xprobe"].shape == (k, 200) and g["bprobe"].shape == (k, 200)
         assert int(g["n"]) == 3 * int(np.prod(g["dims"])) + (int(g["n"]) - 3 * int(np.prod(g["dims"])))
         assert all(f"vtk_field_{N}_Field_A_sketch" in g.files for N in range(1, k - 1))
+
+
+def test_itmax_line_is_written_the_way_the_reference_toolchain_writes_it(oracle):
+    """`print*, norm2(R)` (src/solvers.f90:27): the oracle and the library format that number as flang's list-directed
+    output does -- 217 doubles against what a program compiled with amdflang printed for them
+    (tests/golden/flang_list_directed.json, oracle/make_list_directed_fixture.py), character for character."""
+    import ctypes as C
+    import json
+    import os
+    from conftest import GOLDEN
+    import eddy_currents_3d_amd as E
+    fx = json.load(open(os.path.join(GOLDEN, "flang_list_directed.json")))
+    Lo, Ll = oracle.lib(), E.load_library()
+    Lo.oracle_format_list_directed.argtypes = [C.c_double, C.c_char_p]
+    Lo.oracle_format_list_directed.restype = None
+    for hx, want in zip(fx["values_hex"], fx["text"]):
+        v = float.fromhex(hx)
+        for fn in (Lo.oracle_format_list_directed, Ll.ec3d_format_real8):
+            buf = C.create_string_buffer(64)
+            fn(v, buf)
+            assert buf.value.decode() == want, (hx, fn)
