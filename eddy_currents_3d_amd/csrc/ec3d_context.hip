@@ -1369,7 +1369,7 @@ extern "C" int ec3d_upload(ec3d_handle c, int which, const double *host)
     int rc = ec3d_need_matrix(c, "ec3d_upload");
     if (rc) return rc;
     if (which < 0 || which >= EC3D_NVEC) return 2;
-    if ((rc = ec3d_vec_h2d(c, c->vec[which], host))) return rc;
+    if ((rc = ec3d_vec_h2d(c, cur_vec(c, which), host))) return rc;
     EC3D_HIP(hipStreamSynchronize(c->stream));
     return 0;
 }

@@ -174,6 +174,7 @@ struct SolverState {
     double rr0[2]; // R·R0 entering iteration it is rr0[it & 1]
     double alpha, omega;
     double bnorm, tol;
+    double rnorm;  // ||R|| of the last iteration that got as far as its K5 (what the itmax exit prints, solvers.f90:27)
     int stop_iter; // INT_MAX while running; iteration at which an exit was taken
     int stop_kind; // 1: ‖S‖ exit (solvers.f90:34-38), 2: ‖R‖ exit (:43), 0: none / ‖b‖ = 0
     int restarts;  // times the restart R0 = R, P = R (solvers.f90:47-49) fired in this solve (ec3d_get_restart_count)

@@ -1501,6 +1501,7 @@ __global__ __launch_bounds__(EC3D_THREADS) void k_setup(SolverState *st, RedSrc 
         st->alpha = 0.0;
         st->omega = 0.0;
         st->restarts = 0;
+        st->rnorm = sqrt(v[1]);
         stop_publish(st, (bnorm == 0.0) ? 0 : INT_MAX, 0);
     }
 }
@@ -1704,6 +1705,7 @@ EC3D_SPMV_T __global__ __launch_bounds__(EC3D_THREADS) __attribute__((amdgpu_wav
     const double rnorm = sqrt(d[0]);
     const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
     if (lead && hist && it <= hist_cap) hist[2 * (int64_t)(it - 1) + 1] = rnorm;
+    if (lead) st->rnorm = rnorm;
     if (rnorm / bnorm < tol) {
         if (lead) stop_publish(st, it, 2);
         return;
@@ -1837,6 +1839,7 @@ __global__ __launch_bounds__(EC3D_THREADS) void k5_p_update(SweepV sw, RedSrc sr
     const double rnorm = sqrt(d[0]);
     const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
     if (lead && hist && it <= hist_cap) hist[2 * (int64_t)(it - 1) + 1] = rnorm;
+    if (lead) st->rnorm = rnorm;
     if (rnorm / bnorm < tol) {
         if (lead) stop_publish(st, it, 2);
         return;

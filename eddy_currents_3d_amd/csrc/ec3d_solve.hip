@@ -153,24 +153,10 @@ static int solve_core(ec3d_ctx *c, double tol, int32_t itmax, int32_t *iter, dou
     } else {
         *iter = (int32_t)total; // itmax exit: the reference prints norm2(R) and returns (:25-28)
         if (print_on_itmax) {
-            // ‖R‖ = sqrt(sum of the last K4 partials), summed here in workgroup order
-            std::vector<double> part((size_t)c->sweep.pstride);
-            EC3D_HIP(hipMemcpy(part.data(), c->partials + (size_t)P_RR * c->sweep.pstride,
-                               part.size() * sizeof(double), hipMemcpyDeviceToHost));
-            double s = 0.0;
-            for (int q = 0; q < c->sweep.nblk; ++q) s += part[(size_t)q];
-            if (total == 0) {
-                EC3D_HIP(hipMemcpy(part.data(), c->partials + (size_t)P_RR_INIT * c->sweep.pstride,
-                                   part.size() * sizeof(double), hipMemcpyDeviceToHost));
-                s = 0.0;
-                for (int q = 0; q < c->sweep_s.nblk; ++q) s += part[(size_t)q];
-            }
-            if (ec3d_itmax_print_hold) {
-                *ec3d_itmax_print_hold = std::sqrt(s);
-            } else {
-                ec3d_print_rnorm(std::sqrt(s));
-                fflush(stdout);
-            }
+            // ||R|| as the device summed it: the last K5's value (K5 of iteration itmax + 1 ran without an exit), or the
+            // setup's when no iteration ran at all (itmax < 0) -- the same number the residual history holds
+            if (ec3d_itmax_print_hold) *ec3d_itmax_print_hold = fin.rnorm;
+            else ec3d_print_rnorm(fin.rnorm);
         }
     }
     if (hist_host && c->hist_cap > 0)

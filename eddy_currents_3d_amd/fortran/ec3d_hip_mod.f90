@@ -123,6 +123,24 @@ module ec3d_hip
             real(c_double), intent(in) :: delta(*)
             real(c_float), intent(out) :: fA(*), fEddy(*), fSource(*), fB(*)
         end function
+        ! the same beside the next time step: _begin returns at once (field kernel + copy into a pinned buffer are
+        ! enqueued), _wait blocks until that buffer has landed and returns C pointers to 3*ncells REAL(4) each
+        ! (c_f_pointer them); big_endian /= 0: already in the byte order of the BINARY legacy-VTK file
+        integer(c_int) function ec3d_vtk_fields_begin(h, delta, big_endian, slot) bind(C, name="ec3d_vtk_fields_begin")
+            import :: c_ptr, c_int, c_double
+            type(c_ptr), value :: h
+            real(c_double), intent(in) :: delta(*)
+            integer(c_int), value :: big_endian
+            integer(c_int), intent(out) :: slot
+        end function
+        integer(c_int) function ec3d_vtk_fields_wait(h, slot, fA, fEddy, fSource, fB, ncells) &
+                bind(C, name="ec3d_vtk_fields_wait")
+            import :: c_ptr, c_int, c_int64_t
+            type(c_ptr), value :: h
+            integer(c_int), value :: slot
+            type(c_ptr), intent(out) :: fA, fEddy, fSource, fB
+            integer(c_int64_t), intent(out) :: ncells
+        end function
         integer(c_int) function ec3d_spmv(h, x, y) bind(C, name="ec3d_spmv")
             import :: c_ptr, c_int, c_double
             type(c_ptr), value :: h
