@@ -54,3 +54,27 @@ def test_one_json_line_with_the_agreed_fields(args, ngpu):
         assert sd["bytes_per_row"] == 72 and sd["ms"] > 0 and sd["frac"] == pytest.approx(sd["GBps"] / 8000.0)
     if "--devices" in args or "--force-dist" in args:      # both multi-GPU paths check their transport before timing
         assert "bit for bit" in d["verified"]
+
+
+@pytest.mark.gpu
+def test_headline_line_carries_the_av_and_256_sub_records():
+    """The driver's command at the headline size (fewer steps): the 512^3 line with `roofline`, the plain-DIA SpMV figure
+    with the placement probe's account, and the two sub-records timed after the headline region on fresh handles -- the
+    reference's own A-V system (src/EC3D.f90:408) at 306 x 306 x 72 and the 256^3 cube of BASELINE config 2."""
+    r = _run(["--steps", "6", "--warmup", "2", "--no-cpu-baseline"])
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["config"]["grid"] == [512, 512, 512] and "512^3" in d["config"]["workload"]
+    assert set(d["kernels"]) == {"k3", "k4", "k5"}                      # three launches, asked of the library
+    pl = d["spmv_dia"]["placement"]
+    assert 1 <= len(pl["candidate_us"]) <= 8 and 0 <= pl["kept"] < len(pl["candidate_us"])
+    for name, n, lo in (("av", 21391776, 2.0e10), ("cube256", 256 ** 3, 2.5e10)):
+        s = d[name]
+        assert "error" not in s, s
+        assert s["n"] == n and s["unit"] == "DOF*iters/s" and s["value"] > lo
+        assert s["value"] == pytest.approx(n * s["steps"] / (s["ms_per_step"] * s["steps"] * 1e-3), rel=1e-6)
+        assert set(s["kernels"]) == {"k1", "k2", "k3", "k4", "k5"}        # below 64 Mi rows: five launches
+        dom = s["dominant"]
+        assert dom["frac"] == pytest.approx(dom["achieved"] / 8000.0) and 0.3 < dom["frac"] < 1.2
