@@ -534,42 +534,6 @@ static int choose_sweep(ec3d_ctx *c)
             }
         }
     }
-    // Structured form, four blocks per workgroup (quad_walk; EC3D_SAV_QUAD=1, experiment): a sweep of its own over the
-    // patch positions x z segments of ONE block's planes, four workgroups per CU
-    c->sweep_q = Sweep{};
-    {
-        int quad = 0;
-        if (const char *e = getenv("EC3D_SAV_QUAD")) quad = atoi(e);
-        int qx = 0, qy = 0;
-        if (quad && A.sav && c->halo == 0 && c->nown == 0 && c->pitch > 0 && c->plane % A.off[5] == 0) {
-            const int64_t sdx = A.off[5], sdy = c->plane / sdx;
-            pick_patch_shape(sdx, sdy, qx, qy);
-            if (const char *e = getenv("EC3D_SAV_PATCH_PX")) {
-                const int px = atoi(e);
-                if (px >= 4 && px % 2 == 0 && px <= 256 && sdx % px == 0) { qx = px; qy = EC3D_TILE / px; }
-            }
-            if (qx > 0 && build_patch_tables(c, qx, qy) == 0) {
-                Sweep &q = c->sweep_q;
-                q = ss;
-                const int64_t planes = c->nCd / c->pitch, tpp = (sdx / qx) * ((sdy + qy - 1) / qy), cols = (tpp + 7) / 8 * 8;
-                int want = 1024;
-                if (const char *e = getenv("EC3D_NBLK_QUAD")) want = atoi(e);
-                int64_t nseg = std::max<int64_t>(1, (want + cols / 2) / cols);
-                nseg = std::min<int64_t>(nseg, std::max<int64_t>(1, planes / 2));
-                q.zm_tpp = (int)tpp;
-                q.zm_pps = (int)((planes + nseg - 1) / nseg);
-                q.nblk = (int)(cols * nseg);
-                q.ntiles = 3 * planes * tpp;
-                q.rp_px = qx; q.rp_py = qy; q.rp_npx = (int)(sdx / qx); q.rp_sdy = (int)sdy; q.rp_sdx = sdx;
-                q.rp_pitch = c->pitch;
-                q.rp_flag = A.rp_flag;
-                q.rp_quad = 1;
-                q.ulist = nullptr;
-                q.ulist_n = 0;
-                q.patch_npx = 0;
-            }
-        }
-    }
     // Structured form, U tiles of the z-marching SpMV kernels.  A U tile reads eleven tile-sized operands (its own three
     // planes and +-sdx lines, A_x, three of A_y, three of A_z) and nothing is carried between U tiles; dealt round robin
     // (entry b, b + nblk, ...) the neighbours of a tile run on other XCDs or at other times and every one of those
@@ -1443,8 +1407,7 @@ extern "C" int ec3d_spmv(ec3d_handle c, const double *x, double *y)
     if (rc) return rc;
     // P and AP serve as scratch
     if ((rc = ec3d_vec_h2d(c, c->vec[EC3D_VEC_P], x))) return rc;
-    ec3d_launch_spmv(c->A.view(), c->sweep_q.nblk > 0 ? c->sweep_q : c->sweep_s, c->vec[EC3D_VEC_P], c->vec[EC3D_VEC_AP],
-                     c->stream);
+    ec3d_launch_spmv(c->A.view(), c->sweep_s, c->vec[EC3D_VEC_P], c->vec[EC3D_VEC_AP], c->stream);
     EC3D_HIP(hipGetLastError());
     if ((rc = ec3d_vec_d2h(c, y, c->vec[EC3D_VEC_AP]))) return rc;
     EC3D_HIP(hipStreamSynchronize(c->stream));

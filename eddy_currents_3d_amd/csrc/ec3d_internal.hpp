@@ -94,9 +94,6 @@ struct Sweep {
     int rp_px, rp_py, rp_npx, rp_sdy;
     int64_t rp_sdx, rp_pitch;
     const uint8_t *rp_flag;
-    // rp_quad: ONE workgroup does the Ax, Ay, Az (and, where the patch holds conducting cells, U) tile of a patch position
-    // plane after plane (quad_walk in ec3d_kernels.hip): zm_pps / the z segments then count the planes of ONE block
-    int rp_quad;
     // rows that count in the dot products when this handle holds an A-V slab on an extended grid whose planes
     // are NOT tile aligned (nown > 0; bands + tail, or the structured form on a small grid): [Ax | Ay | Az | U]
     // each contribute one owned index range.  Tile-aligned structured slabs use the window below instead.
@@ -260,7 +257,6 @@ struct ec3d_ctx {
     Sweep sweep{};   // vector kernels: K4's grid (and the geometry every other sweep is derived from)
     Sweep sweep_k2{}, sweep_k5{}; // K2 (2 reads + 1 write) and K5 (3 + 1) like other workgroup counts than K4 (5 + 2)
     Sweep sweep_s{}; // SpMV kernels (K1, K3, residual, spmv)
-    Sweep sweep_q{}; // structured form, four blocks per workgroup (quad_walk): nblk = 0 when not available
     Sweep sweep_int{}, sweep_bnd{}; // z-slab: interior / boundary-plane launches of K1 and K3
     bool can_overlap = false;
     bool fuse23_ok = false; // 2-D tiles: K2 may run inside K3 (single rank only, see ec3d_fused23)

@@ -1873,243 +1873,6 @@ __global__ __launch_bounds__(EC3D_THREADS) void k5_p_update(SweepV sw, RedSrc sr
 }
 
 // ---------------------------------------------------------------------------------------------
-// The four blocks of a cell range in ONE workgroup (round 4; VERDICT r3 item 2, DESIGN.md section 9.3 of round 3).
-// The structured kernels above give every block [Ax | Ay | Az | U] its own workgroups, so the A operands of a U row and
-// the U operands of a coupled A row are fetched a second time, by another workgroup at another moment (K3: 22.7 B per
-// row where 17 would do).  Here a workgroup owns one patch position of the xy plane (runtime-shaped 2-D tiles as in
-// sav_patch_step) and walks the planes of its z segment ONCE, doing at every plane the Ax, Ay, Az tile and -- where the
-// patch holds conducting cells -- the U tile, each block with its own pair of exchange buffers in LDS and its own
-// carried plane below.  Then every coupling operand is a value the step holds anyway for another block's 7-point stencil:
-//   U row:        A_x(cell - 1 .. cell + 1) = the centre plane of the Ax block (exchange buffer, row ends: the edge values
-//                 Ax's own +-1 stencil loaded), A_y(cell -+ sdx) = Ay's +-sdx operands, A_z(cell -+ pitch) = Az's
-//                 plane below / above, the own-cell slots the centre pairs;
-//   coupled A_d:  U(cell + m * step_d), m = -1, 0, +1, from the U block's buffers and registers in the same way; only
-//                 the outer slots m = +-2 (one-sided stencils at a conductor face, src/EC3D.f90:667-676) that fall
-//                 outside the patch or two planes away are fetched, by the waves that meet one.
-// Same products in the same order as sav_pair_zm / sav_patch_step (bands ascending then U slots for A rows, A slots then
-// bands for U rows): A*x is bit-identical; the dot products are summed in this visit order (block after block within a
-// plane), which ec3d_get_visit_order reports to the oracle's twin.  40 KiB of LDS (table 8 + 4 x 8): four workgroups per CU.
-struct QuadPos {
-    int tx, ty;
-    bool live;
-    int64_t po; // the thread's first cell within a plane
-};
-// epi(b, r, live, s0, s1, ctr): rows r, r + 1 of block b are done (s0, s1 = the row sums, ctr = x[r], x[r + 1])
-template <class EPI>
-__device__ __forceinline__ void quad_walk(const MatDev<FMT_SAV> &A, const SweepZ &sw, const double *tbl, double *exch,
-                                          const double *__restrict__ x, EPI &&epi)
-{
-    const int t = threadIdx.x, px = sw.rp_px, py = sw.rp_py, hx = px >> 1;
-    const int64_t pitch = A.pitch, sdx = A.sdx;
-    QuadPos qp;
-    {
-        const int t2 = 2 * t;
-        qp.ty = t2 / px;
-        qp.tx = t2 - qp.ty * px;
-    }
-    const int tx = qp.tx, ty = qp.ty;
-    // the workgroup's column and z segment (the columns dealt to the XCD labels in runs, as walk_zm does)
-    const int cpx = (sw.tpp + 7) >> 3, c = blockIdx.x & 7, sg = blockIdx.x >> 3;
-    const int col = c * cpx + sg % cpx;
-    if (col >= sw.tpp) return;
-    int k0 = (sg / cpx) * sw.pps, k1 = k0 + sw.pps;
-    if (k1 > (int)A.planes) k1 = (int)A.planes;
-    {
-        const int pyi = col / sw.rp_npx, pxi = col - pyi * sw.rp_npx;
-        const int gy = pyi * py + ty;
-        qp.live = ty < py && gy < sw.rp_sdy;
-        qp.po = qp.live ? (int64_t)gy * sdx + (int64_t)pxi * px + tx : 0;
-    }
-    const bool rimrow = ty == 0 || ty == py - 1;
-    const int64_t roff = ty == 0 ? -sdx : sdx;
-    const bool edge_l = tx == 0, edge_r = tx == px - 2;
-    d2 xm[4];         // plane below of each block (the thread's own pair)
-    bool uvalid = false; // the U block's carried state (xm[3], its exchange buffer) belongs to the previous plane
-    typedef const __attribute__((address_space(4))) unsigned *cptr;
-    for (int k = k0; k < k1; ++k) {
-        const bool first = k == k0;
-        const int step = k - k0;
-        // conducting cells in this patch of this plane?  (the coupled flag of the Ax tile: a coupled A row is a
-        // conducting cell, and a conducting cell has a U unknown)
-        bool cond;
-        {
-            const int T = __builtin_amdgcn_readfirstlane(k * sw.tpp + col);
-            const unsigned w = ((cptr)(uintptr_t)sw.rp_flag)[T >> 2];
-            cond = ((w >> ((T & 3) * 8)) & 0xFFu) != 0;
-        }
-        const int nb = cond ? 4 : 3;
-        const bool ufirst = cond && (first || !uvalid);
-        // ---- every load of the step ----
-        int64_t rb[4];
-        d2 zp[4], rim[4];
-        double edge[4];
-        unsigned short cc[4];
-        d2 uout = d2{0.0, 0.0}; // coupled A_x rows at a patch row's ends: U(cell - 2, cell - 1) / U(cell + 2, cell + 3)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            if (b >= nb) break;
-            const int64_t r = ((int64_t)b * A.planes + k) * pitch + qp.po;
-            rb[b] = r;
-            cc[b] = *reinterpret_cast<const unsigned short *>(A.cls + r);
-            zp[b] = *reinterpret_cast<const d2u *>(x + r + pitch);
-            edge[b] = 0.0;
-            if (edge_l || edge_r) edge[b] = x[edge_l ? r - 1 : r + 2];
-            rim[b] = d2{0.0, 0.0};
-            if (rimrow) rim[b] = *reinterpret_cast<const d2u *>(x + r + roff);
-            double *cur = exch + (b * 2 + (step & 1)) * EC3D_TILE;
-            if (b < 3 ? first : ufirst) { // nothing carried over for this block
-                xm[b] = *reinterpret_cast<const d2u *>(x + r - pitch);
-                *reinterpret_cast<d2 *>(cur + 2 * t) = *reinterpret_cast<const d2u *>(x + r);
-            }
-        }
-        if (cond && (edge_l || edge_r)) uout = *reinterpret_cast<const d2u *>(x + rb[3] + (edge_l ? -2 : 2));
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        // ---- the blocks, one after the other ----
-        d2 cxs[4]; // centre pairs (kept for the other blocks' coupling slots and for the carry)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            if (b >= nb) break;
-            const double *cur = exch + (b * 2 + (step & 1)) * EC3D_TILE;
-            cxs[b] = *reinterpret_cast<const d2 *>(cur + 2 * t);
-        }
-        // operands around the centre pair of block b, out of its exchange buffer (patch interior) or its rim / edge loads
-        auto ym_of = [&](int b) -> d2 {
-            const double *cur = exch + (b * 2 + (step & 1)) * EC3D_TILE;
-            return ty > 0 ? *reinterpret_cast<const d2 *>(cur + 2 * (t - hx)) : rim[b];
-        };
-        auto yp_of = [&](int b) -> d2 {
-            const double *cur = exch + (b * 2 + (step & 1)) * EC3D_TILE;
-            return ty < py - 1 ? *reinterpret_cast<const d2 *>(cur + 2 * (t + hx)) : rim[b];
-        };
-        auto left_of = [&](int b) -> double {
-            const double *cur = exch + (b * 2 + (step & 1)) * EC3D_TILE;
-            return tx > 0 ? cur[2 * t - 1] : edge[b];
-        };
-        auto right_of = [&](int b) -> double {
-            const double *cur = exch + (b * 2 + (step & 1)) * EC3D_TILE;
-            return (tx < px - 2 && ty < py) ? cur[2 * t + 2] : edge[b];
-        };
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            if (b >= nb) break;
-            const double *t0 = tbl + (cc[b] & 0xFF) * EC3D_SAV_STRIDE, *t1 = tbl + (cc[b] >> 8) * EC3D_SAV_STRIDE;
-            double s0 = 0.0, s1 = 0.0;
-            const d2 cx = cxs[b], zm = xm[b];
-            auto bands = [&]() {
-                const d2 ym = ym_of(b), yp = yp_of(b);
-                const double left = left_of(b), right = right_of(b);
-                s0 = s0 + t0[0] * zm.x;
-                s1 = s1 + t1[0] * zm.y;
-                s0 = s0 + t0[1] * ym.x;
-                s1 = s1 + t1[1] * ym.y;
-                s0 = s0 + t0[2] * left;
-                s1 = s1 + t1[2] * cx.x;
-                s0 = s0 + t0[3] * cx.x;
-                s1 = s1 + t1[3] * cx.y;
-                s0 = s0 + t0[4] * cx.y;
-                s1 = s1 + t1[4] * right;
-                s0 = s0 + t0[5] * yp.x;
-                s1 = s1 + t1[5] * yp.y;
-                s0 = s0 + t0[6] * zp[b].x;
-                s1 = s1 + t1[6] * zp[b].y;
-            };
-            if (b == 3) {
-                // ---- U rows: the A slots first (A_x, A_y, A_z), then the bands ----
-                {
-                    const double l = left_of(0), rr = right_of(0);
-                    const double o0[3] = {l, cxs[0].x, cxs[0].y}, o1[3] = {cxs[0].x, cxs[0].y, rr};
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        const double v0 = t0[7 + j], v1 = t1[7 + j];
-                        if (v0 != 0.0) s0 = s0 + v0 * o0[j];
-                        if (v1 != 0.0) s1 = s1 + v1 * o1[j];
-                    }
-                }
-                {
-                    const d2 om = ym_of(1), op = yp_of(1), oc = cxs[1];
-                    const double vm0 = t0[10], vm1 = t1[10], vc0 = t0[11], vc1 = t1[11], vp0 = t0[12], vp1 = t1[12];
-                    if (vm0 != 0.0) s0 = s0 + vm0 * om.x;
-                    if (vm1 != 0.0) s1 = s1 + vm1 * om.y;
-                    if (vc0 != 0.0) s0 = s0 + vc0 * oc.x;
-                    if (vc1 != 0.0) s1 = s1 + vc1 * oc.y;
-                    if (vp0 != 0.0) s0 = s0 + vp0 * op.x;
-                    if (vp1 != 0.0) s1 = s1 + vp1 * op.y;
-                }
-                {
-                    const d2 om = xm[2], op = zp[2], oc = cxs[2];
-                    const double vm0 = t0[13], vm1 = t1[13], vc0 = t0[14], vc1 = t1[14], vp0 = t0[15], vp1 = t1[15];
-                    if (vm0 != 0.0) s0 = s0 + vm0 * om.x;
-                    if (vm1 != 0.0) s1 = s1 + vm1 * om.y;
-                    if (vc0 != 0.0) s0 = s0 + vc0 * oc.x;
-                    if (vc1 != 0.0) s1 = s1 + vc1 * oc.y;
-                    if (vp0 != 0.0) s0 = s0 + vp0 * op.x;
-                    if (vp1 != 0.0) s1 = s1 + vp1 * op.y;
-                }
-                bands();
-            } else {
-                // ---- A rows: the bands, then (conducting cells) the U slots m = -2 .. 2 along the component's axis ----
-                bands();
-                if (cond) {
-                    double o0[5], o1[5];
-                    const bool wlo = t0[7] != 0.0 || t1[7] != 0.0, whi = t0[11] != 0.0 || t1[11] != 0.0;
-                    if (b == 0) { // cells r - 2 .. r + 3 of the U block's centre plane
-                        const double *cu = exch + (3 * 2 + (step & 1)) * EC3D_TILE;
-                        const d2 q1 = cxs[3];
-                        d2 q0 = uout, q2 = uout;
-                        if (!edge_l) q0 = d2{cu[2 * t - 2], cu[2 * t - 1]};
-                        if (!edge_r && ty < py) q2 = d2{cu[2 * t + 2], cu[2 * t + 3]};
-                        o0[0] = q0.x; o0[1] = q0.y; o0[2] = q1.x; o0[3] = q1.y; o0[4] = q2.x;
-                        o1[0] = q0.y; o1[1] = q1.x; o1[2] = q1.y; o1[3] = q2.x; o1[4] = q2.y;
-                    } else {
-                        const d2 qm = b == 1 ? ym_of(3) : xm[3], qc = cxs[3], qp2 = b == 1 ? yp_of(3) : zp[3];
-                        o0[1] = qm.x; o0[2] = qc.x; o0[3] = qp2.x;
-                        o1[1] = qm.y; o1[2] = qc.y; o1[3] = qp2.y;
-                        d2 qlo = d2{0.0, 0.0}, qhi = d2{0.0, 0.0};
-                        if (__any(wlo || whi)) { // one-sided stencils at a conductor face only
-                            const int64_t base = rb[3], st = b == 1 ? sdx : pitch;
-                            if (wlo) qlo = *reinterpret_cast<const d2u *>(x + base - 2 * st);
-                            if (whi) qhi = *reinterpret_cast<const d2u *>(x + base + 2 * st);
-                        }
-                        o0[0] = qlo.x; o1[0] = qlo.y;
-                        o0[4] = qhi.x; o1[4] = qhi.y;
-                    }
-#pragma unroll
-                    for (int m = 0; m < 5; ++m) {
-                        const double v0 = t0[7 + m], v1 = t1[7 + m];
-                        if (v0 != 0.0) s0 = s0 + v0 * o0[m];
-                        if (v1 != 0.0) s1 = s1 + v1 * o1[m];
-                    }
-                }
-            }
-            epi(b, rb[b], qp.live, s0, s1, cx);
-        }
-        // ---- the plane above is the next step's centre; the centre its plane below ----
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            if (b >= nb) break;
-            double *nxt = exch + (b * 2 + ((step + 1) & 1)) * EC3D_TILE;
-            *reinterpret_cast<d2 *>(nxt + 2 * t) = zp[b];
-            xm[b] = cxs[b];
-        }
-        uvalid = cond;
-    }
-}
-// LDS behind the class table: 4 blocks x 2 exchange buffers
-#define EC3D_QUAD_LDS(A) ((size_t)(A).ncls * EC3D_SAV_STRIDE * 8 + (size_t)8 * EC3D_TILE * 8)
-
-template <bool NT>
-__global__ __launch_bounds__(EC3D_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void kq_spmv(
-    MatDev<FMT_SAV> A, SweepZ sw, const double *__restrict__ x, double *__restrict__ y)
-{
-    extern __shared__ double tbl[];
-    double *exch = tbl + A.ncls * EC3D_SAV_STRIDE;
-    stage_table<FMT_SAV>(A, tbl);
-    quad_walk(A, sw, tbl, exch, x, [&](int, int64_t r, bool live, double s0, double s1, d2) {
-        store2<NT>(y, r, live ? sw.n : 0, s0, s1);
-    });
-}
-
-// ---------------------------------------------------------------------------------------------
 // launchers
 static inline int fmt_of(const MatView &A)
 {
@@ -2281,13 +2044,6 @@ static inline SweepV sweep_v(const Sweep &sw)
 
 void ec3d_launch_spmv(const MatView &A, const Sweep &sw, const double *x, double *y, hipStream_t s)
 {
-    if (A.sav && sw.rp_quad) {
-        const MatDev<FMT_SAV> Ad = mat_dev<FMT_SAV>(A);
-        const SweepZ swz = sweep_z(sw);
-        if (nt_of(sw)) kq_spmv<true><<<sw.nblk, EC3D_THREADS, EC3D_QUAD_LDS(A), s>>>(Ad, swz, x, y);
-        else kq_spmv<false><<<sw.nblk, EC3D_THREADS, EC3D_QUAD_LDS(A), s>>>(Ad, swz, x, y);
-        return;
-    }
     EC3D_DISPATCH(A, k_spmv, x, y);
 }
 

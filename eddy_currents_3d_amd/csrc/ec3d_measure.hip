@@ -109,7 +109,7 @@ extern "C" int ec3d_time_kernel(ec3d_handle c, int kernel, int32_t reps, double 
     ec3d_launch_iteration(c, A, 1); // populate every partial slot and the scalars
     auto one = [&]() {
         if (kernel == EC3D_K_SPMV)
-            ec3d_launch_spmv(A, c->sweep_q.nblk > 0 ? c->sweep_q : c->sweep_s, v[EC3D_VEC_P], v[EC3D_VEC_AP], s);
+            ec3d_launch_spmv(A, c->sweep_s, v[EC3D_VEC_P], v[EC3D_VEC_AP], s);
         else {
             // K5-in-K1 handles: EC3D_K1 times the plain K1 of iteration 2 (on the AP buffer the fused launch filled),
             // EC3D_K5 the fused K5 + K1 launch
