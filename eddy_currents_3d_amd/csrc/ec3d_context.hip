@@ -342,12 +342,17 @@ static int choose_sweep(ec3d_ctx *c)
         sw.ntiles = 3 * sw.win_nt;
         sw.nown = 0;
     }
+    // Rows the kernels actually stream.  The structured form's device numbering holds a whole grid-shaped block for U, of
+    // which only the tiles with an unknown are ever touched: BASELINE config 5 (LIM at 384 x 192 x 128) has 37.7 M device
+    // rows but streams 29.8 M, and belongs with the sizes where a vector or two still find room in the Infinity Cache
+    // (measured, profiles/r04_keep_and_plans_config5.log: 839 -> 814-819 us per iteration with the mid-size policy).
+    const int64_t rows_eff = (c->A.sav && c->A.ulist) ? (c->A.ntiles_front + (int64_t)c->A.ulist_n) * EC3D_TILE : c->A.n_pad;
     {
         int ntreq = c->nt_request;
         if (const char *e = getenv("EC3D_NT")) ntreq = atoi(e); // read here too: sweeps of launch knobs in one process
         // nontemporal streams from 4.5 Mi rows (tools/keep_sweep.py: at 4 Mi rows = 32 MiB per vector plain caching is
         // still 8 % faster than any nontemporal policy, at 5.2 M rows it is 1.5 % slower than the policy below)
-        sw.nt = (ntreq >= 0 ? ntreq : (c->A.n_pad >= (9 << 19))) & 1;
+        sw.nt = (ntreq >= 0 ? ntreq : (rows_eff >= (9 << 19))) & 1;
         // Between the sizes where everything lives in a cache (< 4 Mi rows: no nontemporal streams at all) and those
         // where nothing does (>= 32 Mi rows), a vector or two fit the 256 MiB Infinity Cache: the output of a kernel
         // that the NEXT kernel reads first is stored cacheable although the launch's other streams are nontemporal
@@ -357,7 +362,7 @@ static int choose_sweep(ec3d_ctx *c)
         // and AS (K3 -> K4) gain nothing or push out what K4 finds there today.  21 M-unknown A-V system: -2.8 %.
         // At 512^3 any of them costs 2-4 %.  EC3D_KEEP=<bits> overrides (1 AP, 2 S, 8 R, 32 P).
         int keep = 0;
-        if (c->A.n_pad < ((int64_t)1 << 25)) keep = 1 | 8 | (c->A.n_pad * 8 <= ((int64_t)136 << 20) ? 2 : 0);
+        if (rows_eff < ((int64_t)1 << 25)) keep = 1 | 8 | (rows_eff * 8 <= ((int64_t)136 << 20) ? 2 : 0);
         if (const char *e = getenv("EC3D_KEEP")) keep = atoi(e);
         if (sw.nt) sw.nt |= keep << 1;
     }
@@ -392,7 +397,7 @@ static int choose_sweep(ec3d_ctx *c)
         return k;
     };
     {
-        const bool big = c->A.n_pad >= ((int64_t)1 << 25); // vectors of 256 MiB and more: nothing stays in a cache
+        const bool big = rows_eff >= ((int64_t)1 << 25); // vectors of 256 MiB and more: nothing stays in a cache
         const VecPlan p2 = plan_of("K2", big ? VecPlan{768, 0, 2} : VecPlan{768, 1, 1});
         const VecPlan p4 = plan_of("K4", big ? VecPlan{256, 0, 2} : VecPlan{768, 1, 1});
         const VecPlan p5 = plan_of("K5", big ? VecPlan{256, 0, 2} : VecPlan{768, 1, 1});
@@ -457,7 +462,7 @@ static int choose_sweep(ec3d_ctx *c)
             // 768 against 85/67) or, with 2-D tiles, 6 per CU (76/59 at 1536 against 89/65 at 768); the structured
             // A-V kernels, whose conductor columns are several times heavier than the others, want the finer grain
             // of 6 per CU (21 M unknowns: 128/108 at 1472, 145/124 at 1104, 137/116 at 1288)
-            const bool big = c->A.n_pad >= ((int64_t)1 << 25);
+            const bool big = rows_eff >= ((int64_t)1 << 25);
             int want_s = c->nblk_request > 0 ? c->nblk_request : A.sav ? 1536 : big ? 1024 : use_patch ? 1536 : 768;
             if (const char *e = getenv("EC3D_NBLK_SPMV")) want_s = atoi(e);
             // tiles per plane and logical tiles of the front sweep as the SpMV kernels count them
