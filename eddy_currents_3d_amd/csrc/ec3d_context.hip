@@ -463,7 +463,11 @@ static int choose_sweep(ec3d_ctx *c)
             // A-V kernels, whose conductor columns are several times heavier than the others, want the finer grain
             // of 6 per CU (21 M unknowns: 128/108 at 1472, 145/124 at 1104, 137/116 at 1288)
             const bool big = rows_eff >= ((int64_t)1 << 25);
-            int want_s = c->nblk_request > 0 ? c->nblk_request : A.sav ? 1536 : big ? 1024 : use_patch ? 1536 : 768;
+            // (round 4: the structured kernels follow the cube's move to four workgroups per CU, a little earlier -- config 5,
+            // 29.8 M rows streamed, K1 / K3 171.5 / 142.3 us on 1440 workgroups, 161.0 / 133.1 on 1008, 172.5 / 140.1 on 1296,
+            // 174.9 / 153.1 on 1584, 160.7 / 133.3 on 3024; the 21 M system stays at 1472: 1104 costs it 13 %)
+            const bool sav_big = A.sav && rows_eff >= ((int64_t)25 << 20);
+            int want_s = c->nblk_request > 0 ? c->nblk_request : A.sav ? (sav_big ? 1024 : 1536) : big ? 1024 : use_patch ? 1536 : 768;
             if (const char *e = getenv("EC3D_NBLK_SPMV")) want_s = atoi(e);
             // tiles per plane and logical tiles of the front sweep as the SpMV kernels count them
             int64_t tpp_s = tpp, ntiles_s = sw.ntiles;
