@@ -84,3 +84,27 @@ def test_source_cell_file_is_the_reference_file():
         cells = np.concatenate([gr[1] for gr in prog.groups]) - 1
         clamped |= bool(((cells % sdx + 1) >= sdx - 2).any())
     assert clamped, "the run was meant to reach the clamp"
+
+
+@pytest.mark.parametrize("case", ["ec_src_move_hole", "LIM"])
+def test_sources_evaluated_ahead_are_the_sequential_ones(case):
+    """host._SourcesAhead (the source program of step k + 1 evaluated on a thread while step k solves; sources are
+    functions of time alone, src/EC3D.f90:245-340) hands the time loop exactly what the sequential evaluation gives:
+    the same (unknown id, value) lists, the same cell groups for src_N.vtk, in the same order, for the same T sequence
+    (T = T + DT accumulated in floating point as the loop does), clamp and movestop state included."""
+    from eddy_currents_3d_amd import host
+    _, _, t, seq = _program(case)
+    _, _, _, par = _program(case)
+    DT, Time, steps = float(t["dt"]), float(t["time"]), 30
+    ahead = host._SourcesAhead(par, 0.0, DT, Time, steps)
+    T = 0.0
+    for k in range(steps):
+        idx, val, moving = seq.step(T)
+        aidx, aval, amoving, agroups = ahead.next(T)
+        assert np.array_equal(idx, aidx) and np.array_equal(val, aval) and moving == amoving
+        assert len(agroups) == len(seq.groups)
+        for (ax, cells, v), (bx, bcells, bv) in zip(seq.groups, agroups):
+            assert ax == bx and v == bv and np.array_equal(cells, bcells)
+        T = T + DT
+    ahead.thread.join(timeout=10)
+    assert not ahead.thread.is_alive()
