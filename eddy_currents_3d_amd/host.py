@@ -334,8 +334,8 @@ def run(model: vxc.VxcModel, solver, steps: int | None = None, out_dir: str | No
 
     ``overlap_output`` (default, single-device handles): the field output of step N runs beside step N+1 -- field
     kernel and device-to-host copy asynchronously, formatting-free writing on a host thread (_OutputPipeline); the
-    files are the same bytes.  ``on_fields(N, fields, info)`` is then called on that thread with views of the pinned
-    buffer (valid during the call).  Without overlap the fields are fetched synchronously after the post-update,
+    files are the same bytes.  ``on_fields(N, fields, info)`` is then called on one of the writer threads with views of
+    the pinned buffer (valid during the call; calls for different N may overlap and arrive out of order).  Without overlap the fields are fetched synchronously after the post-update,
     ``on_fields`` is called in the loop and ``info["fields"]`` holds them when they are not written.
     ``on_written(N, paths)``: after output step N's files are complete (a run of hundreds of 500 MB files may want
     to move them away)."""
