@@ -267,7 +267,8 @@ int cross_wait(hipStream_t stream, hipEvent_t ev)
     // hipStreamWaitEvent is thread safe like every HIP entry point and the threads issue these waits concurrently.
     // Rounds 2 and 3 took a process-wide mutex around every one of them by default -- "a precaution, not a measured
     // need": eight rank threads then queued up behind it at every reduction point and exchange.  It protected against
-    // nothing that was ever observed (tools/multi_stress.py, 2-8 slabs on one card, runs with it off), so it is now
+    // nothing that was ever observed (the suite's 2-8 slab cases and tools/multi_stress.py -- 3, 4 and 8 slabs on one card,
+    // 20 x 7 repeated solves each, bit-identical every time: profiles/r04_multi_stress.log -- run with it off), so it is now
     // off; EC3D_MULTI_SERIALIZE_WAITS=1 brings it back for a run that wants to rule the runtime out.
     static const bool serialize = getenv("EC3D_MULTI_SERIALIZE_WAITS") && atoi(getenv("EC3D_MULTI_SERIALIZE_WAITS")) != 0;
     if (serialize) {
