@@ -1273,6 +1273,52 @@ extern "C" int ec3d_multi_vtk_fields(ec3d_multi_handle m, const double *delta, f
     }, true);
 }
 
+// Field output overlapped with the next time step, over the slabs (ec3d_vtk_fields_begin / _wait on every slab's own
+// handle: its field kernel behind its post-update, its copy into its own pinned buffers on its own side stream).  The
+// slabs take their slots in step, so one slot number names the same output step on all of them; _wait hands out ONE
+// slab's part -- cells k0*sdx*sdy .. k1*sdx*sdy of every vector, which are consecutive in field_N.vtk
+// (src/utilites.f90:222-289 writes cell by cell, z outermost).
+extern "C" int ec3d_multi_vtk_fields_begin(ec3d_multi_handle m, const double *delta, int32_t big_endian, int32_t *slot)
+{
+    int rc = need(m, "ec3d_multi_vtk_fields_begin");
+    if (rc) return rc;
+    if (m->kind != 2 || !slot) {
+        ec3d_set_error("ec3d_multi_vtk_fields_begin: needs a matrix from ec3d_multi_assemble and a slot to return");
+        return m->kind != 2 ? 3 : 2;
+    }
+    std::vector<int32_t> got((size_t)m->n, -1);
+    rc = run_all(m, [&](int r) -> int {
+        Slab &s = *m->slab[(size_t)r];
+        int rc2 = halo_start(m, s, CH_X); // the curl reads the neighbours' planes
+        if (rc2) return rc2;
+        if ((rc2 = halo_wait(s, CH_X))) return rc2;
+        return ec3d_vtk_fields_begin(s.c, delta, big_endian, &got[(size_t)r]); // enqueued only: nothing waits here
+    }, true);
+    if (rc) return rc;
+    for (int r = 1; r < m->n; ++r)
+        if (got[(size_t)r] != got[0]) {
+            ec3d_set_error("ec3d_multi_vtk_fields_begin: the slabs' output slots are out of step");
+            return 4;
+        }
+    *slot = got[0];
+    return 0;
+}
+
+extern "C" int ec3d_multi_vtk_fields_wait(ec3d_multi_handle m, int32_t slot, int32_t rank, const float **field_A,
+                                          const float **field_eddy, const float **field_source, const float **field_B,
+                                          int64_t *cell0, int64_t *ncells)
+{
+    int rc = need(m, "ec3d_multi_vtk_fields_wait");
+    if (rc) return rc;
+    if (rank < 0 || rank >= m->n) {
+        ec3d_set_error("ec3d_multi_vtk_fields_wait: no such slab");
+        return 2;
+    }
+    Slab &s = *m->slab[(size_t)rank];
+    if (cell0) *cell0 = (int64_t)s.k0 * m->kdz;
+    return ec3d_vtk_fields_wait(s.c, slot, field_A, field_eddy, field_source, field_B, ncells);
+}
+
 // ---- bench "steps": exits disabled, launches only ---------------------------------------------------------
 extern "C" int ec3d_multi_iterate_begin(ec3d_multi_handle m)
 {

@@ -17,7 +17,8 @@ module ec3d_hip
               ec3d_vtk_fields, EC3D_VEC_X, EC3D_VEC_B, ec3d_true_residual, &
               ec3d_multi_create, ec3d_multi_destroy, ec3d_multi_assemble, ec3d_multi_set_matrix_csr, &
               ec3d_multi_solve, ec3d_multi_upload, ec3d_multi_download, ec3d_multi_solve_resident, &
-              ec3d_multi_rhs_step, ec3d_multi_post_update, ec3d_multi_vtk_fields, ec3d_multi_true_residual
+              ec3d_multi_rhs_step, ec3d_multi_post_update, ec3d_multi_vtk_fields, ec3d_multi_true_residual, &
+              ec3d_multi_vtk_fields_begin, ec3d_multi_vtk_fields_wait
 
     integer(c_int), parameter :: EC3D_VEC_X = 0, EC3D_VEC_B = 1   ! Uaf, Jaf
 
@@ -240,6 +241,24 @@ module ec3d_hip
             type(c_ptr), value :: mh
             real(c_double), intent(in) :: delta(*)
             real(c_float), intent(out) :: fA(*), fEddy(*), fSource(*), fB(*)   ! 3*nCells each, the WHOLE grid
+        end function
+        ! the overlapped output over the slabs: _begin on all of them, _wait per slab (rank = 0 .. nranks-1): that
+        ! slab's cells cell0 .. cell0+ncells-1 of every vector; fEddy = c_null_ptr for a slab without conductor
+        integer(c_int) function ec3d_multi_vtk_fields_begin(mh, delta, big_endian, slot) &
+                bind(C, name="ec3d_multi_vtk_fields_begin")
+            import :: c_ptr, c_int, c_double
+            type(c_ptr), value :: mh
+            real(c_double), intent(in) :: delta(*)
+            integer(c_int), value :: big_endian
+            integer(c_int), intent(out) :: slot
+        end function
+        integer(c_int) function ec3d_multi_vtk_fields_wait(mh, slot, rank, fA, fEddy, fSource, fB, cell0, ncells) &
+                bind(C, name="ec3d_multi_vtk_fields_wait")
+            import :: c_ptr, c_int, c_int64_t
+            type(c_ptr), value :: mh
+            integer(c_int), value :: slot, rank
+            type(c_ptr), intent(out) :: fA, fEddy, fSource, fB
+            integer(c_int64_t), intent(out) :: cell0, ncells
         end function
         integer(c_int) function ec3d_multi_true_residual(mh, rel, bnorm) bind(C, name="ec3d_multi_true_residual")
             import :: c_ptr, c_int, c_double

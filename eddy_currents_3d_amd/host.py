@@ -332,7 +332,8 @@ def run(model: vxc.VxcModel, solver, steps: int | None = None, out_dir: str | No
     ``write_output(N) -> bool`` (default: always) says whether output step N's files go to disk; the fields are
     computed on the device and brought to the host either way.
 
-    ``overlap_output`` (default, single-device handles): the field output of step N runs beside step N+1 -- field
+    ``overlap_output`` (default; one handle or the slabs of an EC3DMulti, whose ``fields`` are then per-slab lists,
+    vtk.join_parts): the field output of step N runs beside step N+1 -- field
     kernel and device-to-host copy asynchronously, formatting-free writing on a host thread (_OutputPipeline); the
     files are the same bytes.  ``on_fields(N, fields, info)`` is then called on one of the writer threads with views of
     the pinned buffer (valid during the call; calls for different N may overlap and arrive out of order).  Without overlap the fields are fetched synchronously after the post-update,

@@ -66,7 +66,8 @@ EXPORTS = ["sprsbcgstabwr_", "ec3d_invalidate", "ec3d_create", "ec3d_destroy", "
            "ec3d_multi_create", "ec3d_multi_destroy", "ec3d_multi_ranks", "ec3d_multi_slab", "ec3d_multi_set_format",
            "ec3d_multi_assemble_poisson", "ec3d_multi_assemble", "ec3d_multi_set_matrix_csr", "ec3d_multi_size",
            "ec3d_multi_upload", "ec3d_multi_download", "ec3d_multi_solve", "ec3d_multi_solve_resident",
-           "ec3d_multi_rhs_step", "ec3d_multi_post_update", "ec3d_multi_vtk_fields", "ec3d_multi_iterate_begin",
+           "ec3d_multi_rhs_step", "ec3d_multi_post_update", "ec3d_multi_vtk_fields", "ec3d_multi_vtk_fields_begin",
+           "ec3d_multi_vtk_fields_wait", "ec3d_multi_iterate_begin",
            "ec3d_multi_iterate", "ec3d_multi_synchronize", "ec3d_true_residual", "ec3d_multi_true_residual", "ec3d_get_visit_order", "ec3d_probe_csr_multi", "ec3d_multi_spmv", "ec3d_multi_api_calls"]
 
 _f64 = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
@@ -203,6 +204,9 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.ec3d_multi_post_update.argtypes = [hp]
     L.ec3d_multi_spmv.argtypes = [hp, _f64, _f64]
     L.ec3d_multi_vtk_fields.argtypes = [hp, _f64, hp, hp, hp, hp]
+    L.ec3d_multi_vtk_fields_begin.argtypes = [hp, _f64, C.c_int32, C.POINTER(C.c_int32)]
+    L.ec3d_multi_vtk_fields_wait.argtypes = ([hp, C.c_int32, C.c_int32] + [C.POINTER(C.POINTER(C.c_float))] * 4 +
+                                             [C.POINTER(C.c_int64)] * 2)
     L.ec3d_multi_iterate_begin.argtypes = [hp]
     L.ec3d_multi_iterate.argtypes = [hp, C.c_int32, C.c_int32, hp]
     L.ec3d_multi_synchronize.argtypes = [hp]
@@ -725,6 +729,39 @@ class EC3DMulti:
                                                   fe.ctypes.data if conducting else None, fs.ctypes.data,
                                                   fb.ctypes.data), "ec3d_multi_vtk_fields")
         return dict(A=fa, eddy=fe, source=fs, B=fb)
+
+    def vtk_fields_begin(self, delta, big_endian: bool = True) -> int:
+        """EC3DSolver.vtk_fields_begin on every slab (ec3d_multi_vtk_fields_begin): nothing waits; returns the slot."""
+        slot = C.c_int32(0)
+        _chk(self.L, self.L.ec3d_multi_vtk_fields_begin(self.h, np.ascontiguousarray(delta, np.float64), int(big_endian),
+                                                        C.byref(slot)), "ec3d_multi_vtk_fields_begin")
+        return slot.value
+
+    def vtk_fields_wait(self, slot: int, big_endian: bool = True):
+        """dict(A, eddy (None without conductors), source, B); each value is a LIST with one (cells of the slab, 3)
+        view per slab, in z order -- together the cells of field_N.vtk in file order (vtk.field_vtk_pieces writes such
+        lists part by part; vtk.join_parts makes one array of them).  A slab that holds no conductor contributes
+        zeros to eddy.  The views are valid until the third vtk_fields_begin after the one that returned the slot."""
+        dt = np.dtype(">f4") if big_endian else np.dtype(np.float32)
+        parts = {k: [] for k in ("A", "eddy", "source", "B")}
+        at = 0
+        for r in range(self.nranks):
+            p = [C.POINTER(C.c_float)() for _ in range(4)]
+            c0, n = C.c_int64(0), C.c_int64(0)
+            _chk(self.L, self.L.ec3d_multi_vtk_fields_wait(self.h, slot, r, C.byref(p[0]), C.byref(p[1]), C.byref(p[2]),
+                                                           C.byref(p[3]), C.byref(c0), C.byref(n)),
+                 "ec3d_multi_vtk_fields_wait")
+            if c0.value != at:
+                raise EC3DError("ec3d_multi_vtk_fields_wait: the slabs do not tile the grid")
+            at += n.value
+            for k, q in zip(("A", "eddy", "source", "B"), p):
+                parts[k].append(np.ctypeslib.as_array(q, shape=(n.value * 3,)).view(dt).reshape(n.value, 3)
+                                if q else None)
+        if all(e is None for e in parts["eddy"]):
+            parts["eddy"] = None
+        else:
+            parts["eddy"] = [e if e is not None else np.zeros(a.shape, dt) for e, a in zip(parts["eddy"], parts["A"])]
+        return parts
 
     def iterate_begin(self):
         _chk(self.L, self.L.ec3d_multi_iterate_begin(self.h), "ec3d_multi_iterate_begin")

@@ -44,10 +44,13 @@ def field_vtk_pieces(sdx, sdy, sdz, delta, fields):
            _points_block(sdx, sdy, sdz, delta), b"\n", ("POINT_DATA %s\n" % _i8(n)).encode()]
 
     def vec(name, a):
-        a = np.ascontiguousarray(a)
-        if a.dtype != np.dtype(">f4"):
-            a = a.astype(">f4")
-        return [("VECTORS %s float\n" % name).encode(), memoryview(a).cast("B"), b"\n"]
+        out = [("VECTORS %s float\n" % name).encode()]
+        for part in (a if isinstance(a, (list, tuple)) else [a]):     # per-slab parts (EC3DMulti.vtk_fields_wait)
+            part = np.ascontiguousarray(part)
+            if part.dtype != np.dtype(">f4"):
+                part = part.astype(">f4")
+            out.append(memoryview(part).cast("B"))
+        return out + [b"\n"]
 
     out += vec("Field_A", fields["A"])
     if fields.get("eddy") is not None:
@@ -55,6 +58,11 @@ def field_vtk_pieces(sdx, sdy, sdz, delta, fields):
     out += vec("Vector_field_SOURCE", fields["source"])
     out += vec("Vector_field_B", fields["B"])
     return out
+
+
+def join_parts(fields):
+    """Per-slab lists (EC3DMulti.vtk_fields_wait) as one array per vector; arrays pass through."""
+    return {k: (np.concatenate(v) if isinstance(v, (list, tuple)) else v) for k, v in fields.items()}
 
 
 def field_vtk_bytes(sdx, sdy, sdz, delta, fields) -> bytes:

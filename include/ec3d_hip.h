@@ -274,6 +274,14 @@ int ec3d_multi_spmv(ec3d_multi_handle mh, const double *x, double *y);
 int ec3d_multi_true_residual(ec3d_multi_handle mh, double *rel, double *bnorm); /* as ec3d_true_residual */
 int ec3d_multi_vtk_fields(ec3d_multi_handle mh, const double *delta, float *field_A, float *field_eddy,
                           float *field_source, float *field_B);
+/* ec3d_vtk_fields_begin / _wait over the slabs: _begin enqueues every slab's field kernel and its copy into that
+ * slab's pinned buffers and returns; _wait blocks on ONE slab's copy and hands out its part -- cells cell0 ..
+ * cell0 + ncells of every vector (consecutive in field_N.vtk, src/utilites.f90:222-289); field_eddy = NULL for a
+ * slab that holds no conductor (zeros in the file) */
+int ec3d_multi_vtk_fields_begin(ec3d_multi_handle mh, const double *delta, int32_t big_endian, int32_t *slot);
+int ec3d_multi_vtk_fields_wait(ec3d_multi_handle mh, int32_t slot, int32_t rank, const float **field_A,
+                               const float **field_eddy, const float **field_source, const float **field_B,
+                               int64_t *cell0, int64_t *ncells);
 /* bench "steps" as ec3d_iterate_begin / ec3d_iterate: every rank's thread enqueues the iterations and
  * returns; ec3d_multi_synchronize drains all devices.  kernel_ms (5 doubles): rank 0's stage averages. */
 int ec3d_multi_iterate_begin(ec3d_multi_handle mh);

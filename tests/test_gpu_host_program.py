@@ -51,14 +51,17 @@ def test_shipped_input_runs_like_the_reference(case, tmp_path):
         assert info["iter"] == it_ref
 
 
-def test_overlapped_output_writes_the_same_files(tmp_path):
+@pytest.mark.parametrize("slabs", [1, 3], ids=["one-handle", "three-slabs"])
+def test_overlapped_output_writes_the_same_files(tmp_path, slabs):
     """Field output beside the next step's solve (host._OutputPipeline over ec3d_vtk_fields_begin / _wait: field
     kernel behind the post-update, bytes swapped on the device, pinned double buffer, a host thread that writes) must
     leave exactly the files the synchronous path writes -- the moving-coil LIM input, 6 steps, 5 outputs, so both
-    pinned buffers are reused while the loop runs ahead."""
+    pinned buffers are reused while the loop runs ahead.  On three slabs behind one multi handle
+    (ec3d_multi_vtk_fields_begin / _wait) every slab copies its own part and the writer strings them together."""
     import filecmp
     import eddy_currents_3d_amd as E
     from eddy_currents_3d_amd import host, vxc
+    from eddy_currents_3d_amd.vtk import join_parts
     g = load_golden("g4_LIM")
     model = vxc.VxcModel(g["vox"], [str(s) for s in g["names"]], float(str(g["lattice_dim"])),
                          tuple(float(x) for x in g["adj"]))
@@ -66,9 +69,10 @@ def test_overlapped_output_writes_the_same_files(tmp_path):
     for mode in (True, False):
         d = tmp_path / ("overlap" if mode else "sync")
         seen = []
-        with E.EC3DSolver() as s:
+        with (E.EC3DSolver() if slabs == 1 else E.EC3DMulti(slabs, devices=[0] * slabs)) as s:
             logs[mode] = host.run(model, s, steps=6, out_dir=str(d), overlap_output=mode,
-                                  on_fields=lambda N, f, info: seen.append((N, float(np.abs(f["A"].astype(np.float32)).max()))))
+                                  on_fields=lambda N, f, info: seen.append(
+                                      (N, float(np.abs(join_parts(f)["A"].astype(np.float32)).max()))))
         # (overlapped: three writer threads, so the callbacks may arrive out of order)
         assert sorted(n for n, _ in seen) == [1, 2, 3, 4, 5] and all(a > 0 for _, a in seen)
     assert [i["iter"] for i in logs[True]] == [i["iter"] for i in logs[False]]

@@ -192,6 +192,11 @@ def test_multi_fields_reproduce_reference_file(E, world, plane_pitch):
             m.post_update()
             f = m.vtk_fields(g["delta"], sdx * sdy * sdz, True)
             assert field_vtk_bytes(sdx, sdy, sdz, g["delta"], f) == g[f"vtk_field_{k}"].tobytes()
+            # the same through the overlapped entry points: per-slab parts in the file's byte order
+            slot = m.vtk_fields_begin(g["delta"], big_endian=True)
+            parts = m.vtk_fields_wait(slot, big_endian=True)
+            assert all(len(v) == world and v[0].dtype == np.dtype(">f4") for v in parts.values())
+            assert field_vtk_bytes(sdx, sdy, sdz, g["delta"], parts) == g[f"vtk_field_{k}"].tobytes()
 
 
 @pytest.mark.parametrize("dictionary", [True, False])
