@@ -340,6 +340,7 @@ struct ec3d_ctx {
     hipEvent_t out_ev_fields = nullptr, out_ev_free = nullptr, out_ev_copied[EC3D_OUT_SLOTS] = {nullptr, nullptr, nullptr};
     int out_next = 0;
     bool out_busy = false;
+    unsigned out_started = 0;  // bit i: slot i has had an ec3d_vtk_fields_begin (its event is worth waiting for)
 };
 
 // partial-sum slots inside ctx->partials (each nblk doubles)

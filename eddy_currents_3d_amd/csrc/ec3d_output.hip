@@ -150,6 +150,7 @@ void ec3d_free_output(ec3d_ctx *c)
     c->out_stream = nullptr;
     c->out_next = 0;
     c->out_busy = false;
+    c->out_started = 0;
 }
 
 extern "C" int ec3d_vtk_fields(ec3d_handle c, const double *delta, float *field_A, float *field_eddy,
@@ -198,6 +199,7 @@ extern "C" int ec3d_vtk_fields_begin(ec3d_handle c, const double *delta, int32_t
     EC3D_HIP(hipEventRecord(c->out_ev_free, c->out_stream));
     c->out_busy = true;
     c->out_next = (i + 1) % EC3D_OUT_SLOTS;
+    c->out_started |= 1u << i;
     *slot = i;
     return 0;
 }
@@ -205,11 +207,12 @@ extern "C" int ec3d_vtk_fields_begin(ec3d_handle c, const double *delta, int32_t
 extern "C" int ec3d_vtk_fields_wait(ec3d_handle c, int32_t slot, const float **field_A, const float **field_eddy,
                                     const float **field_source, const float **field_B, int64_t *ncells)
 {
-    if (!c || slot < 0 || slot >= EC3D_OUT_SLOTS || !c->out_pinned[slot]) {
+    if (!c || slot < 0 || slot >= EC3D_OUT_SLOTS || !c->out_pinned[slot] || !(c->out_started >> slot & 1u)) {
         ec3d_set_error("ec3d_vtk_fields_wait: no such slot (call ec3d_vtk_fields_begin first)");
         return 2;
     }
-    EC3D_HIP(hipSetDevice(c->device));
+    // (an event can be waited for from any thread, whatever its current device: the caller's device stays as it is --
+    // the writer threads of a multi-GPU host call this for one slab after the other)
     EC3D_HIP(hipEventSynchronize(c->out_ev_copied[slot]));
     const float *p = c->out_pinned[slot];
     const int64_t n = c->out_cells;

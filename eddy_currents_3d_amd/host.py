@@ -297,22 +297,37 @@ class _SourcesAhead:
         import threading
         self.q = queue.Queue(maxsize=2)
         self.error = None
+        self.stop = threading.Event()           # the loop ended early (an error, `steps`): do not wait on a full queue
+
+        def put(item):
+            while not self.stop.is_set():
+                try:
+                    self.q.put(item, timeout=0.2)
+                    return True
+                except queue.Full:
+                    pass
+            return False
 
         def work():
             try:
                 t, k = T, 0
                 while True:
                     idx, val, moving = prog.step(t)
-                    self.q.put((t, idx, val, moving, list(prog.groups)))
+                    if not put((t, idx, val, moving, list(prog.groups))):
+                        return
                     k += 1
                     t = t + DT
                     if not t < Time or (steps is not None and k >= steps):
                         break
             except BaseException as e:
                 self.error = e
-                self.q.put(None)
+                put(None)
         self.thread = threading.Thread(target=work, name="ec3d-sources", daemon=True)
         self.thread.start()
+
+    def close(self):
+        self.stop.set()
+        self.thread.join()
 
     def next(self, T):
         item = self.q.get()
@@ -374,53 +389,144 @@ def _time_loop(solver, t, prog, dims, conducting, out_dir, pipe, steps, on_step,
     sdx, sdy, sdz = dims
     log = []
     ahead = _SourcesAhead(prog, T, DT, Time, steps)
-    while True:
-        idx, val, moving, groups = ahead.next(T)
-        info = dict(T=T, nsrc=len(idx))
-        solver.rhs_step(idx, val, moving=moving)
-        if on_rhs is not None:
-            on_rhs(len(log), solver, info)
-        it, _ = solver.solve_resident(t["tol"], t["itmax"])
-        info["iter"] = it
-        if on_solved is not None:
-            on_solved(len(log), solver, info)
-        solver.post_update()
-        if Ntime >= Nprint and Ntime != 0:               # :437-446
-            Nprint = Ntime + Nout
-            Npoint += 1
-            if out_dir and pipe is not None:
-                pipe.start(Npoint, groups, write_output is None or bool(write_output(Npoint)), info)
-            elif out_dir:
-                f = solver.vtk_fields(t["delta"], sdx * sdy * sdz, conducting)
-                if on_fields is not None:
-                    on_fields(Npoint, f, info)
-                if write_output is None or write_output(Npoint):
-                    paths = [os.path.join(out_dir, f"field_{Npoint}.vtk")]
-                    write_field_vtk(paths[0], sdx, sdy, sdz, t["delta"], f)
-                    if groups:                           # :446  CALL writeVtk_src
-                        paths.append(os.path.join(out_dir, f"src_{Npoint}.vtk"))
-                        write_src_vtk(paths[1], sdx, sdy, sdz, t["delta"], groups)
-                    if on_written is not None:
-                        on_written(Npoint, paths)
-                else:
-                    info["fields"] = f
-            info["output"] = Npoint
-        log.append(info)
-        if on_step is not None:
-            on_step(len(log) - 1, solver, info)
-        Ntime += 1
-        T = T + DT
-        if not T < Time or (steps is not None and len(log) >= steps):
-            break
+    try:
+        while True:
+            idx, val, moving, groups = ahead.next(T)
+            info = dict(T=T, nsrc=len(idx))
+            solver.rhs_step(idx, val, moving=moving)
+            if on_rhs is not None:
+                on_rhs(len(log), solver, info)
+            it, _ = solver.solve_resident(t["tol"], t["itmax"])
+            info["iter"] = it
+            if on_solved is not None:
+                on_solved(len(log), solver, info)
+            solver.post_update()
+            if Ntime >= Nprint and Ntime != 0:               # :437-446
+                Nprint = Ntime + Nout
+                Npoint += 1
+                if out_dir and pipe is not None:
+                    pipe.start(Npoint, groups, write_output is None or bool(write_output(Npoint)), info)
+                elif out_dir:
+                    f = solver.vtk_fields(t["delta"], sdx * sdy * sdz, conducting)
+                    if on_fields is not None:
+                        on_fields(Npoint, f, info)
+                    if write_output is None or write_output(Npoint):
+                        paths = [os.path.join(out_dir, f"field_{Npoint}.vtk")]
+                        write_field_vtk(paths[0], sdx, sdy, sdz, t["delta"], f)
+                        if groups:                           # :446  CALL writeVtk_src
+                            paths.append(os.path.join(out_dir, f"src_{Npoint}.vtk"))
+                            write_src_vtk(paths[1], sdx, sdy, sdz, t["delta"], groups)
+                        if on_written is not None:
+                            on_written(Npoint, paths)
+                    else:
+                        info["fields"] = f
+                info["output"] = Npoint
+            log.append(info)
+            if on_step is not None:
+                on_step(len(log) - 1, solver, info)
+            Ntime += 1
+            T = T + DT
+            if not T < Time or (steps is not None and len(log) >= steps):
+                break
+    finally:
+        ahead.close()
     return log
 
 
+class _SlabOutputPipeline:
+    """field_N.vtk of a one-process-per-GPU run without gathering anything: a z-slab's cells are consecutive bytes of
+    every vector in the file (src/utilites.f90:222-289 writes cell by cell, z outermost), so each rank puts its own part
+    where it belongs (``vtk.field_vtk_layout``, ``os.pwrite``) and rank 0 adds the text, the POINTS block and
+    src_N.vtk.  Per rank the same pipeline as on one GPU: ``ec3d_vtk_fields_begin`` on the slab's handle behind the
+    X halo exchange, three pinned buffers, a writer thread each; ``finish`` joins them -- the caller's barrier after it
+    is what makes the files complete on every rank."""
+
+    def __init__(self, s, dims, delta, conducting, out_dir, rank):
+        import queue
+        import threading
+        from .solver import VTK_SLOTS
+        from .vtk import field_vtk_layout
+        self.s, self.dims, self.delta, self.out_dir, self.rank = s, dims, delta, out_dir, rank
+        sdx, sdy, sdz = dims
+        self.text, self.data, self.size = field_vtk_layout(sdx, sdy, sdz, delta, conducting)
+        self.cell0 = s.k0 * sdx * sdy
+        self.jobs, self.done, self.error = queue.Queue(), [], None
+        self._Event = threading.Event
+        self.slots = VTK_SLOTS
+        self.threads = [threading.Thread(target=self._work, name=f"ec3d-slab-output-{i}", daemon=True)
+                        for i in range(self.slots)]
+        for th in self.threads:
+            th.start()
+
+    def start(self, N, groups):
+        if len(self.done) >= self.slots:
+            self.done[-self.slots].wait()
+        self._raise()
+        ops = self.s.ops
+        with ops.context():
+            self.s.exchange("X")                                   # the curl reads the neighbours' planes
+            slot = ops.local.vtk_fields_begin(self.delta, big_endian=True)
+        ev = self._Event()
+        self.done.append(ev)
+        self.jobs.put((slot, N, [(ax, np.array(nodes), a) for ax, nodes, a in groups] if self.rank == 0 else None, ev))
+
+    def _work(self):
+        sdx, sdy, sdz = self.dims
+        while True:
+            job = self.jobs.get()
+            if job is None:
+                return
+            slot, N, groups, ev = job
+            try:
+                f = self.s.ops.local.vtk_fields_wait(slot, big_endian=True)
+                fd = os.open(os.path.join(self.out_dir, f"field_{N}.vtk"), os.O_WRONLY | os.O_CREAT, 0o644)
+                try:
+                    if self.rank == 0:
+                        os.ftruncate(fd, self.size)
+                        for off, b in self.text:
+                            _pwrite_all(fd, b, off)
+                    for k, off in self.data.items():
+                        part = f[k]
+                        if part is None:                           # a slab without conductor: zeros in the file
+                            part = np.zeros(f["A"].shape, ">f4")
+                        _pwrite_all(fd, part, off + 12 * self.cell0)
+                finally:
+                    os.close(fd)
+                if groups:                                         # rank 0: src/EC3D.f90:446  CALL writeVtk_src
+                    write_src_vtk(os.path.join(self.out_dir, f"src_{N}.vtk"), sdx, sdy, sdz, self.delta, groups)
+            except BaseException as e:
+                self.error = e
+            finally:
+                ev.set()
+
+    def _raise(self):
+        if self.error is not None:
+            e, self.error = self.error, None
+            raise e
+
+    def finish(self):
+        for _ in self.threads:
+            self.jobs.put(None)
+        for th in self.threads:
+            th.join()
+        self._raise()
+
+
+def _pwrite_all(fd, data, offset):
+    mv = memoryview(np.ascontiguousarray(data) if isinstance(data, np.ndarray) else data).cast("B")
+    while len(mv):
+        k = os.pwrite(fd, mv, offset)
+        mv, offset = mv[k:], offset + k
+
+
 def run_slabs(model: vxc.VxcModel, rank: int, world: int, device: int = 0, steps: int | None = None,
-              out_dir: str | None = None, on_step=None):
+              out_dir: str | None = None, on_step=None, overlap_output: bool = True):
     """The same run on ``world`` GPUs, one process per GPU (torch.distributed initialised by the caller):
     z-slabs of the A-V system (eddy_currents_3d_amd/dist.py), every rank evaluates the (tiny) source program
-    itself and keeps its part of the fields resident; rank 0 writes the output files.  Returns the per-step
-    log (identical on all ranks)."""
+    itself and keeps its part of the fields resident.  Output: every rank writes its own cells into field_N.vtk
+    beside the next step's solve (_SlabOutputPipeline; the files are complete when this function returns, after a
+    barrier); ``overlap_output=False``: the fields gathered on rank 0, which writes them inside the loop.  Returns the
+    per-step log (identical on all ranks)."""
     from .dist import HipAVSlabOps, SlabSolver, slab_bounds
     t = vxc.domain_tables(model)
     if t["dt"] is None or t["time"] is None:
@@ -440,6 +546,11 @@ def run_slabs(model: vxc.VxcModel, rank: int, world: int, device: int = 0, steps
     T, Ntime, Nprint, Npoint = 0.0, 0, Nout, 0
     if out_dir and rank == 0:
         os.makedirs(out_dir, exist_ok=True)
+    pipe = None
+    if out_dir and overlap_output:
+        if world > 1:
+            s.dist.barrier()                                 # the directory exists before anyone opens a file in it
+        pipe = _SlabOutputPipeline(s, (sdx, sdy, sdz), t["delta"], conducting, out_dir, rank)
     log = []
     try:
         while True:
@@ -452,7 +563,9 @@ def run_slabs(model: vxc.VxcModel, rank: int, world: int, device: int = 0, steps
                 Nprint = Ntime + Nout
                 Npoint += 1
                 info["output"] = Npoint
-                if out_dir:
+                if pipe is not None:
+                    pipe.start(Npoint, prog.groups)
+                elif out_dir:
                     f = s.vtk_fields(t["delta"], conducting)      # gathered on rank 0
                     if rank == 0:
                         write_field_vtk(os.path.join(out_dir, f"field_{Npoint}.vtk"), sdx, sdy, sdz, t["delta"], f)
@@ -466,6 +579,16 @@ def run_slabs(model: vxc.VxcModel, rank: int, world: int, device: int = 0, steps
             T = T + DT
             if not T < Time or (steps is not None and len(log) >= steps):
                 break
+        if pipe is not None:
+            pipe.finish()
+            pipe = None
+            if world > 1:
+                s.dist.barrier()                             # every rank's part of every file is in place
     finally:
+        if pipe is not None:                                 # an error above: stop the writers, keep the error
+            try:
+                pipe.finish()
+            except BaseException:
+                pass
         ops.close()
     return log

@@ -37,6 +37,10 @@ def _points_block(sdx, sdy, sdz, delta) -> bytes:
 def field_vtk_pieces(sdx, sdy, sdz, delta, fields):
     """The file as a list of bytes-like pieces, in order.  Vectors that already are big-endian float32 (dtype '>f4':
     what EC3DSolver.vtk_fields_wait hands out, swapped on the device) go out as views -- no copy, no conversion."""
+    return _field_vtk_plan(sdx, sdy, sdz, delta, fields)
+
+
+def _field_vtk_plan(sdx, sdy, sdz, delta, fields):
     n = sdx * sdy * sdz
     out = [b"# vtk DataFile Version 3.0\nout data result\nBINARY\n",
            ("DATASET STRUCTURED_GRID\nDIMENSIONS %s\n" % _i8(sdx, sdy, sdz)).encode(),
@@ -46,6 +50,9 @@ def field_vtk_pieces(sdx, sdy, sdz, delta, fields):
     def vec(name, a):
         out = [("VECTORS %s float\n" % name).encode()]
         for part in (a if isinstance(a, (list, tuple)) else [a]):     # per-slab parts (EC3DMulti.vtk_fields_wait)
+            if isinstance(part, _Hole):
+                out.append(part)
+                continue
             part = np.ascontiguousarray(part)
             if part.dtype != np.dtype(">f4"):
                 part = part.astype(">f4")
@@ -58,6 +65,35 @@ def field_vtk_pieces(sdx, sdy, sdz, delta, fields):
     out += vec("Vector_field_SOURCE", fields["source"])
     out += vec("Vector_field_B", fields["B"])
     return out
+
+
+class _Hole:
+    """Stand-in for a vector of `nbytes` bytes when only the positions in the file are wanted."""
+
+    def __init__(self, nbytes):
+        self.nbytes = nbytes
+
+
+def field_vtk_layout(sdx, sdy, sdz, delta, conducting):
+    """Where everything of field_N.vtk lies: (text, data, size) -- text = [(offset, bytes)] for all that does not come
+    from the device (header, POINTS block, the VECTORS lines, the newlines), data = {"A" | "eddy" | "source" | "B":
+    offset of the vector's first byte}, size = the file's length.  Cell c of a vector is the 12 bytes at data[k] + 12 c:
+    slabs of the grid are consecutive bytes, so every process of a multi-process run can put its own part where it
+    belongs (host.run_slabs) and nothing has to be gathered."""
+    n = sdx * sdy * sdz
+    keys = ["A"] + (["eddy"] if conducting else []) + ["source", "B"]
+    fields = {k: _Hole(12 * n) for k in keys}
+    fields.setdefault("eddy", None)
+    text, data, at = [], {}, 0
+    holes = {id(v): k for k, v in fields.items() if v is not None}
+    for p in _field_vtk_plan(sdx, sdy, sdz, delta, fields):
+        if id(p) in holes:
+            data[holes[id(p)]] = at
+            at += p.nbytes
+        else:
+            text.append((at, p))
+            at += len(p)
+    return text, data, at
 
 
 def join_parts(fields):

@@ -151,8 +151,12 @@ def _host_worker(rank, world, port, out):
         g = load_golden("g4_LIM")
         model = vxc.VxcModel(g["vox"], [str(s) for s in g["names"]], float(str(g["lattice_dim"])),
                              tuple(float(x) for x in g["adj"]))
-        log = host.run_slabs(model, rank, world, device=0, steps=3, out_dir=out if rank == 0 else out)
+        log = host.run_slabs(model, rank, world, device=0, steps=3, out_dir=out)
+        # the same with the fields gathered on rank 0 and written inside the loop, as rounds 1-3 did
+        log2 = host.run_slabs(model, rank, world, device=0, steps=3, out_dir=os.path.join(out, "gathered"),
+                              overlap_output=False)
         if rank == 0:
+            assert [i["iter"] for i in log] == [i["iter"] for i in log2]
             np.save(os.path.join(out, "iters.npy"), np.array([i["iter"] for i in log]))
     finally:
         dist.destroy_process_group()
@@ -168,5 +172,9 @@ def test_two_ranks_run_a_shipped_model_end_to_end(tmp_path):
     iters = np.load(os.path.join(out, "iters.npy"))
     print("2 ranks:", iters, "reference:", g["iters"])
     assert np.all(np.abs(iters - g["iters"]) <= np.maximum(3, 0.15 * g["iters"]))
-    assert sorted(f for f in os.listdir(out) if f.endswith(".vtk")) == ["field_1.vtk", "field_2.vtk", "src_1.vtk",
-                                                                        "src_2.vtk"]
+    names = ["field_1.vtk", "field_2.vtk", "src_1.vtk", "src_2.vtk"]
+    assert sorted(f for f in os.listdir(out) if f.endswith(".vtk")) == names
+    # every rank put its own cells into the files, beside the next step's solve: the bytes of the gathered path
+    import filecmp
+    match, mismatch, errors = filecmp.cmpfiles(out, os.path.join(out, "gathered"), names, shallow=False)
+    assert sorted(match) == names and not mismatch and not errors

@@ -70,6 +70,10 @@ def test_device_fields_and_curl_reproduce_reference_file(name, steps, plane_pitc
             fn = s.vtk_fields_wait(slot, big_endian=False)
             assert all(np.array_equal(fn[key], f[key]) for key in ("A", "source", "B"))
             assert (fn["eddy"] is None) == (f["eddy"] is None) and (f["eddy"] is None or np.array_equal(fn["eddy"], f["eddy"]))
+        # a slot nothing was started in is refused, not handed out as whatever the buffer holds
+        if len(steps) == 1:
+            with pytest.raises(E.EC3DError, match="no such slot"):
+                s.vtk_fields_wait(2)
 
 
 @pytest.mark.gpu
