@@ -164,6 +164,7 @@ static void free_vectors(ec3d_ctx *c)
     if (c->partials) (void)hipFree(c->partials);
     if (c->pp_base) (void)hipFree(c->pp_base);
     c->pp_base = nullptr;
+    c->pp_len = 0;
     c->vec_base = nullptr;
     c->partials = nullptr;
     for (auto &v : c->vec) v = nullptr;
@@ -752,25 +753,58 @@ int ec3d_prepare_vectors(ec3d_ctx *c)
     return place_bands(c);
 }
 
-// the second buffers of P and AP for K5-in-K1 (ec3d_fused51): only handles that own their vectors
+// the second buffers of P and AP for K5-in-K1 (ec3d_fused51), and the rings of P and S for the deferred X update
+// (ec3d_xdefer): only handles that own their vectors
 int ec3d_spare_pair(ec3d_ctx *c)
 {
+    for (int j = 0; j < EC3D_XD_MAX; ++j) c->pbuf[j] = c->sbuf[j] = nullptr;
     c->pbuf[1] = c->vec[EC3D_VEC_P];
+    c->sbuf[1] = c->vec[EC3D_VEC_S];
     c->apbuf[1] = c->vec[EC3D_VEC_AP];
+    c->apbuf[0] = nullptr;
+    c->pdepth = 2;
+    c->xdefer = 1;
+    c->pcur = c->apcur = c->scur = 1;
     if (!c->fuse51_ok || !c->own_vectors) {
         if (c->pp_base) (void)hipFree(c->pp_base);
         c->pp_base = nullptr;
-        c->pbuf[0] = c->apbuf[0] = nullptr;
+        c->pp_len = 0;
         return 0;
     }
+    // X every D-th iteration: from the size where both fusions run by themselves (everything streams from HBM there, every
+    // kernel at 5.6-5.9 TB/s of what it moves, so bytes are the only lever: K4 moves 50 B per row on average instead of
+    // 56; 512^3: K4 1278 -> 1185 us, profiles/r04_deferred_x_512.log).  EC3D_XDEFER=1 keeps the classic K4, 2 .. 4 force
+    // a depth on any handle that runs both fusions
+    int D = (c->fuse23_ok && c->A.n_pad >= ((int64_t)1 << 26)) ? 4 : 1;
+    if (const char *e = getenv("EC3D_XDEFER")) D = std::max(1, std::min(EC3D_XD_MAX, atoi(e)));
+    if (!c->fuse23_ok) D = 1;
+    c->xdefer = D;
+    c->pdepth = std::max(2, D);
     const int64_t len = c->ghost + c->A.n_pad + c->ghost;
-    if (!c->pp_base) {
-        EC3D_HIP(hipMalloc(&c->pp_base, (size_t)len * 2 * sizeof(double)));
-        EC3D_HIP(hipMemsetAsync(c->pp_base, 0, (size_t)len * 2 * sizeof(double), c->stream));
-        EC3D_HIP(hipStreamSynchronize(c->stream));
+    const int64_t want = len * ((c->pdepth - 1) + 1 + (D - 1));
+    if (c->pp_base && c->pp_len != want) {
+        (void)hipFree(c->pp_base);
+        c->pp_base = nullptr;
     }
-    c->pbuf[0] = c->pp_base + c->ghost;
-    c->apbuf[0] = c->pp_base + len + c->ghost;
+    if (!c->pp_base) {
+        EC3D_HIP(hipMalloc(&c->pp_base, (size_t)want * sizeof(double)));
+        EC3D_HIP(hipMemsetAsync(c->pp_base, 0, (size_t)want * sizeof(double), c->stream));
+        EC3D_HIP(hipStreamSynchronize(c->stream));
+        c->pp_len = want;
+    }
+    double *at = c->pp_base + c->ghost;
+    c->apbuf[0] = at;
+    at += len;
+    for (int j = 0; j < c->pdepth; ++j)
+        if (j != 1) {
+            c->pbuf[j] = at;
+            at += len;
+        }
+    for (int j = 0; j < D; ++j)
+        if (j != 1) {
+            c->sbuf[j] = at;
+            at += len;
+        }
     return 0;
 }
 
@@ -1368,8 +1402,9 @@ extern "C" int ec3d_get_row_map(ec3d_handle c, int32_t *ref_to_dev)
 // P and AP alternate between two buffers while K5 runs inside K1 (ec3d_fused51): the pair the last launch wrote
 static double *cur_vec(ec3d_ctx *c, int which)
 {
-    if (ec3d_fused51(c) && which == EC3D_VEC_P) return c->pbuf[c->pcur & 1];
-    if (ec3d_fused51(c) && which == EC3D_VEC_AP) return c->apbuf[c->pcur & 1];
+    if (ec3d_fused51(c) && which == EC3D_VEC_P) return c->pbuf[c->pcur];
+    if (ec3d_fused51(c) && which == EC3D_VEC_AP) return c->apbuf[c->apcur];
+    if (ec3d_xdefer(c) > 1 && which == EC3D_VEC_S) return c->sbuf[c->scur];
     return c->vec[which];
 }
 

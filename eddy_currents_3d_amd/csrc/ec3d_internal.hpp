@@ -170,6 +170,7 @@ __host__ __device__ inline int64_t ec3d_tile_of(const SW &sw, int b, int64_t i)
     }
     return t < sw.ntiles ? ec3d_phys_tile(sw, t) : -1;
 }
+#define EC3D_XD_MAX 4 // deepest deferral of the X update (iterations whose P and S are kept)
 struct SolverState {
     double rr0[2]; // R·R0 entering iteration it is rr0[it & 1]
     double alpha, omega;
@@ -179,6 +180,10 @@ struct SolverState {
     int stop_kind; // 1: ‖S‖ exit (solvers.f90:34-38), 2: ‖R‖ exit (:43), 0: none / ‖b‖ = 0
     int restarts;  // times the restart R0 = R, P = R (solvers.f90:47-49) fired in this solve (ec3d_get_restart_count)
     int pad_;
+    // X updates not applied yet (k4d_x_r_update): alpha, omega of the pending iterations, oldest first
+    double pend_alpha[EC3D_XD_MAX], pend_omega[EC3D_XD_MAX];
+    int npend;     // how many
+    int pend_half; // the newest one is the ||S|| exit's X = X + alpha*P (no omega*S term)
 };
 
 // host-side image of the format (CSR conversion / export)
@@ -264,9 +269,17 @@ struct ec3d_ctx {
     // K5-in-K1 reads the previous iteration's P and AP while it writes the new ones (neighbouring workgroups read the
     // old values of cells this one owns), so both vectors alternate between two buffers: P(it) lives in
     // pbuf[it & 1], AP(it) in apbuf[it & 1]; index 1 is vec[EC3D_VEC_P] / vec[EC3D_VEC_AP], index 0 the spare pair
+    // With the X update deferred over D iterations (k4d_x_r_update; only together with both fusions) P(it) lives in
+    // pbuf[it % D] and S(it) in sbuf[it % D] (index 1 = vec[EC3D_VEC_P] / vec[EC3D_VEC_S]); AP keeps its two buffers.
     double *pp_base = nullptr;
-    double *pbuf[2] = {nullptr, nullptr}, *apbuf[2] = {nullptr, nullptr};
-    int pcur = 1;          // which pair holds the CURRENT P / AP (what ec3d_download and ec3d_device_vector hand out)
+    int64_t pp_len = 0;    // doubles allocated at pp_base
+    double *pbuf[EC3D_XD_MAX] = {nullptr}, *sbuf[EC3D_XD_MAX] = {nullptr}, *apbuf[2] = {nullptr, nullptr};
+    int pdepth = 2;        // buffers P cycles through (2, or D)
+    int xdefer = 1;        // D: iterations between two X updates on this handle (1: every iteration, the classic K4)
+    int xd_base = 1;       // the iteration the groups of D are counted from (1 in a solve; ec3d_iterate: its first_iter)
+    int xd_last = 0x7fffffff; // the last iteration the present call is going to launch: it applies whatever is pending
+    int pcur = 1;          // which P buffer holds the CURRENT P (what ec3d_download and ec3d_device_vector hand out)
+    int apcur = 1, scur = 1; // the same for AP and S
     int ap_valid_for = 0;  // K5-in-K1: the iteration whose AP = A P the last K51 launch already produced (0: none)
     // K2/K5 as boundary + interior launches (ec3d_dist_set_boundary_rows): tile lists on the device
     Sweep sweep_vb{}, sweep_vi{};
@@ -423,6 +436,8 @@ RedSrc ec3d_part_of(const ec3d_ctx *c, int producer, bool split = false);
 void ec3d_launch_stage(ec3d_ctx *c, const MatView &A, int it, int k); // k = 1..5, 0 = all five
 inline bool ec3d_fused23(const ec3d_ctx *c) { return c->fuse23_ok && !c->dist && c->halo == 0; }
 inline bool ec3d_fused51(const ec3d_ctx *c) { return c->fuse51_ok && !c->dist && c->halo == 0 && c->pp_base != nullptr; }
+inline int ec3d_xdefer(const ec3d_ctx *c) { return (ec3d_fused23(c) && ec3d_fused51(c) && c->xdefer > 1) ? c->xdefer : 1; }
+int ec3d_flush_x(ec3d_ctx *c, int stop_iter); // the pending X updates after an exit at stop_iter (enqueued)
 void ec3d_launch_iteration(ec3d_ctx *c, const MatView &A, int it);
 int ec3d_launch_begin(ec3d_ctx *c, const MatView &A, double tol);
 int ec3d_single_rank_only(ec3d_ctx *c, const char *who);
@@ -445,6 +460,11 @@ void ec3d_launch_k23(const MatView &A, const Sweep &sw, const RedSrc &src, Solve
 void ec3d_launch_k51(const MatView &A, const Sweep &sw, const RedSrc &src, SolverState *st, int it, const double *r,
                      const double *p_old, const double *ap_old, double *p_new, double *ap_new, double *r0, double *part,
                      double *hist, int64_t hist_cap, hipStream_t s);
+void ec3d_launch_k4d(const Sweep &sw, const RedSrc &src_ss, const RedSrc &src, SolverState *st, int it, int ne, int xm,
+                     const double *const *p, const double *const *sv, const double *as, const double *r0, double *x,
+                     double *r, double *part, double *hist, int64_t hist_cap, hipStream_t s);
+void ec3d_launch_x_flush(const Sweep &sw, const SolverState *st, const double *const *p, const double *const *sv,
+                         double *x, hipStream_t s);
 void ec3d_launch_k4(const Sweep &sw, const RedSrc &src_ss, const RedSrc &src, SolverState *st, int it,
                     const double *p, const double *sv, const double *as, const double *r0, double *x, double *r,
                     double *part, double *hist, int64_t hist_cap, hipStream_t s);

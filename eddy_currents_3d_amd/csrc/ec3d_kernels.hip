@@ -1501,6 +1501,8 @@ __global__ __launch_bounds__(EC3D_THREADS) void k_setup(SolverState *st, RedSrc 
         st->alpha = 0.0;
         st->omega = 0.0;
         st->restarts = 0;
+        st->npend = 0;
+        st->pend_half = 0;
         st->rnorm = sqrt(v[1]);
         stop_publish(st, (bnorm == 0.0) ? 0 : INT_MAX, 0);
     }
@@ -1809,6 +1811,156 @@ __global__ __launch_bounds__(EC3D_THREADS) void k4_x_r_update(SweepV sw, RedSrc 
         part[P_RR * sw.pstride + sw.part_off + blockIdx.x] = acc[0];
         part[P_RR0N * sw.pstride + sw.part_off + blockIdx.x] = acc[1];
     }
+}
+
+// K4 with the X update DEFERRED (single rank, three-launch iteration, vectors far beyond the caches).
+// X = X + alpha*P + omega*S (src/solvers.f90:41) is the only statement of the loop that reads or writes X, and nothing in
+// the loop reads X: the update of iteration k may be carried out LATER, as long as the updates are applied in order and
+// each as the same two rounded additions -- X is then the same bits.  P(k) and S(k) stay untouched for D iterations in
+// rings of D buffers (ec3d_ctx::pbuf / sbuf), alpha(k) and omega(k) wait in the SolverState; D - 1 of D iterations run
+// K4 WITHOUT X (NE = 0: 24 B read, 8 B written per row instead of 40 / 16) and the D-th applies the D updates at once
+// (NE = D: 24 + 16 D B read, 16 written).  Reads are unchanged in total (S is read a second time instead of X), D - 1 of D
+// writes of X never happen: 50 B per row and iteration at D = 4 instead of 56.  An exit with updates pending (the ||S||
+// exit here, the ||R|| exit in K51) leaves them to k_x_flush, which the host launches once it has seen the exit word.
+struct XRing {
+    const double *p[EC3D_XD_MAX]; // P and S of the pending iterations, oldest first; the last entry is this iteration's
+    const double *s[EC3D_XD_MAX];
+};
+template <bool NT, int NE>
+__global__ __launch_bounds__(EC3D_THREADS) void k4d_x_r_update(SweepV sw, RedSrc src_ss, RedSrc src, SolverState *st, int it,
+                                                               int xm, XRing ring, const double *__restrict__ as,
+                                                               const double *__restrict__ r0, double *__restrict__ x,
+                                                               double *__restrict__ rv, double *__restrict__ part,
+                                                               double *hist, int64_t hist_cap)
+{
+    __shared__ double lds[8];
+    constexpr int NC = NE > 0 ? NE - 1 : 0; // entry of this iteration's P and S in the ring argument
+    const int slot_ss[1] = {P_SS};
+    const int slot[2] = {P_D2, P_D3};
+    PartialsEarly<1> pss;
+    PartialsEarly<2> pd;
+    partials_request<1>(src_ss, slot_ss, pss);
+    partials_request<2>(src, slot, pd);
+    const double alpha = st->alpha, bnorm = st->bnorm, tol = st->tol;
+    double pa[EC3D_XD_MAX], po[EC3D_XD_MAX];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        pa[j] = st->pend_alpha[j];
+        po[j] = st->pend_omega[j];
+    }
+    const int stop_it = stop_iter_of(st);
+    EC3D_REQUESTS_OUT;
+    if (stop_it < it) return;
+    double ss[1];
+    partials_finish<1>(src_ss, slot_ss, pss, ss, lds);
+    const double snorm = sqrt(ss[0]);
+    const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+    if (lead && hist && it <= hist_cap) hist[2 * (int64_t)(it - 1)] = snorm;
+    if (snorm / bnorm < tol) { // src/solvers.f90:34-38: X = X + alpha*P joins the pending updates as a half one
+        if (lead) {
+            st->pend_alpha[xm] = alpha;
+            st->pend_omega[xm] = 0.0;
+            st->npend = xm + 1;
+            st->pend_half = 1;
+            stop_publish(st, it, 1);
+        }
+        return;
+    }
+    double d[2];
+    partials_finish<2>(src, slot, pd, d, lds);
+    const double omega = d[0] / d[1];
+    if (lead) {
+        st->omega = omega;
+        if (NE == 0) {
+            st->pend_alpha[xm] = alpha;
+            st->pend_omega[xm] = omega;
+            st->npend = xm + 1;
+        } else {
+            st->npend = 0;
+        }
+    }
+    pa[NC] = alpha;
+    po[NC] = omega;
+    double acc[2] = {0.0, 0.0};
+    struct Ops { d2 xv, pv[NE > 0 ? NE : 1], s[NE > 0 ? NE : 1], a, q; };
+    walk_vec(sw, [&](int64_t tile) {
+        EC3D_ROW;
+        Ops o;
+        if (NE > 0) o.xv = load2<NT>(x + r);
+#pragma unroll
+        for (int j = 0; j < NE; ++j) o.pv[j] = load2<NT>(ring.p[j] + r);
+#pragma unroll
+        for (int j = 0; j < (NE > 0 ? NE : 1); ++j) o.s[j] = load2<NT>(ring.s[j] + r);
+        o.a = load2<NT>(as + r);
+        o.q = load2<NT>(r0 + r);
+        return o;
+    }, [&](int64_t tile, const Ops &o) {
+        EC3D_ROW;
+        if (NE > 0) {
+            d2 xv = o.xv;
+#pragma unroll
+            for (int j = 0; j < NE; ++j) { // one (X + alpha*P) + omega*S per pending iteration, oldest first
+                xv.x = (xv.x + pa[j] * o.pv[j].x) + po[j] * o.s[j].x;
+                xv.y = (xv.y + pa[j] * o.pv[j].y) + po[j] * o.s[j].y;
+            }
+            store2<NT>(x, r, sw.n, xv.x, xv.y);
+        }
+        const d2 s = o.s[NC], a = o.a, q = o.q;
+        double e0 = s.x - omega * a.x, e1 = s.y - omega * a.y;
+        store2k<NT>(rv, r, sw.n, e0, e1, keep_of(sw) & EC3D_KEEP_R);
+        EC3D_MASK2(r, sw, e0, e1);
+        acc[0] = acc[0] + e0 * e0;
+        acc[0] = acc[0] + e1 * e1;
+        acc[1] = acc[1] + e0 * q.x;
+        acc[1] = acc[1] + e1 * q.y;
+    });
+    block_sum<2>(acc, lds);
+    if (threadIdx.x == 0) {
+        part[P_RR * sw.pstride + sw.part_off + blockIdx.x] = acc[0];
+        part[P_RR0N * sw.pstride + sw.part_off + blockIdx.x] = acc[1];
+    }
+}
+
+// the pending X updates after an exit: entries 0 .. npend-1 of the ring, the last one without its omega*S term when the
+// exit was the ||S|| one (src/solvers.f90:34-38).  Launched by the host after the exit word has been seen.
+__global__ __launch_bounds__(EC3D_THREADS) void k_x_flush(SweepV sw, const SolverState *st, XRing ring, double *__restrict__ x)
+{
+    const int np = st->npend, half = st->pend_half;
+    double pa[EC3D_XD_MAX], po[EC3D_XD_MAX];
+#pragma unroll
+    for (int j = 0; j < EC3D_XD_MAX; ++j) {
+        pa[j] = st->pend_alpha[j];
+        po[j] = st->pend_omega[j];
+    }
+    if (np <= 0) return;
+    struct Ops { d2 xv, pv[EC3D_XD_MAX], s[EC3D_XD_MAX]; };
+    walk_vec(sw, [&](int64_t tile) {
+        EC3D_ROW;
+        Ops o;
+        o.xv = *reinterpret_cast<const d2 *>(x + r);
+#pragma unroll
+        for (int j = 0; j < EC3D_XD_MAX; ++j)
+            if (j < np) {
+                o.pv[j] = *reinterpret_cast<const d2 *>(ring.p[j] + r);
+                o.s[j] = (half && j == np - 1) ? d2{0.0, 0.0} : *reinterpret_cast<const d2 *>(ring.s[j] + r);
+            }
+        return o;
+    }, [&](int64_t tile, const Ops &o) {
+        EC3D_ROW;
+        d2 xv = o.xv;
+#pragma unroll
+        for (int j = 0; j < EC3D_XD_MAX; ++j)
+            if (j < np) {
+                if (half && j == np - 1) { // X = X + alpha*P alone: no second addition (X + 0.0 could turn -0 into +0)
+                    xv.x = xv.x + pa[j] * o.pv[j].x;
+                    xv.y = xv.y + pa[j] * o.pv[j].y;
+                } else {
+                    xv.x = (xv.x + pa[j] * o.pv[j].x) + po[j] * o.s[j].x;
+                    xv.y = (xv.y + pa[j] * o.pv[j].y) + po[j] * o.s[j].y;
+                }
+            }
+        store2<false>(x, r, sw.n, xv.x, xv.y);
+    });
 }
 
 // K5: if ‖R‖/Bnorm < tol exit (src/solvers.f90:43) ; beta = (alpha/omega)*rr0_new/rr0 (:45) ;
@@ -2130,6 +2282,53 @@ void ec3d_launch_k4(const Sweep &sw, const RedSrc &src_ss, const RedSrc &src, So
                     double *part, double *hist, int64_t hist_cap, hipStream_t s)
 {
     EC3D_LAUNCH_VEC(k4_x_r_update, src_ss, src, st, it, p, sv, as, r0, x, r, part, hist, hist_cap);
+}
+
+// K4 of an iteration whose X update is deferred (ne = 0) or which applies ne >= 2 pending updates; p[j], sv[j]: the
+// pending iterations' P and S, oldest first, this iteration's last (ne = 0: only sv[0], this iteration's S)
+void ec3d_launch_k4d(const Sweep &sw, const RedSrc &src_ss, const RedSrc &src, SolverState *st, int it, int ne, int xm,
+                     const double *const *p, const double *const *sv, const double *as, const double *r0, double *x,
+                     double *r, double *part, double *hist, int64_t hist_cap, hipStream_t s)
+{
+    XRing ring{};
+    for (int j = 0; j < (ne > 0 ? ne : 1); ++j) {
+        ring.p[j] = p[j];
+        ring.s[j] = sv[j];
+    }
+    SweepV swv = sweep_v(sw);
+    {   // tiles in flight per wave: the launch without X has 4 streams, the applying one 7 + 4 (ne - 1) -- not K4's 7.
+        // Measured at 512^3 (profiles/r04_deferred_x_512.log): without X 1 / 2 / 4 / 8 tiles 1.00 / 0.81 / 0.75 / 0.76 ms,
+        // the applying launch better with one tile at ne >= 3, with two at ne = 2
+        static const int off_depth = getenv("EC3D_XD_OFF_DEPTH") ? atoi(getenv("EC3D_XD_OFF_DEPTH")) : 4;
+        static const int on_depth = getenv("EC3D_XD_ON_DEPTH") ? atoi(getenv("EC3D_XD_ON_DEPTH")) : 0;
+        const int want = ne == 0 ? off_depth : (on_depth > 0 ? on_depth : (ne == 2 ? 2 : 1));
+        if (swv.win_nt == 0) swv.two = (want == 2 || want == 4) ? want : 1;
+    }
+#define EC3D_K4D(NE)                                                                                                         \
+    do {                                                                                                                     \
+        if (nt_of(sw))                                                                                                       \
+            k4d_x_r_update<true, NE><<<sw.nblk, EC3D_THREADS, 0, s>>>(swv, src_ss, src, st, it, xm, ring, as, r0, x, r, part, hist, hist_cap); \
+        else                                                                                                                 \
+            k4d_x_r_update<false, NE><<<sw.nblk, EC3D_THREADS, 0, s>>>(swv, src_ss, src, st, it, xm, ring, as, r0, x, r, part, hist, hist_cap); \
+    } while (0)
+    switch (ne) {
+    case 0: EC3D_K4D(0); break;
+    case 2: EC3D_K4D(2); break;
+    case 3: EC3D_K4D(3); break;
+    default: EC3D_K4D(4); break;
+    }
+#undef EC3D_K4D
+}
+
+void ec3d_launch_x_flush(const Sweep &sw, const SolverState *st, const double *const *p, const double *const *sv,
+                         double *x, hipStream_t s)
+{
+    XRing ring{};
+    for (int j = 0; j < EC3D_XD_MAX; ++j) {
+        ring.p[j] = p[j];
+        ring.s[j] = sv[j];
+    }
+    k_x_flush<<<sw.nblk, EC3D_THREADS, 0, s>>>(sweep_v(sw), st, ring, x);
 }
 
 void ec3d_launch_k5(const Sweep &sw, const RedSrc &src, SolverState *st, int it, const double *r, const double *ap,

@@ -21,6 +21,7 @@ extern "C" int ec3d_time_iterations(ec3d_handle c, int32_t iters, double *ms_tot
     c->hist_cap = 0;
     if ((rc = ec3d_launch_begin(c, A, -1.0))) return rc; // tol < 0: no exit, no restart
     EC3D_HIP(hipEventRecord(c->t0, c->stream));
+    c->xd_last = iters;
     for (int it = 1; it <= iters; ++it) ec3d_launch_iteration(c, A, it);
     EC3D_HIP(hipEventRecord(c->t1, c->stream));
     EC3D_HIP(hipGetLastError());
@@ -51,12 +52,24 @@ extern "C" int ec3d_get_fusion(ec3d_handle c, int32_t *k2_in_k3, int32_t *k5_in_
     return 0;
 }
 
+extern "C" int ec3d_get_x_interval(ec3d_handle c, int32_t *iterations)
+{
+    int rc = ec3d_need_matrix(c, "ec3d_get_x_interval");
+    if (rc) return rc;
+    if (iterations) *iterations = ec3d_xdefer(c);
+    return 0;
+}
+
 extern "C" int ec3d_iterate(ec3d_handle c, int32_t first_iter, int32_t count, double *kernel_ms)
 {
     int rc = ec3d_need_matrix(c, "ec3d_iterate");
     if (rc) return rc;
     if ((rc = ec3d_single_rank_only(c, "ec3d_iterate"))) return rc;
     const MatView A = c->A.view();
+    // deferred X update: groups counted from this call's first iteration, its last one applies what is pending --
+    // every call leaves X complete
+    c->xd_base = first_iter;
+    c->xd_last = first_iter + count - 1;
     if (!kernel_ms) {
         for (int it = first_iter; it < first_iter + count; ++it) ec3d_launch_iteration(c, A, it);
         EC3D_HIP(hipGetLastError());
@@ -106,7 +119,9 @@ extern "C" int ec3d_time_kernel(ec3d_handle c, int kernel, int32_t reps, double 
         return 5;
     }
     if ((rc = ec3d_launch_begin(c, A, -1.0))) return rc;
+    c->xd_last = 1;
     ec3d_launch_iteration(c, A, 1); // populate every partial slot and the scalars
+    c->xd_base = c->xd_last = 2;     // (the single stages below: the classic K4, nothing pending)
     auto one = [&]() {
         if (kernel == EC3D_K_SPMV)
             ec3d_launch_spmv(A, c->sweep_s, v[EC3D_VEC_P], v[EC3D_VEC_AP], s);

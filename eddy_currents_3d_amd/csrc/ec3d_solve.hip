@@ -50,31 +50,68 @@ void ec3d_launch_stage(ec3d_ctx *c, const MatView &A, int it, int k)
     hipStream_t s = c->stream;
     const bool fused = ec3d_fused23(c); // K2 inside K3 (2-D tiles, single rank): stage 2 is empty, stage 3 is K23
     const bool f51 = ec3d_fused51(c);
-    double *P = f51 ? c->pbuf[it & 1] : v[EC3D_VEC_P], *AP = f51 ? c->apbuf[it & 1] : v[EC3D_VEC_AP];
+    const int D = ec3d_xdefer(c), pd = c->pdepth;
+    double *P = f51 ? c->pbuf[it % pd] : v[EC3D_VEC_P], *AP = f51 ? c->apbuf[it & 1] : v[EC3D_VEC_AP];
+    double *S = D > 1 ? c->sbuf[it % D] : v[EC3D_VEC_S];
     // fused: AP(it) was produced by the previous iteration's K51 -- unless this call does not continue that
     // iteration (iteration 1, ec3d_iterate from another first_iter, ec3d_time_kernel): then K1 runs on its own
     if ((k == 0 || k == 1) && (!f51 || it == 1 || c->ap_valid_for != it))
         ec3d_launch_k1(A, ss, c->state, it, P, v[EC3D_VEC_R0], AP, c->partials, s);
     if ((k == 0 || k == 2) && !fused)
-        ec3d_launch_k2(c->sweep_k2, ec3d_src_of(c, EC3D_BY_SPMV), c->state, it, v[EC3D_VEC_R], AP, v[EC3D_VEC_S], c->partials, s);
-    if ((k == 0 || k == 3) && fused)
-        ec3d_launch_k23(A, ss, ec3d_src_of(c, EC3D_BY_SPMV), c->state, it, v[EC3D_VEC_R], AP, v[EC3D_VEC_S],
-                        v[EC3D_VEC_AS], c->partials, s);
+        ec3d_launch_k2(c->sweep_k2, ec3d_src_of(c, EC3D_BY_SPMV), c->state, it, v[EC3D_VEC_R], AP, S, c->partials, s);
+    if ((k == 0 || k == 3) && fused) {
+        ec3d_launch_k23(A, ss, ec3d_src_of(c, EC3D_BY_SPMV), c->state, it, v[EC3D_VEC_R], AP, S, v[EC3D_VEC_AS], c->partials, s);
+        c->scur = D > 1 ? it % D : 1;
+    }
     if ((k == 0 || k == 3) && !fused)
-        ec3d_launch_k3(A, ss, c->state, it, v[EC3D_VEC_S], v[EC3D_VEC_AS], c->partials, s);
-    if (k == 0 || k == 4)
-        ec3d_launch_k4(sw, ec3d_src_of(c, EC3D_BY_K2), ec3d_src_of(c, EC3D_BY_SPMV), c->state, it, P, v[EC3D_VEC_S],
-                       v[EC3D_VEC_AS], v[EC3D_VEC_R0], v[EC3D_VEC_X], v[EC3D_VEC_R], c->partials, c->hist,
-                       c->hist_cap, s);
+        ec3d_launch_k3(A, ss, c->state, it, S, v[EC3D_VEC_AS], c->partials, s);
+    if (k == 0 || k == 4) {
+        // position of this iteration in its group of D, and how many updates an applying launch finds pending
+        const int xm = D > 1 ? (it - c->xd_base) % D : 0;
+        const bool apply = D <= 1 || xm == D - 1 || it >= c->xd_last;
+        if (D <= 1 || (apply && xm == 0)) {
+            ec3d_launch_k4(sw, ec3d_src_of(c, EC3D_BY_K2), ec3d_src_of(c, EC3D_BY_SPMV), c->state, it, P, S, v[EC3D_VEC_AS],
+                           v[EC3D_VEC_R0], v[EC3D_VEC_X], v[EC3D_VEC_R], c->partials, c->hist, c->hist_cap, s);
+        } else {
+            const double *pp[EC3D_XD_MAX] = {nullptr}, *sp[EC3D_XD_MAX] = {nullptr};
+            const int ne = apply ? xm + 1 : 0;
+            for (int j = 0; j < ne; ++j) { // iterations it - xm .. it, oldest first
+                pp[j] = c->pbuf[(it - xm + j) % pd];
+                sp[j] = c->sbuf[(it - xm + j) % D];
+            }
+            if (ne == 0) sp[0] = S;
+            ec3d_launch_k4d(sw, ec3d_src_of(c, EC3D_BY_K2), ec3d_src_of(c, EC3D_BY_SPMV), c->state, it, ne, xm, pp, sp,
+                            v[EC3D_VEC_AS], v[EC3D_VEC_R0], v[EC3D_VEC_X], v[EC3D_VEC_R], c->partials, c->hist, c->hist_cap,
+                            s);
+        }
+    }
     if ((k == 0 || k == 5) && !f51)
         ec3d_launch_k5(c->sweep_k5, ec3d_src_of(c, EC3D_BY_K4), c->state, it, v[EC3D_VEC_R], AP, P,
                        v[EC3D_VEC_R0], c->hist, c->hist_cap, s);
     if ((k == 0 || k == 5) && f51) {
-        ec3d_launch_k51(A, ss, ec3d_src_of(c, EC3D_BY_K4), c->state, it, v[EC3D_VEC_R], P, AP, c->pbuf[(it + 1) & 1],
+        ec3d_launch_k51(A, ss, ec3d_src_of(c, EC3D_BY_K4), c->state, it, v[EC3D_VEC_R], P, AP, c->pbuf[(it + 1) % pd],
                         c->apbuf[(it + 1) & 1], v[EC3D_VEC_R0], c->partials, c->hist, c->hist_cap, s);
         c->ap_valid_for = it + 1;
-        c->pcur = (it + 1) & 1;
+        c->pcur = (it + 1) % pd;
+        c->apcur = (it + 1) & 1;
     }
+}
+
+// The X updates an exit at iteration stop_iter left pending (deferred X update): enqueued behind everything else.
+int ec3d_flush_x(ec3d_ctx *c, int stop_iter)
+{
+    const int D = ec3d_xdefer(c);
+    if (D <= 1 || stop_iter < c->xd_base) return 0;
+    const int xm = (stop_iter - c->xd_base) % D;
+    const double *pp[EC3D_XD_MAX], *sp[EC3D_XD_MAX];
+    for (int j = 0; j < EC3D_XD_MAX; ++j) { // entries past the pending count are never dereferenced: any valid pointer
+        const int itj = stop_iter - xm + std::min(j, xm);
+        pp[j] = c->pbuf[itj % c->pdepth];
+        sp[j] = c->sbuf[itj % D];
+    }
+    ec3d_launch_x_flush(c->sweep, c->state, pp, sp, c->vec[EC3D_VEC_X], c->stream);
+    EC3D_HIP(hipGetLastError());
+    return 0;
 }
 
 void ec3d_launch_iteration(ec3d_ctx *c, const MatView &A, int it) { ec3d_launch_stage(c, A, it, 0); }
@@ -85,8 +122,10 @@ int ec3d_launch_begin(ec3d_ctx *c, const MatView &A, double tol)
     ec3d_launch_residual(A, c->sweep_s, v[EC3D_VEC_X], v[EC3D_VEC_B], v[EC3D_VEC_R], v[EC3D_VEC_R0], v[EC3D_VEC_P],
                          c->partials, c->stream);
     ec3d_launch_setup(c->state, ec3d_src_of(c, EC3D_BY_SPMV), tol, c->stream);
-    c->pcur = 1; // P = R went to vec[P] = pbuf[1]
+    c->pcur = c->apcur = c->scur = 1; // P = R went to vec[P] = pbuf[1]
     c->ap_valid_for = 0;
+    c->xd_base = 1;
+    c->xd_last = INT_MAX;
     EC3D_HIP(hipGetLastError());
     return 0;
 }
@@ -125,6 +164,7 @@ static int solve_core(ec3d_ctx *c, double tol, int32_t itmax, int32_t *iter, dou
     int rc = ensure_hist(c, hist_host ? std::min<int64_t>(hist_cap, total) : 0);
     if (rc) return rc;
     if ((rc = ec3d_launch_begin(c, A, tol))) return rc;
+    c->xd_last = (int)std::min<int64_t>(total, INT_MAX); // the itmax exit: the last iteration applies what is pending
 
     // iterations per poll: about 0.4 ms of device work, so an exit is noticed within ~1 ms
     const double est_us = (double)c->A.n_pad * 264.0 / 4.0e6 + 12.0;
@@ -148,6 +188,10 @@ static int solve_core(ec3d_ctx *c, double tol, int32_t itmax, int32_t *iter, dou
     EC3D_HIP(hipStreamSynchronize(c->stream));
     SolverState fin;
     EC3D_HIP(hipMemcpy(&fin, c->state, sizeof fin, hipMemcpyDeviceToHost));
+    if (fin.stop_iter != INT_MAX && fin.npend > 0) { // an exit with X updates pending (deferred X update): apply them
+        if ((rc = ec3d_flush_x(c, fin.stop_iter))) return rc;
+        EC3D_HIP(hipStreamSynchronize(c->stream));
+    }
     if (fin.stop_iter != INT_MAX) {
         *iter = fin.stop_iter;
     } else {

@@ -395,6 +395,11 @@ int ec3d_iterate(ec3d_handle h, int32_t first_iter, int32_t count, double *kerne
  * preceding iteration's stage 5; P / AP then alternate between two buffers and ec3d_download / ec3d_device_vector
  * hand out the current one. */
 int ec3d_get_fusion(ec3d_handle h, int32_t *k2_in_k3, int32_t *k5_in_k1);
+/* iterations between two updates of X on this handle: 1 = X = X + alpha*P + omega*S in every iteration's K4
+ * (src/solvers.f90:41 where it stands); D > 1 (three-launch iteration on vectors far beyond the caches): K4 leaves X
+ * alone in D - 1 of D iterations and applies the D updates, in order and each as its own two rounded additions, in the
+ * D-th -- nothing in the loop reads X, so X is the same bits; an exit applies what is pending before the solve returns */
+int ec3d_get_x_interval(ec3d_handle h, int32_t *iterations);
 
 int ec3d_device_synchronize(ec3d_handle h);
 

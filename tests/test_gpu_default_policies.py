@@ -4,7 +4,8 @@ GPU-order twin, bit for bit.
 choose_sweep (csrc/ec3d_context.hip) switches by size: nontemporal streams from 4.5 Mi rows, the next kernel's operand
 kept cacheable up to 32 Mi rows, from 32 Mi rows the vector kernels on 256 workgroups with two tiles in flight, and from
 64 Mi rows on 2-D tiles the three-launch iteration (K2 inside K3, K5 inside the next K1, P / AP in alternating
-buffers).  The small
+buffers) with the X update applied every fourth iteration (k4d_x_r_update: six iterations = one whole group and the
+itmax exit's partial one).  The small
 parity cases force those instances through EC3D_NT / EC3D_KEEP / EC3D_FUSE* (tests/test_gpu_parity.py); here NOTHING is
 forced -- the handle is built the way bench.py builds it and the twin follows the launch geometry the library reports
 (ec3d_get_visit_order), for the first iterations of src/solvers.f90:24-50 (the itmax exit of :25-29 ends the run; the
@@ -25,12 +26,13 @@ def E():
 
 def no_knobs(monkeypatch):
     for k in ("EC3D_NT", "EC3D_KEEP", "EC3D_FUSE23", "EC3D_FUSE51", "EC3D_PATCH", "EC3D_NBLK", "EC3D_NBLK_SPMV",
-              "EC3D_VEC_DEPTH", "EC3D_XCD_MAP", "EC3D_PITCH", "EC3D_ZMARCH", "EC3D_SAV_PATCH"):
+              "EC3D_VEC_DEPTH", "EC3D_XCD_MAP", "EC3D_PITCH", "EC3D_ZMARCH", "EC3D_SAV_PATCH", "EC3D_XDEFER",
+              "EC3D_XD_OFF_DEPTH", "EC3D_XD_ON_DEPTH"):
         monkeypatch.delenv(k, raising=False)
 
 
 @pytest.mark.parametrize("dims, fused, iters", [((256, 256, 80), False, 8), ((512, 512, 128), False, 6),
-                                                ((512, 512, 256), True, 4)],
+                                                ((512, 512, 256), True, 6)],
                          ids=["5Mi-rows-nt-keep", "32Mi-rows-all-nontemporal", "64Mi-rows-three-launches"])
 def test_cube_at_the_default_policy_bitwise(E, oracle, dims, fused, iters, monkeypatch):
     """Single-component operator (BASELINE configs 2 / 4 family).  256 x 256 x 80 = 5.2 M rows: nontemporal streams,
@@ -50,6 +52,7 @@ def test_cube_at_the_default_policy_bitwise(E, oracle, dims, fused, iters, monke
         assert g1.patch_x == 128 and g1.zm_tpp == sdx * sdy // 512
         assert (g2.patch_x == 128 and g2.nblk == g1.nblk) == fused      # S.S summed inside the SpMV kernel when fused
         assert s.fusion() == ((1, 1) if fused else (0, 0))
+        assert s.x_interval() == (4 if fused else 1)      # and X updated every 4th iteration (k4d_x_r_update)
         x, it, hist = s.solve(b, x0, 1e-30, iters - 1, hist_cap=iters)
         xo, ito, hs, hr = oracle.twin_solve(s, valA, irow, jcol, b, x0, 1e-30, iters - 1, hist_cap=iters)
     assert it == ito == iters

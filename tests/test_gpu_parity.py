@@ -413,6 +413,61 @@ def test_two_dimensional_tiles_bitwise(E, oracle, grid, fuse, policy, monkeypatc
     assert np.linalg.norm(res["1"][0] - res["0"][0]) <= 1e-6 * np.linalg.norm(res["0"][0])
 
 
+@pytest.mark.parametrize("depth", [2, 3, 4])
+def test_deferred_x_update_bitwise(E, oracle, depth, monkeypatch):
+    """X = X + alpha*P + omega*S (src/solvers.f90:41) applied every `depth`-th iteration (k4d_x_r_update: P and S of the
+    pending iterations wait in rings, alpha and omega in the solver state; the default from 64 Mi rows with depth 2,
+    forced here on the three-launch iteration of a small grid).  Nothing in the loop reads X, the updates are applied in
+    order and each as its own two rounded additions: x must be the twin's bit for bit -- after the ||R|| exit and the
+    ||S|| exit at every position in a group (the pending updates are then applied by k_x_flush before the solve
+    returns, the ||S|| exit's X = X + alpha*P as a half update), after the itmax exit at every position (the last
+    iteration applies what is pending), and after bench-style ec3d_iterate calls of any length."""
+    monkeypatch.setenv("EC3D_FUSE23", "2")
+    monkeypatch.setenv("EC3D_FUSE51", "2")
+    monkeypatch.setenv("EC3D_PATCH", "1")
+    monkeypatch.setenv("EC3D_XDEFER", str(depth))
+    sdx, sdy, sdz = 256, 8, 9
+    n = sdx * sdy * sdz
+    valA, irow, jcol = oracle.poisson_csr(sdx, sdy, sdz)
+    rng = np.random.Generator(np.random.PCG64(414))
+    x0 = rng.standard_normal(n)
+    b = rng.standard_normal(n)
+    with E.EC3DSolver() as s:
+        s.assemble_poisson(sdx, sdy, sdz)
+        assert s.fusion() == (1, 1) and s.x_interval() == depth
+        # to convergence, with the history: the norms below give tolerances that end the solve at chosen iterations
+        x, it, hist = s.solve(b, x0, 1e-10, 5000, hist_cap=64)
+        xo, ito, hs, hr = oracle.twin_solve(s, valA, irow, jcol, b, x0, 1e-10, 5000, hist_cap=64)
+        assert it == ito and np.array_equal(x, xo) and it > 16
+        assert np.array_equal(hist[:16, 0], hs[:16]) and np.array_equal(hist[:16, 1], hr[:16])
+        bnorm = float(np.linalg.norm(b))
+        seen = set()
+        for k in range(1, 14):
+            for col in (0, 1):          # just above ||S_k|| / ||b|| and ||R_k|| / ||b||: an exit at iteration <= k
+                tol = float(hist[k - 1, col]) / bnorm * (1 + 1e-9)
+                xe, ite, _ = s.solve(b, x0, tol, 5000)
+                xeo, iteo, hse, hre = oracle.twin_solve(s, valA, irow, jcol, b, x0, tol, 5000, hist_cap=32)
+                assert ite == iteo and np.array_equal(xe, xeo), (depth, k, col)
+                s_exit = hse[ite - 1] / bnorm < tol
+                seen.add(((ite - 1) % depth, "S" if s_exit else "R"))
+        # both exits met at every position of a group
+        assert seen == {(m, kind) for m in range(depth) for kind in "SR"}, seen
+        for itmax in range(0, 2 * depth + 2):       # src/solvers.f90:25-29 after 1 .. 2 depth + 2 iterations
+            xm, itm, _ = s.solve(b, x0, 1e-30, itmax)
+            xmo, itmo, _, _ = oracle.twin_solve(s, valA, irow, jcol, b, x0, 1e-30, itmax)
+            assert itm == itmo == itmax + 1 and np.array_equal(xm, xmo), (depth, itmax)
+        # bench steps (exits and restart disabled): calls of 5 and 3 iterations leave the X of 8 iterations
+        s.upload("B", b)
+        s.upload("X", x0)
+        s.iterate_begin()
+        s.iterate(1, 5)
+        s.iterate(6, 3)
+        s.synchronize()
+        xi = s.download("X")
+        xr, itr, _ = s.solve(b, x0, 0.0, 7)          # tol = 0: no exit, no restart either -- 8 iterations
+        assert itr == 8 and np.array_equal(xi, xr)
+
+
 def test_large_grid_768_formats_bitwise(E, monkeypatch):
     """Well beyond the benchmark size (768^3, n = 452 984 832, 3.2e9 nonzeros > 2^31): plain DIA streams
     (25 GB) and the dictionary form give bit-identical iterates after 6 iterations -- a size-independent
