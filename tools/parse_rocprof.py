@@ -62,16 +62,31 @@ except (OSError, ValueError, KeyError, IndexError):
 res = {"tag": tag, "grid": grid, "n_gpus": 1, "format": fmt, "workload": workload, "rows": n, "units_note":
        "FETCH_SIZE/WRITE_SIZE are KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM (gfx950 reports 1/2 of a "
        "16-B-per-lane stream); per launch = mean over the launches of the profiled run", "kernels": {}}
-for k in sorted(set(fetch) | set(write)):
-    fv = sum(fetch[k]) / len(fetch[k]) if fetch.get(k) else None
-    wv = sum(write[k]) / len(write[k]) if write.get(k) else None
-    kk = re.match(r"(k[1-5])_", k)
-    kk = kk.group(1) if kk else k
+def stage_of(k, have_k4d):
     if k.startswith("k23_"):   # K2 inside K3: bench.py books it under k3
-        kk = "k3"
+        return "k3"
     if k.startswith("k51_"):   # K5 inside the next K1: booked under k5
-        kk = "k5"
-    res["kernels"][kk] = {"rocprof_name": k, "fetch_kib_raw": fv, "write_kib_raw": wv,
+        return "k5"
+    if k.startswith("k4d_"):   # K4 with the X update deferred: launches without X and applying launches, pooled --
+        return "k4"            # the mean over the launches of the run is the mean bench.py's kernels.k4.ms is
+    if k.startswith("k4_") and have_k4d:
+        return "k4_classic"    # (the lone launches of iteration 1 of a set-up pass)
+    m = re.match(r"(k[1-5])_", k)
+    return m.group(1) if m else k
+
+
+names = sorted(set(fetch) | set(write))
+have_k4d = any(k.startswith("k4d_") for k in names)
+pool_f, pool_w, pool_n = defaultdict(list), defaultdict(list), defaultdict(list)
+for k in names:
+    kk = stage_of(k, have_k4d)
+    pool_f[kk] += fetch.get(k, [])
+    pool_w[kk] += write.get(k, [])
+    pool_n[kk].append(f"{k} x{max(len(fetch.get(k, [])), len(write.get(k, [])))}")
+for kk in pool_n:
+    fv = sum(pool_f[kk]) / len(pool_f[kk]) if pool_f[kk] else None
+    wv = sum(pool_w[kk]) / len(pool_w[kk]) if pool_w[kk] else None
+    res["kernels"][kk] = {"rocprof_name": ", ".join(pool_n[kk]), "fetch_kib_raw": fv, "write_kib_raw": wv,
                          "hbm_read_bytes": None if fv is None else 2 * fv * 1024,
                          "hbm_write_bytes": None if wv is None else wv * 1024}
 for k, v in res["kernels"].items():
