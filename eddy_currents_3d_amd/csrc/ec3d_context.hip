@@ -765,19 +765,23 @@ int ec3d_spare_pair(ec3d_ctx *c)
     c->pdepth = 2;
     c->xdefer = 1;
     c->pcur = c->apcur = c->scur = 1;
-    if (!c->fuse51_ok || !c->own_vectors) {
+    // X every D-th iteration: from the size where both fusions run by themselves (everything streams from HBM there, every
+    // kernel at 5.6-5.9 TB/s of what it moves, so bytes are the only lever: K4 moves 50 B per row on average instead of
+    // 56; 512^3: K4 1278 -> 1185 us, profiles/r04_deferred_x_512.log).  EC3D_XDEFER=1 keeps the classic K4, 2 .. 4 force
+    // a depth on any single-rank handle that owns its vectors (the five-launch iteration too: K5 then writes the new P
+    // into the next buffer of the ring)
+    // Default: from 32 Mi streamed rows (nothing stays in a cache).  Below that the gain is within the noise (A-V 21 M rows
+    // -0.5 %, config 5 -0.4 %, config 3 +0.3 %, 256^3 -0.8 %; 384^3 on five launches -1.9 %: profiles/r04_deferred_x_mid_sizes.log)
+    const int64_t rows_eff = (c->A.sav && c->A.ulist) ? (c->A.ntiles_front + (int64_t)c->A.ulist_n) * EC3D_TILE : c->A.n_pad;
+    int D = rows_eff >= ((int64_t)1 << 25) ? 4 : 1;
+    if (const char *e = getenv("EC3D_XDEFER")) D = std::max(1, std::min(EC3D_XD_MAX, atoi(e)));
+    if (c->fuse23_ok != c->fuse51_ok || c->dist || c->halo != 0) D = 1;
+    if ((!c->fuse51_ok && D <= 1) || !c->own_vectors) {
         if (c->pp_base) (void)hipFree(c->pp_base);
         c->pp_base = nullptr;
         c->pp_len = 0;
         return 0;
     }
-    // X every D-th iteration: from the size where both fusions run by themselves (everything streams from HBM there, every
-    // kernel at 5.6-5.9 TB/s of what it moves, so bytes are the only lever: K4 moves 50 B per row on average instead of
-    // 56; 512^3: K4 1278 -> 1185 us, profiles/r04_deferred_x_512.log).  EC3D_XDEFER=1 keeps the classic K4, 2 .. 4 force
-    // a depth on any handle that runs both fusions
-    int D = (c->fuse23_ok && c->A.n_pad >= ((int64_t)1 << 26)) ? 4 : 1;
-    if (const char *e = getenv("EC3D_XDEFER")) D = std::max(1, std::min(EC3D_XD_MAX, atoi(e)));
-    if (!c->fuse23_ok) D = 1;
     c->xdefer = D;
     c->pdepth = std::max(2, D);
     const int64_t len = c->ghost + c->A.n_pad + c->ghost;
@@ -1402,7 +1406,7 @@ extern "C" int ec3d_get_row_map(ec3d_handle c, int32_t *ref_to_dev)
 // P and AP alternate between two buffers while K5 runs inside K1 (ec3d_fused51): the pair the last launch wrote
 static double *cur_vec(ec3d_ctx *c, int which)
 {
-    if (ec3d_fused51(c) && which == EC3D_VEC_P) return c->pbuf[c->pcur];
+    if ((ec3d_fused51(c) || ec3d_xdefer(c) > 1) && which == EC3D_VEC_P) return c->pbuf[c->pcur];
     if (ec3d_fused51(c) && which == EC3D_VEC_AP) return c->apbuf[c->apcur];
     if (ec3d_xdefer(c) > 1 && which == EC3D_VEC_S) return c->sbuf[c->scur];
     return c->vec[which];

@@ -180,7 +180,8 @@ extern "C" int ec3d_dist_step(ec3d_handle c, int32_t stage, int32_t it, double t
             return 3;
         }
         ec3d_launch_k5(stage == EC3D_STAGE_K5_BND ? c->sweep_vb : c->sweep_vi, ec3d_src_of(c, EC3D_BY_K4), c->state, it,
-                       v[EC3D_VEC_R], v[EC3D_VEC_AP], v[EC3D_VEC_P], v[EC3D_VEC_R0], c->hist, c->hist_cap, c->stream);
+                       v[EC3D_VEC_R], v[EC3D_VEC_AP], v[EC3D_VEC_P], v[EC3D_VEC_P], v[EC3D_VEC_R0], c->hist, c->hist_cap,
+                       c->stream);
         break;
     default: ec3d_set_error("ec3d_dist_step: unknown stage"); return 2;
     }

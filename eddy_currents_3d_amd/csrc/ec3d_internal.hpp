@@ -436,7 +436,12 @@ RedSrc ec3d_part_of(const ec3d_ctx *c, int producer, bool split = false);
 void ec3d_launch_stage(ec3d_ctx *c, const MatView &A, int it, int k); // k = 1..5, 0 = all five
 inline bool ec3d_fused23(const ec3d_ctx *c) { return c->fuse23_ok && !c->dist && c->halo == 0; }
 inline bool ec3d_fused51(const ec3d_ctx *c) { return c->fuse51_ok && !c->dist && c->halo == 0 && c->pp_base != nullptr; }
-inline int ec3d_xdefer(const ec3d_ctx *c) { return (ec3d_fused23(c) && ec3d_fused51(c) && c->xdefer > 1) ? c->xdefer : 1; }
+// deferred X update: single rank, own vectors (the rings exist), and the iteration either fully fused or not at all
+inline int ec3d_xdefer(const ec3d_ctx *c)
+{
+    if (c->xdefer <= 1 || c->dist || c->halo != 0 || c->pp_base == nullptr) return 1;
+    return (ec3d_fused23(c) == ec3d_fused51(c)) ? c->xdefer : 1;
+}
 int ec3d_flush_x(ec3d_ctx *c, int stop_iter); // the pending X updates after an exit at stop_iter (enqueued)
 void ec3d_launch_iteration(ec3d_ctx *c, const MatView &A, int it);
 int ec3d_launch_begin(ec3d_ctx *c, const MatView &A, double tol);
@@ -469,7 +474,7 @@ void ec3d_launch_k4(const Sweep &sw, const RedSrc &src_ss, const RedSrc &src, So
                     const double *p, const double *sv, const double *as, const double *r0, double *x, double *r,
                     double *part, double *hist, int64_t hist_cap, hipStream_t s);
 void ec3d_launch_k5(const Sweep &sw, const RedSrc &src, SolverState *st, int it, const double *r, const double *ap,
-                    double *p, double *r0, double *hist, int64_t hist_cap, hipStream_t s);
+                    const double *p_old, double *p, double *r0, double *hist, int64_t hist_cap, hipStream_t s);
 
 // ec3d_assemble.hip
 // planes [e0, e1) of the global grid are held (e0 = 0, e1 = sdz: everything); rows of planes outside

@@ -1965,11 +1965,14 @@ __global__ __launch_bounds__(EC3D_THREADS) void k_x_flush(SweepV sw, const Solve
 
 // K5: if ‖R‖/Bnorm < tol exit (src/solvers.f90:43) ; beta = (alpha/omega)*rr0_new/rr0 (:45) ;
 //     P = R + beta*(P - omega*AP) (:46) ; restart R0 = R, P = R when |rr0_new|/Bnorm < tol (:47-49)
+//     p_old == p: in place; p_old != p: the new P goes to the next buffer of the ring (deferred X update: the old P is
+//     still wanted by a later K4)
 template <bool NT>
 __global__ __launch_bounds__(EC3D_THREADS) void k5_p_update(SweepV sw, RedSrc src, SolverState *st, int it,
                                                             const double *__restrict__ rv,
-                                                            const double *__restrict__ ap, double *__restrict__ p,
-                                                            double *__restrict__ r0, double *hist, int64_t hist_cap)
+                                                            const double *__restrict__ ap, const double *p_old,
+                                                            double *p, double *__restrict__ r0, double *hist,
+                                                            int64_t hist_cap)
 {
     __shared__ double lds[8];
     // Only exits taken by EARLIER launches end this one: the ||S|| exit of this iteration's K4 (it, kind 1) or
@@ -2015,7 +2018,7 @@ __global__ __launch_bounds__(EC3D_THREADS) void k5_p_update(SweepV sw, RedSrc sr
         struct Ops { d2 q, pv, a; };
         walk_vec(sw, [&](int64_t tile) {
             EC3D_ROW;
-            return Ops{load2<NT>(rv + r), load2<NT>(p + r), load2<NT>(ap + r)};
+            return Ops{load2<NT>(rv + r), load2<NT>(p_old + r), load2<NT>(ap + r)};
         }, [&](int64_t tile, const Ops &o) {
             EC3D_ROW;
             const d2 q = o.q, pv = o.pv, a = o.a;
@@ -2332,7 +2335,7 @@ void ec3d_launch_x_flush(const Sweep &sw, const SolverState *st, const double *c
 }
 
 void ec3d_launch_k5(const Sweep &sw, const RedSrc &src, SolverState *st, int it, const double *r, const double *ap,
-                    double *p, double *r0, double *hist, int64_t hist_cap, hipStream_t s)
+                    const double *p_old, double *p, double *r0, double *hist, int64_t hist_cap, hipStream_t s)
 {
-    EC3D_LAUNCH_VEC(k5_p_update, src, st, it, r, ap, p, r0, hist, hist_cap);
+    EC3D_LAUNCH_VEC(k5_p_update, src, st, it, r, ap, p_old, p, r0, hist, hist_cap);
 }

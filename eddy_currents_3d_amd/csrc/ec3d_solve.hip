@@ -51,14 +51,17 @@ void ec3d_launch_stage(ec3d_ctx *c, const MatView &A, int it, int k)
     const bool fused = ec3d_fused23(c); // K2 inside K3 (2-D tiles, single rank): stage 2 is empty, stage 3 is K23
     const bool f51 = ec3d_fused51(c);
     const int D = ec3d_xdefer(c), pd = c->pdepth;
-    double *P = f51 ? c->pbuf[it % pd] : v[EC3D_VEC_P], *AP = f51 ? c->apbuf[it & 1] : v[EC3D_VEC_AP];
+    const bool ring = D > 1; // P(it) in pbuf[it % pd] also on the five-launch iteration (K5 then writes the next buffer)
+    double *P = (f51 || ring) ? c->pbuf[it % pd] : v[EC3D_VEC_P], *AP = f51 ? c->apbuf[it & 1] : v[EC3D_VEC_AP];
     double *S = D > 1 ? c->sbuf[it % D] : v[EC3D_VEC_S];
     // fused: AP(it) was produced by the previous iteration's K51 -- unless this call does not continue that
     // iteration (iteration 1, ec3d_iterate from another first_iter, ec3d_time_kernel): then K1 runs on its own
     if ((k == 0 || k == 1) && (!f51 || it == 1 || c->ap_valid_for != it))
         ec3d_launch_k1(A, ss, c->state, it, P, v[EC3D_VEC_R0], AP, c->partials, s);
-    if ((k == 0 || k == 2) && !fused)
+    if ((k == 0 || k == 2) && !fused) {
         ec3d_launch_k2(c->sweep_k2, ec3d_src_of(c, EC3D_BY_SPMV), c->state, it, v[EC3D_VEC_R], AP, S, c->partials, s);
+        c->scur = D > 1 ? it % D : 1;
+    }
     if ((k == 0 || k == 3) && fused) {
         ec3d_launch_k23(A, ss, ec3d_src_of(c, EC3D_BY_SPMV), c->state, it, v[EC3D_VEC_R], AP, S, v[EC3D_VEC_AS], c->partials, s);
         c->scur = D > 1 ? it % D : 1;
@@ -85,9 +88,11 @@ void ec3d_launch_stage(ec3d_ctx *c, const MatView &A, int it, int k)
                             s);
         }
     }
-    if ((k == 0 || k == 5) && !f51)
+    if ((k == 0 || k == 5) && !f51) {
         ec3d_launch_k5(c->sweep_k5, ec3d_src_of(c, EC3D_BY_K4), c->state, it, v[EC3D_VEC_R], AP, P,
-                       v[EC3D_VEC_R0], c->hist, c->hist_cap, s);
+                       ring ? c->pbuf[(it + 1) % pd] : P, v[EC3D_VEC_R0], c->hist, c->hist_cap, s);
+        if (ring) c->pcur = (it + 1) % pd;
+    }
     if ((k == 0 || k == 5) && f51) {
         ec3d_launch_k51(A, ss, ec3d_src_of(c, EC3D_BY_K4), c->state, it, v[EC3D_VEC_R], P, AP, c->pbuf[(it + 1) % pd],
                         c->apbuf[(it + 1) & 1], v[EC3D_VEC_R0], c->partials, c->hist, c->hist_cap, s);

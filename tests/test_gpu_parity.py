@@ -413,8 +413,9 @@ def test_two_dimensional_tiles_bitwise(E, oracle, grid, fuse, policy, monkeypatc
     assert np.linalg.norm(res["1"][0] - res["0"][0]) <= 1e-6 * np.linalg.norm(res["0"][0])
 
 
+@pytest.mark.parametrize("fuse", ["2", "0"], ids=["three-launches", "five-launches"])
 @pytest.mark.parametrize("depth", [2, 3, 4])
-def test_deferred_x_update_bitwise(E, oracle, depth, monkeypatch):
+def test_deferred_x_update_bitwise(E, oracle, depth, fuse, monkeypatch):
     """X = X + alpha*P + omega*S (src/solvers.f90:41) applied every `depth`-th iteration (k4d_x_r_update: P and S of the
     pending iterations wait in rings, alpha and omega in the solver state; the default from 64 Mi rows with depth 2,
     forced here on the three-launch iteration of a small grid).  Nothing in the loop reads X, the updates are applied in
@@ -422,8 +423,8 @@ def test_deferred_x_update_bitwise(E, oracle, depth, monkeypatch):
     ||S|| exit at every position in a group (the pending updates are then applied by k_x_flush before the solve
     returns, the ||S|| exit's X = X + alpha*P as a half update), after the itmax exit at every position (the last
     iteration applies what is pending), and after bench-style ec3d_iterate calls of any length."""
-    monkeypatch.setenv("EC3D_FUSE23", "2")
-    monkeypatch.setenv("EC3D_FUSE51", "2")
+    monkeypatch.setenv("EC3D_FUSE23", fuse)     # five launches: K2 writes S, K5 the new P into the next buffer of the rings
+    monkeypatch.setenv("EC3D_FUSE51", fuse)
     monkeypatch.setenv("EC3D_PATCH", "1")
     monkeypatch.setenv("EC3D_XDEFER", str(depth))
     sdx, sdy, sdz = 256, 8, 9
@@ -434,7 +435,7 @@ def test_deferred_x_update_bitwise(E, oracle, depth, monkeypatch):
     b = rng.standard_normal(n)
     with E.EC3DSolver() as s:
         s.assemble_poisson(sdx, sdy, sdz)
-        assert s.fusion() == (1, 1) and s.x_interval() == depth
+        assert s.fusion() == ((1, 1) if fuse == "2" else (0, 0)) and s.x_interval() == depth
         # to convergence, with the history: the norms below give tolerances that end the solve at chosen iterations
         x, it, hist = s.solve(b, x0, 1e-10, 5000, hist_cap=64)
         xo, ito, hs, hr = oracle.twin_solve(s, valA, irow, jcol, b, x0, 1e-10, 5000, hist_cap=64)
@@ -466,6 +467,24 @@ def test_deferred_x_update_bitwise(E, oracle, depth, monkeypatch):
         xi = s.download("X")
         xr, itr, _ = s.solve(b, x0, 0.0, 7)          # tol = 0: no exit, no restart either -- 8 iterations
         assert itr == 8 and np.array_equal(xi, xr)
+
+
+@pytest.mark.parametrize("name", CAPTURED)
+def test_deferred_x_update_on_the_captured_systems(E, oracle, name, plane_pitch, monkeypatch):
+    """The same on the reference's own systems [Ax | Ay | Az | U] (structured form, default and pitched; five launches):
+    every captured call with X applied every fourth iteration -- x, iter and the history are the twin's."""
+    monkeypatch.setenv("EC3D_XDEFER", "4")
+    g = load_golden(name)
+    tol, itmax = float(g["tol"]), int(g["itmax"])
+    with E.EC3DSolver() as s:
+        s.set_matrix_csr(g["valA"], g["irow"], g["jcol"])
+        assert s.x_interval() == 4
+        for k in range(len(g["iters"])):
+            x, it, hist = s.solve(g[f"b{k}"], g[f"xin{k}"], tol, itmax, hist_cap=400)
+            xo, ito, hs, hr = oracle.twin_solve(s, g["valA"], g["irow"], g["jcol"], g[f"b{k}"], g[f"xin{k}"], tol, itmax,
+                                                hist_cap=400)
+            assert it == ito and np.array_equal(x, xo)
+            assert np.array_equal(hist[:it, 0], hs[:it])
 
 
 def test_large_grid_768_formats_bitwise(E, monkeypatch):
