@@ -163,6 +163,22 @@ def stage_table(s, info, kernel_ms):
         fmt_bytes["k5"] += fmt_bytes.pop("k1") - 8
         survey_bytes["k5"] += survey_bytes.pop("k1") - 8
         names["k5"] = "k51_p_spmv_dot (P = R + beta*(P - omega*AP) inside the next AP = A*P; AP.R0)"
+    # What K4 moves when X is updated every D-th iteration (ec3d_get_x_interval) and when it runs as an SpMV kernel that
+    # computes A*S again (ec3d_get_k4_form): D - 1 launches without X and one that applies D updates, averaged.
+    # bytes_per_row is what the launches are built to move; survey_bytes_per_row stays SURVEY 8d's 56 B.
+    D = s.x_interval() if hasattr(s, "x_interval") else 1
+    k4s = bool(s.k4_as_spmv()) if hasattr(s, "k4_as_spmv") else False
+    if k4s:
+        fmt_bytes["k3"] -= 8                       # K2-in-K3 no longer writes AS
+        off, on = 25, 33 + 16 * D                  # S + class byte + R0 read, R written; + X, D P, D - 1 older S; X written
+        names["k4"] = (f"k4s_x_r_spmv (K4 as an SpMV kernel: AS = A*S computed again; X = X + alpha*P + omega*S applied "
+                       f"every {D} iterations, in order)")
+    else:
+        off, on = 32, 40 + 16 * D
+        if D > 1:
+            names["k4"] = f"k4d_x_r_update (K4 with X = X + alpha*P + omega*S applied every {D} iterations, in order)"
+    if k4s or D > 1:
+        fmt_bytes["k4"] = ((D - 1) * off + on) / D
     total = sum(kernel_ms.values())
     kernels = {}
     for k, ms in kernel_ms.items():
@@ -408,6 +424,7 @@ def main():
         info = s.info
         fusion_state = s.fusion()
         x_every = s.x_interval() if hasattr(s, "x_interval") else 1
+        k4_spmv = bool(s.k4_as_spmv()) if hasattr(s, "k4_as_spmv") else False
         parallelism = "single GPU"
     else:
         from eddy_currents_3d_amd.dist import SlabSolver
@@ -463,15 +480,22 @@ def main():
         info = s.local.info
         parallelism = f"z-slab x{world} (halo send/recv + all_gather of dot products, RCCL)"
 
+    if use_dist or in_library:
+        x_every, k4_spmv = 1, False
+
     class _Fusion:       # the headline handle's launches per iteration (multi-rank slabs always run five)
-        def __init__(self, st):
-            self.st = st
+        def __init__(self, st, d, k4s):
+            self.st, self.d, self.k4s = st, d, k4s
 
         def fusion(self):
             return self.st
-    fusion_of = _Fusion(fusion_state if (not use_dist and not in_library) else (0, 0))
-    if use_dist or in_library:
-        x_every = 1
+
+        def x_interval(self):
+            return self.d
+
+        def k4_as_spmv(self):
+            return self.k4s
+    fusion_of = _Fusion(fusion_state if (not use_dist and not in_library) else (0, 0), x_every, k4_spmv)
 
     # The north-star SpMV figure in the driver-run line: the plain 7-band DIA SpMV (56 B of coefficients + x + y =
     # 72 B/row) at the same grid, timed after the headline region on a handle of its own (the
@@ -544,21 +568,9 @@ def main():
                          "avg_launch_ms": kernel_ms[dom]},
         }
         if x_every > 1:
-            # K4 with the X update deferred (ec3d_get_x_interval): x_every - 1 of x_every launches leave X alone (24 B read,
-            # 8 written per row) and one applies the pending updates (24 + 16 D read, 16 written) -- the same X bit for bit;
-            # kernels.k4.ms is the average over both kinds.  roofline.achieved stays SURVEY 8d's 56 B per row over that
-            # average (the work of K4); what the launches MOVE is less, stated here
-            moved = ((x_every - 1) * 32 + (40 + 16 * x_every)) / x_every
             out["config"]["x_update_every"] = x_every
-            out["kernels"]["k4"]["name"] = ("k4d_x_r_update (K4 with X = X + alpha*P + omega*S applied every "
-                                            f"{x_every} iterations, in order)")
-            out["kernels"]["k4"]["moved_bytes_per_row"] = moved
-            out["kernels"]["k4"]["moved_GBps"] = moved * rows / kernel_ms["k4"] / 1e6
-            out["config"]["bytes_per_dof_iter"]["moved"] = sum(fmt_bytes[k] for k in kernel_ms) - 56 + moved
-            if dom == "k4":
-                out["roofline"]["kernel"] = out["kernels"]["k4"]["name"]
-                out["roofline"]["moved_bytes_per_launch"] = moved * rows
-                out["roofline"]["frac_of_moved_bytes"] = moved * rows / (kernel_ms["k4"] * 1e-3) / 1e9 / PEAK_HBM_GBS
+        if k4_spmv:
+            out["config"]["k4_as_spmv"] = True
         if (in_library or use_dist) and verified:
             out["verified"] = verified
         if spmv_ms is not None:

@@ -411,6 +411,7 @@ static int choose_sweep(ec3d_ctx *c)
     Sweep &ss = c->sweep_s;
     c->fuse23_ok = false;
     c->fuse51_ok = false;
+    c->k4s_ok = false;
     const DevMatrix &A = c->A;
     int zm = c->zm_request;
     if (const char *e = getenv("EC3D_ZMARCH")) zm = atoi(e);
@@ -533,7 +534,12 @@ static int choose_sweep(ec3d_ctx *c)
                 // Round 4 measured where the three-launch iteration starts to pay (same box, five against three launches,
                 // us per iteration): 512 x 512 x 128 (32 Mi rows) 841 / 848, 384^3 (54 Mi) 1484 / 1530, 512 x 512 x 256
                 // (64 Mi) 1704 / 1678, 512 x 512 x 384 (96 Mi) 2577 / 2472, 512^3 (128 Mi) -3 ... -4.5 %: from 64 Mi rows.
-                const bool fuse_big = c->A.n_pad >= ((int64_t)1 << 26);
+                // With K4 as an SpMV kernel (k4s_x_r_spmv, below) and X every fourth iteration the three launches move 117 B
+                // per row instead of 154 and pay from 32 Mi rows (profiles/r04_k4s_threshold.log, five launches / three):
+                // 256^3 400 / 448 us, 512 x 512 x 96 604 / 643, 512 x 512 x 128 813 / 745, 384^3 1433 / 1353-1390, 512^3 -7.7 %.
+                int k4s = 1;
+                if (const char *e = getenv("EC3D_K4S")) k4s = atoi(e);
+                const bool fuse_big = c->A.n_pad >= ((int64_t)1 << (k4s != 0 && A.ncls > 0 ? 25 : 26));
                 int fuse = 1;
                 if (const char *e = getenv("EC3D_FUSE23")) fuse = atoi(e);
                 c->fuse23_ok = fuse == 2 || (fuse == 1 && fuse_big);
@@ -541,6 +547,9 @@ static int choose_sweep(ec3d_ctx *c)
                 int fuse5 = 1;
                 if (const char *e = getenv("EC3D_FUSE51")) fuse5 = atoi(e);
                 c->fuse51_ok = fuse5 == 2 || (fuse5 == 1 && fuse_big);
+                // K4 as an SpMV kernel that computes A S again instead of reading the AS that K23 would have written
+                // (k4s_x_r_spmv): 16 B per row and iteration less.  EC3D_K4S=0 never, 2 whenever both fusions run
+                c->k4s_ok = A.ncls > 0 && !A.sav && c->fuse23_ok && c->fuse51_ok && (k4s == 2 || (k4s == 1 && fuse_big));
             }
         }
     }
@@ -1213,7 +1222,10 @@ extern "C" int ec3d_get_reduction_geometry(ec3d_handle c, int which, ec3d_geom *
 {
     int rc = ec3d_need_matrix(c, "ec3d_get_reduction_geometry");
     if (rc) return rc;
-    const Sweep &sw = which == 1 ? c->sweep_s : which == 2 ? (ec3d_fused23(c) ? c->sweep_s : c->sweep_k2) : c->sweep;
+    // 0: who sums R.R and R.R0 (K4 -- a vector kernel, or the SpMV-form K4 on the SpMV kernels' grid), 1: the SpMV kernels,
+    // 2: who sums S.S (K2, or the SpMV kernel it runs inside of)
+    const Sweep &sw = which == 1 ? c->sweep_s : which == 2 ? (ec3d_fused23(c) ? c->sweep_s : c->sweep_k2)
+                                                            : (ec3d_k4s(c) ? c->sweep_s : c->sweep);
     g->n_pad = (int32_t)c->A.n_pad;
     g->tile = EC3D_TILE;
     g->nblk = sw.nblk;
@@ -1277,7 +1289,7 @@ extern "C" int ec3d_get_visit_order(ec3d_handle c, int which, int32_t *nwg, int6
     } else if (which == 2) { // who sums S.S: K2, or the SpMV kernel it runs inside of
         visit_of(c, ec3d_fused23(c) ? c->sweep_s : c->sweep_k2, v);
     } else {
-        visit_of(c, c->sweep, v);
+        visit_of(c, ec3d_k4s(c) ? c->sweep_s : c->sweep, v);
     }
     int64_t tot = 0;
     for (auto &w : v) tot += (int64_t)w.size();

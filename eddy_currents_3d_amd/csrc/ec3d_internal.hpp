@@ -266,6 +266,7 @@ struct ec3d_ctx {
     bool can_overlap = false;
     bool fuse23_ok = false; // 2-D tiles: K2 may run inside K3 (single rank only, see ec3d_fused23)
     bool fuse51_ok = false; // 2-D tiles: K5 may run inside the next iteration's K1 (ec3d_fused51)
+    bool k4s_ok = false;    // dictionary cube on 2-D tiles: K4 may run as an SpMV kernel that computes A S again (ec3d_k4s)
     // K5-in-K1 reads the previous iteration's P and AP while it writes the new ones (neighbouring workgroups read the
     // old values of cells this one owns), so both vectors alternate between two buffers: P(it) lives in
     // pbuf[it & 1], AP(it) in apbuf[it & 1]; index 1 is vec[EC3D_VEC_P] / vec[EC3D_VEC_AP], index 0 the spare pair
@@ -436,6 +437,8 @@ RedSrc ec3d_part_of(const ec3d_ctx *c, int producer, bool split = false);
 void ec3d_launch_stage(ec3d_ctx *c, const MatView &A, int it, int k); // k = 1..5, 0 = all five
 inline bool ec3d_fused23(const ec3d_ctx *c) { return c->fuse23_ok && !c->dist && c->halo == 0; }
 inline bool ec3d_fused51(const ec3d_ctx *c) { return c->fuse51_ok && !c->dist && c->halo == 0 && c->pp_base != nullptr; }
+// K4 in SpMV form (k4s_x_r_spmv): only inside the three-launch iteration
+inline bool ec3d_k4s(const ec3d_ctx *c) { return c->k4s_ok && ec3d_fused23(c) && ec3d_fused51(c); }
 // deferred X update: single rank, own vectors (the rings exist), and the iteration either fully fused or not at all
 inline int ec3d_xdefer(const ec3d_ctx *c)
 {
@@ -468,6 +471,9 @@ void ec3d_launch_k51(const MatView &A, const Sweep &sw, const RedSrc &src, Solve
 void ec3d_launch_k4d(const Sweep &sw, const RedSrc &src_ss, const RedSrc &src, SolverState *st, int it, int ne, int xm,
                      const double *const *p, const double *const *sv, const double *as, const double *r0, double *x,
                      double *r, double *part, double *hist, int64_t hist_cap, hipStream_t s);
+void ec3d_launch_k4s(const MatView &A, const Sweep &sw, const RedSrc &src_ss, const RedSrc &src, SolverState *st, int it,
+                     int ne, int xm, const double *const *p, const double *const *sv, const double *r0, double *x, double *r,
+                     double *part, double *hist, int64_t hist_cap, hipStream_t s);
 void ec3d_launch_x_flush(const Sweep &sw, const SolverState *st, const double *const *p, const double *const *sv,
                          double *x, hipStream_t s);
 void ec3d_launch_k4(const Sweep &sw, const RedSrc &src_ss, const RedSrc &src, SolverState *st, int it,

@@ -1656,7 +1656,7 @@ EC3D_SPMV_T __global__ __launch_bounds__(EC3D_THREADS) __attribute__((amdgpu_wav
         d2 q; // S[r], S[r+1]
         spmv_pair<FMT, ZM, TAIL, NT, PATCH>(A, sw, pp, tbl, stg, pstep, VecFused{rv, ap, alpha}, r, tile, (bool)fc, zr, s0, s1, q);
         store2<NT>(sv, r, nst, q.x, q.y);
-        store2<NT>(as, r, nst, s0, s1);
+        if (as) store2<NT>(as, r, nst, s0, s1); // (nullptr: K4 runs in SpMV form and computes A S again, k4s_x_r_spmv)
         double q0 = q.x, q1 = q.y;
         EC3D_MASK2(r, sw, q0, q1);
         EC3D_IDLE2(q0, q1);
@@ -1909,6 +1909,124 @@ __global__ __launch_bounds__(EC3D_THREADS) void k4d_x_r_update(SweepV sw, RedSrc
         double e0 = s.x - omega * a.x, e1 = s.y - omega * a.y;
         store2k<NT>(rv, r, sw.n, e0, e1, keep_of(sw) & EC3D_KEEP_R);
         EC3D_MASK2(r, sw, e0, e1);
+        acc[0] = acc[0] + e0 * e0;
+        acc[0] = acc[0] + e1 * e1;
+        acc[1] = acc[1] + e0 * q.x;
+        acc[1] = acc[1] + e1 * q.y;
+    });
+    block_sum<2>(acc, lds);
+    if (threadIdx.x == 0) {
+        part[P_RR * sw.pstride + sw.part_off + blockIdx.x] = acc[0];
+        part[P_RR0N * sw.pstride + sw.part_off + blockIdx.x] = acc[1];
+    }
+}
+
+// K4 as an SpMV kernel (2-D tiles, single rank, vectors far beyond the caches): AS = A S is COMPUTED AGAIN here, from the
+// S that K4 reads anyway, instead of being written by K23 and read back -- 8 B written and 8 B read per row less, for 13
+// flops per row on a memory-bound machine.  The same spmv_pair on the same tiles gives the same AS bit for bit, so omega
+// (from K23's AS.S and AS.AS), R = S - omega*AS and everything after it are unchanged; R.R and R.R0 are summed in the SpMV
+// kernels' thread -> cell assignment (the library reports it as geometry 0, the twin follows).  The X update is the
+// deferred one of k4d_x_r_update: NEMAX = 0 leaves X alone, NEMAX = 4 applies ne (1 .. 4) pending updates, oldest first.
+// Both exits leave pending updates to k_x_flush (the ||S|| exit's X = X + alpha*P as a half update).
+template <int FMT, bool NT, int NEMAX>
+__global__ __launch_bounds__(EC3D_THREADS) __attribute__((amdgpu_waves_per_eu(NEMAX > 0 ? 2 : 4))) void k4s_x_r_spmv(
+    MatDev<FMT> A, SweepZ sw, RedSrc src_ss, RedSrc src, SolverState *st, int it, int ne, int xm, XRing ring,
+    const double *__restrict__ r0, double *__restrict__ x, double *__restrict__ rv, double *__restrict__ part, double *hist,
+    int64_t hist_cap)
+{
+    constexpr bool ZM = true, TAIL = false, PATCH = true;
+    __shared__ double lds[8];
+    EC3D_TBL_DECL;
+    const int slot_ss[1] = {P_SS};
+    const int slot[2] = {P_D2, P_D3};
+    PartialsEarly<1> pss;
+    PartialsEarly<2> pd;
+    partials_request<1>(src_ss, slot_ss, pss);
+    partials_request<2>(src, slot, pd);
+    const double alpha = st->alpha, bnorm = st->bnorm, tol = st->tol;
+    double pa[EC3D_XD_MAX], po[EC3D_XD_MAX];
+#pragma unroll
+    for (int j = 0; j < EC3D_XD_MAX - 1; ++j) {
+        pa[j] = NEMAX > 0 ? st->pend_alpha[j] : 0.0;
+        po[j] = NEMAX > 0 ? st->pend_omega[j] : 0.0;
+    }
+    TableEarly te;
+    table_request<FMT>(A, te);
+    const int stop_it = stop_iter_of(st);
+    EC3D_REQUESTS_OUT;
+    if (stop_it < it) return;
+    double ss[1];
+    partials_finish<1>(src_ss, slot_ss, pss, ss, lds);
+    const double snorm = sqrt(ss[0]);
+    const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+    if (lead && hist && it <= hist_cap) hist[2 * (int64_t)(it - 1)] = snorm;
+    if (snorm / bnorm < tol) {
+        if (lead) {
+            st->pend_alpha[xm] = alpha;
+            st->pend_omega[xm] = 0.0;
+            st->npend = xm + 1;
+            st->pend_half = 1;
+            stop_publish(st, it, 1);
+        }
+        return;
+    }
+    double d[2];
+    partials_finish<2>(src, slot, pd, d, lds);
+    const double omega = d[0] / d[1];
+    if (lead) {
+        st->omega = omega;
+        if (NEMAX == 0) {
+            st->pend_alpha[xm] = alpha;
+            st->pend_omega[xm] = omega;
+            st->npend = xm + 1;
+        } else {
+            st->npend = 0;
+        }
+    }
+    // entry ne - 1 is this iteration's: its alpha and omega are known only now
+#pragma unroll
+    for (int j = 0; j < EC3D_XD_MAX; ++j)
+        if (NEMAX > 0 && j == ne - 1) {
+            pa[j] = alpha;
+            po[j] = omega;
+        }
+    table_store<FMT>(A, te, tbl);
+    ZRegs zr;
+    PatchPos pp{};
+    int pstep = 0;
+    double acc[2] = {0.0, 0.0};
+    const double *scur = ring.s[NEMAX > 0 ? ne - 1 : 0];
+    walk_spmv<FMT, ZM, FMT != FMT_SAV, PATCH>(A, sw, pp, [&](int64_t tile, auto fc) {
+        EC3D_ROW_S;
+        // the operands that do not go through the stencil first: they are in flight while it runs
+        const d2 q = load2<NT>(r0 + r);
+        d2 xv{0.0, 0.0}, pv[NEMAX > 0 ? NEMAX : 1], so[NEMAX > 0 ? NEMAX : 1];
+        if (NEMAX > 0) {
+            xv = load2<NT>(x + r);
+#pragma unroll
+            for (int j = 0; j < NEMAX; ++j)
+                if (j < ne) pv[j] = load2<NT>(ring.p[j] + r);
+#pragma unroll
+            for (int j = 0; j < NEMAX - 1; ++j)
+                if (j < ne - 1) so[j] = load2<NT>(ring.s[j] + r);
+        }
+        double a0, a1;
+        d2 sc; // S[r], S[r+1]
+        spmv_pair<FMT, ZM, TAIL, NT, PATCH>(A, sw, pp, tbl, stg, pstep, VecPlain{scur}, r, tile, (bool)fc, zr, a0, a1, sc);
+        if (NEMAX > 0) {
+#pragma unroll
+            for (int j = 0; j < NEMAX; ++j)
+                if (j < ne) { // one (X + alpha*P) + omega*S per pending iteration, oldest first
+                    const d2 sj = (j == ne - 1) ? sc : so[j < NEMAX - 1 ? j : 0];
+                    xv.x = (xv.x + pa[j] * pv[j].x) + po[j] * sj.x;
+                    xv.y = (xv.y + pa[j] * pv[j].y) + po[j] * sj.y;
+                }
+            store2<NT>(x, r, nst, xv.x, xv.y);
+        }
+        double e0 = sc.x - omega * a0, e1 = sc.y - omega * a1;
+        store2k<NT>(rv, r, nst, e0, e1, 0);
+        EC3D_MASK2(r, sw, e0, e1);
+        EC3D_IDLE2(e0, e1);
         acc[0] = acc[0] + e0 * e0;
         acc[0] = acc[0] + e1 * e1;
         acc[1] = acc[1] + e0 * q.x;
@@ -2321,6 +2439,31 @@ void ec3d_launch_k4d(const Sweep &sw, const RedSrc &src_ss, const RedSrc &src, S
     default: EC3D_K4D(4); break;
     }
 #undef EC3D_K4D
+}
+
+// K4 in SpMV form (k4s_x_r_spmv): dictionary cube on 2-D tiles.  ne = 0: X left alone; 1 .. 4: that many updates applied
+void ec3d_launch_k4s(const MatView &A, const Sweep &sw, const RedSrc &src_ss, const RedSrc &src, SolverState *st, int it,
+                     int ne, int xm, const double *const *p, const double *const *sv, const double *r0, double *x, double *r,
+                     double *part, double *hist, int64_t hist_cap, hipStream_t s)
+{
+    XRing ring{};
+    for (int j = 0; j < (ne > 0 ? ne : 1); ++j) {
+        ring.p[j] = p[j];
+        ring.s[j] = sv[j];
+    }
+    const SweepZ swz = sweep_z(sw);
+    const MatDev<FMT_DICT7> Ad = mat_dev<FMT_DICT7>(A);
+    const size_t lds = tbl_bytes(A, FMT_DICT7, true, true);
+#define EC3D_K4S(NT_, NE_) \
+    k4s_x_r_spmv<FMT_DICT7, NT_, NE_><<<sw.nblk, EC3D_THREADS, lds, s>>>(Ad, swz, src_ss, src, st, it, ne, xm, ring, r0, x, r, part, hist, hist_cap)
+    if (nt_of(sw)) {
+        if (ne == 0) EC3D_K4S(true, 0);
+        else EC3D_K4S(true, 4);
+    } else {
+        if (ne == 0) EC3D_K4S(false, 0);
+        else EC3D_K4S(false, 4);
+    }
+#undef EC3D_K4S
 }
 
 void ec3d_launch_x_flush(const Sweep &sw, const SolverState *st, const double *const *p, const double *const *sv,

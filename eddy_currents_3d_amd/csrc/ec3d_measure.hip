@@ -60,6 +60,14 @@ extern "C" int ec3d_get_x_interval(ec3d_handle c, int32_t *iterations)
     return 0;
 }
 
+extern "C" int ec3d_get_k4_form(ec3d_handle c, int32_t *spmv_form)
+{
+    int rc = ec3d_need_matrix(c, "ec3d_get_k4_form");
+    if (rc) return rc;
+    if (spmv_form) *spmv_form = ec3d_k4s(c) ? 1 : 0;
+    return 0;
+}
+
 extern "C" int ec3d_iterate(ec3d_handle c, int32_t first_iter, int32_t count, double *kernel_ms)
 {
     int rc = ec3d_need_matrix(c, "ec3d_iterate");

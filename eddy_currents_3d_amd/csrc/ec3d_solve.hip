@@ -22,7 +22,7 @@
 static int parts_of(const ec3d_ctx *c, int producer, bool split)
 {
     if (producer == EC3D_BY_K2) return ec3d_fused23(c) ? c->sweep_s.nblk : c->sweep_k2.nblk; // fused: S.S comes from K23
-    if (producer == EC3D_BY_K4) return c->sweep.nblk;
+    if (producer == EC3D_BY_K4) return ec3d_k4s(c) ? c->sweep_s.nblk : c->sweep.nblk; // K4 in SpMV form sums on that grid
     return split ? c->sweep_int.nblk + c->sweep_bnd.nblk : c->sweep_s.nblk;
 }
 RedSrc ec3d_src_of(const ec3d_ctx *c, int producer)
@@ -63,7 +63,8 @@ void ec3d_launch_stage(ec3d_ctx *c, const MatView &A, int it, int k)
         c->scur = D > 1 ? it % D : 1;
     }
     if ((k == 0 || k == 3) && fused) {
-        ec3d_launch_k23(A, ss, ec3d_src_of(c, EC3D_BY_SPMV), c->state, it, v[EC3D_VEC_R], AP, S, v[EC3D_VEC_AS], c->partials, s);
+        ec3d_launch_k23(A, ss, ec3d_src_of(c, EC3D_BY_SPMV), c->state, it, v[EC3D_VEC_R], AP, S,
+                        ec3d_k4s(c) ? nullptr : v[EC3D_VEC_AS], c->partials, s); // (K4 in SpMV form computes A S again)
         c->scur = D > 1 ? it % D : 1;
     }
     if ((k == 0 || k == 3) && !fused)
@@ -72,7 +73,17 @@ void ec3d_launch_stage(ec3d_ctx *c, const MatView &A, int it, int k)
         // position of this iteration in its group of D, and how many updates an applying launch finds pending
         const int xm = D > 1 ? (it - c->xd_base) % D : 0;
         const bool apply = D <= 1 || xm == D - 1 || it >= c->xd_last;
-        if (D <= 1 || (apply && xm == 0)) {
+        if (ec3d_k4s(c)) {
+            const double *pp[EC3D_XD_MAX] = {nullptr}, *sp[EC3D_XD_MAX] = {nullptr};
+            const int ne = apply ? xm + 1 : 0;
+            for (int j = 0; j < ne; ++j) { // iterations it - xm .. it, oldest first
+                pp[j] = c->pbuf[(it - xm + j) % pd];
+                sp[j] = D > 1 ? c->sbuf[(it - xm + j) % D] : S;
+            }
+            if (ne == 0) sp[0] = S;
+            ec3d_launch_k4s(A, ss, ec3d_src_of(c, EC3D_BY_K2), ec3d_src_of(c, EC3D_BY_SPMV), c->state, it, ne, xm, pp, sp,
+                            v[EC3D_VEC_R0], v[EC3D_VEC_X], v[EC3D_VEC_R], c->partials, c->hist, c->hist_cap, s);
+        } else if (D <= 1 || (apply && xm == 0)) {
             ec3d_launch_k4(sw, ec3d_src_of(c, EC3D_BY_K2), ec3d_src_of(c, EC3D_BY_SPMV), c->state, it, P, S, v[EC3D_VEC_AS],
                            v[EC3D_VEC_R0], v[EC3D_VEC_X], v[EC3D_VEC_R], c->partials, c->hist, c->hist_cap, s);
         } else {
@@ -106,13 +117,13 @@ void ec3d_launch_stage(ec3d_ctx *c, const MatView &A, int it, int k)
 int ec3d_flush_x(ec3d_ctx *c, int stop_iter)
 {
     const int D = ec3d_xdefer(c);
-    if (D <= 1 || stop_iter < c->xd_base) return 0;
+    if ((D <= 1 && !ec3d_k4s(c)) || stop_iter < c->xd_base) return 0;
     const int xm = (stop_iter - c->xd_base) % D;
     const double *pp[EC3D_XD_MAX], *sp[EC3D_XD_MAX];
     for (int j = 0; j < EC3D_XD_MAX; ++j) { // entries past the pending count are never dereferenced: any valid pointer
         const int itj = stop_iter - xm + std::min(j, xm);
         pp[j] = c->pbuf[itj % c->pdepth];
-        sp[j] = c->sbuf[itj % D];
+        sp[j] = D > 1 ? c->sbuf[itj % D] : c->vec[EC3D_VEC_S];
     }
     ec3d_launch_x_flush(c->sweep, c->state, pp, sp, c->vec[EC3D_VEC_X], c->stream);
     EC3D_HIP(hipGetLastError());

@@ -400,6 +400,11 @@ int ec3d_get_fusion(ec3d_handle h, int32_t *k2_in_k3, int32_t *k5_in_k1);
  * alone in D - 1 of D iterations and applies the D updates, in order and each as its own two rounded additions, in the
  * D-th -- nothing in the loop reads X, so X is the same bits; an exit applies what is pending before the solve returns */
 int ec3d_get_x_interval(ec3d_handle h, int32_t *iterations);
+/* 1: K4 runs as an SpMV kernel that computes AS = A*S again from the S it reads anyway (k4s_x_r_spmv) and K2-in-K3 no
+ * longer writes AS -- 16 B per row and iteration less for 13 flops per row; the same spmv code on the same tiles gives the
+ * same AS bit for bit.  R.R and R.R0 are then summed in the SpMV kernels' order (ec3d_get_reduction_geometry(h, 0, ...)
+ * reports the grid that sums them).  0: the vector-kernel K4 reading the stored AS */
+int ec3d_get_k4_form(ec3d_handle h, int32_t *spmv_form);
 
 int ec3d_device_synchronize(ec3d_handle h);
 

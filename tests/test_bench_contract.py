@@ -68,10 +68,11 @@ def test_headline_line_carries_the_av_and_256_sub_records():
     d = json.loads(lines[0])
     assert d["config"]["grid"] == [512, 512, 512] and "512^3" in d["config"]["workload"]
     assert set(d["kernels"]) == {"k3", "k4", "k5"}                      # three launches, asked of the library
-    # K4 applies the X updates every 4th iteration at this size (ec3d_get_x_interval): the line says so and states what
-    # the launches move next to SURVEY 8d's 56 B per row
-    assert d["config"]["x_update_every"] == 4 and d["kernels"]["k4"]["moved_bytes_per_row"] == 50.0
-    assert d["kernels"]["k4"]["bytes_per_row"] == 56
+    # K4 runs as an SpMV kernel that computes A*S again and applies the X updates every 4th iteration at this size
+    # (ec3d_get_k4_form, ec3d_get_x_interval): the line says so and states what the launches move next to SURVEY 8d's 56 B
+    assert d["config"]["x_update_every"] == 4 and d["config"]["k4_as_spmv"] is True
+    assert d["kernels"]["k4"]["bytes_per_row"] == 43.0 and d["kernels"]["k4"]["survey_bytes_per_row"] == 56
+    assert d["kernels"]["k3"]["bytes_per_row"] == 25 and d["config"]["bytes_per_dof_iter"]["this_format"] == 117.0
     pl = d["spmv_dia"]["placement"]
     assert 1 <= len(pl["candidate_us"]) <= 8 and 0 <= pl["kept"] < len(pl["candidate_us"])
     for name, n, lo in (("av", 21391776, 2.0e10), ("cube256", 256 ** 3, 2.5e10)):

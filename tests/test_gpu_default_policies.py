@@ -2,10 +2,9 @@
 GPU-order twin, bit for bit.
 
 choose_sweep (csrc/ec3d_context.hip) switches by size: nontemporal streams from 4.5 Mi rows, the next kernel's operand
-kept cacheable up to 32 Mi rows, from 32 Mi rows the vector kernels on 256 workgroups with two tiles in flight, and from
-64 Mi rows on 2-D tiles the three-launch iteration (K2 inside K3, K5 inside the next K1, P / AP in alternating
-buffers); from 32 Mi rows -- five launches or three -- the X update is applied every fourth iteration
-(k4d_x_r_update: six iterations = one whole group and the itmax exit's partial one).  The small
+kept cacheable up to 32 Mi rows, and from 32 Mi rows on 2-D tiles the three-launch iteration (K2 inside K3, K5 inside
+the next K1, P / AP in alternating buffers, K4 as an SpMV kernel that computes A S again) with the X update applied
+every fourth iteration (six iterations = one whole group and the itmax exit's partial one).  The small
 parity cases force those instances through EC3D_NT / EC3D_KEEP / EC3D_FUSE* (tests/test_gpu_parity.py); here NOTHING is
 forced -- the handle is built the way bench.py builds it and the twin follows the launch geometry the library reports
 (ec3d_get_visit_order), for the first iterations of src/solvers.f90:24-50 (the itmax exit of :25-29 ends the run; the
@@ -27,18 +26,20 @@ def E():
 def no_knobs(monkeypatch):
     for k in ("EC3D_NT", "EC3D_KEEP", "EC3D_FUSE23", "EC3D_FUSE51", "EC3D_PATCH", "EC3D_NBLK", "EC3D_NBLK_SPMV",
               "EC3D_VEC_DEPTH", "EC3D_XCD_MAP", "EC3D_PITCH", "EC3D_ZMARCH", "EC3D_SAV_PATCH", "EC3D_XDEFER",
-              "EC3D_XD_OFF_DEPTH", "EC3D_XD_ON_DEPTH"):
+              "EC3D_XD_OFF_DEPTH", "EC3D_XD_ON_DEPTH", "EC3D_K4S"):
         monkeypatch.delenv(k, raising=False)
 
 
-@pytest.mark.parametrize("dims, fused, iters", [((256, 256, 80), False, 8), ((512, 512, 128), False, 6),
-                                                ((512, 512, 256), True, 6)],
-                         ids=["5Mi-rows-nt-keep", "32Mi-rows-all-nontemporal", "64Mi-rows-three-launches"])
+@pytest.mark.parametrize("dims, fused, iters", [((256, 256, 80), False, 8), ((512, 512, 96), False, 6),
+                                                ((512, 512, 128), True, 6), ((512, 512, 256), True, 6)],
+                         ids=["5Mi-rows-nt-keep", "24Mi-rows-five-launches", "32Mi-rows-three-launches",
+                              "64Mi-rows-three-launches"])
 def test_cube_at_the_default_policy_bitwise(E, oracle, dims, fused, iters, monkeypatch):
     """Single-component operator (BASELINE configs 2 / 4 family).  256 x 256 x 80 = 5.2 M rows: nontemporal streams,
-    AP / S / R kept cacheable, 2-D tiles, five launches.  512 x 512 x 128 = 2^25 rows: everything nontemporal, the
-    vector kernels on 256 workgroups with two tiles in flight.  512 x 512 x 256 = 2^26 rows: the size from which K2 runs
-    inside K3 and K5 inside the next K1 by themselves -- the configuration of the headline 512^3 run."""
+    AP / S / R kept cacheable, 2-D tiles, five launches.  512 x 512 x 96 = 24 Mi rows: the largest five-launch size
+    class.  512 x 512 x 128 = 2^25 rows: the size from which K2 runs inside K3, K5 inside the next K1, K4 as an SpMV
+    kernel that computes A S again (k4s_x_r_spmv) and X is updated every fourth iteration, all by themselves -- the
+    configuration of the headline 512^3 run; 512 x 512 x 256 the same on twice the planes."""
     no_knobs(monkeypatch)
     sdx, sdy, sdz = dims
     n = sdx * sdy * sdz
@@ -53,6 +54,8 @@ def test_cube_at_the_default_policy_bitwise(E, oracle, dims, fused, iters, monke
         assert (g2.patch_x == 128 and g2.nblk == g1.nblk) == fused      # S.S summed inside the SpMV kernel when fused
         assert s.fusion() == ((1, 1) if fused else (0, 0))
         assert s.x_interval() == (4 if n >= 2 ** 25 else 1)      # X updated every 4th iteration (k4d_x_r_update)
+        g0 = s.geometry(0)                                        # fused: K4 runs as an SpMV kernel (k4s_x_r_spmv)
+        assert (g0.patch_x == 128 and g0.nblk == g1.nblk) == fused
         x, it, hist = s.solve(b, x0, 1e-30, iters - 1, hist_cap=iters)
         xo, ito, hs, hr = oracle.twin_solve(s, valA, irow, jcol, b, x0, 1e-30, iters - 1, hist_cap=iters)
     assert it == ito == iters

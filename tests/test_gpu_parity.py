@@ -413,8 +413,8 @@ def test_two_dimensional_tiles_bitwise(E, oracle, grid, fuse, policy, monkeypatc
     assert np.linalg.norm(res["1"][0] - res["0"][0]) <= 1e-6 * np.linalg.norm(res["0"][0])
 
 
-@pytest.mark.parametrize("fuse", ["2", "0"], ids=["three-launches", "five-launches"])
-@pytest.mark.parametrize("depth", [2, 3, 4])
+@pytest.mark.parametrize("fuse", ["2", "2s", "0"], ids=["three-launches", "three-launches-K4-as-SpMV", "five-launches"])
+@pytest.mark.parametrize("depth", [1, 2, 3, 4])
 def test_deferred_x_update_bitwise(E, oracle, depth, fuse, monkeypatch):
     """X = X + alpha*P + omega*S (src/solvers.f90:41) applied every `depth`-th iteration (k4d_x_r_update: P and S of the
     pending iterations wait in rings, alpha and omega in the solver state; the default from 64 Mi rows with depth 2,
@@ -423,6 +423,13 @@ def test_deferred_x_update_bitwise(E, oracle, depth, fuse, monkeypatch):
     ||S|| exit at every position in a group (the pending updates are then applied by k_x_flush before the solve
     returns, the ||S|| exit's X = X + alpha*P as a half update), after the itmax exit at every position (the last
     iteration applies what is pending), and after bench-style ec3d_iterate calls of any length."""
+    # "2s": K4 as an SpMV kernel (k4s_x_r_spmv) that computes AS = A S again instead of reading what K23 no longer writes
+    # -- the default from 64 Mi rows; R.R and R.R0 are then summed in the SpMV kernels' order (geometry 0 says so)
+    k4s = fuse == "2s"
+    fuse = fuse[0]
+    if depth == 1 and not k4s:
+        pytest.skip("the classic K4: every other parity test")
+    monkeypatch.setenv("EC3D_K4S", "2" if k4s else "0")
     monkeypatch.setenv("EC3D_FUSE23", fuse)     # five launches: K2 writes S, K5 the new P into the next buffer of the rings
     monkeypatch.setenv("EC3D_FUSE51", fuse)
     monkeypatch.setenv("EC3D_PATCH", "1")
@@ -436,6 +443,7 @@ def test_deferred_x_update_bitwise(E, oracle, depth, fuse, monkeypatch):
     with E.EC3DSolver() as s:
         s.assemble_poisson(sdx, sdy, sdz)
         assert s.fusion() == ((1, 1) if fuse == "2" else (0, 0)) and s.x_interval() == depth
+        assert (s.geometry(0).nblk == s.geometry(1).nblk and s.geometry(0).patch_x == 128) == k4s
         # to convergence, with the history: the norms below give tolerances that end the solve at chosen iterations
         x, it, hist = s.solve(b, x0, 1e-10, 5000, hist_cap=64)
         xo, ito, hs, hr = oracle.twin_solve(s, valA, irow, jcol, b, x0, 1e-10, 5000, hist_cap=64)

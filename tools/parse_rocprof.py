@@ -67,7 +67,7 @@ def stage_of(k, have_k4d):
         return "k3"
     if k.startswith("k51_"):   # K5 inside the next K1: booked under k5
         return "k5"
-    if k.startswith("k4d_"):   # K4 with the X update deferred: launches without X and applying launches, pooled --
+    if k.startswith("k4d_") or k.startswith("k4s_"):   # K4 with the X update deferred (vector or SpMV form): launches without X and applying launches, pooled --
         return "k4"            # the mean over the launches of the run is the mean bench.py's kernels.k4.ms is
     if k.startswith("k4_") and have_k4d:
         return "k4_classic"    # (the lone launches of iteration 1 of a set-up pass)
@@ -76,7 +76,7 @@ def stage_of(k, have_k4d):
 
 
 names = sorted(set(fetch) | set(write))
-have_k4d = any(k.startswith("k4d_") for k in names)
+have_k4d = any(k.startswith("k4d_") or k.startswith("k4s_") for k in names)
 pool_f, pool_w, pool_n = defaultdict(list), defaultdict(list), defaultdict(list)
 for k in names:
     kk = stage_of(k, have_k4d)
