@@ -80,6 +80,6 @@ def test_headline_line_carries_the_av_and_256_sub_records():
         assert "error" not in s, s
         assert s["n"] == n and s["unit"] == "DOF*iters/s" and s["value"] > lo
         assert s["value"] == pytest.approx(n * s["steps"] / (s["ms_per_step"] * s["steps"] * 1e-3), rel=1e-6)
-        assert set(s["kernels"]) == {"k1", "k2", "k3", "k4", "k5"}        # below 64 Mi rows: five launches
+        assert set(s["kernels"]) == {"k1", "k2", "k3", "k4", "k5"}        # below 32 Mi rows: five launches
         dom = s["dominant"]
         assert dom["frac"] == pytest.approx(dom["achieved"] / 8000.0) and 0.3 < dom["frac"] < 1.2

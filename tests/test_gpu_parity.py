@@ -417,14 +417,14 @@ def test_two_dimensional_tiles_bitwise(E, oracle, grid, fuse, policy, monkeypatc
 @pytest.mark.parametrize("depth", [1, 2, 3, 4])
 def test_deferred_x_update_bitwise(E, oracle, depth, fuse, monkeypatch):
     """X = X + alpha*P + omega*S (src/solvers.f90:41) applied every `depth`-th iteration (k4d_x_r_update: P and S of the
-    pending iterations wait in rings, alpha and omega in the solver state; the default from 64 Mi rows with depth 2,
+    pending iterations wait in rings, alpha and omega in the solver state; the default from 32 Mi rows with depth 4,
     forced here on the three-launch iteration of a small grid).  Nothing in the loop reads X, the updates are applied in
     order and each as its own two rounded additions: x must be the twin's bit for bit -- after the ||R|| exit and the
     ||S|| exit at every position in a group (the pending updates are then applied by k_x_flush before the solve
     returns, the ||S|| exit's X = X + alpha*P as a half update), after the itmax exit at every position (the last
     iteration applies what is pending), and after bench-style ec3d_iterate calls of any length."""
     # "2s": K4 as an SpMV kernel (k4s_x_r_spmv) that computes AS = A S again instead of reading what K23 no longer writes
-    # -- the default from 64 Mi rows; R.R and R.R0 are then summed in the SpMV kernels' order (geometry 0 says so)
+    # -- the default from 32 Mi rows; R.R and R.R0 are then summed in the SpMV kernels' order (geometry 0 says so)
     k4s = fuse == "2s"
     fuse = fuse[0]
     if depth == 1 and not k4s:
