@@ -791,19 +791,35 @@ int ec3d_spare_pair(ec3d_ctx *c)
         c->pp_len = 0;
         return 0;
     }
-    c->xdefer = D;
-    c->pdepth = std::max(2, D);
     const int64_t len = c->ghost + c->A.n_pad + c->ghost;
-    const int64_t want = len * ((c->pdepth - 1) + 1 + (D - 1));
-    if (c->pp_base && c->pp_len != want) {
-        (void)hipFree(c->pp_base);
+    int64_t want = 0;
+    for (;;) {
+        c->xdefer = D;
+        c->pdepth = std::max(2, D);
+        want = len * ((c->pdepth - 1) + 1 + (D - 1));
+        if (c->pp_base && c->pp_len != want) {
+            (void)hipFree(c->pp_base);
+            c->pp_base = nullptr;
+        }
+        if (c->pp_base) break;
+        if (hipMalloc(&c->pp_base, (size_t)want * sizeof(double)) == hipSuccess) {
+            EC3D_HIP(hipMemsetAsync(c->pp_base, 0, (size_t)want * sizeof(double), c->stream));
+            EC3D_HIP(hipStreamSynchronize(c->stream));
+            c->pp_len = want;
+            break;
+        }
+        // no room for the rings (2 (D - 1) vectors more): the classic K4 with the spare pair alone, or -- when even that
+        // does not fit -- no spare pair: five launches (ec3d_fused51 asks for pp_base)
+        (void)hipGetLastError();
         c->pp_base = nullptr;
-    }
-    if (!c->pp_base) {
-        EC3D_HIP(hipMalloc(&c->pp_base, (size_t)want * sizeof(double)));
-        EC3D_HIP(hipMemsetAsync(c->pp_base, 0, (size_t)want * sizeof(double), c->stream));
-        EC3D_HIP(hipStreamSynchronize(c->stream));
-        c->pp_len = want;
+        c->pp_len = 0;
+        if (D > 1) {
+            D = 1;
+            if (c->fuse51_ok) continue;
+        }
+        c->xdefer = 1;
+        c->pdepth = 2;
+        return 0;
     }
     double *at = c->pp_base + c->ghost;
     c->apbuf[0] = at;
