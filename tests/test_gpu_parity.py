@@ -413,9 +413,10 @@ def test_two_dimensional_tiles_bitwise(E, oracle, grid, fuse, policy, monkeypatc
     assert np.linalg.norm(res["1"][0] - res["0"][0]) <= 1e-6 * np.linalg.norm(res["0"][0])
 
 
+@pytest.mark.parametrize("grid", [(256, 8, 9), (128, 16, 12), (128, 12, 10)], ids=lambda g: "x".join(map(str, g)))
 @pytest.mark.parametrize("fuse", ["2", "2s", "0"], ids=["three-launches", "three-launches-K4-as-SpMV", "five-launches"])
 @pytest.mark.parametrize("depth", [1, 2, 3, 4])
-def test_deferred_x_update_bitwise(E, oracle, depth, fuse, monkeypatch):
+def test_deferred_x_update_bitwise(E, oracle, depth, fuse, grid, monkeypatch):
     """X = X + alpha*P + omega*S (src/solvers.f90:41) applied every `depth`-th iteration (k4d_x_r_update: P and S of the
     pending iterations wait in rings, alpha and omega in the solver state; the default from 32 Mi rows with depth 4,
     forced here on the three-launch iteration of a small grid).  Nothing in the loop reads X, the updates are applied in
@@ -434,10 +435,10 @@ def test_deferred_x_update_bitwise(E, oracle, depth, fuse, monkeypatch):
     monkeypatch.setenv("EC3D_FUSE51", fuse)
     monkeypatch.setenv("EC3D_PATCH", "1")
     monkeypatch.setenv("EC3D_XDEFER", str(depth))
-    sdx, sdy, sdz = 256, 8, 9
+    sdx, sdy, sdz = grid
     n = sdx * sdy * sdz
     valA, irow, jcol = oracle.poisson_csr(sdx, sdy, sdz)
-    rng = np.random.Generator(np.random.PCG64(414))
+    rng = np.random.Generator(np.random.PCG64(414 + sdy))
     x0 = rng.standard_normal(n)
     b = rng.standard_normal(n)
     with E.EC3DSolver() as s:
@@ -459,8 +460,9 @@ def test_deferred_x_update_bitwise(E, oracle, depth, fuse, monkeypatch):
                 assert ite == iteo and np.array_equal(xe, xeo), (depth, k, col)
                 s_exit = hse[ite - 1] / bnorm < tol
                 seen.add(((ite - 1) % depth, "S" if s_exit else "R"))
-        # both exits met at every position of a group
-        assert seen == {(m, kind) for m in range(depth) for kind in "SR"}, seen
+        # both exits met at every position of a group (asserted on the grid where the histories are known to do so)
+        if grid == (256, 8, 9):
+            assert seen == {(m, kind) for m in range(depth) for kind in "SR"}, seen
         for itmax in range(0, 2 * depth + 2):       # src/solvers.f90:25-29 after 1 .. 2 depth + 2 iterations
             xm, itm, _ = s.solve(b, x0, 1e-30, itmax)
             xmo, itmo, _, _ = oracle.twin_solve(s, valA, irow, jcol, b, x0, 1e-30, itmax)
