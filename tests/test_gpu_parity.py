@@ -480,9 +480,12 @@ def test_deferred_x_update_bitwise(E, oracle, depth, fuse, grid, monkeypatch):
 
 
 @pytest.mark.parametrize("name", CAPTURED)
-def test_deferred_x_update_on_the_captured_systems(E, oracle, name, plane_pitch, monkeypatch):
-    """The same on the reference's own systems [Ax | Ay | Az | U] (structured form, default and pitched; five launches):
-    every captured call with X applied every fourth iteration -- x, iter and the history are the twin's."""
+def test_deferred_x_update_on_the_captured_systems(E, oracle, name, plane_pitch, sav_tiles, monkeypatch):
+    """The same on the reference's own systems [Ax | Ay | Az | U] (structured form, default and pitched; five launches
+    on linear and on 2-D tiles, three launches on 2-D tiles): every captured call with X applied every fourth iteration
+    -- x, iter and the history are the twin's."""
+    if sav_tiles != "linear" and plane_pitch != "pitched":
+        pytest.skip("the 2-D tiles of the structured kernels need tile-aligned planes")
     monkeypatch.setenv("EC3D_XDEFER", "4")
     g = load_golden(name)
     tol, itmax = float(g["tol"]), int(g["itmax"])
