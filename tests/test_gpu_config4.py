@@ -45,6 +45,24 @@ def undivided(E, xvec):
     return y, x20
 
 
+def test_x_every_fourth_iteration_leaves_the_same_bits_at_full_size(E, undivided, monkeypatch):
+    """The headline handle applies X = X + alpha*P + omega*S (src/solvers.f90:41) every fourth iteration (k4s_x_r_spmv /
+    k4d_x_r_update, rings of P and S).  A size-independent property: the same 20 iterations with an update in every
+    iteration (EC3D_XDEFER=1, everything else as the library picks it) give the same x, all 134 M entries, bit for bit."""
+    from bench import bar_rhs
+    _, x20 = undivided
+    monkeypatch.setenv("EC3D_XDEFER", "1")
+    with E.EC3DSolver() as s:
+        s.assemble_poisson(N, N, N)
+        assert s.x_interval() == 1 and s.fusion() == (1, 1) and s.k4_as_spmv()
+        x1, it, _ = s.solve(bar_rhs(N), np.zeros(N ** 3), 1e-300, 19)
+    monkeypatch.delenv("EC3D_XDEFER")
+    with E.EC3DSolver() as s:
+        s.assemble_poisson(N, N, N)
+        assert s.x_interval() == 4                                   # what `undivided` ran with
+    assert it == 20 and np.array_equal(x1, x20)
+
+
 def test_undivided_rows_equal_the_oracle_csr_row_sums(oracle, xvec, undivided):
     y, _ = undivided
     kd = N * N
