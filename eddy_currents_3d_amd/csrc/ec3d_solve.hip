@@ -40,9 +40,12 @@ RedSrc ec3d_part_of(const ec3d_ctx *c, int producer, bool split)
 // With the fusions of the 2-D-tile kernels (single rank, vectors beyond the caches) an iteration is THREE launches:
 //   stage 1: K1 -- only in iteration 1 (afterwards AP = A P was produced by the previous iteration's stage 5)
 //   stage 2: empty, stage 3: K23 (S = R - alpha*AP inside AS = A S)
-//   stage 4: K4
+//   stage 4: K4 -- as an SpMV kernel that computes A S again (ec3d_k4s: K23 then does not store AS), or the vector kernel
 //   stage 5: K51 (the exits and the P update of K5, then the NEXT iteration's K1 on the new P)
-// P(it) and AP(it) then live in pbuf[it & 1] / apbuf[it & 1] (ec3d_ctx).
+// P(it) and AP(it) then live in pbuf[it % pdepth] / apbuf[it & 1] (ec3d_ctx).
+// With the X update deferred (ec3d_xdefer = D > 1; three launches or five) P(it) and S(it) live in rings of D buffers, K4
+// leaves X alone except in the last iteration of a group of D (counted from xd_base) or of the call (xd_last), where it
+// applies what is pending; an exit in between is completed by ec3d_flush_x.
 void ec3d_launch_stage(ec3d_ctx *c, const MatView &A, int it, int k)
 {
     double **v = c->vec;
