@@ -2411,8 +2411,12 @@ void ec3d_launch_k4d(const Sweep &sw, const RedSrc &src_ss, const RedSrc &src, S
                      const double *const *p, const double *const *sv, const double *as, const double *r0, double *x,
                      double *r, double *part, double *hist, int64_t hist_cap, hipStream_t s)
 {
+    if (ne == 1) { // one update, this iteration's own: that is the classic K4
+        ec3d_launch_k4(sw, src_ss, src, st, it, p[0], sv[0], as, r0, x, r, part, hist, hist_cap, s);
+        return;
+    }
     XRing ring{};
-    for (int j = 0; j < (ne > 0 ? ne : 1); ++j) {
+    for (int j = 0; j < (ne > 0 ? std::min(ne, EC3D_XD_MAX) : 1); ++j) {
         ring.p[j] = p[j];
         ring.s[j] = sv[j];
     }
