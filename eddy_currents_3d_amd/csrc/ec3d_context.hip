@@ -779,10 +779,14 @@ int ec3d_spare_pair(ec3d_ctx *c)
     // 56; 512^3: K4 1278 -> 1185 us, profiles/r04_deferred_x_512.log).  EC3D_XDEFER=1 keeps the classic K4, 2 .. 4 force
     // a depth on any single-rank handle that owns its vectors (the five-launch iteration too: K5 then writes the new P
     // into the next buffer of the ring)
-    // Default: from 32 Mi streamed rows (nothing stays in a cache).  Below that the gain is within the noise (A-V 21 M rows
-    // -0.5 %, config 5 -0.4 %, config 3 +0.3 %, 256^3 -0.8 %; 384^3 on five launches -1.9 %: profiles/r04_deferred_x_mid_sizes.log)
+    // Default: from 4.5 Mi streamed rows, where the streams turn nontemporal (choose_sweep).  From 32 Mi rows nothing stays in
+    // a cache and the gain is the bytes (512^3 K4 1278 -> 1185 us; 384^3 on five launches -1.9 %).  Between the two K4 reads
+    // S and AS out of the Infinity Cache and gets no faster, but the iteration does, three runs each on one box
+    // (profiles/r04_deferred_x_mid_sizes.log): 256 x 256 x 80 -2.7 %, A-V 8 M rows -2.2 %, 256^3 -1.9 %, A-V 21 M rows and
+    // config 5 -1.4 %, config 3 +0.2 % -- with ONE tile in flight in the launch without X and two in the applying one
+    // (ec3d_launch_k4d picks by the vector plan), not the four / one of the big grids.
     const int64_t rows_eff = (c->A.sav && c->A.ulist) ? (c->A.ntiles_front + (int64_t)c->A.ulist_n) * EC3D_TILE : c->A.n_pad;
-    int D = rows_eff >= ((int64_t)1 << 25) ? 4 : 1;
+    int D = rows_eff >= (9 << 19) ? 4 : 1;
     if (const char *e = getenv("EC3D_XDEFER")) D = std::max(1, std::min(EC3D_XD_MAX, atoi(e)));
     if (c->fuse23_ok != c->fuse51_ok || c->dist || c->halo != 0) D = 1;
     if ((!c->fuse51_ok && D <= 1) || !c->own_vectors) {

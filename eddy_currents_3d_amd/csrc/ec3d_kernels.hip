@@ -2422,11 +2422,13 @@ void ec3d_launch_k4d(const Sweep &sw, const RedSrc &src_ss, const RedSrc &src, S
     }
     SweepV swv = sweep_v(sw);
     {   // tiles in flight per wave: the launch without X has 4 streams, the applying one 7 + 4 (ne - 1) -- not K4's 7.
-        // Measured at 512^3 (profiles/r04_deferred_x_512.log): without X 1 / 2 / 4 / 8 tiles 1.00 / 0.81 / 0.75 / 0.76 ms,
-        // the applying launch better with one tile at ne >= 3, with two at ne = 2
-        static const int off_depth = getenv("EC3D_XD_OFF_DEPTH") ? atoi(getenv("EC3D_XD_OFF_DEPTH")) : 4;
-        static const int on_depth = getenv("EC3D_XD_ON_DEPTH") ? atoi(getenv("EC3D_XD_ON_DEPTH")) : 0;
-        const int want = ne == 0 ? off_depth : (on_depth > 0 ? on_depth : (ne == 2 ? 2 : 1));
+        // Big grids (vector plan of two tiles in flight, nothing cached; 512^3, profiles/r04_deferred_x_512.log): without X
+        // 1 / 2 / 4 / 8 tiles 1.00 / 0.81 / 0.75 / 0.76 ms, the applying launch better with one tile at ne >= 3, with two at
+        // ne = 2.  Mid sizes (plan of one tile, XCD-aware map; r04_deferred_x_mid_sizes.log): one without X, two applying.
+        static const int off_env = getenv("EC3D_XD_OFF_DEPTH") ? atoi(getenv("EC3D_XD_OFF_DEPTH")) : 0;
+        static const int on_env = getenv("EC3D_XD_ON_DEPTH") ? atoi(getenv("EC3D_XD_ON_DEPTH")) : 0;
+        const bool big = sw.vec_depth >= 2;
+        const int want = ne == 0 ? (off_env > 0 ? off_env : big ? 4 : 1) : (on_env > 0 ? on_env : big ? (ne == 2 ? 2 : 1) : 2);
         if (swv.win_nt == 0) swv.two = (want == 2 || want == 4) ? want : 1;
     }
 #define EC3D_K4D(NE)                                                                                                         \

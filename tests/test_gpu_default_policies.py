@@ -1,8 +1,8 @@
 """The kernel instances the library selects BY ITSELF at the sizes the metric is quoted on, against the oracle's
 GPU-order twin, bit for bit.
 
-choose_sweep (csrc/ec3d_context.hip) switches by size: nontemporal streams from 4.5 Mi rows, the next kernel's operand
-kept cacheable up to 32 Mi rows, and from 32 Mi rows on 2-D tiles the three-launch iteration (K2 inside K3, K5 inside
+choose_sweep (csrc/ec3d_context.hip) switches by size: nontemporal streams and the X update every fourth iteration from
+4.5 Mi rows, the next kernel's operand kept cacheable up to 32 Mi rows, and from 32 Mi rows on 2-D tiles the three-launch iteration (K2 inside K3, K5 inside
 the next K1, P / AP in alternating buffers, K4 as an SpMV kernel that computes A S again) with the X update applied
 every fourth iteration (six iterations = one whole group and the itmax exit's partial one).  The small
 parity cases force those instances through EC3D_NT / EC3D_KEEP / EC3D_FUSE* (tests/test_gpu_parity.py); here NOTHING is
@@ -53,7 +53,7 @@ def test_cube_at_the_default_policy_bitwise(E, oracle, dims, fused, iters, monke
         assert g1.patch_x == 128 and g1.zm_tpp == sdx * sdy // 512
         assert (g2.patch_x == 128 and g2.nblk == g1.nblk) == fused      # S.S summed inside the SpMV kernel when fused
         assert s.fusion() == ((1, 1) if fused else (0, 0))
-        assert s.x_interval() == (4 if n >= 2 ** 25 else 1)      # X updated every 4th iteration (k4d_x_r_update)
+        assert s.x_interval() == 4                 # X updated every 4th iteration from 4.5 Mi rows (k4d_x_r_update / k4s)
         g0 = s.geometry(0)                                        # fused: K4 runs as an SpMV kernel (k4s_x_r_spmv)
         assert (g0.patch_x == 128 and g0.nblk == g1.nblk) == fused
         x, it, hist = s.solve(b, x0, 1e-30, iters - 1, hist_cap=iters)
@@ -81,6 +81,7 @@ def test_av_system_at_the_default_policy_bitwise(E, oracle, monkeypatch):
     with E.EC3DSolver() as s:
         s.assemble(geo, geoC, valPHYS, BND, delta, dt)
         assert s.info.tail_rows == 0 and s.geometry(1).zm_tpp > 0           # structured, pitched, z-marching
+        assert s.x_interval() == 4 and s.fusion() == (0, 0)                 # five launches, X every fourth iteration
         va, ir, jc = s.export_csr()
         assert np.array_equal(ir, m["irow"]) and np.array_equal(jc, m["jcol"]) and np.array_equal(va, m["valA"])
         x, it, hist = s.solve(b, x0, 1e-30, iters - 1, hist_cap=iters)
