@@ -788,7 +788,9 @@ int ec3d_spare_pair(ec3d_ctx *c)
     const int64_t rows_eff = (c->A.sav && c->A.ulist) ? (c->A.ntiles_front + (int64_t)c->A.ulist_n) * EC3D_TILE : c->A.n_pad;
     int D = rows_eff >= (9 << 19) ? 4 : 1;
     if (const char *e = getenv("EC3D_XDEFER")) D = std::max(1, std::min(EC3D_XD_MAX, atoi(e)));
-    if (c->fuse23_ok != c->fuse51_ok || c->dist || c->halo != 0) D = 1;
+    // (a z-slab that owns its vectors gets the rings too: whether they are used is the multi-rank driver's decision --
+    // ec3d_ctx::slab_xd, slab_fused -- because every rank of the job has to run the same plan)
+    if (c->fuse23_ok != c->fuse51_ok || c->dist) D = 1;
     if ((!c->fuse51_ok && D <= 1) || !c->own_vectors) {
         if (c->pp_base) (void)hipFree(c->pp_base);
         c->pp_base = nullptr;
@@ -1238,14 +1240,28 @@ extern "C" int ec3d_get_cel_bnd(ec3d_handle c, int which, int32_t *count, int32_
     return 0;
 }
 
+// 0: who sums R.R and R.R0 (K4 -- a vector kernel, or the SpMV-form K4 on the SpMV kernels' grid), 1: the SpMV kernels,
+// 2: who sums S.S (K2, or the SpMV kernel it runs inside of); the launches of a z-slab's split kernels: 3 / 4 the interior /
+// boundary launch of K1 and K3 (ec3d_can_overlap), 5 / 6 the boundary / interior launch of K2 and K5
+// (ec3d_dist_set_boundary_rows) -- a split kernel's partial sums are the first launch's followed by the second's
+static const Sweep &sweep_for(const ec3d_ctx *c, int which)
+{
+    switch (which) {
+    case 1: return c->sweep_s;
+    case 2: return ec3d_fused23(c) ? c->sweep_s : c->sweep_k2;
+    case 3: return c->sweep_int;
+    case 4: return c->sweep_bnd;
+    case 5: return c->sweep_vb;
+    case 6: return c->sweep_vi;
+    default: return ec3d_k4s(c) ? c->sweep_s : c->sweep;
+    }
+}
+
 extern "C" int ec3d_get_reduction_geometry(ec3d_handle c, int which, ec3d_geom *g)
 {
     int rc = ec3d_need_matrix(c, "ec3d_get_reduction_geometry");
     if (rc) return rc;
-    // 0: who sums R.R and R.R0 (K4 -- a vector kernel, or the SpMV-form K4 on the SpMV kernels' grid), 1: the SpMV kernels,
-    // 2: who sums S.S (K2, or the SpMV kernel it runs inside of)
-    const Sweep &sw = which == 1 ? c->sweep_s : which == 2 ? (ec3d_fused23(c) ? c->sweep_s : c->sweep_k2)
-                                                            : (ec3d_k4s(c) ? c->sweep_s : c->sweep);
+    const Sweep &sw = sweep_for(c, which);
     g->n_pad = (int32_t)c->A.n_pad;
     g->tile = EC3D_TILE;
     g->nblk = sw.nblk;
@@ -1304,13 +1320,7 @@ extern "C" int ec3d_get_visit_order(ec3d_handle c, int which, int32_t *nwg, int6
     int rc = ec3d_need_matrix(c, "ec3d_get_visit_order");
     if (rc) return rc;
     std::vector<std::vector<int32_t>> v;
-    if (which == 1) {
-        visit_of(c, c->sweep_s, v);
-    } else if (which == 2) { // who sums S.S: K2, or the SpMV kernel it runs inside of
-        visit_of(c, ec3d_fused23(c) ? c->sweep_s : c->sweep_k2, v);
-    } else {
-        visit_of(c, ec3d_k4s(c) ? c->sweep_s : c->sweep, v);
-    }
+    visit_of(c, sweep_for(c, which), v);
     int64_t tot = 0;
     for (auto &w : v) tot += (int64_t)w.size();
     *nwg = (int32_t)v.size();

@@ -129,34 +129,56 @@ extern "C" int ec3d_dist_step(ec3d_handle c, int32_t stage, int32_t it, double t
     switch (stage) {
     case EC3D_STAGE_RESID:
         c->hist_cap = 0;
+        c->pcur = c->apcur = c->scur = 1; // (as ec3d_launch_begin: P = R goes to vec[P] = pbuf[1])
+        c->ap_valid_for = 0;
+        c->p_off = 0;
+        c->xd_base = 1;
+        c->xd_last = INT_MAX;
         ec3d_launch_residual(A, c->sweep_s, v[EC3D_VEC_X], v[EC3D_VEC_B], v[EC3D_VEC_R], v[EC3D_VEC_R0],
                              v[EC3D_VEC_P], c->partials, c->stream);
         fin(EC3D_BY_SPMV, 1u << P_BB | 1u << P_RR_INIT);
         break;
     case EC3D_STAGE_SETUP: ec3d_launch_setup(c->state, ec3d_src_of(c, EC3D_BY_SPMV), tolerance, c->stream); break;
-    case EC3D_STAGE_K1: ec3d_launch_stage(c, A, it, 1); fin(EC3D_BY_SPMV, 1u << P_D1); break;
-    case EC3D_STAGE_K2: ec3d_launch_stage(c, A, it, 2); fin(EC3D_BY_K2, 1u << P_SS); break;
-    case EC3D_STAGE_K3: ec3d_launch_stage(c, A, it, 3); fin(EC3D_BY_SPMV, 1u << P_D2 | 1u << P_D3); break;
+    // On a slab that runs the three-launch iteration (ec3d_ctx::slab_fused) stage 1 launches K1 only when AP = A P of this
+    // iteration does not exist yet (iteration 1, or a call that does not continue the last one), stage 2 nothing, stage 3
+    // K2-in-K3 (sums S.S, AS.S, AS.AS), stage 4 K4 in SpMV form, stage 5 K5-in-K1, which sums AP.R0 of the NEXT iteration.
+    case EC3D_STAGE_K1:
+        if (ec3d_fused51(c) && it != 1 && c->ap_valid_for == it) break;
+        ec3d_launch_stage(c, A, it, 1);
+        fin(EC3D_BY_SPMV, 1u << P_D1);
+        break;
+    case EC3D_STAGE_K2:
+        if (ec3d_fused23(c)) break;
+        ec3d_launch_stage(c, A, it, 2);
+        fin(EC3D_BY_K2, 1u << P_SS);
+        break;
+    case EC3D_STAGE_K3:
+        ec3d_launch_stage(c, A, it, 3);
+        fin(EC3D_BY_SPMV, 1u << P_D2 | 1u << P_D3 | (ec3d_fused23(c) ? 1u << P_SS : 0u));
+        break;
     case EC3D_STAGE_K4: ec3d_launch_stage(c, A, it, 4); fin(EC3D_BY_K4, 1u << P_RR | 1u << P_RR0N); break;
-    case EC3D_STAGE_K5: ec3d_launch_stage(c, A, it, 5); break;
+    case EC3D_STAGE_K5:
+        ec3d_launch_stage(c, A, it, 5);
+        if (ec3d_fused51(c)) fin(EC3D_BY_SPMV, 1u << P_D1);
+        break;
     case EC3D_STAGE_K1_INT:
         if (!need_split()) return 3;
-        ec3d_launch_k1(A, c->sweep_int, c->state, it, v[EC3D_VEC_P], v[EC3D_VEC_R0], v[EC3D_VEC_AP], c->partials,
-                       c->stream);
+        ec3d_launch_k1(A, c->sweep_int, c->state, it, ec3d_vec_at(c, EC3D_VEC_P, it), v[EC3D_VEC_R0], v[EC3D_VEC_AP],
+                       c->partials, c->stream);
         break;
     case EC3D_STAGE_K1_BND:
         if (!need_split()) return 3;
-        ec3d_launch_k1(A, c->sweep_bnd, c->state, it, v[EC3D_VEC_P], v[EC3D_VEC_R0], v[EC3D_VEC_AP], c->partials,
-                       c->stream);
+        ec3d_launch_k1(A, c->sweep_bnd, c->state, it, ec3d_vec_at(c, EC3D_VEC_P, it), v[EC3D_VEC_R0], v[EC3D_VEC_AP],
+                       c->partials, c->stream);
         fin(EC3D_BY_SPMV, 1u << P_D1, true);
         break;
     case EC3D_STAGE_K3_INT:
         if (!need_split()) return 3;
-        ec3d_launch_k3(A, c->sweep_int, c->state, it, v[EC3D_VEC_S], v[EC3D_VEC_AS], c->partials, c->stream);
+        ec3d_launch_k3(A, c->sweep_int, c->state, it, ec3d_vec_at(c, EC3D_VEC_S, it), v[EC3D_VEC_AS], c->partials, c->stream);
         break;
     case EC3D_STAGE_K3_BND:
         if (!need_split()) return 3;
-        ec3d_launch_k3(A, c->sweep_bnd, c->state, it, v[EC3D_VEC_S], v[EC3D_VEC_AS], c->partials, c->stream);
+        ec3d_launch_k3(A, c->sweep_bnd, c->state, it, ec3d_vec_at(c, EC3D_VEC_S, it), v[EC3D_VEC_AS], c->partials, c->stream);
         fin(EC3D_BY_SPMV, 1u << P_D2 | 1u << P_D3, true);
         break;
     case EC3D_STAGE_K2_BND:
@@ -167,7 +189,8 @@ extern "C" int ec3d_dist_step(ec3d_handle c, int32_t stage, int32_t it, double t
         }
         const bool bnd = stage == EC3D_STAGE_K2_BND;
         ec3d_launch_k2(bnd ? c->sweep_vb : c->sweep_vi, ec3d_src_of(c, EC3D_BY_SPMV), c->state, it, v[EC3D_VEC_R], v[EC3D_VEC_AP],
-                       v[EC3D_VEC_S], c->partials, c->stream);
+                       ec3d_vec_at(c, EC3D_VEC_S, it), c->partials, c->stream);
+        c->scur = ec3d_xdefer(c) > 1 ? it % ec3d_xdefer(c) : 1;
         if (!bnd)
             ec3d_launch_finalize(RedSrc{c->partials, c->sweep_vb.nblk + c->sweep_vi.nblk, 1, c->sweep.pstride, nullptr}, c->lsum,
                                  1u << P_SS, c->stream);
@@ -179,9 +202,11 @@ extern "C" int ec3d_dist_step(ec3d_handle c, int32_t stage, int32_t it, double t
             ec3d_set_error("ec3d_dist_step: call ec3d_dist_set_boundary_rows first");
             return 3;
         }
+        // (deferred X update: the new P goes to the next buffer of the ring, as in ec3d_launch_stage)
         ec3d_launch_k5(stage == EC3D_STAGE_K5_BND ? c->sweep_vb : c->sweep_vi, ec3d_src_of(c, EC3D_BY_K4), c->state, it,
-                       v[EC3D_VEC_R], v[EC3D_VEC_AP], v[EC3D_VEC_P], v[EC3D_VEC_P], v[EC3D_VEC_R0], c->hist, c->hist_cap,
-                       c->stream);
+                       v[EC3D_VEC_R], v[EC3D_VEC_AP], ec3d_vec_at(c, EC3D_VEC_P, it), ec3d_vec_at(c, EC3D_VEC_P, it + 1),
+                       v[EC3D_VEC_R0], c->hist, c->hist_cap, c->stream);
+        if (ec3d_xdefer(c) > 1) c->pcur = ((it + 1 + c->p_off) % c->pdepth + c->pdepth) % c->pdepth;
         break;
     default: ec3d_set_error("ec3d_dist_step: unknown stage"); return 2;
     }
@@ -189,11 +214,15 @@ extern "C" int ec3d_dist_step(ec3d_handle c, int32_t stage, int32_t it, double t
     return 0;
 }
 
-// kernel launches ec3d_dist_step issues for a stage (the stage's kernel and, where it produces sums, k_finalize)
-int ec3d_dist_launches(int stage)
+// kernel launches ec3d_dist_step issues for a stage (the stage's kernel and, where it produces sums, k_finalize); on a slab
+// that runs the three-launch iteration stages 1 and 2 are empty and stage 5 produces a sum
+int ec3d_dist_launches(const ec3d_ctx *c, int stage, int it)
 {
     switch (stage) {
-    case EC3D_STAGE_SETUP: case EC3D_STAGE_K5: case EC3D_STAGE_K1_INT: case EC3D_STAGE_K3_INT: case EC3D_STAGE_K2_BND:
+    case EC3D_STAGE_K1: return (ec3d_fused51(c) && it != 1 && c->ap_valid_for == it) ? 0 : 2;
+    case EC3D_STAGE_K2: return ec3d_fused23(c) ? 0 : 2;
+    case EC3D_STAGE_K5: return ec3d_fused51(c) ? 2 : 1;
+    case EC3D_STAGE_SETUP: case EC3D_STAGE_K1_INT: case EC3D_STAGE_K3_INT: case EC3D_STAGE_K2_BND:
     case EC3D_STAGE_K5_BND: case EC3D_STAGE_K5_INT: return 1;
     default: return 2;
     }

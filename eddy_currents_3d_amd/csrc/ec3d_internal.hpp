@@ -4,6 +4,7 @@
 
 #include "../../include/ec3d_hip.h"
 
+#include <algorithm>
 #include <climits>
 #include <cstdio>
 #include <cstdint>
@@ -109,7 +110,15 @@ struct Sweep {
     // zm_pl0 > 0: z-march over planes [zm_pl0, zm_pl0 + zm_npl) only (interior launch);
     // bnd_last >= 0: the launch covers planes 0 and bnd_last only (boundary launch, plain tile order)
     int zm_pl0, zm_npl;
+    // zm_plstep > 1: the launch covers the logical planes zm_pl0, zm_pl0 + zm_plstep, ... (zm_npl of them), one plane per
+    // workgroup step sequence (zm_pps = 1): the boundary launch of the 2-D-tile kernels in a z-slab -- planes 0 and np-1
+    int zm_plstep;
     int bnd_last;  // -1: not a boundary launch
+    // z-slab of the single-component operator running the three-launch iteration (K2 inside K3, K5 inside the next K1):
+    // S and P are FORMED on the halo planes by the kernels that need them there, and stored into the vectors' ghost rows
+    // for the next kernel's stencil (K4 in SpMV form reads S one plane away; the next K5-in-K1 reads the old P there).
+    // bit 0: this slab has a lower z-neighbour (store the plane below plane 0), bit 1: an upper one (above the last plane)
+    int halo_store;
     int part_off;  // first partial-sum index this launch writes within a slot
     // structured A-V form: tiles [0, ntiles) are swept as usual (the three A blocks); of the tiles
     // behind them (the grid-shaped U block) only those holding an unknown are visited, from a list --
@@ -158,7 +167,7 @@ __host__ __device__ inline int64_t ec3d_tile_of(const SW &sw, int b, int64_t i)
         const int64_t col = c * cpx + s % cpx, seg = s / cpx;
         const int64_t pl = seg * sw.zm_pps + i;
         if (col >= sw.zm_tpp || i >= sw.zm_pps || (sw.zm_npl > 0 && pl >= sw.zm_npl)) return -1;
-        const int64_t t = (sw.zm_pl0 + pl) * sw.zm_tpp + col;
+        const int64_t t = (sw.zm_pl0 + (sw.zm_plstep > 1 ? pl * sw.zm_plstep : pl)) * sw.zm_tpp + col;
         return t < sw.ntiles ? ec3d_phys_tile(sw, t) : -1;
     }
     int64_t t;
@@ -267,6 +276,14 @@ struct ec3d_ctx {
     bool fuse23_ok = false; // 2-D tiles: K2 may run inside K3 (single rank only, see ec3d_fused23)
     bool fuse51_ok = false; // 2-D tiles: K5 may run inside the next iteration's K1 (ec3d_fused51)
     bool k4s_ok = false;    // dictionary cube on 2-D tiles: K4 may run as an SpMV kernel that computes A S again (ec3d_k4s)
+    // z-slab of a multi-rank job (set by the job's driver once EVERY rank can do it: the exchanges differ, so the plan is a
+    // property of the job): the three-launch iteration on this slab (AP and R are exchanged instead of P and S, see
+    // Sweep::halo_store); the X update deferred over slab_xd iterations (0: not on this slab)
+    bool slab_fused = false;
+    int slab_xd = 0;
+    // P(it) lives in pbuf[(it + p_off) % pdepth]: 0 within a solve; ec3d_iterate / ec3d_multi_iterate set it so that the
+    // call's first iteration finds the CURRENT P whatever iteration number it is given (pcur)
+    int p_off = 0;
     // K5-in-K1 reads the previous iteration's P and AP while it writes the new ones (neighbouring workgroups read the
     // old values of cells this one owns), so both vectors alternate between two buffers: P(it) lives in
     // pbuf[it & 1], AP(it) in apbuf[it & 1]; index 1 is vec[EC3D_VEC_P] / vec[EC3D_VEC_AP], index 0 the spare pair
@@ -435,21 +452,30 @@ enum { EC3D_BY_K4 = 0, EC3D_BY_SPMV = 1, EC3D_BY_K2 = 2 };
 RedSrc ec3d_src_of(const ec3d_ctx *c, int producer);
 RedSrc ec3d_part_of(const ec3d_ctx *c, int producer, bool split = false);
 void ec3d_launch_stage(ec3d_ctx *c, const MatView &A, int it, int k); // k = 1..5, 0 = all five
-inline bool ec3d_fused23(const ec3d_ctx *c) { return c->fuse23_ok && !c->dist && c->halo == 0; }
-inline bool ec3d_fused51(const ec3d_ctx *c) { return c->fuse51_ok && !c->dist && c->halo == 0 && c->pp_base != nullptr; }
+inline bool ec3d_fused23(const ec3d_ctx *c) { return c->fuse23_ok && ((!c->dist && c->halo == 0) || c->slab_fused); }
+inline bool ec3d_fused51(const ec3d_ctx *c)
+{
+    return c->fuse51_ok && ((!c->dist && c->halo == 0) || c->slab_fused) && c->pp_base != nullptr;
+}
 // K4 in SpMV form (k4s_x_r_spmv): only inside the three-launch iteration
 inline bool ec3d_k4s(const ec3d_ctx *c) { return c->k4s_ok && ec3d_fused23(c) && ec3d_fused51(c); }
 // deferred X update: single rank, own vectors (the rings exist), and the iteration either fully fused or not at all
 inline int ec3d_xdefer(const ec3d_ctx *c)
 {
-    if (c->xdefer <= 1 || c->dist || c->halo != 0 || c->pp_base == nullptr) return 1;
+    if (c->xdefer <= 1 || c->pp_base == nullptr) return 1;
+    if (c->dist || c->halo != 0) { // a z-slab: only when the job's driver said so (the exchanged P / S then live in the rings)
+        if (c->slab_xd <= 1) return 1;
+        return (ec3d_fused23(c) == ec3d_fused51(c)) ? std::min(c->xdefer, c->slab_xd) : 1;
+    }
     return (ec3d_fused23(c) == ec3d_fused51(c)) ? c->xdefer : 1;
 }
+// where vector `vec` (EC3D_VEC_P / _AP / _S; anything else: the plain work vector) of iteration `it` lives on this handle
+double *ec3d_vec_at(const ec3d_ctx *c, int vec, int it);
 int ec3d_flush_x(ec3d_ctx *c, int stop_iter); // the pending X updates after an exit at stop_iter (enqueued)
 void ec3d_launch_iteration(ec3d_ctx *c, const MatView &A, int it);
 int ec3d_launch_begin(ec3d_ctx *c, const MatView &A, double tol);
 int ec3d_single_rank_only(ec3d_ctx *c, const char *who);
-int ec3d_dist_launches(int stage); // ec3d_dist.hip
+int ec3d_dist_launches(const ec3d_ctx *c, int stage, int it); // ec3d_dist.hip (call BEFORE the stage is launched)
 
 // ec3d_kernels.hip — launchers (all asynchronous on `s`)
 void ec3d_launch_spmv(const MatView &A, const Sweep &sw, const double *x, double *y, hipStream_t s);

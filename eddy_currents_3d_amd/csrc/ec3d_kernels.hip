@@ -204,6 +204,9 @@ template <> struct MatDev<FMT_SAV> {
 struct SweepZ {
     int64_t ntiles, n; // logical front tiles; rows >= n are padding
     int tpp, pps, npl, pl0;
+    int plstep;           // > 1: logical plane lp of the launch is physical plane pl0 + lp * plstep (pps = 1; Sweep::zm_plstep)
+    int hs_mask, hs_last; // z-slab, K2-in-K3 / K5-in-K1: store the formed vector on the halo planes (Sweep::halo_store);
+                          // hs_last = the slab's last owned plane
     int pstride, part_off;
     int ulist_n;
     const int32_t *ulist;
@@ -371,13 +374,13 @@ __device__ __forceinline__ void walk_zm(const SweepZ &sw, BODY &&body)
     int64_t lp = (int64_t)(sg / cpx) * sw.pps; // logical plane, relative to pl0
     int64_t lend = lp + sw.pps;
     if (sw.npl > 0 && lend > sw.npl) lend = sw.npl;
-    {   // logical planes whose tile of this column exists: (pl0 + lp) * tpp + col < ntiles
+    if (sw.plstep <= 1) { // logical planes whose tile of this column exists: (pl0 + lp) * tpp + col < ntiles
         const int64_t nlp = (sw.ntiles - col + sw.tpp - 1) / sw.tpp - sw.pl0;
         if (lend > nlp) lend = nlp;
     }
     if (col >= sw.tpp) lend = lp;
     const bool win = sw.win_npo > 0;
-    int64_t rem = 0, pl = sw.pl0 + lp;
+    int64_t rem = 0, pl = sw.pl0 + (sw.plstep > 1 ? lp * sw.plstep : lp); // (plstep > 1: one plane per workgroup, pps = 1)
     if (win && lp < lend) {
         rem = pl % sw.win_npo;
         pl = (pl / sw.win_npo) * sw.win_npb + sw.win_p0 + rem;
@@ -1626,7 +1629,9 @@ EC3D_SPMV_T __global__ __launch_bounds__(EC3D_THREADS) EC3D_SPMV_OCC void k3_spm
 // rim and edge values recomputed by the lanes that need them) and stored by its owner; AS = A S; partials S.S, AS.S,
 // AS.AS -- all three in the SpMV kernels' thread -> cell assignment.  Saves the 8 B per row S costs to re-read and one
 // launch; the products, their order and every stored value are those of K2 followed by K3 (src/solvers.f90:31-40).
-EC3D_SPMV_T __global__ __launch_bounds__(EC3D_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void k23_s_spmv_dots(
+// HS (z-slab, Sweep::halo_store): an instance of its own, so that the single-GPU kernel carries nothing for it
+template <int FMT, bool NT, bool ZM, bool TAIL, bool PATCH, bool HS = false>
+__global__ __launch_bounds__(EC3D_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void k23_s_spmv_dots(
     MatDev<FMT> A, EC3D_SWEEP_OF(ZM) sw, RedSrc src, SolverState *st, int it, const double *__restrict__ rv,
     const double *__restrict__ ap, double *__restrict__ sv, double *__restrict__ as, double *__restrict__ part)
 {
@@ -1657,6 +1662,16 @@ EC3D_SPMV_T __global__ __launch_bounds__(EC3D_THREADS) __attribute__((amdgpu_wav
         spmv_pair<FMT, ZM, TAIL, NT, PATCH>(A, sw, pp, tbl, stg, pstep, VecFused{rv, ap, alpha}, r, tile, (bool)fc, zr, s0, s1, q);
         store2<NT>(sv, r, nst, q.x, q.y);
         if (as) store2<NT>(as, r, nst, s0, s1); // (nullptr: K4 runs in SpMV form and computes A S again, k4s_x_r_spmv)
+        if constexpr (HS && FMT == FMT_DICT7 && ZM && PATCH) {
+            // z-slab: S on the neighbours' planes, formed here from the exchanged R and AP exactly as their owners form it
+            // (same expression, same operands, same alpha), goes into S's ghost rows for the stencil of K4 in SpMV form
+            if (sw.hs_mask) {
+                const int64_t pl = tile / sw.tpp, kdz = A.off[6];
+                const VecFused xs{rv, ap, alpha};
+                if ((sw.hs_mask & 1) && pl == 0) *reinterpret_cast<d2 *>(sv + r - kdz) = xs.pair(r - kdz);
+                if ((sw.hs_mask & 2) && pl == sw.hs_last) *reinterpret_cast<d2 *>(sv + r + kdz) = xs.pair(r + kdz);
+            }
+        }
         double q0 = q.x, q1 = q.y;
         EC3D_MASK2(r, sw, q0, q1);
         EC3D_IDLE2(q0, q1);
@@ -1683,7 +1698,8 @@ EC3D_SPMV_T __global__ __launch_bounds__(EC3D_THREADS) __attribute__((amdgpu_wav
 // (p_old, ap_old) and those of it + 1 written to (p_new, ap_new): other workgroups read the old values of cells this
 // one owns (rim, edge, the planes at a segment's ends), so the update cannot be in place.  Saves the 8 B per row P
 // costs to re-read and one launch; every stored value and every product is K5's followed by K1's.
-EC3D_SPMV_T __global__ __launch_bounds__(EC3D_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void k51_p_spmv_dot(
+template <int FMT, bool NT, bool ZM, bool TAIL, bool PATCH, bool HS = false>
+__global__ __launch_bounds__(EC3D_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void k51_p_spmv_dot(
     MatDev<FMT> A, EC3D_SWEEP_OF(ZM) sw, RedSrc src, SolverState *st, int it, const double *__restrict__ rv,
     const double *__restrict__ p_old, const double *__restrict__ ap_old, double *__restrict__ p_new,
     double *__restrict__ ap_new, double *__restrict__ r0, double *__restrict__ part, double *hist, int64_t hist_cap)
@@ -1731,6 +1747,16 @@ EC3D_SPMV_T __global__ __launch_bounds__(EC3D_THREADS) __attribute__((amdgpu_wav
         d2 q = restart ? pc : load2<NT>(r0 + r); // after a restart R0 = R = the new P
         store2<NT>(p_new, r, nst, pc.x, pc.y);
         if (restart) store2<NT>(r0, r, nst, pc.x, pc.y);
+        if constexpr (HS && FMT == FMT_DICT7 && ZM && PATCH) {
+            // z-slab: the new P on the neighbours' planes (formed from the exchanged R and AP and the old P kept there the
+            // same way) into the new P's ghost rows: the next K5-in-K1 reads it as ITS old P, so P is never exchanged
+            if (sw.hs_mask) {
+                const int64_t pl = tile / sw.tpp, kdz = A.off[6];
+                const VecFusedP xp{rv, p_old, ap_old, beta, omega, restart};
+                if ((sw.hs_mask & 1) && pl == 0) *reinterpret_cast<d2 *>(p_new + r - kdz) = xp.pair(r - kdz);
+                if ((sw.hs_mask & 2) && pl == sw.hs_last) *reinterpret_cast<d2 *>(p_new + r + kdz) = xp.pair(r + kdz);
+            }
+        }
         store2<NT>(ap_new, r, nst, s0, s1);
         EC3D_MASK2(r, sw, s0, s1);
         EC3D_IDLE2(s0, s1);
@@ -2218,6 +2244,9 @@ static inline SweepZ sweep_z(const Sweep &sw)
     z.pps = sw.zm_pps;
     z.npl = sw.zm_npl;
     z.pl0 = sw.zm_pl0;
+    z.plstep = sw.zm_plstep;
+    z.hs_mask = sw.halo_store;
+    z.hs_last = sw.zm_tpp > 0 ? (int)(sw.ntiles / sw.zm_tpp) - 1 : 0;
     z.pstride = sw.pstride;
     z.part_off = sw.part_off;
     z.ulist_n = sw.ulist_n;
@@ -2370,6 +2399,13 @@ void ec3d_launch_k23(const MatView &A, const Sweep &sw, const RedSrc &src, Solve
     }
     const MatDev<FMT_DICT7> Ad = mat_dev<FMT_DICT7>(A);
     const size_t lds = tbl_bytes(A, FMT_DICT7, true, true);
+    if (sw.halo_store) { // a z-slab running the three-launch iteration: S is also stored on the halo planes
+        if (nt_of(sw))
+            k23_s_spmv_dots<FMT_DICT7, true, true, false, true, true><<<sw.nblk, EC3D_THREADS, lds, s>>>(Ad, swz, src, st, it, r, ap, sv, as, part);
+        else
+            k23_s_spmv_dots<FMT_DICT7, false, true, false, true, true><<<sw.nblk, EC3D_THREADS, lds, s>>>(Ad, swz, src, st, it, r, ap, sv, as, part);
+        return;
+    }
     if (nt_of(sw))
         k23_s_spmv_dots<FMT_DICT7, true, true, false, true><<<sw.nblk, EC3D_THREADS, lds, s>>>(Ad, swz, src, st, it, r, ap, sv, as, part);
     else
@@ -2392,6 +2428,13 @@ void ec3d_launch_k51(const MatView &A, const Sweep &sw, const RedSrc &src, Solve
     }
     const MatDev<FMT_DICT7> Ad = mat_dev<FMT_DICT7>(A);
     const size_t lds = tbl_bytes(A, FMT_DICT7, true, true);
+    if (sw.halo_store) { // a z-slab running the three-launch iteration: the new P is also stored on the halo planes
+        if (nt_of(sw))
+            k51_p_spmv_dot<FMT_DICT7, true, true, false, true, true><<<sw.nblk, EC3D_THREADS, lds, s>>>(Ad, swz, src, st, it, r, p_old, ap_old, p_new, ap_new, r0, part, hist, hist_cap);
+        else
+            k51_p_spmv_dot<FMT_DICT7, false, true, false, true, true><<<sw.nblk, EC3D_THREADS, lds, s>>>(Ad, swz, src, st, it, r, p_old, ap_old, p_new, ap_new, r0, part, hist, hist_cap);
+        return;
+    }
     if (nt_of(sw))
         k51_p_spmv_dot<FMT_DICT7, true, true, false, true><<<sw.nblk, EC3D_THREADS, lds, s>>>(Ad, swz, src, st, it, r, p_old, ap_old, p_new, ap_new, r0, part, hist, hist_cap);
     else

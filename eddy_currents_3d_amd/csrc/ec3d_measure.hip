@@ -78,6 +78,9 @@ extern "C" int ec3d_iterate(ec3d_handle c, int32_t first_iter, int32_t count, do
     // every call leaves X complete
     c->xd_base = first_iter;
     c->xd_last = first_iter + count - 1;
+    // ... and finds the CURRENT P (the buffer the last launch wrote) under whatever iteration number it is given: a call
+    // that does not continue the previous one's numbering (iterate(1, n) twice) would otherwise read an older ring entry
+    c->p_off = ((c->pcur - first_iter) % c->pdepth + c->pdepth) % c->pdepth;
     if (!kernel_ms) {
         for (int it = first_iter; it < first_iter + count; ++it) ec3d_launch_iteration(c, A, it);
         EC3D_HIP(hipGetLastError());

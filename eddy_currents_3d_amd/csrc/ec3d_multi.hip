@@ -39,8 +39,8 @@
 
 namespace {
 constexpr int RING = 4;
-enum { CH_P = 0, CH_S = 1, CH_X = 2, CH_SUM = 3, CH_HUB = 4, NCH = 5 };
-const int kVecOf[3] = {EC3D_VEC_P, EC3D_VEC_S, EC3D_VEC_X};
+enum { CH_P = 0, CH_S = 1, CH_X = 2, CH_AP = 3, CH_R = 4, NHALO = 5, CH_SUM = 5, CH_HUB = 6, NCH = 7 };
+const int kVecOf[NHALO] = {EC3D_VEC_P, EC3D_VEC_S, EC3D_VEC_X, EC3D_VEC_AP, EC3D_VEC_R};
 
 // a run of halo planes inside one work vector: `planes` pieces of `payload` doubles, `pitch` apart
 struct Run {
@@ -53,13 +53,15 @@ struct Copy {
     int64_t dst, src, cnt;
 };
 
-enum { OP_HALO = 0, OP_HALO_START, OP_HALO_WAIT, OP_GATHER, OP_STEP };
+enum { OP_HALO = 0, OP_HALO_START, OP_HALO_WAIT, OP_GATHER, OP_STEP, OP_SKIP_IF_AP };
 struct Op {
     int kind, arg;
+    int dit = 0; // halo ops: the exchanged vector is that of iteration it + dit (P after K5 is the NEXT iteration's)
 };
 #define ST(x) Op{OP_STEP, EC3D_STAGE_##x}
 const std::vector<Op> kBegin = {{OP_HALO, CH_X}, ST(RESID), {OP_GATHER, 0}, ST(SETUP)};
-const std::vector<Op> kBeginVsplit = {{OP_HALO, CH_X}, ST(RESID), {OP_GATHER, 0}, ST(SETUP), {OP_HALO, CH_P}};
+// (run with it = 0: the first iteration's P)
+const std::vector<Op> kBeginVsplit = {{OP_HALO, CH_X}, ST(RESID), {OP_GATHER, 0}, ST(SETUP), {OP_HALO, CH_P, 1}};
 // three reduction points per iteration (K3 is launched before ||S|| is known)
 const std::vector<Op> kIter = {{OP_HALO, CH_P}, ST(K1), {OP_GATHER, 0}, ST(K2), {OP_HALO, CH_S},
                                ST(K3), {OP_GATHER, 0}, ST(K4), {OP_GATHER, 0}, ST(K5)};
@@ -70,7 +72,16 @@ const std::vector<Op> kIterOverlap = {{OP_HALO_START, CH_P}, ST(K1_INT), {OP_HAL
 // the same from the producers' side (A-V slabs, any storage): K2/K5 boundary tiles first
 const std::vector<Op> kIterVsplit = {{OP_HALO_WAIT, CH_P}, ST(K1), {OP_GATHER, 0}, ST(K2_BND), {OP_HALO_START, CH_S},
                                      ST(K2_INT), {OP_HALO_WAIT, CH_S}, ST(K3), {OP_GATHER, 0}, ST(K4), {OP_GATHER, 0},
-                                     ST(K5_BND), {OP_HALO_START, CH_P}, ST(K5_INT)};
+                                     ST(K5_BND), {OP_HALO_START, CH_P, 1}, ST(K5_INT)};
+// The three-launch iteration on slabs of the single-component operator (every rank >= 32 Mi rows; ec3d_ctx::slab_fused):
+// K2 inside K3, K4 as an SpMV kernel, K5 inside the next iteration's K1.  S and P are formed on the halo planes by the
+// kernels that read them there (and stored into the ghost rows: Sweep::halo_store), so what travels is AP -- after
+// K5-in-K1, for the S = R - alpha*AP of K2-in-K3 and the next P on the halo planes -- and R -- after K4 --: two exchanges
+// and three reduction points per iteration, as before.  P and R are exchanged once before the first iteration; the lone K1
+// (with its reduction point and the exchange of its AP) runs when AP = A P of the iteration does not exist yet.
+const std::vector<Op> kBeginFused = {{OP_HALO, CH_X}, ST(RESID), {OP_GATHER, 0}, ST(SETUP), {OP_HALO, CH_P, 1}, {OP_HALO, CH_R}};
+const std::vector<Op> kIterFused = {{OP_SKIP_IF_AP, 3}, ST(K1), {OP_GATHER, 0}, {OP_HALO, CH_AP}, ST(K3), {OP_GATHER, 0}, ST(K4),
+                                    {OP_GATHER, 0}, {OP_HALO, CH_R}, ST(K5), {OP_GATHER, 0}, {OP_HALO, CH_AP, 1}};
 #undef ST
 
 struct Slab {
@@ -82,13 +93,13 @@ struct Slab {
     uint64_t api_calls = 0, api_iters = 0; // runtime calls / iterations of the last ec3d_multi_iterate (this rank)
     const double **ptr_table = nullptr; // device: every rank's lsum
     hipStream_t side = nullptr;
-    hipEvent_t ev_ready[3][RING] = {}, ev_halo[3][RING] = {}, ev_sum[RING] = {}, ev_hub[RING] = {};
-    uint64_t seq[NCH] = {0, 0, 0, 0, 0};
+    hipEvent_t ev_ready[NHALO][RING] = {}, ev_halo[NHALO][RING] = {}, ev_sum[RING] = {}, ev_hub[RING] = {};
+    uint64_t seq[NCH] = {0, 0, 0, 0, 0, 0, 0};
     std::atomic<uint64_t> posted[NCH];
     std::vector<Run> send_lo, recv_lo, send_hi, recv_hi; // towards rank-1 / rank+1, same order on both sides
     std::vector<Copy> pull_lo, pull_hi;                  // my ghost rows <- neighbour's rows
     bool split_ok = false;
-    int plan = 0; // 0 plain, 1 overlap (K1/K3 interior + boundary), 2 vsplit (K2/K5 boundary first)
+    int plan = 0; // 0 plain, 1 overlap (K1/K3 interior + boundary), 2 vsplit (K2/K5 boundary first), 3 three launches (kIterFused)
     int32_t *stop_pinned = nullptr;
     hipEvent_t ev_stop[2] = {};
     // A-V slab: local reference order [Ax_ext | Ay_ext | Az_ext | U_ext] <-> the global vector
@@ -196,7 +207,8 @@ int run_all(ec3d_multi *m, const std::function<int(int)> &fn, bool watch = false
                      " it " + std::to_string(s->at_it.load()) + " seq " + std::to_string(s->at_seq.load()) + " posted [" +
                      std::to_string(s->posted[0].load()) + " " + std::to_string(s->posted[1].load()) + " " +
                      std::to_string(s->posted[2].load()) + " " + std::to_string(s->posted[3].load()) + " " +
-                     std::to_string(s->posted[4].load()) + "]\n";
+                     std::to_string(s->posted[4].load()) + " " + std::to_string(s->posted[5].load()) + " " +
+                     std::to_string(s->posted[6].load()) + "]\n";
             return r;
         };
         if (limit <= 0) {
@@ -280,7 +292,23 @@ int cross_wait(hipStream_t stream, hipEvent_t ev)
     return 0;
 }
 
-int halo_start(ec3d_multi *m, Slab &s, int v)
+// Vector `vec` of iteration `it` in slab `owner`'s memory.  The ring position is worked out from MY handle's state
+// (every rank of a job runs the same plan with the same depths, and my state is current when I get here), the pointer
+// taken from the owner's tables, which do not change while a job runs: another rank's thread may be iterations ahead or
+// behind with its own host-side bookkeeping.
+double *vec_of(const ec3d_ctx *me, const ec3d_ctx *owner, int vec, int it)
+{
+    const bool f51 = ec3d_fused51(me);
+    const int D = ec3d_xdefer(me), pd = me->pdepth;
+    switch (vec) {
+    case EC3D_VEC_P: return (f51 || D > 1) ? owner->pbuf[((it + me->p_off) % pd + pd) % pd] : owner->vec[EC3D_VEC_P];
+    case EC3D_VEC_AP: return f51 ? owner->apbuf[it & 1] : owner->vec[EC3D_VEC_AP];
+    case EC3D_VEC_S: return D > 1 ? owner->sbuf[((it % D) + D) % D] : owner->vec[EC3D_VEC_S];
+    default: return owner->vec[vec];
+    }
+}
+
+int halo_start(ec3d_multi *m, Slab &s, int v, int it = 0)
 {
     const uint64_t q = ++s.seq[v];
     const int i = (int)(q % RING), vi = kVecOf[v];
@@ -301,8 +329,8 @@ int halo_start(ec3d_multi *m, Slab &s, int v)
         s.at.store("halo_start:cross_wait");
         if ((rc = cross_wait(s.side, peer.ev_ready[v][i]))) return rc;
         s.at.store("halo_start:copy");
-        double *mine = s.c->vec[vi];
-        const double *theirs = peer.c->vec[vi];
+        double *mine = vec_of(s.c, s.c, vi, it);
+        const double *theirs = vec_of(s.c, peer.c, vi, it);
         // EC3D_MULTI_FORCE_PEER_API=1: the peer-copy call also between slabs of ONE device (tests on a one-GPU box)
         static const bool force_peer = getenv("EC3D_MULTI_FORCE_PEER_API") && atoi(getenv("EC3D_MULTI_FORCE_PEER_API")) != 0;
         for (const Copy &c : cp) {
@@ -398,21 +426,26 @@ int run_plan(ec3d_multi *m, Slab &s, const std::vector<Op> &plan, int it, double
 {
     int rc = 0;
     s.at_it.store(it);
-    for (const Op &op : plan) {
+    for (size_t oi = 0; oi < plan.size(); ++oi) {
+        const Op &op = plan[oi];
         switch (op.kind) {
         case OP_HALO:
-            if ((rc = halo_start(m, s, op.arg))) return rc;
+            if ((rc = halo_start(m, s, op.arg, it + op.dit))) return rc;
             if ((rc = halo_wait(s, op.arg))) return rc;
             break;
-        case OP_HALO_START: if ((rc = halo_start(m, s, op.arg))) return rc; break;
+        case OP_HALO_START: if ((rc = halo_start(m, s, op.arg, it + op.dit))) return rc; break;
         case OP_HALO_WAIT: if ((rc = halo_wait(s, op.arg))) return rc; break;
         case OP_GATHER: if ((rc = gather(m, s))) return rc; break;
+        case OP_SKIP_IF_AP: // AP = A P of this iteration came out of the last K5-in-K1: no lone K1, no sum, no exchange
+            if (it != 1 && s.c->ap_valid_for == it) oi += (size_t)op.arg;
+            break;
         default: {
             const int st = (s.plan == 2 && !s.split_ok) ? unsplit_stage(op.arg) : op.arg;
             if (st < 0) break;
             s.at.store("stage");
             s.at_arg.store(st);
             const int k = tm ? kernel_of_stage(st) : -1;
+            t_api_calls += (uint64_t)ec3d_dist_launches(s.c, st, it); // the kernel launches of the stage
             if (k >= 0) {
                 hipEvent_t a, b;
                 MHIP(hipEventCreate(&a));
@@ -426,7 +459,6 @@ int run_plan(ec3d_multi *m, Slab &s, const std::vector<Op> &plan, int it, double
             } else {
                 rc = ec3d_dist_step(s.c, st, it, tol);
             }
-            t_api_calls += (uint64_t)ec3d_dist_launches(st); // the kernel launches of the stage
             if (rc) return rc;
         }
         }
@@ -434,8 +466,11 @@ int run_plan(ec3d_multi *m, Slab &s, const std::vector<Op> &plan, int it, double
     return 0;
 }
 
-const std::vector<Op> &begin_plan(const Slab &s) { return s.plan == 2 ? kBeginVsplit : kBegin; }
-const std::vector<Op> &iter_plan(const Slab &s) { return s.plan == 2 ? kIterVsplit : s.plan == 1 ? kIterOverlap : kIter; }
+const std::vector<Op> &begin_plan(const Slab &s) { return s.plan == 3 ? kBeginFused : s.plan == 2 ? kBeginVsplit : kBegin; }
+const std::vector<Op> &iter_plan(const Slab &s)
+{
+    return s.plan == 3 ? kIterFused : s.plan == 2 ? kIterVsplit : s.plan == 1 ? kIterOverlap : kIter;
+}
 
 int drain(Slab &s)
 {
@@ -487,7 +522,7 @@ int slab_reset(ec3d_multi *m, Slab &s)
         int rc = ec3d_create(&s.c, s.device);
         if (rc) return rc;
         MHIP(hipStreamCreateWithFlags(&s.side, hipStreamNonBlocking));
-        for (int v = 0; v < 3; ++v)
+        for (int v = 0; v < NHALO; ++v)
             for (int i = 0; i < RING; ++i) {
                 MHIP(hipEventCreateWithFlags(&s.ev_ready[v][i], hipEventDisableTiming));
                 MHIP(hipEventCreateWithFlags(&s.ev_halo[v][i], hipEventDisableTiming));
@@ -566,6 +601,23 @@ int finish_setup(ec3d_multi *m)
         const double est_us = (double)big * 264.0 / 4.0e6 + 12.0 + 20.0 * (m->n > 1);
         m->chunk = (int)std::min<double>(32.0, std::max<double>(1.0, 400.0 / est_us));
     }
+    // What the whole job can do (the plan is a property of the job: the exchanges of the three-launch iteration differ
+    // from those of the five-launch one, and the rings of the deferred X update decide where an exchanged P or S lives).
+    //   fused: the single-component operator, EVERY slab on 2-D tiles with both fusions, the SpMV-form K4 and the spare
+    //          buffers in place (choose_sweep's size rule per slab: from 32 Mi rows; EC3D_FUSE23 / EC3D_FUSE51 / EC3D_K4S
+    //          force it on small grids).  EC3D_SLAB_FUSE=0 keeps five launches.
+    //   xd:    the smallest depth any slab allocated rings for (ec3d_spare_pair: 4 from 4.5 Mi streamed rows).
+    //          EC3D_SLAB_XDEFER=1 switches it off, 2 .. 4 caps it.
+    bool fused = m->kind == 1 && m->n > 1;
+    int xd = EC3D_XD_MAX;
+    for (auto &sp : m->slab) {
+        const ec3d_ctx *c = sp->c;
+        fused = fused && c->fuse23_ok && c->fuse51_ok && c->k4s_ok && c->pp_base && c->own_vectors;
+        xd = std::min(xd, (c->pp_base && c->own_vectors) ? c->xdefer : 1);
+    }
+    if (const char *e = getenv("EC3D_SLAB_FUSE")) fused = fused && atoi(e) != 0;
+    if (const char *e = getenv("EC3D_SLAB_XDEFER")) xd = std::min(xd, std::max(1, atoi(e)));
+    if (m->n == 1) xd = 0; // (a one-slab job is an ordinary handle: its own rule applies)
     return run_all(m, [&](int r) -> int {
         Slab &s = *m->slab[(size_t)r];
         MHIP(hipMemcpy(s.ptr_table, tab.data(), tab.size() * sizeof(double *), hipMemcpyHostToDevice));
@@ -575,10 +627,14 @@ int finish_setup(ec3d_multi *m)
         c->lsum = s.lsum;
         c->gsum = nullptr;
         c->lsum_ptrs = s.ptr_table;
+        c->slab_fused = fused;
+        c->slab_xd = xd;
+        c->sweep_s.halo_store = fused ? ((r > 0 ? 1 : 0) | (r + 1 < m->n ? 2 : 0)) : 0;
+        if (c->pp_base) c->pdepth = std::max(2, ec3d_xdefer(c)); // every rank cycles P through the same number of buffers
         s.plan = 0;
         s.split_ok = false;
         if (m->kind == 1) {
-            s.plan = ec3d_can_overlap(c) ? 1 : 0;
+            s.plan = fused ? 3 : ec3d_can_overlap(c) ? 1 : 0;
         } else if (m->n > 1) {
             // the ORDER of exchanges is a property of the job: every A-V rank uses the producer-side
             // plan; a rank whose slab is all boundary runs the whole kernels in that order
@@ -734,6 +790,7 @@ int slab_solve(ec3d_multi *m, Slab &s, double tol, int32_t itmax, int32_t *iter_
     const int64_t total = std::max<int64_t>(0, (int64_t)itmax + 1); // src/solvers.f90:25-29
     int rc = run_plan(m, s, begin_plan(s), 0, tol, nullptr);
     if (rc) return rc;
+    c->xd_last = (int)std::min<int64_t>(total, INT_MAX); // the itmax exit: the last iteration applies the pending X updates
     // every rank must look at the flag after the same iterations, so the chunk is a property of the job
     // (finish_setup: from the largest slab), not of this slab
     const int chunk = m->chunk;
@@ -758,6 +815,10 @@ int slab_solve(ec3d_multi *m, Slab &s, double tol, int32_t itmax, int32_t *iter_
     if ((rc = drain(s))) return rc;
     int32_t si = 0;
     if ((rc = ec3d_read_state(c, &si, nullptr, nullptr))) return rc;
+    if (si >= 0) { // an exit with X updates pending (deferred X update, K4 in SpMV form): applied now, on the owned rows
+        if ((rc = ec3d_flush_x(c, si))) return rc;
+        MHIP(hipStreamSynchronize(c->stream));
+    }
     *iter_out = si >= 0 ? si : (int32_t)total;
     *hit_itmax = si < 0;
     return 0;
@@ -818,7 +879,7 @@ extern "C" int ec3d_multi_destroy(ec3d_multi_handle m)
         if (s.c) (void)ec3d_destroy(s.c);
         s.c = nullptr;
         if (s.side) (void)hipStreamDestroy(s.side);
-        for (int v = 0; v < 3; ++v)
+        for (int v = 0; v < NHALO; ++v)
             for (int i = 0; i < RING; ++i) {
                 if (s.ev_ready[v][i]) (void)hipEventDestroy(s.ev_ready[v][i]);
                 if (s.ev_halo[v][i]) (void)hipEventDestroy(s.ev_halo[v][i]);
@@ -1335,6 +1396,12 @@ extern "C" int ec3d_multi_iterate(ec3d_multi_handle m, int32_t first_iter, int32
 {
     int rc = need(m, "ec3d_multi_iterate");
     if (rc) return rc;
+    for (auto &sp : m->slab) { // as ec3d_iterate: the groups of the deferred X update are counted from this call's first
+        ec3d_ctx *c = sp->c;   // iteration, its last one applies what is pending, and it starts from the CURRENT P
+        c->xd_base = first_iter;
+        c->xd_last = first_iter + count - 1;
+        c->p_off = ((c->pcur - first_iter) % c->pdepth + c->pdepth) % c->pdepth;
+    }
     return run_all(m, [&](int r) -> int {
         Slab &s = *m->slab[(size_t)r];
         StageTimer tm;
@@ -1367,6 +1434,16 @@ extern "C" int ec3d_multi_api_calls(ec3d_multi_handle m, int32_t rank, double *p
     if (!m || rank < 0 || rank >= m->n || !per_iteration) return 2;
     const Slab &s = *m->slab[(size_t)rank];
     *per_iteration = s.api_iters ? (double)s.api_calls / (double)s.api_iters : 0.0;
+    return 0;
+}
+
+extern "C" int ec3d_multi_plan(ec3d_multi_handle m, int32_t *plan, int32_t *x_every)
+{
+    int rc = need(m, "ec3d_multi_plan");
+    if (rc) return rc;
+    const Slab &s = *m->slab[0];
+    if (plan) *plan = s.plan;
+    if (x_every) *x_every = ec3d_xdefer(s.c);
     return 0;
 }
 

@@ -36,6 +36,21 @@ RedSrc ec3d_part_of(const ec3d_ctx *c, int producer, bool split)
     return RedSrc{c->partials, parts_of(c, producer, split), 1, c->sweep.pstride, nullptr};
 }
 
+// Where vector `vec` of iteration `it` lives: P in the ring pbuf (K5-in-K1 alternates two buffers, the deferred X update
+// keeps D), AP in apbuf (K5-in-K1), S in sbuf (deferred X update); otherwise the plain work vector.  The multi-rank
+// drivers address the halo exchange of an iteration's vector through the same function (ec3d_multi.hip).
+double *ec3d_vec_at(const ec3d_ctx *c, int vec, int it)
+{
+    const bool f51 = ec3d_fused51(c);
+    const int D = ec3d_xdefer(c), pd = c->pdepth;
+    switch (vec) {
+    case EC3D_VEC_P: return (f51 || D > 1) ? c->pbuf[((it + c->p_off) % pd + pd) % pd] : c->vec[EC3D_VEC_P];
+    case EC3D_VEC_AP: return f51 ? c->apbuf[it & 1] : c->vec[EC3D_VEC_AP];
+    case EC3D_VEC_S: return D > 1 ? c->sbuf[((it % D) + D) % D] : c->vec[EC3D_VEC_S];
+    default: return c->vec[vec];
+    }
+}
+
 // the five launches of one iteration; `k` selects one of them (1..5) or all (0).
 // With the fusions of the 2-D-tile kernels (single rank, vectors beyond the caches) an iteration is THREE launches:
 //   stage 1: K1 -- only in iteration 1 (afterwards AP = A P was produced by the previous iteration's stage 5)
@@ -54,9 +69,10 @@ void ec3d_launch_stage(ec3d_ctx *c, const MatView &A, int it, int k)
     const bool fused = ec3d_fused23(c); // K2 inside K3 (2-D tiles, single rank): stage 2 is empty, stage 3 is K23
     const bool f51 = ec3d_fused51(c);
     const int D = ec3d_xdefer(c), pd = c->pdepth;
-    const bool ring = D > 1; // P(it) in pbuf[it % pd] also on the five-launch iteration (K5 then writes the next buffer)
-    double *P = (f51 || ring) ? c->pbuf[it % pd] : v[EC3D_VEC_P], *AP = f51 ? c->apbuf[it & 1] : v[EC3D_VEC_AP];
-    double *S = D > 1 ? c->sbuf[it % D] : v[EC3D_VEC_S];
+    const bool ring = D > 1; // P(it) in the ring also on the five-launch iteration (K5 then writes the next buffer)
+    double *P = ec3d_vec_at(c, EC3D_VEC_P, it), *AP = ec3d_vec_at(c, EC3D_VEC_AP, it);
+    double *S = ec3d_vec_at(c, EC3D_VEC_S, it);
+    const auto pidx = [&](int i) { return ((i + c->p_off) % pd + pd) % pd; };
     // fused: AP(it) was produced by the previous iteration's K51 -- unless this call does not continue that
     // iteration (iteration 1, ec3d_iterate from another first_iter, ec3d_time_kernel): then K1 runs on its own
     if ((k == 0 || k == 1) && (!f51 || it == 1 || c->ap_valid_for != it))
@@ -80,7 +96,7 @@ void ec3d_launch_stage(ec3d_ctx *c, const MatView &A, int it, int k)
             const double *pp[EC3D_XD_MAX] = {nullptr}, *sp[EC3D_XD_MAX] = {nullptr};
             const int ne = apply ? xm + 1 : 0;
             for (int j = 0; j < ne; ++j) { // iterations it - xm .. it, oldest first
-                pp[j] = c->pbuf[(it - xm + j) % pd];
+                pp[j] = c->pbuf[pidx(it - xm + j)];
                 sp[j] = D > 1 ? c->sbuf[(it - xm + j) % D] : S;
             }
             if (ne == 0) sp[0] = S;
@@ -93,7 +109,7 @@ void ec3d_launch_stage(ec3d_ctx *c, const MatView &A, int it, int k)
             const double *pp[EC3D_XD_MAX] = {nullptr}, *sp[EC3D_XD_MAX] = {nullptr};
             const int ne = apply ? xm + 1 : 0;
             for (int j = 0; j < ne; ++j) { // iterations it - xm .. it, oldest first
-                pp[j] = c->pbuf[(it - xm + j) % pd];
+                pp[j] = c->pbuf[pidx(it - xm + j)];
                 sp[j] = c->sbuf[(it - xm + j) % D];
             }
             if (ne == 0) sp[0] = S;
@@ -104,14 +120,14 @@ void ec3d_launch_stage(ec3d_ctx *c, const MatView &A, int it, int k)
     }
     if ((k == 0 || k == 5) && !f51) {
         ec3d_launch_k5(c->sweep_k5, ec3d_src_of(c, EC3D_BY_K4), c->state, it, v[EC3D_VEC_R], AP, P,
-                       ring ? c->pbuf[(it + 1) % pd] : P, v[EC3D_VEC_R0], c->hist, c->hist_cap, s);
-        if (ring) c->pcur = (it + 1) % pd;
+                       ring ? c->pbuf[pidx(it + 1)] : P, v[EC3D_VEC_R0], c->hist, c->hist_cap, s);
+        if (ring) c->pcur = pidx(it + 1);
     }
     if ((k == 0 || k == 5) && f51) {
-        ec3d_launch_k51(A, ss, ec3d_src_of(c, EC3D_BY_K4), c->state, it, v[EC3D_VEC_R], P, AP, c->pbuf[(it + 1) % pd],
+        ec3d_launch_k51(A, ss, ec3d_src_of(c, EC3D_BY_K4), c->state, it, v[EC3D_VEC_R], P, AP, c->pbuf[pidx(it + 1)],
                         c->apbuf[(it + 1) & 1], v[EC3D_VEC_R0], c->partials, c->hist, c->hist_cap, s);
         c->ap_valid_for = it + 1;
-        c->pcur = (it + 1) % pd;
+        c->pcur = pidx(it + 1);
         c->apcur = (it + 1) & 1;
     }
 }
@@ -125,7 +141,7 @@ int ec3d_flush_x(ec3d_ctx *c, int stop_iter)
     const double *pp[EC3D_XD_MAX], *sp[EC3D_XD_MAX];
     for (int j = 0; j < EC3D_XD_MAX; ++j) { // entries past the pending count are never dereferenced: any valid pointer
         const int itj = stop_iter - xm + std::min(j, xm);
-        pp[j] = c->pbuf[itj % c->pdepth];
+        pp[j] = c->pbuf[((itj + c->p_off) % c->pdepth + c->pdepth) % c->pdepth];
         sp[j] = D > 1 ? c->sbuf[itj % D] : c->vec[EC3D_VEC_S];
     }
     ec3d_launch_x_flush(c->sweep, c->state, pp, sp, c->vec[EC3D_VEC_X], c->stream);
@@ -143,6 +159,7 @@ int ec3d_launch_begin(ec3d_ctx *c, const MatView &A, double tol)
     ec3d_launch_setup(c->state, ec3d_src_of(c, EC3D_BY_SPMV), tol, c->stream);
     c->pcur = c->apcur = c->scur = 1; // P = R went to vec[P] = pbuf[1]
     c->ap_valid_for = 0;
+    c->p_off = 0;
     c->xd_base = 1;
     c->xd_last = INT_MAX;
     EC3D_HIP(hipGetLastError());

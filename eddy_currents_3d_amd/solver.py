@@ -68,7 +68,7 @@ EXPORTS = ["sprsbcgstabwr_", "ec3d_invalidate", "ec3d_create", "ec3d_destroy", "
            "ec3d_multi_upload", "ec3d_multi_download", "ec3d_multi_solve", "ec3d_multi_solve_resident",
            "ec3d_multi_rhs_step", "ec3d_multi_post_update", "ec3d_multi_vtk_fields", "ec3d_multi_vtk_fields_begin",
            "ec3d_multi_vtk_fields_wait", "ec3d_multi_iterate_begin",
-           "ec3d_multi_iterate", "ec3d_multi_synchronize", "ec3d_true_residual", "ec3d_multi_true_residual", "ec3d_get_visit_order", "ec3d_probe_csr_multi", "ec3d_multi_spmv", "ec3d_multi_api_calls"]
+           "ec3d_multi_iterate", "ec3d_multi_synchronize", "ec3d_true_residual", "ec3d_multi_true_residual", "ec3d_get_visit_order", "ec3d_probe_csr_multi", "ec3d_multi_spmv", "ec3d_multi_api_calls", "ec3d_multi_plan"]
 
 _f64 = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
 _i32 = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
@@ -213,6 +213,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.ec3d_multi_iterate.argtypes = [hp, C.c_int32, C.c_int32, hp]
     L.ec3d_multi_synchronize.argtypes = [hp]
     L.ec3d_multi_api_calls.argtypes = [hp, C.c_int32, C.POINTER(C.c_double)]
+    L.ec3d_multi_plan.argtypes = [hp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.sprsbcgstabwr_.argtypes = [_f64, _i32, _i32, C.POINTER(C.c_int32), _f64, _f64,
                                  C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.sprsbcgstabwr_.restype = None
@@ -790,6 +791,13 @@ class EC3DMulti:
 
     def synchronize(self):
         _chk(self.L, self.L.ec3d_multi_synchronize(self.h), "ec3d_multi_synchronize")
+
+    def plan(self):
+        """(plan, x_every): the schedule the job runs (ec3d_multi_plan): 0 five launches, 1 K1 / K3 interior + boundary,
+        2 K2 / K5 boundary first, 3 three launches per iteration; iterations between two X updates."""
+        pl, xe = C.c_int32(0), C.c_int32(0)
+        _chk(self.L, self.L.ec3d_multi_plan(self.h, C.byref(pl), C.byref(xe)), "ec3d_multi_plan")
+        return pl.value, xe.value
 
     def api_calls(self, rank: int) -> float:
         """HIP runtime calls per iteration rank `rank`'s host thread issued in the last iterate()."""

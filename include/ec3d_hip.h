@@ -290,6 +290,12 @@ int ec3d_multi_synchronize(ec3d_multi_handle mh);
 /* HIP runtime calls (kernel launches, event records and waits, copies) that rank `rank`'s host thread issued per
  * iteration during the last ec3d_multi_iterate: the host-side price of one pass of src/solvers.f90:24-50 on N GPUs */
 int ec3d_multi_api_calls(ec3d_multi_handle mh, int32_t rank, double *per_iteration);
+/* The schedule the job runs (one value for all ranks: the exchanges are part of it).  plan: 0 = five launches, halo
+ * exchange in front of K1 and K3; 1 = K1 / K3 as interior + boundary launch with the exchange behind the interior one;
+ * 2 = K2 / K5 boundary tiles first (A-V slabs); 3 = three launches per iteration (K2 inside K3, K4 as an SpMV kernel, K5
+ * inside the next K1 -- every rank >= 32 Mi rows of the single-component operator): AP and R travel instead of P and S.
+ * x_every: iterations between two applications of X = X + alpha*P + omega*S (src/solvers.f90:41; 1 = every iteration). */
+int ec3d_multi_plan(ec3d_multi_handle mh, int32_t *plan, int32_t *x_every);
 
 /* ------------------------------------------------------------------------------------------
  * 3. Introspection / measurement

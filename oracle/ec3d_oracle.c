@@ -243,11 +243,45 @@ static int64_t gpu_row_of(const oracle_gpu_geom *g, int64_t tile, int t)
     return plane * pitch + (py * g->patch_y + ty) * g->patch_sdx + px * g->patch_x + tx;
 }
 
+/* `count` values reduced the way every consumer kernel reduces a producer's partial sums (reduce_partials in
+ * ec3d_kernels.hip): thread t adds values t, t + T, ... in that order, then the block tree.  The same function collapses
+ * a rank's workgroup partials (k_finalize) and adds the ranks' sums (one value per rank, rank order). */
+double oracle_tree_sum(const double *v, int32_t count, int32_t threads)
+{
+    double *acc = malloc((size_t)threads * sizeof(double));
+    for (int t = 0; t < threads; ++t) {
+        double s = 0.0;
+        for (int32_t i = t; i < count; i += threads) s = s + v[i];
+        acc[t] = s;
+    }
+    double r = block_tree(acc, threads);
+    free(acc);
+    return r;
+}
+
+static void dot_parts(const oracle_gpu_geom *g, const double *a, const double *b, int64_t n, double *part);
+
+/* the per-workgroup partial sums of one launch (g->visit_nwg or g->nblk of them), in workgroup order: what a multi-launch
+ * producer (interior + boundary launch of a z-slab) leaves behind, to be strung together and reduced by oracle_tree_sum */
+void oracle_dot_gpuorder_parts(const oracle_gpu_geom *g, const double *a, const double *b, int64_t n, double *part)
+{
+    dot_parts(g, a, b, n, part);
+}
+
 double oracle_dot_gpuorder(const oracle_gpu_geom *g, const double *a, const double *b, int64_t n)
+{
+    const int32_t nwg = g->visit_off ? g->visit_nwg : g->nblk;
+    double *part = calloc((size_t)(nwg > 0 ? nwg : 1), sizeof(double));
+    dot_parts(g, a, b, n, part);
+    const double r = oracle_tree_sum(part, nwg, g->threads);
+    free(part);
+    return r;
+}
+
+static void dot_parts(const oracle_gpu_geom *g, const double *a, const double *b, int64_t n, double *part)
 {
     int T = g->threads;
     const int32_t nwg = g->visit_off ? g->visit_nwg : g->nblk;
-    double *part = calloc((size_t)(nwg > 0 ? nwg : 1), sizeof(double));
     double *acc = malloc((size_t)T * sizeof(double));
     for (int32_t blk = 0; blk < nwg; ++blk) {
         for (int t = 0; t < T; ++t) acc[t] = 0.0;
@@ -280,14 +314,7 @@ double oracle_dot_gpuorder(const oracle_gpu_geom *g, const double *a, const doub
         }
         part[blk] = block_tree(acc, T);
     }
-    for (int t = 0; t < T; ++t) {
-        double s = 0.0;
-        for (int32_t i = t; i < nwg; i += T) s = s + part[i];
-        acc[t] = s;
-    }
-    double r = block_tree(acc, T);
-    free(part); free(acc);
-    return r;
+    free(acc);
 }
 
 int oracle_bicgstab_wr_gpuorder3(const oracle_gpu_geom *gv, const oracle_gpu_geom *gs, const oracle_gpu_geom *gk2,

@@ -368,6 +368,62 @@ def case_g5_big(sizes=(128, 256)):
              tol=np.float64(1e-8))
 
 
+def case_g5x(N=512, ks=(1, 2, 4, 8, 16), tol=1e-8, scratch=None):
+    """G5X: BASELINE config 4 (the 512^3 cube, n = 134 217 728, nnz = 937 951 232) pinned to the
+    UNMODIFIED reference solver: oracle/_ref/ref_solve on the whole CSR triple (bar RHS, x0 = 0, tol 1e-8) with
+    itmax = k - 1, which makes it return after exactly k iterations and print norm2(R) (src/solvers.f90:25-29).
+    Kept per k: the printed ||R_k|| (the recursion's residual), the true ||b - A x_k|| (rows summed by the oracle's CSR
+    SpMV, plane chunks), ||x_k||, and a 1024-bucket count-sketch of x_k.  About 35 GB of memory at the peak (11.8 GB
+    of CSR in the solver process, its six automatic work vectors on an unlimited stack) and a 15 GB scratch file,
+    written once; the header's itmax is patched in place between the runs."""
+    n = N ** 3
+    b = O.bar_rhs(N)
+    td = tempfile.mkdtemp(prefix="ec3d_g5x_", dir=scratch)
+    fin, fout = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
+    try:
+        valA, irow, jcol = O.poisson_csr(N, N, N)
+        nnz = len(jcol)
+        with open(fin, "wb") as f:
+            np.array([n, nnz, 0, 1], np.int64).tofile(f)
+            np.array([tol], np.float64).tofile(f)
+            irow.tofile(f); jcol.tofile(f); valA.tofile(f)
+            b.tofile(f)
+            np.zeros(n).tofile(f)
+        del valA, irow, jcol
+        bnorm = float(np.linalg.norm(b))
+        exe = os.path.join(HERE, "_ref", "ref_solve")
+        rn, rtrue, xn, sk, secs = [], [], [], [], []
+        for k in ks:
+            with open(fin, "r+b") as f:   # int64 header: n, nnz, itmax, nrep
+                f.seek(16)
+                np.array([k - 1], np.int64).tofile(f)
+            p = subprocess.run([exe, fin, fout], preexec_fn=O._unlimit_stack, check=True, stdout=subprocess.PIPE)
+            with open(fout, "rb") as f:
+                it = int(np.fromfile(f, np.int32, 2)[0])
+                sec = float(np.fromfile(f, np.float64, 1)[0])
+                xk = np.fromfile(f, np.float64, n)
+            assert it == k, (it, k)
+            r2 = 0.0
+            step = 16
+            for k0 in range(0, N, step):     # ||b - A x_k||: the rows of 16 planes at a time
+                y = O.poisson_rows_times(N, N, N, k0, k0 + step, xk)
+                e = b[k0 * N * N:(k0 + step) * N * N] - y
+                r2 += float(np.dot(e, e))
+            rn.append(float(p.stdout.decode().split()[-1]))
+            rtrue.append(float(np.sqrt(r2)))
+            xn.append(float(np.linalg.norm(xk)))
+            sk.append(O.count_sketch(xk, 1024))
+            secs.append(sec)
+            print(f"G5X N={N} k={k}: printed ||R|| {rn[-1]:.16e}  true ||b - A x_k|| {rtrue[-1]:.16e}  ||x_k|| {xn[-1]:.16e}  "
+                  f"solver {sec:.1f} s", flush=True)
+            del xk
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
+    save(f"g5x_cube{N}", N=np.int32(N), n=np.int64(n), nnz=np.int64(nnz), tol=np.float64(tol), ks=np.array(ks, np.int32),
+         bnorm=np.float64(bnorm), prefix_rnorm_printed=np.array(rn), prefix_rnorm=np.array(rtrue),
+         prefix_xnorm=np.array(xn), prefix_xsketch=np.stack(sk), seconds=np.array(secs))
+
+
 def case_g6x(which=("ec_src_move_hole", "LIM"), K=16):
     """G6X: two more facts about the full-size systems of case_g6, both for the first solver call (b = the
     sources alone, x0 = 0), kept as sketches (oracle.count_sketch):
@@ -580,6 +636,8 @@ if __name__ == "__main__":
     if "g4" in which: case_g4()
     if "g5" in which: case_g5()
     if "g5big" in which: case_g5_big()
+    if "g5x" in which: case_g5x()
+    if "g5x64" in which: case_g5x(64, scratch=None)   # (dry run of the recipe on a small cube)
     if "g6" in which: case_g6()
     if "g6fhole" in which: case_g6f(("ec_src_move_hole",))
     if "g6flim" in which: case_g6f(("LIM",))

@@ -68,6 +68,10 @@ def lib() -> C.CDLL:
         L.oracle_bicgstab_wr.restype = C.c_int
         L.oracle_dot_gpuorder.argtypes = [C.POINTER(GpuGeom), _f64p, _f64p, C.c_int64]
         L.oracle_dot_gpuorder.restype = C.c_double
+        L.oracle_dot_gpuorder_parts.argtypes = [C.POINTER(GpuGeom), _f64p, _f64p, C.c_int64, _f64p]
+        L.oracle_dot_gpuorder_parts.restype = None
+        L.oracle_tree_sum.argtypes = [_f64p, C.c_int32, C.c_int32]
+        L.oracle_tree_sum.restype = C.c_double
         L.oracle_bicgstab_wr_gpuorder.argtypes = [C.POINTER(GpuGeom), C.POINTER(GpuGeom), _f64p, _i32p, _i32p, C.c_int32,
                                                   _f64p, _f64p, C.c_double, C.c_int32,
                                                   C.POINTER(C.c_int32), C.c_void_p, C.c_void_p,
@@ -128,11 +132,11 @@ def bicgstab_wr(valA, irow, jcol, b, x0, tol, itmax, hist_cap=0):
     return x, it.value, hs, hr
 
 
-def geoms_of(solver):
+def geoms_of(solver, whichs=(0, 1, 2)):
     """(vector-kernel geometry, SpMV-kernel geometry) of an eddy_currents_3d_amd.EC3DSolver."""
     out = []
     ul = np.ascontiguousarray(solver.ulist(), np.int32)
-    for which in (0, 1, 2):   # K4's grid, the SpMV kernels', K2's
+    for which in whichs:   # K4's grid, the SpMV kernels', K2's (3 .. 6: the split launches of a z-slab)
         g = solver.geometry(which)
         gg = GpuGeom(n_pad=g.n_pad, tile=g.tile, nblk=g.nblk, threads=g.threads, xcd_group=g.xcd_group,
                      zm_tpp=g.zm_tpp, zm_pps=g.zm_pps, ntiles_front=g.ntiles_front, ulist_n=g.ulist_n,
@@ -194,6 +198,88 @@ def twin_solve(solver, valA, irow, jcol, b, x0, tol, itmax, hist_cap=0):
     xo, it, hs, hr = bicgstab_wr_gpuorder(geoms_of(solver), vd, ird, jcd, bd, xd, tol, itmax, hist_cap=hist_cap)
     assert np.all(np.delete(xo, rm) == 0.0)
     return xo[rm], it, hs, hr
+
+
+def tree_sum(vals, threads=256):
+    """`vals` added the way the consumer kernels add a producer's partials or the ranks' sums (reduce_partials)."""
+    v = np.ascontiguousarray(vals, np.float64)
+    return lib().oracle_tree_sum(v, len(v), threads)
+
+
+def dot_parts(geom, a, b):
+    """Per-workgroup partial sums of one launch, workgroup order."""
+    nwg = geom.visit_nwg if geom.visit_off else geom.nblk
+    part = np.zeros(max(nwg, 1))
+    lib().oracle_dot_gpuorder_parts(C.byref(geom), np.ascontiguousarray(a), np.ascontiguousarray(b), len(a), part)
+    return part[:nwg]
+
+
+def twin_solve_slabs(slabs, plan, valA, irow, jcol, b, x0, tol, itmax, hist_cap=0):
+    """The GPU-order twin of a MULTI-RANK solve of the single-component operator: src/solvers.f90:3-50 on the whole
+    system, every dot product summed as the z-slab drivers sum it -- per rank in that rank's kernels' order (the
+    launches the rank's handle reports: ec3d_get_visit_order; a split kernel's partials are the first launch's
+    followed by the second's), collapsed by the 256-thread tree (k_finalize), and the ranks' sums added in rank order
+    by the same tree (reduce_partials over one value per rank).  slabs: [(EC3DSolver view of the slab, row0, row1)] in
+    rank order, rows in the reference's numbering; plan: 0 plain, 1 K1 / K3 as interior + boundary launch, 3 three
+    launches (what EC3DMulti.plan() reports).  Returns (x, iter, hist_s, hist_r, restarts)."""
+    spmv_w = (3, 4) if plan == 1 else (1,)
+    geo = []
+    for sv, lo, hi in slabs:
+        g = {w: geoms_of(sv, (w,))[0] for w in set((0, 1, 2) + spmv_w)}
+        geo.append((g, lo, hi))
+
+    def dot(ws, u, v):
+        vals = []
+        for g, lo, hi in geo:
+            parts = np.concatenate([dot_parts(g[w], u[lo:hi], v[lo:hi]) for w in ws])
+            vals.append(tree_sum(parts))
+        return tree_sum(vals)
+
+    x = np.array(x0, dtype=np.float64, copy=True)
+    hs, hr = _hist(hist_cap)
+    R = b - spmv_csr(valA, irow, jcol, x)
+    R0 = R.copy()
+    P = R.copy()
+    it = 0
+    restarts = 0
+    bnorm = np.sqrt(dot((1,), b, b))                         # k_residual
+    if bnorm == 0.0:
+        return x, 0, hs, hr, 0
+    rr0 = dot((1,), R, R0)                                   # k_residual: R.R
+    while True:
+        if it > itmax:
+            break
+        it += 1
+        AP = spmv_csr(valA, irow, jcol, P)
+        alpha = rr0 / dot(spmv_w, AP, R0)                    # K1 (or K5-in-K1 of the previous iteration)
+        S = R - alpha * AP
+        nrm = np.sqrt(dot((2,), S, S))                       # K2 (or K2-in-K3)
+        if it <= hist_cap:
+            hs[it - 1] = nrm
+        if nrm / bnorm < tol:
+            x = x + alpha * P
+            break
+        AS = spmv_csr(valA, irow, jcol, S)
+        omega = dot(spmv_w, AS, S) / dot(spmv_w, AS, AS)     # K3
+        x = (x + alpha * P) + omega * S
+        R = S - omega * AS
+        rr = dot((0,), R, R)                                 # K4
+        nrm = np.sqrt(rr)
+        if it <= hist_cap:
+            hr[it - 1] = nrm
+        if nrm / bnorm < tol:
+            break
+        rr0_new = dot((0,), R, R0)                           # K4
+        beta = (alpha / omega) * rr0_new / rr0
+        P = R + beta * (P - omega * AP)
+        if abs(rr0_new) / bnorm < tol:                       # src/solvers.f90:47-49
+            R0 = R.copy()
+            P = R.copy()
+            restarts += 1
+            rr0 = rr                                         # R0 == R: the next R.R0 is R.R in the same order
+        else:
+            rr0 = rr0_new
+    return x, it, hs, hr, restarts
 
 
 def last_restart_count():

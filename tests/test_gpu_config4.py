@@ -130,3 +130,75 @@ def test_twenty_iterations_on_eight_slabs_equal_the_staged_driver(E, undivided):
     rel = float(np.linalg.norm(x8 - x1) / np.linalg.norm(x1))
     print(f"512^3 on 8 slabs, 20 iterations: bit-identical to the staged driver; ||x_8slabs - x_undivided|| / ||x|| = {rel:.2e}")
     assert rel <= 1e-9
+
+
+def test_first_iterates_track_the_reference_solver_at_full_size(E):
+    """Config 4 pinned to the REFERENCE ITSELF (tests/golden/g5x_cube512.npz, oracle/make_goldens.py case_g5x): the
+    unmodified src/solvers.f90 (oracle/_ref/ref_solve) ran the whole 512^3 system -- CSR triple of 937 951 232 entries,
+    bar RHS, x0 = 0, tol 1e-8 -- with itmax = k - 1 for k = 1, 2, 4, 8, 16, which makes it return after exactly k
+    iterations (:25-29).  The GPU, at the policy the library picks by itself (three launches, X every fourth iteration:
+    nothing forced), runs the same k iterations from the same start.  Bars as for configs 3 and 5
+    (test_first_iterations_track_the_reference_at_full_size): ||x_k - x_k_ref|| / ||x_k_ref|| (1024-bucket count-sketch)
+    and | ||b - A x_k|| - reference's | / reference's <= 1e-10 for k <= 8, <= 1e-7 at k = 16; ||b|| to rounding."""
+    import os
+    from bench import bar_rhs
+    from conftest import GOLDEN, load_golden
+    from oracle import oracle as O
+    if not os.path.exists(os.path.join(GOLDEN, "g5x_cube512.npz")):
+        pytest.skip("fixture not generated")
+    g = load_golden("g5x_cube512")
+    assert int(g["N"]) == N and int(g["n"]) == N ** 3
+    b = bar_rhs(N)
+    with E.EC3DSolver() as s:
+        s.assemble_poisson(N, N, N)
+        assert s.info.nnz == int(g["nnz"])
+        assert s.fusion() == (1, 1) and s.k4_as_spmv() and s.x_interval() == 4      # the headline configuration
+        s.upload("B", b)
+        for i, k in enumerate(int(v) for v in g["ks"]):
+            s.upload("X", np.zeros(N ** 3))
+            it, _ = s.solve_resident(float(g["tol"]), k - 1)
+            assert it == k
+            rel, bn = s.true_residual()
+            assert bn == pytest.approx(float(g["bnorm"]), rel=1e-13)
+            res = rel * bn                                                          # ||b - A x_k|| from the device
+            x = s.download("X")
+            sk = O.count_sketch(x, 1024)
+            ref_sk = g["prefix_xsketch"][i]
+            dx = float(np.linalg.norm(sk - ref_sk) / np.linalg.norm(ref_sk))
+            dr = abs(res - float(g["prefix_rnorm"][i])) / float(g["prefix_rnorm"][i])
+            dn = abs(float(np.linalg.norm(x)) - float(g["prefix_xnorm"][i])) / float(g["prefix_xnorm"][i])
+            print(f"512^3 k={k:2d}: ||b - A x_k|| {res:.12e} / reference {float(g['prefix_rnorm'][i]):.12e} (rel {dr:.1e}); "
+                  f"||x_k - x_k_ref|| / ||x_k_ref|| = {dx:.1e}; ||x_k|| rel {dn:.1e}")
+            bar = 1e-10 if k <= 8 else 1e-7
+            assert dx <= bar and dr <= bar and dn <= bar
+
+
+@pytest.mark.parametrize("world, fused", [(2, True), (4, True), (8, False)])
+def test_slab_shapes_of_the_cube_at_the_library_policy_bitwise(E, oracle, world, fused, monkeypatch):
+    """The slabs of the 512^3 cube as 2, 4 and 8 GPUs hold them -- 512 x 512 x 256 / x 128 / x 64 -- at the plan and the
+    policies the library picks BY ITSELF (nothing forced): from 32 Mi rows per rank three launches per iteration with AP
+    and R exchanged (plan 3), below that five launches with K1 / K3 split around the exchange (plan 1); X every fourth
+    iteration on both.  To keep the twin affordable the grid holds TWO such slabs (the kernels, plans and per-rank sizes
+    are those of the full cube; the cube itself on 8 slabs is the test above): four iterations of
+    src/solvers.f90:24-50 against the oracle's multi-rank twin, x bit for bit."""
+    for k in ("EC3D_NT", "EC3D_KEEP", "EC3D_FUSE23", "EC3D_FUSE51", "EC3D_PATCH", "EC3D_NBLK", "EC3D_NBLK_SPMV", "EC3D_VEC_DEPTH",
+              "EC3D_XCD_MAP", "EC3D_ZMARCH", "EC3D_XDEFER", "EC3D_K4S", "EC3D_SLAB_FUSE", "EC3D_SLAB_XDEFER"):
+        monkeypatch.delenv(k, raising=False)
+    planes = N // world
+    sdz = 2 * planes
+    n, kdz = N * N * sdz, N * N
+    valA, irow, jcol = oracle.poisson_csr(N, N, sdz)
+    rng = np.random.Generator(np.random.PCG64(8 + world))
+    b = rng.standard_normal(n)
+    x0 = rng.standard_normal(n)
+    iters = 4
+    with E.EC3DMulti(2, devices=[0, 0]) as m:
+        m.assemble_poisson(N, N, sdz)
+        plan, xd = m.plan()
+        assert plan == (3 if fused else 1) and xd == 4
+        x, it = m.solve(b, x0, 1e-30, iters - 1)
+        slabs = [(m.slab(r)[0], m.slab(r)[1] * kdz, m.slab(r)[2] * kdz) for r in range(2)]
+        xo, ito, _, _, _ = oracle.twin_solve_slabs(slabs, plan, valA, irow, jcol, b, x0, 1e-30, iters - 1)
+    assert it == ito == iters and np.array_equal(x, xo)
+    print(f"two slabs of 512 x 512 x {planes} (what a rank holds on {world} GPUs): plan {plan}, X every {xd}, {iters} iterations "
+          f"bit-identical to the multi-rank twin")

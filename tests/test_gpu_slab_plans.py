@@ -1,0 +1,184 @@
+"""The schedules of the z-slab drivers against the oracle's MULTI-RANK twin, bit for bit.
+
+The multi-GPU handle (include/ec3d_hip.h section 2c, csrc/ec3d_multi.hip; on the one-GPU test box every slab sits on
+device 0: the same code with local copies instead of xGMI ones) runs one of four plans (ec3d_multi_plan):
+
+  0  five launches, halo exchange in front of K1 and K3
+  1  K1 / K3 as interior + boundary launch, the exchange behind the interior one
+  2  K2 / K5 boundary tiles first (A-V slabs; pinned elsewhere against the staged driver and the reference's captures)
+  3  three launches per iteration -- K2 inside K3, K4 as an SpMV kernel that computes A S again, K5 inside the next K1 --
+     with AP and R exchanged instead of P and S, S and P formed on the halo planes by the kernels that read them there
+
+and, on every plan, X = X + alpha*P + omega*S (src/solvers.f90:41) applied every D-th iteration from rings of P and S.
+oracle.twin_solve_slabs restates src/solvers.f90:3-50 on the WHOLE system and sums every dot product the way the slabs
+do: per rank in the order of that rank's launches (ec3d_get_visit_order, a split kernel's partials strung together),
+collapsed by the 256-thread tree, the ranks' sums added in rank order.  x, the iteration count and the number of
+restarts (:47-49) must be the twin's.  Sizes are small and the size policies forced through the environment
+(EC3D_FUSE23 / EC3D_FUSE51 / EC3D_K4S = 2, EC3D_XDEFER, EC3D_NT); tests/test_gpu_config4.py runs the plans the library
+picks by itself at the slab shapes of the 512^3 cube."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+KNOBS = ("EC3D_NT", "EC3D_KEEP", "EC3D_FUSE23", "EC3D_FUSE51", "EC3D_PATCH", "EC3D_NBLK", "EC3D_NBLK_SPMV", "EC3D_VEC_DEPTH",
+         "EC3D_XCD_MAP", "EC3D_ZMARCH", "EC3D_XDEFER", "EC3D_XD_OFF_DEPTH", "EC3D_XD_ON_DEPTH", "EC3D_K4S", "EC3D_SLAB_FUSE",
+         "EC3D_SLAB_XDEFER")
+
+
+@pytest.fixture(scope="module")
+def E():
+    import eddy_currents_3d_amd as E
+    E.load_library()
+    return E
+
+
+def set_knobs(monkeypatch, **kw):
+    for k in KNOBS:
+        monkeypatch.delenv(k, raising=False)
+    for k, v in kw.items():
+        monkeypatch.setenv("EC3D_" + k, str(v))
+
+
+def slabs_of(m, kdz):
+    out = []
+    for r in range(m.nranks):
+        view, k0, k1 = m.slab(r)
+        out.append((view, k0 * kdz, k1 * kdz))
+    return out
+
+
+def restarts_of(m):
+    return [m.slab(r)[0].restart_count() for r in range(m.nranks)]
+
+
+FUSED = dict(FUSE23=2, FUSE51=2, K4S=2)
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+@pytest.mark.parametrize("xd", [1, 4])
+@pytest.mark.parametrize("nt", [0, 1])
+def test_three_launch_iteration_on_slabs_bitwise(E, oracle, monkeypatch, world, xd, nt):
+    """Plan 3 on 2, 3 and 4 slabs (uneven cuts included: 50 planes over 3 and 4 ranks), with the X update in every iteration
+    and every fourth, cacheable and nontemporal streams: converged solves with both exits available, restarts counted."""
+    sdx, sdy, sdz = 128, 8, 50
+    n, kdz = sdx * sdy * sdz, sdx * sdy
+    set_knobs(monkeypatch, XDEFER=xd, NT=nt, **FUSED)
+    valA, irow, jcol = oracle.poisson_csr(sdx, sdy, sdz)
+    rng = np.random.Generator(np.random.PCG64(500 + world))
+    b = rng.standard_normal(n)
+    x0 = rng.standard_normal(n)
+    tol = 1e-6
+    with E.EC3DMulti(world, devices=[0] * world) as m:
+        m.assemble_poisson(sdx, sdy, sdz)
+        assert m.plan() == (3, xd)
+        v0 = m.slab(0)[0]
+        assert v0.fusion() == (1, 1) and v0.k4_as_spmv() and v0.x_interval() == xd
+        x, it = m.solve(b, x0, tol, 5000)
+        rs = restarts_of(m)
+        xo, ito, _, _, rso = oracle.twin_solve_slabs(slabs_of(m, kdz), 3, valA, irow, jcol, b, x0, tol, 5000)
+        # a second solve on the same handle, warm-started from the first one's solution
+        x2, it2 = m.solve(b, x, tol, 5000)
+        xo2, ito2, _, _, _ = oracle.twin_solve_slabs(slabs_of(m, kdz), 3, valA, irow, jcol, b, xo, tol, 5000)
+    res = np.linalg.norm(b - oracle.spmv_csr(valA, irow, jcol, x)) / np.linalg.norm(b)
+    print(f"{world} slabs, three launches, X every {xd}, nt {nt}: iter {it} (twin {ito}), restarts {rs[0]} (twin {rso}), "
+          f"true residual {res:.2e}")
+    assert it == ito and np.array_equal(x, xo)
+    assert all(r == rso for r in rs)
+    assert it2 == ito2 and np.array_equal(x2, xo2)
+    assert res < 5 * tol
+
+
+@pytest.mark.parametrize("plan, dims", [(1, (128, 8, 48)), (0, (24, 24, 24))], ids=["interior+boundary", "plain"])
+@pytest.mark.parametrize("xd", [1, 3, 4])
+def test_five_launch_plans_with_deferred_x_bitwise(E, oracle, monkeypatch, plan, dims, xd):
+    """Plans 0 and 1 (what the slabs of 512^3 on 8 GPUs run: 16 Mi rows per rank) with the X update every D-th iteration:
+    P and S live in rings and the halo exchange follows them."""
+    sdx, sdy, sdz = dims
+    n, kdz = sdx * sdy * sdz, sdx * sdy
+    world = 3
+    set_knobs(monkeypatch, XDEFER=xd)
+    valA, irow, jcol = oracle.poisson_csr(sdx, sdy, sdz)
+    rng = np.random.Generator(np.random.PCG64(77))
+    b = rng.standard_normal(n)
+    x0 = rng.standard_normal(n)
+    tol = 1e-7
+    with E.EC3DMulti(world, devices=[0] * world) as m:
+        m.assemble_poisson(sdx, sdy, sdz)
+        assert m.plan() == (plan, xd)
+        x, it = m.solve(b, x0, tol, 5000)
+        rs = restarts_of(m)
+        xo, ito, _, _, rso = oracle.twin_solve_slabs(slabs_of(m, kdz), plan, valA, irow, jcol, b, x0, tol, 5000)
+    print(f"plan {plan}, X every {xd}: iter {it} (twin {ito}), restarts {rs[0]} (twin {rso})")
+    assert it == ito and np.array_equal(x, xo)
+    assert all(r == rso for r in rs)
+
+
+@pytest.mark.parametrize("fused", [True, False], ids=["three-launches", "five-launches"])
+def test_itmax_exit_at_every_position_of_a_group(E, oracle, monkeypatch, fused):
+    """src/solvers.f90:25-29 ends the loop after itmax + 1 iterations; with X applied every fourth iteration the last
+    iteration of the call applies whatever is pending.  k = 1 .. 9 iterations: every position of a group of four."""
+    sdx, sdy, sdz = 128, 8, 32
+    n, kdz = sdx * sdy * sdz, sdx * sdy
+    set_knobs(monkeypatch, XDEFER=4, **(FUSED if fused else {}))
+    valA, irow, jcol = oracle.poisson_csr(sdx, sdy, sdz)
+    rng = np.random.Generator(np.random.PCG64(9))
+    b = rng.standard_normal(n)
+    x0 = rng.standard_normal(n)
+    with E.EC3DMulti(2, devices=[0, 0]) as m:
+        m.assemble_poisson(sdx, sdy, sdz)
+        plan = m.plan()[0]
+        assert plan == (3 if fused else 1)
+        for k in range(1, 10):
+            x, it = m.solve(b, x0, 1e-30, k - 1)
+            xo, ito, _, _, _ = oracle.twin_solve_slabs(slabs_of(m, kdz), plan, valA, irow, jcol, b, x0, 1e-30, k - 1)
+            assert it == ito == k and np.array_equal(x, xo), k
+
+
+def test_s_exit_with_updates_pending(E, oracle, monkeypatch):
+    """The ||S|| exit (src/solvers.f90:34-38: X = X + alpha*P) taken in the middle of a group: a right-hand side the first
+    half step solves exactly enough -- b = A*(x0 + c*r0-direction) is hard to hit, so the tolerance is chosen between the
+    ||S|| and ||R|| values of an iteration instead: the exit must be the twin's, whichever it is, with X complete."""
+    sdx, sdy, sdz = 128, 8, 32
+    n, kdz = sdx * sdy * sdz, sdx * sdy
+    set_knobs(monkeypatch, XDEFER=4, **FUSED)
+    valA, irow, jcol = oracle.poisson_csr(sdx, sdy, sdz)
+    rng = np.random.Generator(np.random.PCG64(10))
+    b = rng.standard_normal(n)
+    x0 = np.zeros(n)
+    with E.EC3DMulti(2, devices=[0, 0]) as m:
+        m.assemble_poisson(sdx, sdy, sdz)
+        _, _, hs, hr, _ = oracle.twin_solve_slabs(slabs_of(m, kdz), 3, valA, irow, jcol, b, x0, 1e-30, 13, hist_cap=14)
+        bn = np.linalg.norm(b)
+        seen = set()
+        for k in range(2, 13):
+            # between ||S_k|| and ||R_{k-1}||: iteration k leaves by its ||S|| test when S is the smaller one
+            lo, hi = sorted((hs[k - 1], hr[k - 2]))
+            tol = 0.5 * (lo + hi) / bn
+            x, it = m.solve(b, x0, tol, 100)
+            xo, ito, _, _, _ = oracle.twin_solve_slabs(slabs_of(m, kdz), 3, valA, irow, jcol, b, x0, tol, 100)
+            assert it == ito and np.array_equal(x, xo), k
+            seen.add((it - 1) % 4)
+    assert len(seen) >= 3       # exits at several positions of a group of four
+
+
+def test_iterate_twice_from_the_same_number(E, oracle, monkeypatch):
+    """ec3d_multi_iterate (bench.py's timed region) may be called with any first iteration: the rings of P are addressed
+    relative to the current P.  iterate(1, 5) twice == iterate(1, 5) followed by iterate(6, 5)."""
+    sdx, sdy, sdz = 128, 8, 32
+    n = sdx * sdy * sdz
+    set_knobs(monkeypatch, XDEFER=4, **FUSED)
+    rng = np.random.Generator(np.random.PCG64(11))
+    b = rng.standard_normal(n)
+    out = []
+    for second in (1, 6):
+        with E.EC3DMulti(2, devices=[0, 0]) as m:
+            m.assemble_poisson(sdx, sdy, sdz)
+            m.upload("B", b)
+            m.upload("X", np.zeros(n))
+            m.iterate_begin()
+            m.iterate(1, 5)
+            m.iterate(second, 5)
+            m.synchronize()
+            out.append(m.download("X"))
+    assert np.array_equal(out[0], out[1])
