@@ -266,6 +266,9 @@ def main():
     ap.add_argument("--refine", type=int, default=3)
     ap.add_argument("--force-dist", action="store_true",
                     help="use the z-slab/torch.distributed path even with one rank (rehearsal on one GPU)")
+    ap.add_argument("--rehearse", type=str, default=None, metavar="R,G",
+                    help="with --force-dist on ONE GPU: run rank R of a G-rank job alone (its slab, plan, launches and RCCL "
+                         "calls, neighbours mapped to itself): what one rank's iteration costs, host enqueue included")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-spmv-dia", action="store_true", help="skip the plain-DIA SpMV figure after the timed region")
     ap.add_argument("--no-side-workloads", action="store_true",
@@ -278,6 +281,8 @@ def main():
                     help="in-library multi-GPU path: comma-separated device ordinals, one per slab; a device may "
                          "repeat (rehearsal of N slabs on one card, e.g. --gpus 2 --devices 0,0)")
     args = ap.parse_args()
+    if args.rehearse:
+        args.force_dist = True
 
     # This script's stdout carries exactly one JSON line.  Native libraries write there too (RCCL prints its
     # version banner when the box exports NCCL_DEBUG=VERSION; the reference solver prints ||R|| on the itmax
@@ -390,8 +395,17 @@ def main():
         geom = {"vector": int(slab0.geometry(0).nblk), "spmv": int(slab0.geometry(1).nblk)}
         info = slab0.info
         world = G
+        multi_plan, multi_xd = s.plan()
+        fusion_state = slab0.fusion()
+        x_every = multi_xd
+        k4_spmv = bool(slab0.k4_as_spmv())
         parallelism = (f"z-slab x{G} inside the library (one process, one host thread per slab, halo planes pulled "
-                       f"over peer access, partial sums read in place), devices {devices or list(range(G))}")
+                       f"over peer access, partial sums read in place), devices {devices or list(range(G))}; "
+                       + {0: "five launches per iteration, P and S exchanged in front of K1 / K3",
+                          1: "five launches per iteration, K1 / K3 as interior + boundary launch around the exchange of P / S",
+                          2: "five launches per iteration, K2 / K5 boundary tiles first",
+                          3: "three launches per iteration (K2 inside K3, K4 as an SpMV kernel, K5 inside the next K1), "
+                             "AP and R exchanged"}[multi_plan])
     elif not use_dist:
         s = E.EC3DSolver(device=local_rank, dictionary=args.format == "dict")
         if args.workload == "av":
@@ -427,29 +441,33 @@ def main():
         k4_spmv = bool(s.k4_as_spmv()) if hasattr(s, "k4_as_spmv") else False
         parallelism = "single GPU"
     else:
-        from eddy_currents_3d_amd.dist import SlabSolver
-        s = SlabSolver.poisson_cube(N, rank, world, device=local_rank, dictionary=args.format == "dict")
-        s.set_rhs(bar_rhs(N, s.k0, s.k1), np.zeros(s.n_local))
-        s.iterate_begin()
+        # one process per GPU: this rank's slab, the whole iteration loop enqueued from C++, RCCL between the ranks
+        # (halo planes as ncclSend / ncclRecv on a side stream, the sums by ncclAllGather; csrc/ec3d_multi.hip)
+        from eddy_currents_3d_amd.dist import rccl_rank
+        rehearse = None
+        if args.rehearse:
+            rehearse = tuple(int(t) for t in args.rehearse.split(","))
+            if world != 1:
+                raise SystemExit("bench.py --rehearse R,G runs as ONE process (one rank of a G-rank job on one GPU)")
+        s = rccl_rank(rank, world, local_rank, dictionary=args.format == "dict", rehearse=rehearse)
+        s.assemble_poisson(N, N, N)
+        s.upload("B", bar_rhs(N))
+        view, k0, k1 = s.slab(0)
         verified = None
-        if not args.no_verify:
+        if not args.no_verify and not rehearse:
             # Before anything is timed: this rank's part of A*x, with the halo planes coming from the z-neighbours
             # over RCCL, against the undivided operator on this rank's own GPU, bit for bit; and ||b|| as every rank
             # derives it from the all-gathered sums against the value computed on the host.
-            from eddy_currents_3d_amd.dist import K1
             xs = np.sin(0.37 * np.arange(n_global, dtype=np.float64))
             kd = N * N
-            with s.ops.context():
-                s.ops.set_vector("P", xs[s.k0 * kd:s.k1 * kd])
-                s.exchange("P")
-                s.ops.step(K1, 1, 0.0)                       # AP = A P on the slab (src/solvers.f90:30)
-            ap = s.ops.get_vector("AP")
+            ap = s.spmv(xs)[k0 * kd:k1 * kd]
+            s.upload("X", xs)
+            res_multi = s.true_residual()
             with E.EC3DSolver(device=local_rank, dictionary=args.format == "dict") as one:
                 one.assemble_poisson(N, N, N)
-                y_one = one.spmv(xs)[s.k0 * kd:s.k1 * kd]
+                y_one = one.spmv(xs)[k0 * kd:k1 * kd]
             bad = int(np.count_nonzero(ap != y_one))
-            bn = s.local.read_state()[2]
-            bn_host = float(np.linalg.norm(bar_rhs(N)))
+            bn, bn_host = res_multi[1], float(np.linalg.norm(bar_rhs(N)))
             flag = torch.tensor([bad, int(abs(bn - bn_host) > 1e-12 * bn_host)], dtype=torch.int64, device="cuda")
             dist.all_reduce(flag)
             if int(flag[0]) or int(flag[1]):
@@ -459,14 +477,17 @@ def main():
             verified = (f"A*x over {world} ranks (halo planes over RCCL) == one GPU bit for bit on every slab; ||b|| from "
                         f"the all-gathered sums equal to {abs(bn - bn_host) / bn_host:.1e}")
             del xs, ap, y_one
-            s.set_rhs(bar_rhs(N, s.k0, s.k1), np.zeros(s.n_local))
-            s.iterate_begin()
+        s.upload("X", np.zeros(n_global))
+        s.iterate_begin()
         s.iterate(1, W)
+        s.synchronize()
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         s.iterate(W + 1, K)
+        t_enq = time.perf_counter() - t0
+        s.synchronize()
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
@@ -474,16 +495,30 @@ def main():
         el = torch.tensor([t1 - t0], dtype=torch.float64, device="cuda")
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el.item())
+        api_calls = s.api_calls(0)          # of the timed call (the instrumented pass below adds its events)
         kernel_ms = s.iterate(W + K + 1, min(K, 20), per_kernel=True)
         spmv_ms = None
-        geom = {"vector": int(s.local.geometry(0).nblk), "spmv": int(s.local.geometry(1).nblk)}
-        info = s.local.info
-        parallelism = f"z-slab x{world} (halo send/recv + all_gather of dot products, RCCL)"
+        geom = {"vector": int(view.geometry(0).nblk), "spmv": int(view.geometry(1).nblk)}
+        info = view.info
+        multi_plan, multi_xd = s.plan()
+        fusion_state = view.fusion()
+        x_every = multi_xd
+        k4_spmv = bool(view.k4_as_spmv())
+        host_enqueue_ms = t_enq * 1e3 / K
+        if rehearse:
+            # one rank of a G-rank job alone on this GPU: its rows x K iterations (NOT the job's throughput)
+            n_global = int(info.n)
+            workload += (f"; REHEARSAL of rank {rehearse[0]} of {rehearse[1]} on one GPU: its slab ({k1 - k0} planes), plan, "
+                         f"launches and RCCL calls, neighbours mapped to itself -- a timing of one rank's iteration, not a "
+                         f"solve")
+        parallelism = (f"z-slab x{rehearse[1] if rehearse else world}, one process per GPU, iteration loop in C++, RCCL: halo "
+                       f"planes as ncclSend/ncclRecv on a side stream, the sums by ncclAllGather; "
+                       + {0: "five launches per iteration", 1: "five launches per iteration, K1 / K3 split around the exchange",
+                          2: "five launches per iteration, K2 / K5 boundary tiles first",
+                          3: "three launches per iteration, AP and R exchanged"}[multi_plan])
 
-    if use_dist or in_library:
-        x_every, k4_spmv = 1, False
 
-    class _Fusion:       # the headline handle's launches per iteration (multi-rank slabs always run five)
+    class _Fusion:       # the headline handle's launches per iteration
         def __init__(self, st, d, k4s):
             self.st, self.d, self.k4s = st, d, k4s
 
@@ -495,7 +530,7 @@ def main():
 
         def k4_as_spmv(self):
             return self.k4s
-    fusion_of = _Fusion(fusion_state if (not use_dist and not in_library) else (0, 0), x_every, k4_spmv)
+    fusion_of = _Fusion(fusion_state, x_every, k4_spmv)
 
     # The north-star SpMV figure in the driver-run line: the plain 7-band DIA SpMV (56 B of coefficients + x + y =
     # 72 B/row) at the same grid, timed after the headline region on a handle of its own (the
@@ -573,6 +608,10 @@ def main():
             out["config"]["k4_as_spmv"] = True
         if (in_library or use_dist) and verified:
             out["verified"] = verified
+        if use_dist:
+            out["host"] = {"enqueue_ms_per_iteration": host_enqueue_ms, "api_calls_per_iteration": api_calls,
+                           "note": "rank 0's host thread: time for ec3d_multi_iterate to ENQUEUE the timed iterations (launches, "
+                                   "event records / waits, RCCL calls), which has to stay below ms_per_step"}
         if spmv_ms is not None:
             out["spmv"] = {"kernel": "k_spmv (y = A*x, 7 bands)", "ms": spmv_ms,
                            "survey_bytes_per_row": 72, "survey_GBps": 72 * rows / spmv_ms / 1e6,
@@ -593,7 +632,7 @@ def main():
     if in_library:
         s.close()
     elif use_dist:
-        s.ops.close()          # detach the library from the torch-owned stream and vectors before torch goes away
+        s.close()              # the communicators go first
         dist.barrier()
         dist.destroy_process_group()
     else:

@@ -132,6 +132,7 @@ extern "C" int ec3d_dist_step(ec3d_handle c, int32_t stage, int32_t it, double t
         c->pcur = c->apcur = c->scur = 1; // (as ec3d_launch_begin: P = R goes to vec[P] = pbuf[1])
         c->ap_valid_for = 0;
         c->p_off = 0;
+        c->it_next = 1;
         c->xd_base = 1;
         c->xd_last = INT_MAX;
         ec3d_launch_residual(A, c->sweep_s, v[EC3D_VEC_X], v[EC3D_VEC_B], v[EC3D_VEC_R], v[EC3D_VEC_R0],
@@ -207,6 +208,7 @@ extern "C" int ec3d_dist_step(ec3d_handle c, int32_t stage, int32_t it, double t
                        v[EC3D_VEC_R], v[EC3D_VEC_AP], ec3d_vec_at(c, EC3D_VEC_P, it), ec3d_vec_at(c, EC3D_VEC_P, it + 1),
                        v[EC3D_VEC_R0], c->hist, c->hist_cap, c->stream);
         if (ec3d_xdefer(c) > 1) c->pcur = ((it + 1 + c->p_off) % c->pdepth + c->pdepth) % c->pdepth;
+        c->it_next = it + 1;
         break;
     default: ec3d_set_error("ec3d_dist_step: unknown stage"); return 2;
     }

@@ -281,9 +281,11 @@ struct ec3d_ctx {
     // Sweep::halo_store); the X update deferred over slab_xd iterations (0: not on this slab)
     bool slab_fused = false;
     int slab_xd = 0;
-    // P(it) lives in pbuf[(it + p_off) % pdepth]: 0 within a solve; ec3d_iterate / ec3d_multi_iterate set it so that the
-    // call's first iteration finds the CURRENT P whatever iteration number it is given (pcur)
+    // P(it) lives in pbuf[(it + p_off) % pdepth] (0: iterations are numbered from the last ec3d_launch_begin)
     int p_off = 0;
+    // The iteration the next launch has to be: the device state is addressed by the iteration number (rr0[it & 1], AP in
+    // apbuf[it & 1], P and S in their rings), so ec3d_iterate / ec3d_multi_iterate must continue where the last call ended
+    int it_next = 1;
     // K5-in-K1 reads the previous iteration's P and AP while it writes the new ones (neighbouring workgroups read the
     // old values of cells this one owns), so both vectors alternate between two buffers: P(it) lives in
     // pbuf[it & 1], AP(it) in apbuf[it & 1]; index 1 is vec[EC3D_VEC_P] / vec[EC3D_VEC_AP], index 0 the spare pair

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <string>
 
 // ---------------------------------------------------------------------------------------------
 // measurement
@@ -76,11 +77,16 @@ extern "C" int ec3d_iterate(ec3d_handle c, int32_t first_iter, int32_t count, do
     const MatView A = c->A.view();
     // deferred X update: groups counted from this call's first iteration, its last one applies what is pending --
     // every call leaves X complete
+    // The device state is addressed by the iteration number -- rr0[it & 1], AP in apbuf[it & 1], P and S in their rings --
+    // so a call has to continue where the last one ended (ec3d_iterate_begin starts again from 1): iterate(1, n) twice
+    // would read an older P and the other rr0.
+    if (first_iter != c->it_next) {
+        ec3d_set_error("ec3d_iterate: first_iter = " + std::to_string(first_iter) + " does not continue the iterations of this "
+                       "handle (next: " + std::to_string(c->it_next) + "; ec3d_iterate_begin starts again from 1)");
+        return 6;
+    }
     c->xd_base = first_iter;
     c->xd_last = first_iter + count - 1;
-    // ... and finds the CURRENT P (the buffer the last launch wrote) under whatever iteration number it is given: a call
-    // that does not continue the previous one's numbering (iterate(1, n) twice) would otherwise read an older ring entry
-    c->p_off = ((c->pcur - first_iter) % c->pdepth + c->pdepth) % c->pdepth;
     if (!kernel_ms) {
         for (int it = first_iter; it < first_iter + count; ++it) ec3d_launch_iteration(c, A, it);
         EC3D_HIP(hipGetLastError());

@@ -20,8 +20,16 @@
 //     same plan, and always posts before it waits, so there is no cycle).
 // Several slabs may share one device (tests and rehearsals on a one-GPU box): same code, the peer copies
 // become local ones.
+//
+// ONE PROCESS PER GPU (ec3d_multi_create_rank; what torch.distributed.run launches): the same handle, plans and stages with
+// ONE local slab -- this process's rank of `world` -- and RCCL as the transport: the halo planes travel as ncclSend /
+// ncclRecv pairs in one group on the side stream (communicator of its own, so the transfer runs beside the interior
+// launch), the eight sums of every rank are all-gathered (64 B per rank) on the compute stream and added in rank order by
+// the consumer kernels, exactly like the gathered copy of eddy_currents_3d_amd/dist.py.  The whole iteration loop is
+// enqueued from C++: no Python between two launches.
 #include "../../include/ec3d_hip.h"
 #include "ec3d_internal.hpp"
+#include "ec3d_rccl.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -51,6 +59,9 @@ struct Run {
 };
 struct Copy {
     int64_t dst, src, cnt;
+};
+struct Piece {
+    int64_t off, cnt;
 };
 
 enum { OP_HALO = 0, OP_HALO_START, OP_HALO_WAIT, OP_GATHER, OP_STEP, OP_SKIP_IF_AP };
@@ -98,6 +109,7 @@ struct Slab {
     std::atomic<uint64_t> posted[NCH];
     std::vector<Run> send_lo, recv_lo, send_hi, recv_hi; // towards rank-1 / rank+1, same order on both sides
     std::vector<Copy> pull_lo, pull_hi;                  // my ghost rows <- neighbour's rows
+    std::vector<Piece> snd_lo, rcv_lo, snd_hi, rcv_hi;   // RCCL: contiguous pieces of my rows to send / my ghost rows to fill
     bool split_ok = false;
     int plan = 0; // 0 plain, 1 overlap (K1/K3 interior + boundary), 2 vsplit (K2/K5 boundary first), 3 three launches (kIterFused)
     int32_t *stop_pinned = nullptr;
@@ -128,7 +140,19 @@ struct Pool {
 } // namespace
 
 struct ec3d_multi {
-    int n = 0;
+    int n = 0;     // LOCAL slabs = host threads of this process (all of them, or one: this process's rank)
+    int world = 0; // ranks of the job (== n unless one process per GPU)
+    // one process per GPU: RCCL transport (ec3d_multi_create_rank)
+    const ec3d_rccl_api *nccl = nullptr;
+    ncclComm_t comm_halo = nullptr, comm_sum = nullptr;
+    int comm_rank = 0, comm_world = 1; // this process in the communicators
+    // Rehearsal of ONE rank of a larger job on one GPU (ec3d_multi_create_rank with as_world > nranks = 1): the slab, plan,
+    // launches and RCCL calls of rank `as_rank` of `as_world` -- world and Slab::rank then describe THAT geometry -- with
+    // every neighbour mapped to this process itself (send / recv to self) and the sums gathered over the one real rank.
+    // Timing and call counts are those of the real rank; the numbers computed are not a solution of anything.
+    bool rehearse = false;
+    double *gsum = nullptr;    // [world * P_NSLOT] the all-gathered sums
+    double *agbuf = nullptr;   // [(world + 1) * 8] set-up exchanges between the ranks
     std::vector<std::unique_ptr<Slab>> slab;
     Pool pool;
     std::atomic<bool> abort{false};
@@ -151,6 +175,16 @@ thread_local uint64_t t_api_calls = 0;
         if (e_ != hipSuccess) {                                                                \
             ec3d_set_error(std::string(#call) + ": " + hipGetErrorString(e_));                 \
             return 100;                                                                        \
+        }                                                                                      \
+    } while (0)
+
+#define MNCCL(m_, call)                                                                        \
+    do {                                                                                       \
+        ++t_api_calls;                                                                         \
+        ncclResult_t e_ = (call);                                                              \
+        if (e_ != ncclSuccess) {                                                               \
+            ec3d_set_error(std::string(#call) + ": " + (m_)->nccl->GetErrorString(e_));        \
+            return 108;                                                                        \
         }                                                                                      \
     } while (0)
 
@@ -296,8 +330,10 @@ int cross_wait(hipStream_t stream, hipEvent_t ev)
 // (every rank of a job runs the same plan with the same depths, and my state is current when I get here), the pointer
 // taken from the owner's tables, which do not change while a job runs: another rank's thread may be iterations ahead or
 // behind with its own host-side bookkeeping.
+constexpr int kPlainVec = INT_MIN; // `it` of a caller that means the plain work vector (uploads, probes, the time loop's X)
 double *vec_of(const ec3d_ctx *me, const ec3d_ctx *owner, int vec, int it)
 {
+    if (it == kPlainVec) return owner->vec[vec];
     const bool f51 = ec3d_fused51(me);
     const int D = ec3d_xdefer(me), pd = me->pdepth;
     switch (vec) {
@@ -308,7 +344,7 @@ double *vec_of(const ec3d_ctx *me, const ec3d_ctx *owner, int vec, int it)
     }
 }
 
-int halo_start(ec3d_multi *m, Slab &s, int v, int it = 0)
+int halo_start(ec3d_multi *m, Slab &s, int v, int it = kPlainVec)
 {
     const uint64_t q = ++s.seq[v];
     const int i = (int)(q % RING), vi = kVecOf[v];
@@ -319,6 +355,31 @@ int halo_start(ec3d_multi *m, Slab &s, int v, int it = 0)
     s.posted[v].store(q, std::memory_order_release);
     // my own earlier readers of the ghost rows are behind this point of my compute stream
     MHIP(hipStreamWaitEvent(s.side, s.ev_ready[v][i], 0));
+    if (m->nccl) {
+        // one process per GPU: my boundary rows go out and my ghost rows come in as send / recv pairs of ONE group on the
+        // side stream (the neighbour's matching pair is in its group; lower neighbour first on every rank)
+        // (the k-th send to a neighbour meets its k-th receive from me: both sides list the blocks in the same order)
+        double *mine = vec_of(s.c, s.c, vi, it);
+        const bool lo = s.rank > 0 && !(s.snd_lo.empty() && s.rcv_lo.empty());
+        const bool hi = s.rank + 1 < m->world && !(s.snd_hi.empty() && s.rcv_hi.empty());
+        if (lo || hi) {
+            s.at.store("halo_start:rccl group");
+            MNCCL(m, m->nccl->GroupStart());
+            if (lo) {
+                const int pr = m->rehearse ? m->comm_rank : s.rank - 1;
+                for (const Piece &c : s.snd_lo) MNCCL(m, m->nccl->Send(mine + c.off, (size_t)c.cnt, ncclDouble, pr, m->comm_halo, s.side));
+                for (const Piece &c : s.rcv_lo) MNCCL(m, m->nccl->Recv(mine + c.off, (size_t)c.cnt, ncclDouble, pr, m->comm_halo, s.side));
+            }
+            if (hi) {
+                const int pr = m->rehearse ? m->comm_rank : s.rank + 1;
+                for (const Piece &c : s.snd_hi) MNCCL(m, m->nccl->Send(mine + c.off, (size_t)c.cnt, ncclDouble, pr, m->comm_halo, s.side));
+                for (const Piece &c : s.rcv_hi) MNCCL(m, m->nccl->Recv(mine + c.off, (size_t)c.cnt, ncclDouble, pr, m->comm_halo, s.side));
+            }
+            MNCCL(m, m->nccl->GroupEnd());
+        }
+        MHIP(hipEventRecord(s.ev_halo[v][i], s.side));
+        return 0;
+    }
     for (int dir = -1; dir <= 1; dir += 2) {
         const std::vector<Copy> &cp = dir < 0 ? s.pull_lo : s.pull_hi;
         const int pr = s.rank + dir;
@@ -365,6 +426,13 @@ int gather(ec3d_multi *m, Slab &s)
     const int i = (int)(q % RING);
     s.at.store("gather:record");
     s.at_seq.store(q);
+    if (m->nccl) {
+        // one process per GPU: every rank's eight sums to every rank (64 B each), on the compute stream, where the
+        // producer's collapse launch wrote them and the consumer kernel reads the gathered copy
+        s.at.store("gather:rccl all_gather");
+        MNCCL(m, m->nccl->AllGather(s.lsum, m->gsum, P_NSLOT, ncclDouble, m->comm_sum, s.c->stream));
+        return 0;
+    }
     if (m->n == 1) return 0;
     static const bool flat = getenv("EC3D_MULTI_FLAT_HUB") && atoi(getenv("EC3D_MULTI_FLAT_HUB")) != 0;
     Slab &hub = *m->slab[0];
@@ -588,17 +656,77 @@ int finish_setup(ec3d_multi *m)
         return 0;
     };
     int rc = 0;
-    for (int g = 0; g < m->n; ++g) {
-        Slab &s = *m->slab[(size_t)g];
-        if (g + 1 < m->n && (rc = pair_up(s.recv_hi, m->slab[(size_t)g + 1]->send_lo, s.pull_hi))) return rc;
-        if (g > 0 && (rc = pair_up(s.recv_lo, m->slab[(size_t)g - 1]->send_hi, s.pull_lo))) return rc;
+    // one process per GPU: contiguous pieces of my own runs (the neighbour's matching lists come out of the same rules on
+    // the same grid and storage format, which the ranks compare below)
+    auto pieces_of = [](const std::vector<Run> &runs, std::vector<Piece> &out) {
+        out.clear();
+        for (const Run &r : runs) {
+            if (r.payload == 0) continue;
+            out.push_back(Piece{r.start, r.planes == 1 ? r.payload : (int64_t)r.planes * r.pitch});
+        }
+    };
+    if (m->nccl) {
+        Slab &s = *m->slab[0];
+        pieces_of(s.send_lo, s.snd_lo);
+        pieces_of(s.recv_lo, s.rcv_lo);
+        pieces_of(s.send_hi, s.snd_hi);
+        pieces_of(s.recv_hi, s.rcv_hi);
+    } else {
+        for (int g = 0; g < m->n; ++g) {
+            Slab &s = *m->slab[(size_t)g];
+            if (g + 1 < m->n && (rc = pair_up(s.recv_hi, m->slab[(size_t)g + 1]->send_lo, s.pull_hi))) return rc;
+            if (g > 0 && (rc = pair_up(s.recv_lo, m->slab[(size_t)g - 1]->send_hi, s.pull_lo))) return rc;
+        }
     }
     std::vector<const double *> tab((size_t)m->n);
     for (int g = 0; g < m->n; ++g) tab[(size_t)g] = m->slab[(size_t)g]->lsum;
+    // What every rank has to know of every other: can it run the three-launch iteration, the depth of its rings, its
+    // storage format, its size, what it sends to its neighbours.  One process: read off the slabs; one process per GPU:
+    // eight doubles per rank, all-gathered once.
+    struct RankFacts { double fused_ok, xd, sav, n_pad, snd_lo, rcv_lo, snd_hi, rcv_hi; };
+    static_assert(sizeof(RankFacts) == 8 * sizeof(double), "eight doubles");
+    std::vector<RankFacts> facts((size_t)(m->nccl ? m->comm_world : m->n));
+    auto facts_of = [&](const Slab &sl) {
+        const ec3d_ctx *c = sl.c;
+        auto total = [](const std::vector<Run> &rs) { double t = 0; for (const Run &r : rs) t += (double)r.payload * r.planes; return t; };
+        RankFacts f{};
+        f.fused_ok = (c->fuse23_ok && c->fuse51_ok && c->k4s_ok && c->pp_base && c->own_vectors) ? 1.0 : 0.0;
+        f.xd = (c->pp_base && c->own_vectors) ? (double)c->xdefer : 1.0;
+        f.sav = c->A.sav ? 1.0 : 0.0;
+        f.n_pad = (double)c->A.n_pad;
+        f.snd_lo = total(sl.send_lo); f.rcv_lo = total(sl.recv_lo); f.snd_hi = total(sl.send_hi); f.rcv_hi = total(sl.recv_hi);
+        return f;
+    };
+    if (m->nccl) {
+        const RankFacts mine = facts_of(*m->slab[0]);
+        rc = run_all(m, [&](int) -> int {
+            Slab &s = *m->slab[0];
+            double *snd = m->agbuf + (size_t)m->comm_world * 8;
+            MHIP(hipMemcpyAsync(snd, &mine, sizeof mine, hipMemcpyHostToDevice, s.c->stream));
+            MNCCL(m, m->nccl->AllGather(snd, m->agbuf, 8, ncclDouble, m->comm_sum, s.c->stream));
+            MHIP(hipMemcpyAsync(facts.data(), m->agbuf, facts.size() * sizeof(RankFacts), hipMemcpyDeviceToHost, s.c->stream));
+            MHIP(hipStreamSynchronize(s.c->stream));
+            return 0;
+        }, true);
+        if (rc) return rc;
+    } else {
+        for (int g = 0; g < m->n; ++g) facts[(size_t)g] = facts_of(*m->slab[(size_t)g]);
+    }
+    for (size_t g = 0; g + 1 < facts.size(); ++g) {
+        if (facts[(size_t)g].sav != facts[(size_t)g + 1].sav) {
+            ec3d_set_error("ec3d_multi: slabs chose different storage formats; call ec3d_multi_set_format(h, -1, 0) to use "
+                           "bands + tail everywhere");
+            return 105;
+        }
+        if (facts[(size_t)g].snd_hi != facts[(size_t)g + 1].rcv_lo || facts[(size_t)g].rcv_hi != facts[(size_t)g + 1].snd_lo) {
+            ec3d_set_error("ec3d_multi: neighbouring slabs disagree on the halo size");
+            return 105;
+        }
+    }
     {   // about 0.4 ms of device work between two looks at the stop flag (as ec3d_solve.hip does)
-        int64_t big = 0;
-        for (auto &s : m->slab) big = std::max<int64_t>(big, s->c->A.n_pad);
-        const double est_us = (double)big * 264.0 / 4.0e6 + 12.0 + 20.0 * (m->n > 1);
+        double big = 0;
+        for (const RankFacts &f : facts) big = std::max(big, f.n_pad);
+        const double est_us = big * 264.0 / 4.0e6 + 12.0 + 20.0 * (m->world > 1);
         m->chunk = (int)std::min<double>(32.0, std::max<double>(1.0, 400.0 / est_us));
     }
     // What the whole job can do (the plan is a property of the job: the exchanges of the three-launch iteration differ
@@ -608,34 +736,33 @@ int finish_setup(ec3d_multi *m)
     //          force it on small grids).  EC3D_SLAB_FUSE=0 keeps five launches.
     //   xd:    the smallest depth any slab allocated rings for (ec3d_spare_pair: 4 from 4.5 Mi streamed rows).
     //          EC3D_SLAB_XDEFER=1 switches it off, 2 .. 4 caps it.
-    bool fused = m->kind == 1 && m->n > 1;
+    bool fused = m->kind == 1 && m->world > 1;
     int xd = EC3D_XD_MAX;
-    for (auto &sp : m->slab) {
-        const ec3d_ctx *c = sp->c;
-        fused = fused && c->fuse23_ok && c->fuse51_ok && c->k4s_ok && c->pp_base && c->own_vectors;
-        xd = std::min(xd, (c->pp_base && c->own_vectors) ? c->xdefer : 1);
+    for (const RankFacts &f : facts) {
+        fused = fused && f.fused_ok != 0.0;
+        xd = std::min(xd, (int)f.xd);
     }
     if (const char *e = getenv("EC3D_SLAB_FUSE")) fused = fused && atoi(e) != 0;
     if (const char *e = getenv("EC3D_SLAB_XDEFER")) xd = std::min(xd, std::max(1, atoi(e)));
-    if (m->n == 1) xd = 0; // (a one-slab job is an ordinary handle: its own rule applies)
+    if (m->world == 1) xd = 0; // (a one-slab job is an ordinary handle: its own rule applies)
     return run_all(m, [&](int r) -> int {
         Slab &s = *m->slab[(size_t)r];
         MHIP(hipMemcpy(s.ptr_table, tab.data(), tab.size() * sizeof(double *), hipMemcpyHostToDevice));
         ec3d_ctx *c = s.c;
         c->dist = true;
-        c->nranks = m->n;
+        c->nranks = m->nccl ? m->comm_world : m->world;
         c->lsum = s.lsum;
-        c->gsum = nullptr;
-        c->lsum_ptrs = s.ptr_table;
+        c->gsum = m->nccl ? m->gsum : nullptr;          // one process per GPU: the all-gathered copy
+        c->lsum_ptrs = m->nccl ? nullptr : s.ptr_table; // one process: every rank's sums read in place
         c->slab_fused = fused;
         c->slab_xd = xd;
-        c->sweep_s.halo_store = fused ? ((r > 0 ? 1 : 0) | (r + 1 < m->n ? 2 : 0)) : 0;
+        c->sweep_s.halo_store = fused ? ((s.rank > 0 ? 1 : 0) | (s.rank + 1 < m->world ? 2 : 0)) : 0;
         if (c->pp_base) c->pdepth = std::max(2, ec3d_xdefer(c)); // every rank cycles P through the same number of buffers
         s.plan = 0;
         s.split_ok = false;
         if (m->kind == 1) {
             s.plan = fused ? 3 : ec3d_can_overlap(c) ? 1 : 0;
-        } else if (m->n > 1) {
+        } else if (m->world > 1) {
             // the ORDER of exchanges is a property of the job: every A-V rank uses the producer-side
             // plan; a rank whose slab is all boundary runs the whole kernels in that order
             s.plan = 2;
@@ -850,6 +977,7 @@ extern "C" int ec3d_multi_create(ec3d_multi_handle *mh, int32_t nranks, const in
         }
     ec3d_multi *m = new ec3d_multi();
     m->n = nranks;
+    m->world = nranks;
     for (int r = 0; r < nranks; ++r) {
         m->slab.emplace_back(new Slab());
         m->slab.back()->rank = r;
@@ -859,6 +987,87 @@ extern "C" int ec3d_multi_create(ec3d_multi_handle *mh, int32_t nranks, const in
     for (int r = 0; r < nranks; ++r) m->pool.th.emplace_back(worker, m, r);
     int rc = run_all(m, [&](int r) { return enable_peers(m, *m->slab[(size_t)r]); }); // all of them, then allocate
     if (!rc) rc = run_all(m, [&](int r) { return slab_reset(m, *m->slab[(size_t)r]); });
+    if (rc) {
+        std::string keep = ec3d_last_error();
+        ec3d_multi_destroy(m);
+        ec3d_set_error(keep);
+        return rc;
+    }
+    *mh = m;
+    return 0;
+}
+
+// ---- one process per GPU ------------------------------------------------------------------------------------
+extern "C" int ec3d_rccl_unique_id(void *id128)
+{
+    std::string why;
+    const ec3d_rccl_api *api = ec3d_rccl_load(why);
+    if (!api || !id128) {
+        ec3d_set_error("ec3d_rccl_unique_id: " + (api ? std::string("no buffer") : why));
+        return api ? 2 : 109;
+    }
+    static_assert(sizeof(ncclUniqueId) == 128, "the C ABI hands the id around as 128 bytes");
+    ncclUniqueId id;
+    ncclResult_t e = api->GetUniqueId(&id);
+    if (e != ncclSuccess) {
+        ec3d_set_error(std::string("ncclGetUniqueId: ") + api->GetErrorString(e));
+        return 108;
+    }
+    memcpy(id128, &id, sizeof id);
+    return 0;
+}
+
+extern "C" int ec3d_multi_create_rank(ec3d_multi_handle *mh, int32_t rank, int32_t nranks, int32_t device,
+                                      const void *id_halo, const void *id_sum, int32_t as_rank, int32_t as_world)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        ec3d_set_error("ec3d_multi_create_rank: no HIP device available (this library has no CPU path)");
+        return 101;
+    }
+    if (nranks < 1 || rank < 0 || rank >= nranks || device < 0 || device >= ndev || !id_halo || !id_sum) {
+        ec3d_set_error("ec3d_multi_create_rank: need 0 <= rank < nranks, a device of this machine and two unique ids");
+        return 2;
+    }
+    const bool rehearse = as_world > 0;
+    if (rehearse && (nranks != 1 || as_rank < 0 || as_rank >= as_world)) {
+        ec3d_set_error("ec3d_multi_create_rank: a rehearsal (as_world > 0) runs in a one-rank job, 0 <= as_rank < as_world");
+        return 2;
+    }
+    std::string why;
+    const ec3d_rccl_api *api = ec3d_rccl_load(why);
+    if (!api) {
+        ec3d_set_error("ec3d_multi_create_rank: " + why);
+        return 109;
+    }
+    ec3d_multi *m = new ec3d_multi();
+    m->n = 1;
+    m->nccl = api;
+    m->comm_rank = rank;
+    m->comm_world = nranks;
+    m->rehearse = rehearse;
+    m->world = rehearse ? as_world : nranks;
+    m->slab.emplace_back(new Slab());
+    m->slab.back()->rank = rehearse ? as_rank : rank;
+    m->slab.back()->device = device;
+    m->pool.rc.assign(1, 0);
+    m->pool.th.emplace_back(worker, m, 0);
+    ncclUniqueId ih, is;
+    memcpy(&ih, id_halo, sizeof ih);
+    memcpy(&is, id_sum, sizeof is);
+    int rc = run_all(m, [&](int) -> int {
+        Slab &s = *m->slab[0];
+        int rc2 = slab_reset(m, s);
+        if (rc2) return rc2;
+        // two communicators: the halo planes travel on the side stream while the compute stream -- which carries the
+        // all-gathers of the sums -- runs the interior launch; every rank issues the calls of each in the same order
+        MNCCL(m, api->CommInitRank(&m->comm_halo, nranks, ih, rank));
+        MNCCL(m, api->CommInitRank(&m->comm_sum, nranks, is, rank));
+        MHIP(hipMalloc(&m->gsum, (size_t)nranks * P_NSLOT * sizeof(double)));
+        MHIP(hipMemset(m->gsum, 0, (size_t)nranks * P_NSLOT * sizeof(double)));
+        MHIP(hipMalloc(&m->agbuf, (size_t)(nranks + 1) * 8 * sizeof(double)));
+        return 0;
+    });
     if (rc) {
         std::string keep = ec3d_last_error();
         ec3d_multi_destroy(m);
@@ -893,6 +1102,12 @@ extern "C" int ec3d_multi_destroy(ec3d_multi_handle m)
         if (s.stop_pinned) (void)hipHostFree(s.stop_pinned);
         if (s.lsum) (void)hipFree(s.lsum);
         if (s.ptr_table) (void)hipFree(s.ptr_table);
+        if (m->nccl) {
+            if (m->comm_halo) (void)m->nccl->CommDestroy(m->comm_halo);
+            if (m->comm_sum) (void)m->nccl->CommDestroy(m->comm_sum);
+            if (m->gsum) (void)hipFree(m->gsum);
+            if (m->agbuf) (void)hipFree(m->agbuf);
+        }
         return 0;
     });
     {
@@ -905,7 +1120,7 @@ extern "C" int ec3d_multi_destroy(ec3d_multi_handle m)
     return 0;
 }
 
-extern "C" int ec3d_multi_ranks(ec3d_multi_handle m) { return m ? m->n : 0; }
+extern "C" int ec3d_multi_ranks(ec3d_multi_handle m) { return m ? m->world : 0; }
 
 extern "C" int ec3d_multi_slab(ec3d_multi_handle m, int32_t rank, ec3d_handle *h, int32_t *k0, int32_t *k1)
 {
@@ -932,7 +1147,7 @@ extern "C" int ec3d_multi_assemble_poisson(ec3d_multi_handle m, int32_t sdx, int
                                            const double *BND, const double *delta)
 {
     if (!m) return 2;
-    if (sdz < m->n) {
+    if (sdz < m->world) {
         ec3d_set_error("ec3d_multi_assemble_poisson: fewer z-planes than ranks");
         return 2;
     }
@@ -946,23 +1161,23 @@ extern "C" int ec3d_multi_assemble_poisson(ec3d_multi_handle m, int32_t sdx, int
         Slab &s = *m->slab[(size_t)r];
         int rc2 = slab_reset(m, s);
         if (rc2) return rc2;
-        slab_bounds(sdz, r, m->n, s.k0, s.k1);
+        slab_bounds(sdz, s.rank, m->world, s.k0, s.k1);
         s.e0 = s.k0;
         s.e1 = s.k1;
-        rc2 = m->n == 1 ? ec3d_assemble_poisson(s.c, sdx, sdy, sdz, BND, delta)
-                        : ec3d_assemble_poisson_slab(s.c, sdx, sdy, sdz, s.k0, s.k1, BND, delta);
+        rc2 = m->world == 1 ? ec3d_assemble_poisson(s.c, sdx, sdy, sdz, BND, delta)
+                            : ec3d_assemble_poisson_slab(s.c, sdx, sdy, sdz, s.k0, s.k1, BND, delta);
         if (rc2) return rc2;
         const int64_t kdz = m->kdz, n = (int64_t)(s.k1 - s.k0) * kdz;
         s.n_local = n;
-        if (s.c->ghost < kdz && m->n > 1) {
+        if (s.c->ghost < kdz && m->world > 1) {
             ec3d_set_error("ec3d_multi: ghost zone smaller than a plane");
             return 105;
         }
-        if (r > 0) {
+        if (s.rank > 0) {
             s.send_lo.push_back(Run{0, kdz, kdz, 1});
             s.recv_lo.push_back(Run{-kdz, kdz, kdz, 1});
         }
-        if (r + 1 < m->n) {
+        if (s.rank + 1 < m->world) {
             s.send_hi.push_back(Run{n - kdz, kdz, kdz, 1});
             s.recv_hi.push_back(Run{n, kdz, kdz, 1});
         }
@@ -983,7 +1198,7 @@ extern "C" int ec3d_multi_assemble(ec3d_multi_handle m, int32_t sdx, int32_t sdy
 {
     if (!m) return 2;
     const int H = 2;
-    if (m->n > 1 && sdz < H * m->n) {
+    if (m->world > 1 && sdz < H * m->world) {
         ec3d_set_error("ec3d_multi_assemble: every rank needs at least two z-planes");
         return 2;
     }
@@ -1004,7 +1219,7 @@ extern "C" int ec3d_multi_assemble(ec3d_multi_handle m, int32_t sdx, int32_t sdy
         Slab &s = *m->slab[(size_t)r];
         int rc2 = slab_reset(m, s);
         if (rc2) return rc2;
-        slab_bounds(sdz, r, m->n, s.k0, s.k1);
+        slab_bounds(sdz, s.rank, m->world, s.k0, s.k1);
         s.e0 = std::max(0, s.k0 - H);
         s.e1 = std::min(sdz, s.k1 + H);
         const int64_t kdz = m->kdz, np = s.e1 - s.e0, nC = np * kdz;
@@ -1025,7 +1240,7 @@ extern "C" int ec3d_multi_assemble(ec3d_multi_handle m, int32_t sdx, int32_t sdy
         s.nC_ext = nC;
         s.nU_ext = mloc;
         s.n_local = 3 * nC + mloc;
-        if (m->n == 1)
+        if (m->world == 1)
             rc2 = ec3d_assemble(s.c, sdx, sdy, sdz, geo, gc_ext.data(), valPHYS, nsub_glob, BND, delta, dt);
         else
             rc2 = ec3d_assemble_slab(s.c, sdx, sdy, sdz, s.e0, s.e1, s.k0, s.k1, geo, gc_ext.data(), valPHYS, nsub_glob,
@@ -1035,14 +1250,8 @@ extern "C" int ec3d_multi_assemble(ec3d_multi_handle m, int32_t sdx, int32_t sdy
         return 0;
     });
     if (rc) return rc;
-    // neighbours must agree on the storage (a slab that fell back to bands + tail next to a structured one
-    // would exchange differently shaped blocks)
-    for (int g = 0; g + 1 < m->n; ++g)
-        if ((m->slab[(size_t)g]->c->A.sav != 0) != (m->slab[(size_t)g + 1]->c->A.sav != 0)) {
-            ec3d_set_error("ec3d_multi_assemble: slabs chose different storage formats; call "
-                           "ec3d_multi_set_format(h, -1, 0) to use bands + tail everywhere");
-            return 105;
-        }
+    // (neighbours must agree on the storage -- a slab that fell back to bands + tail next to a structured one would
+    // exchange differently shaped blocks: finish_setup compares)
     m->kind = 2;
     m->nnz = 0; // per-slab counts include inert halo rows: not summed
     return finish_setup(m);
@@ -1059,7 +1268,7 @@ static int multi_set_cube_csr(ec3d_multi *m, int32_t n, const double *valA, cons
     int64_t sdx = 0, kdz = 0;
     if (!ec3d_host_matrix_is_cube(M, sdx, kdz)) return -1;
     const int64_t sdz = (int64_t)n / kdz;
-    if (sdz < m->n) {
+    if (sdz < m->world) {
         ec3d_set_error("ec3d_multi_set_matrix_csr: fewer z-planes than ranks");
         return 2;
     }
@@ -1072,7 +1281,7 @@ static int multi_set_cube_csr(ec3d_multi *m, int32_t n, const double *valA, cons
         Slab &s = *m->slab[(size_t)r];
         int rc2 = slab_reset(m, s);
         if (rc2) return rc2;
-        slab_bounds((int)sdz, r, m->n, s.k0, s.k1);
+        slab_bounds((int)sdz, s.rank, m->world, s.k0, s.k1);
         s.e0 = s.k0;
         s.e1 = s.k1;
         const int64_t rows = (int64_t)(s.k1 - s.k0) * kdz, r0 = (int64_t)s.k0 * kdz;
@@ -1090,17 +1299,17 @@ static int multi_set_cube_csr(ec3d_multi *m, int32_t n, const double *valA, cons
         S.nnz = 0;
         for (int64_t q = r0; q < r0 + rows; ++q) S.nnz += irow[q + 1] - irow[q];
         if (s.c->use_dict) ec3d_build_dictionary_host(S);
-        if ((rc2 = ec3d_upload_matrix(s.c, S, m->n > 1 ? kdz : 0))) return rc2;
+        if ((rc2 = ec3d_upload_matrix(s.c, S, m->world > 1 ? kdz : 0))) return rc2;
         s.n_local = rows;
-        if (s.c->ghost < kdz && m->n > 1) {
+        if (s.c->ghost < kdz && m->world > 1) {
             ec3d_set_error("ec3d_multi: ghost zone smaller than a plane");
             return 105;
         }
-        if (r > 0) {
+        if (s.rank > 0) {
             s.send_lo.push_back(Run{0, kdz, kdz, 1});
             s.recv_lo.push_back(Run{-kdz, kdz, kdz, 1});
         }
-        if (r + 1 < m->n) {
+        if (s.rank + 1 < m->world) {
             s.send_hi.push_back(Run{rows - kdz, kdz, kdz, 1});
             s.recv_hi.push_back(Run{rows, kdz, kdz, 1});
         }
@@ -1132,7 +1341,7 @@ extern "C" int ec3d_multi_set_matrix_csr(ec3d_multi_handle m, int32_t n, const d
     const int64_t sdz = G.nCd / G.pitch;
     {
         std::string why;
-        const int rc0 = ec3d_sav_cuttable(G, m->n, why);
+        const int rc0 = ec3d_sav_cuttable(G, m->world, why);
         if (rc0) { // e.g. a cube whose plane count is a multiple of 3, read as three blocks of planes / 3 (too few planes
                    // per rank for that reading, or coupled across the blocks' faces): as ec3d_probe_csr_multi, any
                    // refusal of the A-V reading is followed by the single-component one
@@ -1153,11 +1362,11 @@ extern "C" int ec3d_multi_set_matrix_csr(ec3d_multi_handle m, int32_t n, const d
         Slab &s = *m->slab[(size_t)r];
         int rc2 = slab_reset(m, s);
         if (rc2) return rc2;
-        slab_bounds((int)sdz, r, m->n, s.k0, s.k1);
+        slab_bounds((int)sdz, s.rank, m->world, s.k0, s.k1);
         s.e0 = std::max(0, s.k0 - H);
         s.e1 = std::min((int32_t)sdz, s.k1 + H);
         const int64_t np = s.e1 - s.e0;
-        if (m->n == 1) {
+        if (m->world == 1) {
             if ((rc2 = ec3d_upload_sav(s.c, G))) return rc2;
         } else {
             SavHost L;
@@ -1234,7 +1443,14 @@ extern "C" int ec3d_multi_solve_resident(ec3d_multi_handle m, double tolerance, 
         // itmax exit: the reference prints norm2(R) and returns (src/solvers.f90:25-28); ||R||^2 = the ranks'
         // last R.R sums added in rank order
         double s = 0.0;
+        if (m->nccl) { // one process per GPU: every rank's last sums are in the gathered copy
+            std::vector<double> all((size_t)m->comm_world * P_NSLOT);
+            (void)hipSetDevice(m->slab[0]->device);
+            EC3D_HIP(hipMemcpy(all.data(), m->gsum, all.size() * sizeof(double), hipMemcpyDeviceToHost));
+            for (int g = 0; g < m->comm_world; ++g) s += all[(size_t)g * P_NSLOT + P_RR];
+        }
         for (auto &sl : m->slab) {
+            if (m->nccl) break;
             double v = 0.0;
             (void)hipSetDevice(sl->device);
             EC3D_HIP(hipMemcpy(&v, sl->lsum + P_RR, sizeof v, hipMemcpyDeviceToHost));
@@ -1396,11 +1612,16 @@ extern "C" int ec3d_multi_iterate(ec3d_multi_handle m, int32_t first_iter, int32
 {
     int rc = need(m, "ec3d_multi_iterate");
     if (rc) return rc;
+    if (first_iter != m->slab[0]->c->it_next) { // (as ec3d_iterate: the device state is addressed by the iteration number)
+        ec3d_set_error("ec3d_multi_iterate: first_iter = " + std::to_string(first_iter) + " does not continue the iterations "
+                       "of this handle (next: " + std::to_string(m->slab[0]->c->it_next) + "; ec3d_multi_iterate_begin "
+                       "starts again from 1)");
+        return 6;
+    }
     for (auto &sp : m->slab) { // as ec3d_iterate: the groups of the deferred X update are counted from this call's first
-        ec3d_ctx *c = sp->c;   // iteration, its last one applies what is pending, and it starts from the CURRENT P
+        ec3d_ctx *c = sp->c;   // iteration, its last one applies what is pending
         c->xd_base = first_iter;
         c->xd_last = first_iter + count - 1;
-        c->p_off = ((c->pcur - first_iter) % c->pdepth + c->pdepth) % c->pdepth;
     }
     return run_all(m, [&](int r) -> int {
         Slab &s = *m->slab[(size_t)r];
@@ -1466,14 +1687,24 @@ extern "C" int ec3d_multi_true_residual(ec3d_multi_handle m, double *rel, double
 {
     int rc = need(m, "ec3d_multi_true_residual");
     if (rc) return rc;
-    std::vector<double> bb((size_t)m->n, 0.0), rr((size_t)m->n, 0.0);
+    std::vector<double> bb((size_t)std::max(m->world, m->comm_world), 0.0), rr((size_t)std::max(m->world, m->comm_world), 0.0);
     rc = run_all(m, [&](int r) -> int {
         Slab &s = *m->slab[(size_t)r];
         int rc2 = halo_start(m, s, CH_X);
         if (rc2) return rc2;
         if ((rc2 = halo_wait(s, CH_X))) return rc2;
         if ((rc2 = ec3d_dist_step(s.c, EC3D_STAGE_RESID, 0, 0.0))) return rc2;
+        if (m->nccl && (rc2 = gather(m, s))) return rc2;
         if ((rc2 = drain(s))) return rc2;
+        if (m->nccl) { // every rank's two sums, rank order
+            std::vector<double> all((size_t)m->comm_world * P_NSLOT);
+            MHIP(hipMemcpy(all.data(), m->gsum, all.size() * sizeof(double), hipMemcpyDeviceToHost));
+            for (int g = 0; g < m->comm_world; ++g) {
+                bb[(size_t)g] = all[(size_t)g * P_NSLOT + P_BB];
+                rr[(size_t)g] = all[(size_t)g * P_NSLOT + P_RR_INIT];
+            }
+            return 0;
+        }
         double v[P_NSLOT];
         MHIP(hipMemcpy(v, s.lsum, sizeof v, hipMemcpyDeviceToHost));
         bb[(size_t)r] = v[P_BB];
@@ -1482,9 +1713,9 @@ extern "C" int ec3d_multi_true_residual(ec3d_multi_handle m, double *rel, double
     }, true);
     if (rc) return rc;
     double sb = 0.0, sr = 0.0;
-    for (int r = 0; r < m->n; ++r) {
-        sb += bb[(size_t)r];
-        sr += rr[(size_t)r];
+    for (size_t r = 0; r < bb.size(); ++r) {
+        sb += bb[r];
+        sr += rr[r];
     }
     if (bnorm) *bnorm = std::sqrt(sb);
     *rel = sb > 0.0 ? std::sqrt(sr / sb) : std::sqrt(sr);
@@ -1504,7 +1735,7 @@ extern "C" int ec3d_multi_spmv(ec3d_multi_handle m, const double *x, double *y)
         int rc2 = slab_upload(m, s, EC3D_VEC_P, x);
         if (rc2) return rc2;
         // the probe must depend on the transport: what the exchange is to deliver is NaN until it does
-        if (m->n > 1 && (rc2 = poison_recv_rows(s, EC3D_VEC_P))) return rc2;
+        if (m->world > 1 && (rc2 = poison_recv_rows(s, EC3D_VEC_P))) return rc2;
         if ((rc2 = halo_start(m, s, CH_P))) return rc2;
         if ((rc2 = halo_wait(s, CH_P))) return rc2;
         ec3d_launch_spmv(s.c->A.view(), s.c->sweep_s, s.c->vec[EC3D_VEC_P], s.c->vec[EC3D_VEC_AP], s.c->stream);

@@ -118,6 +118,7 @@ void ec3d_launch_stage(ec3d_ctx *c, const MatView &A, int it, int k)
                             s);
         }
     }
+    if (k == 0 || k == 5) c->it_next = it + 1;
     if ((k == 0 || k == 5) && !f51) {
         ec3d_launch_k5(c->sweep_k5, ec3d_src_of(c, EC3D_BY_K4), c->state, it, v[EC3D_VEC_R], AP, P,
                        ring ? c->pbuf[pidx(it + 1)] : P, v[EC3D_VEC_R0], c->hist, c->hist_cap, s);
@@ -160,6 +161,7 @@ int ec3d_launch_begin(ec3d_ctx *c, const MatView &A, double tol)
     c->pcur = c->apcur = c->scur = 1; // P = R went to vec[P] = pbuf[1]
     c->ap_valid_for = 0;
     c->p_off = 0;
+    c->it_next = 1;
     c->xd_base = 1;
     c->xd_last = INT_MAX;
     EC3D_HIP(hipGetLastError());

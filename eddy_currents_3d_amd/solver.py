@@ -68,7 +68,7 @@ EXPORTS = ["sprsbcgstabwr_", "ec3d_invalidate", "ec3d_create", "ec3d_destroy", "
            "ec3d_multi_upload", "ec3d_multi_download", "ec3d_multi_solve", "ec3d_multi_solve_resident",
            "ec3d_multi_rhs_step", "ec3d_multi_post_update", "ec3d_multi_vtk_fields", "ec3d_multi_vtk_fields_begin",
            "ec3d_multi_vtk_fields_wait", "ec3d_multi_iterate_begin",
-           "ec3d_multi_iterate", "ec3d_multi_synchronize", "ec3d_true_residual", "ec3d_multi_true_residual", "ec3d_get_visit_order", "ec3d_probe_csr_multi", "ec3d_multi_spmv", "ec3d_multi_api_calls", "ec3d_multi_plan"]
+           "ec3d_multi_iterate", "ec3d_multi_synchronize", "ec3d_true_residual", "ec3d_multi_true_residual", "ec3d_get_visit_order", "ec3d_probe_csr_multi", "ec3d_multi_spmv", "ec3d_multi_api_calls", "ec3d_multi_plan", "ec3d_rccl_unique_id", "ec3d_multi_create_rank"]
 
 _f64 = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
 _i32 = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
@@ -214,6 +214,9 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.ec3d_multi_synchronize.argtypes = [hp]
     L.ec3d_multi_api_calls.argtypes = [hp, C.c_int32, C.POINTER(C.c_double)]
     L.ec3d_multi_plan.argtypes = [hp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.ec3d_rccl_unique_id.argtypes = [C.c_char_p]
+    L.ec3d_multi_create_rank.argtypes = [C.POINTER(hp), C.c_int32, C.c_int32, C.c_int32, C.c_char_p, C.c_char_p, C.c_int32,
+                                         C.c_int32]
     L.sprsbcgstabwr_.argtypes = [_f64, _i32, _i32, C.POINTER(C.c_int32), _f64, _f64,
                                  C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.sprsbcgstabwr_.restype = None
@@ -640,6 +643,37 @@ class EC3DMulti:
             _chk(self.L, self.L.ec3d_multi_set_format(self.h, -1 if dictionary is None else int(bool(dictionary)),
                                                       -1 if structured is None else int(bool(structured))),
                  "ec3d_multi_set_format")
+
+    @staticmethod
+    def rccl_unique_id() -> bytes:
+        """A fresh RCCL unique id (128 bytes; ec3d_rccl_unique_id): made on ONE rank, handed to all."""
+        L = load_library()
+        buf = C.create_string_buffer(128)
+        _chk(L, L.ec3d_rccl_unique_id(buf), "ec3d_rccl_unique_id")
+        return buf.raw
+
+    @classmethod
+    def for_rank(cls, rank: int, world: int, device: int, id_halo: bytes, id_sum: bytes, dictionary: bool | None = None,
+                 structured: bool | None = None, rehearse=None):
+        """One process per GPU (ec3d_multi_create_rank): this process's slab of a `world`-rank job on `device`, RCCL
+        between the ranks, the iteration loop enqueued from C++.  Same methods as the one-process handle; host vectors are
+        global on every rank (download / solve fill this rank's planes only).  rehearse=(as_rank, as_world): one rank of
+        a larger job on one GPU, its neighbours mapped to itself -- for timing."""
+        self = cls.__new__(cls)
+        self.L = load_library()
+        self.h = C.c_void_p()
+        ar, aw = rehearse if rehearse else (-1, 0)
+        if len(id_halo) != 128 or len(id_sum) != 128:
+            raise ValueError("an RCCL unique id is 128 bytes")
+        _chk(self.L, self.L.ec3d_multi_create_rank(C.byref(self.h), int(rank), int(world), int(device), id_halo, id_sum,
+                                                   int(ar), int(aw)), "ec3d_multi_create_rank")
+        self.nranks = 1            # LOCAL slabs (slab(0) is this rank's)
+        self.rank, self.world = int(rank), int(world)
+        if dictionary is not None or structured is not None:
+            _chk(self.L, self.L.ec3d_multi_set_format(self.h, -1 if dictionary is None else int(bool(dictionary)),
+                                                      -1 if structured is None else int(bool(structured))),
+                 "ec3d_multi_set_format")
+        return self
 
     def close(self):
         if getattr(self, "h", None) and self.h.value:

@@ -238,6 +238,20 @@ int ec3d_get_restart_count(ec3d_handle h, int32_t *count);
  * ---------------------------------------------------------------------------------------- */
 typedef struct ec3d_multi *ec3d_multi_handle;
 int ec3d_multi_create(ec3d_multi_handle *mh, int32_t nranks, const int32_t *devices);
+/* ONE PROCESS PER GPU (the launch form of torch.distributed.run / mpirun): the same handle and the same calls, but this
+ * process holds ONE slab -- rank `rank` of `nranks` -- on `device`, and RCCL carries what crosses the ranks: the halo
+ * planes as ncclSend / ncclRecv pairs in one group on a side stream (beside the interior launch), the eight partial
+ * sums of every rank by ncclAllGather on the compute stream, added in rank order by the consumer kernels.  The whole
+ * iteration loop is enqueued from C++.  id_halo, id_sum: two RCCL unique ids (128 bytes each), made by
+ * ec3d_rccl_unique_id on ONE rank and handed to all of them by the launcher's own means (the Python host uses the
+ * torch.distributed store; an MPI host would broadcast them); the call returns when every rank has made it.  Host
+ * vectors (ec3d_multi_upload / _download / _solve, the time loop's source lists) are GLOBAL on every rank, each rank
+ * takes and fills its own planes.  RCCL is loaded at run time (librccl.so.1; status 109 when it is missing).
+ * as_world > 0 (with nranks = 1): a REHEARSAL of rank as_rank of as_world on one GPU -- that rank's slab, plan, launches
+ * and RCCL calls, every neighbour mapped to this process itself; for timing, not for results. */
+int ec3d_rccl_unique_id(void *id128);
+int ec3d_multi_create_rank(ec3d_multi_handle *mh, int32_t rank, int32_t nranks, int32_t device, const void *id_halo,
+                           const void *id_sum, int32_t as_rank, int32_t as_world);
 int ec3d_multi_destroy(ec3d_multi_handle mh);
 int ec3d_multi_ranks(ec3d_multi_handle mh);
 /* the slab of one rank (an ordinary handle in multi-rank mode: introspection only) and its planes */

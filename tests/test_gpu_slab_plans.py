@@ -89,6 +89,32 @@ def test_three_launch_iteration_on_slabs_bitwise(E, oracle, monkeypatch, world, 
     assert res < 5 * tol
 
 
+@pytest.mark.parametrize("fused", [True, False], ids=["three-launches", "five-launches"])
+def test_restart_rule_on_slabs(E, oracle, monkeypatch, fused):
+    """The restart R0 = R, P = R (src/solvers.f90:47-49) on slabs: inside K5-in-K1 it also decides what the kernel forms on
+    the halo planes (P = R there too).  Tolerance and start as in tests/test_gpu_parity.py's 2-D-tile case, where the rule
+    fires; counted on every slab's device and in the twin."""
+    sdx, sdy, sdz = 256, 8, 31
+    n, kdz = sdx * sdy * sdz, sdx * sdy
+    set_knobs(monkeypatch, XDEFER=4, **(FUSED if fused else {}))
+    valA, irow, jcol = oracle.poisson_csr(sdx, sdy, sdz)
+    rng = np.random.Generator(np.random.PCG64(2026))
+    x0 = np.zeros(n)
+    rng.standard_normal(n)
+    b = rng.standard_normal(n)
+    tol = 1e-9
+    with E.EC3DMulti(3, devices=[0, 0, 0]) as m:
+        m.assemble_poisson(sdx, sdy, sdz)
+        plan = m.plan()[0]
+        assert plan == (3 if fused else 1)
+        x, it = m.solve(b, x0, tol, 5000)
+        rs = restarts_of(m)
+        xo, ito, _, _, rso = oracle.twin_solve_slabs(slabs_of(m, kdz), plan, valA, irow, jcol, b, x0, tol, 5000)
+    print(f"plan {plan}: iter {it} (twin {ito}), restarts {rs} (twin {rso})")
+    assert it == ito and np.array_equal(x, xo)
+    assert rso > 0 and all(r == rso for r in rs)
+
+
 @pytest.mark.parametrize("plan, dims", [(1, (128, 8, 48)), (0, (24, 24, 24))], ids=["interior+boundary", "plain"])
 @pytest.mark.parametrize("xd", [1, 3, 4])
 def test_five_launch_plans_with_deferred_x_bitwise(E, oracle, monkeypatch, plan, dims, xd):
@@ -162,23 +188,31 @@ def test_s_exit_with_updates_pending(E, oracle, monkeypatch):
     assert len(seen) >= 3       # exits at several positions of a group of four
 
 
-def test_iterate_twice_from_the_same_number(E, oracle, monkeypatch):
-    """ec3d_multi_iterate (bench.py's timed region) may be called with any first iteration: the rings of P are addressed
-    relative to the current P.  iterate(1, 5) twice == iterate(1, 5) followed by iterate(6, 5)."""
+def test_iterate_continues_and_refuses_to_restart_its_numbering(E, oracle, monkeypatch):
+    """ec3d_multi_iterate (bench.py's timed region) in pieces: the device state is addressed by the iteration number
+    (rr0[it & 1], AP in apbuf[it & 1], P and S in their rings), so iterate(1, 5) + iterate(6, 5) == iterate(1, 10), and a
+    call that does not continue the numbering -- iterate(1, 5) twice -- is refused instead of reading an older P."""
     sdx, sdy, sdz = 128, 8, 32
     n = sdx * sdy * sdz
     set_knobs(monkeypatch, XDEFER=4, **FUSED)
     rng = np.random.Generator(np.random.PCG64(11))
     b = rng.standard_normal(n)
     out = []
-    for second in (1, 6):
+    for pieces in ((10,), (5, 5), (3, 3, 4)):
         with E.EC3DMulti(2, devices=[0, 0]) as m:
             m.assemble_poisson(sdx, sdy, sdz)
             m.upload("B", b)
             m.upload("X", np.zeros(n))
             m.iterate_begin()
-            m.iterate(1, 5)
-            m.iterate(second, 5)
+            at = 1
+            for c in pieces:
+                m.iterate(at, c)
+                at += c
             m.synchronize()
             out.append(m.download("X"))
-    assert np.array_equal(out[0], out[1])
+            with pytest.raises(E.EC3DError, match="does not continue"):
+                m.iterate(1, 5)
+            m.iterate_begin()          # ... which starts again from 1
+            m.iterate(1, 2)
+            m.synchronize()
+    assert np.array_equal(out[0], out[1]) and np.array_equal(out[0], out[2])

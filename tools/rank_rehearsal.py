@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""One rank of the 512^3 job on G GPUs, alone on ONE card, through the driver the launcher's form of bench.py uses: the
+C++ iteration loop over RCCL (ec3d_multi_create_rank with as_world = G: that rank's slab, plan, launches, send / recv
+groups and all-gathers, its neighbours mapped to this process).  Prints, per G, ms per iteration of the rank, the host
+thread's enqueue time per iteration and its runtime calls per iteration; then the same on a grid so small that the kernels
+take no time (the host-side floor).
+
+    python tools/rank_rehearsal.py [iters]
+"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch  # noqa: F401
+from eddy_currents_3d_amd.dist import rccl_rank
+
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+
+
+def run(N, sdz, G, r):
+    n = N * N * sdz
+    with rccl_rank(0, 1, 0, rehearse=(r, G)) as m:
+        m.assemble_poisson(N, N, sdz)
+        view, k0, k1 = m.slab(0)
+        m.upload("B", np.random.Generator(np.random.PCG64(1)).standard_normal(n))
+        m.upload("X", np.zeros(n))
+        m.iterate_begin()
+        m.iterate(1, 20)
+        m.synchronize()
+        t0 = time.perf_counter()
+        m.iterate(21, iters)
+        t1 = time.perf_counter()
+        m.synchronize()
+        t2 = time.perf_counter()
+        plan, xd = m.plan()
+        calls = m.api_calls(0)
+        km = m.iterate(21 + iters, 20, per_kernel=True)
+    rows = N * N * (k1 - k0)
+    print(f"{N}x{N}x{sdz} on {G} ranks, rank {r} ({k1 - k0} planes, {rows / 2**20:.2f} Mi rows): plan {plan}, X every {xd}: "
+          f"{1e3 * (t2 - t0) / iters:.4f} ms per iteration ({rows * iters / (t2 - t0) / 1e9:.2f} G DOF*iters/s on this rank), host "
+          f"enqueue {1e3 * (t1 - t0) / iters:.4f} ms per iteration, {calls:.0f} runtime calls per iteration; stages "
+          + " ".join(f"{k}={v * 1e3:.0f}us" for k, v in km.items()), flush=True)
+
+
+for G in (2, 4, 8):
+    run(512, 512, G, G // 2)
+run(256, 256, 8, 3)
+run(64, 128, 8, 3)       # the host-side floor: kernels of a few microseconds
