@@ -536,9 +536,13 @@ def main():
     # 72 B/row) at the same grid, timed after the headline region on a handle of its own (the
     # default format's handle is closed first: 7.5 GB of bands + 8.6 GB of vectors), 20 launches back to back.
     spmv_dia = None
+    iter_dia = None
     if rank == 0 and not use_dist and not in_library and args.workload == "cube" and args.format == "dict" \
             and not args.no_spmv_dia:
         s.close()
+        # (X = X + alpha*P + omega*S in EVERY iteration on this handle: SURVEY section 8d's K4 moves 56 B per row)
+        xd_env = os.environ.get("EC3D_XDEFER")
+        os.environ["EC3D_XDEFER"] = "1"
         with E.EC3DSolver(device=local_rank, dictionary=False) as sd:
             sd.assemble_poisson(N, N, N)
             sd.upload("B", bar_rhs(N))
@@ -553,6 +557,31 @@ def main():
                                 "put the 7.5 GB of band streams (1.68 ... 2.0 ms at 512^3 from one allocation to the "
                                 "next), so the library looks at up to 8 placements at set-up and keeps the fastest "
                                 "(DESIGN.md section 4, profiles/r03_dia_placement.log)"}
+            # The WHOLE iteration on SURVEY section 8d's exact byte model, driver-timed: plain DIA streams, five launches
+            # (K1 80 + K2 24 + K3 72 + K4 56 + K5 32 = 264 B per DOF*iter), X updated in every iteration.
+            Kd, Wd = 200, 5
+            sd.iterate_begin()
+            sd.iterate(1, Wd)
+            sd.synchronize()
+            torch.cuda.synchronize()
+            td0 = time.perf_counter()
+            sd.iterate(Wd + 1, Kd)
+            sd.synchronize()
+            torch.cuda.synchronize()
+            td = time.perf_counter() - td0
+            kd_ms = sd.iterate(Wd + Kd + 1, 50, per_kernel=True)
+            iter_dia = {"workload": f"the same {N}^3 operator as seven plain fp64 band streams, five launches per iteration, "
+                                    f"X updated every iteration: SURVEY section 8d's byte model exactly",
+                        "byte_model": "survey_8d", "steps": Kd, "warmup": Wd, "ms_per_step": td * 1e3 / Kd,
+                        "value": n_global * Kd / td, "unit": "DOF*iters/s", "bytes_per_dof_iter": ITER_BYTES_PER_DOF,
+                        "frac": ITER_BYTES_PER_DOF * n_global * Kd / td / 1e9 / PEAK_HBM_GBS,
+                        "fusion": list(sd.fusion()), "x_update_every": sd.x_interval(),
+                        "kernels": {k: {"ms": v, "bytes_per_row": SURVEY_BYTES[k], "GBps": SURVEY_BYTES[k] * n_global / v / 1e6,
+                                        "frac": SURVEY_BYTES[k] * n_global / v / 1e6 / PEAK_HBM_GBS} for k, v in kd_ms.items()}}
+        if xd_env is None:
+            del os.environ["EC3D_XDEFER"]
+        else:
+            os.environ["EC3D_XDEFER"] = xd_env
 
     # Driver-timed figures for the reference's own system and for config 2's grid: the headline
     # handle is gone by now, each runs on a fresh handle, config.workload stays the 512^3 cube.
@@ -594,6 +623,11 @@ def main():
             "kernels": kernels,
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved,
                          "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
+                         # whose bytes `achieved` counts: "format" = what this storage format and these launches are built
+                         # to move (class byte + LDS table instead of 56 B of coefficients per row, fused launches);
+                         # "survey_8d" = SURVEY section 8d's plain-DIA five-kernel model (--format dia; the `iter_dia`
+                         # sub-record carries the whole iteration on that model, `spmv_dia` the bare SpMV)
+                         "byte_model": "format" if info.dict_classes > 0 else "survey_8d",
                          "traffic": traffic,
                          # not measured in this run: PMC counters need their own rocprofv3 passes
                          # (tools/profile_bench.sh); this is the committed profile of the same configuration
@@ -619,6 +653,8 @@ def main():
                            "bytes_per_row": fmt_bytes["spmv"], "GBps": fmt_bytes["spmv"] * rows / spmv_ms / 1e6}
         if spmv_dia is not None:
             out["spmv_dia"] = spmv_dia
+        if iter_dia is not None:
+            out["iter_dia"] = iter_dia
         for name, rec in side.items():
             out[name] = rec
         if world == 1 and not args.no_cpu_baseline:

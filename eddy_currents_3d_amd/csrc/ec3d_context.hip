@@ -27,6 +27,39 @@ static int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
  * 0 <= e <= 15, otherwise d.dddE+ee with at least two exponent digits (" 9.87654321E-03", " 1.E+16", " 1.E-300").  Checked
  * against random doubles printed by a program compiled with amdflang (a sample: tests/test_oracle_golden.py).  buf >= 40. */
 extern "C" void ec3d_format_real8(double v, char *buf) { ec3d_format_list_directed(v, buf); }
+
+/* gfortran: a REAL(8) in list-directed output is one blank and G25.17E3 -- 17 significant digits, F editing with five
+ * trailing blanks when 0.1 <= |x| < 10^17 (after rounding), d.dddE+eee otherwise; zero as 0.0000000000000000. */
+extern "C" void ec3d_format_real8_gfortran(double v, char *buf) { ec3d_format_list_directed_gfortran(v, buf); }
+void ec3d_format_list_directed_gfortran(double v, char *buf)
+{
+    char t[64];
+    if (v != v) { snprintf(buf, 40, " %25s", "NaN"); return; }
+    if (v > 1.7976931348623157e308 || v < -1.7976931348623157e308) { snprintf(buf, 40, " %25s", v > 0 ? "Infinity" : "-Infinity"); return; }
+    if (v == 0.0) { snprintf(buf, 40, " %20s     ", (1.0 / v < 0.0) ? "-0.0000000000000000" : "0.0000000000000000"); return; }
+    snprintf(t, sizeof t, "%.16e", v < 0 ? -v : v);       /* rounded to 17 significant digits: its decimal exponent */
+    const int k = atoi(strchr(t, 'e') + 1) + 1;         /* digits in front of the point */
+    if (k >= 0 && k <= 17) {
+        snprintf(t, sizeof t, "%.*f", 17 - k, v);
+        snprintf(buf, 40, " %20s     ", t);
+    } else {
+        snprintf(t, sizeof t, "%.16E", v);                /* d.ddddddddddddddddE+ee -> three exponent digits */
+        char *e = strchr(t, 'E');
+        const int ex = atoi(e + 1);
+        snprintf(e, sizeof t - (size_t)(e - t), "E%c%03d", ex < 0 ? '-' : '+', ex < 0 ? -ex : ex);
+        snprintf(buf, 40, " %25s", t);
+    }
+}
+
+void ec3d_print_rnorm(double rnorm)
+{
+    char line[48];
+    const char *style = getenv("EC3D_PRINT_STYLE");
+    if (style && (style[0] == 'g' || style[0] == 'G')) ec3d_format_list_directed_gfortran(rnorm, line);
+    else ec3d_format_list_directed(rnorm, line);
+    printf("%s\n", line);
+    fflush(stdout);
+}
 void ec3d_format_list_directed(double v, char *buf)
 {
     char big[64], ds[24], cand[48];
@@ -627,10 +660,38 @@ static int choose_sweep(ec3d_ctx *c)
             c->can_overlap = true;
         }
     }
+    // z-slab of the single-component operator on 2-D tiles: the 2-D-tile kernels in two launches too -- planes 0 and np-1
+    // (one plane per workgroup: zm_plstep), then planes 1 .. np-2 -- for the producers of the exchanged vectors in the
+    // three-launch iteration (K4 in SpMV form makes R, K5-in-K1 the next AP; ec3d_multi.hip plan 4)
+    c->can_fsplit = false;
+    c->sweep_fb = c->sweep_fi = ss;
+    if (c->halo > 0 && c->nown == 0 && ss.zm_tpp > 0 && ss.patch_npx > 0) {
+        const int64_t np = sw.ntiles / ss.zm_tpp;
+        if (np * ss.zm_tpp == sw.ntiles && np >= 3) {
+            Sweep &fb = c->sweep_fb, &fi = c->sweep_fi;
+            const int64_t tpp = ss.zm_tpp, npl = np - 2, cols = (tpp + 7) / 8 * 8;
+            fb.zm_pl0 = 0;
+            fb.zm_plstep = (int)(np - 1);
+            fb.zm_npl = 2;
+            fb.zm_pps = 1;
+            fb.nblk = (int)(cols * 2);
+            fb.part_off = 0;
+            int64_t nseg = std::max<int64_t>(1, ((int64_t)ss.nblk + cols / 2) / cols);
+            nseg = std::min<int64_t>(nseg, std::max<int64_t>(1, npl / 2));
+            fi.zm_pl0 = 1;
+            fi.zm_npl = (int)npl;
+            fi.zm_pps = (int)((npl + nseg - 1) / nseg);
+            fi.nblk = (int)(cols * nseg);
+            fi.part_off = fb.nblk;
+            parts = std::max(parts, fb.nblk + fi.nblk);
+            c->can_fsplit = true;
+        }
+    }
     // room for a vector kernel in two launches as well (boundary list <= 256 workgroups)
     const int vmax = std::max(sw.nblk, std::max(c->sweep_k2.nblk, c->sweep_k5.nblk));
     const int ps = std::max(vmax + 256, std::max(ss.nblk, parts));
     sw.pstride = ss.pstride = c->sweep_int.pstride = c->sweep_bnd.pstride = ps;
+    c->sweep_fb.pstride = c->sweep_fi.pstride = ps;
     c->sweep_k2.pstride = c->sweep_k5.pstride = ps;
     return 0;
 }
@@ -733,6 +794,14 @@ static int place_bands(ec3d_ctx *c)
 int ec3d_prepare_vectors(ec3d_ctx *c)
 {
     free_vectors(c);
+    // a parked copy of plain band streams (ec3d_free_matrix keeps the placement a probe chose) that the NEW matrix did not
+    // take back -- it has no plain bands, or bands of another size -- is of no use any more: 7.5 GB at 512^3 that would
+    // otherwise stay allocated until ec3d_destroy and could push ec3d_spare_pair into its fallbacks
+    if (c->placed_bands) {
+        (void)hipFree(c->placed_bands);
+        c->placed_bands = nullptr;
+        c->placed_bytes = 0;
+    }
     c->A.ulist_host.resize((size_t)c->A.ulist_n);
     if (c->A.ulist_n)
         EC3D_HIP(hipMemcpy(c->A.ulist_host.data(), c->A.ulist, (size_t)c->A.ulist_n * 4, hipMemcpyDeviceToHost));
@@ -1253,6 +1322,8 @@ static const Sweep &sweep_for(const ec3d_ctx *c, int which)
     case 4: return c->sweep_bnd;
     case 5: return c->sweep_vb;
     case 6: return c->sweep_vi;
+    case 7: return c->sweep_fb; // boundary / interior launch of K4 in SpMV form and of K5-in-K1 (three-launch iteration)
+    case 8: return c->sweep_fi;
     default: return ec3d_k4s(c) ? c->sweep_s : c->sweep;
     }
 }

@@ -210,6 +210,23 @@ extern "C" int ec3d_dist_step(ec3d_handle c, int32_t stage, int32_t it, double t
         if (ec3d_xdefer(c) > 1) c->pcur = ((it + 1 + c->p_off) % c->pdepth + c->pdepth) % c->pdepth;
         c->it_next = it + 1;
         break;
+    case EC3D_STAGE_K4F_BND:
+    case EC3D_STAGE_K4F_INT:
+    case EC3D_STAGE_K5F_BND:
+    case EC3D_STAGE_K5F_INT: {
+        if (!c->can_fsplit || !c->slab_fused || !ec3d_k4s(c)) {
+            ec3d_set_error("ec3d_dist_step: this slab does not run the three-launch iteration in split launches");
+            return 3;
+        }
+        const bool k4 = stage == EC3D_STAGE_K4F_BND || stage == EC3D_STAGE_K4F_INT;
+        const bool second = stage == EC3D_STAGE_K4F_INT || stage == EC3D_STAGE_K5F_INT;
+        ec3d_launch_stage(c, A, it, k4 ? 4 : 5, second ? 2 : 1);
+        if (second) {
+            if (k4) fin(EC3D_BY_K4, 1u << P_RR | 1u << P_RR0N, true);
+            else fin(EC3D_BY_SPMV, 1u << P_D1, true);
+        }
+        break;
+    }
     default: ec3d_set_error("ec3d_dist_step: unknown stage"); return 2;
     }
     EC3D_HIP(hipGetLastError());
@@ -225,7 +242,7 @@ int ec3d_dist_launches(const ec3d_ctx *c, int stage, int it)
     case EC3D_STAGE_K2: return ec3d_fused23(c) ? 0 : 2;
     case EC3D_STAGE_K5: return ec3d_fused51(c) ? 2 : 1;
     case EC3D_STAGE_SETUP: case EC3D_STAGE_K1_INT: case EC3D_STAGE_K3_INT: case EC3D_STAGE_K2_BND:
-    case EC3D_STAGE_K5_BND: case EC3D_STAGE_K5_INT: return 1;
+    case EC3D_STAGE_K5_BND: case EC3D_STAGE_K5_INT: case EC3D_STAGE_K4F_BND: case EC3D_STAGE_K5F_BND: return 1;
     default: return 2;
     }
 }

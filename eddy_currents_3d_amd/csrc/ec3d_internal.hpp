@@ -273,6 +273,10 @@ struct ec3d_ctx {
     Sweep sweep_s{}; // SpMV kernels (K1, K3, residual, spmv)
     Sweep sweep_int{}, sweep_bnd{}; // z-slab: interior / boundary-plane launches of K1 and K3
     bool can_overlap = false;
+    // z-slab on 2-D tiles: planes {0, np-1} / 1 .. np-2 as two launches of the 2-D-tile kernels (K4 in SpMV form and
+    // K5-in-K1 of the three-launch iteration: the producers of the exchanged R and AP); can_fsplit: np >= 3
+    Sweep sweep_fb{}, sweep_fi{};
+    bool can_fsplit = false;
     bool fuse23_ok = false; // 2-D tiles: K2 may run inside K3 (single rank only, see ec3d_fused23)
     bool fuse51_ok = false; // 2-D tiles: K5 may run inside the next iteration's K1 (ec3d_fused51)
     bool k4s_ok = false;    // dictionary cube on 2-D tiles: K4 may run as an SpMV kernel that computes A S again (ec3d_k4s)
@@ -382,14 +386,12 @@ enum { P_BB = 0, P_RR_INIT = 1, P_D1 = 2, P_SS = 3, P_D2 = 4, P_D3 = 5, P_RR = 6
 void ec3d_set_error(const std::string &msg);
 // a REAL(8) as the reference's `print*` writes it (src/solvers.f90:27, flang's list-directed output); buf >= 40
 void ec3d_format_list_directed(double v, char *buf);
-// the itmax exit's line: norm2(R) on stdout, as the reference prints it
-inline void ec3d_print_rnorm(double rnorm)
-{
-    char line[48];
-    ec3d_format_list_directed(rnorm, line);
-    printf("%s\n", line);
-    fflush(stdout);
-}
+// the same value as gfortran's list-directed output writes it (one blank + G25.17E3); buf >= 40
+void ec3d_format_list_directed_gfortran(double v, char *buf);
+// the itmax exit's line: norm2(R) on stdout, as the reference prints it (src/solvers.f90:27, `print*`).  List-directed
+// output is compiler specific: flang's form by default (the toolchain of this image, which built oracle/_ref),
+// EC3D_PRINT_STYLE=gfortran for the form of the reference's own Makefile (src/Makefile:1-28)
+void ec3d_print_rnorm(double rnorm);
 // itmax exit: the reference prints norm2(R) (src/solvers.f90:25-28).  When this points somewhere, the solve entry
 // points store the value there instead of printing it (the drop-in prints it once its result is accepted).
 extern thread_local double *ec3d_itmax_print_hold;
@@ -453,7 +455,9 @@ int ec3d_need_matrix(ec3d_ctx *c, const char *who); // 0, or 3 + error text when
 enum { EC3D_BY_K4 = 0, EC3D_BY_SPMV = 1, EC3D_BY_K2 = 2 };
 RedSrc ec3d_src_of(const ec3d_ctx *c, int producer);
 RedSrc ec3d_part_of(const ec3d_ctx *c, int producer, bool split = false);
-void ec3d_launch_stage(ec3d_ctx *c, const MatView &A, int it, int k); // k = 1..5, 0 = all five
+// k = 1..5, 0 = all five; part: 0 the whole launch, 1 / 2 the boundary / interior launch of stage 4 or 5 on a slab that runs
+// the three-launch iteration (sweep_fb / sweep_fi)
+void ec3d_launch_stage(ec3d_ctx *c, const MatView &A, int it, int k, int part = 0);
 inline bool ec3d_fused23(const ec3d_ctx *c) { return c->fuse23_ok && ((!c->dist && c->halo == 0) || c->slab_fused); }
 inline bool ec3d_fused51(const ec3d_ctx *c)
 {

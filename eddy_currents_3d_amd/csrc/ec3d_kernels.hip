@@ -1721,7 +1721,9 @@ __global__ __launch_bounds__(EC3D_THREADS) __attribute__((amdgpu_waves_per_eu(4)
     double d[2];
     partials_finish<2>(src, slot, pe, d, lds);
     const double rnorm = sqrt(d[0]);
-    const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+    // (the second launch of a split K5-in-K1 -- z-slab, interior planes behind the boundary planes -- leaves the state
+    // alone: the first one has written it, and the restart counter must count once)
+    const bool lead = blockIdx.x == 0 && threadIdx.x == 0 && sw.part_off == 0;
     if (lead && hist && it <= hist_cap) hist[2 * (int64_t)(it - 1) + 1] = rnorm;
     if (lead) st->rnorm = rnorm;
     if (rnorm / bnorm < tol) {
@@ -1984,7 +1986,7 @@ __global__ __launch_bounds__(EC3D_THREADS) __attribute__((amdgpu_waves_per_eu(NE
     double ss[1];
     partials_finish<1>(src_ss, slot_ss, pss, ss, lds);
     const double snorm = sqrt(ss[0]);
-    const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+    const bool lead = blockIdx.x == 0 && threadIdx.x == 0 && sw.part_off == 0; // (split launch: the first one writes the state)
     if (lead && hist && it <= hist_cap) hist[2 * (int64_t)(it - 1)] = snorm;
     if (snorm / bnorm < tol) {
         if (lead) {

@@ -93,6 +93,13 @@ const std::vector<Op> kIterVsplit = {{OP_HALO_WAIT, CH_P}, ST(K1), {OP_GATHER, 0
 const std::vector<Op> kBeginFused = {{OP_HALO, CH_X}, ST(RESID), {OP_GATHER, 0}, ST(SETUP), {OP_HALO, CH_P, 1}, {OP_HALO, CH_R}};
 const std::vector<Op> kIterFused = {{OP_SKIP_IF_AP, 3}, ST(K1), {OP_GATHER, 0}, {OP_HALO, CH_AP}, ST(K3), {OP_GATHER, 0}, ST(K4),
                                     {OP_GATHER, 0}, {OP_HALO, CH_R}, ST(K5), {OP_GATHER, 0}, {OP_HALO, CH_AP, 1}};
+// the same with the two exchanges hidden: the PRODUCERS of R and AP run planes 0 and np-1 first, the exchange starts, the
+// interior planes follow while the planes travel; the consumer's side waits in front of the launch that reads the halo.
+// Exchanges and reduction points come in the same order as in kIterFused, so ranks may mix the two.
+const std::vector<Op> kIterFusedOverlap = {{OP_SKIP_IF_AP, 3}, ST(K1), {OP_GATHER, 0}, {OP_HALO, CH_AP}, {OP_HALO_WAIT, CH_AP},
+                                           ST(K3), {OP_GATHER, 0}, ST(K4F_BND), {OP_HALO_START, CH_R}, ST(K4F_INT), {OP_GATHER, 0},
+                                           {OP_HALO_WAIT, CH_R}, ST(K5F_BND), {OP_HALO_START, CH_AP, 1}, ST(K5F_INT),
+                                           {OP_GATHER, 0}};
 #undef ST
 
 struct Slab {
@@ -111,7 +118,8 @@ struct Slab {
     std::vector<Copy> pull_lo, pull_hi;                  // my ghost rows <- neighbour's rows
     std::vector<Piece> snd_lo, rcv_lo, snd_hi, rcv_hi;   // RCCL: contiguous pieces of my rows to send / my ghost rows to fill
     bool split_ok = false;
-    int plan = 0; // 0 plain, 1 overlap (K1/K3 interior + boundary), 2 vsplit (K2/K5 boundary first), 3 three launches (kIterFused)
+    int plan = 0; // 0 plain, 1 overlap (K1/K3 interior + boundary), 2 vsplit (K2/K5 boundary first), 3 three launches
+                  // (kIterFused), 4 three launches with the producers of R and AP split around the exchange
     int32_t *stop_pinned = nullptr;
     hipEvent_t ev_stop[2] = {};
     // A-V slab: local reference order [Ax_ext | Ay_ext | Az_ext | U_ext] <-> the global vector
@@ -479,8 +487,8 @@ int kernel_of_stage(int st)
     case EC3D_STAGE_K1: case EC3D_STAGE_K1_INT: case EC3D_STAGE_K1_BND: return 0;
     case EC3D_STAGE_K2: case EC3D_STAGE_K2_INT: case EC3D_STAGE_K2_BND: return 1;
     case EC3D_STAGE_K3: case EC3D_STAGE_K3_INT: case EC3D_STAGE_K3_BND: return 2;
-    case EC3D_STAGE_K4: return 3;
-    case EC3D_STAGE_K5: case EC3D_STAGE_K5_INT: case EC3D_STAGE_K5_BND: return 4;
+    case EC3D_STAGE_K4: case EC3D_STAGE_K4F_BND: case EC3D_STAGE_K4F_INT: return 3;
+    case EC3D_STAGE_K5: case EC3D_STAGE_K5_INT: case EC3D_STAGE_K5_BND: case EC3D_STAGE_K5F_BND: case EC3D_STAGE_K5F_INT: return 4;
     default: return -1;
     }
 }
@@ -534,10 +542,11 @@ int run_plan(ec3d_multi *m, Slab &s, const std::vector<Op> &plan, int it, double
     return 0;
 }
 
-const std::vector<Op> &begin_plan(const Slab &s) { return s.plan == 3 ? kBeginFused : s.plan == 2 ? kBeginVsplit : kBegin; }
+const std::vector<Op> &begin_plan(const Slab &s) { return s.plan >= 3 ? kBeginFused : s.plan == 2 ? kBeginVsplit : kBegin; }
 const std::vector<Op> &iter_plan(const Slab &s)
 {
-    return s.plan == 3 ? kIterFused : s.plan == 2 ? kIterVsplit : s.plan == 1 ? kIterOverlap : kIter;
+    return s.plan == 4 ? kIterFusedOverlap : s.plan == 3 ? kIterFused : s.plan == 2 ? kIterVsplit
+           : s.plan == 1 ? kIterOverlap : kIter;
 }
 
 int drain(Slab &s)
@@ -757,11 +766,13 @@ int finish_setup(ec3d_multi *m)
         c->slab_fused = fused;
         c->slab_xd = xd;
         c->sweep_s.halo_store = fused ? ((s.rank > 0 ? 1 : 0) | (s.rank + 1 < m->world ? 2 : 0)) : 0;
+        c->sweep_fb.halo_store = c->sweep_fi.halo_store = c->sweep_s.halo_store;
         if (c->pp_base) c->pdepth = std::max(2, ec3d_xdefer(c)); // every rank cycles P through the same number of buffers
         s.plan = 0;
         s.split_ok = false;
         if (m->kind == 1) {
-            s.plan = fused ? 3 : ec3d_can_overlap(c) ? 1 : 0;
+            const bool no_fsplit = getenv("EC3D_SLAB_FSPLIT") && atoi(getenv("EC3D_SLAB_FSPLIT")) == 0;
+            s.plan = fused ? ((c->can_fsplit && !no_fsplit) ? 4 : 3) : ec3d_can_overlap(c) ? 1 : 0;
         } else if (m->world > 1) {
             // the ORDER of exchanges is a property of the job: every A-V rank uses the producer-side
             // plan; a rank whose slab is all boundary runs the whole kernels in that order

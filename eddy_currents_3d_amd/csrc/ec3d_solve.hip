@@ -21,8 +21,12 @@
 // vector kernels (sweep) -- every consumer reads slots of one producer class only.
 static int parts_of(const ec3d_ctx *c, int producer, bool split)
 {
+    // (a split launch of the three-launch iteration -- K4 in SpMV form or K5-in-K1 as boundary + interior launch -- leaves
+    // the boundary launch's partials followed by the interior launch's)
+    const int fsplit = c->sweep_fb.nblk + c->sweep_fi.nblk;
     if (producer == EC3D_BY_K2) return ec3d_fused23(c) ? c->sweep_s.nblk : c->sweep_k2.nblk; // fused: S.S comes from K23
-    if (producer == EC3D_BY_K4) return ec3d_k4s(c) ? c->sweep_s.nblk : c->sweep.nblk; // K4 in SpMV form sums on that grid
+    if (producer == EC3D_BY_K4) return ec3d_k4s(c) ? (split ? fsplit : c->sweep_s.nblk) : c->sweep.nblk; // K4 in SpMV form sums on that grid
+    if (split && ec3d_fused51(c) && c->slab_fused) return fsplit;
     return split ? c->sweep_int.nblk + c->sweep_bnd.nblk : c->sweep_s.nblk;
 }
 RedSrc ec3d_src_of(const ec3d_ctx *c, int producer)
@@ -61,10 +65,10 @@ double *ec3d_vec_at(const ec3d_ctx *c, int vec, int it)
 // With the X update deferred (ec3d_xdefer = D > 1; three launches or five) P(it) and S(it) live in rings of D buffers, K4
 // leaves X alone except in the last iteration of a group of D (counted from xd_base) or of the call (xd_last), where it
 // applies what is pending; an exit in between is completed by ec3d_flush_x.
-void ec3d_launch_stage(ec3d_ctx *c, const MatView &A, int it, int k)
+void ec3d_launch_stage(ec3d_ctx *c, const MatView &A, int it, int k, int part)
 {
     double **v = c->vec;
-    const Sweep &sw = c->sweep, &ss = c->sweep_s;
+    const Sweep &sw = c->sweep, &ss = part == 1 ? c->sweep_fb : part == 2 ? c->sweep_fi : c->sweep_s;
     hipStream_t s = c->stream;
     const bool fused = ec3d_fused23(c); // K2 inside K3 (2-D tiles, single rank): stage 2 is empty, stage 3 is K23
     const bool f51 = ec3d_fused51(c);
@@ -118,7 +122,7 @@ void ec3d_launch_stage(ec3d_ctx *c, const MatView &A, int it, int k)
                             s);
         }
     }
-    if (k == 0 || k == 5) c->it_next = it + 1;
+    if ((k == 0 || k == 5) && part != 1) c->it_next = it + 1;
     if ((k == 0 || k == 5) && !f51) {
         ec3d_launch_k5(c->sweep_k5, ec3d_src_of(c, EC3D_BY_K4), c->state, it, v[EC3D_VEC_R], AP, P,
                        ring ? c->pbuf[pidx(it + 1)] : P, v[EC3D_VEC_R0], c->hist, c->hist_cap, s);

@@ -15,12 +15,18 @@ def _i8(*vals):
     return " ".join("%8d" % v for v in vals).strip()
 
 
-_POINTS = {}   # (sdx, sdy, sdz, delta) -> the big-endian POINTS block: the same bytes in every file of a run
+# One-entry caches, each a single (key, value) tuple that is replaced in ONE assignment: the writer and source threads of
+# host._OutputPipeline call these functions side by side, and a dict that is cleared and refilled can lose its entry
+# between one thread's store and its own lookup.  A thread that finds another key builds its value locally and returns
+# that local; at worst two threads build the same block once.
+_POINTS = (None, None)   # ((sdx, sdy, sdz, delta), the big-endian POINTS block): the same bytes in every file of a run
 
 
 def _points_block(sdx, sdy, sdz, delta) -> bytes:
+    global _POINTS
     key = (sdx, sdy, sdz, tuple(float(d) for d in delta))
-    if key not in _POINTS:
+    have_key, have = _POINTS
+    if have_key != key:
         # REAL(k,8)*delta - delta, then REAL(.,4)   (utilites.f90:210-219)
         x = (np.arange(1, sdx + 1, dtype=np.float64) * delta[0] - delta[0]).astype(np.float32)
         y = (np.arange(1, sdy + 1, dtype=np.float64) * delta[1] - delta[1]).astype(np.float32)
@@ -29,9 +35,9 @@ def _points_block(sdx, sdy, sdz, delta) -> bytes:
         pts[..., 0] = x[None, None, :]
         pts[..., 1] = y[None, :, None]
         pts[..., 2] = z[:, None, None]
-        _POINTS.clear()                      # one grid at a time: the block is 12 bytes per cell
-        _POINTS[key] = pts.tobytes()
-    return _POINTS[key]
+        have = pts.tobytes()
+        _POINTS = (key, have)                # one grid at a time: the block is 12 bytes per cell
+    return have
 
 
 def field_vtk_pieces(sdx, sdy, sdz, delta, fields):
@@ -123,7 +129,7 @@ def write_field_vtk(path, sdx, sdy, sdz, delta, fields):
     _write_pieces(path, field_vtk_pieces(sdx, sdy, sdz, delta, fields))
 
 
-_SRC_FIXED = {}   # ncell -> (connectivity block, cell-type block): they depend on the number of cells only
+_SRC_FIXED = (None, None)   # (ncell, (connectivity block, cell-type block)): they depend on the number of cells only
 
 
 def src_vtk_pieces(sdx, sdy, sdz, delta, groups):
@@ -150,13 +156,15 @@ def src_vtk_pieces(sdx, sdy, sdz, delta, groups):
         pts[at:at + k] = (ijk + corner[None, :, :]) * d - d     # REAL(i,8)*delta - delta
         vec[at:at + k, axis] = value
         at += k
-    if ncell not in _SRC_FIXED:
+    global _SRC_FIXED
+    have_n, fixed = _SRC_FIXED
+    if have_n != ncell:
         conn = np.empty((ncell, 9), ">i4")
         conn[:, 0] = 8
         conn[:, 1:] = 8 * np.arange(ncell)[:, None] + np.arange(8)[None, :]
-        _SRC_FIXED.clear()
-        _SRC_FIXED[ncell] = (conn.tobytes(), np.full(ncell, 11, ">i4").tobytes())
-    conn_b, types_b = _SRC_FIXED[ncell]
+        fixed = (conn.tobytes(), np.full(ncell, 11, ">i4").tobytes())
+        _SRC_FIXED = (ncell, fixed)
+    conn_b, types_b = fixed
     return [b"# vtk DataFile Version 3.0\nout data result\nBINARY\n", b"DATASET UNSTRUCTURED_GRID\n",
             ("POINTS %s double\n" % _i8(8 * ncell)).encode(), memoryview(pts).cast("B"), b"\n",
             ("CELLS %s %s\n" % (_i8(ncell), _i8(9 * ncell))).encode(), conn_b, b"\n",

@@ -202,7 +202,12 @@ enum { EC3D_STAGE_RESID = 0, /* R = B - A X, R0 = P = R; lsum <- B.B, R.R      s
         * receive, ec3d_dist_set_boundary_rows), then the exchange starts, then *_INT (everything else)
         * while the planes travel.  K2 produces S (K2_INT also collapses both launches' S.S partials),
         * K5 produces P. */
-       EC3D_STAGE_K2_BND = 11, EC3D_STAGE_K2_INT = 12, EC3D_STAGE_K5_BND = 13, EC3D_STAGE_K5_INT = 14 };
+       EC3D_STAGE_K2_BND = 11, EC3D_STAGE_K2_INT = 12, EC3D_STAGE_K5_BND = 13, EC3D_STAGE_K5_INT = 14,
+       /* A slab that runs the THREE-launch iteration (in-library / RCCL drivers only: it needs the library's own spare
+        * buffers; stage 3 is then K2-in-K3, stage 4 K4 in SpMV form, stage 5 K5-in-K1): the producers of the exchanged
+        * vectors -- K4 makes R, K5-in-K1 makes the next AP -- in two launches, planes 0 and np-1 first (*_BND), then the
+        * exchange starts, then planes 1 .. np-2 (*_INT, which also collapses both launches' partial sums). */
+       EC3D_STAGE_K4F_BND = 15, EC3D_STAGE_K4F_INT = 16, EC3D_STAGE_K5F_BND = 17, EC3D_STAGE_K5F_INT = 18 };
 int ec3d_dist_step(ec3d_handle h, int32_t stage, int32_t it, double tolerance);
 /* Device-row ranges [lo, hi) this rank sends AND receives in a halo exchange (the first/last owned planes
  * of every block; the halo rows of an extended slab, which the interior launch must not overwrite once
@@ -307,7 +312,8 @@ int ec3d_multi_api_calls(ec3d_multi_handle mh, int32_t rank, double *per_iterati
 /* The schedule the job runs (one value for all ranks: the exchanges are part of it).  plan: 0 = five launches, halo
  * exchange in front of K1 and K3; 1 = K1 / K3 as interior + boundary launch with the exchange behind the interior one;
  * 2 = K2 / K5 boundary tiles first (A-V slabs); 3 = three launches per iteration (K2 inside K3, K4 as an SpMV kernel, K5
- * inside the next K1 -- every rank >= 32 Mi rows of the single-component operator): AP and R travel instead of P and S.
+ * inside the next K1 -- every rank >= 32 Mi rows of the single-component operator): AP and R travel instead of P and S;
+ * 4 = the same with K4 and K5-in-K1 -- the producers of R and AP -- as boundary + interior launch around the exchange.
  * x_every: iterations between two applications of X = X + alpha*P + omega*S (src/solvers.f90:41; 1 = every iteration). */
 int ec3d_multi_plan(ec3d_multi_handle mh, int32_t *plan, int32_t *x_every);
 
@@ -432,6 +438,10 @@ int ec3d_device_synchronize(ec3d_handle h);
  * src/solvers.f90:27), in the list-directed format of the toolchain the reference is built with in this image (flang):
  * leading blank, shortest digits, " .5813987794206226" / " 16.27049629976871" / " 9.87654321E-03".  buf >= 40 bytes. */
 void ec3d_format_real8(double v, char *buf);
+/* List-directed output is compiler specific, and the reference's own Makefile builds with gfortran (src/Makefile:1-28),
+ * which writes the same value as one blank and G25.17E3: "   0.58139877942062257     ".  EC3D_PRINT_STYLE=gfortran makes the
+ * library print the itmax line that way (default: flang's, above); this is the formatter.  buf >= 40 bytes. */
+void ec3d_format_real8_gfortran(double v, char *buf);
 
 #ifdef __cplusplus
 }

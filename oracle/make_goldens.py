@@ -499,6 +499,17 @@ def case_g6f(which=("ec_src_move_hole", "LIM"), steps=4):
                          for k in range(len(fast))])
         gx["self_distance_steps"] = dist
         gx["iters_fast_steps"] = np.array([c["iter"] for c in fast], np.int32)
+        # ... and of every vector of the field_N.vtk files the fast-math build wrote meanwhile against the exact build's
+        # (sketches held in g6_*): what two runs of the reference's own program end up apart in the OUTPUT it writes
+        for fn, blob in sorted(fast[0]["vtk"].items()):
+            if not fn.startswith("field_"):
+                continue
+            for vname, v in vtk_vectors(blob).items():
+                key = f"vtk_{fn[:-4]}_{vname}_sketch"
+                if key in g6.files and float(np.linalg.norm(g6[key])) > 0.0:
+                    d = float(np.linalg.norm(O.count_sketch(v.astype(np.float64)) - g6[key]) / np.linalg.norm(g6[key]))
+                    gx[f"self_distance_{fn[:-4]}_{vname}"] = np.float64(d)
+                    print(stem, fn, vname, f"reference against itself: {d:.3e}", flush=True)
         print(stem, "fast-math build, iterations per step", gx["iters_fast_steps"], "exact build", g6["iters"],
               "distance per step", dist, flush=True)
         save("g6x_" + stem + name, **gx)

@@ -49,9 +49,16 @@ def test_one_json_line_with_the_agreed_fields(args, ngpu):
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s"
     assert rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"])
     assert "traffic" in rf
+    assert rf["byte_model"] == "format"                     # dictionary storage: NOT SURVEY 8d's plain-DIA byte model
     if ngpu == 1 and "--force-dist" not in args:           # the north-star SpMV figure travels in the driver-run line
         sd = d["spmv_dia"]
         assert sd["bytes_per_row"] == 72 and sd["ms"] > 0 and sd["frac"] == pytest.approx(sd["GBps"] / 8000.0)
+        it = d["iter_dia"]                                  # ... and the whole iteration on SURVEY 8d's exact model
+        assert it["byte_model"] == "survey_8d" and it["bytes_per_dof_iter"] == 264 and it["x_update_every"] == 1
+        assert it["fusion"] == [0, 0] and set(it["kernels"]) == {"k1", "k2", "k3", "k4", "k5"}
+        assert it["frac"] == pytest.approx(264 * 64 ** 3 / (it["ms_per_step"] * 1e-3) / 8e12, rel=1e-6)
+    if "--force-dist" in args:                              # one process per GPU: the C++ loop over RCCL says what it costs
+        assert d["host"]["enqueue_ms_per_iteration"] > 0 and d["host"]["api_calls_per_iteration"] > 5
     if "--devices" in args or "--force-dist" in args:      # both multi-GPU paths check their transport before timing
         assert "bit for bit" in d["verified"]
 
@@ -75,6 +82,10 @@ def test_headline_line_carries_the_av_and_256_sub_records():
     assert d["kernels"]["k3"]["bytes_per_row"] == 25 and d["config"]["bytes_per_dof_iter"]["this_format"] == 117.0
     pl = d["spmv_dia"]["placement"]
     assert 1 <= len(pl["candidate_us"]) <= 8 and 0 <= pl["kept"] < len(pl["candidate_us"])
+    it = d["iter_dia"]         # SURVEY 8d's 264 B per DOF*iter, plain DIA, five launches, driver-timed (200 iterations)
+    assert it["steps"] == 200 and it["x_update_every"] == 1 and it["fusion"] == [0, 0]
+    assert 0.55 < it["frac"] < 0.9 and it["frac"] == pytest.approx(264 * 512 ** 3 / (it["ms_per_step"] * 1e-3) / 8e12, rel=1e-6)
+    assert d["roofline"]["byte_model"] == "format" 
     for name, n, lo in (("av", 21391776, 2.0e10), ("cube256", 256 ** 3, 2.5e10)):
         s = d[name]
         assert "error" not in s, s

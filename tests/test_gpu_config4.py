@@ -177,7 +177,8 @@ def test_first_iterates_track_the_reference_solver_at_full_size(E):
 def test_slab_shapes_of_the_cube_at_the_library_policy_bitwise(E, oracle, world, fused, monkeypatch):
     """The slabs of the 512^3 cube as 2, 4 and 8 GPUs hold them -- 512 x 512 x 256 / x 128 / x 64 -- at the plan and the
     policies the library picks BY ITSELF (nothing forced): from 32 Mi rows per rank three launches per iteration with AP
-    and R exchanged (plan 3), below that five launches with K1 / K3 split around the exchange (plan 1); X every fourth
+    and R exchanged behind the boundary launches of their producers (plan 4), below that five launches with K1 / K3 split
+    around the exchange (plan 1); X every fourth
     iteration on both.  To keep the twin affordable the grid holds TWO such slabs (the kernels, plans and per-rank sizes
     are those of the full cube; the cube itself on 8 slabs is the test above): four iterations of
     src/solvers.f90:24-50 against the oracle's multi-rank twin, x bit for bit."""
@@ -195,7 +196,7 @@ def test_slab_shapes_of_the_cube_at_the_library_policy_bitwise(E, oracle, world,
     with E.EC3DMulti(2, devices=[0, 0]) as m:
         m.assemble_poisson(N, N, sdz)
         plan, xd = m.plan()
-        assert plan == (3 if fused else 1) and xd == 4
+        assert plan == (4 if fused else 1) and xd == 4
         x, it = m.solve(b, x0, 1e-30, iters - 1)
         slabs = [(m.slab(r)[0], m.slab(r)[1] * kdz, m.slab(r)[2] * kdz) for r in range(2)]
         xo, ito, _, _, _ = oracle.twin_solve_slabs(slabs, plan, valA, irow, jcol, b, x0, 1e-30, iters - 1)

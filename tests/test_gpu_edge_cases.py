@@ -143,3 +143,42 @@ def test_assembly_stops_where_the_reference_stops(E, oracle, case, structured):
         assert f"({code})" in str(err.value), (str(err.value), code)
         s.assemble(g["geoPHYS"], g["geoPHYS_C"], g["valPHYS"], g["BND"], g["delta"], float(g["dt"]))   # still usable
         assert s.n == len(g["irow"]) - 1
+
+
+def test_parked_band_placement_is_reused_once_and_released(E):
+    """Plain band streams of >= 32 Mi rows get a placement probe at set-up (place_bands); the chosen
+    allocation is parked when the matrix is replaced and handed back to the next matrix of the same size (no second probe,
+    no transient second copy), and released as soon as a matrix arrives that does not take it (another size, another
+    storage).  A*x and a short solve on the re-assembled handle equal a fresh handle's bit for bit; the device memory
+    the parked copy held (3.7 GB here) is free again afterwards."""
+    import torch
+    sdx, sdy, sdz = 512, 512, 128
+    n = sdx * sdy * sdz
+    rng = np.random.Generator(np.random.PCG64(31))
+    x = rng.standard_normal(n)
+    b = rng.standard_normal(n)
+    with E.EC3DSolver(dictionary=False) as fresh:
+        fresh.assemble_poisson(sdx, sdy, sdz)
+        y_ref = fresh.spmv(x)
+        x_ref, it_ref, _ = fresh.solve(b, np.zeros(n), 1e-30, 4)
+    with E.EC3DSolver(dictionary=False) as s:
+        s.assemble_poisson(sdx, sdy, sdz)
+        first = s.band_placement()
+        assert len(first[0]) >= 1 and 0 <= first[1] < len(first[0])
+        s.assemble_poisson(sdx, sdy, sdz)                    # the same size again: the parked allocation comes back
+        assert s.band_placement() == first                   # no new probe
+        assert np.array_equal(s.spmv(x), y_ref)
+        x2, it2, _ = s.solve(b, np.zeros(n), 1e-30, 4)
+        assert it2 == it_ref == 5 and np.array_equal(x2, x_ref)
+        torch.cuda.synchronize()
+        free_with_bands = torch.cuda.mem_get_info()[0]
+        s.assemble_poisson(256, 256, 64)                     # another size: nothing parked may survive
+        xs = rng.standard_normal(256 * 256 * 64)
+        with E.EC3DSolver(dictionary=False) as small:
+            small.assemble_poisson(256, 256, 64)
+            assert np.array_equal(s.spmv(xs), small.spmv(xs))
+        torch.cuda.synchronize()
+        free_small = torch.cuda.mem_get_info()[0]
+        # the large system held 7 band streams + 8 work vectors + 7 ring buffers of 8 n bytes each: all of it must be free
+        # again; a parked copy of the band streams (7 of the 22) would leave the difference at 15
+        assert free_small - free_with_bands > 8 * n * 18.5

@@ -15,7 +15,7 @@ Tolerances.  SURVEY section 8d: ||x_gpu - x_ref||_2 / ||x_ref||_2 <= 10*tol -- b
 residual of tol = 5e-3 (src/solvers.f90:34, :43), and fields derived from x inherit the bar.  Single entries
 may differ by more than that fraction of the largest entry (printed, not asserted: the bar is a 2-norm, and the
 systems are ill conditioned enough that two 5e-3 solutions differ visibly).  The bar is asserted as it stands; the
-three entries that exceed it are listed one by one in KNOWN_EXCEEDANCES with their measured values.  What is asserted strictly is what the
+three entries that exceed it are listed one by one in KNOWN_EXCEEDANCES, each bounded by 1.5 x the distance the reference lands from ITSELF on that entry (tests/golden/g6x_*).  What is asserted strictly is what the
 algorithm promises: the TRUE residual ||b - A x|| / ||b|| of every GPU solution, computed on the device, is
 below tol.  Iteration counts are printed side by side; at these sizes unpreconditioned BiCGSTAB's path is not
 reproducible under re-association of the dot products (the reference's own
@@ -33,19 +33,32 @@ CASES = {"ec_src_move_hole": ("g6_ec_src_move_hole_256x256x60", 50),
          "LIM": ("g6_LIM_384x192x128", 200)}
 
 # SURVEY section 8d's bar, ||x_gpu - x_ref||_2 / ||x_ref||_2 <= 10*tol, is what every step and every field is held
-# to -- except the entries listed here, each with the value measured on the MI355X (round 3; the reduction order of
-# the kernels is fixed, so the numbers reproduce) and, for orientation, how far the REFERENCE lands from ITSELF on
-# the same solve when only its summation order changes (-O3 -ffast-math build of src/solvers.f90, tests/golden/g6x_*).
-# Asserted for a listed entry: measured value + 15 %.  Nothing else may exceed 10*tol; a new exceedance fails.
+# to -- except the entries listed here.  Each is bounded by a number the REFERENCE holds, not by anything the GPU produced:
+# 1.5 x the distance the reference lands from ITSELF on the same solve / the same output vector when only its summation
+# order changes (the same program with src/solvers.f90 built -O3 -ffast-math, oracle/make_goldens.py case_g6f:
+# tests/golden/g6x_*: self_distance_steps per time step, self_distance_field_N_<vector> per vector of field_N.vtk).  The
+# values measured on the MI355X (the kernels' reduction order is fixed, so they reproduce) are kept beside them for the
+# record.  Nothing else may exceed 10*tol; a new exceedance fails.
 KNOWN_EXCEEDANCES = {
     ("ec_src_move_hole", "x", 0): 0.1313,                            # the reference against itself: 0.102
-    ("ec_src_move_hole", "field_2", "Vector_field_eddy"): 0.0660,    # derived from x of steps 1 and 2 (4.3e-2, 4.0e-2)
+    ("ec_src_move_hole", "field_2", "Vector_field_eddy"): 0.0660,    # the reference against itself: 0.0714
     ("LIM", "x", 3): 0.0516,                                         # the reference against itself: 0.054
 }
+SELF_FACTOR = 1.5
 
 
-def _bar(tol, *key):
-    return 1.15 * KNOWN_EXCEEDANCES[key] if key in KNOWN_EXCEEDANCES else 10 * tol
+def _self_distance(case, *key):
+    """The reference-against-itself distance of a listed entry, from the g6x fixture."""
+    gx = load_golden(CASES[case][0].replace("g6_", "g6x_"))
+    if key[0] == "x":
+        return float(gx["self_distance_steps"][key[1]])
+    return float(gx[f"self_distance_{key[0]}_{key[1]}"])
+
+
+def _bar(tol, case, *key):
+    if (case,) + key in KNOWN_EXCEEDANCES:
+        return SELF_FACTOR * _self_distance(case, *key)
+    return 10 * tol
 
 
 def _have(case):

@@ -8,6 +8,8 @@ device 0: the same code with local copies instead of xGMI ones) runs one of four
   2  K2 / K5 boundary tiles first (A-V slabs; pinned elsewhere against the staged driver and the reference's captures)
   3  three launches per iteration -- K2 inside K3, K4 as an SpMV kernel that computes A S again, K5 inside the next K1 --
      with AP and R exchanged instead of P and S, S and P formed on the halo planes by the kernels that read them there
+  4  plan 3 with the producers of R and AP (K4, K5-in-K1) as a boundary launch (planes 0 and np-1) and an interior launch,
+     the exchange behind the boundary launch
 
 and, on every plan, X = X + alpha*P + omega*S (src/solvers.f90:41) applied every D-th iteration from rings of P and S.
 oracle.twin_solve_slabs restates src/solvers.f90:3-50 on the WHOLE system and sums every dot product the way the slabs
@@ -21,7 +23,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-KNOBS = ("EC3D_NT", "EC3D_KEEP", "EC3D_FUSE23", "EC3D_FUSE51", "EC3D_PATCH", "EC3D_NBLK", "EC3D_NBLK_SPMV", "EC3D_VEC_DEPTH",
+KNOBS = ("EC3D_SLAB_FSPLIT", "EC3D_NT", "EC3D_KEEP", "EC3D_FUSE23", "EC3D_FUSE51", "EC3D_PATCH", "EC3D_NBLK", "EC3D_NBLK_SPMV", "EC3D_VEC_DEPTH",
          "EC3D_XCD_MAP", "EC3D_ZMARCH", "EC3D_XDEFER", "EC3D_XD_OFF_DEPTH", "EC3D_XD_ON_DEPTH", "EC3D_K4S", "EC3D_SLAB_FUSE",
          "EC3D_SLAB_XDEFER")
 
@@ -57,13 +59,14 @@ FUSED = dict(FUSE23=2, FUSE51=2, K4S=2)
 
 @pytest.mark.parametrize("world", [2, 3, 4])
 @pytest.mark.parametrize("xd", [1, 4])
-@pytest.mark.parametrize("nt", [0, 1])
-def test_three_launch_iteration_on_slabs_bitwise(E, oracle, monkeypatch, world, xd, nt):
-    """Plan 3 on 2, 3 and 4 slabs (uneven cuts included: 50 planes over 3 and 4 ranks), with the X update in every iteration
-    and every fourth, cacheable and nontemporal streams: converged solves with both exits available, restarts counted."""
+@pytest.mark.parametrize("nt, fsplit", [(0, 1), (1, 1), (0, 0)])
+def test_three_launch_iteration_on_slabs_bitwise(E, oracle, monkeypatch, world, xd, nt, fsplit):
+    """Plans 3 and 4 on 2, 3 and 4 slabs (uneven cuts included: 50 planes over 3 and 4 ranks), with the X update in every
+    iteration and every fourth, cacheable and nontemporal streams: converged solves with both exits available."""
     sdx, sdy, sdz = 128, 8, 50
     n, kdz = sdx * sdy * sdz, sdx * sdy
-    set_knobs(monkeypatch, XDEFER=xd, NT=nt, **FUSED)
+    set_knobs(monkeypatch, XDEFER=xd, NT=nt, SLAB_FSPLIT=fsplit, **FUSED)
+    P3 = 4 if fsplit else 3
     valA, irow, jcol = oracle.poisson_csr(sdx, sdy, sdz)
     rng = np.random.Generator(np.random.PCG64(500 + world))
     b = rng.standard_normal(n)
@@ -71,17 +74,18 @@ def test_three_launch_iteration_on_slabs_bitwise(E, oracle, monkeypatch, world, 
     tol = 1e-6
     with E.EC3DMulti(world, devices=[0] * world) as m:
         m.assemble_poisson(sdx, sdy, sdz)
-        assert m.plan() == (3, xd)
+        assert m.plan() == (P3, xd)
         v0 = m.slab(0)[0]
         assert v0.fusion() == (1, 1) and v0.k4_as_spmv() and v0.x_interval() == xd
+        assert np.array_equal(m.spmv(x0), oracle.spmv_csr(valA, irow, jcol, x0))      # (the probe's exchange: plain vectors)
         x, it = m.solve(b, x0, tol, 5000)
         rs = restarts_of(m)
-        xo, ito, _, _, rso = oracle.twin_solve_slabs(slabs_of(m, kdz), 3, valA, irow, jcol, b, x0, tol, 5000)
+        xo, ito, _, _, rso = oracle.twin_solve_slabs(slabs_of(m, kdz), P3, valA, irow, jcol, b, x0, tol, 5000)
         # a second solve on the same handle, warm-started from the first one's solution
         x2, it2 = m.solve(b, x, tol, 5000)
-        xo2, ito2, _, _, _ = oracle.twin_solve_slabs(slabs_of(m, kdz), 3, valA, irow, jcol, b, xo, tol, 5000)
+        xo2, ito2, _, _, _ = oracle.twin_solve_slabs(slabs_of(m, kdz), P3, valA, irow, jcol, b, xo, tol, 5000)
     res = np.linalg.norm(b - oracle.spmv_csr(valA, irow, jcol, x)) / np.linalg.norm(b)
-    print(f"{world} slabs, three launches, X every {xd}, nt {nt}: iter {it} (twin {ito}), restarts {rs[0]} (twin {rso}), "
+    print(f"{world} slabs, plan {P3}, X every {xd}, nt {nt}: iter {it} (twin {ito}), restarts {rs[0]} (twin {rso}), "
           f"true residual {res:.2e}")
     assert it == ito and np.array_equal(x, xo)
     assert all(r == rso for r in rs)
@@ -106,7 +110,7 @@ def test_restart_rule_on_slabs(E, oracle, monkeypatch, fused):
     with E.EC3DMulti(3, devices=[0, 0, 0]) as m:
         m.assemble_poisson(sdx, sdy, sdz)
         plan = m.plan()[0]
-        assert plan == (3 if fused else 1)
+        assert plan == (4 if fused else 1)
         x, it = m.solve(b, x0, tol, 5000)
         rs = restarts_of(m)
         xo, ito, _, _, rso = oracle.twin_solve_slabs(slabs_of(m, kdz), plan, valA, irow, jcol, b, x0, tol, 5000)
@@ -154,7 +158,7 @@ def test_itmax_exit_at_every_position_of_a_group(E, oracle, monkeypatch, fused):
     with E.EC3DMulti(2, devices=[0, 0]) as m:
         m.assemble_poisson(sdx, sdy, sdz)
         plan = m.plan()[0]
-        assert plan == (3 if fused else 1)
+        assert plan == (4 if fused else 1)
         for k in range(1, 10):
             x, it = m.solve(b, x0, 1e-30, k - 1)
             xo, ito, _, _, _ = oracle.twin_solve_slabs(slabs_of(m, kdz), plan, valA, irow, jcol, b, x0, 1e-30, k - 1)
@@ -174,7 +178,9 @@ def test_s_exit_with_updates_pending(E, oracle, monkeypatch):
     x0 = np.zeros(n)
     with E.EC3DMulti(2, devices=[0, 0]) as m:
         m.assemble_poisson(sdx, sdy, sdz)
-        _, _, hs, hr, _ = oracle.twin_solve_slabs(slabs_of(m, kdz), 3, valA, irow, jcol, b, x0, 1e-30, 13, hist_cap=14)
+        P3 = m.plan()[0]
+        assert P3 == 4
+        _, _, hs, hr, _ = oracle.twin_solve_slabs(slabs_of(m, kdz), P3, valA, irow, jcol, b, x0, 1e-30, 13, hist_cap=14)
         bn = np.linalg.norm(b)
         seen = set()
         for k in range(2, 13):
@@ -182,7 +188,7 @@ def test_s_exit_with_updates_pending(E, oracle, monkeypatch):
             lo, hi = sorted((hs[k - 1], hr[k - 2]))
             tol = 0.5 * (lo + hi) / bn
             x, it = m.solve(b, x0, tol, 100)
-            xo, ito, _, _, _ = oracle.twin_solve_slabs(slabs_of(m, kdz), 3, valA, irow, jcol, b, x0, tol, 100)
+            xo, ito, _, _, _ = oracle.twin_solve_slabs(slabs_of(m, kdz), P3, valA, irow, jcol, b, x0, tol, 100)
             assert it == ito and np.array_equal(x, xo), k
             seen.add((it - 1) % 4)
     assert len(seen) >= 3       # exits at several positions of a group of four

@@ -166,3 +166,29 @@ def test_itmax_line_is_written_the_way_the_reference_toolchain_writes_it(oracle)
             buf = C.create_string_buffer(64)
             fn(v, buf)
             assert buf.value.decode() == want, (hx, fn)
+
+
+def test_itmax_line_in_gfortran_style():
+    """List-directed output is compiler specific: the reference's own Makefile builds with gfortran (src/Makefile:1-28),
+    which writes a REAL(8) as one blank and G25.17E3.  EC3D_PRINT_STYLE=gfortran selects this formatter for the itmax line
+    (src/solvers.f90:27); no gfortran exists in this image, so the expectations are the edit descriptor's rules: 17
+    significant digits, F editing with five trailing blanks for 0.1 <= |x| < 10^17, d.dddE+eee otherwise, 26 characters."""
+    import ctypes as C
+    import eddy_currents_3d_amd as E
+    L = E.load_library()
+    L.ec3d_format_real8_gfortran.argtypes = [C.c_double, C.c_char_p]
+    L.ec3d_format_real8_gfortran.restype = None
+
+    def f(v):
+        buf = C.create_string_buffer(64)
+        L.ec3d_format_real8_gfortran(v, buf)
+        return buf.value.decode()
+    assert f(0.5813987794206226) == "  0.58139877942062257     "
+    assert f(1.0e-5) == "   1.0000000000000001E-005"
+    assert f(1.0) == "   1.0000000000000000     "
+    assert f(-16.27049629976871) == "  -16.270496299768709     "
+    assert f(0.0) == "   0.0000000000000000     "
+    assert f(1.0e17).strip() == "1.0000000000000000E+017"
+    for v in (3.14159, 2.5e10, 7e-300, 123456789.125, 0.1, 0.099999999):
+        s = f(v)
+        assert len(s) == 26 and float(s) == v
