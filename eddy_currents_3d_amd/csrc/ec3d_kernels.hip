@@ -128,6 +128,75 @@ __device__ __forceinline__ void partials_finish(const RedSrc &src, const int (&s
     block_sum<NV>(out, lds);
 }
 
+// A producer's workgroup leaves its partial sums.  Single rank: a plain store; the consumer kernel re-reduces them.
+// Multi rank (fold_lsum != nullptr: a z-slab whose sums the other ranks read, csrc/ec3d_multi.hip / dist.py): the LAST
+// workgroup of the launch to arrive also collapses ALL the kernel's partials -- an earlier launch's of a split kernel
+// included: count = part_off + gridDim.x -- into lsum[slot], in exactly the order of the one-workgroup k_finalize launch
+// that used to follow every producer (thread t adds values t, t + 256, ..., then the block tree): the same bits, four
+// launches per iteration less.  Round 1 tried this with a device-wide fence per workgroup and lost a factor of two (every
+// workgroup's release wrote the XCD's L2 back).  Here nothing is flushed: the partial is stored write-through (agent
+// scope), its completion waited for, the arrival counted with relaxed atomics -- per blockIdx % 8 first, so that at most
+// an eighth of the workgroups meet on one counter, then once per group -- and the last workgroup reads the partials with
+// agent-scope loads, which do not trust a stale L2 line.  The counters are zero again when the launch ends.
+template <int NV, class SW>
+__device__ __forceinline__ void publish_partials(const SW &sw, double *part, const int (&slot)[NV], const double (&acc)[NV],
+                                                 double *lds)
+{
+    if (sw.fold_lsum == nullptr) {
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) part[slot[k] * sw.pstride + sw.part_off + blockIdx.x] = acc[k];
+        }
+        return;
+    }
+    __shared__ int fold_last;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k)
+            __hip_atomic_store(&part[slot[k] * sw.pstride + sw.part_off + blockIdx.x], acc[k], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the write-through stores above have been acknowledged
+        asm volatile("" ::: "memory");
+        const unsigned x = blockIdx.x & 7u, n = gridDim.x;
+        const unsigned mine = (n - x + 7u) >> 3; // workgroups of this launch with blockIdx % 8 == x
+        int last = 0;
+        if (__hip_atomic_fetch_add(&sw.fold_cnt[x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == mine - 1u) {
+            const unsigned groups = n < 8u ? n : 8u;
+            last = __hip_atomic_fetch_add(&sw.fold_cnt[8], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groups - 1u;
+        }
+        fold_last = last;
+    }
+    __syncthreads();
+    if (!fold_last) return;
+    if (threadIdx.x < 9) __hip_atomic_store(&sw.fold_cnt[threadIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int count = sw.part_off + (int)gridDim.x;
+    // every load of the collapse is requested before the first value is added (a thread adds up to eight values per slot:
+    // as a chain of dependent agent-scope loads that was eight trips to memory, 10-15 us behind the last workgroup)
+    constexpr int FMAX = 8;
+    double e[NV][FMAX];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const double *p = part + (int64_t)slot[k] * sw.pstride;
+#pragma unroll
+        for (int j = 0; j < FMAX; ++j) {
+            const int i = (int)threadIdx.x + j * EC3D_THREADS;
+            e[k][j] = __hip_atomic_load(&p[i < count ? i : 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) { // slot by slot, as k_finalize: reduce_partials<1> of each, the same order of additions
+        double v[1] = {0.0};
+        const double *p = part + (int64_t)slot[k] * sw.pstride;
+#pragma unroll
+        for (int j = 0; j < FMAX; ++j)
+            if ((int)threadIdx.x + j * EC3D_THREADS < count) v[0] = v[0] + e[k][j];
+        for (int i = (int)threadIdx.x + FMAX * EC3D_THREADS; i < count; i += EC3D_THREADS)
+            v[0] = v[0] + __hip_atomic_load(&p[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        block_sum<1>(v, lds);
+        if (threadIdx.x == 0) sw.fold_lsum[slot[k]] = v[0];
+    }
+}
+
 // Streams that are touched once per launch use the nontemporal (streaming) cache policy when the
 // vectors are far larger than the 256 MiB Infinity Cache (NT = true): on a 512^3 grid that is worth
 // +10..25 % on the pure vector stages (tools/stream_bench.hip).  Small problems keep the default
@@ -208,6 +277,8 @@ struct SweepZ {
     int hs_mask, hs_last; // z-slab, K2-in-K3 / K5-in-K1: store the formed vector on the halo planes (Sweep::halo_store);
                           // hs_last = the slab's last owned plane
     int pstride, part_off;
+    double *fold_lsum;   // multi rank: the last workgroup collapses the kernel's partials into fold_lsum[slot] (publish_partials)
+    unsigned *fold_cnt;  // its arrival counters (9, zero between launches)
     int ulist_n;
     const int32_t *ulist;
     int64_t win_npo, win_npb, win_p0; // window in planes (owned per block, held per block, first owned); npo = 0: none
@@ -225,6 +296,8 @@ struct SweepV {
     int64_t ntiles, n;
     int S, nblk;
     int pstride, part_off;
+    double *fold_lsum;   // (see SweepZ)
+    unsigned *fold_cnt;
     int ulist_n, two;
     const int32_t *ulist;
     int64_t win_nt, win_blk, win_t0;
@@ -1436,9 +1509,9 @@ EC3D_SPMV_T __global__ __launch_bounds__(EC3D_THREADS) EC3D_SPMV_OCC void k_resi
         acc[1] = acc[1] + e1 * e1;
     });
     block_sum<2>(acc, lds);
-    if (threadIdx.x == 0) {
-        part[P_BB * sw.pstride + sw.part_off + blockIdx.x] = acc[0];
-        part[P_RR_INIT * sw.pstride + sw.part_off + blockIdx.x] = acc[1];
+    {
+        const int pslot_[2] = {P_BB, P_RR_INIT};
+        publish_partials<2>(sw, part, pslot_, acc, lds);
     }
 }
 
@@ -1545,7 +1618,10 @@ EC3D_SPMV_T __global__ __launch_bounds__(EC3D_THREADS) EC3D_SPMV_OCC void k1_spm
         acc[0] = acc[0] + s1 * q.y;
     });
     block_sum<1>(acc, lds);
-    if (threadIdx.x == 0) part[P_D1 * sw.pstride + sw.part_off + blockIdx.x] = acc[0];
+    {
+        const int pslot_[1] = {P_D1};
+        publish_partials<1>(sw, part, pslot_, acc, lds);
+    }
 }
 
 // K2: alpha = rr0 / (AP·R0) ; S = R - alpha*AP ; partial S·S   (src/solvers.f90:31-34)
@@ -1582,7 +1658,10 @@ __global__ __launch_bounds__(EC3D_THREADS) void k2_s_update(SweepV sw, RedSrc sr
         acc[0] = acc[0] + s1 * s1;
     });
     block_sum<1>(acc, lds);
-    if (threadIdx.x == 0) part[P_SS * sw.pstride + sw.part_off + blockIdx.x] = acc[0];
+    {
+        const int pslot_[1] = {P_SS};
+        publish_partials<1>(sw, part, pslot_, acc, lds);
+    }
 }
 
 // K3: AS = A S ; partials AS·S and AS·AS (src/solvers.f90:39-40).  Launched before ‖S‖ is known
@@ -1618,9 +1697,9 @@ EC3D_SPMV_T __global__ __launch_bounds__(EC3D_THREADS) EC3D_SPMV_OCC void k3_spm
         acc[1] = acc[1] + s1 * s1;
     });
     block_sum<2>(acc, lds);
-    if (threadIdx.x == 0) {
-        part[P_D2 * sw.pstride + sw.part_off + blockIdx.x] = acc[0];
-        part[P_D3 * sw.pstride + sw.part_off + blockIdx.x] = acc[1];
+    {
+        const int pslot_[2] = {P_D2, P_D3};
+        publish_partials<2>(sw, part, pslot_, acc, lds);
     }
 }
 
@@ -1685,10 +1764,9 @@ __global__ __launch_bounds__(EC3D_THREADS) __attribute__((amdgpu_waves_per_eu(4)
         acc[2] = acc[2] + s1 * s1;
     });
     block_sum<3>(acc, lds);
-    if (threadIdx.x == 0) {
-        part[P_SS * sw.pstride + sw.part_off + blockIdx.x] = acc[0];
-        part[P_D2 * sw.pstride + sw.part_off + blockIdx.x] = acc[1];
-        part[P_D3 * sw.pstride + sw.part_off + blockIdx.x] = acc[2];
+    {
+        const int pslot_[3] = {P_SS, P_D2, P_D3};
+        publish_partials<3>(sw, part, pslot_, acc, lds);
     }
 }
 
@@ -1766,7 +1844,10 @@ __global__ __launch_bounds__(EC3D_THREADS) __attribute__((amdgpu_waves_per_eu(4)
         acc[0] = acc[0] + s1 * q.y;
     });
     block_sum<1>(acc, lds);
-    if (threadIdx.x == 0) part[P_D1 * sw.pstride + sw.part_off + blockIdx.x] = acc[0];
+    {
+        const int pslot_[1] = {P_D1};
+        publish_partials<1>(sw, part, pslot_, acc, lds);
+    }
 }
 
 // K4: if ‖S‖/Bnorm < tol: X += alpha*P, exit (src/solvers.f90:34-38); else
@@ -1835,9 +1916,9 @@ __global__ __launch_bounds__(EC3D_THREADS) void k4_x_r_update(SweepV sw, RedSrc 
         acc[1] = acc[1] + e1 * q.y;
     });
     block_sum<2>(acc, lds);
-    if (threadIdx.x == 0) {
-        part[P_RR * sw.pstride + sw.part_off + blockIdx.x] = acc[0];
-        part[P_RR0N * sw.pstride + sw.part_off + blockIdx.x] = acc[1];
+    {
+        const int pslot_[2] = {P_RR, P_RR0N};
+        publish_partials<2>(sw, part, pslot_, acc, lds);
     }
 }
 
@@ -1943,9 +2024,9 @@ __global__ __launch_bounds__(EC3D_THREADS) void k4d_x_r_update(SweepV sw, RedSrc
         acc[1] = acc[1] + e1 * q.y;
     });
     block_sum<2>(acc, lds);
-    if (threadIdx.x == 0) {
-        part[P_RR * sw.pstride + sw.part_off + blockIdx.x] = acc[0];
-        part[P_RR0N * sw.pstride + sw.part_off + blockIdx.x] = acc[1];
+    {
+        const int pslot_[2] = {P_RR, P_RR0N};
+        publish_partials<2>(sw, part, pslot_, acc, lds);
     }
 }
 
@@ -2061,9 +2142,9 @@ __global__ __launch_bounds__(EC3D_THREADS) __attribute__((amdgpu_waves_per_eu(NE
         acc[1] = acc[1] + e1 * q.y;
     });
     block_sum<2>(acc, lds);
-    if (threadIdx.x == 0) {
-        part[P_RR * sw.pstride + sw.part_off + blockIdx.x] = acc[0];
-        part[P_RR0N * sw.pstride + sw.part_off + blockIdx.x] = acc[1];
+    {
+        const int pslot_[2] = {P_RR, P_RR0N};
+        publish_partials<2>(sw, part, pslot_, acc, lds);
     }
 }
 
@@ -2251,6 +2332,8 @@ static inline SweepZ sweep_z(const Sweep &sw)
     z.hs_last = sw.zm_tpp > 0 ? (int)(sw.ntiles / sw.zm_tpp) - 1 : 0;
     z.pstride = sw.pstride;
     z.part_off = sw.part_off;
+    z.fold_lsum = sw.fold_lsum;
+    z.fold_cnt = sw.fold_cnt;
     z.ulist_n = sw.ulist_n;
     z.ulist = sw.ulist;
     z.win_npo = sw.win_nt > 0 ? sw.win_nt / sw.zm_tpp : 0;
@@ -2323,6 +2406,8 @@ static inline SweepV sweep_v(const Sweep &sw)
     v.nblk = sw.nblk;
     v.pstride = sw.pstride;
     v.part_off = sw.part_off;
+    v.fold_lsum = sw.fold_lsum;
+    v.fold_cnt = sw.fold_cnt;
     v.ulist_n = sw.ulist_n;
     v.two = sw.vec_depth;
     v.ulist = sw.ulist;

@@ -767,12 +767,16 @@ int finish_setup(ec3d_multi *m)
         c->slab_xd = xd;
         c->sweep_s.halo_store = fused ? ((s.rank > 0 ? 1 : 0) | (s.rank + 1 < m->world ? 2 : 0)) : 0;
         c->sweep_fb.halo_store = c->sweep_fi.halo_store = c->sweep_s.halo_store;
+        ec3d_fold_configure(c);
         if (c->pp_base) c->pdepth = std::max(2, ec3d_xdefer(c)); // every rank cycles P through the same number of buffers
         s.plan = 0;
         s.split_ok = false;
-        if (m->kind == 1) {
+        // EC3D_SLAB_PLAN (the SAME value on every rank: plan 2 orders its exchanges differently) picks the five-launch plan of
+        // a single-component job: 0 exchange in front of K1 / K3, 1 K1 / K3 split around it, 2 K2 / K5 boundary tiles first
+        const int want_plan = getenv("EC3D_SLAB_PLAN") ? atoi(getenv("EC3D_SLAB_PLAN")) : -1;
+        if (m->kind == 1 && !(want_plan == 2 && !fused && m->world > 1)) {
             const bool no_fsplit = getenv("EC3D_SLAB_FSPLIT") && atoi(getenv("EC3D_SLAB_FSPLIT")) == 0;
-            s.plan = fused ? ((c->can_fsplit && !no_fsplit) ? 4 : 3) : ec3d_can_overlap(c) ? 1 : 0;
+            s.plan = fused ? ((c->can_fsplit && !no_fsplit) ? 4 : 3) : (ec3d_can_overlap(c) && want_plan != 0) ? 1 : 0;
         } else if (m->world > 1) {
             // the ORDER of exchanges is a property of the job: every A-V rank uses the producer-side
             // plan; a rank whose slab is all boundary runs the whole kernels in that order
@@ -785,7 +789,10 @@ int finish_setup(ec3d_multi *m)
                         hi.push_back(r.hi());
                     }
             int32_t en = 0;
-            if (!lo.empty()) {
+            if (m->kind == 1) { // the single-component operator: whole planes, window sweeps
+                int rc2 = ec3d_dist_set_boundary_planes(c, &en);
+                if (rc2) return rc2;
+            } else if (!lo.empty()) {
                 int rc2 = ec3d_dist_set_boundary_rows(c, (int32_t)lo.size(), lo.data(), hi.data(), &en);
                 if (rc2) return rc2;
             }

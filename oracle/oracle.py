@@ -220,15 +220,17 @@ def twin_solve_slabs(slabs, plan, valA, irow, jcol, b, x0, tol, itmax, hist_cap=
     launches the rank's handle reports: ec3d_get_visit_order; a split kernel's partials are the first launch's
     followed by the second's), collapsed by the 256-thread tree (k_finalize), and the ranks' sums added in rank order
     by the same tree (reduce_partials over one value per rank).  slabs: [(EC3DSolver view of the slab, row0, row1)] in
-    rank order, rows in the reference's numbering; plan: 0 plain, 1 K1 / K3 as interior + boundary launch, 3 three
+    rank order, rows in the reference's numbering; plan: 0 plain, 1 K1 / K3 as interior + boundary launch, 2 K2 / K5 as
+    boundary + interior launch, 3 three
     launches, 4 three launches with K4 and K5-in-K1 as boundary + interior launch (what EC3DMulti.plan() reports).
     Returns (x, iter, hist_s, hist_r, restarts)."""
     spmv_w = (3, 4) if plan == 1 else (1,)
+    ss_w = (5, 6) if plan == 2 else (2,)           # who sums S.S (plan 2: K2 as boundary + interior launch)
     k4_w = (7, 8) if plan == 4 else (0,)           # who sums R.R and R.R0
     k51_w = (7, 8) if plan == 4 else spmv_w        # who sums AP.R0 from the second iteration on (K5-in-K1 of the one before)
     geo = []
     for sv, lo, hi in slabs:
-        g = {w: geoms_of(sv, (w,))[0] for w in set((0, 1, 2) + spmv_w + k4_w + k51_w)}
+        g = {w: geoms_of(sv, (w,))[0] for w in set((0, 1) + ss_w + spmv_w + k4_w + k51_w)}
         geo.append((g, lo, hi))
 
     def dot(ws, u, v):
@@ -256,7 +258,7 @@ def twin_solve_slabs(slabs, plan, valA, irow, jcol, b, x0, tol, itmax, hist_cap=
         AP = spmv_csr(valA, irow, jcol, P)
         alpha = rr0 / dot(spmv_w if it == 1 else k51_w, AP, R0)   # K1 (or K5-in-K1 of the previous iteration)
         S = R - alpha * AP
-        nrm = np.sqrt(dot((2,), S, S))                       # K2 (or K2-in-K3)
+        nrm = np.sqrt(dot(ss_w, S, S))                       # K2 (or K2-in-K3)
         if it <= hist_cap:
             hs[it - 1] = nrm
         if nrm / bnorm < tol:

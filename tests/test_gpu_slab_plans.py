@@ -23,7 +23,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-KNOBS = ("EC3D_SLAB_FSPLIT", "EC3D_NT", "EC3D_KEEP", "EC3D_FUSE23", "EC3D_FUSE51", "EC3D_PATCH", "EC3D_NBLK", "EC3D_NBLK_SPMV", "EC3D_VEC_DEPTH",
+KNOBS = ("EC3D_SLAB_FSPLIT", "EC3D_SLAB_PLAN", "EC3D_FOLD", "EC3D_NT", "EC3D_KEEP", "EC3D_FUSE23", "EC3D_FUSE51", "EC3D_PATCH", "EC3D_NBLK", "EC3D_NBLK_SPMV", "EC3D_VEC_DEPTH",
          "EC3D_XCD_MAP", "EC3D_ZMARCH", "EC3D_XDEFER", "EC3D_XD_OFF_DEPTH", "EC3D_XD_ON_DEPTH", "EC3D_K4S", "EC3D_SLAB_FUSE",
          "EC3D_SLAB_XDEFER")
 
@@ -119,7 +119,8 @@ def test_restart_rule_on_slabs(E, oracle, monkeypatch, fused):
     assert rso > 0 and all(r == rso for r in rs)
 
 
-@pytest.mark.parametrize("plan, dims", [(1, (128, 8, 48)), (0, (24, 24, 24))], ids=["interior+boundary", "plain"])
+@pytest.mark.parametrize("plan, dims", [(1, (128, 8, 48)), (0, (24, 24, 24)), (2, (128, 8, 48)), (0, (128, 8, 48))],
+                         ids=["interior+boundary", "plain", "producers-split", "plain-zmarch"])
 @pytest.mark.parametrize("xd", [1, 3, 4])
 def test_five_launch_plans_with_deferred_x_bitwise(E, oracle, monkeypatch, plan, dims, xd):
     """Plans 0 and 1 (what the slabs of 512^3 on 8 GPUs run: 16 Mi rows per rank) with the X update every D-th iteration:
@@ -127,7 +128,7 @@ def test_five_launch_plans_with_deferred_x_bitwise(E, oracle, monkeypatch, plan,
     sdx, sdy, sdz = dims
     n, kdz = sdx * sdy * sdz, sdx * sdy
     world = 3
-    set_knobs(monkeypatch, XDEFER=xd)
+    set_knobs(monkeypatch, XDEFER=xd, SLAB_PLAN=plan)
     valA, irow, jcol = oracle.poisson_csr(sdx, sdy, sdz)
     rng = np.random.Generator(np.random.PCG64(77))
     b = rng.standard_normal(n)

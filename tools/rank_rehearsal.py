@@ -41,6 +41,11 @@ def run(N, sdz, G, r):
           + " ".join(f"{k}={v * 1e3:.0f}us" for k, v in km.items()), flush=True)
 
 
+if os.environ.get("REHEARSE_ONLY"):
+    for tok in os.environ["REHEARSE_ONLY"].split(";"):
+        N, sdz, G, r = (int(t) for t in tok.split(","))
+        run(N, sdz, G, r)
+    sys.exit(0)
 for G in (2, 4, 8):
     run(512, 512, G, G // 2)
 run(256, 256, 8, 3)
