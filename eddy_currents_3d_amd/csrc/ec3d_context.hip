@@ -178,8 +178,6 @@ extern "C" int ec3d_create(ec3d_handle *h, int device)
     EC3D_HIP(hipStreamCreateWithFlags(&c->own_stream_obj, hipStreamNonBlocking));
     c->stream = c->own_stream_obj;
     EC3D_HIP(hipMalloc(&c->state, sizeof(SolverState)));
-    EC3D_HIP(hipMalloc(&c->fold_cnt, 16 * sizeof(unsigned)));
-    EC3D_HIP(hipMemset(c->fold_cnt, 0, 16 * sizeof(unsigned)));
     EC3D_HIP(hipHostMalloc(&c->state_pinned, 2 * sizeof(SolverState), hipHostMallocDefault));
     for (int i = 0; i < 2; ++i) EC3D_HIP(hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming));
     EC3D_HIP(hipEventCreate(&c->t0));
@@ -244,7 +242,6 @@ void ec3d_free_matrix(ec3d_ctx *c)
     c->nranks = 1;
     c->lsum = c->gsum = nullptr;
     c->lsum_ptrs = nullptr;
-    c->fold_on = false;
     c->slab_fused = false;
     c->slab_xd = 0;
     ec3d_free_rhs(c);
@@ -273,7 +270,6 @@ extern "C" int ec3d_destroy(ec3d_handle c)
     c->placed_bands = nullptr;
     if (c->hist) (void)hipFree(c->hist);
     if (c->state) (void)hipFree(c->state);
-    if (c->fold_cnt) (void)hipFree(c->fold_cnt);
     if (c->state_pinned) (void)hipHostFree(c->state_pinned);
     for (int i = 0; i < 2; ++i)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);

@@ -40,25 +40,6 @@ extern "C" int ec3d_adopt_vectors(ec3d_handle c, double *base)
     return ec3d_spare_pair(c); // adopted vectors: no spare pair, the kernels of an iteration stay unfused
 }
 
-// Multi-rank mode: the sum-producing sweeps point at lsum, so that the last launch of every kernel collapses its partial sums
-// itself (publish_partials in ec3d_kernels.hip) and no k_finalize launch follows it.  The FIRST launch of a split kernel
-// (K1 / K3 interior, K2 / K5 boundary tiles, the boundary launch of the three-launch iteration's producers) leaves its
-// partials to the second.  EC3D_FOLD=0: the separate collapse launches of rounds 1-4.
-void ec3d_fold_configure(ec3d_ctx *c)
-{
-    bool on = c->dist && c->lsum != nullptr && c->fold_cnt != nullptr;
-    if (const char *e = getenv("EC3D_FOLD")) on = on && atoi(e) != 0;
-    c->fold_on = on;
-    for (Sweep *s : {&c->sweep, &c->sweep_k2, &c->sweep_k5, &c->sweep_s, &c->sweep_bnd, &c->sweep_vi, &c->sweep_fi}) {
-        s->fold_lsum = on ? c->lsum : nullptr;
-        s->fold_cnt = c->fold_cnt;
-    }
-    for (Sweep *s : {&c->sweep_int, &c->sweep_vb, &c->sweep_fb}) {
-        s->fold_lsum = nullptr;
-        s->fold_cnt = c->fold_cnt;
-    }
-}
-
 extern "C" int ec3d_dist_configure(ec3d_handle c, int32_t nranks, double *lsum_device, double *gsum_device)
 {
     if (nranks == 1 && !lsum_device && !gsum_device) { // back to the single-rank loop (ec3d_solve & co.)
@@ -66,7 +47,6 @@ extern "C" int ec3d_dist_configure(ec3d_handle c, int32_t nranks, double *lsum_d
         c->lsum = c->gsum = nullptr;
         c->lsum_ptrs = nullptr;
         c->dist = false;
-        ec3d_fold_configure(c);
         return 0;
     }
     if (nranks < 1 || !lsum_device || !gsum_device) {
@@ -77,7 +57,6 @@ extern "C" int ec3d_dist_configure(ec3d_handle c, int32_t nranks, double *lsum_d
     c->lsum = lsum_device;
     c->gsum = gsum_device;
     c->dist = true;
-    ec3d_fold_configure(c);
     return 0;
 }
 
@@ -126,7 +105,6 @@ extern "C" int ec3d_dist_set_boundary_rows(ec3d_handle c, int32_t nranges, const
     c->sweep_vb = list_sweep(c->vb_list, vb.size(), 256, 0);
     c->sweep_vi = list_sweep(c->vi_list, vi.size(), sw.nblk, c->sweep_vb.nblk);
     c->can_vsplit = true;
-    ec3d_fold_configure(c);
     if (enabled) *enabled = 1;
     return 0;
 }
@@ -165,7 +143,6 @@ int ec3d_dist_set_boundary_planes(ec3d_ctx *c, int32_t *enabled)
     c->sweep_vb = vb;
     c->sweep_vi = vi;
     c->can_vsplit = true;
-    ec3d_fold_configure(c);
     if (enabled) *enabled = 1;
     return 0;
 }
@@ -181,7 +158,6 @@ extern "C" int ec3d_dist_step(ec3d_handle c, int32_t stage, int32_t it, double t
     const MatView A = c->A.view();
     double **v = c->vec;
     auto fin = [&](int producer, unsigned mask, bool split = false) {
-        if (c->fold_on) return; // the producer's last workgroup has collapsed the partials already (publish_partials)
         ec3d_launch_finalize(ec3d_part_of(c, producer, split), c->lsum, mask, c->stream);
     };
     auto need_split = [&]() {
@@ -254,7 +230,7 @@ extern "C" int ec3d_dist_step(ec3d_handle c, int32_t stage, int32_t it, double t
         ec3d_launch_k2(bnd ? c->sweep_vb : c->sweep_vi, ec3d_src_of(c, EC3D_BY_SPMV), c->state, it, v[EC3D_VEC_R], v[EC3D_VEC_AP],
                        ec3d_vec_at(c, EC3D_VEC_S, it), c->partials, c->stream);
         c->scur = ec3d_xdefer(c) > 1 ? it % ec3d_xdefer(c) : 1;
-        if (!bnd && !c->fold_on)
+        if (!bnd)
             ec3d_launch_finalize(RedSrc{c->partials, c->sweep_vb.nblk + c->sweep_vi.nblk, 1, c->sweep.pstride, nullptr}, c->lsum,
                                  1u << P_SS, c->stream);
         break;
@@ -299,7 +275,7 @@ extern "C" int ec3d_dist_step(ec3d_handle c, int32_t stage, int32_t it, double t
 // that runs the three-launch iteration stages 1 and 2 are empty and stage 5 produces a sum
 int ec3d_dist_launches(const ec3d_ctx *c, int stage, int it)
 {
-    const int fin = c->fold_on ? 0 : 1; // the collapse launch behind a producer of sums
+    const int fin = 1; // the collapse launch behind a producer of sums
     switch (stage) {
     case EC3D_STAGE_K1: return (ec3d_fused51(c) && it != 1 && c->ap_valid_for == it) ? 0 : 1 + fin;
     case EC3D_STAGE_K2: return ec3d_fused23(c) ? 0 : 1 + fin;

@@ -120,11 +120,6 @@ struct Sweep {
     // bit 0: this slab has a lower z-neighbour (store the plane below plane 0), bit 1: an upper one (above the last plane)
     int halo_store;
     int part_off;  // first partial-sum index this launch writes within a slot
-    // multi rank: the launch's last workgroup collapses the kernel's partial sums (indices 0 .. part_off + nblk - 1 of every
-    // slot it produces) into fold_lsum[slot], what a k_finalize launch did before (publish_partials in ec3d_kernels.hip);
-    // nullptr: no (single rank; the first launch of a split kernel).  fold_cnt: nine arrival counters of the handle.
-    double *fold_lsum;
-    unsigned *fold_cnt;
     // structured A-V form: tiles [0, ntiles) are swept as usual (the three A blocks); of the tiles
     // behind them (the grid-shaped U block) only those holding an unknown are visited, from a list --
     // everything else there is identically zero in every vector and stays so
@@ -341,8 +336,6 @@ struct ec3d_ctx {
     int zm_request = 1;  // z-marching SpMV map when the grid allows it (EC3D_ZMARCH)
     int shuffle_request = 1; // +-1 neighbours by lane shuffle (EC3D_SHUFFLE)
     double *partials = nullptr; // 8 * nblk doubles
-    unsigned *fold_cnt = nullptr; // arrival counters of publish_partials (multi-rank mode), zero between launches
-    bool fold_on = false;         // the producers collapse their own partials into lsum (ec3d_fold_configure)
     SolverState *state = nullptr;
     SolverState *state_pinned = nullptr; // 2 slots
     double *hist = nullptr;
@@ -488,9 +481,6 @@ int ec3d_flush_x(ec3d_ctx *c, int stop_iter); // the pending X updates after an 
 void ec3d_launch_iteration(ec3d_ctx *c, const MatView &A, int it);
 int ec3d_launch_begin(ec3d_ctx *c, const MatView &A, double tol);
 int ec3d_single_rank_only(ec3d_ctx *c, const char *who);
-// multi-rank mode: point the sum-producing sweeps at lsum (the last launch of every kernel collapses its partials itself);
-// call whenever dist / lsum / the split sweeps change.  EC3D_FOLD=0 keeps the k_finalize launches.
-void ec3d_fold_configure(ec3d_ctx *c);
 // K2 / K5 of a single-component z-slab as boundary-plane + interior launch (window sweeps, no tile lists); ec3d_dist.hip
 int ec3d_dist_set_boundary_planes(ec3d_ctx *c, int32_t *enabled);
 int ec3d_dist_launches(const ec3d_ctx *c, int stage, int it); // ec3d_dist.hip (call BEFORE the stage is launched)

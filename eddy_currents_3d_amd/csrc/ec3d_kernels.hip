@@ -128,72 +128,20 @@ __device__ __forceinline__ void partials_finish(const RedSrc &src, const int (&s
     block_sum<NV>(out, lds);
 }
 
-// A producer's workgroup leaves its partial sums.  Single rank: a plain store; the consumer kernel re-reduces them.
-// Multi rank (fold_lsum != nullptr: a z-slab whose sums the other ranks read, csrc/ec3d_multi.hip / dist.py): the LAST
-// workgroup of the launch to arrive also collapses ALL the kernel's partials -- an earlier launch's of a split kernel
-// included: count = part_off + gridDim.x -- into lsum[slot], in exactly the order of the one-workgroup k_finalize launch
-// that used to follow every producer (thread t adds values t, t + 256, ..., then the block tree): the same bits, four
-// launches per iteration less.  Round 1 tried this with a device-wide fence per workgroup and lost a factor of two (every
-// workgroup's release wrote the XCD's L2 back).  Here nothing is flushed: the partial is stored write-through (agent
-// scope), its completion waited for, the arrival counted with relaxed atomics -- per blockIdx % 8 first, so that at most
-// an eighth of the workgroups meet on one counter, then once per group -- and the last workgroup reads the partials with
-// agent-scope loads, which do not trust a stale L2 line.  The counters are zero again when the launch ends.
+// A producer's workgroup leaves its partial sums: one per slot, at the launch's offset within the slot.  The consumer kernel
+// re-reduces them (single rank), or a one-workgroup k_finalize launch collapses them into the rank's eight sums (multi rank).
+// (Round 5 built the collapse INTO the producers -- the last workgroup to arrive, found through per-blockIdx % 8 arrival
+// counters, folding the partials in k_finalize's order; write-through partials and agent-scope loads, no cache flushed --
+// bit-identical and no faster than the four small launches it replaced: the serial tail behind the last workgroup costs what a
+// launch costs.  Removed; profiles/r05_partial_sum_collapse_in_kernel_vs_launch.log, commit "Experiment: partial sums
+// collapsed by the producers' last workgroup".)
 template <int NV, class SW>
 __device__ __forceinline__ void publish_partials(const SW &sw, double *part, const int (&slot)[NV], const double (&acc)[NV],
-                                                 double *lds)
+                                                 double *)
 {
-    if (sw.fold_lsum == nullptr) {
-        if (threadIdx.x == 0) {
-#pragma unroll
-            for (int k = 0; k < NV; ++k) part[slot[k] * sw.pstride + sw.part_off + blockIdx.x] = acc[k];
-        }
-        return;
-    }
-    __shared__ int fold_last;
     if (threadIdx.x == 0) {
 #pragma unroll
-        for (int k = 0; k < NV; ++k)
-            __hip_atomic_store(&part[slot[k] * sw.pstride + sw.part_off + blockIdx.x], acc[k], __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the write-through stores above have been acknowledged
-        asm volatile("" ::: "memory");
-        const unsigned x = blockIdx.x & 7u, n = gridDim.x;
-        const unsigned mine = (n - x + 7u) >> 3; // workgroups of this launch with blockIdx % 8 == x
-        int last = 0;
-        if (__hip_atomic_fetch_add(&sw.fold_cnt[x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == mine - 1u) {
-            const unsigned groups = n < 8u ? n : 8u;
-            last = __hip_atomic_fetch_add(&sw.fold_cnt[8], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groups - 1u;
-        }
-        fold_last = last;
-    }
-    __syncthreads();
-    if (!fold_last) return;
-    if (threadIdx.x < 9) __hip_atomic_store(&sw.fold_cnt[threadIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int count = sw.part_off + (int)gridDim.x;
-    // every load of the collapse is requested before the first value is added (a thread adds up to eight values per slot:
-    // as a chain of dependent agent-scope loads that was eight trips to memory, 10-15 us behind the last workgroup)
-    constexpr int FMAX = 8;
-    double e[NV][FMAX];
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        const double *p = part + (int64_t)slot[k] * sw.pstride;
-#pragma unroll
-        for (int j = 0; j < FMAX; ++j) {
-            const int i = (int)threadIdx.x + j * EC3D_THREADS;
-            e[k][j] = __hip_atomic_load(&p[i < count ? i : 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < NV; ++k) { // slot by slot, as k_finalize: reduce_partials<1> of each, the same order of additions
-        double v[1] = {0.0};
-        const double *p = part + (int64_t)slot[k] * sw.pstride;
-#pragma unroll
-        for (int j = 0; j < FMAX; ++j)
-            if ((int)threadIdx.x + j * EC3D_THREADS < count) v[0] = v[0] + e[k][j];
-        for (int i = (int)threadIdx.x + FMAX * EC3D_THREADS; i < count; i += EC3D_THREADS)
-            v[0] = v[0] + __hip_atomic_load(&p[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        block_sum<1>(v, lds);
-        if (threadIdx.x == 0) sw.fold_lsum[slot[k]] = v[0];
+        for (int k = 0; k < NV; ++k) part[slot[k] * sw.pstride + sw.part_off + blockIdx.x] = acc[k];
     }
 }
 
@@ -277,8 +225,6 @@ struct SweepZ {
     int hs_mask, hs_last; // z-slab, K2-in-K3 / K5-in-K1: store the formed vector on the halo planes (Sweep::halo_store);
                           // hs_last = the slab's last owned plane
     int pstride, part_off;
-    double *fold_lsum;   // multi rank: the last workgroup collapses the kernel's partials into fold_lsum[slot] (publish_partials)
-    unsigned *fold_cnt;  // its arrival counters (9, zero between launches)
     int ulist_n;
     const int32_t *ulist;
     int64_t win_npo, win_npb, win_p0; // window in planes (owned per block, held per block, first owned); npo = 0: none
@@ -296,8 +242,6 @@ struct SweepV {
     int64_t ntiles, n;
     int S, nblk;
     int pstride, part_off;
-    double *fold_lsum;   // (see SweepZ)
-    unsigned *fold_cnt;
     int ulist_n, two;
     const int32_t *ulist;
     int64_t win_nt, win_blk, win_t0;
@@ -2332,8 +2276,6 @@ static inline SweepZ sweep_z(const Sweep &sw)
     z.hs_last = sw.zm_tpp > 0 ? (int)(sw.ntiles / sw.zm_tpp) - 1 : 0;
     z.pstride = sw.pstride;
     z.part_off = sw.part_off;
-    z.fold_lsum = sw.fold_lsum;
-    z.fold_cnt = sw.fold_cnt;
     z.ulist_n = sw.ulist_n;
     z.ulist = sw.ulist;
     z.win_npo = sw.win_nt > 0 ? sw.win_nt / sw.zm_tpp : 0;
@@ -2406,8 +2348,6 @@ static inline SweepV sweep_v(const Sweep &sw)
     v.nblk = sw.nblk;
     v.pstride = sw.pstride;
     v.part_off = sw.part_off;
-    v.fold_lsum = sw.fold_lsum;
-    v.fold_cnt = sw.fold_cnt;
     v.ulist_n = sw.ulist_n;
     v.two = sw.vec_depth;
     v.ulist = sw.ulist;

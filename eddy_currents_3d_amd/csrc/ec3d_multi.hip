@@ -767,7 +767,6 @@ int finish_setup(ec3d_multi *m)
         c->slab_xd = xd;
         c->sweep_s.halo_store = fused ? ((s.rank > 0 ? 1 : 0) | (s.rank + 1 < m->world ? 2 : 0)) : 0;
         c->sweep_fb.halo_store = c->sweep_fi.halo_store = c->sweep_s.halo_store;
-        ec3d_fold_configure(c);
         if (c->pp_base) c->pdepth = std::max(2, ec3d_xdefer(c)); // every rank cycles P through the same number of buffers
         s.plan = 0;
         s.split_ok = false;
