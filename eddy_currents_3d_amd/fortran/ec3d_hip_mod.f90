@@ -18,7 +18,8 @@ module ec3d_hip
               ec3d_multi_create, ec3d_multi_destroy, ec3d_multi_assemble, ec3d_multi_set_matrix_csr, &
               ec3d_multi_solve, ec3d_multi_upload, ec3d_multi_download, ec3d_multi_solve_resident, &
               ec3d_multi_rhs_step, ec3d_multi_post_update, ec3d_multi_vtk_fields, ec3d_multi_true_residual, &
-              ec3d_multi_vtk_fields_begin, ec3d_multi_vtk_fields_wait
+              ec3d_multi_vtk_fields_begin, ec3d_multi_vtk_fields_wait, ec3d_rccl_unique_id, ec3d_multi_create_rank, &
+              ec3d_multi_plan
 
     integer(c_int), parameter :: EC3D_VEC_X = 0, EC3D_VEC_B = 1   ! Uaf, Jaf
 
@@ -170,6 +171,29 @@ module ec3d_hip
             type(c_ptr), intent(out) :: mh
             integer(c_int32_t), value :: nranks
             type(c_ptr), value :: devices
+        end function
+        ! ---- one process per GPU (mpirun / torch.distributed.run style launch): this process holds rank `rank` of
+        ! `nranks` on `device`; RCCL carries the halo planes (ncclSend / ncclRecv on a side stream) and the partial sums
+        ! (ncclAllGather).  id_halo, id_sum: two 128-byte RCCL unique ids made by ec3d_rccl_unique_id on ONE rank and
+        ! handed to all (e.g. MPI_Bcast of a character(len=1) :: id(128) array).  Every other ec3d_multi_* call then takes
+        ! the same GLOBAL arrays on every rank.  as_rank = -1, as_world = 0 (a rehearsal of one rank of a larger job
+        ! otherwise, see include/ec3d_hip.h).
+        integer(c_int) function ec3d_rccl_unique_id(id128) bind(C, name="ec3d_rccl_unique_id")
+            import :: c_int, c_char
+            character(kind=c_char), intent(out) :: id128(128)
+        end function
+        integer(c_int) function ec3d_multi_create_rank(mh, rank, nranks, device, id_halo, id_sum, as_rank, as_world) &
+                bind(C, name="ec3d_multi_create_rank")
+            import :: c_ptr, c_int, c_int32_t, c_char
+            type(c_ptr), intent(out) :: mh
+            integer(c_int32_t), value :: rank, nranks, device, as_rank, as_world
+            character(kind=c_char), intent(in) :: id_halo(128), id_sum(128)
+        end function
+        ! the schedule the job runs (0 .. 4, include/ec3d_hip.h) and the iterations between two X updates
+        integer(c_int) function ec3d_multi_plan(mh, plan, x_every) bind(C, name="ec3d_multi_plan")
+            import :: c_ptr, c_int, c_int32_t
+            type(c_ptr), value :: mh
+            integer(c_int32_t), intent(out) :: plan, x_every
         end function
         integer(c_int) function ec3d_multi_destroy(mh) bind(C, name="ec3d_multi_destroy")
             import :: c_ptr, c_int
