@@ -405,7 +405,9 @@ def main():
                           1: "five launches per iteration, K1 / K3 as interior + boundary launch around the exchange of P / S",
                           2: "five launches per iteration, K2 / K5 boundary tiles first",
                           3: "three launches per iteration (K2 inside K3, K4 as an SpMV kernel, K5 inside the next K1), "
-                             "AP and R exchanged"}[multi_plan])
+                             "AP and R exchanged",
+                          4: "three launches per iteration (K2 inside K3, K4 as an SpMV kernel, K5 inside the next K1), AP and "
+                             "R exchanged behind the boundary launches of their producers"}[multi_plan])
     elif not use_dist:
         s = E.EC3DSolver(device=local_rank, dictionary=args.format == "dict")
         if args.workload == "av":
@@ -515,7 +517,9 @@ def main():
                        f"planes as ncclSend/ncclRecv on a side stream, the sums by ncclAllGather; "
                        + {0: "five launches per iteration", 1: "five launches per iteration, K1 / K3 split around the exchange",
                           2: "five launches per iteration, K2 / K5 boundary tiles first",
-                          3: "three launches per iteration, AP and R exchanged"}[multi_plan])
+                          3: "three launches per iteration, AP and R exchanged",
+                          4: "three launches per iteration, AP and R exchanged behind the boundary launches of their "
+                             "producers"}[multi_plan])
 
 
     class _Fusion:       # the headline handle's launches per iteration
