@@ -79,6 +79,46 @@ def test_rehearsal_of_a_middle_rank_runs_every_plan(E, monkeypatch, dims, knobs,
     assert calls > 10
 
 
+@pytest.mark.parametrize("name", ["g2_conducting_hole_16x15x14", "g3_moving_coil_18x16x12"])
+def test_one_rank_av_job_over_rccl_reproduces_the_reference_captures(E, name):
+    """The full A-V system [Ax | Ay | Az | U] (src/EC3D.f90:408) through the rank handle: native assembly, the reference's
+    captured time steps (tests/golden/g2_*, g3_*: b, x_in, x_out, iter of the unmodified program): same iteration counts, x
+    within 10*tol of the reference's, and bit-identical to the plain handle."""
+    from conftest import load_golden
+    from eddy_currents_3d_amd.dist import rccl_rank
+    g = load_golden(name)
+    tol, itmax = float(g["tol"]), int(g["itmax"])
+    with E.EC3DSolver() as s, rccl_rank(0, 1, 0) as m:
+        s.assemble(g["geoPHYS"], g["geoPHYS_C"], g["valPHYS"], g["BND"], g["delta"], float(g["dt"]))
+        m.assemble(g["geoPHYS"], g["geoPHYS_C"], g["valPHYS"], g["BND"], g["delta"], float(g["dt"]))
+        assert m.n == len(g["irow"]) - 1
+        for k in (0, 1):
+            xs, its, _ = s.solve(g[f"b{k}"], g[f"xin{k}"], tol, itmax)
+            x, it = m.solve(g[f"b{k}"], g[f"xin{k}"], tol, itmax)
+            xr = g[f"xout{k}"]
+            assert it == its == int(g["iters"][k]) and np.array_equal(x, xs)
+            assert np.linalg.norm(x - xr) <= 10 * tol * np.linalg.norm(xr)
+
+
+def test_rehearsal_of_a_middle_av_rank(E, monkeypatch):
+    """Rank 1 of 3 of an A-V job alone on this GPU (plan 2: K2 / K5 boundary tiles first; four blocks exchanged per
+    neighbour, the U block two planes deep), X every fourth iteration forced: the schedule runs to the end."""
+    from conftest import load_golden
+    from eddy_currents_3d_amd.dist import rccl_rank
+    monkeypatch.setenv("EC3D_XDEFER", "4")
+    g = load_golden("g2_conducting_hole_16x15x14")
+    n = len(g["irow"]) - 1
+    with rccl_rank(0, 1, 0, rehearse=(1, 3)) as m:
+        m.assemble(g["geoPHYS"], g["geoPHYS_C"], g["valPHYS"], g["BND"], g["delta"], float(g["dt"]))
+        assert m.plan() == (2, 4)
+        m.upload("B", g["b0"])
+        m.upload("X", np.zeros(n))
+        m.iterate_begin()
+        m.iterate(1, 30)
+        m.synchronize()
+        assert m.api_calls(0) > 10
+
+
 def test_two_ranks_in_two_processes():
     """The real thing: two processes, two GPUs, torch.distributed.run; bench.py verifies A*x over the ranks against one
     GPU bit for bit and the reductions through ||b|| before it times anything, and fails without a number otherwise."""

@@ -192,3 +192,68 @@ def test_itmax_line_in_gfortran_style():
     for v in (3.14159, 2.5e10, 7e-300, 123456789.125, 0.1, 0.099999999):
         s = f(v)
         assert len(s) == 26 and float(s) == v
+
+
+class _FakeSlab:
+    """Stands in for an EC3DSolver view of a slab (what oracle.geoms_of asks of it): one launch geometry for every kernel."""
+
+    def __init__(self, oracle, n_rows, nblk, xg=0):
+        self.O, self.n_rows, self.nblk, self.xg = oracle, n_rows, nblk, xg
+
+    def ulist(self):
+        import numpy as np
+        return np.zeros(0, np.int32)
+
+    def geometry(self, which):
+        n_pad = (self.n_rows + 511) // 512 * 512
+        return self.O.GpuGeom(n_pad=n_pad, tile=512, nblk=self.nblk, threads=256, xcd_group=self.xg)
+
+
+def test_multi_rank_twin_on_one_rank_is_the_single_rank_twin(oracle):
+    """oracle.twin_solve_slabs -- the whole system, every dot product summed rank by rank in the ranks' launch order, the
+    ranks' sums added by the 256-thread tree (what tests/test_gpu_slab_plans.py holds the z-slab drivers to) -- with ONE
+    rank must be the C twin (oracle_bicgstab_wr_gpuorder) bit for bit: x, iter, both histories; and with two and three
+    ranks it must still be src/solvers.f90:3-50: the same solution to the solver tolerance, a true residual below it."""
+    N = 16
+    valA, irow, jcol = oracle.poisson_csr(N, N, N)
+    n = N ** 3
+    rng = np.random.Generator(np.random.PCG64(3))
+    b = rng.standard_normal(n)
+    x0 = rng.standard_normal(n)
+    tol = 1e-9
+    one = _FakeSlab(oracle, n, 8)
+    g = oracle.geoms_of(one, (0,))[0]
+    xc, itc, hsc, hrc = oracle.bicgstab_wr_gpuorder(g, valA, irow, jcol, b, x0, tol, 5000, hist_cap=32)
+    xt, itt, hst, hrt, rst = oracle.twin_solve_slabs([(one, 0, n)], 0, valA, irow, jcol, b, x0, tol, 5000, hist_cap=32)
+    assert itt == itc and np.array_equal(xt, xc)
+    assert np.array_equal(hst[:min(itt, 32)], hsc[:min(itt, 32)]) and np.array_equal(hrt[:min(itt, 32) - 1], hrc[:min(itt, 32) - 1])
+    assert rst == oracle.last_restart_count()
+    for world in (2, 3):
+        cuts = [n * r // world // 256 * 256 for r in range(world)] + [n]
+        slabs = [(_FakeSlab(oracle, cuts[r + 1] - cuts[r], 8), cuts[r], cuts[r + 1]) for r in range(world)]
+        xw, itw, _, _, _ = oracle.twin_solve_slabs(slabs, 0, valA, irow, jcol, b, x0, tol, 5000)
+        res = np.linalg.norm(b - oracle.spmv_csr(valA, irow, jcol, xw)) / np.linalg.norm(b)
+        assert res < 5 * tol and np.linalg.norm(xw - xc) <= 1e-6 * np.linalg.norm(xc)
+        assert abs(itw - itc) <= 0.25 * itc
+
+
+def test_tree_sum_is_the_kernels_tree(oracle):
+    """oracle_tree_sum: thread t of 256 adds values t, t + 256, ... in order; 64-lane shuffle tree per wave; the four wave
+    sums left to right (reduce_partials / k_finalize in csrc/ec3d_kernels.hip).  Eight rank sums: ((v0+v4)+(v2+v6)) +
+    ((v1+v5)+(v3+v7))."""
+    v = np.array([1e16, 1.0, -1e16, 1.0, 3.0, 1e-3, 7.0, -1.0])
+    want = ((v[0] + v[4]) + (v[2] + v[6])) + ((v[1] + v[5]) + (v[3] + v[7]))
+    assert oracle.tree_sum(v) == want
+    w = np.arange(1.0, 601.0)            # 600 values: threads 0..87 add three each, the others two
+    acc = np.zeros(256)
+    for i, x in enumerate(w):
+        acc[i % 256] = acc[i % 256] + x
+    waves = []
+    for k in range(4):
+        q = acc[64 * k:64 * k + 64].copy()
+        off = 32
+        while off:
+            q[:off] = q[:off] + q[off:2 * off]
+            off //= 2
+        waves.append(q[0])
+    assert oracle.tree_sum(w) == ((waves[0] + waves[1]) + waves[2]) + waves[3]
