@@ -1475,7 +1475,7 @@ extern "C" int ec3d_multi_solve_resident(ec3d_multi_handle m, double tolerance, 
         }
         if (ec3d_itmax_print_hold) {
             *ec3d_itmax_print_hold = std::sqrt(s);
-        } else {
+        } else if (!m->nccl || m->comm_rank == 0) { // one process per GPU: the line appears once, as the reference's does
             ec3d_print_rnorm(std::sqrt(s));
             fflush(stdout);
         }
