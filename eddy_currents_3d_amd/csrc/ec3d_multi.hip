@@ -776,6 +776,8 @@ int finish_setup(ec3d_multi *m)
         if (m->kind == 1 && !(want_plan == 2 && !fused && m->world > 1)) {
             const bool no_fsplit = getenv("EC3D_SLAB_FSPLIT") && atoi(getenv("EC3D_SLAB_FSPLIT")) == 0;
             s.plan = fused ? ((c->can_fsplit && !no_fsplit) ? 4 : 3) : (ec3d_can_overlap(c) && want_plan != 0) ? 1 : 0;
+        } else if (m->kind == 2 && want_plan == 0) {
+            s.plan = 0; // (measurement: the A-V job with the exchange in front of K1 / K3, no split launches)
         } else if (m->world > 1) {
             // the ORDER of exchanges is a property of the job: every A-V rank uses the producer-side
             // plan; a rank whose slab is all boundary runs the whole kernels in that order

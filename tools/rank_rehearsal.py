@@ -41,6 +41,43 @@ def run(N, sdz, G, r):
           + " ".join(f"{k}={v * 1e3:.0f}us" for k, v in km.items()), flush=True)
 
 
+def run_av(case, dims, G, r):
+    """One rank of an A-V job (BASELINE configs 3 / 5: the shipped geometry resampled to `dims`) alone on this GPU."""
+    from eddy_currents_3d_amd import vxc
+    g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", f"g4_{case}.npz"))
+    model = vxc.resample(vxc.VxcModel(g["vox"], [str(x) for x in g["names"]], float(str(g["lattice_dim"])),
+                                      tuple(float(x) for x in g["adj"])), *dims)
+    t = vxc.domain_tables(model)
+    for label, reh in (("undivided", None), (f"rank {r} of {G}", (r, G))):
+        ctx = rccl_rank(0, 1, 0, rehearse=reh)
+        with ctx as m:
+            m.assemble(t["geoPHYS"], t["geoPHYS_C"], t["valPHYS"], t["BND"], t["delta"], t["dt"])
+            n = m.n
+            view, k0, k1 = m.slab(0)
+            m.upload("B", np.random.Generator(np.random.PCG64(7)).standard_normal(n))
+            m.upload("X", np.zeros(n))
+            m.iterate_begin()
+            m.iterate(1, 20)
+            m.synchronize()
+            t0 = time.perf_counter()
+            m.iterate(21, iters)
+            t1 = time.perf_counter()
+            m.synchronize()
+            t2 = time.perf_counter()
+            plan, xd = m.plan()
+            calls = m.api_calls(0)
+            km = m.iterate(21 + iters, 20, per_kernel=True)
+        print(f"{case} {dims[0]}x{dims[1]}x{dims[2]} (n = {n}), {label} through the RCCL driver ({k1 - k0} planes): plan {plan}, X every "
+              f"{xd}: {1e3 * (t2 - t0) / iters:.4f} ms per iteration, host enqueue {1e3 * (t1 - t0) / iters:.4f} ms, {calls:.0f} runtime "
+              f"calls per iteration; stages " + " ".join(f"{k}={v * 1e3:.0f}us" for k, v in km.items()), flush=True)
+
+
+if os.environ.get("REHEARSE_AV"):
+    run_av("LIM", (384, 192, 128), 8, 3)
+    run_av("LIM", (384, 192, 128), 4, 1)
+    if os.environ["REHEARSE_AV"] != "lim":
+        run_av("ec_src_move_hole", (256, 256, 60), 2, 1)
+    sys.exit(0)
 if os.environ.get("REHEARSE_ONLY"):
     for tok in os.environ["REHEARSE_ONLY"].split(";"):
         N, sdz, G, r = (int(t) for t in tok.split(","))
