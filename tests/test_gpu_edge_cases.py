@@ -182,3 +182,38 @@ def test_parked_band_placement_is_reused_once_and_released(E):
         # the large system held 7 band streams + 8 work vectors + 7 ring buffers of 8 n bytes each: all of it must be free
         # again; a parked copy of the band streams (7 of the 22) would leave the difference at 15
         assert free_small - free_with_bands > 8 * n * 18.5
+
+
+def test_iterate_must_continue_its_numbering(E):
+    """ec3d_iterate addresses the device state by the iteration number (rr0[it & 1], AP in apbuf[it & 1], P and S in rings of
+    up to four buffers): a call that does not continue where the last one ended -- iterate(1, 5) twice -- would iterate on
+    an older P and the other rr0, so it is refused (status 6); pieces that do continue give what one call gives; and
+    ec3d_iterate_begin starts the numbering again."""
+    import os
+    N = 32
+    n = N ** 3
+    b = np.random.Generator(np.random.PCG64(12)).standard_normal(n)
+    os.environ["EC3D_XDEFER"] = "4"            # rings of four P / S buffers on this small grid too
+    try:
+        outs = []
+        for pieces in ((9,), (5, 4), (2, 3, 4)):
+            with E.EC3DSolver() as s:
+                s.assemble_poisson(N, N, N)
+                assert s.x_interval() == 4
+                s.upload("B", b)
+                s.upload("X", np.zeros(n))
+                s.iterate_begin()
+                at = 1
+                for c in pieces:
+                    s.iterate(at, c)
+                    at += c
+                s.synchronize()
+                outs.append(s.download("X"))
+                with pytest.raises(E.EC3DError, match="does not continue"):
+                    s.iterate(1, 5)
+                s.iterate_begin()
+                s.iterate(1, 3)
+                s.synchronize()
+        assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    finally:
+        del os.environ["EC3D_XDEFER"]
