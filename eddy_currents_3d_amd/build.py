@@ -20,7 +20,7 @@ CSRC = os.path.join(PKG, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(PKG, "libec3d_hip.so")
 SOURCES = ["ec3d_kernels.hip", "ec3d_context.hip", "ec3d_solve.hip", "ec3d_measure.hip", "ec3d_dist.hip", "ec3d_multi.hip",
-           "ec3d_rccl.cpp", "ec3d_dropin.hip", "ec3d_assemble.hip", "ec3d_rhs.hip", "ec3d_output.hip", "ec3d_format.cpp",
+           "ec3d_rccl.cpp", "ec3d_rccl_loopback.cpp", "ec3d_dropin.hip", "ec3d_assemble.hip", "ec3d_rhs.hip", "ec3d_output.hip", "ec3d_format.cpp",
            "ec3d_sav_csr.cpp"]
 HEADERS = [os.path.join(CSRC, "ec3d_internal.hpp"), os.path.join(CSRC, "ec3d_rccl.hpp"),
            os.path.join(os.path.dirname(PKG), "include", "ec3d_hip.h")]

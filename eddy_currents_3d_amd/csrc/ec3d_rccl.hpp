@@ -26,3 +26,6 @@ struct ec3d_rccl_api {
 // librccl.so.1 is taken when there is one (under Python that is the copy PyTorch ships beside its own HIP runtime, which
 // this library shares then), else the system's (/opt/rocm/lib).
 const ec3d_rccl_api *ec3d_rccl_load(std::string &why);
+// the same table served by threads of ONE process copying between their buffers (EC3D_RCCL_LOOPBACK=1; a test double for
+// the transport: ec3d_rccl_loopback.cpp says what it keeps of the real calls' semantics)
+const ec3d_rccl_api *ec3d_rccl_loopback();

@@ -1,0 +1,193 @@
+"""SEVERAL ranks of the one-process-per-GPU driver (ec3d_multi_create_rank, csrc/ec3d_multi.hip) on ONE GPU.
+
+RCCL refuses two ranks on one device (tools/rccl_two_ranks_one_gpu_probe.py), so tests/test_gpu_rccl_rank.py can run that
+driver only as a one-rank job or as the rehearsal of one rank.  What several ranks add -- which planes go to which
+neighbour and in which order the sends and receives of a group pair up, where rank r's eight sums land in the gathered
+table, the facts the ranks agree on at set-up (one plan, one X interval, one ring depth for the whole job), every rank
+leaving the loop at the same iteration -- is covered here through the LOOPBACK transport (EC3D_RCCL_LOOPBACK=1,
+csrc/ec3d_rccl_loopback.cpp): the nine RCCL entry points served by threads of this process that copy between the ranks'
+buffers with the ordering the real calls give.  Every rank is a thread with its own handle, created exactly as a process
+of the launcher's job creates it; everything above the transport is the product's code.
+
+The bar: x (each rank returns its own planes), the iteration count, the plan, the true residual and A*x of the rank job
+equal those of the ONE-process handle on the same slabs bit for bit -- and that handle is pinned against the oracle's
+multi-rank twin in tests/test_gpu_slab_plans.py and against the reference's captures in tests/test_gpu_multi.py."""
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+KNOBS = ("EC3D_SLAB_FSPLIT", "EC3D_SLAB_PLAN", "EC3D_NT", "EC3D_FUSE23", "EC3D_FUSE51", "EC3D_XDEFER", "EC3D_K4S", "EC3D_SLAB_FUSE",
+         "EC3D_SLAB_XDEFER")
+
+
+@pytest.fixture(scope="module")
+def E():
+    import eddy_currents_3d_amd as E
+    E.load_library()
+    return E
+
+
+def set_knobs(monkeypatch, **kw):
+    for k in KNOBS:
+        monkeypatch.delenv(k, raising=False)
+    for k, v in kw.items():
+        monkeypatch.setenv("EC3D_" + k, str(v))
+    monkeypatch.setenv("EC3D_RCCL_LOOPBACK", "1")
+
+
+def run_ranks(E, world, body, **fmt):
+    """body(m, rank) on `world` threads, each with the handle of one rank of a loopback job; the list of results."""
+    ids = [E.EC3DMulti.rccl_unique_id(), E.EC3DMulti.rccl_unique_id()]
+    assert ids[0] != ids[1]
+    out, err = [None] * world, [None] * world
+
+    def rank_main(r):
+        try:
+            with E.EC3DMulti.for_rank(r, world, 0, ids[0], ids[1], **fmt) as m:
+                out[r] = body(m, r)
+        except BaseException as e:   # noqa: BLE001 -- reported by the caller's thread
+            err[r] = e
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for r, e in enumerate(err):
+        if e is not None:
+            raise AssertionError(f"rank {r}: {e!r}") from e
+    return out
+
+
+def merge(x0, parts):
+    """Every rank returns the global vector with ITS rows filled (the others as handed in)."""
+    x = x0.copy()
+    for p in parts:
+        mine = p != x0
+        x[mine] = p[mine]
+    return x
+
+
+FUSED = dict(FUSE23=2, FUSE51=2, K4S=2)
+CASES = [
+    ("five-launches", (20, 12, 31), dict(), 0),
+    ("interior+boundary", (128, 8, 48), dict(), 1),
+    ("three-launches,X/4", (128, 8, 48), dict(FUSED, XDEFER=4, SLAB_FSPLIT=0), 3),
+    ("three-launches-split,X/4", (128, 8, 48), dict(FUSED, XDEFER=4), 4),
+    ("three-launches-split,X/3", (128, 8, 48), dict(FUSED, XDEFER=3), 4),
+]
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+@pytest.mark.parametrize("name, dims, knobs, plan", CASES, ids=[c[0] for c in CASES])
+def test_rank_job_equals_the_one_process_handle(E, oracle, monkeypatch, world, name, dims, knobs, plan):
+    set_knobs(monkeypatch, **knobs)
+    sdx, sdy, sdz = dims
+    n = sdx * sdy * sdz
+    rng = np.random.Generator(np.random.PCG64(11))
+    b = rng.standard_normal(n)
+    xs = rng.standard_normal(n)
+    x0 = np.zeros(n)
+    tol, itmax = 1e-9, 400
+    with E.EC3DMulti(world, devices=[0] * world) as one:
+        one.assemble_poisson(sdx, sdy, sdz)
+        want_plan = one.plan()
+        x_one, it_one = one.solve(b, x0, tol, itmax)
+        res_one = one.true_residual()
+        y_one = one.spmv(xs)
+        cuts = [one.slab(r)[1:] for r in range(world)]
+    if sdz // world >= 10:  # (thinner slabs have no interior launch: the library falls back by itself, on both drivers)
+        assert want_plan[0] == plan, want_plan
+
+    def body(m, r):
+        m.assemble_poisson(sdx, sdy, sdz)
+        assert m.n == n and m.slab(0)[1:] == cuts[r] and m.plan() == want_plan
+        x, it = m.solve(b, x0, tol, itmax)
+        res = m.true_residual()
+        y = m.spmv(xs)
+        return x, it, res, y
+
+    got = run_ranks(E, world, body)
+    assert [g[1] for g in got] == [it_one] * world                 # every rank leaves at the same iteration
+    assert all(g[2] == res_one for g in got)                       # ... and holds the same sums
+    assert np.array_equal(merge(x0, [g[0] for g in got]), x_one)
+    assert np.array_equal(merge(np.zeros(n), [g[3] for g in got]), y_one)
+    assert it_one > 20
+
+
+def test_restarts_and_itmax_on_a_rank_job(E, oracle, monkeypatch):
+    """The system of tests/test_gpu_slab_plans.py::test_restart_rule_on_slabs (the rule of src/solvers.f90:47-49 fires) on
+    three ranks, three launches per iteration, X every fourth: every rank restarts at the same iterations.  Then the same
+    system stopped by itmax in the middle of a group of four (src/solvers.f90:59-61): every rank runs exactly itmax
+    iterations (and reports itmax + 1, as the reference's counter stands then) and X holds all of them."""
+    set_knobs(monkeypatch, **dict(FUSED, XDEFER=4))
+    sdx, sdy, sdz, world = 256, 8, 31, 3
+    n = sdx * sdy * sdz
+    rng = np.random.Generator(np.random.PCG64(2026))
+    x0 = np.zeros(n)
+    rng.standard_normal(n)
+    b = rng.standard_normal(n)
+    with E.EC3DMulti(world, devices=[0] * world) as one:
+        one.assemble_poisson(sdx, sdy, sdz)
+        x_one, it_one = one.solve(b, x0, 1e-9, 5000)
+        restarts = [one.slab(r)[0].restart_count() for r in range(world)]
+        x_cut, it_cut = one.solve(b, x0, 1e-9, 38)
+    assert restarts[0] > 0 and it_cut == 39 < it_one      # (the reference's loop counter has passed itmax: src/solvers.f90:59)
+
+    def body(m, r):
+        m.assemble_poisson(sdx, sdy, sdz)
+        x, it = m.solve(b, x0, 1e-9, 5000)
+        rs = m.slab(0)[0].restart_count()
+        xc, itc = m.solve(b, x0, 1e-9, 38)
+        return x, it, rs, xc, itc
+
+    got = run_ranks(E, world, body)
+    assert [g[1] for g in got] == [it_one] * world and [g[2] for g in got] == restarts
+    assert np.array_equal(merge(x0, [g[0] for g in got]), x_one)
+    assert [g[4] for g in got] == [39] * world
+    assert np.array_equal(merge(x0, [g[3] for g in got]), x_cut)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_av_rank_job_reproduces_the_reference_capture(E, monkeypatch, world):
+    """The A-V system [Ax | Ay | Az | U] (src/EC3D.f90:408) cut into slabs of the structured form: four blocks exchanged per
+    neighbour, the U block two planes deep.  Two time steps of the reference's capture: its iteration counts, and the
+    one-process handle's x bit for bit."""
+    from conftest import load_golden
+    set_knobs(monkeypatch)
+    g = load_golden("g2_conducting_hole_16x15x14")
+    tol, itmax = float(g["tol"]), int(g["itmax"])
+    geo = (g["geoPHYS"], g["geoPHYS_C"], g["valPHYS"], g["BND"], g["delta"], float(g["dt"]))
+    with E.EC3DMulti(world, devices=[0] * world) as one:
+        one.assemble(*geo)
+        want_plan = one.plan()
+        ref = [one.solve(g[f"b{k}"], g[f"xin{k}"], tol, itmax) for k in (0, 1)]
+
+    def body(m, r):
+        m.assemble(*geo)
+        assert m.plan() == want_plan
+        return [m.solve(g[f"b{k}"], g[f"xin{k}"], tol, itmax) for k in (0, 1)]
+
+    got = run_ranks(E, world, body)
+    for k in (0, 1):
+        assert [got[r][k][1] for r in range(world)] == [ref[k][1]] * world
+        x = merge(g[f"xin{k}"], [got[r][k][0] for r in range(world)])
+        assert np.array_equal(x, ref[k][0])
+        assert abs(ref[k][1] - int(g["iters"][k])) <= 1
+        assert np.linalg.norm(x - g[f"xout{k}"]) <= 10 * tol * np.linalg.norm(g[f"xout{k}"])
+
+
+def test_the_transport_itself(E, monkeypatch):
+    """ec3d_rccl_loopback_selftest (csrc/ec3d_rccl_loopback.cpp): two ranks exchange and gather known values in the order
+    of the driver's calls (values checked on the device side of each rank), and a receive that meets a send of another
+    length is an error on the spot (real RCCL would hang or write past the buffer) -- so a wrong halo piece in the driver
+    cannot pass the tests above silently."""
+    import ctypes as C
+    set_knobs(monkeypatch)
+    L = E.load_library()
+    L.ec3d_rccl_loopback_selftest.restype = C.c_int
+    rc = L.ec3d_rccl_loopback_selftest()
+    assert rc == 0, (rc, L.ec3d_last_error().decode())
