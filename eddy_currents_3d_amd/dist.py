@@ -60,32 +60,45 @@ def slab_bounds(sdz: int, rank: int, world: int):
     return k0, k0 + base + (1 if rank < rem else 0)
 
 
+def share_unique_ids(ids, rank: int, world: int, device: int):
+    """Rank 0's two RCCL unique ids (128 bytes each) handed to every rank of the torch.distributed job that is already
+    running -- as ONE uint8 tensor on the backend's own kind of memory (this rank's GPU under nccl, the host under gloo),
+    so no object is pickled through a side channel.  Returns [id_halo, id_sum] on every rank."""
+    import torch
+    import torch.distributed as dist
+    dev = torch.device("cuda", device) if dist.get_backend() == "nccl" else torch.device("cpu")
+    if rank == 0:
+        if len(ids[0]) != 128 or len(ids[1]) != 128:
+            raise ValueError("an RCCL unique id is 128 bytes")
+        t = torch.frombuffer(bytearray(ids[0] + ids[1]), dtype=torch.uint8).to(dev)
+    else:
+        t = torch.zeros(256, dtype=torch.uint8, device=dev)
+    dist.broadcast(t, src=0)
+    raw = bytes(t.cpu().numpy().tobytes())
+    return [raw[:128], raw[128:]]
+
+
 def rccl_rank(rank: int, world: int, device: int, dictionary=None, structured=None, rehearse=None):
     """This process's slab of a `world`-rank job as an EC3DMulti driven from C++ over RCCL (include/ec3d_hip.h section 2c,
     ec3d_multi_create_rank): rank 0 makes the two RCCL unique ids, torch.distributed -- already initialised by the
-    launcher's form of this job -- hands them to every rank.  Without a process group (a one-rank rehearsal started by
-    hand) the ids stay local."""
+    launcher's form of this job -- hands them to every rank (share_unique_ids).  Without a process group (a one-rank job
+    or a rehearsal started by hand) the ids stay local; a job of several ranks without one is refused: its ranks could
+    not meet."""
     from .solver import EC3DMulti
-    ids = [None, None]
     have_group = False
     try:
         import torch.distributed as dist
         have_group = dist.is_available() and dist.is_initialized() and dist.get_world_size() == world
     except ImportError:
         pass
-    if rank == 0 or not have_group:
+    if world > 1 and not have_group:
+        raise RuntimeError(f"rccl_rank: a job of {world} ranks needs torch.distributed initialised with that world size "
+                           f"(it carries rank 0's RCCL ids to the others)")
+    ids = [None, None]
+    if rank == 0:
         ids = [EC3DMulti.rccl_unique_id(), EC3DMulti.rccl_unique_id()]
-    if have_group and world > 1:
-        import torch
-        import torch.distributed as dist
-        # as a tensor on this rank's GPU: works on every backend without pickling through a side channel
-        dev = torch.device("cuda", device) if dist.get_backend() == "nccl" else torch.device("cpu")
-        t = torch.zeros(256, dtype=torch.uint8, device=dev)
-        if rank == 0:
-            t = torch.frombuffer(bytearray(ids[0] + ids[1]), dtype=torch.uint8).to(dev)
-        dist.broadcast(t, src=0)
-        raw = bytes(t.cpu().numpy().tobytes())
-        ids = [raw[:128], raw[128:]]
+    if world > 1:
+        ids = share_unique_ids(ids, rank, world, device)
     return EC3DMulti.for_rank(rank, world, device, ids[0], ids[1], dictionary=dictionary, structured=structured,
                               rehearse=rehearse)
 

@@ -102,3 +102,37 @@ def test_in_process_slabs_equal_single_slab(oracle):
     assert np.linalg.norm(xs[0] - xs[1]) <= 1e-6 * np.linalg.norm(xs[0])
     valA, irow, jcol = oracle.poisson_csr(N, N, N)
     assert np.linalg.norm(b - oracle.spmv_csr(valA, irow, jcol, xs[1])) / np.linalg.norm(b) < 5 * TOL
+
+
+def _ids_worker(rank, world, port, out):
+    import sys
+    sys.path.insert(0, REPO)
+    import torch.distributed as dist
+    from eddy_currents_3d_amd.dist import share_unique_ids, rccl_rank
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.Generator(np.random.PCG64(99))       # what rank 0 "made"; the others hold nothing
+        ids = [rng.bytes(128), rng.bytes(128)] if rank == 0 else [None, None]
+        got = share_unique_ids(ids, rank, world, 0)
+        np.save(f"{out}.{rank}.npy", np.frombuffer(got[0] + got[1], np.uint8))
+        try:    # a job of another size than the process group's has nobody to carry the ids
+            rccl_rank(rank, world + 1, 0)
+            refused = False
+        except RuntimeError as e:
+            refused = "needs torch.distributed" in str(e)
+        assert refused
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rank_zero_ids_reach_every_rank(tmp_path):
+    """What carries the two RCCL unique ids of the one-process-per-GPU driver (dist.rccl_rank -> ec3d_multi_create_rank)
+    from rank 0 to the others: one broadcast of 256 bytes on the job's own process group.  gloo, 3 ranks."""
+    world, out = 3, str(tmp_path / "ids")
+    mp.spawn(_ids_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    rng = np.random.Generator(np.random.PCG64(99))
+    want = np.frombuffer(rng.bytes(128) + rng.bytes(128), np.uint8)
+    for r in range(world):
+        assert np.array_equal(np.load(f"{out}.{r}.npy"), want)
