@@ -639,6 +639,7 @@ class EC3DMulti:
         _chk(self.L, self.L.ec3d_multi_create(C.byref(self.h), int(nranks), None if dev is None else dev.ctypes.data),
              "ec3d_multi_create")
         self.nranks = int(nranks)
+        self.rank = None           # (set on the handle of ONE rank of a one-process-per-GPU job: for_rank)
         if dictionary is not None or structured is not None:
             _chk(self.L, self.L.ec3d_multi_set_format(self.h, -1 if dictionary is None else int(bool(dictionary)),
                                                       -1 if structured is None else int(bool(structured))),
@@ -800,6 +801,9 @@ class EC3DMulti:
             _chk(self.L, self.L.ec3d_multi_vtk_fields_wait(self.h, slot, r, C.byref(p[0]), C.byref(p[1]), C.byref(p[2]),
                                                            C.byref(p[3]), C.byref(c0), C.byref(n)),
                  "ec3d_multi_vtk_fields_wait")
+            if r == 0 and getattr(self, "rank", None) is not None:
+                at = c0.value      # one process per GPU: this rank's slab starts where the ranks below it end
+                self.first_cell = at
             if c0.value != at:
                 raise EC3DError("ec3d_multi_vtk_fields_wait: the slabs do not tile the grid")
             at += n.value

@@ -191,3 +191,85 @@ def test_the_transport_itself(E, monkeypatch):
     L.ec3d_rccl_loopback_selftest.restype = C.c_int
     rc = L.ec3d_rccl_loopback_selftest()
     assert rc == 0, (rc, L.ec3d_last_error().decode())
+
+
+@pytest.mark.parametrize("name, moving, world", [("g2_conducting_hole_16x15x14", False, 2), ("g3_moving_coil_18x16x12", True, 3)])
+def test_time_loop_state_on_rank_handles(E, monkeypatch, name, moving, world):
+    """src/EC3D.f90:370-404 (RHS build) and :412-433 (post-update) on the rank handles: every rank's rows of the assembled b
+    and of the post-updated x are the reference's loop state bit for bit (host vectors are global on every rank)."""
+    from conftest import load_golden
+    from test_gpu_timeloop import coil_sources
+    set_knobs(monkeypatch)
+    g = load_golden(name)
+    n = len(g["irow"]) - 1
+    steps = len(g["iters"])
+
+    def body(m, r):
+        m.assemble(g["geoPHYS"], g["geoPHYS_C"], g["valPHYS"], g["BND"], g["delta"], float(g["dt"]))
+        m.upload("X", np.zeros(n))
+        m.upload("B", np.zeros(n))
+        xs, bs = [], []
+        for k in range(steps):
+            if k > 0:
+                m.upload("X", g[f"xout{k - 1}"])
+                m.upload("B", g[f"b{k - 1}"])
+                m.post_update()
+                xs.append(m.download("X"))
+            idx, val = coil_sources(g, k, moving)
+            m.rhs_step(idx, val, moving=moving)
+            bs.append(m.download("B"))
+        return xs, bs
+
+    got = run_ranks(E, world, body)
+    # download fills this rank's rows of a zero vector: the rows of all ranks together are the whole vector
+    for k in range(steps):
+        assert np.array_equal(merge(np.zeros(n), [got[r][1][k] for r in range(world)]), g[f"b{k}"]), f"b of step {k}"
+        if k > 0:
+            assert np.array_equal(merge(np.zeros(n), [got[r][0][k - 1] for r in range(world)]), g[f"xin{k}"]), f"x of step {k}"
+
+
+def keep(parts):
+    """(the parts are views of buffers the handle owns: copied before the handle goes)"""
+    return {k: (None if v is None else [np.array(a) for a in v]) for k, v in parts.items()}
+
+
+def test_fields_and_csr_route_on_rank_handles(E, monkeypatch):
+    """Field output (src/EC3D.f90:241-366: B = curl A, the eddy current density) and the drop-in's way in (the reference's
+    CSR triple, cut by every rank for itself) on three rank handles: each rank's cells equal the matching slab of the
+    one-process handle, whose file bytes tests/test_gpu_multi.py pins to the reference's."""
+    from conftest import load_golden
+    set_knobs(monkeypatch)
+    world = 3
+    g = load_golden("g3_moving_coil_18x16x12")
+    tol, itmax = float(g["tol"]), int(g["itmax"])
+    geo = (g["geoPHYS"], g["geoPHYS_C"], g["valPHYS"], g["BND"], g["delta"], float(g["dt"]))
+    with E.EC3DMulti(world, devices=[0] * world) as one:
+        one.assemble(*geo)
+        one.upload("X", g["xout1"])
+        one.upload("B", g["b1"])
+        one.post_update()
+        slot = one.vtk_fields_begin(g["delta"], big_endian=True)
+        want = keep(one.vtk_fields_wait(slot, big_endian=True))
+        x_one, it_one = one.solve(g["b0"], g["xin0"], tol, itmax)
+
+    def body(m, r):
+        m.assemble(*geo)
+        m.upload("X", g["xout1"])
+        m.upload("B", g["b1"])
+        m.post_update()
+        slot = m.vtk_fields_begin(g["delta"], big_endian=True)
+        parts = keep(m.vtk_fields_wait(slot, big_endian=True))
+        m.set_matrix_csr(g["valA"], g["irow"], g["jcol"])
+        return parts, m.solve(g["b0"], g["xin0"], tol, itmax)
+
+    got = run_ranks(E, world, body)
+    for r in range(world):
+        parts = got[r][0]
+        assert set(parts) == set(want)
+        for key in want:
+            if parts[key] is None:     # (a rank without a conductor has no eddy part; the one-process handle fills zeros)
+                assert key == "eddy" and not np.any(want[key][r])
+                continue
+            assert len(parts[key]) == 1 and np.array_equal(parts[key][0], want[key][r]), (r, key)
+        assert got[r][1][1] == it_one
+    assert np.array_equal(merge(g["xin0"], [got[r][1][0] for r in range(world)]), x_one)
