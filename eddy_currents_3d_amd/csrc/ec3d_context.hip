@@ -265,6 +265,14 @@ extern "C" int ec3d_destroy(ec3d_handle c)
     else
         (void)hipStreamSynchronize(c->stream);
     c->stream = c->own_stream_obj;
+    if (c->xstream) {
+        (void)hipStreamSynchronize(c->xstream);
+        (void)hipStreamDestroy(c->xstream);
+        if (c->ev_xready) (void)hipEventDestroy(c->ev_xready);
+        for (int i = 0; i < 2; ++i)
+            if (c->ev_xdone[i]) (void)hipEventDestroy(c->ev_xdone[i]);
+        c->xstream = nullptr;
+    }
     ec3d_free_matrix(c);
     if (c->placed_bands) (void)hipFree(c->placed_bands);
     c->placed_bands = nullptr;
@@ -837,12 +845,15 @@ int ec3d_prepare_vectors(ec3d_ctx *c)
 // (ec3d_xdefer): only handles that own their vectors
 int ec3d_spare_pair(ec3d_ctx *c)
 {
-    for (int j = 0; j < EC3D_XD_MAX; ++j) c->pbuf[j] = c->sbuf[j] = nullptr;
+    for (int j = 0; j < 2 * EC3D_XD_MAX; ++j) c->pbuf[j] = c->sbuf[j] = nullptr;
     c->pbuf[1] = c->vec[EC3D_VEC_P];
     c->sbuf[1] = c->vec[EC3D_VEC_S];
     c->apbuf[1] = c->vec[EC3D_VEC_AP];
     c->apbuf[0] = nullptr;
     c->pdepth = 2;
+    c->sdepth = 1;
+    c->ring_cap = 0;
+    c->xasync_cap = c->xasync_forced = false;
     c->xdefer = 1;
     c->pcur = c->apcur = c->scur = 1;
     // X every D-th iteration: from the size where both fusions run by themselves (everything streams from HBM there, every
@@ -870,10 +881,26 @@ int ec3d_spare_pair(ec3d_ctx *c)
     }
     const int64_t len = c->ghost + c->A.n_pad + c->ghost;
     int64_t want = 0;
+    // The groups of D X updates on a stream of their own (ec3d_xasync) need rings of TWO groups.  OFF unless asked for:
+    // measured through the rank rehearsal on one card (profiles/r05_x_groups_on_a_second_stream.log, 128 workgroups), five-launch
+    // slabs gain 0 ... 2 % -- rank 4 of 8 of 512^3 0.480-0.485 -> 0.476 ms per iteration, 384^3 / 8 0.272 -> 0.267-0.271, config 5 on
+    // 8 / 4 ranks 0.301-0.305 -> 0.297-0.300 / 0.377-0.383 -> 0.373-0.375 -- and three-launch slabs (from 32 Mi rows) LOSE 3 ... 20 %:
+    // what the second launch moves, K5-in-K1 and K2-in-K3 beside it lose, as on the undivided handle in round 4 (DESIGN
+    // section 5).  One card has no gaps worth filling; a job on several has them where halo planes and gathered sums are
+    // under way, which one card cannot show.  EC3D_XASYNC=1: z-slabs that run the five-launch iteration; 2: whenever the X
+    // update is deferred, three-launch slabs and plain handles too (tests).
+    int xa = 0;
+    if (const char *e = getenv("EC3D_XASYNC")) xa = atoi(e);
+    const bool three_launch_slab = c->fuse23_ok && c->fuse51_ok && c->k4s_ok;
+    bool two_groups = D > 1 && xa != 0 && ((c->halo > 0 && !three_launch_slab) || xa == 2);
     for (;;) {
         c->xdefer = D;
-        c->pdepth = std::max(2, D);
-        want = len * ((c->pdepth - 1) + 1 + (D - 1));
+        c->ring_cap = two_groups ? 2 * D : D;
+        c->pdepth = std::max(2, c->ring_cap);
+        c->sdepth = std::max(1, c->ring_cap);
+        c->xasync_cap = two_groups;
+        c->xasync_forced = two_groups && xa == 2;
+        want = len * ((c->pdepth - 1) + 1 + (c->sdepth - 1));
         if (c->pp_base && c->pp_len != want) {
             (void)hipFree(c->pp_base);
             c->pp_base = nullptr;
@@ -890,13 +917,32 @@ int ec3d_spare_pair(ec3d_ctx *c)
         (void)hipGetLastError();
         c->pp_base = nullptr;
         c->pp_len = 0;
+        if (two_groups) { // rings of one group: the D-th K4 applies the updates
+            two_groups = false;
+            continue;
+        }
         if (D > 1) {
             D = 1;
             if (c->fuse51_ok) continue;
         }
         c->xdefer = 1;
         c->pdepth = 2;
+        c->sdepth = 1;
+        c->ring_cap = 0;
+        c->xasync_cap = c->xasync_forced = false;
         return 0;
+    }
+    if (c->xasync_cap && !c->xstream) {
+        // The second stream has the iteration's own priority.  At the LOWEST priority (EC3D_XASYNC_PRIO=1) every kernel of
+        // the iteration ran at half speed for as long as a group's launch was resident (16 Mi-row slab: 0.486 -> 0.93 ms per
+        // iteration, whatever its workgroup count): what keeps the second launch out of the way is its small grid
+        // (ec3d_launch_x_group_of), not the queue's priority.
+        int least = 0, greatest = 0;
+        EC3D_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        const bool low = getenv("EC3D_XASYNC_PRIO") && atoi(getenv("EC3D_XASYNC_PRIO")) == 1;
+        EC3D_HIP(hipStreamCreateWithPriority(&c->xstream, hipStreamNonBlocking, low ? least : 0));
+        EC3D_HIP(hipEventCreateWithFlags(&c->ev_xready, hipEventDisableTiming));
+        for (int i = 0; i < 2; ++i) EC3D_HIP(hipEventCreateWithFlags(&c->ev_xdone[i], hipEventDisableTiming));
     }
     double *at = c->pp_base + c->ghost;
     c->apbuf[0] = at;
@@ -906,7 +952,7 @@ int ec3d_spare_pair(ec3d_ctx *c)
             c->pbuf[j] = at;
             at += len;
         }
-    for (int j = 0; j < D; ++j)
+    for (int j = 0; j < c->sdepth; ++j)
         if (j != 1) {
             c->sbuf[j] = at;
             at += len;

@@ -173,6 +173,7 @@ extern "C" int ec3d_dist_step(ec3d_handle c, int32_t stage, int32_t it, double t
         c->it_next = 1;
         c->xd_base = 1;
         c->xd_last = INT_MAX;
+        ec3d_xgroups_reset(c);
         ec3d_launch_residual(A, c->sweep_s, v[EC3D_VEC_X], v[EC3D_VEC_B], v[EC3D_VEC_R], v[EC3D_VEC_R0],
                              v[EC3D_VEC_P], c->partials, c->stream);
         fin(EC3D_BY_SPMV, 1u << P_BB | 1u << P_RR_INIT);

@@ -190,7 +190,9 @@ struct SolverState {
     int restarts;  // times the restart R0 = R, P = R (solvers.f90:47-49) fired in this solve (ec3d_get_restart_count)
     int pad_;
     // X updates not applied yet (k4d_x_r_update): alpha, omega of the pending iterations, oldest first
-    double pend_alpha[EC3D_XD_MAX], pend_omega[EC3D_XD_MAX];
+    // (two groups' worth: with the groups applied by a kernel of their own beside the iteration -- ec3d_xasync -- the
+    // entry of iteration it is it % (2 D), and group g + 1 fills its half while group g's kernel still reads the other)
+    double pend_alpha[2 * EC3D_XD_MAX], pend_omega[2 * EC3D_XD_MAX];
     int npend;     // how many
     int pend_half; // the newest one is the ||S|| exit's X = X + alpha*P (no omega*S term)
 };
@@ -297,8 +299,20 @@ struct ec3d_ctx {
     // pbuf[it % D] and S(it) in sbuf[it % D] (index 1 = vec[EC3D_VEC_P] / vec[EC3D_VEC_S]); AP keeps its two buffers.
     double *pp_base = nullptr;
     int64_t pp_len = 0;    // doubles allocated at pp_base
-    double *pbuf[EC3D_XD_MAX] = {nullptr}, *sbuf[EC3D_XD_MAX] = {nullptr}, *apbuf[2] = {nullptr, nullptr};
-    int pdepth = 2;        // buffers P cycles through (2, or D)
+    double *pbuf[2 * EC3D_XD_MAX] = {nullptr}, *sbuf[2 * EC3D_XD_MAX] = {nullptr}, *apbuf[2] = {nullptr, nullptr};
+    int pdepth = 2;        // buffers P cycles through (2, or D; 2 D with the X groups on a stream of their own)
+    int sdepth = 1;        // buffers S cycles through (D; 2 D with the X groups on a stream of their own)
+    int ring_cap = 0;      // ring buffers allocated for each of P and S (ec3d_spare_pair): D, or 2 D
+    // The groups of D pending X updates applied by a kernel of their own (k_x_group) on a second, low-priority stream,
+    // beside the following iterations, instead of by every D-th K4: nothing in the loop reads X, so the work fills what
+    // the iteration leaves idle -- on a z-slab the waits for halo planes and reduced sums (ec3d_xasync)
+    bool xasync_cap = false;  // the rings hold two groups (2 D buffers each)
+    bool xasync_forced = false; // EC3D_XASYNC=2: also on a handle that is no slab (tests)
+    bool slab_xasync = false; // a z-slab: the job's driver said so (every rank the same ring depth)
+    hipStream_t xstream = nullptr;
+    hipEvent_t ev_xready = nullptr, ev_xdone[2] = {nullptr, nullptr};
+    int xg_n = 0;          // groups launched since the last ec3d_launch_begin
+    int xg_done_upto = 0;  // the last iteration whose X update an enqueued k_x_group covers
     int xdefer = 1;        // D: iterations between two X updates on this handle (1: every iteration, the classic K4)
     int xd_base = 1;       // the iteration the groups of D are counted from (1 in a solve; ec3d_iterate: its first_iter)
     int xd_last = 0x7fffffff; // the last iteration the present call is going to launch: it applies whatever is pending
@@ -475,9 +489,17 @@ inline int ec3d_xdefer(const ec3d_ctx *c)
     }
     return (ec3d_fused23(c) == ec3d_fused51(c)) ? c->xdefer : 1;
 }
+// the pending X updates applied group by group on a stream of their own (only with the X update deferred)
+inline bool ec3d_xasync(const ec3d_ctx *c)
+{
+    if (!c->xasync_cap || ec3d_xdefer(c) <= 1) return false;
+    return (c->dist || c->halo != 0) ? c->slab_xasync : c->xasync_forced;
+}
 // where vector `vec` (EC3D_VEC_P / _AP / _S; anything else: the plain work vector) of iteration `it` lives on this handle
 double *ec3d_vec_at(const ec3d_ctx *c, int vec, int it);
 int ec3d_flush_x(ec3d_ctx *c, int stop_iter); // the pending X updates after an exit at stop_iter (enqueued)
+void ec3d_launch_x_group_of(ec3d_ctx *c, int first, int count, bool join);
+void ec3d_xgroups_reset(ec3d_ctx *c);
 void ec3d_launch_iteration(ec3d_ctx *c, const MatView &A, int it);
 int ec3d_launch_begin(ec3d_ctx *c, const MatView &A, double tol);
 int ec3d_single_rank_only(ec3d_ctx *c, const char *who);
@@ -510,6 +532,8 @@ void ec3d_launch_k4s(const MatView &A, const Sweep &sw, const RedSrc &src_ss, co
                      double *part, double *hist, int64_t hist_cap, hipStream_t s);
 void ec3d_launch_x_flush(const Sweep &sw, const SolverState *st, const double *const *p, const double *const *sv,
                          double *x, hipStream_t s);
+void ec3d_launch_x_group(const Sweep &sw, const SolverState *st, const double *const *p, const double *const *sv, int first,
+                         int count, int d2, double *x, int nblk, hipStream_t s);
 void ec3d_launch_k4(const Sweep &sw, const RedSrc &src_ss, const RedSrc &src, SolverState *st, int it,
                     const double *p, const double *sv, const double *as, const double *r0, double *x, double *r,
                     double *part, double *hist, int64_t hist_cap, hipStream_t s);

@@ -2542,6 +2542,81 @@ void ec3d_launch_k4s(const MatView &A, const Sweep &sw, const RedSrc &src_ss, co
 #undef EC3D_K4S
 }
 
+// A GROUP of X updates -- iterations first .. first + count - 1 -- applied by a launch of its own on a second stream, beside
+// the iterations that follow (ec3d_xasync: every K4 then leaves X alone).  alpha / omega of iteration it wait in entry
+// it % nent of the SolverState (nent = two groups), P and S in rings of nent buffers; the iterations' own kernels only come
+// back to those entries and buffers after this launch has finished (the host makes the main stream wait).  An exit
+// INSIDE the group ends it there -- the ||S|| exit's X = X + alpha*P without the omega*S term (src/solvers.f90:34-38) --
+// and an exit before it leaves nothing to do: the stop word any kernel of the group's iterations published is final when
+// this launch starts (it is ordered behind the group's last K4; a later ||R|| exit of that same iteration means "all").
+// One (X + alpha*P) + omega*S per iteration, oldest first: the bits of k4d_x_r_update's applying form.
+__global__ __launch_bounds__(EC3D_THREADS) void k_x_group(SweepV sw, const SolverState *st, XRing ring, int first, int count, int nent,
+                                                          double *__restrict__ x)
+{
+    int si, kind;
+    stop_read(st, si, kind);
+    double pa[EC3D_XD_MAX], po[EC3D_XD_MAX];
+#pragma unroll
+    for (int j = 0; j < EC3D_XD_MAX; ++j) {
+        const int e = (first + (j < count ? j : 0)) % nent;
+        pa[j] = st->pend_alpha[e];
+        po[j] = st->pend_omega[e];
+    }
+    if (si < first) return;
+    int np = count, half = 0;
+    if (si - first < count) {
+        np = si - first + 1;
+        half = kind == 1;
+    }
+    struct Ops { d2 xv, pv[EC3D_XD_MAX], s[EC3D_XD_MAX]; };
+    walk_vec(sw, [&](int64_t tile) {
+        EC3D_ROW;
+        Ops o;
+        o.xv = load2<true>(x + r);
+#pragma unroll
+        for (int j = 0; j < EC3D_XD_MAX; ++j)
+            if (j < np) {
+                o.pv[j] = load2<true>(ring.p[j] + r);
+                o.s[j] = (half && j == np - 1) ? d2{0.0, 0.0} : load2<true>(ring.s[j] + r);
+            }
+        return o;
+    }, [&](int64_t tile, const Ops &o) {
+        EC3D_ROW;
+        d2 xv = o.xv;
+#pragma unroll
+        for (int j = 0; j < EC3D_XD_MAX; ++j)
+            if (j < np) {
+                if (half && j == np - 1) { // X = X + alpha*P alone: no second addition (X + 0.0 could turn -0 into +0)
+                    xv.x = xv.x + pa[j] * o.pv[j].x;
+                    xv.y = xv.y + pa[j] * o.pv[j].y;
+                } else {
+                    xv.x = (xv.x + pa[j] * o.pv[j].x) + po[j] * o.s[j].x;
+                    xv.y = (xv.y + pa[j] * o.pv[j].y) + po[j] * o.s[j].y;
+                }
+            }
+        store2<true>(x, r, sw.n, xv.x, xv.y);
+    });
+}
+
+void ec3d_launch_x_group(const Sweep &sw, const SolverState *st, const double *const *p, const double *const *sv, int first,
+                         int count, int d2, double *x, int nblk, hipStream_t s)
+{
+    XRing ring{};
+    for (int j = 0; j < EC3D_XD_MAX; ++j) {
+        ring.p[j] = p[j];
+        ring.s[j] = sv[j];
+    }
+    SweepV swv = sweep_v(sw);
+    // fewer workgroups than the iteration's kernels when asked for (a smaller share of the bandwidth while they run);
+    // the tile walk is a stride over whatever grid it is given
+    const int wg = nblk > 0 ? std::min(nblk, sw.nblk) : sw.nblk;
+    if (wg != sw.nblk) { // (a plain stride over the tiles: the XCD-aware deal is tied to the full grid)
+        swv.nblk = wg;
+        swv.S = 0;
+    }
+    k_x_group<<<wg, EC3D_THREADS, 0, s>>>(swv, st, ring, first, count, d2, x);
+}
+
 void ec3d_launch_x_flush(const Sweep &sw, const SolverState *st, const double *const *p, const double *const *sv,
                          double *x, hipStream_t s)
 {

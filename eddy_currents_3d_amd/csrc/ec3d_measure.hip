@@ -61,6 +61,15 @@ extern "C" int ec3d_get_x_interval(ec3d_handle c, int32_t *iterations)
     return 0;
 }
 
+extern "C" int ec3d_get_x_groups(ec3d_handle c, int32_t *second_stream, int32_t *groups_launched)
+{
+    int rc = ec3d_need_matrix(c, "ec3d_get_x_groups");
+    if (rc) return rc;
+    if (second_stream) *second_stream = ec3d_xasync(c) ? 1 : 0;
+    if (groups_launched) *groups_launched = c->xg_n;
+    return 0;
+}
+
 extern "C" int ec3d_get_k4_form(ec3d_handle c, int32_t *spmv_form)
 {
     int rc = ec3d_need_matrix(c, "ec3d_get_k4_form");

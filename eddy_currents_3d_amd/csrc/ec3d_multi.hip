@@ -160,7 +160,7 @@ struct ec3d_multi {
     // Timing and call counts are those of the real rank; the numbers computed are not a solution of anything.
     bool rehearse = false;
     double *gsum = nullptr;    // [world * P_NSLOT] the all-gathered sums
-    double *agbuf = nullptr;   // [(world + 1) * 8] set-up exchanges between the ranks
+    double *agbuf = nullptr;   // [(world + 1) * kFacts] set-up exchanges between the ranks
     std::vector<std::unique_ptr<Slab>> slab;
     Pool pool;
     std::atomic<bool> abort{false};
@@ -338,6 +338,7 @@ int cross_wait(hipStream_t stream, hipEvent_t ev)
 // (every rank of a job runs the same plan with the same depths, and my state is current when I get here), the pointer
 // taken from the owner's tables, which do not change while a job runs: another rank's thread may be iterations ahead or
 // behind with its own host-side bookkeeping.
+constexpr int kFacts = 10;         // doubles every rank tells the others at set-up (finish_setup)
 constexpr int kPlainVec = INT_MIN; // `it` of a caller that means the plain work vector (uploads, probes, the time loop's X)
 double *vec_of(const ec3d_ctx *me, const ec3d_ctx *owner, int vec, int it)
 {
@@ -347,7 +348,7 @@ double *vec_of(const ec3d_ctx *me, const ec3d_ctx *owner, int vec, int it)
     switch (vec) {
     case EC3D_VEC_P: return (f51 || D > 1) ? owner->pbuf[((it + me->p_off) % pd + pd) % pd] : owner->vec[EC3D_VEC_P];
     case EC3D_VEC_AP: return f51 ? owner->apbuf[it & 1] : owner->vec[EC3D_VEC_AP];
-    case EC3D_VEC_S: return D > 1 ? owner->sbuf[((it % D) + D) % D] : owner->vec[EC3D_VEC_S];
+    case EC3D_VEC_S: return D > 1 ? owner->sbuf[((it % me->sdepth) + me->sdepth) % me->sdepth] : owner->vec[EC3D_VEC_S];
     default: return owner->vec[vec];
     }
 }
@@ -692,8 +693,8 @@ int finish_setup(ec3d_multi *m)
     // What every rank has to know of every other: can it run the three-launch iteration, the depth of its rings, its
     // storage format, its size, what it sends to its neighbours.  One process: read off the slabs; one process per GPU:
     // eight doubles per rank, all-gathered once.
-    struct RankFacts { double fused_ok, xd, sav, n_pad, snd_lo, rcv_lo, snd_hi, rcv_hi; };
-    static_assert(sizeof(RankFacts) == 8 * sizeof(double), "eight doubles");
+    struct RankFacts { double fused_ok, xd, sav, n_pad, snd_lo, rcv_lo, snd_hi, rcv_hi, xasync, spare; };
+    static_assert(sizeof(RankFacts) == kFacts * sizeof(double), "kFacts doubles");
     std::vector<RankFacts> facts((size_t)(m->nccl ? m->comm_world : m->n));
     auto facts_of = [&](const Slab &sl) {
         const ec3d_ctx *c = sl.c;
@@ -701,6 +702,7 @@ int finish_setup(ec3d_multi *m)
         RankFacts f{};
         f.fused_ok = (c->fuse23_ok && c->fuse51_ok && c->k4s_ok && c->pp_base && c->own_vectors) ? 1.0 : 0.0;
         f.xd = (c->pp_base && c->own_vectors) ? (double)c->xdefer : 1.0;
+        f.xasync = (c->pp_base && c->own_vectors && c->xasync_cap) ? 1.0 : 0.0;
         f.sav = c->A.sav ? 1.0 : 0.0;
         f.n_pad = (double)c->A.n_pad;
         f.snd_lo = total(sl.send_lo); f.rcv_lo = total(sl.recv_lo); f.snd_hi = total(sl.send_hi); f.rcv_hi = total(sl.recv_hi);
@@ -710,9 +712,9 @@ int finish_setup(ec3d_multi *m)
         const RankFacts mine = facts_of(*m->slab[0]);
         rc = run_all(m, [&](int) -> int {
             Slab &s = *m->slab[0];
-            double *snd = m->agbuf + (size_t)m->comm_world * 8;
+            double *snd = m->agbuf + (size_t)m->comm_world * kFacts;
             MHIP(hipMemcpyAsync(snd, &mine, sizeof mine, hipMemcpyHostToDevice, s.c->stream));
-            MNCCL(m, m->nccl->AllGather(snd, m->agbuf, 8, ncclDouble, m->comm_sum, s.c->stream));
+            MNCCL(m, m->nccl->AllGather(snd, m->agbuf, kFacts, ncclDouble, m->comm_sum, s.c->stream));
             MHIP(hipMemcpyAsync(facts.data(), m->agbuf, facts.size() * sizeof(RankFacts), hipMemcpyDeviceToHost, s.c->stream));
             MHIP(hipStreamSynchronize(s.c->stream));
             return 0;
@@ -745,11 +747,16 @@ int finish_setup(ec3d_multi *m)
     //          force it on small grids).  EC3D_SLAB_FUSE=0 keeps five launches.
     //   xd:    the smallest depth any slab allocated rings for (ec3d_spare_pair: 4 from 4.5 Mi streamed rows).
     //          EC3D_SLAB_XDEFER=1 switches it off, 2 .. 4 caps it.
+    //   xasync: the groups of X updates on a stream of their own (ec3d_xasync) when every slab holds rings of two groups
+    //          (ec3d_spare_pair: a z-slab with the X update deferred does; EC3D_XASYNC=0 never) -- the ring depth decides
+    //          where an exchanged P or S lives, so it is the job's, like xd.
     bool fused = m->kind == 1 && m->world > 1;
+    bool xasync = m->world > 1;
     int xd = EC3D_XD_MAX;
     for (const RankFacts &f : facts) {
         fused = fused && f.fused_ok != 0.0;
         xd = std::min(xd, (int)f.xd);
+        xasync = xasync && f.xasync != 0.0;
     }
     if (const char *e = getenv("EC3D_SLAB_FUSE")) fused = fused && atoi(e) != 0;
     if (const char *e = getenv("EC3D_SLAB_XDEFER")) xd = std::min(xd, std::max(1, atoi(e)));
@@ -765,9 +772,16 @@ int finish_setup(ec3d_multi *m)
         c->lsum_ptrs = m->nccl ? nullptr : s.ptr_table; // one process: every rank's sums read in place
         c->slab_fused = fused;
         c->slab_xd = xd;
+        // (three-launch slabs keep the applying K4: measured, the second launch costs them more than it fills)
+        const bool xa_forced = getenv("EC3D_XASYNC") && atoi(getenv("EC3D_XASYNC")) == 2;
+        c->slab_xasync = xasync && xd > 1 && (!fused || xa_forced);
         c->sweep_s.halo_store = fused ? ((s.rank > 0 ? 1 : 0) | (s.rank + 1 < m->world ? 2 : 0)) : 0;
         c->sweep_fb.halo_store = c->sweep_fi.halo_store = c->sweep_s.halo_store;
-        if (c->pp_base) c->pdepth = std::max(2, ec3d_xdefer(c)); // every rank cycles P through the same number of buffers
+        if (c->pp_base) { // every rank cycles P and S through the same number of buffers
+            const int D = ec3d_xdefer(c), depth = ec3d_xasync(c) ? 2 * D : D;
+            c->pdepth = std::max(2, depth);
+            c->sdepth = std::max(1, depth);
+        }
         s.plan = 0;
         s.split_ok = false;
         // EC3D_SLAB_PLAN (the SAME value on every rank: plan 2 orders its exchanges differently) picks the five-launch plan of
@@ -1084,7 +1098,7 @@ extern "C" int ec3d_multi_create_rank(ec3d_multi_handle *mh, int32_t rank, int32
         MNCCL(m, api->CommInitRank(&m->comm_sum, nranks, is, rank));
         MHIP(hipMalloc(&m->gsum, (size_t)nranks * P_NSLOT * sizeof(double)));
         MHIP(hipMemset(m->gsum, 0, (size_t)nranks * P_NSLOT * sizeof(double)));
-        MHIP(hipMalloc(&m->agbuf, (size_t)(nranks + 1) * 8 * sizeof(double)));
+        MHIP(hipMalloc(&m->agbuf, (size_t)(nranks + 1) * kFacts * sizeof(double)));
         return 0;
     });
     if (rc) {

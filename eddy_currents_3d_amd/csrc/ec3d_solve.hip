@@ -50,7 +50,7 @@ double *ec3d_vec_at(const ec3d_ctx *c, int vec, int it)
     switch (vec) {
     case EC3D_VEC_P: return (f51 || D > 1) ? c->pbuf[((it + c->p_off) % pd + pd) % pd] : c->vec[EC3D_VEC_P];
     case EC3D_VEC_AP: return f51 ? c->apbuf[it & 1] : c->vec[EC3D_VEC_AP];
-    case EC3D_VEC_S: return D > 1 ? c->sbuf[((it % D) + D) % D] : c->vec[EC3D_VEC_S];
+    case EC3D_VEC_S: return D > 1 ? c->sbuf[((it % c->sdepth) + c->sdepth) % c->sdepth] : c->vec[EC3D_VEC_S];
     default: return c->vec[vec];
     }
 }
@@ -83,28 +83,33 @@ void ec3d_launch_stage(ec3d_ctx *c, const MatView &A, int it, int k, int part)
         ec3d_launch_k1(A, ss, c->state, it, P, v[EC3D_VEC_R0], AP, c->partials, s);
     if ((k == 0 || k == 2) && !fused) {
         ec3d_launch_k2(c->sweep_k2, ec3d_src_of(c, EC3D_BY_SPMV), c->state, it, v[EC3D_VEC_R], AP, S, c->partials, s);
-        c->scur = D > 1 ? it % D : 1;
+        c->scur = D > 1 ? it % c->sdepth : 1;
     }
     if ((k == 0 || k == 3) && fused) {
         ec3d_launch_k23(A, ss, ec3d_src_of(c, EC3D_BY_SPMV), c->state, it, v[EC3D_VEC_R], AP, S,
                         ec3d_k4s(c) ? nullptr : v[EC3D_VEC_AS], c->partials, s); // (K4 in SpMV form computes A S again)
-        c->scur = D > 1 ? it % D : 1;
+        c->scur = D > 1 ? it % c->sdepth : 1;
     }
     if ((k == 0 || k == 3) && !fused)
         ec3d_launch_k3(A, ss, c->state, it, S, v[EC3D_VEC_AS], c->partials, s);
     if (k == 0 || k == 4) {
         // position of this iteration in its group of D, and how many updates an applying launch finds pending
         const int xm = D > 1 ? (it - c->xd_base) % D : 0;
-        const bool apply = D <= 1 || xm == D - 1 || it >= c->xd_last;
+        // (ec3d_xasync: no K4 touches X; alpha / omega of iteration it wait in entry it % 2D, and the group's own launch --
+        // below, behind the K4 of its last iteration -- applies them)
+        const bool xa = ec3d_xasync(c);
+        const bool group_end = D > 1 && (xm == D - 1 || it >= c->xd_last);
+        const bool apply = !xa && (D <= 1 || group_end);
+        const int xe = xa ? it % (2 * D) : xm; // the entry this K4 leaves its alpha / omega in
         if (ec3d_k4s(c)) {
             const double *pp[EC3D_XD_MAX] = {nullptr}, *sp[EC3D_XD_MAX] = {nullptr};
             const int ne = apply ? xm + 1 : 0;
             for (int j = 0; j < ne; ++j) { // iterations it - xm .. it, oldest first
                 pp[j] = c->pbuf[pidx(it - xm + j)];
-                sp[j] = D > 1 ? c->sbuf[(it - xm + j) % D] : S;
+                sp[j] = D > 1 ? c->sbuf[(it - xm + j) % c->sdepth] : S;
             }
             if (ne == 0) sp[0] = S;
-            ec3d_launch_k4s(A, ss, ec3d_src_of(c, EC3D_BY_K2), ec3d_src_of(c, EC3D_BY_SPMV), c->state, it, ne, xm, pp, sp,
+            ec3d_launch_k4s(A, ss, ec3d_src_of(c, EC3D_BY_K2), ec3d_src_of(c, EC3D_BY_SPMV), c->state, it, ne, xe, pp, sp,
                             v[EC3D_VEC_R0], v[EC3D_VEC_X], v[EC3D_VEC_R], c->partials, c->hist, c->hist_cap, s);
         } else if (D <= 1 || (apply && xm == 0)) {
             ec3d_launch_k4(sw, ec3d_src_of(c, EC3D_BY_K2), ec3d_src_of(c, EC3D_BY_SPMV), c->state, it, P, S, v[EC3D_VEC_AS],
@@ -114,13 +119,14 @@ void ec3d_launch_stage(ec3d_ctx *c, const MatView &A, int it, int k, int part)
             const int ne = apply ? xm + 1 : 0;
             for (int j = 0; j < ne; ++j) { // iterations it - xm .. it, oldest first
                 pp[j] = c->pbuf[pidx(it - xm + j)];
-                sp[j] = c->sbuf[(it - xm + j) % D];
+                sp[j] = c->sbuf[(it - xm + j) % c->sdepth];
             }
             if (ne == 0) sp[0] = S;
-            ec3d_launch_k4d(sw, ec3d_src_of(c, EC3D_BY_K2), ec3d_src_of(c, EC3D_BY_SPMV), c->state, it, ne, xm, pp, sp,
+            ec3d_launch_k4d(sw, ec3d_src_of(c, EC3D_BY_K2), ec3d_src_of(c, EC3D_BY_SPMV), c->state, it, ne, xe, pp, sp,
                             v[EC3D_VEC_AS], v[EC3D_VEC_R0], v[EC3D_VEC_X], v[EC3D_VEC_R], c->partials, c->hist, c->hist_cap,
                             s);
         }
+        if (xa && group_end && part != 1) ec3d_launch_x_group_of(c, it - xm, xm + 1, it >= c->xd_last);
     }
     if ((k == 0 || k == 5) && part != 1) c->it_next = it + 1;
     if ((k == 0 || k == 5) && !f51) {
@@ -137,17 +143,62 @@ void ec3d_launch_stage(ec3d_ctx *c, const MatView &A, int it, int k, int part)
     }
 }
 
+// a new run of iterations on this handle: whatever the second stream still holds belongs to the last one and is waited for
+void ec3d_xgroups_reset(ec3d_ctx *c)
+{
+    if (c->xstream && c->xg_n > 0) (void)hipStreamWaitEvent(c->stream, c->ev_xdone[(c->xg_n - 1) & 1], 0);
+    c->xg_n = 0;
+    c->xg_done_upto = 0;
+}
+
+// ec3d_xasync: the X updates of iterations first .. first + count - 1 as a launch of their own on the second stream,
+// ordered behind what the main stream holds now (the K4 of the group's last iteration).  Before that, the main stream
+// is made to wait for the PREVIOUS group's launch: the kernels that follow write the ring buffers and SolverState
+// entries two groups back, i.e. that group's.  join: the main stream also waits for this launch (the last group of a
+// call: whoever synchronises the main stream then has X).
+void ec3d_launch_x_group_of(ec3d_ctx *c, int first, int count, bool join)
+{
+    const int D = ec3d_xdefer(c), d2 = 2 * D, pd = c->pdepth;
+    const double *pp[EC3D_XD_MAX], *sp[EC3D_XD_MAX];
+    for (int j = 0; j < EC3D_XD_MAX; ++j) { // entries past the count are never dereferenced: any valid pointer
+        const int itj = first + std::min(j, count - 1);
+        pp[j] = c->pbuf[((itj + c->p_off) % pd + pd) % pd];
+        sp[j] = c->sbuf[itj % c->sdepth];
+    }
+    // 128 workgroups (half a workgroup per CU): beside the iteration's kernels the launch takes a small share of the
+    // bandwidth, in the gaps between them -- halo planes under way, sums being gathered -- it has the card to itself.
+    // 64 ... 256 measured within 2 % of each other on 7 - 16 Mi-row slabs, the vector kernels' own grid (512 and more) 3 % worse
+    // (profiles/r05_x_groups_on_a_second_stream.log).  EC3D_XASYNC_WGS overrides (0: the vector kernels' grid).
+    const int wgs = getenv("EC3D_XASYNC_WGS") ? atoi(getenv("EC3D_XASYNC_WGS")) : 128;
+    (void)hipEventRecord(c->ev_xready, c->stream);
+    if (c->xg_n > 0) (void)hipStreamWaitEvent(c->stream, c->ev_xdone[(c->xg_n - 1) & 1], 0);
+    (void)hipStreamWaitEvent(c->xstream, c->ev_xready, 0);
+    ec3d_launch_x_group(c->sweep, c->state, pp, sp, first, count, d2, c->vec[EC3D_VEC_X], wgs, c->xstream);
+    (void)hipEventRecord(c->ev_xdone[c->xg_n & 1], c->xstream);
+    if (join) (void)hipStreamWaitEvent(c->stream, c->ev_xdone[c->xg_n & 1], 0);
+    ++c->xg_n;
+    c->xg_done_upto = first + count - 1;
+}
+
 // The X updates an exit at iteration stop_iter left pending (deferred X update): enqueued behind everything else.
 int ec3d_flush_x(ec3d_ctx *c, int stop_iter)
 {
     const int D = ec3d_xdefer(c);
+    if (ec3d_xasync(c)) {
+        // the groups already enqueued end themselves at the exit (k_x_group); the group the exit lies in may not have
+        // been enqueued yet (the host stopped before its last iteration): now, cut at the exit by the kernel itself
+        if (stop_iter > c->xg_done_upto) ec3d_launch_x_group_of(c, c->xg_done_upto + 1, D, true);
+        else if (c->xg_n > 0) EC3D_HIP(hipStreamWaitEvent(c->stream, c->ev_xdone[(c->xg_n - 1) & 1], 0));
+        EC3D_HIP(hipGetLastError());
+        return 0;
+    }
     if ((D <= 1 && !ec3d_k4s(c)) || stop_iter < c->xd_base) return 0;
     const int xm = (stop_iter - c->xd_base) % D;
     const double *pp[EC3D_XD_MAX], *sp[EC3D_XD_MAX];
     for (int j = 0; j < EC3D_XD_MAX; ++j) { // entries past the pending count are never dereferenced: any valid pointer
         const int itj = stop_iter - xm + std::min(j, xm);
         pp[j] = c->pbuf[((itj + c->p_off) % c->pdepth + c->pdepth) % c->pdepth];
-        sp[j] = D > 1 ? c->sbuf[itj % D] : c->vec[EC3D_VEC_S];
+        sp[j] = D > 1 ? c->sbuf[itj % c->sdepth] : c->vec[EC3D_VEC_S];
     }
     ec3d_launch_x_flush(c->sweep, c->state, pp, sp, c->vec[EC3D_VEC_X], c->stream);
     EC3D_HIP(hipGetLastError());
@@ -168,6 +219,7 @@ int ec3d_launch_begin(ec3d_ctx *c, const MatView &A, double tol)
     c->it_next = 1;
     c->xd_base = 1;
     c->xd_last = INT_MAX;
+    ec3d_xgroups_reset(c);
     EC3D_HIP(hipGetLastError());
     return 0;
 }

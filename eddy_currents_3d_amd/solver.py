@@ -57,7 +57,7 @@ EXPORTS = ["sprsbcgstabwr_", "ec3d_invalidate", "ec3d_create", "ec3d_destroy", "
            "ec3d_upload", "ec3d_download", "ec3d_device_vector", "ec3d_solve_resident", "ec3d_spmv",
            "ec3d_export_csr", "ec3d_get_cel_bnd", "ec3d_get_reduction_geometry",
            "ec3d_set_workgroups", "ec3d_get_matrix_info", "ec3d_time_kernel", "ec3d_time_iterations",
-           "ec3d_iterate_begin", "ec3d_iterate", "ec3d_get_fusion", "ec3d_get_x_interval", "ec3d_get_k4_form", "ec3d_get_band_placement", "ec3d_set_format", "ec3d_set_stream",
+           "ec3d_iterate_begin", "ec3d_iterate", "ec3d_get_fusion", "ec3d_get_x_interval", "ec3d_get_x_groups", "ec3d_get_k4_form", "ec3d_get_band_placement", "ec3d_set_format", "ec3d_set_stream",
            "ec3d_assemble_poisson_slab", "ec3d_vector_layout", "ec3d_adopt_vectors",
            "ec3d_dist_configure", "ec3d_dist_step", "ec3d_dist_set_boundary_rows", "ec3d_read_state_async", "ec3d_read_state", "ec3d_get_restart_count", "ec3d_set_zmarch", "ec3d_can_overlap",
            "ec3d_rhs_step", "ec3d_post_update", "ec3d_assemble_slab", "ec3d_vtk_fields", "ec3d_vtk_fields_begin", "ec3d_vtk_fields_wait",
@@ -165,6 +165,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.ec3d_iterate.argtypes = [hp, C.c_int32, C.c_int32, hp]
     L.ec3d_get_fusion.argtypes = [hp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.ec3d_get_x_interval.argtypes = [hp, C.POINTER(C.c_int32)]
+    L.ec3d_get_x_groups.argtypes = [hp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.ec3d_get_k4_form.argtypes = [hp, C.POINTER(C.c_int32)]
     L.ec3d_get_band_placement.argtypes = [hp, C.c_int32, hp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.ec3d_set_format.argtypes = [hp, C.c_int]
@@ -586,6 +587,13 @@ class EC3DSolver:
         d = C.c_int32(0)
         _chk(self.L, self.L.ec3d_get_x_interval(self.h, C.byref(d)), "ec3d_get_x_interval")
         return d.value
+
+    def x_groups(self):
+        """(on a second stream?, launches so far): whether the groups of deferred X updates are applied by launches of
+        their own beside the iteration instead of by every D-th K4 (ec3d_get_x_groups)."""
+        a, b = C.c_int32(0), C.c_int32(0)
+        _chk(self.L, self.L.ec3d_get_x_groups(self.h, C.byref(a), C.byref(b)), "ec3d_get_x_groups")
+        return bool(a.value), b.value
 
     def k4_as_spmv(self) -> bool:
         """K4 computes AS = A*S again instead of reading a stored AS (ec3d_get_k4_form)."""

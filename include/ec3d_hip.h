@@ -426,6 +426,12 @@ int ec3d_get_fusion(ec3d_handle h, int32_t *k2_in_k3, int32_t *k5_in_k1);
  * alone in D - 1 of D iterations and applies the D updates, in order and each as its own two rounded additions, in the
  * D-th -- nothing in the loop reads X, so X is the same bits; an exit applies what is pending before the solve returns */
 int ec3d_get_x_interval(ec3d_handle h, int32_t *iterations);
+/* second_stream = 1: with the X update deferred, NO K4 touches X; every group of D updates is applied by a launch of its own
+ * (k_x_group) on a second HIP stream beside the iterations that follow, P and S kept in rings of two groups -- the same
+ * additions in the same order, the same X.  Meant for z-slabs of a multi-GPU job, whose iteration waits for halo planes
+ * and gathered sums (EC3D_XASYNC=1; off by default: one card shows 0 ... 2 %).  groups_launched:
+ * such launches since the last solve / ec3d_iterate_begin started (tests) */
+int ec3d_get_x_groups(ec3d_handle h, int32_t *second_stream, int32_t *groups_launched);
 /* 1: K4 runs as an SpMV kernel that computes AS = A*S again from the S it reads anyway (k4s_x_r_spmv) and K2-in-K3 no
  * longer writes AS -- 16 B per row and iteration less for 13 flops per row; the same spmv code on the same tiles gives the
  * same AS bit for bit.  R.R and R.R0 are then summed in the SpMV kernels' order (ec3d_get_reduction_geometry(h, 0, ...)

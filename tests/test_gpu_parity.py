@@ -417,6 +417,23 @@ def test_two_dimensional_tiles_bitwise(E, oracle, grid, fuse, policy, monkeypatc
 @pytest.mark.parametrize("fuse", ["2", "2s", "0"], ids=["three-launches", "three-launches-K4-as-SpMV", "five-launches"])
 @pytest.mark.parametrize("depth", [1, 2, 3, 4])
 def test_deferred_x_update_bitwise(E, oracle, depth, fuse, grid, monkeypatch):
+    deferred_x_case(E, oracle, depth, fuse, grid, monkeypatch, False)
+
+
+@pytest.mark.parametrize("fuse", ["2", "2s", "0"], ids=["three-launches", "three-launches-K4-as-SpMV", "five-launches"])
+@pytest.mark.parametrize("depth", [2, 3, 4])
+def test_deferred_x_update_on_a_second_stream_bitwise(E, oracle, depth, fuse, monkeypatch):
+    """The same cases with every group of `depth` updates applied by a launch of its own (k_x_group) on a second stream,
+    beside the iterations that follow (EC3D_XASYNC=2 forces it on a plain handle; meant for z-slabs): no K4 touches X, P and
+    S wait in rings of two groups, alpha / omega in entry it % (2 depth) of the device state; the group an exit lies in
+    ends there by itself (or is added by the host when it had not been enqueued yet), the last group of a call is cut
+    short and joined.  Eight workgroups, so the launch's stride differs from the vector kernels' grid."""
+    monkeypatch.setenv("EC3D_XASYNC", "2")
+    monkeypatch.setenv("EC3D_XASYNC_WGS", "8")
+    deferred_x_case(E, oracle, depth, fuse, (256, 8, 9), monkeypatch, True)
+
+
+def deferred_x_case(E, oracle, depth, fuse, grid, monkeypatch, second_stream):
     """X = X + alpha*P + omega*S (src/solvers.f90:41) applied every `depth`-th iteration (k4d_x_r_update: P and S of the
     pending iterations wait in rings, alpha and omega in the solver state; the default from 32 Mi rows with depth 4,
     forced here on the three-launch iteration of a small grid).  Nothing in the loop reads X, the updates are applied in
@@ -444,6 +461,7 @@ def test_deferred_x_update_bitwise(E, oracle, depth, fuse, grid, monkeypatch):
     with E.EC3DSolver() as s:
         s.assemble_poisson(sdx, sdy, sdz)
         assert s.fusion() == ((1, 1) if fuse == "2" else (0, 0)) and s.x_interval() == depth
+        assert s.x_groups()[0] == (second_stream and depth > 1)
         assert (s.geometry(0).nblk == s.geometry(1).nblk and s.geometry(0).patch_x == 128) == k4s
         # to convergence, with the history: the norms below give tolerances that end the solve at chosen iterations
         x, it, hist = s.solve(b, x0, 1e-10, 5000, hist_cap=64)

@@ -20,7 +20,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 KNOBS = ("EC3D_SLAB_FSPLIT", "EC3D_SLAB_PLAN", "EC3D_NT", "EC3D_FUSE23", "EC3D_FUSE51", "EC3D_XDEFER", "EC3D_K4S", "EC3D_SLAB_FUSE",
-         "EC3D_SLAB_XDEFER")
+         "EC3D_SLAB_XDEFER", "EC3D_XASYNC", "EC3D_XASYNC_WGS")
 
 
 @pytest.fixture(scope="module")
@@ -78,6 +78,9 @@ CASES = [
     ("three-launches,X/4", (128, 8, 48), dict(FUSED, XDEFER=4, SLAB_FSPLIT=0), 3),
     ("three-launches-split,X/4", (128, 8, 48), dict(FUSED, XDEFER=4), 4),
     ("three-launches-split,X/3", (128, 8, 48), dict(FUSED, XDEFER=3), 4),
+    # the groups of X updates as launches of their own on a second stream (rings of two groups: the exchanged P and S live there)
+    ("interior+boundary,X/4 beside the iteration", (128, 8, 48), dict(XDEFER=4, XASYNC=1, XASYNC_WGS=8), 1),
+    ("three-launches-split,X/4 beside the iteration", (128, 8, 48), dict(FUSED, XDEFER=4, XASYNC=2, XASYNC_WGS=8), 4),
 ]
 
 

@@ -25,7 +25,7 @@ pytestmark = pytest.mark.gpu
 
 KNOBS = ("EC3D_SLAB_FSPLIT", "EC3D_SLAB_PLAN", "EC3D_NT", "EC3D_KEEP", "EC3D_FUSE23", "EC3D_FUSE51", "EC3D_PATCH", "EC3D_NBLK", "EC3D_NBLK_SPMV", "EC3D_VEC_DEPTH",
          "EC3D_XCD_MAP", "EC3D_ZMARCH", "EC3D_XDEFER", "EC3D_XD_OFF_DEPTH", "EC3D_XD_ON_DEPTH", "EC3D_K4S", "EC3D_SLAB_FUSE",
-         "EC3D_SLAB_XDEFER")
+         "EC3D_SLAB_XDEFER", "EC3D_XASYNC", "EC3D_XASYNC_WGS", "EC3D_XASYNC_PRIO")
 
 
 @pytest.fixture(scope="module")
@@ -223,3 +223,60 @@ def test_iterate_continues_and_refuses_to_restart_its_numbering(E, oracle, monke
             m.iterate(1, 2)
             m.synchronize()
     assert np.array_equal(out[0], out[1]) and np.array_equal(out[0], out[2])
+
+
+@pytest.mark.parametrize("fused", [True, False], ids=["three-launches", "five-launches"])
+def test_x_groups_on_a_second_stream_bitwise(E, oracle, monkeypatch, fused):
+    """EC3D_XASYNC: no K4 touches X; every group of four updates is applied by a launch of its own (k_x_group) on a second
+    stream beside the iterations that follow, P and S in rings of two groups, alpha / omega in entry it % 8 of the device
+    state.  The same additions in the same order: x, iter and restarts are the twin's -- on the system where the restart
+    rule fires, with the itmax exit at every position of a group (the last group of a call is cut short and joined), and
+    with the ||S|| exit inside a group (the group's launch, or the flush the host adds when it had not enqueued it yet,
+    ends at the exit with the half update).  The second launch runs on 8 workgroups here, so its stride differs from
+    the vector kernels' grid."""
+    set_knobs(monkeypatch, XDEFER=4, XASYNC=2, XASYNC_WGS=8, **(FUSED if fused else {}))
+    # -- restarts, a full solve, three slabs
+    sdx, sdy, sdz = 256, 8, 31
+    n, kdz = sdx * sdy * sdz, sdx * sdy
+    valA, irow, jcol = oracle.poisson_csr(sdx, sdy, sdz)
+    rng = np.random.Generator(np.random.PCG64(2026))
+    x0 = np.zeros(n)
+    rng.standard_normal(n)
+    b = rng.standard_normal(n)
+    with E.EC3DMulti(3, devices=[0, 0, 0]) as m:
+        m.assemble_poisson(sdx, sdy, sdz)
+        plan = m.plan()[0]
+        assert plan == (4 if fused else 1)
+        x, it = m.solve(b, x0, 1e-9, 5000)
+        rs = restarts_of(m)
+        on = [m.slab(r)[0].x_groups() for r in range(3)]
+        xo, ito, _, _, rso = oracle.twin_solve_slabs(slabs_of(m, kdz), plan, valA, irow, jcol, b, x0, 1e-9, 5000)
+    assert all(a and g >= it // 4 for a, g in on), on          # the mode was on, and a launch per group went out
+    assert it == ito and np.array_equal(x, xo) and rso > 0 and all(r == rso for r in rs)
+    # -- itmax at every position of a group; the ||S|| exit inside a group; two slabs
+    sdx, sdy, sdz = 128, 8, 32
+    n, kdz = sdx * sdy * sdz, sdx * sdy
+    valA, irow, jcol = oracle.poisson_csr(sdx, sdy, sdz)
+    rng = np.random.Generator(np.random.PCG64(10))
+    b = rng.standard_normal(n)
+    x0 = np.zeros(n)
+    with E.EC3DMulti(2, devices=[0, 0]) as m:
+        m.assemble_poisson(sdx, sdy, sdz)
+        plan = m.plan()[0]
+        sl = slabs_of(m, kdz)
+        for k in range(1, 10):
+            x, it = m.solve(b, x0, 1e-30, k - 1)
+            xo, ito, _, _, _ = oracle.twin_solve_slabs(sl, plan, valA, irow, jcol, b, x0, 1e-30, k - 1)
+            assert it == ito == k and np.array_equal(x, xo), k
+        _, _, hs, hr, _ = oracle.twin_solve_slabs(sl, plan, valA, irow, jcol, b, x0, 1e-30, 13, hist_cap=14)
+        bn = np.linalg.norm(b)
+        seen = set()
+        for k in range(2, 13):
+            lo, hi = sorted((hs[k - 1], hr[k - 2]))
+            tol = 0.5 * (lo + hi) / bn
+            x, it = m.solve(b, x0, tol, 100)
+            xo, ito, _, _, _ = oracle.twin_solve_slabs(sl, plan, valA, irow, jcol, b, x0, tol, 100)
+            assert it == ito and np.array_equal(x, xo), k
+            seen.add((it - 1) % 4)
+        assert m.slab(0)[0].x_groups()[0]
+    assert len(seen) >= 3
