@@ -230,7 +230,7 @@ extern "C" int ec3d_dist_step(ec3d_handle c, int32_t stage, int32_t it, double t
         const bool bnd = stage == EC3D_STAGE_K2_BND;
         ec3d_launch_k2(bnd ? c->sweep_vb : c->sweep_vi, ec3d_src_of(c, EC3D_BY_SPMV), c->state, it, v[EC3D_VEC_R], v[EC3D_VEC_AP],
                        ec3d_vec_at(c, EC3D_VEC_S, it), c->partials, c->stream);
-        c->scur = ec3d_xdefer(c) > 1 ? it % ec3d_xdefer(c) : 1;
+        c->scur = ec3d_xdefer(c) > 1 ? it % c->sdepth : 1;
         if (!bnd)
             ec3d_launch_finalize(RedSrc{c->partials, c->sweep_vb.nblk + c->sweep_vi.nblk, 1, c->sweep.pstride, nullptr}, c->lsum,
                                  1u << P_SS, c->stream);
