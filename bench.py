@@ -404,6 +404,7 @@ def main():
                        + {0: "five launches per iteration, P and S exchanged in front of K1 / K3",
                           1: "five launches per iteration, K1 / K3 as interior + boundary launch around the exchange of P / S",
                           2: "five launches per iteration, K2 / K5 boundary tiles first",
+                          5: "five launches per iteration, K2 / K5 boundary planes first and K1 / K3 interior planes first",
                           3: "three launches per iteration (K2 inside K3, K4 as an SpMV kernel, K5 inside the next K1), "
                              "AP and R exchanged",
                           4: "three launches per iteration (K2 inside K3, K4 as an SpMV kernel, K5 inside the next K1), AP and "
@@ -517,6 +518,7 @@ def main():
                        f"planes as ncclSend/ncclRecv on a side stream, the sums by ncclAllGather; "
                        + {0: "five launches per iteration", 1: "five launches per iteration, K1 / K3 split around the exchange",
                           2: "five launches per iteration, K2 / K5 boundary tiles first",
+                          5: "five launches per iteration, K2 / K5 boundary planes first and K1 / K3 interior planes first",
                           3: "three launches per iteration, AP and R exchanged",
                           4: "three launches per iteration, AP and R exchanged behind the boundary launches of their "
                              "producers"}[multi_plan])

@@ -113,6 +113,15 @@ extern "C" int ec3d_dist_set_boundary_rows(ec3d_handle c, int32_t nranges, const
 // launch takes the first and the last owned plane, the interior launch the planes between, both as windows of the ordinary
 // strided sweep (Sweep::win_*: logical tile t of the boundary launch is tile t of plane 0 for t < tpp, of plane np-1 after;
 // the interior launch starts at plane 1) -- a list-driven K2 / K5 costs 15-30 us more at 16 Mi rows than the strided one.
+// can K2 / K5 of this slab run as a launch over planes 0 and np-1 followed by one over the planes between?
+bool ec3d_dist_can_split_planes(const ec3d_ctx *c)
+{
+    const Sweep &ss = c->sweep_s, &k2 = c->sweep_k2;
+    if (c->A.sav || c->halo <= 0 || c->nown != 0 || k2.ulist_n != 0 || ss.zm_tpp <= 0 || k2.win_nt != 0) return false;
+    const int64_t tpp = ss.zm_tpp, total = k2.ntiles, np = total / tpp;
+    return np * tpp == total && np >= 3;
+}
+
 int ec3d_dist_set_boundary_planes(ec3d_ctx *c, int32_t *enabled)
 {
     if (enabled) *enabled = 0;
@@ -121,9 +130,8 @@ int ec3d_dist_set_boundary_planes(ec3d_ctx *c, int32_t *enabled)
     if (c->vi_list) (void)hipFree(c->vi_list);
     c->vb_list = c->vi_list = nullptr;
     c->can_vsplit = false;
-    if (c->A.sav || c->halo <= 0 || c->nown != 0 || k2.ulist_n != 0 || ss.zm_tpp <= 0 || k2.win_nt != 0) return 0;
-    const int64_t tpp = ss.zm_tpp, total = k2.ntiles, np = total / tpp;
-    if (np * tpp != total || np < 3) return 0;
+    if (!ec3d_dist_can_split_planes(c)) return 0;
+    const int64_t tpp = ss.zm_tpp, total = k2.ntiles;
     Sweep vb = k2, vi = k2;
     vb.ntiles = 2 * tpp;
     vb.win_nt = tpp;

@@ -498,6 +498,7 @@ inline bool ec3d_xasync(const ec3d_ctx *c)
 // where vector `vec` (EC3D_VEC_P / _AP / _S; anything else: the plain work vector) of iteration `it` lives on this handle
 double *ec3d_vec_at(const ec3d_ctx *c, int vec, int it);
 int ec3d_flush_x(ec3d_ctx *c, int stop_iter); // the pending X updates after an exit at stop_iter (enqueued)
+bool ec3d_dist_can_split_planes(const ec3d_ctx *c);
 void ec3d_launch_x_group_of(ec3d_ctx *c, int first, int count, bool join);
 void ec3d_xgroups_reset(ec3d_ctx *c);
 void ec3d_launch_iteration(ec3d_ctx *c, const MatView &A, int it);

@@ -2175,7 +2175,7 @@ __global__ __launch_bounds__(EC3D_THREADS) void k5_p_update(SweepV sw, RedSrc sr
     const bool restart = fabs(rr0_new) / bnorm < tol;
     // next iteration's R·R0: after a restart R0 == R, so it is R·R in the same summation order
     if (lead) st->rr0[(it + 1) & 1] = restart ? d[0] : rr0_new;
-    if (lead && restart) st->restarts = st->restarts + 1;
+    if (lead && restart && sw.part_off == 0) st->restarts = st->restarts + 1; // (a split K5 -- boundary + interior launch -- counts once)
     if (restart) {
         walk_vec(sw, [&](int64_t tile) {
             EC3D_ROW;

@@ -84,6 +84,14 @@ const std::vector<Op> kIterOverlap = {{OP_HALO_START, CH_P}, ST(K1_INT), {OP_HAL
 const std::vector<Op> kIterVsplit = {{OP_HALO_WAIT, CH_P}, ST(K1), {OP_GATHER, 0}, ST(K2_BND), {OP_HALO_START, CH_S},
                                      ST(K2_INT), {OP_HALO_WAIT, CH_S}, ST(K3), {OP_GATHER, 0}, ST(K4), {OP_GATHER, 0},
                                      ST(K5_BND), {OP_HALO_START, CH_P, 1}, ST(K5_INT)};
+// both at once (plan 5, single-component slabs): the producers K2 / K5 run the boundary planes first and start the
+// exchange, the consumers K1 / K3 run their interior planes before they wait for it -- the planes have the producer's
+// interior launch AND the consumer's to arrive behind, instead of one of the two.  Same exchanges in the same order as
+// kIterVsplit (the first P travels from the begin plan on).
+const std::vector<Op> kBeginBoth = {{OP_HALO, CH_X}, ST(RESID), {OP_GATHER, 0}, ST(SETUP), {OP_HALO_START, CH_P, 1}};
+const std::vector<Op> kIterBoth = {ST(K1_INT), {OP_HALO_WAIT, CH_P}, ST(K1_BND), {OP_GATHER, 0}, ST(K2_BND),
+                                   {OP_HALO_START, CH_S}, ST(K2_INT), ST(K3_INT), {OP_HALO_WAIT, CH_S}, ST(K3_BND),
+                                   {OP_GATHER, 0}, ST(K4), {OP_GATHER, 0}, ST(K5_BND), {OP_HALO_START, CH_P, 1}, ST(K5_INT)};
 // The three-launch iteration on slabs of the single-component operator (every rank >= 32 Mi rows; ec3d_ctx::slab_fused):
 // K2 inside K3, K4 as an SpMV kernel, K5 inside the next iteration's K1.  S and P are formed on the halo planes by the
 // kernels that read them there (and stored into the ghost rows: Sweep::halo_store), so what travels is AP -- after
@@ -117,9 +125,11 @@ struct Slab {
     std::vector<Run> send_lo, recv_lo, send_hi, recv_hi; // towards rank-1 / rank+1, same order on both sides
     std::vector<Copy> pull_lo, pull_hi;                  // my ghost rows <- neighbour's rows
     std::vector<Piece> snd_lo, rcv_lo, snd_hi, rcv_hi;   // RCCL: contiguous pieces of my rows to send / my ghost rows to fill
-    bool split_ok = false;
+    bool split_ok = false;   // K2 / K5 can run as boundary + interior launch on this slab
+    bool overlap_ok = false; // K1 / K3 can run as interior + boundary launch on this slab
     int plan = 0; // 0 plain, 1 overlap (K1/K3 interior + boundary), 2 vsplit (K2/K5 boundary first), 3 three launches
-                  // (kIterFused), 4 three launches with the producers of R and AP split around the exchange
+                  // (kIterFused), 4 three launches with the producers of R and AP split around the exchange, 5 = 1 and 2
+                  // together (kIterBoth)
     int32_t *stop_pinned = nullptr;
     hipEvent_t ev_stop[2] = {};
     // A-V slab: local reference order [Ax_ext | Ay_ext | Az_ext | U_ext] <-> the global vector
@@ -470,6 +480,18 @@ int gather(ec3d_multi *m, Slab &s)
     return 0;
 }
 
+// a slab too thin for interior + boundary launches of K1 / K3 inside plan 5: the whole kernel where the boundary launch stands
+int unsplit_spmv_stage(int st)
+{
+    switch (st) {
+    case EC3D_STAGE_K1_BND: return EC3D_STAGE_K1;
+    case EC3D_STAGE_K3_BND: return EC3D_STAGE_K3;
+    case EC3D_STAGE_K1_INT:
+    case EC3D_STAGE_K3_INT: return -1;
+    default: return st;
+    }
+}
+
 int unsplit_stage(int st)
 {
     switch (st) {
@@ -517,7 +539,9 @@ int run_plan(ec3d_multi *m, Slab &s, const std::vector<Op> &plan, int it, double
             if (it != 1 && s.c->ap_valid_for == it) oi += (size_t)op.arg;
             break;
         default: {
-            const int st = (s.plan == 2 && !s.split_ok) ? unsplit_stage(op.arg) : op.arg;
+            int st = op.arg;
+            if ((s.plan == 2 || s.plan == 5) && !s.split_ok) st = unsplit_stage(st);
+            if (s.plan == 5 && !s.overlap_ok) st = unsplit_spmv_stage(st);
             if (st < 0) break;
             s.at.store("stage");
             s.at_arg.store(st);
@@ -543,10 +567,13 @@ int run_plan(ec3d_multi *m, Slab &s, const std::vector<Op> &plan, int it, double
     return 0;
 }
 
-const std::vector<Op> &begin_plan(const Slab &s) { return s.plan >= 3 ? kBeginFused : s.plan == 2 ? kBeginVsplit : kBegin; }
+const std::vector<Op> &begin_plan(const Slab &s)
+{
+    return s.plan == 5 ? kBeginBoth : s.plan >= 3 ? kBeginFused : s.plan == 2 ? kBeginVsplit : kBegin;
+}
 const std::vector<Op> &iter_plan(const Slab &s)
 {
-    return s.plan == 4 ? kIterFusedOverlap : s.plan == 3 ? kIterFused : s.plan == 2 ? kIterVsplit
+    return s.plan == 5 ? kIterBoth : s.plan == 4 ? kIterFusedOverlap : s.plan == 3 ? kIterFused : s.plan == 2 ? kIterVsplit
            : s.plan == 1 ? kIterOverlap : kIter;
 }
 
@@ -693,7 +720,7 @@ int finish_setup(ec3d_multi *m)
     // What every rank has to know of every other: can it run the three-launch iteration, the depth of its rings, its
     // storage format, its size, what it sends to its neighbours.  One process: read off the slabs; one process per GPU:
     // eight doubles per rank, all-gathered once.
-    struct RankFacts { double fused_ok, xd, sav, n_pad, snd_lo, rcv_lo, snd_hi, rcv_hi, xasync, spare; };
+    struct RankFacts { double fused_ok, xd, sav, n_pad, snd_lo, rcv_lo, snd_hi, rcv_hi, xasync, both_splits; };
     static_assert(sizeof(RankFacts) == kFacts * sizeof(double), "kFacts doubles");
     std::vector<RankFacts> facts((size_t)(m->nccl ? m->comm_world : m->n));
     auto facts_of = [&](const Slab &sl) {
@@ -703,6 +730,7 @@ int finish_setup(ec3d_multi *m)
         f.fused_ok = (c->fuse23_ok && c->fuse51_ok && c->k4s_ok && c->pp_base && c->own_vectors) ? 1.0 : 0.0;
         f.xd = (c->pp_base && c->own_vectors) ? (double)c->xdefer : 1.0;
         f.xasync = (c->pp_base && c->own_vectors && c->xasync_cap) ? 1.0 : 0.0;
+        f.both_splits = (c->have_matrix && c->can_overlap && ec3d_dist_can_split_planes(c)) ? 1.0 : 0.0;
         f.sav = c->A.sav ? 1.0 : 0.0;
         f.n_pad = (double)c->A.n_pad;
         f.snd_lo = total(sl.send_lo); f.rcv_lo = total(sl.recv_lo); f.snd_hi = total(sl.send_hi); f.rcv_hi = total(sl.recv_hi);
@@ -750,14 +778,25 @@ int finish_setup(ec3d_multi *m)
     //   xasync: the groups of X updates on a stream of their own (ec3d_xasync) when every slab holds rings of two groups
     //          (ec3d_spare_pair: a z-slab with the X update deferred does; EC3D_XASYNC=0 never) -- the ring depth decides
     //          where an exchanged P or S lives, so it is the job's, like xd.
+    //   both:  five launches with the exchange behind TWO of them (plan 5: K2 / K5 boundary planes first and K1 / K3 interior
+    //          planes first) when every slab can split both ways and the largest holds fewer than 10 Mi rows.  Measured
+    //          through the rank rehearsal against plan 1 (profiles/r05_plan5_both_splits.log): 2 Mi rows per rank 0.158 ->
+    //          0.149 ms per iteration, 6.75 Mi 0.268 -> 0.261, 16 Mi 0.480 -> 0.493 (there the four extra launches, each
+    //          beside a send / recv kernel, cost more than the waiting they remove).  The START of the P exchange differs
+    //          from plans 0 / 1 (behind K5's boundary launch, an iteration ahead), so the choice is the job's.
     bool fused = m->kind == 1 && m->world > 1;
     bool xasync = m->world > 1;
+    bool both = m->kind == 1 && m->world > 1;
+    double job_rows = 0;
     int xd = EC3D_XD_MAX;
     for (const RankFacts &f : facts) {
         fused = fused && f.fused_ok != 0.0;
         xd = std::min(xd, (int)f.xd);
         xasync = xasync && f.xasync != 0.0;
+        both = both && f.both_splits != 0.0;
+        job_rows = std::max(job_rows, f.n_pad);
     }
+    both = both && job_rows < 10.0 * 1048576.0;
     if (const char *e = getenv("EC3D_SLAB_FUSE")) fused = fused && atoi(e) != 0;
     if (const char *e = getenv("EC3D_SLAB_XDEFER")) xd = std::min(xd, std::max(1, atoi(e)));
     if (m->world == 1) xd = 0; // (a one-slab job is an ordinary handle: its own rule applies)
@@ -786,8 +825,10 @@ int finish_setup(ec3d_multi *m)
         s.split_ok = false;
         // EC3D_SLAB_PLAN (the SAME value on every rank: plan 2 orders its exchanges differently) picks the five-launch plan of
         // a single-component job: 0 exchange in front of K1 / K3, 1 K1 / K3 split around it, 2 K2 / K5 boundary tiles first
-        const int want_plan = getenv("EC3D_SLAB_PLAN") ? atoi(getenv("EC3D_SLAB_PLAN")) : -1;
-        if (m->kind == 1 && !(want_plan == 2 && !fused && m->world > 1)) {
+        int want_plan = getenv("EC3D_SLAB_PLAN") ? atoi(getenv("EC3D_SLAB_PLAN")) : -1;
+        if (want_plan < 0 && both && !fused) want_plan = 5;
+        s.overlap_ok = false;
+        if (m->kind == 1 && !((want_plan == 2 || want_plan == 5) && !fused && m->world > 1)) {
             const bool no_fsplit = getenv("EC3D_SLAB_FSPLIT") && atoi(getenv("EC3D_SLAB_FSPLIT")) == 0;
             s.plan = fused ? ((c->can_fsplit && !no_fsplit) ? 4 : 3) : (ec3d_can_overlap(c) && want_plan != 0) ? 1 : 0;
         } else if (m->kind == 2 && want_plan == 0) {
@@ -795,7 +836,8 @@ int finish_setup(ec3d_multi *m)
         } else if (m->world > 1) {
             // the ORDER of exchanges is a property of the job: every A-V rank uses the producer-side
             // plan; a rank whose slab is all boundary runs the whole kernels in that order
-            s.plan = 2;
+            s.plan = (m->kind == 1 && want_plan == 5) ? 5 : 2;
+            s.overlap_ok = s.plan == 5 && ec3d_can_overlap(c);
             std::vector<int64_t> lo, hi;
             for (const std::vector<Run> *rs : {&s.send_lo, &s.recv_lo, &s.send_hi, &s.recv_hi})
                 for (const Run &r : *rs)

@@ -222,10 +222,11 @@ def twin_solve_slabs(slabs, plan, valA, irow, jcol, b, x0, tol, itmax, hist_cap=
     by the same tree (reduce_partials over one value per rank).  slabs: [(EC3DSolver view of the slab, row0, row1)] in
     rank order, rows in the reference's numbering; plan: 0 plain, 1 K1 / K3 as interior + boundary launch, 2 K2 / K5 as
     boundary + interior launch, 3 three
-    launches, 4 three launches with K4 and K5-in-K1 as boundary + interior launch (what EC3DMulti.plan() reports).
+    launches, 4 three launches with K4 and K5-in-K1 as boundary + interior launch, 5 = 1 and 2 together (what
+    EC3DMulti.plan() reports).
     Returns (x, iter, hist_s, hist_r, restarts)."""
-    spmv_w = (3, 4) if plan == 1 else (1,)
-    ss_w = (5, 6) if plan == 2 else (2,)           # who sums S.S (plan 2: K2 as boundary + interior launch)
+    spmv_w = (3, 4) if plan in (1, 5) else (1,)    # (plan 5: both splits at once)
+    ss_w = (5, 6) if plan in (2, 5) else (2,)      # who sums S.S (plan 2: K2 as boundary + interior launch)
     k4_w = (7, 8) if plan == 4 else (0,)           # who sums R.R and R.R0
     k51_w = (7, 8) if plan == 4 else spmv_w        # who sums AP.R0 from the second iteration on (K5-in-K1 of the one before)
     geo = []

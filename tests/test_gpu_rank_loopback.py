@@ -74,12 +74,16 @@ def merge(x0, parts):
 FUSED = dict(FUSE23=2, FUSE51=2, K4S=2)
 CASES = [
     ("five-launches", (20, 12, 31), dict(), 0),
-    ("interior+boundary", (128, 8, 48), dict(), 1),
+    ("interior+boundary", (128, 8, 48), dict(SLAB_PLAN=1), 1),
+    ("both-split by default", (128, 8, 48), dict(), 5),
     ("three-launches,X/4", (128, 8, 48), dict(FUSED, XDEFER=4, SLAB_FSPLIT=0), 3),
     ("three-launches-split,X/4", (128, 8, 48), dict(FUSED, XDEFER=4), 4),
     ("three-launches-split,X/3", (128, 8, 48), dict(FUSED, XDEFER=3), 4),
+    ("both-split,X/4", (128, 8, 48), dict(XDEFER=4), 5),
+    ("producers-split,X/4", (128, 8, 48), dict(XDEFER=4, SLAB_PLAN=2), 2),
     # the groups of X updates as launches of their own on a second stream (rings of two groups: the exchanged P and S live there)
-    ("interior+boundary,X/4 beside the iteration", (128, 8, 48), dict(XDEFER=4, XASYNC=1, XASYNC_WGS=8), 1),
+    ("interior+boundary,X/4 beside the iteration", (128, 8, 48), dict(XDEFER=4, XASYNC=1, XASYNC_WGS=8, SLAB_PLAN=1), 1),
+    ("both-split,X/4 beside the iteration", (128, 8, 48), dict(XDEFER=4, XASYNC=1, XASYNC_WGS=8), 5),
     ("three-launches-split,X/4 beside the iteration", (128, 8, 48), dict(FUSED, XDEFER=4, XASYNC=2, XASYNC_WGS=8), 4),
 ]
 

@@ -47,16 +47,17 @@ def test_one_rank_job_over_rccl_equals_the_plain_handle(E, oracle):
     assert np.array_equal(y, oracle.spmv_csr(valA, irow, jcol, xs))
 
 
-@pytest.mark.parametrize("dims, knobs, plan", [((128, 8, 96), {}, 1), ((24, 24, 24), {}, 0),
+@pytest.mark.parametrize("dims, knobs, plan", [((128, 8, 96), dict(SLAB_PLAN=1), 1), ((24, 24, 24), {}, 0), ((128, 8, 96), {}, 5),
                                                ((128, 8, 96), dict(FUSE23=2, FUSE51=2, K4S=2, XDEFER=4), 4),
                                                ((128, 8, 96), dict(FUSE23=2, FUSE51=2, K4S=2, XDEFER=4, SLAB_FSPLIT=0), 3)],
-                         ids=["interior+boundary", "plain", "three-launches-split", "three-launches"])
+                         ids=["interior+boundary", "plain", "both-split", "three-launches-split", "three-launches"])
 def test_rehearsal_of_a_middle_rank_runs_every_plan(E, monkeypatch, dims, knobs, plan):
     """Rank 1 of 4 alone on this GPU: both neighbours exist (and are this process), so every halo exchange is a group of
     two sends and two receives on the side stream and every reduction point an all-gather.  Exits disabled; the values
     mean nothing (the slab is wrapped onto itself), the schedule is the real rank's."""
     from eddy_currents_3d_amd.dist import rccl_rank
-    for k in ("EC3D_FUSE23", "EC3D_FUSE51", "EC3D_K4S", "EC3D_XDEFER", "EC3D_SLAB_FUSE", "EC3D_SLAB_XDEFER", "EC3D_NT", "EC3D_SLAB_FSPLIT"):
+    for k in ("EC3D_FUSE23", "EC3D_FUSE51", "EC3D_K4S", "EC3D_XDEFER", "EC3D_SLAB_FUSE", "EC3D_SLAB_XDEFER", "EC3D_NT", "EC3D_SLAB_FSPLIT",
+              "EC3D_SLAB_PLAN"):
         monkeypatch.delenv(k, raising=False)
     for k, v in knobs.items():
         monkeypatch.setenv("EC3D_" + k, str(v))

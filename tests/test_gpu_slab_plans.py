@@ -10,6 +10,8 @@ device 0: the same code with local copies instead of xGMI ones) runs one of four
      with AP and R exchanged instead of P and S, S and P formed on the halo planes by the kernels that read them there
   4  plan 3 with the producers of R and AP (K4, K5-in-K1) as a boundary launch (planes 0 and np-1) and an interior launch,
      the exchange behind the boundary launch
+  5  plans 1 and 2 together (EC3D_SLAB_PLAN=5): K2 / K5 boundary planes first AND K1 / K3 interior planes first -- the
+     exchange behind two launches
 
 and, on every plan, X = X + alpha*P + omega*S (src/solvers.f90:41) applied every D-th iteration from rings of P and S.
 oracle.twin_solve_slabs restates src/solvers.f90:3-50 on the WHOLE system and sums every dot product the way the slabs
@@ -110,7 +112,7 @@ def test_restart_rule_on_slabs(E, oracle, monkeypatch, fused):
     with E.EC3DMulti(3, devices=[0, 0, 0]) as m:
         m.assemble_poisson(sdx, sdy, sdz)
         plan = m.plan()[0]
-        assert plan == (4 if fused else 1)
+        assert plan == (4 if fused else 5)     # (five launches: small slabs that split both ways take plan 5)
         x, it = m.solve(b, x0, tol, 5000)
         rs = restarts_of(m)
         xo, ito, _, _, rso = oracle.twin_solve_slabs(slabs_of(m, kdz), plan, valA, irow, jcol, b, x0, tol, 5000)
@@ -119,8 +121,8 @@ def test_restart_rule_on_slabs(E, oracle, monkeypatch, fused):
     assert rso > 0 and all(r == rso for r in rs)
 
 
-@pytest.mark.parametrize("plan, dims", [(1, (128, 8, 48)), (0, (24, 24, 24)), (2, (128, 8, 48)), (0, (128, 8, 48))],
-                         ids=["interior+boundary", "plain", "producers-split", "plain-zmarch"])
+@pytest.mark.parametrize("plan, dims", [(1, (128, 8, 48)), (0, (24, 24, 24)), (2, (128, 8, 48)), (0, (128, 8, 48)), (5, (128, 8, 48))],
+                         ids=["interior+boundary", "plain", "producers-split", "plain-zmarch", "both-split"])
 @pytest.mark.parametrize("xd", [1, 3, 4])
 def test_five_launch_plans_with_deferred_x_bitwise(E, oracle, monkeypatch, plan, dims, xd):
     """Plans 0 and 1 (what the slabs of 512^3 on 8 GPUs run: 16 Mi rows per rank) with the X update every D-th iteration:
@@ -159,7 +161,7 @@ def test_itmax_exit_at_every_position_of_a_group(E, oracle, monkeypatch, fused):
     with E.EC3DMulti(2, devices=[0, 0]) as m:
         m.assemble_poisson(sdx, sdy, sdz)
         plan = m.plan()[0]
-        assert plan == (4 if fused else 1)
+        assert plan == (4 if fused else 5)     # (five launches: small slabs that split both ways take plan 5)
         for k in range(1, 10):
             x, it = m.solve(b, x0, 1e-30, k - 1)
             xo, ito, _, _, _ = oracle.twin_solve_slabs(slabs_of(m, kdz), plan, valA, irow, jcol, b, x0, 1e-30, k - 1)
@@ -246,7 +248,7 @@ def test_x_groups_on_a_second_stream_bitwise(E, oracle, monkeypatch, fused):
     with E.EC3DMulti(3, devices=[0, 0, 0]) as m:
         m.assemble_poisson(sdx, sdy, sdz)
         plan = m.plan()[0]
-        assert plan == (4 if fused else 1)
+        assert plan == (4 if fused else 5)     # (five launches: small slabs that split both ways take plan 5)
         x, it = m.solve(b, x0, 1e-9, 5000)
         rs = restarts_of(m)
         on = [m.slab(r)[0].x_groups() for r in range(3)]
