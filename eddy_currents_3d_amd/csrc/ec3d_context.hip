@@ -231,6 +231,9 @@ void ec3d_free_matrix(ec3d_ctx *c)
     c->vb_list = c->vi_list = nullptr;
     if (c->us_list) (void)hipFree(c->us_list);
     c->us_list = nullptr;
+    if (c->ii_list) (void)hipFree(c->ii_list);
+    if (c->ib_list) (void)hipFree(c->ib_list);
+    c->ii_list = c->ib_list = nullptr;
     c->us_host.clear();
     c->can_vsplit = false;
     c->n_ref = 0;
@@ -668,6 +671,83 @@ static int choose_sweep(ec3d_ctx *c)
             sb.part_off = si.nblk;
             parts = si.nblk + sb.nblk;
             c->can_overlap = true;
+        }
+    }
+    // z-slab of the STRUCTURED A-V form with tile-aligned planes (the windowed sweep above): K1 / K3 as interior + boundary
+    // launch too.  The A rows and the U rows read A one plane away, the one-sided A-U stencils (src/EC3D.f90:697-706) read
+    // U two planes away, so the two owned planes next to each cut are "boundary" in all four blocks.  Interior launch: the
+    // z-march over the window narrowed by two planes at both ends in every A block, then the U tiles of those planes (in
+    // the XCD-local order of the whole list).  Boundary launch: no front sweep at all -- the tiles of the four outer planes
+    // of the three A blocks and the U tiles there, as ONE list (a listed tile starts its march afresh, which is what a
+    // tile of a lone plane needs anyway).  Every owned tile is visited by exactly one of the two (ec3d_get_visit_order 3 / 4).
+    if (c->ib_list) (void)hipFree(c->ib_list);
+    if (c->ii_list) (void)hipFree(c->ii_list);
+    c->ib_list = c->ii_list = nullptr;
+    if (A.sav && c->halo > 0 && sw.win_nt > 0 && ss.zm_tpp > 0 && ss.rp_px == 0 && c->A.ulist &&
+        (int)c->A.ulist_host.size() == c->A.ulist_n) {
+        const int64_t tpp = ss.zm_tpp, npo = sw.win_nt / tpp, H = 2, blk = sw.win_blk, p0 = sw.win_t0 / tpp;
+        int split = 1;
+        if (const char *e = getenv("EC3D_SAV_SPLIT")) split = atoi(e);
+        if (split && npo * tpp == sw.win_nt && p0 * tpp == sw.win_t0 && npo >= 2 * H + 2) {
+            const int64_t npi = npo - 2 * H;
+            std::vector<int32_t> ui, ub;
+            bool owned_only = true;
+            for (int32_t t : c->A.ulist_host) {
+                const int64_t pl = ((int64_t)t - 3 * blk) / tpp - p0; // owned plane of the U block this tile lies in
+                if (t < 3 * blk || pl < 0 || pl >= npo) owned_only = false;
+                else if (pl >= H && pl < npo - H) ui.push_back(t);
+                else ub.push_back(t);
+            }
+            if (owned_only) {
+                Sweep &si = c->sweep_int, &sb = c->sweep_bnd;
+                const int64_t cols = (tpp + 7) / 8 * 8;
+                int64_t nseg = std::max<int64_t>(1, (int64_t)ss.nblk / cols);
+                nseg = std::min<int64_t>(nseg, std::max<int64_t>(1, 3 * npi / 2));
+                si.win_t0 = sw.win_t0 + H * tpp;
+                si.win_nt = npi * tpp;
+                si.ntiles = 3 * si.win_nt;
+                si.zm_pps = (int)((3 * npi + nseg - 1) / nseg);
+                si.nblk = (int)(cols * nseg);
+                si.part_off = 0;
+                // the interior U tiles in the XCD-local order (as us_list above): by column into eight shares, a share plane by plane
+                std::vector<int32_t> perm;
+                if (!ui.empty()) {
+                    const int64_t G = si.nblk, Gx = G / 8, L = (int64_t)ui.size();
+                    std::vector<int32_t> byc(ui);
+                    std::stable_sort(byc.begin(), byc.end(), [&](int32_t a, int32_t b) { return a % tpp < b % tpp; });
+                    int64_t K = 0;
+                    std::vector<std::vector<int32_t>> share(8);
+                    for (int x = 0; x < 8; ++x) {
+                        share[x].assign(byc.begin() + L * x / 8, byc.begin() + L * (x + 1) / 8);
+                        std::sort(share[x].begin(), share[x].end());
+                        K = std::max<int64_t>(K, ((int64_t)share[x].size() + Gx - 1) / Gx);
+                    }
+                    perm.assign((size_t)(K * G), -1);
+                    for (int x = 0; x < 8; ++x)
+                        for (size_t i = 0; i < share[x].size(); ++i)
+                            perm[(size_t)(((int64_t)i / Gx) * G + ((int64_t)i % Gx) * 8 + x)] = share[x][i];
+                    EC3D_HIP(hipMalloc(&c->ii_list, perm.size() * 4));
+                    EC3D_HIP(hipMemcpy(c->ii_list, perm.data(), perm.size() * 4, hipMemcpyHostToDevice));
+                }
+                si.ulist = c->ii_list;
+                si.ulist_n = (int)perm.size();
+                // the boundary list: A tiles of planes 0, 1, npo-2, npo-1 of every block, plane by plane, then the U tiles there
+                std::vector<int32_t> bl;
+                for (int d = 0; d < 3; ++d)
+                    for (int64_t pl : {(int64_t)0, (int64_t)1, npo - 2, npo - 1})
+                        for (int64_t q = 0; q < tpp; ++q) bl.push_back((int32_t)(d * blk + (p0 + pl) * tpp + q));
+                bl.insert(bl.end(), ub.begin(), ub.end());
+                EC3D_HIP(hipMalloc(&c->ib_list, bl.size() * 4));
+                EC3D_HIP(hipMemcpy(c->ib_list, bl.data(), bl.size() * 4, hipMemcpyHostToDevice));
+                sb.ntiles = 0; // (no front sweep: ec3d_tile_of / walk_zm find no plane whose tile exists)
+                sb.win_nt = 0;
+                sb.ulist = c->ib_list;
+                sb.ulist_n = (int)bl.size();
+                sb.nblk = (int)std::max<int64_t>(8, std::min<int64_t>((int64_t)bl.size(), 768) / 8 * 8);
+                sb.part_off = si.nblk;
+                parts = std::max(parts, si.nblk + sb.nblk);
+                c->can_overlap = true;
+            }
         }
     }
     // z-slab of the single-component operator on 2-D tiles: the 2-D-tile kernels in two launches too -- planes 0 and np-1

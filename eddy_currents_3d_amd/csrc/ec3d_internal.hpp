@@ -323,6 +323,7 @@ struct ec3d_ctx {
     Sweep sweep_vb{}, sweep_vi{};
     int32_t *vb_list = nullptr, *vi_list = nullptr;
     int32_t *us_list = nullptr; // structured form: the U tiles in the order the z-marching SpMV kernels take them (choose_sweep)
+    int32_t *ii_list = nullptr, *ib_list = nullptr; // structured z-slab, K1 / K3 split: the interior launch's U tiles, the boundary launch's tiles
     std::vector<int32_t> us_host; // host copy (visit-order export)
     bool can_vsplit = false;
     int nown = 0;    // ownership ranges of an A-V slab (see Sweep)

@@ -730,7 +730,8 @@ int finish_setup(ec3d_multi *m)
         f.fused_ok = (c->fuse23_ok && c->fuse51_ok && c->k4s_ok && c->pp_base && c->own_vectors) ? 1.0 : 0.0;
         f.xd = (c->pp_base && c->own_vectors) ? (double)c->xdefer : 1.0;
         f.xasync = (c->pp_base && c->own_vectors && c->xasync_cap) ? 1.0 : 0.0;
-        f.both_splits = (c->have_matrix && c->can_overlap && ec3d_dist_can_split_planes(c)) ? 1.0 : 0.0;
+        // (an A-V slab splits K2 / K5 by tile lists made from its halo runs: always possible where there is a neighbour)
+        f.both_splits = (c->have_matrix && c->can_overlap && (c->A.sav || ec3d_dist_can_split_planes(c))) ? 1.0 : 0.0;
         f.sav = c->A.sav ? 1.0 : 0.0;
         f.n_pad = (double)c->A.n_pad;
         f.snd_lo = total(sl.send_lo); f.rcv_lo = total(sl.recv_lo); f.snd_hi = total(sl.send_hi); f.rcv_hi = total(sl.recv_hi);
@@ -786,7 +787,7 @@ int finish_setup(ec3d_multi *m)
     //          from plans 0 / 1 (behind K5's boundary launch, an iteration ahead), so the choice is the job's.
     bool fused = m->kind == 1 && m->world > 1;
     bool xasync = m->world > 1;
-    bool both = m->kind == 1 && m->world > 1;
+    bool both = m->world > 1;
     double job_rows = 0;
     int xd = EC3D_XD_MAX;
     for (const RankFacts &f : facts) {
@@ -796,7 +797,7 @@ int finish_setup(ec3d_multi *m)
         both = both && f.both_splits != 0.0;
         job_rows = std::max(job_rows, f.n_pad);
     }
-    both = both && job_rows < 10.0 * 1048576.0;
+    both = both && job_rows < (m->kind == 1 ? 10.0 : 16.0) * 1048576.0;
     if (const char *e = getenv("EC3D_SLAB_FUSE")) fused = fused && atoi(e) != 0;
     if (const char *e = getenv("EC3D_SLAB_XDEFER")) xd = std::min(xd, std::max(1, atoi(e)));
     if (m->world == 1) xd = 0; // (a one-slab job is an ordinary handle: its own rule applies)
@@ -836,7 +837,7 @@ int finish_setup(ec3d_multi *m)
         } else if (m->world > 1) {
             // the ORDER of exchanges is a property of the job: every A-V rank uses the producer-side
             // plan; a rank whose slab is all boundary runs the whole kernels in that order
-            s.plan = (m->kind == 1 && want_plan == 5) ? 5 : 2;
+            s.plan = want_plan == 5 ? 5 : 2;
             s.overlap_ok = s.plan == 5 && ec3d_can_overlap(c);
             std::vector<int64_t> lo, hi;
             for (const std::vector<Run> *rs : {&s.send_lo, &s.recv_lo, &s.send_hi, &s.recv_hi})

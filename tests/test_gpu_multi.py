@@ -78,9 +78,12 @@ def test_multi_with_one_rank_equals_plain_handle(E, oracle):
 @pytest.mark.parametrize("name,world", [("g2_conducting_hole_16x15x14", 2), ("g2_conducting_hole_16x15x14", 3),
                                         ("g3_moving_coil_18x16x12", 2), ("g2v_conducting_moving_16x15x14", 4)])
 @pytest.mark.parametrize("structured", [True, False])
-def test_multi_av_slabs_match_staged_driver_and_reference(E, name, world, structured, plane_pitch):
-    """The full A-V system cut through the conductor; native assembly on slabs inside the library."""
+def test_multi_av_slabs_match_staged_driver_and_reference(E, name, world, structured, plane_pitch, monkeypatch):
+    """The full A-V system cut through the conductor; native assembly on slabs inside the library.  The staged driver runs
+    the producer-side schedule (K2 / K5 boundary tiles first), so the library is held to plan 2 here; what it picks by
+    itself (plan 5 where the slabs can split K1 / K3 too) is the next test's."""
     from eddy_currents_3d_amd.dist import HipAVSlabOps, InProcessSlabs, slab_bounds
+    monkeypatch.setenv("EC3D_SLAB_PLAN", "2")
     g = load_golden(name)
     sdz = g["geoPHYS"].shape[0]
     n = len(g["irow"]) - 1
@@ -110,6 +113,50 @@ def test_multi_av_slabs_match_staged_driver_and_reference(E, name, world, struct
             assert it == it_ref and np.array_equal(x, x_ref)
             assert rel <= 10 * tol
             assert abs(it - int(g["iters"][k])) <= max(3, 0.15 * int(g["iters"][k]))
+
+
+@pytest.mark.parametrize("name,world", [("g2_conducting_hole_16x15x14", 2), ("g3_moving_coil_18x16x12", 2)])
+def test_multi_av_slabs_both_splits_reproduce_the_reference(E, name, world, monkeypatch):
+    """Plan 5 on A-V slabs of the structured form (the library's own choice where every slab can split K1 / K3 as well: the
+    exchange behind two launches): K1 / K3 as an interior launch -- the z-march over the window narrowed by two planes at
+    both ends of every A block, then the U tiles of those planes -- and a boundary launch over ONE list of the outer
+    planes' tiles of all four blocks.  Every owned tile is visited by exactly one of the two launches (visit orders 3 / 4
+    against 1); AP = A P of the first iteration is the same bits as on plan 2 (the rows do not care which launch computes
+    them); the reference's captured time steps come out with the reference's iteration counts and x to rounding."""
+    monkeypatch.delenv("EC3D_SLAB_PLAN", raising=False)
+    monkeypatch.setenv("EC3D_PITCH", "2")       # tile-aligned planes also on these small grids (the default from 4.5 Mi rows)
+    g = load_golden(name)
+    n = len(g["irow"]) - 1
+    tol, itmax = float(g["tol"]), int(g["itmax"])
+    geo = (g["geoPHYS"], g["geoPHYS_C"], g["valPHYS"], g["BND"], g["delta"], float(g["dt"]))
+    ap = {}
+    for plan in (2, 5):
+        monkeypatch.setenv("EC3D_SLAB_PLAN", str(plan))
+        with E.EC3DMulti(world, devices=[0] * world, structured=True) as m:
+            m.assemble(*geo)
+            m.upload("B", g["b0"])
+            m.upload("X", g["xin0"])
+            m.iterate_begin()
+            m.iterate(1, 1)
+            m.synchronize()
+            ap[plan] = m.download("AP")
+    assert np.array_equal(ap[2], ap[5]) and np.linalg.norm(ap[2]) > 0
+    monkeypatch.delenv("EC3D_SLAB_PLAN")
+    with E.EC3DMulti(world, devices=[0] * world, structured=True) as m:
+        m.assemble(*geo)
+        assert m.plan()[0] == 5
+        for r in range(world):
+            v = m.slab(r)[0]
+            assert v.can_overlap()
+            whole = np.sort(v.visit_order(1)[1])
+            parts = np.sort(np.concatenate([v.visit_order(3)[1], v.visit_order(4)[1]]))
+            assert np.array_equal(whole, parts) and len(np.unique(whole)) == len(whole)
+        for k in range(len(g["iters"])):
+            x, it = m.solve(g[f"b{k}"], g[f"xin{k}"], tol, itmax)
+            xr = g[f"xout{k}"]
+            rel = np.linalg.norm(x - xr) / np.linalg.norm(xr)
+            print(f"{name} in {world} slabs, plan 5, step {k}: iter {it} / reference {int(g['iters'][k])}, rel diff {rel:.2e}")
+            assert it == int(g["iters"][k]) and rel <= 1e-12
 
 
 @pytest.mark.parametrize("name,world", [("g2_conducting_hole_16x15x14", 2), ("g3_moving_coil_18x16x12", 3)])

@@ -158,19 +158,24 @@ def test_restarts_and_itmax_on_a_rank_job(E, oracle, monkeypatch):
     assert np.array_equal(merge(x0, [g[3] for g in got]), x_cut)
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_av_rank_job_reproduces_the_reference_capture(E, monkeypatch, world):
+@pytest.mark.parametrize("world, pitched", [(2, False), (3, False), (2, True)], ids=["2", "3", "2-both-splits"])
+def test_av_rank_job_reproduces_the_reference_capture(E, monkeypatch, world, pitched):
     """The A-V system [Ax | Ay | Az | U] (src/EC3D.f90:408) cut into slabs of the structured form: four blocks exchanged per
     neighbour, the U block two planes deep.  Two time steps of the reference's capture: its iteration counts, and the
     one-process handle's x bit for bit."""
     from conftest import load_golden
     set_knobs(monkeypatch)
+    if pitched:     # tile-aligned planes: the slabs can split K1 / K3 too and the job takes plan 5 (the exchange behind two launches)
+        monkeypatch.setenv("EC3D_PITCH", "2")
+    else:
+        monkeypatch.delenv("EC3D_PITCH", raising=False)
     g = load_golden("g2_conducting_hole_16x15x14")
     tol, itmax = float(g["tol"]), int(g["itmax"])
     geo = (g["geoPHYS"], g["geoPHYS_C"], g["valPHYS"], g["BND"], g["delta"], float(g["dt"]))
     with E.EC3DMulti(world, devices=[0] * world) as one:
         one.assemble(*geo)
         want_plan = one.plan()
+        assert want_plan[0] == (5 if pitched else 2)
         ref = [one.solve(g[f"b{k}"], g[f"xin{k}"], tol, itmax) for k in (0, 1)]
 
     def body(m, r):

@@ -76,7 +76,9 @@ if os.environ.get("REHEARSE_AV"):
     run_av("LIM", (384, 192, 128), 8, 3)
     run_av("LIM", (384, 192, 128), 4, 1)
     if os.environ["REHEARSE_AV"] != "lim":
+        run_av("LIM", (384, 192, 128), 2, 1)
         run_av("ec_src_move_hole", (256, 256, 60), 2, 1)
+        run_av("ec_src_move_hole", (256, 256, 60), 4, 1)
     sys.exit(0)
 if os.environ.get("REHEARSE_ONLY"):
     for tok in os.environ["REHEARSE_ONLY"].split(";"):
