@@ -785,6 +785,10 @@ int finish_setup(ec3d_multi *m)
     //          0.149 ms per iteration, 6.75 Mi 0.268 -> 0.261, 16 Mi 0.480 -> 0.493 (there the four extra launches, each
     //          beside a send / recv kernel, cost more than the waiting they remove).  The START of the P exchange differs
     //          from plans 0 / 1 (behind K5's boundary launch, an iteration ahead), so the choice is the job's.
+    //          A-V slabs of the structured form (five planes per neighbour travel, one interior launch of a vector kernel
+    //          does not cover them): plan 5 against plan 2 -- config 5 on 8 / 4 / 2 ranks 0.306 -> 0.287 / 0.383 -> 0.343 /
+    //          0.504 -> 0.484 ms per iteration, config 3 on 2 / 4 ranks 0.277 -> 0.259 / 0.255 -> 0.249
+    //          (profiles/r05_plan5_av_slabs.log): at every size.
     bool fused = m->kind == 1 && m->world > 1;
     bool xasync = m->world > 1;
     bool both = m->world > 1;
@@ -797,7 +801,7 @@ int finish_setup(ec3d_multi *m)
         both = both && f.both_splits != 0.0;
         job_rows = std::max(job_rows, f.n_pad);
     }
-    both = both && job_rows < (m->kind == 1 ? 10.0 : 16.0) * 1048576.0;
+    both = both && (m->kind == 2 || job_rows < 10.0 * 1048576.0); // (A-V slabs: measured a gain at every size, below)
     if (const char *e = getenv("EC3D_SLAB_FUSE")) fused = fused && atoi(e) != 0;
     if (const char *e = getenv("EC3D_SLAB_XDEFER")) xd = std::min(xd, std::max(1, atoi(e)));
     if (m->world == 1) xd = 0; // (a one-slab job is an ordinary handle: its own rule applies)
