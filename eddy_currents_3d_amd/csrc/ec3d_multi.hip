@@ -888,10 +888,22 @@ void av_layout(ec3d_multi *m, Slab &s, const std::vector<int64_t> &upl)
     } else {
         for (int d = 0; d < 3; ++d) blocks.push_back(Blk{d * nC, kdz, kdz, 1});
     }
+    // Structured form: the U block is grid-shaped, but only cells of a conductor hold an unknown -- every other row of it
+    // is inert and stays exactly zero in every vector.  Two planes of U that hold no conductor cell therefore need not
+    // travel: the ghost rows they would fill are zero already (most cuts of a real model lie in air: BASELINE config 5 on
+    // 8 ranks has the conductor at ONE of its seven cuts).  Both sides of a cut decide from the same planes' cell counts.
+    const bool u_always = getenv("EC3D_AV_SEND_EMPTY_U") && atoi(getenv("EC3D_AV_SEND_EMPTY_U")) != 0;
+    auto u_cells = [&](int64_t a, int64_t b) { return upl[(size_t)std::min<int64_t>(b, (int64_t)upl.size() - 1)] - upl[(size_t)std::max<int64_t>(a, 0)]; };
+    // (a rehearsal sends to itself: what it sends towards a cut must pair with what it receives from there, so a side's U
+    // planes travel when EITHER of the two pairs of planes around the cut holds a conductor cell)
+    auto travels = [&](const Blk &b, int64_t first_plane, int64_t cut) {
+        if (!structured || b.h != H || u_always) return true;
+        return m->rehearse ? u_cells(cut - H, cut + H) > 0 : u_cells(first_plane, first_plane + H) > 0;
+    };
     if (s.e0 < s.k0) {
         for (const Blk &b : blocks) {
-            s.send_lo.push_back(Run{b.base + p0 * b.pitch, b.pitch, b.payload, b.h});
-            s.recv_lo.push_back(Run{b.base + (p0 - b.h) * b.pitch, b.pitch, b.payload, b.h});
+            if (travels(b, p0, p0)) s.send_lo.push_back(Run{b.base + p0 * b.pitch, b.pitch, b.payload, b.h});
+            if (travels(b, p0 - b.h, p0)) s.recv_lo.push_back(Run{b.base + (p0 - b.h) * b.pitch, b.pitch, b.payload, b.h});
         }
         if (!structured) { // compact U block: the U cells of my first two owned planes / my lower halo planes
             const int64_t ulo = upl[(size_t)p0], cnt_s = upl[(size_t)(p0 + H)] - ulo;
@@ -901,8 +913,8 @@ void av_layout(ec3d_multi *m, Slab &s, const std::vector<int64_t> &upl)
     }
     if (s.k1 < s.e1) {
         for (const Blk &b : blocks) {
-            s.send_hi.push_back(Run{b.base + (p1 - b.h) * b.pitch, b.pitch, b.payload, b.h});
-            s.recv_hi.push_back(Run{b.base + p1 * b.pitch, b.pitch, b.payload, b.h});
+            if (travels(b, p1 - b.h, p1)) s.send_hi.push_back(Run{b.base + (p1 - b.h) * b.pitch, b.pitch, b.payload, b.h});
+            if (travels(b, p1, p1)) s.recv_hi.push_back(Run{b.base + p1 * b.pitch, b.pitch, b.payload, b.h});
         }
         if (!structured) {
             const int64_t uend = upl[(size_t)p1], cnt_s = uend - upl[(size_t)(p1 - H)], cnt_r = mloc - uend;

@@ -315,7 +315,7 @@ int ec3d_multi_api_calls(ec3d_multi_handle mh, int32_t rank, double *per_iterati
  * inside the next K1 -- every rank >= 32 Mi rows of the single-component operator): AP and R travel instead of P and S;
  * 4 = the same with K4 and K5-in-K1 -- the producers of R and AP -- as boundary + interior launch around the exchange;
  * 5 = 1 and 2 together: K2 / K5 boundary planes first and K1 / K3 interior planes first, the exchange behind two launches
- * (single-component slabs below 10 Mi rows per rank).
+ * (single-component slabs below 10 Mi rows per rank; A-V slabs of the structured form with tile-aligned planes).
  * x_every: iterations between two applications of X = X + alpha*P + omega*S (src/solvers.f90:41; 1 = every iteration). */
 int ec3d_multi_plan(ec3d_multi_handle mh, int32_t *plan, int32_t *x_every);
 
