@@ -168,6 +168,18 @@ extern "C" int ec3d_dist_step(ec3d_handle c, int32_t stage, int32_t it, double t
     auto fin = [&](int producer, unsigned mask, bool split = false) {
         ec3d_launch_finalize(ec3d_part_of(c, producer, split), c->lsum, mask, c->stream);
     };
+    // K2's S.S is wanted behind the SAME gather as K3's AS.S and AS.AS (K3 is launched before ||S|| is known: the S exit is
+    // K4's), so K2 leaves its workgroups' partials where they are and K3's collapse launch folds both: one launch fewer per
+    // iteration on the five-launch plans, the same sums in the same order
+    auto fin_k3 = [&](bool split) {
+        const RedSrc k3 = ec3d_part_of(c, EC3D_BY_SPMV, split);
+        const unsigned m3 = 1u << P_D2 | 1u << P_D3 | (ec3d_fused23(c) ? 1u << P_SS : 0u);
+        if (c->ss_parts > 0 && !ec3d_fused23(c))
+            ec3d_launch_finalize2(RedSrc{c->partials, c->ss_parts, 1, c->sweep.pstride, nullptr}, 1u << P_SS, k3, m3, c->lsum, c->stream);
+        else
+            ec3d_launch_finalize(k3, c->lsum, m3, c->stream);
+        c->ss_parts = 0;
+    };
     auto need_split = [&]() {
         if (!c->can_overlap) ec3d_set_error("ec3d_dist_step: this slab cannot split K1/K3 (see ec3d_can_overlap)");
         return c->can_overlap;
@@ -181,6 +193,7 @@ extern "C" int ec3d_dist_step(ec3d_handle c, int32_t stage, int32_t it, double t
         c->it_next = 1;
         c->xd_base = 1;
         c->xd_last = INT_MAX;
+        c->ss_parts = 0;
         ec3d_xgroups_reset(c);
         ec3d_launch_residual(A, c->sweep_s, v[EC3D_VEC_X], v[EC3D_VEC_B], v[EC3D_VEC_R], v[EC3D_VEC_R0],
                              v[EC3D_VEC_P], c->partials, c->stream);
@@ -198,11 +211,11 @@ extern "C" int ec3d_dist_step(ec3d_handle c, int32_t stage, int32_t it, double t
     case EC3D_STAGE_K2:
         if (ec3d_fused23(c)) break;
         ec3d_launch_stage(c, A, it, 2);
-        fin(EC3D_BY_K2, 1u << P_SS);
+        c->ss_parts = ec3d_part_of(c, EC3D_BY_K2, false).count;
         break;
     case EC3D_STAGE_K3:
         ec3d_launch_stage(c, A, it, 3);
-        fin(EC3D_BY_SPMV, 1u << P_D2 | 1u << P_D3 | (ec3d_fused23(c) ? 1u << P_SS : 0u));
+        fin_k3(false);
         break;
     case EC3D_STAGE_K4: ec3d_launch_stage(c, A, it, 4); fin(EC3D_BY_K4, 1u << P_RR | 1u << P_RR0N); break;
     case EC3D_STAGE_K5:
@@ -227,7 +240,7 @@ extern "C" int ec3d_dist_step(ec3d_handle c, int32_t stage, int32_t it, double t
     case EC3D_STAGE_K3_BND:
         if (!need_split()) return 3;
         ec3d_launch_k3(A, c->sweep_bnd, c->state, it, ec3d_vec_at(c, EC3D_VEC_S, it), v[EC3D_VEC_AS], c->partials, c->stream);
-        fin(EC3D_BY_SPMV, 1u << P_D2 | 1u << P_D3, true);
+        fin_k3(true);
         break;
     case EC3D_STAGE_K2_BND:
     case EC3D_STAGE_K2_INT: {
@@ -239,9 +252,7 @@ extern "C" int ec3d_dist_step(ec3d_handle c, int32_t stage, int32_t it, double t
         ec3d_launch_k2(bnd ? c->sweep_vb : c->sweep_vi, ec3d_src_of(c, EC3D_BY_SPMV), c->state, it, v[EC3D_VEC_R], v[EC3D_VEC_AP],
                        ec3d_vec_at(c, EC3D_VEC_S, it), c->partials, c->stream);
         c->scur = ec3d_xdefer(c) > 1 ? it % c->sdepth : 1;
-        if (!bnd)
-            ec3d_launch_finalize(RedSrc{c->partials, c->sweep_vb.nblk + c->sweep_vi.nblk, 1, c->sweep.pstride, nullptr}, c->lsum,
-                                 1u << P_SS, c->stream);
+        if (!bnd) c->ss_parts = c->sweep_vb.nblk + c->sweep_vi.nblk; // (both launches' partials, folded by K3's collapse launch)
         break;
     }
     case EC3D_STAGE_K5_BND:
@@ -287,9 +298,9 @@ int ec3d_dist_launches(const ec3d_ctx *c, int stage, int it)
     const int fin = 1; // the collapse launch behind a producer of sums
     switch (stage) {
     case EC3D_STAGE_K1: return (ec3d_fused51(c) && it != 1 && c->ap_valid_for == it) ? 0 : 1 + fin;
-    case EC3D_STAGE_K2: return ec3d_fused23(c) ? 0 : 1 + fin;
+    case EC3D_STAGE_K2: return ec3d_fused23(c) ? 0 : 1; // (its S.S partials are folded by K3's collapse launch)
     case EC3D_STAGE_K5: return ec3d_fused51(c) ? 1 + fin : 1;
-    case EC3D_STAGE_SETUP: case EC3D_STAGE_K1_INT: case EC3D_STAGE_K3_INT: case EC3D_STAGE_K2_BND:
+    case EC3D_STAGE_SETUP: case EC3D_STAGE_K1_INT: case EC3D_STAGE_K3_INT: case EC3D_STAGE_K2_BND: case EC3D_STAGE_K2_INT:
     case EC3D_STAGE_K5_BND: case EC3D_STAGE_K5_INT: case EC3D_STAGE_K4F_BND: case EC3D_STAGE_K5F_BND: return 1;
     default: return 1 + fin;
     }

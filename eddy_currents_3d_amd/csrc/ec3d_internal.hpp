@@ -311,6 +311,7 @@ struct ec3d_ctx {
     bool slab_xasync = false; // a z-slab: the job's driver said so (every rank the same ring depth)
     hipStream_t xstream = nullptr;
     hipEvent_t ev_xready = nullptr, ev_xdone[2] = {nullptr, nullptr};
+    int ss_parts = 0;      // z-slab: workgroup partials of S.S that K2 left for K3's collapse launch to fold (0: none pending)
     int xg_n = 0;          // groups launched since the last ec3d_launch_begin
     int xg_done_upto = 0;  // the last iteration whose X update an enqueued k_x_group covers
     int xdefer = 1;        // D: iterations between two X updates on this handle (1: every iteration, the classic K4)
@@ -514,6 +515,7 @@ void ec3d_launch_spmv(const MatView &A, const Sweep &sw, const double *x, double
 void ec3d_launch_residual(const MatView &A, const Sweep &sw, const double *x, const double *b, double *r,
                           double *r0, double *p, double *part, hipStream_t s);
 void ec3d_launch_finalize(const RedSrc &src, double *lsum, unsigned mask, hipStream_t s);
+void ec3d_launch_finalize2(const RedSrc &a, unsigned mask_a, const RedSrc &b, unsigned mask_b, double *lsum, hipStream_t s);
 void ec3d_launch_setup(SolverState *st, const RedSrc &src, double tol, hipStream_t s);
 void ec3d_launch_k1(const MatView &A, const Sweep &sw, const SolverState *st, int it, const double *p,
                     const double *r0, double *ap, double *part, hipStream_t s);

@@ -1473,6 +1473,22 @@ __global__ __launch_bounds__(EC3D_THREADS) void k_finalize(RedSrc src, double *l
     }
 }
 
+__global__ __launch_bounds__(EC3D_THREADS) void k_finalize2(RedSrc a, unsigned mask_a, RedSrc b, unsigned mask_b, double *lsum)
+{
+    __shared__ double lds[4];
+    for (int pass = 0; pass < 2; ++pass) {
+        const RedSrc &src = pass ? b : a;
+        const unsigned mask = pass ? mask_b : mask_a;
+        for (int sl = 0; sl < P_NSLOT; ++sl) {
+            if (!(mask & (1u << sl))) continue;
+            const int slot[1] = {sl};
+            double v[1];
+            reduce_partials<1>(src, slot, v, lds);
+            if (threadIdx.x == 0) lsum[sl] = v[0];
+        }
+    }
+}
+
 // The exit state travels as ONE 64-bit word: stop_iter in the low half, stop_kind in the high half
 // (SolverState keeps them adjacent and 8-byte aligned).  A reader never sees the iteration of one exit with
 // the kind of another, whoever wrote it and whenever: K5's entry test reads a pair that its own launch's lead
@@ -2385,6 +2401,11 @@ void ec3d_launch_residual(const MatView &A, const Sweep &sw, const double *x, co
 void ec3d_launch_finalize(const RedSrc &src, double *lsum, unsigned mask, hipStream_t s)
 {
     k_finalize<<<1, EC3D_THREADS, 0, s>>>(src, lsum, mask);
+}
+// two producers' partials in ONE launch (K2's S.S waits for K3's AS.S and AS.AS: nobody reads it before the gather behind K3)
+void ec3d_launch_finalize2(const RedSrc &a, unsigned mask_a, const RedSrc &b, unsigned mask_b, double *lsum, hipStream_t s)
+{
+    k_finalize2<<<1, EC3D_THREADS, 0, s>>>(a, mask_a, b, mask_b, lsum);
 }
 
 void ec3d_launch_setup(SolverState *st, const RedSrc &src, double tol, hipStream_t s)

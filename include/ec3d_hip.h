@@ -188,9 +188,9 @@ int ec3d_dist_configure(ec3d_handle h, int32_t nranks, double *lsum_device, doub
 enum { EC3D_STAGE_RESID = 0, /* R = B - A X, R0 = P = R; lsum <- B.B, R.R      src/solvers.f90:14-21 */
        EC3D_STAGE_SETUP = 1, /* Bnorm, rr0 from gsum                                            :21-23 */
        EC3D_STAGE_K1 = 2,    /* AP = A P; lsum <- AP.R0        (P halo must be current)          :30-32 */
-       EC3D_STAGE_K2 = 3,    /* alpha, S = R - alpha AP; lsum <- S.S                             :32-34 */
-       EC3D_STAGE_K3 = 4,    /* AS = A S; lsum <- AS.S, AS.AS (S halo current; no gather needed
-                                between K2 and K3: the S exit is taken by K4)                     :39-40 */
+       EC3D_STAGE_K2 = 3,    /* alpha, S = R - alpha AP; partials of S.S (collapsed by K3's stage) :32-34 */
+       EC3D_STAGE_K3 = 4,    /* AS = A S; lsum <- S.S (K2's), AS.S, AS.AS (S halo current; no gather
+                                needed between K2 and K3: the S exit is taken by K4)              :39-40 */
        EC3D_STAGE_K4 = 5,    /* S exit (X += alpha P) or omega, X, R; lsum <- R.R, R.R0          :34-44 */
        EC3D_STAGE_K5 = 6,    /* R exit, beta, P, restart                                         :43-49 */
        /* K1 and K3 in two launches, so the halo exchange of P / S overlaps the first one:
@@ -200,7 +200,7 @@ enum { EC3D_STAGE_RESID = 0, /* R = B - A X, R0 = P = R; lsum <- B.B, R.R      s
        /* The other way to hide the exchange, for any slab and storage format: the PRODUCERS of the
         * exchanged vectors run in two launches -- *_BND first (the tiles holding the rows the neighbours
         * receive, ec3d_dist_set_boundary_rows), then the exchange starts, then *_INT (everything else)
-        * while the planes travel.  K2 produces S (K2_INT also collapses both launches' S.S partials),
+        * while the planes travel.  K2 produces S (both launches' S.S partials are collapsed by K3's stage),
         * K5 produces P. */
        EC3D_STAGE_K2_BND = 11, EC3D_STAGE_K2_INT = 12, EC3D_STAGE_K5_BND = 13, EC3D_STAGE_K5_INT = 14,
        /* A slab that runs the THREE-launch iteration (in-library / RCCL drivers only: it needs the library's own spare
