@@ -804,7 +804,7 @@ int finish_setup(ec3d_multi *m)
     both = both && (m->kind == 2 || job_rows < 10.0 * 1048576.0); // (A-V slabs: measured a gain at every size, below)
     if (const char *e = getenv("EC3D_SLAB_FUSE")) fused = fused && atoi(e) != 0;
     if (const char *e = getenv("EC3D_SLAB_XDEFER")) xd = std::min(xd, std::max(1, atoi(e)));
-    if (m->world == 1) xd = 0; // (a one-slab job is an ordinary handle: its own rule applies)
+    // (a one-slab job keeps its slab's own depth: five launches, X every D-th iteration from 4.5 Mi rows, like any slab)
     return run_all(m, [&](int r) -> int {
         Slab &s = *m->slab[(size_t)r];
         MHIP(hipMemcpy(s.ptr_table, tab.data(), tab.size() * sizeof(double *), hipMemcpyHostToDevice));
