@@ -1760,6 +1760,18 @@ extern "C" int ec3d_multi_plan(ec3d_multi_handle m, int32_t *plan, int32_t *x_ev
     return 0;
 }
 
+extern "C" int ec3d_multi_halo_rows(ec3d_multi_handle m, int32_t rank, int64_t *sent, int64_t *received)
+{
+    int rc = need(m, "ec3d_multi_halo_rows");
+    if (rc) return rc;
+    if (rank < 0 || rank >= m->n) return 2;
+    const Slab &s = *m->slab[(size_t)rank];
+    auto total = [](const std::vector<Run> &rs) { int64_t t = 0; for (const Run &r : rs) t += r.payload * (int64_t)r.planes; return t; };
+    if (sent) *sent = total(s.send_lo) + total(s.send_hi);
+    if (received) *received = total(s.recv_lo) + total(s.recv_hi);
+    return 0;
+}
+
 extern "C" int ec3d_multi_synchronize(ec3d_multi_handle m)
 {
     if (!m) return 2;

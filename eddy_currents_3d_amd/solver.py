@@ -68,7 +68,7 @@ EXPORTS = ["sprsbcgstabwr_", "ec3d_invalidate", "ec3d_create", "ec3d_destroy", "
            "ec3d_multi_upload", "ec3d_multi_download", "ec3d_multi_solve", "ec3d_multi_solve_resident",
            "ec3d_multi_rhs_step", "ec3d_multi_post_update", "ec3d_multi_vtk_fields", "ec3d_multi_vtk_fields_begin",
            "ec3d_multi_vtk_fields_wait", "ec3d_multi_iterate_begin",
-           "ec3d_multi_iterate", "ec3d_multi_synchronize", "ec3d_true_residual", "ec3d_multi_true_residual", "ec3d_get_visit_order", "ec3d_probe_csr_multi", "ec3d_multi_spmv", "ec3d_multi_api_calls", "ec3d_multi_plan", "ec3d_rccl_unique_id", "ec3d_multi_create_rank", "ec3d_format_real8_gfortran"]
+           "ec3d_multi_iterate", "ec3d_multi_synchronize", "ec3d_true_residual", "ec3d_multi_true_residual", "ec3d_get_visit_order", "ec3d_probe_csr_multi", "ec3d_multi_spmv", "ec3d_multi_api_calls", "ec3d_multi_plan", "ec3d_multi_halo_rows", "ec3d_rccl_unique_id", "ec3d_multi_create_rank", "ec3d_format_real8_gfortran"]
 
 _f64 = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
 _i32 = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
@@ -215,6 +215,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.ec3d_multi_synchronize.argtypes = [hp]
     L.ec3d_multi_api_calls.argtypes = [hp, C.c_int32, C.POINTER(C.c_double)]
     L.ec3d_multi_plan.argtypes = [hp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.ec3d_multi_halo_rows.argtypes = [hp, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.ec3d_rccl_unique_id.argtypes = [C.c_char_p]
     L.ec3d_multi_create_rank.argtypes = [C.POINTER(hp), C.c_int32, C.c_int32, C.c_int32, C.c_char_p, C.c_char_p, C.c_int32,
                                          C.c_int32]
@@ -844,6 +845,12 @@ class EC3DMulti:
         pl, xe = C.c_int32(0), C.c_int32(0)
         _chk(self.L, self.L.ec3d_multi_plan(self.h, C.byref(pl), C.byref(xe)), "ec3d_multi_plan")
         return pl.value, xe.value
+
+    def halo_rows(self, rank: int = 0):
+        """(sent, received): rows local slab `rank` moves in ONE halo exchange of a vector (ec3d_multi_halo_rows)."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        _chk(self.L, self.L.ec3d_multi_halo_rows(self.h, int(rank), C.byref(a), C.byref(b)), "ec3d_multi_halo_rows")
+        return a.value, b.value
 
     def api_calls(self, rank: int) -> float:
         """HIP runtime calls per iteration rank `rank`'s host thread issued in the last iterate()."""

@@ -318,6 +318,10 @@ int ec3d_multi_api_calls(ec3d_multi_handle mh, int32_t rank, double *per_iterati
  * (single-component slabs below 10 Mi rows per rank; A-V slabs of the structured form with tile-aligned planes).
  * x_every: iterations between two applications of X = X + alpha*P + omega*S (src/solvers.f90:41; 1 = every iteration). */
 int ec3d_multi_plan(ec3d_multi_handle mh, int32_t *plan, int32_t *x_every);
+/* rows (8 bytes each, per exchanged vector) local slab `rank` sends to / receives from its z-neighbours in ONE halo exchange:
+ * a plane per neighbour for the single-component operator; for the A-V system a plane of each of A_x, A_y, A_z and -- only
+ * where they hold a conductor cell -- two planes of U (the other rows of the U block are zero in every vector) */
+int ec3d_multi_halo_rows(ec3d_multi_handle mh, int32_t rank, int64_t *sent, int64_t *received);
 
 /* ------------------------------------------------------------------------------------------
  * 3. Introspection / measurement

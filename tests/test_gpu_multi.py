@@ -544,3 +544,43 @@ def test_two_ranks_over_rccl_match_the_undivided_solve(E, tmp_path):
     print(f"2 ranks over RCCL: iter {it} / undivided {itr}, true residual {res:.2e}")
     assert res < 5e-8
     assert np.linalg.norm(x - xr) <= 1e-5 * np.linalg.norm(xr)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_av_slabs_on_a_resampled_model_cover_and_skip_exactly(E, world, monkeypatch):
+    """The LIM geometry (tests/golden/g4_LIM: the shipped input's voxels) resampled to 64 x 32 x 48: the conductor lies
+    between two cuts, so most cuts pass through air.  (a) K1 / K3 of plan 5 as interior + boundary launch visit every owned
+    tile exactly once on every slab; (b) a cut's two U planes that hold no conductor cell stay at home by default -- the
+    solve is the SAME BITS as with EC3D_AV_SEND_EMPTY_U=1, which sends them (their rows are zero in every vector), and the
+    slabs really exchange less; (c) the solution solves the system (true residual, computed on the device)."""
+    from eddy_currents_3d_amd import vxc
+    g = load_golden("g4_LIM")
+    model = vxc.resample(vxc.VxcModel(g["vox"], [str(x) for x in g["names"]], float(str(g["lattice_dim"])),
+                                      tuple(float(x) for x in g["adj"])), 64, 32, 48)
+    t = vxc.domain_tables(model)
+    geo = (t["geoPHYS"], t["geoPHYS_C"], t["valPHYS"], t["BND"], t["delta"], t["dt"])
+    monkeypatch.delenv("EC3D_SLAB_PLAN", raising=False)
+    out = {}
+    for send_all in ("1", "0"):
+        monkeypatch.setenv("EC3D_AV_SEND_EMPTY_U", send_all)
+        with E.EC3DMulti(world, devices=[0] * world) as m:
+            m.assemble(*geo)
+            assert m.plan()[0] == 5
+            n = m.n
+            b = m.spmv(np.random.Generator(np.random.PCG64(3)).standard_normal(n))       # a right-hand side in the range of A
+            for r in range(world):
+                v = m.slab(r)[0]
+                whole = np.sort(v.visit_order(1)[1])
+                parts = np.sort(np.concatenate([v.visit_order(3)[1], v.visit_order(4)[1]]))
+                assert v.can_overlap() and np.array_equal(whole, parts) and len(np.unique(whole)) == len(whole)
+            x, it = m.solve(b, np.zeros(n), 1e-8, 5000)
+            rel, _ = m.true_residual()
+            out[send_all] = (x, it, [m.halo_rows(r) for r in range(world)])
+            assert it <= 5000 and rel < 5e-8
+    assert out["0"][1] == out["1"][1] and np.array_equal(out["0"][0], out["1"][0])
+    sent = {k: sum(a for a, _ in v[2]) for k, v in out.items()}
+    recv = {k: sum(b for _, b in v[2]) for k, v in out.items()}
+    print(f"{world} slabs: rows sent per exchange {sent['1']} with the empty U planes, {sent['0']} without")
+    assert sent["0"] == recv["0"] and sent["1"] == recv["1"]
+    # two slabs: the one cut passes through the conductor, everything travels; four: two of the three cuts lie in air
+    assert sent["0"] == sent["1"] if world == 2 else sent["0"] < sent["1"]
