@@ -285,3 +285,39 @@ def test_fields_and_csr_route_on_rank_handles(E, monkeypatch):
             assert len(parts[key]) == 1 and np.array_equal(parts[key][0], want[key][r]), (r, key)
         assert got[r][1][1] == it_one
     assert np.array_equal(merge(g["xin0"], [got[r][1][0] for r in range(world)]), x_one)
+
+
+def test_av_rank_job_with_uneven_u_exchange(E, monkeypatch):
+    """Five ranks of an A-V job on the LIM geometry resampled to 64 x 32 x 48 (tests/golden/g4_LIM; conductor in planes 20 .. 27,
+    cuts at 9, 19, 28, 38): the conductor ends next to two of the four cuts, so there a rank sends its two U planes down but
+    receives none from below (or the other way round), and the outer cuts carry no U plane at all.  The k-th send to a neighbour must meet
+    its k-th receive from me with the same length (the loopback transport checks every pair): x and iter of the rank job
+    equal the one-process handle's bit for bit, on plan 5 (K1 / K3 split as well)."""
+    from conftest import load_golden
+    from eddy_currents_3d_amd import vxc
+    set_knobs(monkeypatch)
+    monkeypatch.delenv("EC3D_PITCH", raising=False)
+    world = 5
+    g = load_golden("g4_LIM")
+    model = vxc.resample(vxc.VxcModel(g["vox"], [str(x) for x in g["names"]], float(str(g["lattice_dim"])),
+                                      tuple(float(x) for x in g["adj"])), 64, 32, 48)
+    t = vxc.domain_tables(model)
+    geo = (t["geoPHYS"], t["geoPHYS_C"], t["valPHYS"], t["BND"], t["delta"], t["dt"])
+    with E.EC3DMulti(world, devices=[0] * world) as one:
+        one.assemble(*geo)
+        n = one.n
+        want_plan = one.plan()
+        rows = [one.halo_rows(r) for r in range(world)]
+        b = one.spmv(np.random.Generator(np.random.PCG64(3)).standard_normal(n))
+        x_one, it_one = one.solve(b, np.zeros(n), 1e-8, 5000)
+    assert want_plan[0] == 5
+    assert any(s != r for s, r in rows) and len({s for s, _ in rows}) >= 2      # uneven, and not the same on every rank
+
+    def body(m, r):
+        m.assemble(*geo)
+        assert m.plan() == want_plan and m.halo_rows(0) == rows[r]
+        return m.solve(b, np.zeros(n), 1e-8, 5000)
+
+    got = run_ranks(E, world, body)
+    assert [g_[1] for g_ in got] == [it_one] * world
+    assert np.array_equal(merge(np.zeros(n), [g_[0] for g_ in got]), x_one)
