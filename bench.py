@@ -97,6 +97,22 @@ def av_system(refine):
             np.array([dx / f] * 3), 1e-3, b)
 
 
+def av256_system(dims=(256, 256, 256)):
+    """BASELINE config 3 at the size BASELINE.json writes: the shipped ec_src_move_hole geometry (tests/golden/g4:
+    plate with a hole under a moving coil pair) resampled to 256 x 256 x 256 with the physical size kept
+    (vxc.resample -- the input oracle/make_goldens.py case_g7x ran through the unmodified reference), as the tables
+    ec3d_assemble takes plus the first time step's sources (src/EC3D.f90:345-365)."""
+    import numpy as np
+    from eddy_currents_3d_amd import host, vxc
+    g = np.load(os.path.join(REPO, "tests", "golden", "g4_ec_src_move_hole.npz"))
+    small = vxc.VxcModel(g["vox"], [str(x) for x in g["names"]], float(str(g["lattice_dim"])),
+                         tuple(float(x) for x in g["adj"]))
+    model = vxc.resample(small, *dims)
+    t = vxc.domain_tables(model)
+    idx, val, moving = host.SourceProgram(model, t).step(0.0)
+    return model, t, idx, val, moving
+
+
 def cpu_baseline(N=256, iters=20):
     """Reference solver on one host core, bounded sample (never the thing measured as product): a fixed
     number of iterations on the 256^3 cube of BASELINE config 2, as SURVEY section 8d prescribes for the
@@ -196,11 +212,14 @@ def side_workload(E, name, device, K=200, W=5):
     instrumented pass with hipEvents at every kernel boundary), condensed to one sub-record.
       av       the full A-V system [Ax | Ay | Az | U] (the matrix src/EC3D.f90:408 solves) of the shipped
                compare_to_Elmer geometry refined x3 per axis: 306 x 306 x 72, n = 21.4 M
+      av256    BASELINE config 3 at its stated size: ec_src_move_hole resampled to 256 x 256 x 256, n = 50.3 M + U --
+               400 MB per vector, beyond the 256 MiB Infinity Cache: the reference's own matrix on the HBM roofline
       cube256  the 256^3 cube of BASELINE config 2"""
     import numpy as np
     import torch
     t_wall = time.perf_counter()
     with E.EC3DSolver(device=device) as s:
+        b = None
         if name == "av":
             geo, geoC, valPHYS, BND, delta, dt, b = av_system(3)
             s.assemble(geo, geoC, valPHYS, BND, delta, dt)
@@ -208,14 +227,27 @@ def side_workload(E, name, device, K=200, W=5):
             what = (f"full A-V system of the shipped compare_to_Elmer geometry refined x3: grid "
                     f"{geo.shape[2]}x{geo.shape[1]}x{geo.shape[0]}, {int(np.count_nonzero(geoC))} conducting cells, "
                     f"coil RHS, x0=0, exits disabled")
+        elif name == "av256":
+            model, t, idx, val, moving = av256_system()
+            s.assemble(t["geoPHYS"], t["geoPHYS_C"], t["valPHYS"], t["BND"], t["delta"], t["dt"])
+            n = s.n
+            sdz, sdy, sdx = model.vox.shape
+            what = (f"BASELINE config 3 at its stated size: full A-V system [Ax|Ay|Az|U] of the shipped ec_src_move_hole "
+                    f"geometry resampled to {sdx}x{sdy}x{sdz} (physical size kept; the input of tests/golden/g7x_*), "
+                    f"{int(t['ncells0'])} conducting cells, first time step's coil RHS (src/EC3D.f90:345-404), x0=0, "
+                    f"exits disabled")
         else:
             N = 256
             s.assemble_poisson(N, N, N)
             n = N ** 3
             b = bar_rhs(N)
             what = "synthetic 256^3 7-pt operator (BASELINE config 2 grid), bar RHS, x0=0, exits disabled"
-        s.upload("B", b)
         s.upload("X", np.zeros(n))
+        if name == "av256":
+            s.upload("B", np.zeros(n))
+            s.rhs_step(idx, val, moving=moving)     # the reference's Jaf of the first step, built on the device
+        else:
+            s.upload("B", b)
         s.iterate_begin()
         s.iterate(1, W)
         s.synchronize()
@@ -260,9 +292,10 @@ def main():
     ap.add_argument("--grid", type=int, default=512, help="cube edge N (512 = headline, 256 = config 2)")
     ap.add_argument("--format", choices=["dict", "dia"], default="dict",
                     help="band storage: dictionary (default, 1 B/row) or plain DIA streams (56 B/row)")
-    ap.add_argument("--workload", choices=["cube", "av"], default="cube",
+    ap.add_argument("--workload", choices=["cube", "av", "av256"], default="cube",
                     help="cube: the synthetic N^3 operator the metric is quoted on (default); av: the full A-V "
-                         "system of the shipped compare_to_Elmer geometry refined by --refine (1 GPU only)")
+                         "system of the shipped compare_to_Elmer geometry refined by --refine; av256: BASELINE config 3 at "
+                         "its stated size, ec_src_move_hole resampled to 256^3 (n = 53.2 M; 1 GPU only)")
     ap.add_argument("--refine", type=int, default=3)
     ap.add_argument("--force-dist", action="store_true",
                     help="use the z-slab/torch.distributed path even with one rank (rehearsal on one GPU)")
@@ -330,6 +363,8 @@ def main():
     workload = (f"synthetic {N}^3 7-pt operator (BASELINE config {'4' if N == 512 else '2'} grid), bar RHS, "
                 f"x0=0, exits disabled")
     grid = [N, N, N]
+    if args.workload == "av256" and (use_dist or in_library):
+        raise SystemExit("bench.py --workload av256 runs on one GPU")
     if args.workload == "av" and use_dist:
         raise SystemExit("bench.py --workload av runs on one GPU or on the in-library multi-GPU path")
     if in_library:
@@ -420,6 +455,16 @@ def main():
                         f"{args.refine} per axis (BASELINE config 3 style): grid {grid[0]}x{grid[1]}x{grid[2]}, "
                         f"{int(np.count_nonzero(geoC))} conducting cells, coil RHS, x0=0, exits disabled")
             s.upload("B", b)
+        elif args.workload == "av256":
+            model, t, idx, val, moving = av256_system()
+            s.assemble(t["geoPHYS"], t["geoPHYS_C"], t["valPHYS"], t["BND"], t["delta"], t["dt"])
+            n_global = s.n
+            grid = list(model.vox.shape[::-1])
+            workload = (f"BASELINE config 3 at its stated size: full A-V system [Ax|Ay|Az|U] of the shipped ec_src_move_hole "
+                        f"geometry resampled to {grid[0]}x{grid[1]}x{grid[2]} (physical size kept), {int(t['ncells0'])} "
+                        f"conducting cells, first time step's coil RHS, x0=0, exits disabled")
+            s.upload("B", np.zeros(n_global))
+            s.rhs_step(idx, val, moving=moving)
         else:
             s.assemble_poisson(N, N, N)
             s.upload("B", bar_rhs(N))
@@ -594,7 +639,7 @@ def main():
     side = {}
     if rank == 0 and not use_dist and not in_library and args.workload == "cube" and args.format == "dict" \
             and N == 512 and not args.no_side_workloads:
-        for name in ("av", "cube256"):
+        for name in ("av", "av256", "cube256"):
             try:
                 side[name] = side_workload(E, name, local_rank)
             except Exception as e:     # reporting only: the headline number does not depend on it
@@ -618,7 +663,7 @@ def main():
             "config": {"workload": workload,
                        "n": n_global, "grid": grid, "parallelism": parallelism,
                        "band_format": ("structured A-V form (1 class byte/row, U on the grid)"
-                                       if args.workload == "av" and info.tail_rows == 0 and info.dict_classes > 0
+                                       if args.workload in ("av", "av256") and info.tail_rows == 0 and info.dict_classes > 0
                                        else "dictionary (1 B/row + table)" if info.dict_classes > 0
                                        else "plain DIA"),
                        "workgroups": geom,

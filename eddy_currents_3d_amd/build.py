@@ -20,7 +20,7 @@ CSRC = os.path.join(PKG, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(PKG, "libec3d_hip.so")
 SOURCES = ["ec3d_kernels.hip", "ec3d_context.hip", "ec3d_solve.hip", "ec3d_measure.hip", "ec3d_dist.hip", "ec3d_multi.hip",
-           "ec3d_rccl.cpp", "ec3d_rccl_loopback.cpp", "ec3d_dropin.hip", "ec3d_assemble.hip", "ec3d_rhs.hip", "ec3d_output.hip", "ec3d_format.cpp",
+           "ec3d_rccl.cpp", "ec3d_dropin.hip", "ec3d_assemble.hip", "ec3d_rhs.hip", "ec3d_output.hip", "ec3d_format.cpp",
            "ec3d_sav_csr.cpp"]
 HEADERS = [os.path.join(CSRC, "ec3d_internal.hpp"), os.path.join(CSRC, "ec3d_rccl.hpp"),
            os.path.join(os.path.dirname(PKG), "include", "ec3d_hip.h")]
@@ -77,5 +77,26 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+# ---- test support (NOT part of the product library) -----------------------------------------------------------
+# tests/libec3d_loopback.so: the loopback stand-in for librccl (tests/support/rccl_loopback.cpp) the rank-driver tests
+# name in EC3D_RCCL_LIB.  Built here because it needs the same compiler; lives under tests/ and travels to the GPU box
+# like the product library (git-ignored, not gpurun-ignored).
+LOOPBACK_SRC = os.path.join(os.path.dirname(PKG), "tests", "support", "rccl_loopback.cpp")
+LOOPBACK_LIB = os.path.join(os.path.dirname(PKG), "tests", "libec3d_loopback.so")
+
+
+def build_test_support(force: bool = False, verbose: bool = False) -> str:
+    if not os.path.exists(LOOPBACK_SRC):
+        return ""
+    if not force and os.path.exists(LOOPBACK_LIB) and os.path.getmtime(LOOPBACK_LIB) >= os.path.getmtime(LOOPBACK_SRC):
+        return LOOPBACK_LIB
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", LOOPBACK_SRC, "-o", LOOPBACK_LIB]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return LOOPBACK_LIB
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_test_support(force="--force" in sys.argv, verbose=True))

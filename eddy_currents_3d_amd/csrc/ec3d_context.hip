@@ -4,6 +4,7 @@
 #include "ec3d_internal.hpp"
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -229,6 +230,10 @@ void ec3d_free_matrix(ec3d_ctx *c)
     if (c->vb_list) (void)hipFree(c->vb_list);
     if (c->vi_list) (void)hipFree(c->vi_list);
     c->vb_list = c->vi_list = nullptr;
+    if (c->il_umask) (void)hipFree(c->il_umask);
+    c->il_umask = nullptr;
+    if (c->il_seg) (void)hipFree(c->il_seg);
+    c->il_seg = nullptr;
     if (c->us_list) (void)hipFree(c->us_list);
     c->us_list = nullptr;
     if (c->ii_list) (void)hipFree(c->ii_list);
@@ -553,6 +558,113 @@ static int choose_sweep(ec3d_ctx *c)
             ss.nblk = (int)(cols * nseg);
             ss.S = 0;
             ss.ntiles = ntiles_s;
+            // The INTERLEAVED z-march of the structured form (Sweep::il_*, walk_zm_il): the tiles of A_x, A_y, A_z and U
+            // at one (column, plane) visited together, so that a row's coupling operands are lines this workgroup just
+            // fetched.  Single-rank handles with tile-aligned planes on the linear tiles.  Measured at BASELINE config 3's
+            // stated size (256^3, 53.2 M unknowns, HBM-bound; profiles/r06_av256_*): the separate U list re-read ten
+            // tile-sized operands per U tile from HBM -- K1 / K3 fetched 31.0 / 22.7 B per row for 25 / 17 algorithmic.
+            // EC3D_SAV_IL=0 never, 2 on every such grid (tests: the small fixtures).
+            if (c->il_umask) (void)hipFree(c->il_umask);
+            if (c->il_seg) (void)hipFree(c->il_seg);
+            c->il_umask = nullptr;
+            c->il_seg = nullptr;
+            c->il_umask_host.clear();
+            c->il_seg_host.clear();
+            {
+                int il = 1;
+                if (const char *e = getenv("EC3D_SAV_IL")) il = atoi(e);
+                const int64_t P = nplanes / 3;
+                const bool il_big = rows_eff >= ((int64_t)25 << 20);
+                if (A.sav && !sav_patch && (il == 2 || (il == 1 && il_big)) && c->halo == 0 && c->nown == 0 && sw.win_nt == 0 &&
+                    P * 3 == nplanes && P * 3 * tpp == sw.ntiles && (int)c->A.ulist_host.size() == c->A.ulist_n &&
+                    c->A.n == 4 * P * tpp * EC3D_TILE /* every row of a visited tile is a row of the system: no masks */) {
+                    const int nw = (int)((P + 31) / 32);
+                    std::vector<uint32_t> um((size_t)(tpp * nw), 0u);
+                    bool ok = true;
+                    for (int32_t t : c->A.ulist_host) {
+                        const int64_t k = (int64_t)t / tpp - 3 * P, col = (int64_t)t % tpp;
+                        if (k < 0 || k >= P) { ok = false; break; }
+                        um[(size_t)(col * nw + k / 32)] |= 1u << (k % 32);
+                    }
+                    // a coupled A tile must lie where a U tile is visited (its rows' cells carry U unknowns): checked, not assumed
+                    if (ok && A.tile_flag) {
+                        std::vector<uint8_t> tf((size_t)sw.ntiles);
+                        EC3D_HIP(hipMemcpy(tf.data(), A.tile_flag, tf.size(), hipMemcpyDeviceToHost));
+                        for (int64_t t = 0; t < sw.ntiles && ok; ++t)
+                            if (tf[(size_t)t]) {
+                                const int64_t k = (t / tpp) % P, col = t % tpp;
+                                ok = (um[(size_t)(col * nw + k / 32)] >> (k % 32)) & 1u;
+                            }
+                    }
+                    if (ok) {
+                        // The work list.  Two workgroups per CU are resident (a step holds the band operands of four tiles), all
+                        // of them from the launch's start to its end, so the launch lasts as long as its heaviest workgroup:
+                        // planes are dealt by weight -- a plane with a U tile (four tiles, the coupling slots of every row) counts
+                        // il_w percent of one without -- column by column, the segments of a column of equal weight, the number of
+                        // segments of a column in proportion to its weight.
+                        int64_t want_il = 512;
+                        if (c->nblk_request > 0) want_il = c->nblk_request;
+                        if (const char *e = getenv("EC3D_NBLK_SPMV")) want_il = std::max(8, atoi(e));
+                        int il_w = 160;
+                        if (const char *e = getenv("EC3D_IL_W")) il_w = std::max(100, atoi(e));
+                        const int64_t cpx = (tpp + 7) / 8;
+                        auto bit = [&](int64_t col, int64_t k) { return (um[(size_t)(col * nw + k / 32)] >> (k % 32)) & 1u; };
+                        std::vector<int64_t> wcol((size_t)tpp, 0);
+                        int64_t wtot = 0;
+                        for (int64_t col = 0; col < tpp; ++col) {
+                            for (int64_t k = 0; k < P; ++k) wcol[(size_t)col] += bit(col, k) ? il_w : 100;
+                            wtot += wcol[(size_t)col];
+                        }
+                        const double target = (double)wtot / (double)want_il;
+                        std::vector<std::vector<int32_t>> perx(8); // per XCD label: (col, k0, k1) triples in dispatch order
+                        int64_t max_seg = 0;
+                        std::vector<std::vector<std::array<int32_t, 2>>> cuts((size_t)tpp);
+                        for (int64_t col = 0; col < tpp; ++col) {
+                            int64_t ns = std::max<int64_t>(1, (int64_t)std::llround((double)wcol[(size_t)col] / target));
+                            ns = std::min<int64_t>(ns, std::max<int64_t>(1, P / min_pps));
+                            int64_t k0 = 0, acc = 0;
+                            for (int64_t sgi = 0; sgi < ns; ++sgi) {
+                                const int64_t goal = wcol[(size_t)col] * (sgi + 1) / ns;
+                                int64_t k1 = k0;
+                                while (k1 < P && (acc < goal || sgi + 1 == ns)) { acc += bit(col, k1) ? il_w : 100; ++k1; }
+                                cuts[(size_t)col].push_back({(int32_t)k0, (int32_t)k1});
+                                k0 = k1;
+                            }
+                            max_seg = std::max<int64_t>(max_seg, ns);
+                        }
+                        // dispatch order within an XCD: segment index outermost, so that the workgroups that start together work
+                        // on neighbouring columns at about the same planes (their +-sdx lines meet in that XCD's L2)
+                        for (int x = 0; x < 8; ++x)
+                            for (int64_t sgi = 0; sgi < max_seg; ++sgi)
+                                for (int64_t col = x * cpx; col < std::min<int64_t>((x + 1) * cpx, tpp); ++col)
+                                    if (sgi < (int64_t)cuts[(size_t)col].size()) {
+                                        perx[(size_t)x].push_back((int32_t)col);
+                                        perx[(size_t)x].push_back(cuts[(size_t)col][(size_t)sgi][0]);
+                                        perx[(size_t)x].push_back(cuts[(size_t)col][(size_t)sgi][1]);
+                                    }
+                        size_t per = 0;
+                        for (int x = 0; x < 8; ++x) per = std::max(per, perx[(size_t)x].size() / 3);
+                        std::vector<int32_t> seg(per * 8 * 4, 0);
+                        for (int x = 0; x < 8; ++x)
+                            for (size_t j = 0; j < perx[(size_t)x].size() / 3; ++j)
+                                for (int q = 0; q < 3; ++q) seg[(j * 8 + (size_t)x) * 4 + (size_t)q] = perx[(size_t)x][j * 3 + (size_t)q];
+                        EC3D_HIP(hipMalloc(&c->il_umask, std::max<size_t>(um.size(), 1) * 4 + 4));
+                        EC3D_HIP(hipMemcpy(c->il_umask, um.data(), um.size() * 4, hipMemcpyHostToDevice));
+                        EC3D_HIP(hipMalloc(&c->il_seg, std::max<size_t>(seg.size(), 4) * 4));
+                        EC3D_HIP(hipMemcpy(c->il_seg, seg.data(), seg.size() * 4, hipMemcpyHostToDevice));
+                        c->il_umask_host = um;
+                        c->il_seg_host = seg;
+                        ss.il_planes = (int)P;
+                        ss.il_nw = nw;
+                        ss.il_umask = c->il_umask;
+                        ss.il_seg = c->il_seg;
+                        ss.zm_pps = (int)((P * tpp + (int64_t)per * 8 - 1) / ((int64_t)per * 8)); // (average; the list decides)
+                        ss.nblk = (int)(per * 8);
+                        ss.ulist = nullptr; // the U tiles are visited inside the march
+                        ss.ulist_n = 0;
+                    }
+                }
+            }
             if (sav_patch) {
                 const int64_t sdy = c->plane / sdx;
                 ss.rp_px = rp_px;
@@ -1499,6 +1611,20 @@ static void visit_of(const ec3d_ctx *c, const Sweep &sw, std::vector<std::vector
             ul.resize((size_t)sw.ulist_n);
             (void)hipMemcpy(ul.data(), sw.ulist, ul.size() * 4, hipMemcpyDeviceToHost);
         }
+    }
+    if (sw.il_planes > 0) { // the interleaved z-march of the structured form: walk_zm_il, step by step
+        const int64_t tpp = sw.zm_tpp, P = sw.il_planes, blk_t = P * tpp;
+        for (int b = 0; b < sw.nblk; ++b) {
+            std::vector<int32_t> v;
+            const int64_t col = c->il_seg_host[(size_t)b * 4];
+            for (int64_t k = c->il_seg_host[(size_t)b * 4 + 1]; k < c->il_seg_host[(size_t)b * 4 + 2]; ++k) {
+                const int64_t t0 = k * tpp + col;
+                for (int d = 0; d < 3; ++d) v.push_back((int32_t)(t0 + d * blk_t));
+                if ((c->il_umask_host[(size_t)(col * sw.il_nw + k / 32)] >> (k % 32)) & 1u) v.push_back((int32_t)(t0 + 3 * blk_t));
+            }
+            out.push_back(std::move(v));
+        }
+        return;
     }
     for (int b = 0; b < sw.nblk; ++b) {
         std::vector<int32_t> v;

@@ -125,6 +125,19 @@ struct Sweep {
     // everything else there is identically zero in every vector and stays so
     const int32_t *ulist;
     int ulist_n;
+    // INTERLEAVED z-march of the structured A-V form (il_planes > 0; single-rank handle, tile-aligned planes; walk_zm_il in
+    // ec3d_kernels.hip): a workgroup owns one column and a range of xy planes k of ONE block's extent, and at every plane
+    // visits the tiles of A_x, A_y, A_z there and -- when it holds an unknown -- the U tile, before it moves to plane
+    // k + 1.  The coupling operands of a row (U next to an A row's cell, A_x / A_y / A_z next to a U row's cell,
+    // src/EC3D.f90:656-711, :766-959) are then lines the same workgroup (or its XCD neighbour) fetched within the last
+    // step or two: they come out of the L2 instead of HBM.  il_planes = planes per block, il_umask = one bit per
+    // (column, plane): word col * il_nw + plane / 32; the trailing U list is empty (ulist_n = 0).
+    int il_planes = 0, il_nw = 0;
+    const uint32_t *il_umask = nullptr;
+    // the march's work list: workgroup b takes planes [il_seg[4 b + 1], il_seg[4 b + 2]) of column il_seg[4 b] (an empty range:
+    // nothing).  Cut by WEIGHT (a plane with a U tile costs more than one without), per column, the columns of XCD label x =
+    // b % 8 being its cpx adjacent ones, so that every workgroup of the launch ends at about the same time.
+    const int32_t *il_seg = nullptr;
 };
 
 // first of the two consecutive rows thread t of a workgroup owns in `tile`
@@ -326,6 +339,10 @@ struct ec3d_ctx {
     int32_t *us_list = nullptr; // structured form: the U tiles in the order the z-marching SpMV kernels take them (choose_sweep)
     int32_t *ii_list = nullptr, *ib_list = nullptr; // structured z-slab, K1 / K3 split: the interior launch's U tiles, the boundary launch's tiles
     std::vector<int32_t> us_host; // host copy (visit-order export)
+    uint32_t *il_umask = nullptr;      // interleaved z-march of the structured form (Sweep::il_*): one bit per (column, plane)
+    std::vector<uint32_t> il_umask_host;
+    int32_t *il_seg = nullptr;         // ... and its work list (four int32 per workgroup)
+    std::vector<int32_t> il_seg_host;
     bool can_vsplit = false;
     int nown = 0;    // ownership ranges of an A-V slab (see Sweep)
     int64_t own_lo[4] = {0}, own_hi[4] = {0};

@@ -234,6 +234,9 @@ struct SweepZ {
     int keep; // producers whose output stays cacheable (EC3D_KEEP_*)
     int rp_px, rp_py, rp_npx, rp_sdy; // runtime-shaped 2-D tiles of the structured kernels (Sweep::rp_*)
     const uint8_t *rp_flag;
+    int il_planes, il_nw; // interleaved z-march of the structured form (Sweep::il_*)
+    const uint32_t *il_umask;
+    const int32_t *il_seg;
 };
 // the launch of a vector kernel (K2, K4, K5) as it sees it: logical tiles t0, t0 + stride, ... of the front sweep
 // (the XCD-aware map of ec3d_tile_of: t0 = (b % 8) * S + b / 8, stride = 8 S; or t0 = b, stride = nblk), then its
@@ -929,6 +932,225 @@ __device__ __forceinline__ void sav_pair_zm(const MatDev<FMT_SAV> &A, const doub
 }
 
 // ---------------------------------------------------------------------------------------------
+// The INTERLEAVED z-march of the structured A-V form (round 6; Sweep::il_*, single-rank handles with tile-aligned planes).
+// A workgroup owns one column (a 512-cell position of the xy plane) and a range of planes, and at every plane k takes the
+// tiles of A_x, A_y, A_z there TOGETHER -- and, where the cell range holds a conductor cell, the U tile as well (one bit per
+// (column, plane), il_umask; a coupled A row implies that bit: its cell carries a U unknown).  Every block's planes below /
+// at the row are carried in registers of its own, the band operands of all (three or four) tiles of a step are requested
+// before the first value is looked at, and then EVERY coupling operand of the reference's rows is a band operand of another
+// block that is already there:
+//   A_x row (src/EC3D.f90:656-711), U(cell + m), m = -2 .. 2:   U's centre pair and its two neighbour lanes' pairs
+//   A_y row, U(cell + m sdx):    m = -1, 0, +1 = U's ym, c, yp;  m = -2, +2 (conductor faces only) loaded by the waves that meet one
+//   A_z row, U(cell + m pitch):  m = -1, 0, +1 = U's zm, c, zp;  m = -2, +2 likewise
+//   U row (:766-959), A_x(cell - 1 .. cell + 1) = A_x's left, c, right;  A_y(cell -+ sdx, cell) = A_y's ym, yp, c;
+//                     A_z(cell -+ pitch, cell) = A_z's zm, zp, c
+// -- no staged loads, no second look at memory.  With the U tiles in a list behind the front sweep (sav_pair_zm) these
+// operands were fetched again: measured at BASELINE config 3's stated size (256^3, 53.2 M unknowns: HBM-bound, each vector 426
+// MB), the SpMV kernels read 781 MB per launch where the same system WITHOUT its conductor reads 488 MB and the U rows add 34 MB
+// of their own -- 260 MB of re-fetched coupling operands (profiles/r06_av256_*).  Same products, same order as sav_pair_zm:
+// bands ascending then U slots (A rows), A slots then bands (U rows) = ascending columns = the reference's row sum
+// (src/solvers.f90:59 after src/EC3D.f90:715); a zero slot is neither loaded nor added.  The dot products are summed in the
+// visit order A_x, A_y, A_z, (U) per plane, which ec3d_get_visit_order reports to the oracle's twin.
+// What a block carries from step to step: the planes below / at the row, and -- requested a step AHEAD, as the last loads a
+// step issues -- everything of the NEXT step that comes from HBM: the plane above (the +-sdx rows and the edge lanes are lines
+// a neighbour fetched a step earlier: L2), the class bytes and the kernel's own operand (K1: R0).  The memory counter retires
+// loads in order -- a wait for a later load is a wait for every earlier one -- so behind the step's own loads these requests
+// delay nothing of the step; they are in flight while it computes (the copies of the carried registers at the loop's boundary
+// are what finally waits for them).  Two things measured and not kept (profiles/r06_av256_*): the same requests by LDS-DMA
+// into slots (no registers, three workgroups per CU) -- the compiler puts vmcnt(0) in front of the first LDS read behind an
+// LDS-DMA, the class table's included, so the step waited for its requests at once; and under `if (more)` -- the carried
+// register is then defined on two paths and the copy that merges them is a use of the loaded value.
+struct IlRegs {
+    d2 xm, xc, xn, qn;
+    unsigned short ccn;
+};
+struct IlOps {
+    SavBand b;
+    unsigned short cc;
+};
+// the step's loads of one block: U = the U block (outer neighbours as PAIRS: the A_x rows read U two cells away)
+template <bool U, class V, class PRE>
+__device__ __forceinline__ void il_block_loads(const MatDev<FMT_SAV> &A, const V &x, PRE &&pre, int64_t r, bool first, IlRegs &z,
+                                               IlOps &o, d2 &q, d2 &epair)
+{
+    const int lane = threadIdx.x & 63;
+    if constexpr (U) {
+        epair = d2{0.0, 0.0};
+        if (lane == 0 || lane == 63) epair = x.pair(lane == 0 ? r - 2 : r + 2); // one predicated load (see sav_band_loads)
+        o.b.left = epair.y;  // lane 0: U(r - 1)
+        o.b.right = epair.x; // lane 63: U(r + 2)
+    } else {
+        double edge = 0.0;
+        if (lane == 0 || lane == 63) edge = x.at(lane == 0 ? r - 1 : r + 2);
+        o.b.left = edge;
+        o.b.right = edge;
+    }
+    o.b.ym = x.pair(r - A.sdx);
+    o.b.yp = x.pair(r + A.sdx);
+    if (first) { // nothing carried, nothing requested ahead
+        o.b.zm = x.pair(r - A.pitch);
+        o.b.c = x.pair(r);
+        o.b.zp = x.pair(r + A.pitch);
+        o.cc = *reinterpret_cast<const unsigned short *>(A.cls + r);
+        q = pre(r);
+    } else {
+        o.b.zm = z.xm;
+        o.b.c = z.xc;
+        o.b.zp = z.xn;
+        o.cc = z.ccn;
+        q = z.qn;
+    }
+    z.xm = o.b.c;
+    z.xc = o.b.zp;
+}
+// ... and, last of the step, what the block's NEXT step needs from HBM (the workgroup's last step asks for its own plane
+// again and drops it: no branch)
+template <class V, class PRE>
+__device__ __forceinline__ void il_block_ahead(const MatDev<FMT_SAV> &A, const V &x, PRE &&pre, int64_t r, bool more, IlRegs &z)
+{
+    const int64_t rn = r + (more ? A.pitch : 0);
+    z.xn = x.pair(rn + A.pitch);
+    z.ccn = *reinterpret_cast<const unsigned short *>(A.cls + rn);
+    z.qn = pre(rn);
+}
+// the U slots m = -2 .. 2 of rows r, r + 1 of an A block, operands given
+__device__ __forceinline__ void il_a_slots(const double *t0, const double *t1, const double (&o0)[5], const double (&o1)[5],
+                                           double &s0, double &s1)
+{
+#pragma unroll
+    for (int m = 0; m < 5; ++m) {
+        const double v0 = t0[7 + m], v1 = t1[7 + m];
+        if (v0 != 0.0) s0 = s0 + v0 * o0[m];
+        if (v1 != 0.0) s1 = s1 + v1 * o1[m];
+    }
+}
+//   pre(r) -> d2   the kernel's own operand of rows r, r + 1 (K1: R0; the residual kernel: b; or nothing)
+//   emit(r, s0, s1, ctr, q)   the row sums of rows r, r + 1, the centre pair of x there, and what pre returned for r
+template <class V, class PRE, class EMIT>
+__device__ __forceinline__ void walk_zm_il(const MatDev<FMT_SAV> &A, const SweepZ &sw, const double *tbl, const V &x, PRE &&pre,
+                                           EMIT &&emit)
+{
+    const int lane = threadIdx.x & 63;
+    typedef const __attribute__((address_space(4))) uint32_t *cptr; // through the scalar unit (see sav_tile_coupled)
+    // this workgroup's entry of the work list (Sweep::il_seg): column, first plane, end
+    const cptr sgp = (cptr)(uintptr_t)sw.il_seg + 4 * (int64_t)blockIdx.x;
+    const int col = (int)sgp[0];
+    int k = (int)sgp[1];
+    const int kend = (int)sgp[2];
+    const cptr um = (cptr)(uintptr_t)sw.il_umask + (int64_t)col * sw.il_nw;
+    auto ubit = [&](int kk) -> bool { return (um[kk >> 5] >> (kk & 31)) & 1u; };
+    IlRegs z0, z1, z2, z3;
+    bool first = true, ufirst = true;
+    bool cpl = k < kend ? ubit(k) : false;
+    for (; k < kend; ++k) {
+        const bool more = k + 1 < kend;
+        const bool ncpl = more ? ubit(k + 1) : false; // (a scalar load of its own counter; the word stays in the scalar cache)
+        // (the tile number through an opaque scalar register: left to itself the compiler strength-reduces every stream's
+        // address of every block into an induction variable of its own -- some forty 64-bit pointers, and spills)
+        int64_t t0 = (int64_t)k * sw.tpp + col;
+        asm volatile("" : "+s"(t0));
+        const int64_t r0 = t0 * EC3D_TILE + 2 * (int64_t)threadIdx.x, r1 = r0 + A.nC, r2 = r1 + A.nC, r3 = r2 + A.nC;
+        // two copies of the step, each without the other's loads
+        auto step = [&](auto cplc) {
+            constexpr bool CPL = decltype(cplc)::value;
+            // ---- the step's own loads (L2), then the next step's (HBM) ----
+            IlOps a0, a1, a2, au;
+            d2 ue, none, q0, q1, q2, q3;
+            il_block_loads<false>(A, x, pre, r0, first, z0, a0, q0, none);
+            il_block_loads<false>(A, x, pre, r1, first, z1, a1, q1, none);
+            il_block_loads<false>(A, x, pre, r2, first, z2, a2, q2, none);
+            if constexpr (CPL) il_block_loads<true>(A, x, pre, r3, ufirst, z3, au, q3, ue);
+            il_block_ahead(A, x, pre, r0, more, z0);
+            il_block_ahead(A, x, pre, r1, more, z1);
+            il_block_ahead(A, x, pre, r2, more, z2);
+            if constexpr (CPL) il_block_ahead(A, x, pre, r3, more, z3); // (used when the next plane has a U tile as well)
+            const SavBand &b0 = a0.b, &b1 = a1.b, &b2 = a2.b, &bu = au.b;
+            // ---- A_x rows ----
+            double s0 = 0.0, s1 = 0.0;
+            {
+                const double *t0p = tbl + (a0.cc & 0xFF) * EC3D_SAV_STRIDE, *t1p = tbl + (a0.cc >> 8) * EC3D_SAV_STRIDE;
+                sav_band_sum(t0p, t1p, b0, s0, s1);
+                if constexpr (CPL) { // U(cell - 2 .. cell + 3): the centre pairs of lanes l - 1, l, l + 1
+                    d2 lo, hi;
+                    lo.x = __shfl_up(bu.c.x, 1, 64);
+                    lo.y = __shfl_up(bu.c.y, 1, 64);
+                    hi.x = __shfl_down(bu.c.x, 1, 64);
+                    hi.y = __shfl_down(bu.c.y, 1, 64);
+                    if (lane == 0) lo = ue;
+                    if (lane == 63) hi = ue;
+                    const double o0[5] = {lo.x, lo.y, bu.c.x, bu.c.y, hi.x}, o1[5] = {lo.y, bu.c.x, bu.c.y, hi.x, hi.y};
+                    il_a_slots(t0p, t1p, o0, o1, s0, s1);
+                }
+                emit(r0, s0, s1, b0.c, q0);
+            }
+            // ---- A_y, A_z rows ----
+            auto a_rows = [&](const IlOps &a, const d2 q, const int64_t r, const d2 um1, const d2 up1, const int64_t st) {
+                const double *t0p = tbl + (a.cc & 0xFF) * EC3D_SAV_STRIDE, *t1p = tbl + (a.cc >> 8) * EC3D_SAV_STRIDE;
+                s0 = 0.0;
+                s1 = 0.0;
+                sav_band_sum(t0p, t1p, a.b, s0, s1);
+                if constexpr (CPL) {
+                    // outer slots: one-sided stencils at a conductor face (src/EC3D.f90:667-676) only
+                    const bool wlo = t0p[7] != 0.0 || t1p[7] != 0.0, whi = t0p[11] != 0.0 || t1p[11] != 0.0;
+                    d2 qlo = d2{0.0, 0.0}, qhi = d2{0.0, 0.0};
+                    if (__any(wlo || whi)) {
+                        if (wlo) qlo = x.pair(r3 - 2 * st);
+                        if (whi) qhi = x.pair(r3 + 2 * st);
+                    }
+                    const double o0[5] = {qlo.x, um1.x, bu.c.x, up1.x, qhi.x}, o1[5] = {qlo.y, um1.y, bu.c.y, up1.y, qhi.y};
+                    il_a_slots(t0p, t1p, o0, o1, s0, s1);
+                }
+                emit(r, s0, s1, a.b.c, q);
+            };
+            a_rows(a1, q1, r1, bu.ym, bu.yp, A.sdx);
+            a_rows(a2, q2, r2, bu.zm, bu.zp, A.pitch);
+            // ---- U rows: the A slots (A_x, A_y, A_z: the lower columns), then the bands ----
+            if constexpr (CPL) {
+                const double *t0p = tbl + (au.cc & 0xFF) * EC3D_SAV_STRIDE, *t1p = tbl + (au.cc >> 8) * EC3D_SAV_STRIDE;
+                s0 = 0.0;
+                s1 = 0.0;
+                {
+                    double xal = b0.left, xar = b0.right;
+                    const double l = __shfl_up(b0.c.y, 1, 64), rr = __shfl_down(b0.c.x, 1, 64);
+                    if (lane != 0) xal = l;
+                    if (lane != 63) xar = rr;
+                    const double o0[3] = {xal, b0.c.x, b0.c.y}, o1[3] = {b0.c.x, b0.c.y, xar};
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const double v0 = t0p[7 + j], v1 = t1p[7 + j];
+                        if (v0 != 0.0) s0 = s0 + v0 * o0[j];
+                        if (v1 != 0.0) s1 = s1 + v1 * o1[j];
+                    }
+                }
+                auto a_slots = [&](const int dd, const d2 om, const d2 oc, const d2 op) {
+                    const double vm0 = t0p[7 + 3 * dd], vm1 = t1p[7 + 3 * dd], vc0 = t0p[8 + 3 * dd], vc1 = t1p[8 + 3 * dd],
+                                 vp0 = t0p[9 + 3 * dd], vp1 = t1p[9 + 3 * dd];
+                    if (vm0 != 0.0) s0 = s0 + vm0 * om.x;
+                    if (vm1 != 0.0) s1 = s1 + vm1 * om.y;
+                    if (vc0 != 0.0) s0 = s0 + vc0 * oc.x;
+                    if (vc1 != 0.0) s1 = s1 + vc1 * oc.y;
+                    if (vp0 != 0.0) s0 = s0 + vp0 * op.x;
+                    if (vp1 != 0.0) s1 = s1 + vp1 * op.y;
+                };
+                a_slots(1, b1.ym, b1.c, b1.yp);
+                a_slots(2, b2.zm, b2.c, b2.zp);
+                sav_band_sum(t0p, t1p, bu, s0, s1);
+                emit(r3, s0, s1, bu.c, q3);
+            }
+        };
+        if (cpl) {
+            step(TrueC());
+            ufirst = false;
+        } else {
+            step(FalseC());
+            ufirst = true;
+        }
+        first = false;
+        cpl = ncpl;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Structured A-V form on runtime-shaped 2-D tiles (round 4).  What patch_pair below does for the single-component
 // cube -- a workgroup owns a patch of the xy plane and marches in z; the plane above is ONE 16-byte global load per
 // thread, the plane below and the centre are carried in registers, and the in-plane neighbours are the centre values
@@ -1388,7 +1610,10 @@ __device__ __forceinline__ void spmv_pair(const MatDev<FMT> &A, const SW &sw, co
 // the SpMV grids are sized for 6 workgroups per CU (choose_sweep): keep the register count within that
 // (the structured form without z-marching only runs on grids too small for plane-aligned tiles: it takes the
 // registers it needs -- 5 per CU -- instead of spilling)
-#define EC3D_SPMV_OCC __attribute__((amdgpu_waves_per_eu((FMT == FMT_SAV && !ZM) ? 5 : 6)))
+// (the interleaved z-march of the structured form -- TAIL stands for it there, EC3D_IL -- holds the band operands of
+// four blocks at once: two workgroups per CU)
+#define EC3D_IL (FMT == FMT_SAV && ZM && TAIL && !PATCH)
+#define EC3D_SPMV_OCC __attribute__((amdgpu_waves_per_eu(EC3D_IL ? 2 : (FMT == FMT_SAV && !ZM) ? 5 : 6)))
 #define EC3D_SPMV_T template <int FMT, bool NT, bool ZM, bool TAIL, bool PATCH>
 #define EC3D_SWEEP_OF(ZM_) typename SweepSel<ZM_>::type
 // classes in the LDS table (0 for the formats without one)
@@ -1412,13 +1637,18 @@ EC3D_SPMV_T __global__ __launch_bounds__(EC3D_THREADS) EC3D_SPMV_OCC void k_spmv
     ZRegs zr;
     PatchPos pp{};
     int pstep = 0; // steps taken (2-D tiles: which of the two LDS buffers holds the centre plane)
-    walk_spmv<FMT, ZM, FMT != FMT_SAV, PATCH>(A, sw, pp, [&](int64_t tile, auto fc) {
-        EC3D_ROW_S;
-        double s0, s1;
-        d2 ctr;
-        spmv_pair<FMT, ZM, TAIL, NT, PATCH>(A, sw, pp, tbl, stg, pstep, VecPlain{x}, r, tile, (bool)fc, zr, s0, s1, ctr);
-        store2<NT>(y, r, nst, s0, s1);
-    });
+    if constexpr (EC3D_IL) {
+        walk_zm_il(A, sw, tbl, VecPlain{x}, [](int64_t) { return d2{0.0, 0.0}; },
+                   [&](int64_t r, double s0, double s1, d2, d2) { store2<NT>(y, r, INT64_MAX, s0, s1); });
+    } else {
+        walk_spmv<FMT, ZM, FMT != FMT_SAV, PATCH>(A, sw, pp, [&](int64_t tile, auto fc) {
+            EC3D_ROW_S;
+            double s0, s1;
+            d2 ctr;
+            spmv_pair<FMT, ZM, TAIL, NT, PATCH>(A, sw, pp, tbl, stg, pstep, VecPlain{x}, r, tile, (bool)fc, zr, s0, s1, ctr);
+            store2<NT>(y, r, nst, s0, s1);
+        });
+    }
 }
 
 // setup: R = B - A X ; R0 = R ; P = R ; partials of B·B and R·R   (src/solvers.f90:14-21)
@@ -1433,25 +1663,39 @@ EC3D_SPMV_T __global__ __launch_bounds__(EC3D_THREADS) EC3D_SPMV_OCC void k_resi
     PatchPos pp{};
     int pstep = 0; // steps taken (2-D tiles: which of the two LDS buffers holds the centre plane)
     double acc[2] = {0.0, 0.0};
-    walk_spmv<FMT, ZM, FMT != FMT_SAV, PATCH>(A, sw, pp, [&](int64_t tile, auto fc) {
-        EC3D_ROW_S;
-        double s0, s1;
-        d2 ctr;
-        spmv_pair<FMT, ZM, TAIL, NT, PATCH>(A, sw, pp, tbl, stg, pstep, VecPlain{x}, r, tile, (bool)fc, zr, s0, s1, ctr);
-        d2 bv = load2<NT>(b + r);
-        double e0 = bv.x - s0, e1 = bv.y - s1, b0 = bv.x, b1 = bv.y;
-        store2<NT>(rv, r, nst, e0, e1);
-        store2<NT>(r0, r, nst, e0, e1);
-        store2<NT>(p, r, nst, e0, e1);
-        EC3D_MASK2(r, sw, e0, e1);
-        EC3D_IDLE2(e0, e1);
-        EC3D_MASK2(r, sw, b0, b1);
-        EC3D_IDLE2(b0, b1);
-        acc[0] = acc[0] + b0 * b0;
-        acc[0] = acc[0] + b1 * b1;
-        acc[1] = acc[1] + e0 * e0;
-        acc[1] = acc[1] + e1 * e1;
-    });
+    if constexpr (EC3D_IL) {
+        walk_zm_il(A, sw, tbl, VecPlain{x}, [&](int64_t r) { return load2<NT>(b + r); },
+                   [&](int64_t r, double s0, double s1, d2, d2 bv) {
+                       double e0 = bv.x - s0, e1 = bv.y - s1, b0 = bv.x, b1 = bv.y;
+                       store2<NT>(rv, r, INT64_MAX, e0, e1); // (every row of the interleaved march is a row of the system)
+                       store2<NT>(r0, r, INT64_MAX, e0, e1);
+                       store2<NT>(p, r, INT64_MAX, e0, e1);
+                       acc[0] = acc[0] + b0 * b0;
+                       acc[0] = acc[0] + b1 * b1;
+                       acc[1] = acc[1] + e0 * e0;
+                       acc[1] = acc[1] + e1 * e1;
+                   });
+    } else {
+        walk_spmv<FMT, ZM, FMT != FMT_SAV, PATCH>(A, sw, pp, [&](int64_t tile, auto fc) {
+            EC3D_ROW_S;
+            double s0, s1;
+            d2 ctr;
+            spmv_pair<FMT, ZM, TAIL, NT, PATCH>(A, sw, pp, tbl, stg, pstep, VecPlain{x}, r, tile, (bool)fc, zr, s0, s1, ctr);
+            d2 bv = load2<NT>(b + r);
+            double e0 = bv.x - s0, e1 = bv.y - s1, b0 = bv.x, b1 = bv.y;
+            store2<NT>(rv, r, nst, e0, e1);
+            store2<NT>(r0, r, nst, e0, e1);
+            store2<NT>(p, r, nst, e0, e1);
+            EC3D_MASK2(r, sw, e0, e1);
+            EC3D_IDLE2(e0, e1);
+            EC3D_MASK2(r, sw, b0, b1);
+            EC3D_IDLE2(b0, b1);
+            acc[0] = acc[0] + b0 * b0;
+            acc[0] = acc[0] + b1 * b1;
+            acc[1] = acc[1] + e0 * e0;
+            acc[1] = acc[1] + e1 * e1;
+        });
+    }
     block_sum<2>(acc, lds);
     {
         const int pslot_[2] = {P_BB, P_RR_INIT};
@@ -1561,22 +1805,31 @@ EC3D_SPMV_T __global__ __launch_bounds__(EC3D_THREADS) EC3D_SPMV_OCC void k1_spm
     PatchPos pp{};
     int pstep = 0; // steps taken (2-D tiles: which of the two LDS buffers holds the centre plane)
     double acc[1] = {0.0};
-    walk_spmv<FMT, ZM, FMT != FMT_SAV, PATCH>(A, sw, pp, [&](int64_t tile, auto fc) {
-        EC3D_ROW_S;
-        double s0, s1;
-        d2 ctr;
-        // R0's pair: requested before the step's own loads in the structured kernels (A-V K1 128 -> 124 us; their
-        // steps wait on LDS-DMA slots), after them elsewhere (2-D tiles: 593 vs 603 us at 512^3, 76 vs 80 at 256^3)
-        d2 q;
-        if constexpr (FMT == FMT_SAV && !PATCH) q = load2<NT>(r0 + r);
-        spmv_pair<FMT, ZM, TAIL, NT, PATCH>(A, sw, pp, tbl, stg, pstep, VecPlain{p}, r, tile, (bool)fc, zr, s0, s1, ctr);
-        if constexpr (FMT != FMT_SAV || PATCH) q = load2<NT>(r0 + r);
-        store2k<NT>(ap, r, nst, s0, s1, keep_of(sw) & EC3D_KEEP_AP);
-        EC3D_MASK2(r, sw, s0, s1);
-        EC3D_IDLE2(s0, s1);
-        acc[0] = acc[0] + s0 * q.x;
-        acc[0] = acc[0] + s1 * q.y;
-    });
+    if constexpr (EC3D_IL) {
+        walk_zm_il(A, sw, tbl, VecPlain{p}, [&](int64_t r) { return load2<NT>(r0 + r); },
+                   [&](int64_t r, double s0, double s1, d2, d2 q) {
+                       store2k<NT>(ap, r, INT64_MAX, s0, s1, keep_of(sw) & EC3D_KEEP_AP);
+                       acc[0] = acc[0] + s0 * q.x;
+                       acc[0] = acc[0] + s1 * q.y;
+                   });
+    } else {
+        walk_spmv<FMT, ZM, FMT != FMT_SAV, PATCH>(A, sw, pp, [&](int64_t tile, auto fc) {
+            EC3D_ROW_S;
+            double s0, s1;
+            d2 ctr;
+            // R0's pair: requested before the step's own loads in the structured kernels (A-V K1 128 -> 124 us; their
+            // steps wait on LDS-DMA slots), after them elsewhere (2-D tiles: 593 vs 603 us at 512^3, 76 vs 80 at 256^3)
+            d2 q;
+            if constexpr (FMT == FMT_SAV && !PATCH) q = load2<NT>(r0 + r);
+            spmv_pair<FMT, ZM, TAIL, NT, PATCH>(A, sw, pp, tbl, stg, pstep, VecPlain{p}, r, tile, (bool)fc, zr, s0, s1, ctr);
+            if constexpr (FMT != FMT_SAV || PATCH) q = load2<NT>(r0 + r);
+            store2k<NT>(ap, r, nst, s0, s1, keep_of(sw) & EC3D_KEEP_AP);
+            EC3D_MASK2(r, sw, s0, s1);
+            EC3D_IDLE2(s0, s1);
+            acc[0] = acc[0] + s0 * q.x;
+            acc[0] = acc[0] + s1 * q.y;
+        });
+    }
     block_sum<1>(acc, lds);
     {
         const int pslot_[1] = {P_D1};
@@ -1643,19 +1896,30 @@ EC3D_SPMV_T __global__ __launch_bounds__(EC3D_THREADS) EC3D_SPMV_OCC void k3_spm
     PatchPos pp{};
     int pstep = 0; // steps taken (2-D tiles: which of the two LDS buffers holds the centre plane)
     double acc[2] = {0.0, 0.0};
-    walk_spmv<FMT, ZM, FMT != FMT_SAV, PATCH>(A, sw, pp, [&](int64_t tile, auto fc) {
-        EC3D_ROW_S;
-        double s0, s1;
-        d2 q;
-        spmv_pair<FMT, ZM, TAIL, NT, PATCH>(A, sw, pp, tbl, stg, pstep, VecPlain{sv}, r, tile, (bool)fc, zr, s0, s1, q);
-        store2<NT>(as, r, nst, s0, s1);
-        EC3D_MASK2(r, sw, s0, s1);
-        EC3D_IDLE2(s0, s1);
-        acc[0] = acc[0] + s0 * q.x;
-        acc[0] = acc[0] + s1 * q.y;
-        acc[1] = acc[1] + s0 * s0;
-        acc[1] = acc[1] + s1 * s1;
-    });
+    if constexpr (EC3D_IL) {
+        walk_zm_il(A, sw, tbl, VecPlain{sv}, [](int64_t) { return d2{0.0, 0.0}; },
+                   [&](int64_t r, double s0, double s1, d2 q, d2) {
+                       store2<NT>(as, r, INT64_MAX, s0, s1);
+                       acc[0] = acc[0] + s0 * q.x;
+                       acc[0] = acc[0] + s1 * q.y;
+                       acc[1] = acc[1] + s0 * s0;
+                       acc[1] = acc[1] + s1 * s1;
+                   });
+    } else {
+        walk_spmv<FMT, ZM, FMT != FMT_SAV, PATCH>(A, sw, pp, [&](int64_t tile, auto fc) {
+            EC3D_ROW_S;
+            double s0, s1;
+            d2 q;
+            spmv_pair<FMT, ZM, TAIL, NT, PATCH>(A, sw, pp, tbl, stg, pstep, VecPlain{sv}, r, tile, (bool)fc, zr, s0, s1, q);
+            store2<NT>(as, r, nst, s0, s1);
+            EC3D_MASK2(r, sw, s0, s1);
+            EC3D_IDLE2(s0, s1);
+            acc[0] = acc[0] + s0 * q.x;
+            acc[0] = acc[0] + s1 * q.y;
+            acc[1] = acc[1] + s0 * s0;
+            acc[1] = acc[1] + s1 * s1;
+        });
+    }
     block_sum<2>(acc, lds);
     {
         const int pslot_[2] = {P_D2, P_D3};
@@ -2306,13 +2570,19 @@ static inline SweepZ sweep_z(const Sweep &sw)
     z.rp_npx = sw.rp_npx;
     z.rp_sdy = sw.rp_sdy;
     z.rp_flag = sw.rp_flag;
+    z.il_planes = sw.il_planes;
+    z.il_nw = sw.il_nw;
+    z.il_umask = sw.il_umask;
+    z.il_seg = sw.il_seg;
     return z;
 }
 // dynamic LDS: the class table (a full 256-class table of the structured form would be 32 KiB and cap the CU
 // at 4 workgroups; real problems have 64 classes = 8 KiB) and, for the z-marching structured kernels, the
 // staging slots behind it (16 KiB): 24.6 KiB per workgroup, six of them fit a CU's 160 KiB
-static inline size_t tbl_bytes(const MatView &A, int F, bool zm, bool patch)
+static inline size_t tbl_bytes(const MatView &A, int F, bool zm, bool patch, bool il = false)
 {
+    // structured form, interleaved z-march: the table alone (walk_zm_il stages nothing)
+    if (il && F == FMT_SAV) return (size_t)A.ncls * EC3D_SAV_STRIDE * 8;
     // structured form on runtime-shaped 2-D tiles: table, two exchange buffers, two staging slots (sav_patch_step)
     if (patch && F == FMT_SAV) return (size_t)A.ncls * EC3D_SAV_STRIDE * 8 + (size_t)(2 + EC3D_NSTAGE_RT) * EC3D_TILE * 8;
     if (patch) return (size_t)((F == FMT_DICT7 ? A.ncls * 7 + 1 : 0) & ~1) * 8 + (size_t)2 * EC3D_TILE * 8;
@@ -2324,13 +2594,14 @@ static inline size_t tbl_bytes(const MatView &A, int F, bool zm, bool patch)
     do {                                                                                                            \
         const bool tail_ = F != FMT_SAV && A.has_tail;                                                              \
         const bool patch_ = zm_ && !tail_ && ((sw.patch_npx > 0 && F == FMT_DICT7) || (sw.rp_px > 0 && F == FMT_SAV)); /* choose_sweep */ \
-        const size_t lds_ = tbl_bytes(A, F, zm_, patch_);                                                           \
+        const size_t lds_ = tbl_bytes(A, F, zm_, patch_, zm_ && !patch_ && sw.il_planes > 0);                       \
         const MatDev<F> Ad = mat_dev<F>(A);                                                                         \
         if constexpr (F != FMT_GENERIC) {                                                                           \
             if (zm_) {                                                                                              \
                 const SweepZ swz = sweep_z(sw);                                                                     \
                 if (patch_) { if constexpr (F == FMT_DICT7 || F == FMT_SAV) KERNEL<F, NT_, true, false, true><<<sw.nblk, EC3D_THREADS, lds_, s>>>(Ad, swz, __VA_ARGS__); } \
                 else if (tail_) { if constexpr (F != FMT_SAV) KERNEL<F, NT_, true, true, false><<<sw.nblk, EC3D_THREADS, lds_, s>>>(Ad, swz, __VA_ARGS__); } \
+                else if (F == FMT_SAV && sw.il_planes > 0) { if constexpr (F == FMT_SAV) KERNEL<F, NT_, true, true, false><<<sw.nblk, EC3D_THREADS, lds_, s>>>(Ad, swz, __VA_ARGS__); } /* interleaved z-march: EC3D_IL */ \
                 else KERNEL<F, NT_, true, false, false><<<sw.nblk, EC3D_THREADS, lds_, s>>>(Ad, swz, __VA_ARGS__);   \
                 break;                                                                                              \
             }                                                                                                       \

@@ -348,7 +348,7 @@ int cross_wait(hipStream_t stream, hipEvent_t ev)
 // (every rank of a job runs the same plan with the same depths, and my state is current when I get here), the pointer
 // taken from the owner's tables, which do not change while a job runs: another rank's thread may be iterations ahead or
 // behind with its own host-side bookkeeping.
-constexpr int kFacts = 10;         // doubles every rank tells the others at set-up (finish_setup)
+constexpr int kFacts = 15;         // doubles every rank tells the others at set-up (finish_setup)
 constexpr int kPlainVec = INT_MIN; // `it` of a caller that means the plain work vector (uploads, probes, the time loop's X)
 double *vec_of(const ec3d_ctx *me, const ec3d_ctx *owner, int vec, int it)
 {
@@ -720,7 +720,10 @@ int finish_setup(ec3d_multi *m)
     // What every rank has to know of every other: can it run the three-launch iteration, the depth of its rings, its
     // storage format, its size, what it sends to its neighbours.  One process: read off the slabs; one process per GPU:
     // eight doubles per rank, all-gathered once.
-    struct RankFacts { double fused_ok, xd, sav, n_pad, snd_lo, rcv_lo, snd_hi, rcv_hi, xasync, both_splits; };
+    // (h_*: a digest of the SEQUENCE of piece lengths of that direction -- one process per GPU: the k-th ncclSend of a
+    // rank must meet the k-th ncclRecv of its neighbour with the same count, and a mismatch there is a hang, not an error)
+    struct RankFacts { double fused_ok, xd, sav, n_pad, snd_lo, rcv_lo, snd_hi, rcv_hi, xasync, both_splits, fsplit,
+                       h_snd_lo, h_rcv_lo, h_snd_hi, h_rcv_hi; };
     static_assert(sizeof(RankFacts) == kFacts * sizeof(double), "kFacts doubles");
     std::vector<RankFacts> facts((size_t)(m->nccl ? m->comm_world : m->n));
     auto facts_of = [&](const Slab &sl) {
@@ -735,6 +738,16 @@ int finish_setup(ec3d_multi *m)
         f.sav = c->A.sav ? 1.0 : 0.0;
         f.n_pad = (double)c->A.n_pad;
         f.snd_lo = total(sl.send_lo); f.rcv_lo = total(sl.recv_lo); f.snd_hi = total(sl.send_hi); f.rcv_hi = total(sl.recv_hi);
+        f.fsplit = c->can_fsplit ? 1.0 : 0.0;
+        // FNV-1a over (count, then every piece's length in order), folded to 52 bits: exact in a double
+        auto digest = [](const std::vector<Piece> &ps) {
+            uint64_t h = 1469598103934665603ull;
+            auto mix = [&](uint64_t v) { for (int b = 0; b < 8; ++b) { h ^= (v >> (8 * b)) & 0xFFu; h *= 1099511628211ull; } };
+            mix((uint64_t)ps.size());
+            for (const Piece &q : ps) mix((uint64_t)q.cnt);
+            return (double)((h ^ (h >> 52)) & ((1ull << 52) - 1));
+        };
+        f.h_snd_lo = digest(sl.snd_lo); f.h_rcv_lo = digest(sl.rcv_lo); f.h_snd_hi = digest(sl.snd_hi); f.h_rcv_hi = digest(sl.rcv_hi);
         return f;
     };
     if (m->nccl) {
@@ -760,6 +773,12 @@ int finish_setup(ec3d_multi *m)
         }
         if (facts[(size_t)g].snd_hi != facts[(size_t)g + 1].rcv_lo || facts[(size_t)g].rcv_hi != facts[(size_t)g + 1].snd_lo) {
             ec3d_set_error("ec3d_multi: neighbouring slabs disagree on the halo size");
+            return 105;
+        }
+        if (m->nccl && (facts[(size_t)g].h_snd_hi != facts[(size_t)g + 1].h_rcv_lo ||
+                        facts[(size_t)g].h_rcv_hi != facts[(size_t)g + 1].h_snd_lo)) {
+            ec3d_set_error("ec3d_multi: ranks " + std::to_string(g) + " and " + std::to_string(g + 1) +
+                           " cut their halo into different pieces (same total): the send / receive pairs would not meet");
             return 105;
         }
     }
@@ -792,6 +811,7 @@ int finish_setup(ec3d_multi *m)
     bool fused = m->kind == 1 && m->world > 1;
     bool xasync = m->world > 1;
     bool both = m->world > 1;
+    bool fsplit = true; // plans 3 and 4 issue the all-gather and the send / recv group in opposite host order: the job's choice
     double job_rows = 0;
     int xd = EC3D_XD_MAX;
     for (const RankFacts &f : facts) {
@@ -799,6 +819,7 @@ int finish_setup(ec3d_multi *m)
         xd = std::min(xd, (int)f.xd);
         xasync = xasync && f.xasync != 0.0;
         both = both && f.both_splits != 0.0;
+        fsplit = fsplit && f.fsplit != 0.0;
         job_rows = std::max(job_rows, f.n_pad);
     }
     both = both && (m->kind == 2 || job_rows < 10.0 * 1048576.0); // (A-V slabs: measured a gain at every size, below)
@@ -831,11 +852,14 @@ int finish_setup(ec3d_multi *m)
         // EC3D_SLAB_PLAN (the SAME value on every rank: plan 2 orders its exchanges differently) picks the five-launch plan of
         // a single-component job: 0 exchange in front of K1 / K3, 1 K1 / K3 split around it, 2 K2 / K5 boundary tiles first
         int want_plan = getenv("EC3D_SLAB_PLAN") ? atoi(getenv("EC3D_SLAB_PLAN")) : -1;
-        if (want_plan < 0 && both && !fused) want_plan = 5;
+        // Plan 5 is OPT-IN (EC3D_SLAB_PLAN=5, the same on every rank) until a job of two real devices has verified it
+        // bit for bit: everything measured for it (-3 ... -5 % below 10 Mi rows per rank, -10 % on A-V slabs) was measured
+        // with the "neighbour" on the same card (`both` says where the one-card measurements would have picked it).
+        (void)both;
         s.overlap_ok = false;
         if (m->kind == 1 && !((want_plan == 2 || want_plan == 5) && !fused && m->world > 1)) {
             const bool no_fsplit = getenv("EC3D_SLAB_FSPLIT") && atoi(getenv("EC3D_SLAB_FSPLIT")) == 0;
-            s.plan = fused ? ((c->can_fsplit && !no_fsplit) ? 4 : 3) : (ec3d_can_overlap(c) && want_plan != 0) ? 1 : 0;
+            s.plan = fused ? ((fsplit && !no_fsplit) ? 4 : 3) : (ec3d_can_overlap(c) && want_plan != 0) ? 1 : 0;
         } else if (m->kind == 2 && want_plan == 0) {
             s.plan = 0; // (measurement: the A-V job with the exchange in front of K1 / K3, no split launches)
         } else if (m->world > 1) {
@@ -892,7 +916,8 @@ void av_layout(ec3d_multi *m, Slab &s, const std::vector<int64_t> &upl)
     // is inert and stays exactly zero in every vector.  Two planes of U that hold no conductor cell therefore need not
     // travel: the ghost rows they would fill are zero already (most cuts of a real model lie in air: BASELINE config 5 on
     // 8 ranks has the conductor at ONE of its seven cuts).  Both sides of a cut decide from the same planes' cell counts.
-    const bool u_always = getenv("EC3D_AV_SEND_EMPTY_U") && atoi(getenv("EC3D_AV_SEND_EMPTY_U")) != 0;
+    // OPT-IN (EC3D_AV_SEND_EMPTY_U=0) until a job of two real devices has run once: by default every U plane travels.
+    const bool u_always = !(getenv("EC3D_AV_SEND_EMPTY_U") && atoi(getenv("EC3D_AV_SEND_EMPTY_U")) == 0);
     auto u_cells = [&](int64_t a, int64_t b) { return upl[(size_t)std::min<int64_t>(b, (int64_t)upl.size() - 1)] - upl[(size_t)std::max<int64_t>(a, 0)]; };
     // (a rehearsal sends to itself: what it sends towards a cut must pair with what it receives from there, so a side's U
     // planes travel when EITHER of the two pairs of planes around the cut holds a conductor cell)

@@ -20,12 +20,15 @@ struct ec3d_rccl_api {
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
     const char *(*GetErrorString)(ncclResult_t);
+    // optional (diagnostics: ec3d_multi_rccl_info): may be null
+    ncclResult_t (*CommCount)(const ncclComm_t, int *);
+    ncclResult_t (*GetVersion)(int *);
+    char path[512]; // file the entry points were resolved from (dladdr)
 };
 
 // the table, or nullptr with the reason in `why` (library not found / symbol missing).  The process's already loaded
 // librccl.so.1 is taken when there is one (under Python that is the copy PyTorch ships beside its own HIP runtime, which
 // this library shares then), else the system's (/opt/rocm/lib).
+// EC3D_RCCL_LIB=<path> names the library to take them from instead (announced on stderr; tests: the loopback transport of
+// tests/support/rccl_loopback.cpp, which is NOT part of this library).
 const ec3d_rccl_api *ec3d_rccl_load(std::string &why);
-// the same table served by threads of ONE process copying between their buffers (EC3D_RCCL_LOOPBACK=1; a test double for
-// the transport: ec3d_rccl_loopback.cpp says what it keeps of the real calls' semantics)
-const ec3d_rccl_api *ec3d_rccl_loopback();

@@ -207,14 +207,12 @@ def domain_tables(model: VxcModel):
     cells = vox.size
     nsub = int(vox.max())
     v = vox.reshape(-1).astype(np.int32).copy()
-    j, k = 0, 1
-    for idx in np.flatnonzero(v == 0):           # :316-333
-        j += 1
-        if j == 500000:
-            j = 0
-            k += 1
-        v[idx] = nsub + k
-    if j == 0:
+    # :316-333 -- the air cells in scan order, a new domain id every 500 000 cells: the p-th air cell (1-based) gets
+    # nsub + 1 + p // 500000 (the counter is reset and the id advanced BEFORE the cell that completes a block is set)
+    air = np.flatnonzero(v == 0)
+    v[air] = nsub + 1 + np.arange(1, air.size + 1, dtype=np.int64) // 500000
+    k = 1 + air.size // 500000
+    if air.size % 500000 == 0:
         k -= 1
     nsub_glob = nsub + k
     if nsub_glob > 127:

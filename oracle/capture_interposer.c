@@ -17,6 +17,10 @@
  * same x_in with itmax = k-1, k = 1..K -- it then returns after exactly k iterations (src/solvers.f90:25-29) --
  * and $EC3D_CAPTURE_DIR/prefix_%02d.bin receives double ||b - A x_k||_2, double ||b||_2, then x_k[n]: the first
  * K iterates of the unmodified reference on the full-size system.
+ * EC3D_CAPTURE_REAL_ITMAX=M: the forwarded call runs with itmax = M instead of the input's (a cap on the hours a
+ * full-size system may take on one core; iter_out = M+1 says the cap was reached, src/solvers.f90:25-29).  The
+ * header's itmax stays the caller's.  After the forwarded call the true residual ||b - A x_out|| / ||b|| goes to
+ * stderr ("[capture] call N true residual ...") when EC3D_CAPTURE_TRUE_RESIDUAL is set.
  */
 #define _POSIX_C_SOURCE 199309L
 #include <math.h>
@@ -69,11 +73,23 @@ void sprsbcgstabwr_(double *valA, int32_t *irow, int32_t *jcol, int32_t *n, doub
     }
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
-    ref_sprsbcgstabwr_(valA, irow, jcol, n, b, x, tol, itmax, iter);
+    const char *cap = getenv("EC3D_CAPTURE_REAL_ITMAX");
+    int32_t itmax_used = cap ? atoi(cap) : *itmax;
+    ref_sprsbcgstabwr_(valA, irow, jcol, n, b, x, tol, &itmax_used, iter);
     clock_gettime(CLOCK_MONOTONIC, &t1);
     double sec = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
     fprintf(stderr, "[capture] call %d n=%lld nnz=%lld iter=%d t=%.4fs\n", ncall, (long long)nn,
             (long long)nnz, *iter, sec);
+    if (getenv("EC3D_CAPTURE_TRUE_RESIDUAL")) {
+        double rr = 0.0, bb = 0.0;
+        for (int64_t r = 0; r < nn; ++r) {
+            double s = 0.0;
+            for (int64_t p = irow[r] - 1; p < irow[r + 1] - 1; ++p) s += valA[p] * x[jcol[p] - 1];
+            rr += (b[r] - s) * (b[r] - s);
+            bb += b[r] * b[r];
+        }
+        fprintf(stderr, "[capture] call %d true residual %.17e\n", ncall, sqrt(rr) / sqrt(bb));
+    }
     if (dir) {
         char path[4096];
         snprintf(path, sizeof path, "%s/call_%04d.bin", dir, ncall);

@@ -70,7 +70,7 @@ def read_shipped_vxc(path):
 
 
 def run_reference(vox, names, lattice_dim, adj=(1, 1, 1), max_calls=3, all_matrices=False, exe=None,
-                  extra_env=None, before_cleanup=None):
+                  extra_env=None, before_cleanup=None, log_file=None):
     """Run EC3D_capture (or another build of the same program, e.g. _ref/EC3D_dropin) on the given
     case; returns the list of captured calls (dicts)."""
     td = tempfile.mkdtemp(prefix="ec3d_gold_")
@@ -86,9 +86,14 @@ def run_reference(vox, names, lattice_dim, adj=(1, 1, 1), max_calls=3, all_matri
         if all_matrices:
             env["EC3D_CAPTURE_ALL_MATRICES"] = "1"
         env.update(extra_env or {})
-        p = subprocess.run([exe or EXE], cwd=td, env=env, preexec_fn=O._unlimit_stack,
-                           stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-        log = p.stdout.decode(errors="replace") + p.stderr.decode(errors="replace")
+        if log_file:      # hours-long runs: the program's output goes to a file one can watch
+            with open(log_file, "wb") as lf:
+                subprocess.run([exe or EXE], cwd=td, env=env, preexec_fn=O._unlimit_stack, stdout=lf, stderr=lf)
+            log = open(log_file, "rb").read().decode(errors="replace")
+        else:
+            p = subprocess.run([exe or EXE], cwd=td, env=env, preexec_fn=O._unlimit_stack,
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            log = p.stdout.decode(errors="replace") + p.stderr.decode(errors="replace")
         calls = []
         for fn in sorted(os.listdir(cap)):
             if not fn.startswith("call_"):
@@ -475,6 +480,70 @@ def case_g6x(which=("ec_src_move_hole", "LIM"), K=16):
         save("g6x_" + stem + "_%dx%dx%d" % dims[stem], **d)
 
 
+def case_g7x(stem="ec_src_move_hole", dims=(256, 256, 256), K=8, cap=3000, fast=False):
+    """G7X: BASELINE config 3 at the size BASELINE.json writes -- ec_src_move_hole resampled (vxc.resample, physical
+    size kept) to 256x256x256, n = 3*256^3 + the conductor's U unknowns -- through the UNMODIFIED reference: assembly
+    (src/EC3D.f90:465-1049: nnz and the row-length histogram from the captured irow), the first solver call's b, the
+    first K iterates (the solver run with itmax = k-1, src/solvers.f90:25-29: x_k and ||b - A x_k||), and the
+    first time step's solve, capped at `cap` iterations (EC3D_CAPTURE_REAL_ITMAX; iter_ref = cap+1 says it was
+    reached) with its true residual.  Vectors are 400 MB: norms, 200 probes and count-sketches are kept.
+    `fast`: the same with only src/solvers.f90 built -O3 -ffast-math (the reference against itself) added to an
+    existing fixture as iter_fast / self_distance."""
+    from eddy_currents_3d_amd import vxc
+    g = np.load(os.path.join(GOLD, f"g4_{stem}.npz"))
+    model = vxc.VxcModel(g["vox"], [str(s) for s in g["names"]], float(str(g["lattice_dim"])),
+                         tuple(float(x) for x in g["adj"]))
+    big = vxc.resample(model, *dims)
+    args = (big.vox, big.names, repr(big.lattice_dim), tuple(repr(a) for a in big.adj))
+    name = "g7x_" + stem + "_%dx%dx%d" % tuple(dims)
+    env = {"EC3D_CAPTURE_NO_MATRIX": "1", "EC3D_CAPTURE_REAL_ITMAX": str(cap), "EC3D_CAPTURE_TRUE_RESIDUAL": "1"}
+    if fast:
+        gx = dict(np.load(os.path.join(GOLD, name + ".npz")))
+        calls, log = run_reference(*args, max_calls=1, extra_env=env, log_file=f"/tmp/{name}_fast.log",
+                                   exe=os.path.join(HERE, "_ref", "EC3D_capture_fast"))
+        x_fast = calls[0]["x_out"]
+        gx["iter_fast"] = np.int32(calls[0]["iter"])
+        gx["xnorm_fast"] = np.float64(np.linalg.norm(x_fast))
+        gx["xsketch_fast"] = O.count_sketch(x_fast)
+        gx["self_distance"] = np.float64(np.linalg.norm(gx["xsketch_fast"] - gx["xsketch_ref"]) /
+                                         np.linalg.norm(gx["xsketch_ref"]))
+        gx["true_residual_fast"] = np.float64(re.search(r"call 0 true residual\s+(\S+)", log).group(1))
+        print(name, "fast-math build: iter", int(gx["iter_fast"]), "self distance", float(gx["self_distance"]))
+        save(name, **gx)
+        return
+    keep = {}
+
+    def grab(td):
+        for k in range(1, K + 1):
+            with open(os.path.join(td, "cap", f"prefix_{k:02d}.bin"), "rb") as f:
+                hd = np.fromfile(f, np.float64, 2)
+                xk = np.fromfile(f, np.float64)
+            keep[k] = (hd, float(np.linalg.norm(xk)), O.count_sketch(xk, 1024))
+
+    env["EC3D_CAPTURE_PREFIX_ITERS"] = str(K)
+    calls, log = run_reference(*args, max_calls=1, extra_env=env, before_cleanup=grab, log_file=f"/tmp/{name}.log")
+    c = calls[0]
+    n = c["n"]
+    rng = np.random.Generator(np.random.PCG64(2026))
+    probes = np.sort(rng.choice(n, 200, replace=False)).astype(np.int64)
+    d = dict(dims=np.array(dims, np.int32), adj=np.array(big.adj), delta=big.delta, n=np.int64(n),
+             nnz=np.int64(c["irow"][-1] - 1), rowlen_hist=np.bincount(np.diff(c["irow"]), minlength=14),
+             tol=np.float64(c["tol"]), itmax=np.int32(c["itmax"]), K=np.int32(K), cap=np.int32(cap),
+             bnorm=np.float64(keep[1][0][1]), bprobe=c["b"][probes], probes=probes,
+             bsketch=O.count_sketch(c["b"]),
+             prefix_rnorm=np.array([keep[k][0][0] for k in range(1, K + 1)]),
+             prefix_xnorm=np.array([keep[k][1] for k in range(1, K + 1)]),
+             prefix_xsketch=np.stack([keep[k][2] for k in range(1, K + 1)]),
+             iter_ref=np.int32(c["iter"]), seconds=np.float64(c["seconds"]),
+             xnorm_ref=np.float64(np.linalg.norm(c["x_out"])), xprobe=c["x_out"][probes],
+             xsketch_ref=O.count_sketch(c["x_out"]),
+             true_residual=np.float64(re.search(r"call 0 true residual\s+(\S+)", log).group(1)))
+    print(name, "n", n, "nnz", int(d["nnz"]), "rows by length", d["rowlen_hist"], "iter", int(d["iter_ref"]),
+          "seconds", float(d["seconds"]), "true residual", float(d["true_residual"]),
+          "prefix residuals", d["prefix_rnorm"] / d["bnorm"], flush=True)
+    save(name, **d)
+
+
 def case_g6f(which=("ec_src_move_hole", "LIM"), steps=4):
     """G6F: the reference against itself over the first `steps` TIME STEPS of the full-size runs of case_g6: the
     same program with only src/solvers.f90 built -O3 -ffast-math.  From step 1 on the two runs start from states
@@ -652,6 +721,9 @@ if __name__ == "__main__":
     if "g6" in which: case_g6()
     if "g6fhole" in which: case_g6f(("ec_src_move_hole",))
     if "g6flim" in which: case_g6f(("LIM",))
+    if "g7x" in which: case_g7x()
+    if "g7xfast" in which: case_g7x(fast=True)
+    if "g7xdry" in which: case_g7x(dims=(64, 64, 64), K=4, cap=50)      # (dry run of the recipe on a small grid)
     if "g6xhole" in which: case_g6x(("ec_src_move_hole",))
     if "g6xlim" in which: case_g6x(("LIM",))
     if "g6hole" in which: case_g6(("ec_src_move_hole",))

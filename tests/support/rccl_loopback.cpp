@@ -1,5 +1,7 @@
-// ec3d_rccl_loopback.cpp — a LOOPBACK implementation of the nine RCCL entry points the rank driver uses (ec3d_rccl.hpp), for
-// tests: EC3D_RCCL_LOOPBACK=1 makes ec3d_rccl_load() return this table instead of librccl's.
+// rccl_loopback.cpp — a LOOPBACK implementation of the RCCL entry points the rank driver uses (csrc/ec3d_rccl.hpp), for
+// tests.  TEST INFRASTRUCTURE: built into tests/libec3d_loopback.so (eddy_currents_3d_amd/build.py build_test_support), NOT
+// part of libec3d_hip.so.  It exports the entry points under their RCCL names (ncclSend, ncclRecv, ...), so it stands where
+// a librccl stands: the product loads it only when EC3D_RCCL_LIB names its path (csrc/ec3d_rccl.cpp announces that on stderr).
 //
 // Why it exists.  RCCL (like NCCL) refuses two ranks on one device ("invalid usage": tools/rccl_two_ranks_one_gpu_probe.py),
 // so on a one-GPU box the one-process-per-GPU driver of csrc/ec3d_multi.hip can only run as a job of ONE rank or as the
@@ -15,7 +17,7 @@
 //   * ncclCommInitRank returns when all ranks of the id have called it.
 // Data moves by hipMemcpyAsync between the ranks' buffers (all on devices of this process); nothing touches the host.
 // It is a test double for the TRANSPORT only: plans, stages, kernels and reductions are the product's.
-#include "ec3d_rccl.hpp"
+#include <rccl/rccl.h>
 
 #include <hip/hip_runtime.h>
 
@@ -288,10 +290,53 @@ const char *lb_GetErrorString(ncclResult_t r)
 }
 } // namespace
 
-const ec3d_rccl_api *ec3d_rccl_loopback()
+// the entry points under their RCCL names (signatures as <rccl/rccl.h> declares them)
+extern "C" {
+ncclResult_t ncclGetUniqueId(ncclUniqueId *id) { return lb_GetUniqueId(id); }
+ncclResult_t ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId id, int rank) { return lb_CommInitRank(comm, nranks, id, rank); }
+ncclResult_t ncclCommDestroy(ncclComm_t c) { return lb_CommDestroy(c); }
+ncclResult_t ncclGroupStart() { return lb_GroupStart(); }
+ncclResult_t ncclGroupEnd() { return lb_GroupEnd(); }
+ncclResult_t ncclSend(const void *buf, size_t count, ncclDataType_t t, int peer, ncclComm_t c, hipStream_t s)
 {
-    static const ec3d_rccl_api api = {lb_GetUniqueId, lb_CommInitRank, lb_CommDestroy, lb_GroupStart, lb_GroupEnd,
-                                      lb_Send,        lb_Recv,         lb_AllGather,   lb_GetErrorString};
+    return lb_Send(buf, count, t, peer, c, s);
+}
+ncclResult_t ncclRecv(void *buf, size_t count, ncclDataType_t t, int peer, ncclComm_t c, hipStream_t s)
+{
+    return lb_Recv(buf, count, t, peer, c, s);
+}
+ncclResult_t ncclAllGather(const void *send, void *recv, size_t count, ncclDataType_t t, ncclComm_t c, hipStream_t s)
+{
+    return lb_AllGather(send, recv, count, t, c, s);
+}
+const char *ncclGetErrorString(ncclResult_t r) { return lb_GetErrorString(r); }
+ncclResult_t ncclCommCount(const ncclComm_t c, int *count)
+{
+    *count = reinterpret_cast<const Comm *>(c)->w->nranks;
+    return ncclSuccess;
+}
+ncclResult_t ncclGetVersion(int *version)
+{
+    *version = -1; // not an RCCL: the loopback transport
+    return ncclSuccess;
+}
+}
+
+struct lb_api {
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *);
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
+    ncclResult_t (*CommDestroy)(ncclComm_t);
+    ncclResult_t (*GroupStart)(void);
+    ncclResult_t (*GroupEnd)(void);
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
+    const char *(*GetErrorString)(ncclResult_t);
+};
+static const lb_api *ec3d_rccl_loopback()
+{
+    static const lb_api api = {lb_GetUniqueId, lb_CommInitRank, lb_CommDestroy, lb_GroupStart, lb_GroupEnd,
+                               lb_Send,        lb_Recv,         lb_AllGather,   lb_GetErrorString};
     return &api;
 }
 
@@ -301,7 +346,7 @@ const ec3d_rccl_api *ec3d_rccl_loopback()
 // an error.  0 = all as expected; the first failing check otherwise.
 extern "C" int ec3d_rccl_loopback_selftest()
 {
-    const ec3d_rccl_api *api = ec3d_rccl_loopback();
+    const lb_api *api = ec3d_rccl_loopback();
     ncclUniqueId id, id2;
     api->GetUniqueId(&id);
     api->GetUniqueId(&id2);

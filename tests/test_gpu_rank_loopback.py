@@ -4,20 +4,24 @@ RCCL refuses two ranks on one device (tools/rccl_two_ranks_one_gpu_probe.py), so
 driver only as a one-rank job or as the rehearsal of one rank.  What several ranks add -- which planes go to which
 neighbour and in which order the sends and receives of a group pair up, where rank r's eight sums land in the gathered
 table, the facts the ranks agree on at set-up (one plan, one X interval, one ring depth for the whole job), every rank
-leaving the loop at the same iteration -- is covered here through the LOOPBACK transport (EC3D_RCCL_LOOPBACK=1,
-csrc/ec3d_rccl_loopback.cpp): the nine RCCL entry points served by threads of this process that copy between the ranks'
+leaving the loop at the same iteration -- is covered here through the LOOPBACK transport (tests/support/rccl_loopback.cpp,
+built into tests/libec3d_loopback.so -- NOT part of the product library -- and named in EC3D_RCCL_LIB, where a librccl
+would be named): the RCCL entry points served by threads of this process that copy between the ranks'
 buffers with the ordering the real calls give.  Every rank is a thread with its own handle, created exactly as a process
 of the launcher's job creates it; everything above the transport is the product's code.
 
 The bar: x (each rank returns its own planes), the iteration count, the plan, the true residual and A*x of the rank job
 equal those of the ONE-process handle on the same slabs bit for bit -- and that handle is pinned against the oracle's
 multi-rank twin in tests/test_gpu_slab_plans.py and against the reference's captures in tests/test_gpu_multi.py."""
+import os
 import threading
 
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+LOOPBACK = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libec3d_loopback.so")
 
 KNOBS = ("EC3D_SLAB_FSPLIT", "EC3D_SLAB_PLAN", "EC3D_NT", "EC3D_FUSE23", "EC3D_FUSE51", "EC3D_XDEFER", "EC3D_K4S", "EC3D_SLAB_FUSE",
          "EC3D_SLAB_XDEFER", "EC3D_XASYNC", "EC3D_XASYNC_WGS")
@@ -35,7 +39,10 @@ def set_knobs(monkeypatch, **kw):
         monkeypatch.delenv(k, raising=False)
     for k, v in kw.items():
         monkeypatch.setenv("EC3D_" + k, str(v))
-    monkeypatch.setenv("EC3D_RCCL_LOOPBACK", "1")
+    if not os.path.exists(LOOPBACK):
+        from eddy_currents_3d_amd import build
+        build.build_test_support()
+    monkeypatch.setenv("EC3D_RCCL_LIB", LOOPBACK)
 
 
 def run_ranks(E, world, body, **fmt):
@@ -75,15 +82,16 @@ FUSED = dict(FUSE23=2, FUSE51=2, K4S=2)
 CASES = [
     ("five-launches", (20, 12, 31), dict(), 0),
     ("interior+boundary", (128, 8, 48), dict(SLAB_PLAN=1), 1),
-    ("both-split by default", (128, 8, 48), dict(), 5),
+    ("interior+boundary by default", (128, 8, 48), dict(), 1),      # (plan 5 is opt-in until two real devices have verified it)
+    ("both-split", (128, 8, 48), dict(SLAB_PLAN=5), 5),
     ("three-launches,X/4", (128, 8, 48), dict(FUSED, XDEFER=4, SLAB_FSPLIT=0), 3),
     ("three-launches-split,X/4", (128, 8, 48), dict(FUSED, XDEFER=4), 4),
     ("three-launches-split,X/3", (128, 8, 48), dict(FUSED, XDEFER=3), 4),
-    ("both-split,X/4", (128, 8, 48), dict(XDEFER=4), 5),
+    ("both-split,X/4", (128, 8, 48), dict(XDEFER=4, SLAB_PLAN=5), 5),
     ("producers-split,X/4", (128, 8, 48), dict(XDEFER=4, SLAB_PLAN=2), 2),
     # the groups of X updates as launches of their own on a second stream (rings of two groups: the exchanged P and S live there)
     ("interior+boundary,X/4 beside the iteration", (128, 8, 48), dict(XDEFER=4, XASYNC=1, XASYNC_WGS=8, SLAB_PLAN=1), 1),
-    ("both-split,X/4 beside the iteration", (128, 8, 48), dict(XDEFER=4, XASYNC=1, XASYNC_WGS=8), 5),
+    ("both-split,X/4 beside the iteration", (128, 8, 48), dict(XDEFER=4, XASYNC=1, XASYNC_WGS=8, SLAB_PLAN=5), 5),
     ("three-launches-split,X/4 beside the iteration", (128, 8, 48), dict(FUSED, XDEFER=4, XASYNC=2, XASYNC_WGS=8), 4),
 ]
 
@@ -164,8 +172,8 @@ def test_av_rank_job_reproduces_the_reference_capture(E, monkeypatch, world, pit
     neighbour, the U block two planes deep.  Two time steps of the reference's capture: its iteration counts, and the
     one-process handle's x bit for bit."""
     from conftest import load_golden
-    set_knobs(monkeypatch)
-    if pitched:     # tile-aligned planes: the slabs can split K1 / K3 too and the job takes plan 5 (the exchange behind two launches)
+    set_knobs(monkeypatch, **(dict(SLAB_PLAN=5) if pitched else {}))
+    if pitched:     # tile-aligned planes: the slabs can split K1 / K3 too: plan 5 (the exchange behind two launches; asked for)
         monkeypatch.setenv("EC3D_PITCH", "2")
     else:
         monkeypatch.delenv("EC3D_PITCH", raising=False)
@@ -193,16 +201,27 @@ def test_av_rank_job_reproduces_the_reference_capture(E, monkeypatch, world, pit
 
 
 def test_the_transport_itself(E, monkeypatch):
-    """ec3d_rccl_loopback_selftest (csrc/ec3d_rccl_loopback.cpp): two ranks exchange and gather known values in the order
+    """ec3d_rccl_loopback_selftest (tests/support/rccl_loopback.cpp): two ranks exchange and gather known values in the order
     of the driver's calls (values checked on the device side of each rank), and a receive that meets a send of another
     length is an error on the spot (real RCCL would hang or write past the buffer) -- so a wrong halo piece in the driver
     cannot pass the tests above silently."""
     import ctypes as C
     set_knobs(monkeypatch)
-    L = E.load_library()
-    L.ec3d_rccl_loopback_selftest.restype = C.c_int
-    rc = L.ec3d_rccl_loopback_selftest()
-    assert rc == 0, (rc, L.ec3d_last_error().decode())
+    E.load_library()                       # (one HIP runtime in the process: the product library's)
+    T = C.CDLL(LOOPBACK, mode=C.RTLD_LOCAL)
+    T.ec3d_rccl_loopback_selftest.restype = C.c_int
+    assert T.ec3d_rccl_loopback_selftest() == 0
+
+
+def test_the_product_library_holds_no_transport_double(E):
+    """The loopback transport is test infrastructure: libec3d_hip.so neither contains it nor looks for a switch of its
+    own -- a stand-in has to be NAMED (EC3D_RCCL_LIB=<path>), and naming one is announced on stderr."""
+    import subprocess
+    from eddy_currents_3d_amd import build
+    syms = subprocess.run(["nm", "-D", "--defined-only", build.LIB], capture_output=True, text=True, check=True).stdout
+    assert "loopback" not in syms.lower()
+    blob = open(build.LIB, "rb").read()
+    assert b"EC3D_RCCL_LOOPBACK" not in blob and b"EC3D_RCCL_LIB" in blob
 
 
 @pytest.mark.parametrize("name, moving, world", [("g2_conducting_hole_16x15x14", False, 2), ("g3_moving_coil_18x16x12", True, 3)])
@@ -295,7 +314,8 @@ def test_av_rank_job_with_uneven_u_exchange(E, monkeypatch):
     equal the one-process handle's bit for bit, on plan 5 (K1 / K3 split as well)."""
     from conftest import load_golden
     from eddy_currents_3d_amd import vxc
-    set_knobs(monkeypatch)
+    set_knobs(monkeypatch, SLAB_PLAN=5)
+    monkeypatch.setenv("EC3D_AV_SEND_EMPTY_U", "0")      # (both opt-in until two real devices have verified them)
     monkeypatch.delenv("EC3D_PITCH", raising=False)
     world = 5
     g = load_golden("g4_LIM")

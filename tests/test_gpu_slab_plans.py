@@ -102,7 +102,7 @@ def test_restart_rule_on_slabs(E, oracle, monkeypatch, fused):
     fires; counted on every slab's device and in the twin."""
     sdx, sdy, sdz = 256, 8, 31
     n, kdz = sdx * sdy * sdz, sdx * sdy
-    set_knobs(monkeypatch, XDEFER=4, **(FUSED if fused else {}))
+    set_knobs(monkeypatch, XDEFER=4, **(FUSED if fused else dict(SLAB_PLAN=5)))
     valA, irow, jcol = oracle.poisson_csr(sdx, sdy, sdz)
     rng = np.random.Generator(np.random.PCG64(2026))
     x0 = np.zeros(n)
@@ -112,7 +112,7 @@ def test_restart_rule_on_slabs(E, oracle, monkeypatch, fused):
     with E.EC3DMulti(3, devices=[0, 0, 0]) as m:
         m.assemble_poisson(sdx, sdy, sdz)
         plan = m.plan()[0]
-        assert plan == (4 if fused else 5)     # (five launches: small slabs that split both ways take plan 5)
+        assert plan == (4 if fused else 5)     # (five launches: plan 5 -- both splits -- asked for; opt-in since round 6)
         x, it = m.solve(b, x0, tol, 5000)
         rs = restarts_of(m)
         xo, ito, _, _, rso = oracle.twin_solve_slabs(slabs_of(m, kdz), plan, valA, irow, jcol, b, x0, tol, 5000)
@@ -153,7 +153,7 @@ def test_itmax_exit_at_every_position_of_a_group(E, oracle, monkeypatch, fused):
     iteration of the call applies whatever is pending.  k = 1 .. 9 iterations: every position of a group of four."""
     sdx, sdy, sdz = 128, 8, 32
     n, kdz = sdx * sdy * sdz, sdx * sdy
-    set_knobs(monkeypatch, XDEFER=4, **(FUSED if fused else {}))
+    set_knobs(monkeypatch, XDEFER=4, **(FUSED if fused else dict(SLAB_PLAN=5)))
     valA, irow, jcol = oracle.poisson_csr(sdx, sdy, sdz)
     rng = np.random.Generator(np.random.PCG64(9))
     b = rng.standard_normal(n)
@@ -161,7 +161,7 @@ def test_itmax_exit_at_every_position_of_a_group(E, oracle, monkeypatch, fused):
     with E.EC3DMulti(2, devices=[0, 0]) as m:
         m.assemble_poisson(sdx, sdy, sdz)
         plan = m.plan()[0]
-        assert plan == (4 if fused else 5)     # (five launches: small slabs that split both ways take plan 5)
+        assert plan == (4 if fused else 5)     # (five launches: plan 5 -- both splits -- asked for; opt-in since round 6)
         for k in range(1, 10):
             x, it = m.solve(b, x0, 1e-30, k - 1)
             xo, ito, _, _, _ = oracle.twin_solve_slabs(slabs_of(m, kdz), plan, valA, irow, jcol, b, x0, 1e-30, k - 1)
@@ -236,7 +236,7 @@ def test_x_groups_on_a_second_stream_bitwise(E, oracle, monkeypatch, fused):
     with the ||S|| exit inside a group (the group's launch, or the flush the host adds when it had not enqueued it yet,
     ends at the exit with the half update).  The second launch runs on 8 workgroups here, so its stride differs from
     the vector kernels' grid."""
-    set_knobs(monkeypatch, XDEFER=4, XASYNC=2, XASYNC_WGS=8, **(FUSED if fused else {}))
+    set_knobs(monkeypatch, XDEFER=4, XASYNC=2, XASYNC_WGS=8, **(FUSED if fused else dict(SLAB_PLAN=5)))
     # -- restarts, a full solve, three slabs
     sdx, sdy, sdz = 256, 8, 31
     n, kdz = sdx * sdy * sdz, sdx * sdy
@@ -248,7 +248,7 @@ def test_x_groups_on_a_second_stream_bitwise(E, oracle, monkeypatch, fused):
     with E.EC3DMulti(3, devices=[0, 0, 0]) as m:
         m.assemble_poisson(sdx, sdy, sdz)
         plan = m.plan()[0]
-        assert plan == (4 if fused else 5)     # (five launches: small slabs that split both ways take plan 5)
+        assert plan == (4 if fused else 5)     # (five launches: plan 5 -- both splits -- asked for; opt-in since round 6)
         x, it = m.solve(b, x0, 1e-9, 5000)
         rs = restarts_of(m)
         on = [m.slab(r)[0].x_groups() for r in range(3)]
