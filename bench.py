@@ -9,16 +9,32 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W     -> one JSO
     targets are quoted on; it fits one GPU (16 GB), so every N runs the SAME grid: scaling "strong".
     RHS = the deterministic bar source of SURVEY §8c, x0 = 0; operator, b and x are resident in HBM
     before the timed region starts (assembly is on the device, nothing crosses PCIe in the loop);
-  * N > 1, two ways to the same z-slab decomposition (rank g owns planes [g*N/G, (g+1)*N/G)):
-      - plain `python bench.py --gpus N`: ONE process, N devices, inside the library (include/ec3d_hip.h
-        section 2c, csrc/ec3d_multi.hip): one host thread per slab, halo planes pulled over peer access
-        (xGMI) behind the interior planes, partial sums read in place, rank-ordered.  Exits with
-        "needs N devices" before touching a GPU when the machine has fewer; before anything is timed, A*x over the
-        N devices is checked bit for bit against one device and the reductions through the true residual
-        (`verified` in the line; a broken transport ends the run without a number);
-      - under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` (the driver's form):
-        one process per GPU, torch.distributed (backend nccl = RCCL), halo planes by send/recv and the dot
-        products by all_gather (eddy_currents_3d_amd/dist.py);
+  * N > 1, two transports behind the same z-slab decomposition (rank g owns planes [g*N/G, (g+1)*N/G)) and ONE invocation
+    that runs both:
+      - RCCL, one process per GPU (the headline): every rank drives its slab's iteration loop from C++
+        (ec3d_multi_create_rank, csrc/ec3d_multi.hip) -- halo planes as ncclSend / ncclRecv pairs on a side stream, the
+        eight sums of every rank by ncclAllGather, torch.distributed only hands round the two RCCL ids and the barriers;
+      - in-library (sub-record `in_library`): ONE process, N devices behind one handle (include/ec3d_hip.h section 2c),
+        one host thread per slab, halo planes pulled over peer access, partial sums read in place.
+    `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` (the driver's form): the ranks ARE the RCCL job;
+    when its timed region is over and the process group is gone, rank 0 starts the in-library form as a fresh child process.
+    Plain `python bench.py --gpus N`: a parent that never initialises a GPU (it only counts devices) starts N fresh rank
+    processes, then the in-library child, and prints the one line.  No process that has touched a GPU is ever re-executed.
+    Before anything is timed each form checks itself: A*x over the N slabs against the undivided operator on one device bit
+    for bit, and ||b|| through the reduction path (`verified`).  A form that fails its check (or dies, or exceeds its time
+    limit) is reported as {"error": ...} and the other carries the line; only when both fail is the exit status non-zero.
+    The in-library form is retried once with EC3D_MULTI_SERIALIZE_WAITS=1 EC3D_MULTI_FLAT_HUB=1 before it is given up.
+    `--gpus 2 --devices 0,0` (rehearsal on one card): the in-library record, and `rccl: {"skipped": ...}` -- RCCL refuses two
+    ranks of one communicator on one device, which is known before anything is started.
+    Keys of the line beyond the driver's contract when N > 1:
+      transport        "rccl" | "in_library": which form the top-level numbers are
+      rccl             {nranks (ncclCommCount, as RCCL itself counts the communicator), version (ncclGetVersion), library (file
+                       the entry points came from), ranks: [{rank, device, planes, plan, x_update_every, ms_per_step (this
+                       rank's own clock around its K steps), stage_us {k1..k5}, reduction_points {us_per_iteration, per_iteration},
+                       halo_waits {...}, host {enqueue_ms_per_iteration, api_calls_per_iteration}}, ...]}  | {"skipped"|"error": text}
+      in_library       the in-library form's whole line (same keys; its own `verified`), or {"error": text[, "retried_with": ...]}
+      verified         text of the check the headline form passed
+      host             rank 0's enqueue cost (as before)
   * roofline: the kernel with the largest share of the iteration (measured, not assumed), its
     algorithmic bytes per row from SURVEY §8d / DESIGN.md §4, duration measured live with hipEvents on
     the library's stream inside an extra instrumented pass of the same K iterations; peak 8.0 TB/s
@@ -283,6 +299,170 @@ def side_workload(E, name, device, K=200, W=5):
             "wall_s": time.perf_counter() - t_wall}
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# N > 1: child processes.  Nothing here touches a GPU; every child is a fresh `python bench.py ...` process.
+PASS_FLAGS = ("steps", "warmup", "grid", "format", "workload", "refine", "cpu_grid", "cpu_iters")
+
+
+def child_argv(args, gpus, extra):
+    argv = [sys.executable, os.path.abspath(__file__), "--gpus", str(gpus)]
+    for k in PASS_FLAGS:
+        argv += ["--" + k.replace("_", "-"), str(getattr(args, k))]
+    if args.no_verify:
+        argv.append("--no-verify")
+    return argv + ["--no-cpu-baseline", "--no-side-workloads", "--no-spmv-dia"] + list(extra)
+
+
+def last_json_line(text):
+    for line in reversed(text.strip().splitlines()):
+        line = line.strip()
+        if line.startswith("{"):
+            try:
+                return json.loads(line)
+            except ValueError:
+                continue
+    return None
+
+
+def run_in_library_child(args, devices, timeout_s):
+    """Today's one-process form as a fresh child: its whole JSON line, or {"error": ...}; retried once with the
+    conservative synchronisation (EC3D_MULTI_SERIALIZE_WAITS=1 EC3D_MULTI_FLAT_HUB=1) before it is given up."""
+    import subprocess
+    argv = child_argv(args, len(devices), ["--role", "inlib", "--devices", ",".join(str(d) for d in devices)])
+    first_error = None
+    for attempt, extra_env in enumerate(({}, {"EC3D_MULTI_SERIALIZE_WAITS": "1", "EC3D_MULTI_FLAT_HUB": "1"})):
+        env = dict(os.environ, **extra_env)
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID"):
+            env.pop(k, None)     # (under the launcher: the child is not a rank of that job)
+        try:
+            p = subprocess.run(argv, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
+            rec = last_json_line(p.stdout.decode(errors="replace"))
+            if p.returncode == 0 and rec is not None:
+                if attempt:
+                    rec["retried_with"] = extra_env
+                    rec["first_attempt_error"] = first_error
+                return rec
+            err = (f"exit status {p.returncode}: " + p.stderr.decode(errors="replace").strip()[-600:])
+        except subprocess.TimeoutExpired:
+            err = f"no result within {timeout_s} s (killed)"
+        if first_error is None:
+            first_error = err
+    return {"error": first_error, "retried_with": {"EC3D_MULTI_SERIALIZE_WAITS": "1", "EC3D_MULTI_FLAT_HUB": "1"},
+            "retry_error": err}
+
+
+def run_rccl_ranks(args, devices, timeout_s):
+    """N fresh rank processes of the RCCL driver (what the launcher would start), rank r on device devices[r]; rank 0's
+    JSON line, or {"error": ...}.  A rank that ends with an error ends the others (their exact PIDs)."""
+    import socket
+    import subprocess
+    import tempfile
+    N = len(devices)
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    argv = child_argv(args, N, ["--role", "rank", "--no-in-library"])
+    logdir = tempfile.mkdtemp(prefix="ec3d_bench_ranks_")
+    procs = []
+    for r, d in enumerate(devices):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(N), LOCAL_RANK=str(d), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        err = open(os.path.join(logdir, f"rank{r}.err"), "wb")
+        procs.append((subprocess.Popen(argv, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=err), err))
+    t0 = time.time()
+    failed = None
+    while True:
+        codes = [p.poll() for p, _ in procs]
+        bad = [r for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = f"rank {bad[0]} ended with exit status {codes[bad[0]]}"
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.time() - t0 > timeout_s:
+            failed = f"no result within {timeout_s} s"
+            break
+        time.sleep(0.2)
+    out0 = b""
+    if failed:
+        for p, _ in procs:
+            if p.poll() is None:
+                p.kill()
+    try:
+        out0 = procs[0][0].communicate(timeout=30)[0] or b""
+    except Exception:      # noqa: BLE001 -- reporting only
+        pass
+    for p, err in procs:
+        try:
+            p.wait(timeout=30)
+        except Exception:  # noqa: BLE001
+            pass
+        err.close()
+    rec = last_json_line(out0.decode(errors="replace")) if not failed else None
+    if rec is None:
+        tails = []
+        for r in range(N):
+            try:
+                with open(os.path.join(logdir, f"rank{r}.err"), "rb") as f:
+                    t = f.read().decode(errors="replace").strip()
+                if t:
+                    tails.append(f"[rank {r}] " + t[-400:])
+            except OSError:
+                pass
+        return {"error": (failed or "rank 0 printed no line") + ("; " + " | ".join(tails) if tails else "")}
+    return rec
+
+
+def merge_forms(rccl_rec, inlib_rec):
+    """The one line of an N > 1 invocation from its two forms: RCCL carries it when it produced numbers, else the in-library
+    form; the other travels as a sub-record.  Returns (line, exit status)."""
+    rccl_ok = isinstance(rccl_rec, dict) and "value" in rccl_rec
+    inlib_ok = isinstance(inlib_rec, dict) and "value" in inlib_rec
+    if rccl_ok:
+        out = rccl_rec
+        out["transport"] = "rccl"
+        if inlib_rec is not None:
+            out["in_library"] = inlib_rec
+        return out, 0
+    if inlib_ok:
+        out = dict(inlib_rec)
+        out["transport"] = "in_library"
+        out["rccl"] = rccl_rec if rccl_rec is not None else {"skipped": "not attempted"}
+        out["in_library"] = {k: inlib_rec[k] for k in ("value", "ms_per_step", "verified", "retried_with", "first_attempt_error")
+                             if k in inlib_rec}
+        return out, 0
+    return {"metric": "DOF*iters/s (fp64 BiCGSTAB-with-restart, 7-pt A-V operator)", "value": None, "unit": "DOF*iters/s",
+            "rccl": rccl_rec, "in_library": inlib_rec, "error": "both multi-GPU forms failed"}, 1
+
+
+def parent(args):
+    """Plain `python bench.py --gpus N [--devices ...]`: start the two forms as fresh processes; never touch a GPU here."""
+    import torch
+    N = args.gpus
+    if args.devices is not None:
+        devices = [int(t) for t in args.devices.split(",")]
+        if len(devices) != N:
+            raise SystemExit(f"bench.py: --devices names {len(devices)} devices for --gpus {N}")
+    else:
+        devices = list(range(N))
+    have = torch.cuda.device_count()     # counting does not initialise the GPU
+    if max(devices) >= have:
+        raise SystemExit(f"bench.py --gpus {N} needs {max(devices) + 1} devices, this machine has {have}")
+    if len(set(devices)) < N:
+        rccl_rec = {"skipped": f"RCCL (like NCCL) refuses two ranks of one communicator on one device (devices {devices}): "
+                               f"known before anything is started, so no rank process was -- the in-library form below runs "
+                               f"the same slabs, plans and kernels with local copies in place of the transport"}
+    elif args.workload != "cube":
+        rccl_rec = {"skipped": "the one-process-per-GPU form of this script runs the cube workloads"}
+    else:
+        rccl_rec = run_rccl_ranks(args, devices, args.child_timeout)
+    inlib_rec = None if args.no_in_library else run_in_library_child(args, devices, args.child_timeout)
+    out, status = merge_forms(rccl_rec, inlib_rec)
+    sys.stdout.write(json.dumps(out) + "\n")
+    sys.stdout.flush()
+    raise SystemExit(status)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -313,9 +493,17 @@ def main():
     ap.add_argument("--devices", type=str, default=None,
                     help="in-library multi-GPU path: comma-separated device ordinals, one per slab; a device may "
                          "repeat (rehearsal of N slabs on one card, e.g. --gpus 2 --devices 0,0)")
+    ap.add_argument("--role", choices=["rank", "inlib"], default=None,
+                    help="(set by this script for its child processes) rank: one rank of the RCCL job, as the launcher starts "
+                         "it; inlib: the in-library form in this one process")
+    ap.add_argument("--no-in-library", action="store_true", help="N > 1: skip the in-library form's sub-record")
+    ap.add_argument("--child-timeout", type=int, default=420, help="N > 1: seconds a child form may take")
     args = ap.parse_args()
     if args.rehearse:
         args.force_dist = True
+    under_launcher = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if args.role is None and not under_launcher and not args.force_dist and (args.gpus > 1 or args.devices is not None):
+        parent(args)      # (does not return)
 
     # This script's stdout carries exactly one JSON line.  Native libraries write there too (RCCL prints its
     # version banner when the box exports NCCL_DEBUG=VERSION; the reference solver prints ||R|| on the itmax
@@ -330,9 +518,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    under_launcher = "WORLD_SIZE" in os.environ and "RANK" in os.environ
-    # plain `python bench.py --gpus N`: N devices inside the library, this one process (no re-exec, no spawn)
-    in_library = (not under_launcher and (args.gpus > 1 or args.devices is not None)) and not args.force_dist
+    # the in-library form: N devices behind one handle, this one process (a child of parent() / of the launcher's rank 0)
+    in_library = args.role == "inlib"
     devices = None
     if in_library:
         if args.devices is not None:
@@ -347,7 +534,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU path)")
     torch.cuda.set_device(local_rank)
-    use_dist = world > 1 or args.force_dist
+    use_dist = world > 1 or args.force_dist or args.role == "rank"
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -519,9 +706,20 @@ def main():
             flag = torch.tensor([bad, int(abs(bn - bn_host) > 1e-12 * bn_host)], dtype=torch.int64, device="cuda")
             dist.all_reduce(flag)
             if int(flag[0]) or int(flag[1]):
-                raise SystemExit(f"bench.py rank {rank}: A*x over {world} ranks differs from one GPU in {bad} rows of this "
-                                 f"slab (all ranks: {int(flag[0])}), ||b|| {bn!r} vs {bn_host!r} -- the exchange over "
-                                 f"RCCL is broken; no number reported")
+                # every rank sees the same flags: all leave together; rank 0 reports the failure and lets the in-library
+                # form carry the line (exit status 0 only if that one verifies)
+                text = (f"A*x over {world} ranks differs from one GPU in {int(flag[0])} rows (rank {rank}: {bad} of its slab), "
+                        f"||b|| from the all-gathered sums {bn!r} vs {bn_host!r} on {int(flag[1])} ranks -- the exchange over "
+                        f"RCCL is broken; nothing timed on this transport")
+                s.close()
+                dist.barrier()
+                dist.destroy_process_group()
+                if rank != 0:
+                    raise SystemExit(0)
+                inlib = None if args.no_in_library else run_in_library_child(args, list(range(world)), args.child_timeout)
+                line, status = merge_forms({"error": text}, inlib)
+                os.write(real_stdout, (json.dumps(line) + "\n").encode())
+                raise SystemExit(status)
             verified = (f"A*x over {world} ranks (halo planes over RCCL) == one GPU bit for bit on every slab; ||b|| from "
                         f"the all-gathered sums equal to {abs(bn - bn_host) / bn_host:.1e}")
             del xs, ap, y_one
@@ -544,7 +742,9 @@ def main():
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el.item())
         api_calls = s.api_calls(0)          # of the timed call (the instrumented pass below adds its events)
-        kernel_ms = s.iterate(W + K + 1, min(K, 20), per_kernel=True)
+        # instrumented pass: this rank's stages, and how long its compute stream stood at the reduction points and at the
+        # waits for halo planes (events on the compute stream around each: ec3d_multi_iterate_timed)
+        kernel_ms, sync = s.iterate_timed(W + K + 1, min(K, 20), 0)
         spmv_ms = None
         geom = {"vector": int(view.geometry(0).nblk), "spmv": int(view.geometry(1).nblk)}
         info = view.info
@@ -553,6 +753,23 @@ def main():
         x_every = multi_xd
         k4_spmv = bool(view.k4_as_spmv())
         host_enqueue_ms = t_enq * 1e3 / K
+        # what RCCL itself says about the job, and every rank's own account (all ranks, not rank 0 only)
+        rc_n, rc_v, rc_path = s.rccl_info()
+        mine = {"rank": rank, "device": local_rank, "planes": [int(k0), int(k1)], "plan": int(multi_plan),
+                "x_update_every": int(multi_xd), "ms_per_step": (t1 - t0) * 1e3 / K,
+                "stage_us": {k: v * 1e3 for k, v in kernel_ms.items()},
+                "reduction_points": {"us_per_iteration": sync["reduction_points"][0] * 1e3,
+                                     "per_iteration": sync["reduction_points"][1]},
+                "halo_waits": {"us_per_iteration": sync["halo_waits"][0] * 1e3, "per_iteration": sync["halo_waits"][1]},
+                "host": {"enqueue_ms_per_iteration": host_enqueue_ms, "api_calls_per_iteration": api_calls},
+                "rccl_nranks": int(rc_n)}
+        all_ranks = [None] * world
+        dist.all_gather_object(all_ranks, mine)
+        rccl_record = {"nranks": int(rc_n), "version": int(rc_v), "library": rc_path,
+                       "nranks_agreed": all(r["rccl_nranks"] == rc_n for r in all_ranks), "ranks": all_ranks,
+                       "note": "nranks = ncclCommCount of the communicator the sums travel on; stage_us / reduction_points / "
+                               "halo_waits from an instrumented pass after the timed region (events on each rank's compute "
+                               "stream); ms_per_step is each rank's own clock around the timed iterations"}
         if rehearse:
             # one rank of a G-rank job alone on this GPU: its rows x K iterations (NOT the job's throughput)
             n_global = int(info.n)
@@ -694,6 +911,8 @@ def main():
         if (in_library or use_dist) and verified:
             out["verified"] = verified
         if use_dist:
+            out["transport"] = "rccl"
+            out["rccl"] = rccl_record
             out["host"] = {"enqueue_ms_per_iteration": host_enqueue_ms, "api_calls_per_iteration": api_calls,
                            "note": "rank 0's host thread: time for ec3d_multi_iterate to ENQUEUE the timed iterations (launches, "
                                    "event records / waits, RCCL calls), which has to stay below ms_per_step"}
@@ -714,16 +933,21 @@ def main():
             except Exception as e:  # the baseline is reporting only; never fail the GPU number on it
                 out["cpu_baseline"] = {"value": None, "unit": "DOF*iters/s", "cores": 1, "kind": "port",
                                        "sample": f"failed: {e!r}"}
-        sys.stdout.flush()
-        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if in_library:
         s.close()
     elif use_dist:
         s.close()              # the communicators go first
         dist.barrier()
         dist.destroy_process_group()
+        # the other transport as a sub-record: a fresh child process running the in-library form on the same devices, now
+        # that this job's ranks are done with them (rank 0 only; the other ranks have nothing left to do)
+        if rank == 0 and world > 1 and not args.rehearse and not args.no_in_library:
+            out["in_library"] = run_in_library_child(args, list(range(world)), args.child_timeout)
     else:
         s.close()
+    if rank == 0:
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":

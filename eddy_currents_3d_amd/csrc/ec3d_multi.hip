@@ -518,8 +518,27 @@ int kernel_of_stage(int st)
 
 struct StageTimer {
     std::vector<hipEvent_t> ev; // pairs
-    std::vector<int> kern;
+    std::vector<int> kern;      // 0 .. 4: the stage's kernel; T_GATHER / T_HALO_WAIT: a reduction point / a wait for halo planes
+    bool sync_points = false;   // bracket the reduction points and the halo waits on the compute stream as well
 };
+enum { T_GATHER = 5, T_HALO_WAIT = 6 };
+// instrumented pass: how long the compute stream stands at a reduction point / a wait for halo planes (an event in front, one
+// behind: with nothing to wait for, the pair measures what two events cost)
+template <class F> int timed_sync(StageTimer *tm, Slab &s, int kind, F &&f)
+{
+    if (!tm || !tm->sync_points) return f();
+    hipEvent_t a, b;
+    MHIP(hipEventCreate(&a));
+    MHIP(hipEventCreate(&b));
+    MHIP(hipEventRecord(a, s.c->stream));
+    int rc = f();
+    if (rc) return rc;
+    MHIP(hipEventRecord(b, s.c->stream));
+    tm->ev.push_back(a);
+    tm->ev.push_back(b);
+    tm->kern.push_back(kind);
+    return 0;
+}
 
 int run_plan(ec3d_multi *m, Slab &s, const std::vector<Op> &plan, int it, double tol, StageTimer *tm)
 {
@@ -530,11 +549,11 @@ int run_plan(ec3d_multi *m, Slab &s, const std::vector<Op> &plan, int it, double
         switch (op.kind) {
         case OP_HALO:
             if ((rc = halo_start(m, s, op.arg, it + op.dit))) return rc;
-            if ((rc = halo_wait(s, op.arg))) return rc;
+            if ((rc = timed_sync(tm, s, T_HALO_WAIT, [&] { return halo_wait(s, op.arg); }))) return rc;
             break;
         case OP_HALO_START: if ((rc = halo_start(m, s, op.arg, it + op.dit))) return rc; break;
-        case OP_HALO_WAIT: if ((rc = halo_wait(s, op.arg))) return rc; break;
-        case OP_GATHER: if ((rc = gather(m, s))) return rc; break;
+        case OP_HALO_WAIT: if ((rc = timed_sync(tm, s, T_HALO_WAIT, [&] { return halo_wait(s, op.arg); }))) return rc; break;
+        case OP_GATHER: if ((rc = timed_sync(tm, s, T_GATHER, [&] { return gather(m, s); }))) return rc; break;
         case OP_SKIP_IF_AP: // AP = A P of this iteration came out of the last K5-in-K1: no lone K1, no sum, no exchange
             if (it != 1 && s.c->ap_valid_for == it) oi += (size_t)op.arg;
             break;
@@ -1725,7 +1744,11 @@ extern "C" int ec3d_multi_iterate_begin(ec3d_multi_handle m)
     }, true);
 }
 
-extern "C" int ec3d_multi_iterate(ec3d_multi_handle m, int32_t first_iter, int32_t count, double *kernel_ms)
+namespace {
+// kernel_ms[5]: stage averages of local slab `timed_rank`; sync_ms[2] / sync_n[2]: per iteration, the time the compute stream of
+// that slab stood at the reduction points / at the waits for halo planes, and how many of each an iteration has
+int multi_iterate(ec3d_multi *m, int32_t first_iter, int32_t count, int timed_rank, double *kernel_ms, double *sync_ms,
+                  int32_t *sync_n)
 {
     int rc = need(m, "ec3d_multi_iterate");
     if (rc) return rc;
@@ -1743,7 +1766,8 @@ extern "C" int ec3d_multi_iterate(ec3d_multi_handle m, int32_t first_iter, int32
     return run_all(m, [&](int r) -> int {
         Slab &s = *m->slab[(size_t)r];
         StageTimer tm;
-        StageTimer *tp = (kernel_ms && r == 0) ? &tm : nullptr;
+        tm.sync_points = sync_ms != nullptr;
+        StageTimer *tp = (kernel_ms && r == timed_rank) ? &tm : nullptr;
         int rc2 = 0;
         const uint64_t calls0 = t_api_calls;
         for (int it = first_iter; it < first_iter + count; ++it)
@@ -1754,15 +1778,58 @@ extern "C" int ec3d_multi_iterate(ec3d_multi_handle m, int32_t first_iter, int32
         if ((rc2 = drain(s))) return rc2;
         if (tp) {
             for (int k = 0; k < 5; ++k) kernel_ms[k] = 0.0;
+            if (sync_ms) sync_ms[0] = sync_ms[1] = 0.0;
+            if (sync_n) sync_n[0] = sync_n[1] = 0;
             for (size_t i = 0; i < tm.kern.size(); ++i) {
                 float ms = 0.f;
                 MHIP(hipEventElapsedTime(&ms, tm.ev[2 * i], tm.ev[2 * i + 1]));
-                kernel_ms[tm.kern[i]] += (double)ms / std::max(1, count);
+                const int k = tm.kern[i];
+                if (k < 5) {
+                    kernel_ms[k] += (double)ms / std::max(1, count);
+                } else if (sync_ms) {
+                    sync_ms[k - T_GATHER] += (double)ms / std::max(1, count);
+                    if (sync_n) ++sync_n[k - T_GATHER];
+                }
             }
+            if (sync_n)
+                for (int q = 0; q < 2; ++q) sync_n[q] /= std::max(1, count);
             for (hipEvent_t e : tm.ev) (void)hipEventDestroy(e);
         }
         return 0;
     }, true);
+}
+} // namespace
+
+extern "C" int ec3d_multi_iterate(ec3d_multi_handle m, int32_t first_iter, int32_t count, double *kernel_ms)
+{
+    return multi_iterate(m, first_iter, count, 0, kernel_ms, nullptr, nullptr);
+}
+
+extern "C" int ec3d_multi_iterate_timed(ec3d_multi_handle m, int32_t first_iter, int32_t count, int32_t rank, double *kernel_ms,
+                                        double *sync_ms, int32_t *sync_n)
+{
+    if (!m || rank < 0 || rank >= m->n || !kernel_ms || !sync_ms || !sync_n) return 2;
+    return multi_iterate(m, first_iter, count, rank, kernel_ms, sync_ms, sync_n);
+}
+
+// which RCCL this one-process-per-GPU handle talks through, and what IT says the job is: ranks of the communicator
+// (ncclCommCount on the communicator the sums travel on), library version (ncclGetVersion), file the entry points came from
+extern "C" int ec3d_multi_rccl_info(ec3d_multi_handle m, int32_t *nranks, int32_t *version, char *path, int32_t path_cap)
+{
+    if (!m || !m->nccl) {
+        ec3d_set_error("ec3d_multi_rccl_info: not a one-process-per-GPU handle (ec3d_multi_create_rank)");
+        return 3;
+    }
+    int n = -1, v = 0;
+    if (m->nccl->CommCount && m->comm_sum) MNCCL(m, m->nccl->CommCount(m->comm_sum, &n));
+    if (m->nccl->GetVersion) MNCCL(m, m->nccl->GetVersion(&v));
+    if (nranks) *nranks = n;
+    if (version) *version = v;
+    if (path && path_cap > 0) {
+        strncpy(path, m->nccl->path, (size_t)path_cap - 1);
+        path[path_cap - 1] = 0;
+    }
+    return 0;
 }
 
 // HIP runtime calls (launches, event records / waits, copies) rank `rank`'s thread issued per iteration in the last

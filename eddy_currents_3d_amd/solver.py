@@ -68,7 +68,7 @@ EXPORTS = ["sprsbcgstabwr_", "ec3d_invalidate", "ec3d_create", "ec3d_destroy", "
            "ec3d_multi_upload", "ec3d_multi_download", "ec3d_multi_solve", "ec3d_multi_solve_resident",
            "ec3d_multi_rhs_step", "ec3d_multi_post_update", "ec3d_multi_vtk_fields", "ec3d_multi_vtk_fields_begin",
            "ec3d_multi_vtk_fields_wait", "ec3d_multi_iterate_begin",
-           "ec3d_multi_iterate", "ec3d_multi_synchronize", "ec3d_true_residual", "ec3d_multi_true_residual", "ec3d_get_visit_order", "ec3d_probe_csr_multi", "ec3d_multi_spmv", "ec3d_multi_api_calls", "ec3d_multi_plan", "ec3d_multi_halo_rows", "ec3d_rccl_unique_id", "ec3d_multi_create_rank", "ec3d_format_real8_gfortran"]
+           "ec3d_multi_iterate", "ec3d_multi_synchronize", "ec3d_true_residual", "ec3d_multi_true_residual", "ec3d_get_visit_order", "ec3d_probe_csr_multi", "ec3d_multi_spmv", "ec3d_multi_api_calls", "ec3d_multi_plan", "ec3d_multi_halo_rows", "ec3d_rccl_unique_id", "ec3d_multi_create_rank", "ec3d_format_real8_gfortran", "ec3d_multi_iterate_timed", "ec3d_multi_rccl_info"]
 
 _f64 = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
 _i32 = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
@@ -214,6 +214,8 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.ec3d_multi_iterate.argtypes = [hp, C.c_int32, C.c_int32, hp]
     L.ec3d_multi_synchronize.argtypes = [hp]
     L.ec3d_multi_api_calls.argtypes = [hp, C.c_int32, C.POINTER(C.c_double)]
+    L.ec3d_multi_iterate_timed.argtypes = [hp, C.c_int32, C.c_int32, C.c_int32, hp, hp, hp]
+    L.ec3d_multi_rccl_info.argtypes = [hp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_char_p, C.c_int32]
     L.ec3d_multi_plan.argtypes = [hp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.ec3d_multi_halo_rows.argtypes = [hp, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.ec3d_rccl_unique_id.argtypes = [C.c_char_p]
@@ -851,6 +853,24 @@ class EC3DMulti:
         a, b = C.c_int64(0), C.c_int64(0)
         _chk(self.L, self.L.ec3d_multi_halo_rows(self.h, int(rank), C.byref(a), C.byref(b)), "ec3d_multi_halo_rows")
         return a.value, b.value
+
+    def iterate_timed(self, first_iter: int, count: int, rank: int = 0):
+        """The instrumented pass with the synchronisation points bracketed too (ec3d_multi_iterate_timed): ({stage: ms},
+        {"reduction_points": (ms per iteration, points per iteration), "halo_waits": (...)}) for local slab `rank`."""
+        ms = np.zeros(5)
+        sm = np.zeros(2)
+        sn = np.zeros(2, np.int32)
+        _chk(self.L, self.L.ec3d_multi_iterate_timed(self.h, first_iter, count, rank, ms.ctypes.data, sm.ctypes.data,
+                                                     sn.ctypes.data), "ec3d_multi_iterate_timed")
+        return ({f"k{i + 1}": float(ms[i]) for i in range(5)},
+                {"reduction_points": (float(sm[0]), int(sn[0])), "halo_waits": (float(sm[1]), int(sn[1]))})
+
+    def rccl_info(self):
+        """(ranks of the communicator as RCCL counts them, RCCL version, file of the library) of a for_rank handle."""
+        n, v = C.c_int32(0), C.c_int32(0)
+        buf = C.create_string_buffer(512)
+        _chk(self.L, self.L.ec3d_multi_rccl_info(self.h, C.byref(n), C.byref(v), buf, 512), "ec3d_multi_rccl_info")
+        return n.value, v.value, buf.value.decode()
 
     def api_calls(self, rank: int) -> float:
         """HIP runtime calls per iteration rank `rank`'s host thread issued in the last iterate()."""

@@ -306,6 +306,17 @@ int ec3d_multi_vtk_fields_wait(ec3d_multi_handle mh, int32_t slot, int32_t rank,
 int ec3d_multi_iterate_begin(ec3d_multi_handle mh);
 int ec3d_multi_iterate(ec3d_multi_handle mh, int32_t first_iter, int32_t count, double *kernel_ms);
 int ec3d_multi_synchronize(ec3d_multi_handle mh);
+/* The instrumented pass with the synchronisation points bracketed as well, for local slab `rank` (0 on a one-process-per-GPU
+ * handle): kernel_ms[5] as above; sync_ms[0] / sync_n[0]: per iteration, how long that slab's compute stream stood at its
+ * reduction points (collapse of the partial sums + all-gather / event tree; the dot products of src/solvers.f90:31-44) and how
+ * many it has; sync_ms[1] / sync_n[1]: the same for the waits for halo planes in front of the SpMV stages (src/solvers.f90:30,
+ * :39).  Events on the compute stream around each point: what the NEXT kernel waited there, not the transport's own time. */
+int ec3d_multi_iterate_timed(ec3d_multi_handle mh, int32_t first_iter, int32_t count, int32_t rank, double *kernel_ms,
+                             double *sync_ms, int32_t *sync_n);
+/* one process per GPU (ec3d_multi_create_rank): what the RCCL in use says about the job -- ranks of the communicator the sums
+ * travel on (ncclCommCount), library version (ncclGetVersion; -1: the tests' loopback stand-in), and the file the entry points
+ * were resolved from (librccl.so.1 of the process / the system, or what EC3D_RCCL_LIB names) */
+int ec3d_multi_rccl_info(ec3d_multi_handle mh, int32_t *nranks, int32_t *version, char *path, int32_t path_cap);
 /* HIP runtime calls (kernel launches, event records and waits, copies) that rank `rank`'s host thread issued per
  * iteration during the last ec3d_multi_iterate: the host-side price of one pass of src/solvers.f90:24-50 on N GPUs */
 int ec3d_multi_api_calls(ec3d_multi_handle mh, int32_t rank, double *per_iteration);
@@ -315,7 +326,7 @@ int ec3d_multi_api_calls(ec3d_multi_handle mh, int32_t rank, double *per_iterati
  * inside the next K1 -- every rank >= 32 Mi rows of the single-component operator): AP and R travel instead of P and S;
  * 4 = the same with K4 and K5-in-K1 -- the producers of R and AP -- as boundary + interior launch around the exchange;
  * 5 = 1 and 2 together: K2 / K5 boundary planes first and K1 / K3 interior planes first, the exchange behind two launches
- * (single-component slabs below 10 Mi rows per rank; A-V slabs of the structured form with tile-aligned planes).
+ * (asked for with EC3D_SLAB_PLAN=5, the same on every rank: opt-in until a job of two real devices has verified it).
  * x_every: iterations between two applications of X = X + alpha*P + omega*S (src/solvers.f90:41; 1 = every iteration). */
 int ec3d_multi_plan(ec3d_multi_handle mh, int32_t *plan, int32_t *x_every);
 /* rows (8 bytes each, per exchanged vector) local slab `rank` sends to / receives from its z-neighbours in ONE halo exchange:
