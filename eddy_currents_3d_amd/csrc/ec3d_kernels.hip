@@ -1388,6 +1388,9 @@ template <int FMT, bool NTB, class V>
 __device__ __forceinline__ void patch_pair(const MatDev<FMT> &A, const double *tbl, double *pbuf, int step, const V &x,
                                            int64_t r, bool first, ZRegs &z, double &s0, double &s1, d2 &ctr)
 {
+    // (Round 6 measured the plane above requested a step AHEAD here, as the interleaved march of the structured form does:
+    // K2-in-K3 680 -> 818 us, K5-in-K1 1227 -> 1275 us at 512^3 -- behind the barrier of the LDS exchange the four waves of a
+    // workgroup wait for the slowest one's request at the end of EVERY step; profiles/r06_patch_plane_ahead_512.log.)
     constexpr int HX = EC3D_PX / 2; // lanes per patch row
     const int t = threadIdx.x, y = t / HX, q = t % HX;
     const int64_t sdx = A.off[5], kdz = A.off[6];
