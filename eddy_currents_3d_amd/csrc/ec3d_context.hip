@@ -41,7 +41,7 @@ void ec3d_format_list_directed_gfortran(double v, char *buf)
     snprintf(t, sizeof t, "%.16e", v < 0 ? -v : v);       /* rounded to 17 significant digits: its decimal exponent */
     const int k = atoi(strchr(t, 'e') + 1) + 1;         /* digits in front of the point */
     if (k >= 0 && k <= 17) {
-        snprintf(t, sizeof t, "%.*f", 17 - k, v);
+        snprintf(t, sizeof t, "%#.*f", 17 - k, v);       /* '#': the point stays when no digit follows it (1e16 <= |x| < 1e17) */
         snprintf(buf, 40, " %20s     ", t);
     } else {
         snprintf(t, sizeof t, "%.16E", v);                /* d.ddddddddddddddddE+ee -> three exponent digits */

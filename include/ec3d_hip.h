@@ -462,7 +462,7 @@ int ec3d_device_synchronize(ec3d_handle h);
  * leading blank, shortest digits, " .5813987794206226" / " 16.27049629976871" / " 9.87654321E-03".  buf >= 40 bytes. */
 void ec3d_format_real8(double v, char *buf);
 /* List-directed output is compiler specific, and the reference's own Makefile builds with gfortran (src/Makefile:1-28),
- * which writes the same value as one blank and G25.17E3: "   0.58139877942062257     ".  EC3D_PRINT_STYLE=gfortran makes the
+ * which writes the same value as one blank and G25.17E3: "  0.58139877942062257     " (and "   12345678901234568.     ").  EC3D_PRINT_STYLE=gfortran makes the
  * library print the itmax line that way (default: flang's, above); this is the formatter.  buf >= 40 bytes. */
 void ec3d_format_real8_gfortran(double v, char *buf);
 

@@ -189,6 +189,8 @@ def test_itmax_line_in_gfortran_style():
     assert f(-16.27049629976871) == "  -16.270496299768709     "
     assert f(0.0) == "   0.0000000000000000     "
     assert f(1.0e17).strip() == "1.0000000000000000E+017"
+    assert f(12345678901234567.0) == "   12345678901234568.     "       # 17 digits in front of the point: the point stays
+    assert f(1.0e16) == "   10000000000000000.     "
     for v in (3.14159, 2.5e10, 7e-300, 123456789.125, 0.1, 0.099999999):
         s = f(v)
         assert len(s) == 26 and float(s) == v
