@@ -45,7 +45,8 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W     -> one JSO
   * cpu_baseline (rank 0, N = 1 only): the unmodified reference solver (oracle/_ref/ref_solve,
     src/solvers.f90 compiled with amdflang; "port" = our C restatement when that binary is absent)
     on one host core: 20 fixed iterations on the 256^3 cube of BASELINE config 2, its
-    wall time reported next to it (`wall_s`).
+    wall time reported next to it (`wall_s`); `cpu_baseline_all_cores`: the same sample through the CPU restatement
+    under OpenMP on every host core the process may use (thread count in `cores`) -- context, as BASELINE.md section 3 allows.
 """
 from __future__ import annotations
 
@@ -147,6 +148,38 @@ def cpu_baseline(N=256, iters=20):
             "sample": f"{N}^3 cube of the same operator/RHS (n={n}, BASELINE config 2 grid), {it} fixed iterations of "
                       f"{'src/solvers.f90 (amdflang -O2)' if kind == 'reference' else 'oracle/ec3d_oracle.c'}"
                       f" in {sec:.2f} s inside the solver call, 1 thread, host cores available: {os.cpu_count()}",
+            "solver_s": sec, "wall_s": time.perf_counter() - t_wall}
+
+
+def cpu_baseline_all_cores(N=256, iters=20):
+    """The same sample on ALL host cores this process may use: the CPU restatement under OpenMP (oracle/ec3d_oracle_omp.c --
+    the reference itself is serial, src/solvers.f90 has no parallel construct), thread count stated.  Context only
+    (BASELINE.md section 3); never the thing measured as product, never a parity checker."""
+    import numpy as np
+    from oracle import oracle as O
+    t_wall = time.perf_counter()
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(avail, 32))     # (the GPU box gives one GPU's share of the host: 16 cores)
+    valA, irow, jcol = O.poisson_csr(N, N, N)
+    b = bar_rhs(N)
+    n = N ** 3
+    old = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OMP_PROC_BIND", "OMP_WAIT_POLICY")}
+    os.environ.update(OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="close", OMP_WAIT_POLICY="passive")
+    try:
+        x, it, sec, _ = O.solve_process("port_omp", valA, irow, jcol, b, np.zeros(n), 1e-300, iters - 1, capture_stdout=True)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return {"value": n * it / sec, "unit": "DOF*iters/s", "cores": threads, "kind": "port (OpenMP)",
+            "sample": f"{N}^3 cube of the same operator/RHS (n={n}), {it} fixed iterations of oracle/ec3d_oracle_omp.c (the CPU "
+                      f"restatement of src/solvers.f90 with its loops and dot products under OpenMP; sums in another order than "
+                      f"the reference's) in {sec:.2f} s inside the solver call, {threads} threads of {avail} cores available",
             "solver_s": sec, "wall_s": time.perf_counter() - t_wall}
 
 
@@ -933,6 +966,11 @@ def main():
             except Exception as e:  # the baseline is reporting only; never fail the GPU number on it
                 out["cpu_baseline"] = {"value": None, "unit": "DOF*iters/s", "cores": 1, "kind": "port",
                                        "sample": f"failed: {e!r}"}
+            try:    # the labelled all-cores column: context, never credit
+                out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.cpu_grid, args.cpu_iters)
+            except Exception as e:
+                out["cpu_baseline_all_cores"] = {"value": None, "unit": "DOF*iters/s", "cores": 0, "kind": "port (OpenMP)",
+                                                 "sample": f"failed: {e!r}"}
     if in_library:
         s.close()
     elif use_dist:

@@ -519,12 +519,20 @@ int ec3d_assemble_poisson_device(ec3d_ctx *c, int32_t sdx, int32_t sdy, int32_t 
     const int64_t nblk = (g.nCells + 255) / 256;
     if (c->use_dict) {
         if (build_device_table(c, g, nullptr, 0) <= 0) return 100;
+        if (!A.cls) { // what the kernel stores through: checked on the host, an error code instead of a fault
+            ec3d_set_error("ec3d_assemble_poisson: no class array");
+            return 100;
+        }
         k_assemble_poisson<<<(unsigned)nblk, 256, 0, c->stream>>>(g, nullptr, A.cls);
     } else {
         const size_t bb = (size_t)7 * A.n_pad * sizeof(double);
         {
             const int rcb = ec3d_alloc_bands(c, &A.bands, bb); // the placement a probe chose for this size, if any
             if (rcb) return rcb;
+        }
+        if (!A.bands) { // (ec3d_alloc_bands checks too: a NULL stream base would be a store at row * 8 from address zero)
+            ec3d_set_error("ec3d_assemble_poisson: no band streams");
+            return 100;
         }
         EC3D_HIP(hipMemsetAsync(A.bands, 0, bb, c->stream));
         A.bytes = (int64_t)bb;

@@ -920,6 +920,10 @@ int ec3d_alloc_bands(ec3d_ctx *c, double **bands, size_t bytes)
     c->placed_bands = nullptr;
     c->bands_placed = false;
     EC3D_HIP(hipMalloc(bands, bytes));
+    if (!*bands && bytes) { // (never seen; the r03j aborts were stores at row * 8 from a NULL stream base)
+        ec3d_set_error("ec3d_alloc_bands: the allocation of the band streams returned no memory");
+        return 100;
+    }
     return 0;
 }
 

@@ -288,6 +288,7 @@ extern "C" int ec3d_dist_step(ec3d_handle c, int32_t stage, int32_t it, double t
     default: ec3d_set_error("ec3d_dist_step: unknown stage"); return 2;
     }
     EC3D_HIP(hipGetLastError());
+    EC3D_ASYNC_CHECK(c);
     return 0;
 }
 

@@ -324,6 +324,10 @@ struct ec3d_ctx {
     bool slab_xasync = false; // a z-slab: the job's driver said so (every rank the same ring depth)
     hipStream_t xstream = nullptr;
     hipEvent_t ev_xready = nullptr, ev_xdone[2] = {nullptr, nullptr};
+    // first failed runtime call of a launcher that cannot return a status (ec3d_launch_x_group_of sits inside the void stage
+    // launchers): noted there, turned into an error code by whoever checks the stage's launches (EC3D_ASYNC_CHECK)
+    hipError_t async_err = hipSuccess;
+    const char *async_what = nullptr;
     int ss_parts = 0;      // z-slab: workgroup partials of S.S that K2 left for K3's collapse launch to fold (0: none pending)
     int xg_n = 0;          // groups launched since the last ec3d_launch_begin
     int xg_done_upto = 0;  // the last iteration whose X update an enqueued k_x_group covers
@@ -433,6 +437,24 @@ extern thread_local double *ec3d_itmax_print_hold;
         hipError_t e_ = (call);                                                                \
         if (e_ != hipSuccess) {                                                                \
             ec3d_set_error(std::string(#call) + ": " + hipGetErrorString(e_));                 \
+            return 100;                                                                        \
+        }                                                                                      \
+    } while (0)
+// a runtime call inside a launcher without a status of its own: the first failure is kept in the context ...
+#define EC3D_NOTE(c_, call)                                                                    \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess && (c_)->async_err == hipSuccess) {                               \
+            (c_)->async_err = e_;                                                              \
+            (c_)->async_what = #call;                                                          \
+        }                                                                                      \
+    } while (0)
+// ... and reported where the stage's launches are checked
+#define EC3D_ASYNC_CHECK(c_)                                                                   \
+    do {                                                                                       \
+        if ((c_)->async_err != hipSuccess) {                                                   \
+            ec3d_set_error(std::string((c_)->async_what) + ": " + hipGetErrorString((c_)->async_err)); \
+            (c_)->async_err = hipSuccess;                                                      \
             return 100;                                                                        \
         }                                                                                      \
     } while (0)

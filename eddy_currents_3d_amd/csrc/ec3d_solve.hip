@@ -170,12 +170,12 @@ void ec3d_launch_x_group_of(ec3d_ctx *c, int first, int count, bool join)
     // 64 ... 256 measured within 2 % of each other on 7 - 16 Mi-row slabs, the vector kernels' own grid (512 and more) 3 % worse
     // (profiles/r05_x_groups_on_a_second_stream.log).  EC3D_XASYNC_WGS overrides (0: the vector kernels' grid).
     const int wgs = getenv("EC3D_XASYNC_WGS") ? atoi(getenv("EC3D_XASYNC_WGS")) : 128;
-    (void)hipEventRecord(c->ev_xready, c->stream);
-    if (c->xg_n > 0) (void)hipStreamWaitEvent(c->stream, c->ev_xdone[(c->xg_n - 1) & 1], 0);
-    (void)hipStreamWaitEvent(c->xstream, c->ev_xready, 0);
+    EC3D_NOTE(c, hipEventRecord(c->ev_xready, c->stream));
+    if (c->xg_n > 0) EC3D_NOTE(c, hipStreamWaitEvent(c->stream, c->ev_xdone[(c->xg_n - 1) & 1], 0));
+    EC3D_NOTE(c, hipStreamWaitEvent(c->xstream, c->ev_xready, 0));
     ec3d_launch_x_group(c->sweep, c->state, pp, sp, first, count, d2, c->vec[EC3D_VEC_X], wgs, c->xstream);
-    (void)hipEventRecord(c->ev_xdone[c->xg_n & 1], c->xstream);
-    if (join) (void)hipStreamWaitEvent(c->stream, c->ev_xdone[c->xg_n & 1], 0);
+    EC3D_NOTE(c, hipEventRecord(c->ev_xdone[c->xg_n & 1], c->xstream));
+    if (join) EC3D_NOTE(c, hipStreamWaitEvent(c->stream, c->ev_xdone[c->xg_n & 1], 0));
     ++c->xg_n;
     c->xg_done_upto = first + count - 1;
 }
@@ -190,6 +190,7 @@ int ec3d_flush_x(ec3d_ctx *c, int stop_iter)
         if (stop_iter > c->xg_done_upto) ec3d_launch_x_group_of(c, c->xg_done_upto + 1, D, true);
         else if (c->xg_n > 0) EC3D_HIP(hipStreamWaitEvent(c->stream, c->ev_xdone[(c->xg_n - 1) & 1], 0));
         EC3D_HIP(hipGetLastError());
+        EC3D_ASYNC_CHECK(c);
         return 0;
     }
     if ((D <= 1 && !ec3d_k4s(c)) || stop_iter < c->xd_base) return 0;
@@ -270,6 +271,7 @@ static int solve_core(ec3d_ctx *c, double tol, int32_t itmax, int32_t *iter, dou
         const int64_t m = std::min<int64_t>(chunk, total - launched);
         for (int64_t i = 0; i < m; ++i) ec3d_launch_iteration(c, A, (int)(++launched));
         EC3D_HIP(hipGetLastError());
+        EC3D_ASYNC_CHECK(c);
         EC3D_HIP(hipMemcpyAsync(&c->state_pinned[ci & 1], c->state, sizeof(SolverState), hipMemcpyDeviceToHost,
                                 c->stream));
         EC3D_HIP(hipEventRecord(c->ev[ci & 1], c->stream));

@@ -416,11 +416,13 @@ def count_sketch(x, m=4096, seed=0x9E3779B97F4A7C15):
 
 
 def solve_process(kind, valA, irow, jcol, b, x0, tol, itmax, nrep=1, capture_stdout=False):
-    """Run ``kind`` in {"reference", "port"} as a child process on one core.
+    """Run ``kind`` in {"reference", "port"} as a child process on one core ("port_omp": the restatement under OpenMP on
+    OMP_NUM_THREADS cores -- reporting only, see ec3d_oracle_omp.c).
     Returns (x, iter, seconds[, stdout])."""
-    exe = os.path.join(REF_DIR, "ref_solve") if kind == "reference" else os.path.join(HERE, "oracle_solve")
+    exe = (os.path.join(REF_DIR, "ref_solve") if kind == "reference" else
+           os.path.join(HERE, "oracle_solve_omp") if kind == "port_omp" else os.path.join(HERE, "oracle_solve"))
     if not os.path.exists(exe):
-        if kind == "port":
+        if kind in ("port", "port_omp"):
             build(with_ref=False)
         else:
             raise FileNotFoundError(exe)

@@ -5,6 +5,7 @@
  *   oracle/_ref/ref_solve   links oracle/_ref/libref_solver.so  = the unmodified reference
  *                            src/solvers.f90:3 sprsBCGstabWR compiled with amdflang
  *   oracle/oracle_solve     links liboracle.so (-DUSE_ORACLE)   = our C restatement
+ *   oracle/oracle_solve_omp ec3d_oracle_omp.c (-DUSE_ORACLE_OMP) = the restatement under OpenMP (all-cores column only)
  *
  * Why a process of its own: the reference keeps six work vectors as automatic arrays
  * (src/solvers.f90:11-12), i.e. 48·n bytes of stack; the caller raises RLIMIT_STACK before
@@ -21,7 +22,11 @@
 #include <string.h>
 #include <time.h>
 
-#ifdef USE_ORACLE
+#ifdef USE_ORACLE_OMP
+void oracle_omp_sprsbcgstabwr_(const double *, const int32_t *, const int32_t *, const int32_t *,
+                               const double *, double *, const double *, const int32_t *, int32_t *);
+#define SOLVE oracle_omp_sprsbcgstabwr_
+#elif defined(USE_ORACLE)
 void oracle_sprsbcgstabwr_(const double *, const int32_t *, const int32_t *, const int32_t *,
                            const double *, double *, const double *, const int32_t *, int32_t *);
 #define SOLVE oracle_sprsbcgstabwr_
