@@ -150,8 +150,7 @@ MatView DevMatrix::view() const
     v.sav_zero = sav_zero;
     v.sav_nC = sav_nC;
     for (int d = 0; d < 3; ++d) v.sav_step[d] = sav_step[d];
-    static const bool shuffle_off = getenv("EC3D_SHUFFLE") && atoi(getenv("EC3D_SHUFFLE")) == 0;
-    v.pm1 = (nb == 7 && off[2] == -1 && off[4] == 1 && !shuffle_off) ? 1 : 0;
+    v.pm1 = (nb == 7 && off[2] == -1 && off[4] == 1) ? 1 : 0;
     v.has_tail = ntail > 0;
     v.tail_id = tail_id;
     v.tile_flag = tile_flag;
@@ -542,9 +541,8 @@ static int choose_sweep(ec3d_ctx *c)
             // plane were spread over 8 steps; on a problem that fits the caches that left the shipped 102 x 102 x 24
             // system with 216 workgroups of 8 DEPENDENT steps each, under one workgroup per CU and a memory round trip per
             // step: K1 / K3 20.4 / 20.9 us against 12.4 / 13.1 us on 864 workgroups of 2 steps; 128^3: 84.8 -> 81.4 us
-            // per iteration; no difference from 4 M rows up, where the grid is full either way.  EC3D_MIN_PPS overrides.)
-            int64_t min_pps = 2;
-            if (const char *e = getenv("EC3D_MIN_PPS")) min_pps = std::max(1, atoi(e));
+            // per iteration; no difference from 4 M rows up, where the grid is full either way.)
+            const int64_t min_pps = 2;
             const int64_t max_seg = std::max<int64_t>(1, nplanes / min_pps);
             if (c->nblk_request > 0 || getenv("EC3D_NBLK_SPMV")) {
                 nseg = std::max<int64_t>(1, (want_s + cols / 2) / cols); // explicit request: nearest
@@ -605,8 +603,7 @@ static int choose_sweep(ec3d_ctx *c)
                         int64_t want_il = 512;
                         if (c->nblk_request > 0) want_il = c->nblk_request;
                         if (const char *e = getenv("EC3D_NBLK_SPMV")) want_il = std::max(8, atoi(e));
-                        int il_w = 160;
-                        if (const char *e = getenv("EC3D_IL_W")) il_w = std::max(100, atoi(e));
+                        const int il_w = 160; // (100 ... 250 measured at 256^3: 130 ... 180 within 1.5 %, profiles/r06_av256_*)
                         const int64_t cpx = (tpp + 7) / 8;
                         auto bit = [&](int64_t col, int64_t k) { return (um[(size_t)(col * nw + k / 32)] >> (k % 32)) & 1u; };
                         std::vector<int64_t> wcol((size_t)tpp, 0);
@@ -723,8 +720,7 @@ static int choose_sweep(ec3d_ctx *c)
     c->us_list = nullptr;
     c->us_host.clear();
     {
-        int local = 1;
-        if (const char *e = getenv("EC3D_ULIST_XCD")) local = atoi(e);
+        const int local = 1;
         // on runtime-shaped 2-D tiles the list holds PATCH tiles of the U block (build_patch_tables); there is no plain
         // form of it on the device, so the XCD-local order is always taken
         const bool rp = ss.rp_px > 0;
@@ -798,8 +794,7 @@ static int choose_sweep(ec3d_ctx *c)
     if (A.sav && c->halo > 0 && sw.win_nt > 0 && ss.zm_tpp > 0 && ss.rp_px == 0 && c->A.ulist &&
         (int)c->A.ulist_host.size() == c->A.ulist_n) {
         const int64_t tpp = ss.zm_tpp, npo = sw.win_nt / tpp, H = 2, blk = sw.win_blk, p0 = sw.win_t0 / tpp;
-        int split = 1;
-        if (const char *e = getenv("EC3D_SAV_SPLIT")) split = atoi(e);
+        const int split = 1;
         if (split && npo * tpp == sw.win_nt && p0 * tpp == sw.win_t0 && npo >= 2 * H + 2) {
             const int64_t npi = npo - 2 * H;
             std::vector<int32_t> ui, ub;
@@ -939,8 +934,7 @@ static int place_bands(ec3d_ctx *c)
     c->place_us.clear();
     c->place_kept = 0;
     const auto t_begin = std::chrono::steady_clock::now();
-    double budget_ms = 400.0; // the whole search: a candidate costs a 7.5 GB device copy and three launches (~15 ms at 512^3)
-    if (const char *e = getenv("EC3D_PLACE_BUDGET_MS")) budget_ms = atof(e);
+    const double budget_ms = 400.0; // the whole search: a candidate costs a 7.5 GB device copy and three launches (~15 ms at 512^3)
     const size_t bb = (size_t)A.nb * A.n_pad * sizeof(double);
     const bool verbose = getenv("EC3D_PLACE_VERBOSE") != nullptr;
     hipEvent_t e0, e1;
@@ -1015,8 +1009,7 @@ int ec3d_prepare_vectors(ec3d_ctx *c)
     for (int b = 0; b < c->A.nb; ++b) maxoff = std::max<int64_t>(maxoff, std::llabs(c->A.off[b]));
     if (c->A.sav) maxoff *= 2; // the one-sided A-U slots reach two planes
     else if (c->A.nb == 7) maxoff += std::llabs(c->A.off[5]); // 2-D tiles ask for the row beside the plane above (patch_pair)
-    int64_t galign = 64;
-    if (const char *e = getenv("EC3D_GHOST_ALIGN")) galign = std::max<int64_t>(2, atoll(e));
+    const int64_t galign = 64;
     c->ghost = round_up(maxoff + 2, galign);
     const int64_t len = c->ghost + c->A.n_pad + c->ghost;
     EC3D_HIP(hipMalloc(&c->vec_base, (size_t)len * EC3D_NVEC * sizeof(double)));
