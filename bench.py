@@ -114,14 +114,14 @@ def av_system(refine):
             np.array([dx / f] * 3), 1e-3, b)
 
 
-def av256_system(dims=(256, 256, 256)):
+def av256_system(dims=(256, 256, 256), stem="ec_src_move_hole"):
     """BASELINE config 3 at the size BASELINE.json writes: the shipped ec_src_move_hole geometry (tests/golden/g4:
     plate with a hole under a moving coil pair) resampled to 256 x 256 x 256 with the physical size kept
     (vxc.resample -- the input oracle/make_goldens.py case_g7x ran through the unmodified reference), as the tables
     ec3d_assemble takes plus the first time step's sources (src/EC3D.f90:345-365)."""
     import numpy as np
     from eddy_currents_3d_amd import host, vxc
-    g = np.load(os.path.join(REPO, "tests", "golden", "g4_ec_src_move_hole.npz"))
+    g = np.load(os.path.join(REPO, "tests", "golden", f"g4_{stem}.npz"))
     small = vxc.VxcModel(g["vox"], [str(x) for x in g["names"]], float(str(g["lattice_dim"])),
                          tuple(float(x) for x in g["adj"]))
     model = vxc.resample(small, *dims)

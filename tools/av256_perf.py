@@ -2,7 +2,7 @@
 """On-box probe for BASELINE config 3 at its stated size (ec_src_move_hole resampled to 256^3, n = 53.2 M: bench.py's
 `av256` system): per-stage times of the iteration, the bare SpMV, tile census.  Knobs come from the environment
 (EC3D_*), one process per setting, so a shell loop compares settings inside one gpurun call.
-usage: av256_perf.py [label] [sdx sdy sdz]"""
+usage: av256_perf.py [label] [sdx sdy sdz]   (STEM=LIM: the LIM geometry, e.g. 384 192 128 = BASELINE config 5)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -11,7 +11,7 @@ import eddy_currents_3d_amd as E
 
 label = sys.argv[1] if len(sys.argv) > 1 else "default"
 dims = tuple(int(a) for a in sys.argv[2:5]) if len(sys.argv) >= 5 else (256, 256, 256)
-model, t, idx, val, moving = bench.av256_system(dims)
+model, t, idx, val, moving = bench.av256_system(dims, os.environ.get("STEM", "ec_src_move_hole"))
 if os.environ.get("AIR"):      # no conductor: the three A blocks alone (what the format costs without couplings)
     t["geoPHYS_C"] = np.zeros_like(t["geoPHYS_C"])
     t["ncells0"] = 0
