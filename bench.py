@@ -317,6 +317,7 @@ def side_workload(E, name, device, K=200, W=5):
         info = s.info
         kernels, names, fmt_bytes, dom = stage_table(s, info, kernel_ms)
         geom = {"vector": int(s.geometry(0).nblk), "spmv": int(s.geometry(1).nblk)}
+        vplace = s.vector_placement() if hasattr(s, "vector_placement") else ([], -1, 0.0)
     rows = int(info.n)
     achieved = fmt_bytes[dom] * rows / (kernels[dom]["ms"] * 1e-3) / 1e9
     per_iter = sum(fmt_bytes[k] for k in kernels)
@@ -329,6 +330,8 @@ def side_workload(E, name, device, K=200, W=5):
                          "achieved": achieved, "frac": achieved / PEAK_HBM_GBS},
             "spmv": {"ms": spmv_ms, "bytes_per_row": fmt_bytes["spmv"], "GBps": fmt_bytes["spmv"] * rows / spmv_ms / 1e6,
                      "frac": fmt_bytes["spmv"] * rows / spmv_ms / 1e6 / PEAK_HBM_GBS},
+            **({"vector_placement": {"candidate_us_per_iteration": [round(v, 1) for v in vplace[0]], "kept": vplace[1],
+                                     "search_ms": round(vplace[2], 1)}} if vplace[0] else {}),
             "wall_s": time.perf_counter() - t_wall}
 
 
@@ -707,6 +710,7 @@ def main():
         fusion_state = s.fusion()
         x_every = s.x_interval() if hasattr(s, "x_interval") else 1
         k4_spmv = bool(s.k4_as_spmv()) if hasattr(s, "k4_as_spmv") else False
+        vplace = s.vector_placement() if hasattr(s, "vector_placement") else ([], -1, 0.0)
         parallelism = "single GPU"
     else:
         # one process per GPU: this rank's slab, the whole iteration loop enqueued from C++, RCCL between the ranks
@@ -937,6 +941,14 @@ def main():
                          "algorithmic_bytes_per_launch": fmt_bytes[dom] * rows,
                          "avg_launch_ms": kernel_ms[dom]},
         }
+        if world == 1 and not use_dist and vplace[0]:
+            out["config"]["vector_placement"] = {
+                "candidate_us_per_iteration": [round(v, 1) for v in vplace[0]], "kept": vplace[1],
+                "search_ms": round(vplace[2], 1),
+                "note": "where the driver puts the work vectors is worth 2-3 % of the iteration at this size (each allocation "
+                        "runs at its own time for as long as it lives), so at set-up -- outside the timed region -- the "
+                        "library iterates a right-hand side of ones on up to EC3D_PLACE_VEC (4) allocations and keeps the "
+                        "fastest (ec3d_get_vector_placement; profiles/r06_vector_placement.log)"}
         if x_every > 1:
             out["config"]["x_update_every"] = x_every
         if k4_spmv:

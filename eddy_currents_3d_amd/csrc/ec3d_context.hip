@@ -3,6 +3,7 @@
 #include "../../include/ec3d_hip.h"
 #include "ec3d_internal.hpp"
 
+#include <climits>
 #include <algorithm>
 #include <array>
 #include <cmath>
@@ -178,6 +179,13 @@ extern "C" int ec3d_create(ec3d_handle *h, int device)
     EC3D_HIP(hipStreamCreateWithFlags(&c->own_stream_obj, hipStreamNonBlocking));
     c->stream = c->own_stream_obj;
     EC3D_HIP(hipMalloc(&c->state, sizeof(SolverState)));
+    {   // a state nobody has set up yet reads "running, nothing pending": a stage driven from outside before any set-up stage
+        // (ec3d_stage; tests/test_gpu_formats_dist.py drives K1 alone) otherwise meets whatever the allocation held before --
+        // an exit word of 0 makes every stage return at once
+        SolverState init{};
+        init.stop_iter = INT_MAX;
+        EC3D_HIP(hipMemcpy(c->state, &init, sizeof init, hipMemcpyHostToDevice));
+    }
     EC3D_HIP(hipHostMalloc(&c->state_pinned, 2 * sizeof(SolverState), hipHostMallocDefault));
     for (int i = 0; i < 2; ++i) EC3D_HIP(hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming));
     EC3D_HIP(hipEventCreate(&c->t0));
@@ -254,6 +262,16 @@ void ec3d_free_matrix(ec3d_ctx *c)
     ec3d_free_rhs(c);
     ec3d_free_output(c);
     c->have_matrix = false;
+    if (c->vplace_len > 0 && c->own_vectors && c->vec_base) { // keep the placement the search chose for the next matrix of this size
+        if (c->parked_vec) (void)hipFree(c->parked_vec);
+        if (c->parked_pp) (void)hipFree(c->parked_pp);
+        c->parked_vec = c->vec_base;
+        c->parked_pp = c->pp_base;
+        c->parked_pp_len = c->pp_len;
+        c->vec_base = nullptr;
+        c->pp_base = nullptr;
+        c->pp_len = 0;
+    }
     free_vectors(c);
     for (auto &l : c->cel_bnd) l.clear();
     c->sdx = c->sdy = c->sdz = 0;
@@ -283,6 +301,9 @@ extern "C" int ec3d_destroy(ec3d_handle c)
     ec3d_free_matrix(c);
     if (c->placed_bands) (void)hipFree(c->placed_bands);
     c->placed_bands = nullptr;
+    if (c->parked_vec) (void)hipFree(c->parked_vec);
+    if (c->parked_pp) (void)hipFree(c->parked_pp);
+    c->parked_vec = c->parked_pp = nullptr;
     if (c->hist) (void)hipFree(c->hist);
     if (c->state) (void)hipFree(c->state);
     if (c->state_pinned) (void)hipHostFree(c->state_pinned);
@@ -991,8 +1012,24 @@ static int place_bands(ec3d_ctx *c)
 }
 
 // vectors: [ghost | n_pad | ghost] doubles each, zero filled; kernels only ever write [0, n_pad)
+static int place_vectors(ec3d_ctx *c, int cand, bool force);
+
 int ec3d_prepare_vectors(ec3d_ctx *c)
 {
+    // vectors and rings of a handle whose placement a search has chosen (place_vectors) are kept for the next matrix of the
+    // same size: parked by ec3d_free_matrix (or set aside here), taken back below if the lengths agree
+    double *kept_vec = c->parked_vec, *kept_pp = c->parked_pp;
+    int64_t kept_pp_len = c->parked_pp_len;
+    c->parked_vec = c->parked_pp = nullptr;
+    c->parked_pp_len = 0;
+    if (!kept_vec && c->vplace_len > 0 && c->own_vectors && c->vec_base) {
+        kept_vec = c->vec_base;
+        kept_pp = c->pp_base;
+        kept_pp_len = c->pp_len;
+        c->vec_base = nullptr;
+        c->pp_base = nullptr;
+        c->pp_len = 0;
+    }
     free_vectors(c);
     // a parked copy of plain band streams (ec3d_free_matrix keeps the placement a probe chose) that the NEW matrix did not
     // take back -- it has no plain bands, or bands of another size -- is of no use any more: 7.5 GB at 512^3 that would
@@ -1012,7 +1049,19 @@ int ec3d_prepare_vectors(ec3d_ctx *c)
     const int64_t galign = 64;
     c->ghost = round_up(maxoff + 2, galign);
     const int64_t len = c->ghost + c->A.n_pad + c->ghost;
-    EC3D_HIP(hipMalloc(&c->vec_base, (size_t)len * EC3D_NVEC * sizeof(double)));
+    if (kept_vec && c->vplace_len == len) {
+        c->vec_base = kept_vec;
+        if (kept_pp) { // (ec3d_spare_pair keeps rings of the length it wants and replaces any other)
+            c->pp_base = kept_pp;
+            c->pp_len = kept_pp_len;
+            EC3D_HIP(hipMemsetAsync(c->pp_base, 0, (size_t)c->pp_len * sizeof(double), c->stream));
+        }
+    } else {
+        if (kept_vec) (void)hipFree(kept_vec);
+        if (kept_pp) (void)hipFree(kept_pp);
+        c->vplace_len = 0;
+        EC3D_HIP(hipMalloc(&c->vec_base, (size_t)len * EC3D_NVEC * sizeof(double)));
+    }
     EC3D_HIP(hipMemsetAsync(c->vec_base, 0, (size_t)len * EC3D_NVEC * sizeof(double), c->stream));
     for (int v = 0; v < EC3D_NVEC; ++v) c->vec[v] = c->vec_base + (size_t)v * len + c->ghost;
     if (c->n_ref == 0) c->n_ref = c->A.n;
@@ -1027,7 +1076,162 @@ int ec3d_prepare_vectors(ec3d_ctx *c)
         int rc = ec3d_spare_pair(c);
         if (rc) return rc;
     }
-    return place_bands(c);
+    {
+        int rc = place_bands(c);
+        if (rc) return rc;
+    }
+    int cand = 4;
+    if (const char *e = getenv("EC3D_PLACE_VEC")) cand = atoi(e);
+    return place_vectors(c, cand, false);
+}
+
+// Where the driver puts the work vectors and the rings decides 2-3 % of the iteration at 512^3: five handles alive together
+// in one process ran it in 2.80 ... 2.89 ms, each at its own time for as long as its allocation lived, the kernels moving
+// independently of each other (K5-in-K1 1121 ... 1179 us, K2-in-K3 594 ... 616, K4 1081 ... 1119: profiles/r06_vector_placement.log)
+// -- the physical pages, which a caller cannot ask for but can look at, as place_bands does for the plain band streams.  From
+// 32 Mi rows, on a handle that runs the three-launch iteration, owns its vectors and is no z-slab: a second set of vectors + rings is allocated while the first
+// is held, a right-hand side of ones is iterated on each (one group of X updates to warm up, one timed, exits disabled) and
+// the faster set kept, until one is 2.5 % faster than the slowest seen, EC3D_PLACE_VEC candidates (default 4; 0 or 1: no
+// probe) have been tried or 0.3 s are gone.  Once per handle and vector length: ec3d_prepare_vectors keeps the chosen
+// allocation for the next matrix of that size.  Everything the probe wrote is zeroed again; the state reads "never set up".
+// (force: ec3d_place_vectors -- at any size, and again on a handle that has chosen before)
+static int place_vectors(ec3d_ctx *c, int cand, bool force)
+{
+    const int64_t len = c->ghost + c->A.n_pad + c->ghost;
+    if (c->vplace_len == len && !force) return 0; // chosen before, allocation kept
+    c->vplace_us.clear();
+    c->vplace_kept = -1;
+    c->vplace_ms = 0.f;
+    if (cand < 2 || !c->own_vectors || c->halo > 0 || c->dist || c->nranks > 1 || !c->vec_base) return 0;
+    // by itself only where it has been seen to matter: the three-launch iteration (2-D tiles from 32 Mi rows, 1 GiB per
+    // vector at 512^3).  The five-launch iteration of the structured A-V system at 53 M rows ran at 1437 ... 1447 us on every
+    // one of twelve allocations (profiles/r06_vector_placement.log): nothing to choose there.
+    if (!force && (c->A.n_pad < ((int64_t)1 << 25) || !ec3d_fused23(c) || !ec3d_fused51(c))) return 0;
+    const auto t_begin = std::chrono::steady_clock::now();
+    const double budget_ms = 300.0;
+    const bool verbose = getenv("EC3D_PLACE_VERBOSE") != nullptr;
+    const MatView V = c->A.view();
+    c->hist_cap = 0; // (no residual history from these iterations)
+    const size_t vec_bytes = (size_t)len * EC3D_NVEC * sizeof(double), pp_bytes = (size_t)c->pp_len * sizeof(double);
+    const int D = std::max(1, ec3d_xdefer(c));
+    hipEvent_t e0, e1;
+    EC3D_HIP(hipEventCreate(&e0));
+    EC3D_HIP(hipEventCreate(&e1));
+    auto time_it = [&](float &ms) -> int { // on whatever c->vec / the rings point at; leaves them dirty
+        EC3D_HIP(hipMemsetAsync(c->vec[EC3D_VEC_X], 0, (size_t)c->A.n_pad * sizeof(double), c->stream));
+        EC3D_HIP(hipMemsetAsync(c->vec[EC3D_VEC_B], 0x3f, (size_t)c->A.n * sizeof(double), c->stream)); // 4.8e-4 in every row
+        int rc = ec3d_launch_begin(c, V, -1.0); // tol < 0: no exit, no restart
+        if (rc) return rc;
+        c->xd_last = 2 * D;
+        for (int it = 1; it <= D; ++it) ec3d_launch_iteration(c, V, it);
+        EC3D_HIP(hipEventRecord(e0, c->stream));
+        for (int it = D + 1; it <= 2 * D; ++it) ec3d_launch_iteration(c, V, it);
+        EC3D_HIP(hipEventRecord(e1, c->stream));
+        EC3D_HIP(hipEventSynchronize(e1));
+        EC3D_HIP(hipGetLastError());
+        EC3D_HIP(hipEventElapsedTime(&ms, e0, e1));
+        ms /= (float)D;
+        return 0;
+    };
+    auto repoint = [&](double *vb, double *pb) -> int {
+        c->vec_base = vb;
+        for (int v = 0; v < EC3D_NVEC; ++v) c->vec[v] = vb + (size_t)v * len + c->ghost;
+        c->pp_base = pb;
+        return ec3d_spare_pair(c); // pp_len is what it wants: the ring pointers follow pp_base
+    };
+    float best = 0.f;
+    int rc = time_it(best);
+    float worst = best;
+    c->vplace_us.push_back(1e3f * best);
+    c->vplace_kept = 0;
+    if (verbose) fprintf(stderr, "libec3d_hip: vector placement 0: %.1f us per iteration\n", 1e3 * best);
+    double *best_v = c->vec_base, *best_p = c->pp_base;
+    for (int k = 1; k < cand && !rc && best > 0.975f * worst; ++k) {
+        if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count() > budget_ms) break;
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < vec_bytes + pp_bytes + ((size_t)2 << 30)) break;
+        double *nv = nullptr, *np = nullptr;
+        if (hipMalloc(&nv, vec_bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            break;
+        }
+        if (pp_bytes && hipMalloc(&np, pp_bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipFree(nv);
+            break;
+        }
+        if (hipMemsetAsync(nv, 0, vec_bytes, c->stream) != hipSuccess ||
+            (np && hipMemsetAsync(np, 0, pp_bytes, c->stream) != hipSuccess)) {
+            rc = 100;
+        }
+        if (!rc) rc = repoint(nv, np);
+        float ms = 0.f;
+        if (!rc) rc = time_it(ms);
+        if (rc) { // back to the best so far; the candidate goes
+            (void)repoint(best_v, best_p);
+            (void)hipFree(nv);
+            if (np) (void)hipFree(np);
+            break;
+        }
+        if (verbose) fprintf(stderr, "libec3d_hip: vector placement %d: %.1f us per iteration\n", k, 1e3 * ms);
+        c->vplace_us.push_back(1e3f * ms);
+        worst = std::max(worst, ms);
+        if (ms < best) {
+            best = ms;
+            c->vplace_kept = k;
+            (void)hipFree(best_v);
+            if (best_p) (void)hipFree(best_p);
+            best_v = nv;
+            best_p = np;
+        } else {
+            (void)hipFree(nv);
+            if (np) (void)hipFree(np);
+        }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (!rc) rc = repoint(best_v, best_p);
+    if (rc) return rc;
+    // as ec3d_prepare_vectors left them: everything zero, nothing set up
+    EC3D_HIP(hipMemsetAsync(c->vec_base, 0, vec_bytes, c->stream));
+    if (c->pp_base) EC3D_HIP(hipMemsetAsync(c->pp_base, 0, pp_bytes, c->stream));
+    EC3D_HIP(hipMemsetAsync(c->partials, 0, (size_t)P_NSLOT * c->sweep.pstride * sizeof(double), c->stream));
+    {
+        SolverState init{};
+        init.stop_iter = INT_MAX;
+        EC3D_HIP(hipMemcpyAsync(c->state, &init, sizeof init, hipMemcpyHostToDevice, c->stream));
+    }
+    EC3D_HIP(hipStreamSynchronize(c->stream));
+    c->it_next = 1;
+    c->vplace_len = len;
+    c->vplace_ms = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    return 0;
+}
+
+extern "C" int ec3d_place_vectors(ec3d_handle c, int32_t candidates)
+{
+    int rc = ec3d_need_matrix(c, "ec3d_place_vectors");
+    if (rc) return rc;
+    if ((rc = ec3d_single_rank_only(c, "ec3d_place_vectors"))) return rc;
+    if (!c->own_vectors) {
+        ec3d_set_error("ec3d_place_vectors: this handle works on vectors it does not own");
+        return 4;
+    }
+    EC3D_HIP(hipSetDevice(c->device));
+    EC3D_HIP(hipStreamSynchronize(c->stream));
+    return place_vectors(c, candidates, true);
+}
+
+// what the placement probe of the work vectors found on this handle (bench.py prints it)
+extern "C" int ec3d_get_vector_placement(ec3d_handle c, int32_t cap, double *candidate_us, int32_t *tried, int32_t *kept,
+                                         double *search_ms)
+{
+    if (!c || !tried || !kept) return 2;
+    *tried = (int32_t)c->vplace_us.size();
+    *kept = c->vplace_kept;
+    if (search_ms) *search_ms = c->vplace_ms;
+    for (int32_t i = 0; candidate_us && i < cap && i < *tried; ++i) candidate_us[i] = c->vplace_us[(size_t)i];
+    return 0;
 }
 
 // the second buffers of P and AP for K5-in-K1 (ec3d_fused51), and the rings of P and S for the deferred X update

@@ -403,6 +403,14 @@ struct ec3d_ctx {
     bool bands_placed = false;
     std::vector<float> place_us;
     int place_kept = -1;
+    // the work vectors' placement (place_vectors): doubles per vector the probe last ran for (0: never), the candidates'
+    // iteration times, which one was kept, what the search cost
+    int64_t vplace_len = 0;
+    double *parked_vec = nullptr, *parked_pp = nullptr; // the chosen allocation between two matrices (ec3d_free_matrix)
+    int64_t parked_pp_len = 0;
+    std::vector<float> vplace_us;
+    int vplace_kept = -1;
+    float vplace_ms = 0.f;
     std::vector<uint64_t> src_seen; // host: one bit per A unknown, all zero between calls (repeat check of ec3d_rhs_step)
     // field output (ec3d_output.hip): device scratch for the four float32 vectors, the conductor mask, and -- for
     // output overlapped with the next time step -- a side stream with two pinned host buffers

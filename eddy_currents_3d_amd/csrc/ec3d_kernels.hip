@@ -533,10 +533,21 @@ __device__ __forceinline__ void walk_spmv(const AD &A, const SW &sw, PatchPos &p
 
 // The vector a row kernel multiplies by, behind a small accessor (pair = two consecutive entries from
 // an 8-byte-aligned address, at = one gathered entry).
+// (rpair / rat + form: the same values in two halves -- the loads, and what is computed from them -- for a caller that
+// wants every request of a step out before the first one is waited for: a fused vector's pair() under `if` keeps its
+// arithmetic, and with it a wait for everything in flight, inside the branch)
 struct VecPlain {
     const double *__restrict__ x;
+    struct Raw2 { d2 v; };
+    struct Raw1 { double v; };
     __device__ __forceinline__ d2 pair(int64_t i) const { return *reinterpret_cast<const d2u *>(x + i); }
     __device__ __forceinline__ double at(int64_t i) const { return x[i]; }
+    __device__ __forceinline__ Raw2 rpair(int64_t i) const { return Raw2{pair(i)}; }
+    __device__ __forceinline__ Raw1 rat(int64_t i) const { return Raw1{x[i]}; }
+    __device__ __forceinline__ d2 form(const Raw2 &w) const { return w.v; }
+    __device__ __forceinline__ double form(const Raw1 &w) const { return w.v; }
+    static __device__ __forceinline__ void to_carry(const Raw2 &w, d2 (&c)[3]) { c[0] = w.v; }
+    static __device__ __forceinline__ Raw2 from_carry(const d2 (&c)[3]) { return Raw2{c[0]}; }
 };
 // S = R - alpha*AP formed where it is read (K2 fused into K3, src/solvers.f90:33 inside :39): every value is the same
 // expression, rounded the same way, whichever thread forms it -- the owner that stores it or a neighbour that needs it
@@ -550,6 +561,17 @@ struct VecFused {
         return d2{q.x - alpha * a.x, q.y - alpha * a.y};
     }
     __device__ __forceinline__ double at(int64_t i) const { return rv[i] - alpha * ap[i]; }
+    struct Raw2 { d2 q, a; };
+    struct Raw1 { double q, a; };
+    __device__ __forceinline__ Raw2 rpair(int64_t i) const
+    {
+        return Raw2{*reinterpret_cast<const d2u *>(rv + i), *reinterpret_cast<const d2u *>(ap + i)};
+    }
+    __device__ __forceinline__ Raw1 rat(int64_t i) const { return Raw1{rv[i], ap[i]}; }
+    __device__ __forceinline__ d2 form(const Raw2 &w) const { return d2{w.q.x - alpha * w.a.x, w.q.y - alpha * w.a.y}; }
+    __device__ __forceinline__ double form(const Raw1 &w) const { return w.q - alpha * w.a; }
+    static __device__ __forceinline__ void to_carry(const Raw2 &w, d2 (&c)[3]) { c[0] = w.q; c[1] = w.a; }
+    static __device__ __forceinline__ Raw2 from_carry(const d2 (&c)[3]) { return Raw2{c[0], c[1]}; }
 };
 // P = R + beta*(P - omega*AP) formed where it is read (K5 fused into the next iteration's K1, src/solvers.f90:46 inside
 // :30), or P = R after a restart (:47-49); reads the PREVIOUS iteration's P and AP, which live in other buffers than
@@ -572,6 +594,40 @@ struct VecFusedP {
         if (restart) return rv[i];
         return rv[i] + beta * (p[i] - omega * ap[i]);
     }
+    struct Raw2 { d2 q, pv, a; };
+    struct Raw1 { double q, pv, a; };
+    __device__ __forceinline__ Raw2 rpair(int64_t i) const
+    {
+        Raw2 w{};
+        w.q = *reinterpret_cast<const d2u *>(rv + i);
+        if (!restart) {
+            w.pv = *reinterpret_cast<const d2u *>(p + i);
+            w.a = *reinterpret_cast<const d2u *>(ap + i);
+        }
+        return w;
+    }
+    __device__ __forceinline__ Raw1 rat(int64_t i) const
+    {
+        Raw1 w{};
+        w.q = rv[i];
+        if (!restart) {
+            w.pv = p[i];
+            w.a = ap[i];
+        }
+        return w;
+    }
+    __device__ __forceinline__ d2 form(const Raw2 &w) const
+    {
+        if (restart) return w.q;
+        return d2{w.q.x + beta * (w.pv.x - omega * w.a.x), w.q.y + beta * (w.pv.y - omega * w.a.y)};
+    }
+    __device__ __forceinline__ double form(const Raw1 &w) const
+    {
+        if (restart) return w.q;
+        return w.q + beta * (w.pv - omega * w.a);
+    }
+    static __device__ __forceinline__ void to_carry(const Raw2 &w, d2 (&c)[3]) { c[0] = w.q; c[1] = w.pv; c[2] = w.a; }
+    static __device__ __forceinline__ Raw2 from_carry(const d2 (&c)[3]) { return Raw2{c[0], c[1], c[2]}; }
 };
 // Tail of one row: s += tval[e] * x[tcol[e]] over the row's slots of its 64-row slice, in stored order.
 // The loads are issued in batches (all values/columns of a batch, then all gathers, then the adds in
@@ -708,6 +764,8 @@ __device__ __forceinline__ void sav_a_post(const MatDev<FMT_SAV> &A, const doubl
 struct ZRegs {
     d2 xm, xc;
     d2 rim; // 2-D tiles: the outer neighbour row of the NEXT step's centre plane (first / last patch row only)
+    d2 cr[3]; // ... or its operands as requested at the end of a step, still on their way (patch_pair, request mode 4)
+    double edge; // 2-D tiles, request mode 5: the cell beside the patch row's end in the NEXT step's centre plane (edge lanes)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -1384,8 +1442,26 @@ __device__ __forceinline__ void sav_patch_step(const MatDev<FMT_SAV> &A, const S
 // for their outer neighbour.  Global loads per wave and step: 1 full + the rim (two of the four waves) + 2 lanes of edge,
 // where the linear tile issues 3 full + 2 lanes.  Same products in the same order: A*x is bit-identical; the dot
 // products are summed in this thread -> cell assignment, which ec3d_geom::patch_x tells the oracle's twin.
+// How patch_pair makes a step's requests, per operand vector (A/B switches of round 6; the defaults are what was measured
+// best at 512^3): 0 = every request of the step together, forms behind the LDS exchange; 1 = the rim row's requests behind
+// the barrier (the neighbouring patch's requests for the same lines are then out already); 2 = the round-5 step (edge
+// lanes and rim row each formed inside their branch, behind a wait for everything in flight); 3 = the rim row behind the
+// arrival of the plane above; 4 = the rim row at the END of the step, its operands carried into the next step unformed;
+// 5 = as 3, and the edge cells a plane ahead with the rim row (a step's first requests are the plane above and nothing else)
+#ifndef EC3D_PP_PLAIN
+#define EC3D_PP_PLAIN 2
+#endif
+#ifndef EC3D_PP_FUSED
+#define EC3D_PP_FUSED 4
+#endif
+#ifndef EC3D_PP_FUSEDP
+#define EC3D_PP_FUSEDP 5
+#endif
+template <class V> struct PatchReq { static constexpr int mode = EC3D_PP_PLAIN; };
+template <> struct PatchReq<VecFused> { static constexpr int mode = EC3D_PP_FUSED; };
+template <> struct PatchReq<VecFusedP> { static constexpr int mode = EC3D_PP_FUSEDP; };
 template <int FMT, bool NTB, class V>
-__device__ __forceinline__ void patch_pair(const MatDev<FMT> &A, const double *tbl, double *pbuf, int step, const V &x,
+__device__ __forceinline__ void patch_pair_branchy(const MatDev<FMT> &A, const double *tbl, double *pbuf, int step, const V &x,
                                            int64_t r, bool first, ZRegs &z, double &s0, double &s1, d2 &ctr)
 {
     // (Round 6 measured the plane above requested a step AHEAD here, as the interleaved march of the structured form does:
@@ -1478,6 +1554,138 @@ __device__ __forceinline__ void patch_pair(const MatDev<FMT> &A, const double *t
     *reinterpret_cast<d2 *>(nxt + 2 * t) = zp;
     z.xm = cx;
     z.xc = zp;
+}
+
+template <int FMT, bool NTB, class V>
+__device__ __forceinline__ void patch_pair(const MatDev<FMT> &A, const double *tbl, double *pbuf, int step, const V &x,
+                                           int64_t r, bool first, ZRegs &z, double &s0, double &s1, d2 &ctr)
+{
+    // (Round 6 measured the plane above requested a step AHEAD here, as the interleaved march of the structured form does:
+    // K2-in-K3 680 -> 818 us, K5-in-K1 1227 -> 1275 us at 512^3 -- behind the barrier of the LDS exchange the four waves of a
+    // workgroup wait for the slowest one's request at the end of EVERY step; profiles/r06_patch_plane_ahead_512.log.)
+    constexpr int RQ = PatchReq<V>::mode;
+    if constexpr (RQ == 2) {
+        patch_pair_branchy<FMT, NTB>(A, tbl, pbuf, step, x, r, first, z, s0, s1, ctr);
+        return;
+    }
+    constexpr int HX = EC3D_PX / 2; // lanes per patch row
+    const int t = threadIdx.x, y = t / HX, q = t % HX;
+    const int64_t sdx = A.off[5], kdz = A.off[6];
+    double *cur = pbuf + (step & 1) * EC3D_TILE, *nxt = pbuf + ((step + 1) & 1) * EC3D_TILE;
+    unsigned short cc = 0;
+    if constexpr (FMT == FMT_DICT7) cc = *reinterpret_cast<const unsigned short *>(A.cls + r);
+    d2 c[7];
+    if constexpr (FMT == FMT_DIA7) {
+#pragma unroll
+        for (int b = 0; b < 7; ++b) c[b] = load2<NTB>(A.band[b] + r);
+    }
+    // Every request of the step first, and nothing formed from any of them yet (round 6): with a fused vector
+    // (S = R - alpha*AP, P = R + beta*(P - omega*AP)) an x.at() / x.pair() under `if` kept its arithmetic inside the branch,
+    // and the branch then began with a wait for EVERYTHING in flight -- the plane above included: the edge lanes (every
+    // wave has them), then the rim row, each cost the wave a memory round trip of its own before the barrier.  Now: the
+    // raw operands of plane above, edge cell (ONE predicated request for both edge lanes, as sav_band_loads) and rim
+    // row go out together, the LDS exchange runs beside them, and the forms follow behind it, by every lane (a lane
+    // that requested nothing forms zeros).  Same expressions on the same operands: the same bits.
+    const typename V::Raw2 zp_r = x.rpair(r + kdz);
+    const bool edge = q == 0 || q == HX - 1;
+    typename V::Raw1 e_r{};
+    if (edge && (RQ != 5 || first)) e_r = x.rat(q == 0 ? r - 1 : r + 2);
+    // The patch's first and last row take their outer neighbour from memory -- one plane AHEAD: the row asked for now
+    // is the one beside the plane above, i.e. the lines the neighbouring patch is asking for at this very step as ITS
+    // plane above, so the two requests meet in the L2.  Asked for a step later (beside the centre plane, as the stencil
+    // reads it) the lines had to survive a whole step of every workgroup of the XCD: with the three operand vectors of
+    // K5-in-K1 they did not (PMC 56.3 B/row against 49; 52.3 now).  The vectors' ghost zones cover the row beside the plane
+    // above the last one (ec3d_prepare_vectors); it is never used.
+    const bool rimrow = y == 0 || y == EC3D_PY - 1;
+    const int64_t roff = y == 0 ? -sdx : sdx;
+    typename V::Raw2 rimc_r{}, rimn_r{};
+    if (rimrow) {
+        if (first) rimc_r = x.rpair(r + roff);
+        if (RQ == 0 || (RQ == 1 && first)) rimn_r = x.rpair(r + kdz + roff);
+    }
+    d2 zm, cx;
+    if (first) { // nothing carried over: plane below and centre from memory, centre into this step's buffer
+        const typename V::Raw2 zm_r = x.rpair(r - kdz), cx_r = x.rpair(r);
+        zm = x.form(zm_r);
+        cx = x.form(cx_r);
+        *reinterpret_cast<d2 *>(cur + 2 * t) = cx;
+    } else {
+        zm = z.xm;
+        cx = z.xc;
+    }
+    // this step's buffer is complete (written at the end of the previous step, or just now).  A raw barrier behind a
+    // wait for the LDS writes only: __syncthreads() also drains every global load in flight (vmcnt(0)) before the
+    // barrier, which would put the LDS exchange BEHIND the arrival of the plane above instead of beside it
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if constexpr (RQ == 1) {
+        if (rimrow && !first) rimn_r = x.rpair(r + kdz + roff);
+    }
+    d2 rimc;
+    if constexpr (RQ == 4) rimc = first ? x.form(rimc_r) : x.form(V::from_carry(z.cr));
+    else rimc = first ? x.form(rimc_r) : z.rim;
+    d2 ym = rimc, yp = rimc;
+    if (y > 0) ym = *reinterpret_cast<const d2 *>(cur + 2 * (t - HX));
+    if (y < EC3D_PY - 1) yp = *reinterpret_cast<const d2 *>(cur + 2 * (t + HX));
+    ctr = cx;
+    double left, right;
+    {
+        double ev = x.form(e_r);
+        if constexpr (RQ == 5) ev = first ? ev : z.edge;
+        const double l = __shfl_up(cx.y, 1, 64), rr = __shfl_down(cx.x, 1, 64);
+        left = q != 0 ? l : ev;
+        right = q != HX - 1 ? rr : ev;
+    }
+    const d2 zp = x.form(zp_r);
+    typename V::Raw1 en_r{};
+    if constexpr (RQ == 3 || RQ == 5) { // the rim row behind the arrival of the plane above: one more round trip, beside the sums
+        if (rimrow) rimn_r = x.rpair(r + kdz + roff);
+        if constexpr (RQ == 5) { // ... and the edge cells of the plane above, for the next step
+            if (edge) en_r = x.rat(q == 0 ? r + kdz - 1 : r + kdz + 2);
+        }
+    }
+    if constexpr (FMT == FMT_DIA7) {
+        s0 = c[0].x * zm.x;
+        s1 = c[0].y * zm.y;
+        s0 = s0 + c[1].x * ym.x;
+        s1 = s1 + c[1].y * ym.y;
+        s0 = s0 + c[2].x * left;
+        s1 = s1 + c[2].y * cx.x;
+        s0 = s0 + c[3].x * cx.x;
+        s1 = s1 + c[3].y * cx.y;
+        s0 = s0 + c[4].x * cx.y;
+        s1 = s1 + c[4].y * right;
+        s0 = s0 + c[5].x * yp.x;
+        s1 = s1 + c[5].y * yp.y;
+        s0 = s0 + c[6].x * zp.x;
+        s1 = s1 + c[6].y * zp.y;
+    } else {
+        const double *t0 = tbl + (cc & 0xFF) * 7, *t1 = tbl + (cc >> 8) * 7;
+        s0 = t0[0] * zm.x;
+        s1 = t1[0] * zm.y;
+        s0 = s0 + t0[1] * ym.x;
+        s1 = s1 + t1[1] * ym.y;
+        s0 = s0 + t0[2] * left;
+        s1 = s1 + t1[2] * cx.x;
+        s0 = s0 + t0[3] * cx.x;
+        s1 = s1 + t1[3] * cx.y;
+        s0 = s0 + t0[4] * cx.y;
+        s1 = s1 + t1[4] * right;
+        s0 = s0 + t0[5] * yp.x;
+        s1 = s1 + t1[5] * yp.y;
+        s0 = s0 + t0[6] * zp.x;
+        s1 = s1 + t1[6] * zp.y;
+    }
+    // the plane above is the next step's centre: into the other buffer (nobody reads that one before the next barrier)
+    *reinterpret_cast<d2 *>(nxt + 2 * t) = zp;
+    z.xm = cx;
+    z.xc = zp;
+    if constexpr (RQ == 4) { // the rim row requested now, waited for behind the next step's barrier
+        if (rimrow) rimn_r = x.rpair(r + kdz + roff);
+        V::to_carry(rimn_r, z.cr);
+    } else {
+        z.rim = x.form(rimn_r);
+        if constexpr (RQ == 5) z.edge = x.form(en_r);
+    }
 }
 
 // rows r, r+1 of A*x (src/solvers.f90:58-59): bands in ascending column order, then the tail.
@@ -2045,12 +2253,18 @@ __global__ __launch_bounds__(EC3D_THREADS) __attribute__((amdgpu_waves_per_eu(4)
     PatchPos pp{};
     int pstep = 0;
     double acc[1] = {0.0};
+    // (Round 6 measured AP.R0's products a step LATER -- R0's pair still requested behind the step, but waited for behind the
+    // next step's plane above: 1185-1190 us either way at 512^3, profiles/r06_patch_requests_512.log; not kept.)
     walk_spmv<FMT, ZM, FMT != FMT_SAV, PATCH>(A, sw, pp, [&](int64_t tile, auto fc) {
         EC3D_ROW_S;
         double s0, s1;
         d2 pc; // the new P[r], P[r+1]
         spmv_pair<FMT, ZM, TAIL, NT, PATCH>(A, sw, pp, tbl, stg, pstep, VecFusedP{rv, p_old, ap_old, beta, omega, restart}, r, tile,
                                             (bool)fc, zr, s0, s1, pc);
+        // R0's pair BEHIND the step, a memory round trip of its own.  Requested with the step's first requests it loses
+        // (round 3: 1176 -> 1206 us), and so it does behind the arrival of the plane above, with the rim row (round 6:
+        // 1120-1185 -> 1215-1218 us; AP.R0 summed before the step's stores instead of behind them: no difference) --
+        // profiles/r06_patch_requests_512.log
         d2 q = restart ? pc : load2<NT>(r0 + r); // after a restart R0 = R = the new P
         store2<NT>(p_new, r, nst, pc.x, pc.y);
         if (restart) store2<NT>(r0, r, nst, pc.x, pc.y);

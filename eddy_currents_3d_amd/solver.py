@@ -57,7 +57,7 @@ EXPORTS = ["sprsbcgstabwr_", "ec3d_invalidate", "ec3d_create", "ec3d_destroy", "
            "ec3d_upload", "ec3d_download", "ec3d_device_vector", "ec3d_solve_resident", "ec3d_spmv",
            "ec3d_export_csr", "ec3d_get_cel_bnd", "ec3d_get_reduction_geometry",
            "ec3d_set_workgroups", "ec3d_get_matrix_info", "ec3d_time_kernel", "ec3d_time_iterations",
-           "ec3d_iterate_begin", "ec3d_iterate", "ec3d_get_fusion", "ec3d_get_x_interval", "ec3d_get_x_groups", "ec3d_get_k4_form", "ec3d_get_band_placement", "ec3d_set_format", "ec3d_set_stream",
+           "ec3d_iterate_begin", "ec3d_iterate", "ec3d_get_fusion", "ec3d_get_x_interval", "ec3d_get_x_groups", "ec3d_get_k4_form", "ec3d_get_band_placement", "ec3d_get_vector_placement", "ec3d_place_vectors", "ec3d_set_format", "ec3d_set_stream",
            "ec3d_assemble_poisson_slab", "ec3d_vector_layout", "ec3d_adopt_vectors",
            "ec3d_dist_configure", "ec3d_dist_step", "ec3d_dist_set_boundary_rows", "ec3d_read_state_async", "ec3d_read_state", "ec3d_get_restart_count", "ec3d_set_zmarch", "ec3d_can_overlap",
            "ec3d_rhs_step", "ec3d_post_update", "ec3d_assemble_slab", "ec3d_vtk_fields", "ec3d_vtk_fields_begin", "ec3d_vtk_fields_wait",
@@ -168,6 +168,8 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.ec3d_get_x_groups.argtypes = [hp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.ec3d_get_k4_form.argtypes = [hp, C.POINTER(C.c_int32)]
     L.ec3d_get_band_placement.argtypes = [hp, C.c_int32, hp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.ec3d_get_vector_placement.argtypes = [hp, C.c_int32, hp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+    L.ec3d_place_vectors.argtypes = [hp, C.c_int32]
     L.ec3d_set_format.argtypes = [hp, C.c_int]
     L.ec3d_set_structured.argtypes = [hp, C.c_int]
     L.ec3d_get_row_map.argtypes = [hp, _i32]
@@ -611,6 +613,20 @@ class EC3DSolver:
         _chk(self.L, self.L.ec3d_get_band_placement(self.h, 16, us.ctypes.data, C.byref(tried), C.byref(kept)),
              "ec3d_get_band_placement")
         return [float(v) for v in us[:tried.value]], kept.value
+
+    def vector_placement(self):
+        """(candidate iteration times in us, index kept, search time in ms) of the placement probe of the work vectors
+        (ec3d_get_vector_placement); ([], -1, 0.0): none ran."""
+        us = np.zeros(16)
+        tried, kept, ms = C.c_int32(0), C.c_int32(-1), C.c_double(0.0)
+        _chk(self.L, self.L.ec3d_get_vector_placement(self.h, 16, us.ctypes.data, C.byref(tried), C.byref(kept), C.byref(ms)),
+             "ec3d_get_vector_placement")
+        return [float(v) for v in us[:tried.value]], kept.value, ms.value
+
+    def place_vectors(self, candidates: int = 4):
+        """Run the placement search of the work vectors now (ec3d_place_vectors): every vector is zero afterwards."""
+        _chk(self.L, self.L.ec3d_place_vectors(self.h, candidates), "ec3d_place_vectors")
+        return self.vector_placement()
 
     def restart_count(self) -> int:
         """Times the restart of src/solvers.f90:47-49 fired in the last solve (counted on the device)."""

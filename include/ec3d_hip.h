@@ -388,6 +388,19 @@ int ec3d_get_matrix_info(ec3d_handle h, ec3d_matrix_info *info);
  * their SpMV times in microseconds (the first `cap` of them), and which one was kept; *tried = 0: no probe ran. */
 int ec3d_get_band_placement(ec3d_handle h, int32_t cap, double *candidate_us, int32_t *tried, int32_t *kept);
 
+/* Work vectors of >= 32 Mi rows under the three-launch iteration (a handle that owns them and is no z-slab): the physical pages they land on are worth
+ * 2-3 % of the iteration at 512^3, so the library looks at up to EC3D_PLACE_VEC (default 4) allocations of vectors + rings
+ * when such a matrix is first set on a handle -- a right-hand side of ones iterated on each, at most ~0.3 s, once per handle
+ * and size (the chosen allocation is kept for the next matrix of that size) -- and keeps the fastest; vectors and state
+ * are left as if nothing had run.  This reports what it saw: *tried candidates, their times per iteration in microseconds
+ * (the first `cap`), which one was kept, and what the search cost (*search_ms; may be NULL); *tried = 0: no probe ran. */
+int ec3d_get_vector_placement(ec3d_handle h, int32_t cap, double *candidate_us, int32_t *tried, int32_t *kept,
+                              double *search_ms);
+/* The same search on request: at any size, with `candidates` allocations (>= 2), on a handle that has a matrix, owns its
+ * vectors and is no z-slab (4 otherwise).  EVERY work vector is zero afterwards (X, B and the warm start included): call it
+ * before uploading anything. */
+int ec3d_place_vectors(ec3d_handle h, int32_t candidates);
+
 /* Host-only check (no GPU needed, no handle): would ec3d_set_matrix_csr / sprsbcgstabwr_ store this
  * matrix in the structured A-V form?  structured = 0 means bands + tail (still exact, slower on the U
  * couplings).  The test is the one the library runs: every entry of the matrix gen_sparse_matrix builds

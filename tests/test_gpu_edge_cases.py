@@ -1,5 +1,7 @@
 """Edge cases of the hot path on the GPU: ragged/tiny/odd grids, explicit zeros, unsorted and duplicate
 CSR entries, degenerate iteration limits, the drop-in's matrix cache."""
+import os
+
 import numpy as np
 import pytest
 
@@ -217,3 +219,55 @@ def test_iterate_must_continue_its_numbering(E):
         assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
     finally:
         del os.environ["EC3D_XDEFER"]
+
+
+def test_vector_placement_search_leaves_no_trace_and_is_kept(E):
+    """Work vectors of >= 32 Mi rows get a placement search at set-up (place_vectors): a right-hand side
+    of ones is iterated on up to EC3D_PLACE_VEC allocations of vectors + rings and the fastest kept.  Whatever it picks,
+    nothing of it may show: a solve afterwards equals a handle's that never searched, bit for bit (x, iteration count,
+    residual history); the chosen allocation is kept for the next matrix of the same size (no second search).  Forced at
+    small sizes through ec3d_place_vectors -- the five-launch iteration on a cube and the structured A-V system -- and by
+    itself on 512 x 512 x 128 (the three-launch iteration with the X update deferred)."""
+    rng = np.random.Generator(np.random.PCG64(77))
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g2_conducting_hole_16x15x14.npz"))
+
+    def cube(s):
+        s.assemble_poisson(128, 128, 48)
+
+    def av(s):
+        s.assemble(g["geoPHYS"], g["geoPHYS_C"], g["valPHYS"], g["BND"], g["delta"], float(g["dt"]))
+
+    for setup, tol, itmax in ((cube, 1e-9, 60), (av, float(g["tol"]), int(g["itmax"]))):
+        with E.EC3DSolver() as fresh:
+            setup(fresh)
+            n = fresh.n
+            b = rng.standard_normal(n)
+            assert fresh.vector_placement() == ([], -1, 0.0)         # below 32 Mi rows nothing is searched
+            x_ref, it_ref, h_ref = fresh.solve(b, np.zeros(n), tol, itmax, hist_cap=64)
+        with E.EC3DSolver() as s:
+            setup(s)
+            us, kept, ms = s.place_vectors(3)
+            assert 2 <= len(us) <= 3 and 0 <= kept < len(us) and all(u > 0 for u in us) and ms > 0
+            x, it, h = s.solve(b, np.zeros(n), tol, itmax, hist_cap=64)
+            assert it == it_ref and np.array_equal(x, x_ref) and np.array_equal(h, h_ref, equal_nan=True)
+            setup(s)                                                 # the same size again: allocation kept, no search
+            assert s.vector_placement() == (us, kept, ms)
+            x, it, h = s.solve(b, np.zeros(n), tol, itmax, hist_cap=64)
+            assert it == it_ref and np.array_equal(x, x_ref) and np.array_equal(h, h_ref, equal_nan=True)
+    sdx, sdy, sdz = 512, 512, 128
+    n = sdx * sdy * sdz
+    b = rng.standard_normal(n)
+    os.environ["EC3D_PLACE_VEC"] = "0"
+    try:
+        with E.EC3DSolver() as plain:
+            plain.assemble_poisson(sdx, sdy, sdz)
+            assert plain.vector_placement() == ([], -1, 0.0)
+            x_ref, it_ref, h_ref = plain.solve(b, np.zeros(n), 1e-30, 9, hist_cap=16)
+    finally:
+        del os.environ["EC3D_PLACE_VEC"]
+    with E.EC3DSolver() as s:
+        s.assemble_poisson(sdx, sdy, sdz)
+        us, kept, ms = s.vector_placement()
+        assert 2 <= len(us) <= 4 and 0 <= kept < len(us) and us[kept] == min(us) and ms < 3000
+        x, it, h = s.solve(b, np.zeros(n), 1e-30, 9, hist_cap=16)
+        assert it == it_ref == 10 and np.array_equal(x, x_ref) and np.array_equal(h, h_ref, equal_nan=True)
