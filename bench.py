@@ -233,11 +233,18 @@ def stage_table(s, info, kernel_ms):
     # bytes_per_row is what the launches are built to move; survey_bytes_per_row stays SURVEY 8d's 56 B.
     D = s.x_interval() if hasattr(s, "x_interval") else 1
     k4s = bool(s.k4_as_spmv()) if hasattr(s, "k4_as_spmv") else False
+    xg = s.x_groups()[0] if hasattr(s, "x_groups") else 0
     if k4s:
         fmt_bytes["k3"] -= 8                       # K2-in-K3 no longer writes AS
         off, on = 25, 33 + 16 * D                  # S + class byte + R0 read, R written; + X, D P, D - 1 older S; X written
         names["k4"] = (f"k4s_x_r_spmv (K4 as an SpMV kernel: AS = A*S computed again; X = X + alpha*P + omega*S applied "
                        f"every {D} iterations, in order)")
+        if int(xg) == 2:
+            # every K4 the light launch; each group of D updates by a streaming launch of its own on the same stream
+            # (k_x_group: X, D P, D S read, X written), timed with the K4 of the group's last iteration
+            on = 25 + 16 + 16 * D
+            names["k4"] = (f"k4s_x_r_spmv (K4 as an SpMV kernel: AS = A*S computed again) + k_x_group every {D} iterations "
+                           f"(X = X + alpha*P + omega*S of the group, in order, a launch of its own on the same stream)")
     else:
         off, on = 32, 40 + 16 * D
         if D > 1:
@@ -590,6 +597,7 @@ def main():
         raise SystemExit("bench.py --workload av256 runs on one GPU")
     if args.workload == "av" and use_dist:
         raise SystemExit("bench.py --workload av runs on one GPU or on the in-library multi-GPU path")
+    x_group_mode, vplace = 0, ([], -1, 0.0)
     if in_library:
         G = args.gpus
         s = E.EC3DMulti(G, devices=devices, dictionary=args.format == "dict")
@@ -710,6 +718,7 @@ def main():
         fusion_state = s.fusion()
         x_every = s.x_interval() if hasattr(s, "x_interval") else 1
         k4_spmv = bool(s.k4_as_spmv()) if hasattr(s, "k4_as_spmv") else False
+        x_group_mode = int(s.x_groups()[0]) if hasattr(s, "x_groups") else 0
         vplace = s.vector_placement() if hasattr(s, "vector_placement") else ([], -1, 0.0)
         parallelism = "single GPU"
     else:
@@ -824,8 +833,11 @@ def main():
 
 
     class _Fusion:       # the headline handle's launches per iteration
-        def __init__(self, st, d, k4s):
-            self.st, self.d, self.k4s = st, d, k4s
+        def __init__(self, st, d, k4s, xg=0):
+            self.st, self.d, self.k4s, self.xg = st, d, k4s, xg
+
+        def x_groups(self):
+            return self.xg, 0
 
         def fusion(self):
             return self.st
@@ -835,7 +847,7 @@ def main():
 
         def k4_as_spmv(self):
             return self.k4s
-    fusion_of = _Fusion(fusion_state, x_every, k4_spmv)
+    fusion_of = _Fusion(fusion_state, x_every, k4_spmv, x_group_mode)
 
     # The north-star SpMV figure in the driver-run line: the plain 7-band DIA SpMV (56 B of coefficients + x + y =
     # 72 B/row) at the same grid, timed after the headline region on a handle of its own (the
@@ -953,6 +965,8 @@ def main():
             out["config"]["x_update_every"] = x_every
         if k4_spmv:
             out["config"]["k4_as_spmv"] = True
+        if fusion_of.xg == 2:
+            out["config"]["x_groups"] = "a launch of its own per group on the iteration's stream (k_x_group), timed with K4"
         if (in_library or use_dist) and verified:
             out["verified"] = verified
         if use_dist:

@@ -1247,6 +1247,7 @@ int ec3d_spare_pair(ec3d_ctx *c)
     c->sdepth = 1;
     c->ring_cap = 0;
     c->xasync_cap = c->xasync_forced = false;
+    c->xinline = false;
     c->xdefer = 1;
     c->pcur = c->apcur = c->scur = 1;
     // X every D-th iteration: from the size where both fusions run by themselves (everything streams from HBM there, every
@@ -1282,10 +1283,16 @@ int ec3d_spare_pair(ec3d_ctx *c)
     // section 5).  One card has no gaps worth filling; a job on several has them where halo planes and gathered sums are
     // under way, which one card cannot show.  EC3D_XASYNC=1: z-slabs that run the five-launch iteration; 2: whenever the X
     // update is deferred, three-launch slabs and plain handles too (tests).
-    int xa = 0;
-    if (const char *e = getenv("EC3D_XASYNC")) xa = atoi(e);
+    // EC3D_XASYNC=3: the groups as launches of their own on the iteration's OWN stream, each behind the K4 of its last iteration
+    // (every K4 then the light one; rings of one group).  The default of an undivided handle on the three-launch iteration
+    // (round 6, 512^3, same box: iteration 2797-2813 -> 2751-2769 us; the applying K4 in SpMV form, 2366 us with its ten more
+    // operand streams, ran 18 % over what its bytes allow -- a light K4 of 598 us and a streaming launch of ~1600 us do not;
+    // profiles/r06_x_groups_own_launch.log); 0 keeps the applying K4.
     const bool three_launch_slab = c->fuse23_ok && c->fuse51_ok && c->k4s_ok;
-    bool two_groups = D > 1 && xa != 0 && ((c->halo > 0 && !three_launch_slab) || xa == 2);
+    const bool undivided = c->halo == 0 && !c->dist && c->nranks <= 1;
+    int xa = (three_launch_slab && undivided) ? 3 : 0;
+    if (const char *e = getenv("EC3D_XASYNC")) xa = atoi(e);
+    bool two_groups = D > 1 && (xa == 1 || xa == 2) && ((c->halo > 0 && !three_launch_slab) || xa == 2);
     for (;;) {
         c->xdefer = D;
         c->ring_cap = two_groups ? 2 * D : D;
@@ -1293,6 +1300,7 @@ int ec3d_spare_pair(ec3d_ctx *c)
         c->sdepth = std::max(1, c->ring_cap);
         c->xasync_cap = two_groups;
         c->xasync_forced = two_groups && xa == 2;
+        c->xinline = D > 1 && xa == 3 && undivided;
         want = len * ((c->pdepth - 1) + 1 + (c->sdepth - 1));
         if (c->pp_base && c->pp_len != want) {
             (void)hipFree(c->pp_base);
@@ -1323,6 +1331,7 @@ int ec3d_spare_pair(ec3d_ctx *c)
         c->sdepth = 1;
         c->ring_cap = 0;
         c->xasync_cap = c->xasync_forced = false;
+        c->xinline = false;
         return 0;
     }
     if (c->xasync_cap && !c->xstream) {

@@ -322,6 +322,10 @@ struct ec3d_ctx {
     bool xasync_cap = false;  // the rings hold two groups (2 D buffers each)
     bool xasync_forced = false; // EC3D_XASYNC=2: also on a handle that is no slab (tests)
     bool slab_xasync = false; // a z-slab: the job's driver said so (every rank the same ring depth)
+    // ... or as launches of their own on the iteration's OWN stream, behind the K4 of each group's last iteration (rings of one
+    // group suffice): the undivided handle's three-launch iteration, where K4 in SpMV form with ten more operand streams in
+    // the applying launch ran 18 % over what its bytes allow and a light K4 + one streaming launch per group do not
+    bool xinline = false;
     hipStream_t xstream = nullptr;
     hipEvent_t ev_xready = nullptr, ev_xdone[2] = {nullptr, nullptr};
     // first failed runtime call of a launcher that cannot return a status (ec3d_launch_x_group_of sits inside the void stage
@@ -541,7 +545,9 @@ inline int ec3d_xdefer(const ec3d_ctx *c)
 // the pending X updates applied group by group on a stream of their own (only with the X update deferred)
 inline bool ec3d_xasync(const ec3d_ctx *c)
 {
-    if (!c->xasync_cap || ec3d_xdefer(c) <= 1) return false;
+    if (ec3d_xdefer(c) <= 1) return false;
+    if (c->xinline && !c->dist && c->halo == 0) return true;
+    if (!c->xasync_cap) return false;
     return (c->dist || c->halo != 0) ? c->slab_xasync : c->xasync_forced;
 }
 // where vector `vec` (EC3D_VEC_P / _AP / _S; anything else: the plain work vector) of iteration `it` lives on this handle

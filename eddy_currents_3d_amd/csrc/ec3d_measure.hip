@@ -65,7 +65,7 @@ extern "C" int ec3d_get_x_groups(ec3d_handle c, int32_t *second_stream, int32_t 
 {
     int rc = ec3d_need_matrix(c, "ec3d_get_x_groups");
     if (rc) return rc;
-    if (second_stream) *second_stream = ec3d_xasync(c) ? 1 : 0;
+    if (second_stream) *second_stream = !ec3d_xasync(c) ? 0 : (c->xinline && !c->dist && c->halo == 0) ? 2 : 1;
     if (groups_launched) *groups_launched = c->xg_n;
     return 0;
 }

@@ -165,6 +165,12 @@ void ec3d_launch_x_group_of(ec3d_ctx *c, int first, int count, bool join)
         pp[j] = c->pbuf[((itj + c->p_off) % pd + pd) % pd];
         sp[j] = c->sbuf[itj % c->sdepth];
     }
+    if (c->xinline) { // on the iteration's own stream, the vector kernels' grid: ordered by the stream itself
+        ec3d_launch_x_group(c->sweep, c->state, pp, sp, first, count, d2, c->vec[EC3D_VEC_X], 0, c->stream);
+        ++c->xg_n;
+        c->xg_done_upto = first + count - 1;
+        return;
+    }
     // 128 workgroups (half a workgroup per CU): beside the iteration's kernels the launch takes a small share of the
     // bandwidth, in the gaps between them -- halo planes under way, sums being gathered -- it has the card to itself.
     // 64 ... 256 measured within 2 % of each other on 7 - 16 Mi-row slabs, the vector kernels' own grid (512 and more) 3 % worse
@@ -188,7 +194,7 @@ int ec3d_flush_x(ec3d_ctx *c, int stop_iter)
         // the groups already enqueued end themselves at the exit (k_x_group); the group the exit lies in may not have
         // been enqueued yet (the host stopped before its last iteration): now, cut at the exit by the kernel itself
         if (stop_iter > c->xg_done_upto) ec3d_launch_x_group_of(c, c->xg_done_upto + 1, D, true);
-        else if (c->xg_n > 0) EC3D_HIP(hipStreamWaitEvent(c->stream, c->ev_xdone[(c->xg_n - 1) & 1], 0));
+        else if (c->xg_n > 0 && !c->xinline) EC3D_HIP(hipStreamWaitEvent(c->stream, c->ev_xdone[(c->xg_n - 1) & 1], 0));
         EC3D_HIP(hipGetLastError());
         EC3D_ASYNC_CHECK(c);
         return 0;

@@ -594,11 +594,12 @@ class EC3DSolver:
         return d.value
 
     def x_groups(self):
-        """(on a second stream?, launches so far): whether the groups of deferred X updates are applied by launches of
-        their own beside the iteration instead of by every D-th K4 (ec3d_get_x_groups)."""
+        """(how, launches so far): whether the groups of deferred X updates are applied by launches of their own instead of
+        by every D-th K4 -- 0: no; 1: on a second stream beside the iteration; 2: on the iteration's own stream, behind the
+        K4 of each group's last iteration (ec3d_get_x_groups)."""
         a, b = C.c_int32(0), C.c_int32(0)
         _chk(self.L, self.L.ec3d_get_x_groups(self.h, C.byref(a), C.byref(b)), "ec3d_get_x_groups")
-        return bool(a.value), b.value
+        return a.value, b.value
 
     def k4_as_spmv(self) -> bool:
         """K4 computes AS = A*S again instead of reading a stored AS (ec3d_get_k4_form)."""

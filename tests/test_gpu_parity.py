@@ -417,7 +417,19 @@ def test_two_dimensional_tiles_bitwise(E, oracle, grid, fuse, policy, monkeypatc
 @pytest.mark.parametrize("fuse", ["2", "2s", "0"], ids=["three-launches", "three-launches-K4-as-SpMV", "five-launches"])
 @pytest.mark.parametrize("depth", [1, 2, 3, 4])
 def test_deferred_x_update_bitwise(E, oracle, depth, fuse, grid, monkeypatch):
+    monkeypatch.setenv("EC3D_XASYNC", "0")      # the K4 of a group's last iteration applies the group itself
     deferred_x_case(E, oracle, depth, fuse, grid, monkeypatch, False)
+
+
+@pytest.mark.parametrize("grid", [(256, 8, 9), (128, 12, 10)], ids=lambda g: "x".join(map(str, g)))
+@pytest.mark.parametrize("depth", [2, 3, 4])
+def test_deferred_x_update_as_launches_of_the_iterations_stream_bitwise(E, oracle, depth, grid, monkeypatch):
+    """The default of an undivided handle on the three-launch iteration with K4 in SpMV form (from 32 Mi rows; forced on a
+    small grid here, no EC3D_XASYNC in the environment): no K4 touches X, every group of `depth` updates is applied by a
+    launch of its own (k_x_group) on the iteration's OWN stream behind the K4 of the group's last iteration, P and S in
+    rings of ONE group -- every exit at every position of a group, the itmax exit, bench-style calls: the twin's bits."""
+    monkeypatch.delenv("EC3D_XASYNC", raising=False)
+    deferred_x_case(E, oracle, depth, "2s", grid, monkeypatch, 2)
 
 
 @pytest.mark.parametrize("fuse", ["2", "2s", "0"], ids=["three-launches", "three-launches-K4-as-SpMV", "five-launches"])
@@ -461,7 +473,7 @@ def deferred_x_case(E, oracle, depth, fuse, grid, monkeypatch, second_stream):
     with E.EC3DSolver() as s:
         s.assemble_poisson(sdx, sdy, sdz)
         assert s.fusion() == ((1, 1) if fuse == "2" else (0, 0)) and s.x_interval() == depth
-        assert s.x_groups()[0] == (second_stream and depth > 1)
+        assert s.x_groups()[0] == (int(second_stream) if depth > 1 else 0)
         assert (s.geometry(0).nblk == s.geometry(1).nblk and s.geometry(0).patch_x == 128) == k4s
         # to convergence, with the history: the norms below give tolerances that end the solve at chosen iterations
         x, it, hist = s.solve(b, x0, 1e-10, 5000, hist_cap=64)
