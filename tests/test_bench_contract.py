@@ -75,11 +75,16 @@ def test_headline_line_carries_the_av_and_256_sub_records():
     d = json.loads(lines[0])
     assert d["config"]["grid"] == [512, 512, 512] and "512^3" in d["config"]["workload"]
     assert set(d["kernels"]) == {"k3", "k4", "k5"}                      # three launches, asked of the library
-    # K4 runs as an SpMV kernel that computes A*S again and applies the X updates every 4th iteration at this size
-    # (ec3d_get_k4_form, ec3d_get_x_interval): the line says so and states what the launches move next to SURVEY 8d's 56 B
-    assert d["config"]["x_update_every"] == 4 and d["config"]["k4_as_spmv"] is True
-    assert d["kernels"]["k4"]["bytes_per_row"] == 43.0 and d["kernels"]["k4"]["survey_bytes_per_row"] == 56
-    assert d["kernels"]["k3"]["bytes_per_row"] == 25 and d["config"]["bytes_per_dof_iter"]["this_format"] == 117.0
+    # K4 runs as an SpMV kernel that computes A*S again (25 B per row in every iteration); the X updates of four iterations
+    # are applied by a launch of their own on the same stream (k_x_group: X, 4 P, 4 S read, X written = 80 B per row) that is
+    # timed with the K4 of the group's last iteration (ec3d_get_k4_form, ec3d_get_x_interval, ec3d_get_x_groups): the line
+    # says so and states what the launches move next to SURVEY 8d's 56 B
+    assert d["config"]["x_update_every"] == 4 and d["config"]["k4_as_spmv"] is True and "k_x_group" in d["config"]["x_groups"]
+    assert d["kernels"]["k4"]["bytes_per_row"] == 45.0 and d["kernels"]["k4"]["survey_bytes_per_row"] == 56
+    assert d["kernels"]["k3"]["bytes_per_row"] == 25 and d["config"]["bytes_per_dof_iter"]["this_format"] == 119.0
+    vp = d["config"]["vector_placement"]    # the work vectors' placement search ran at set-up and says what it saw and cost
+    assert 2 <= len(vp["candidate_us_per_iteration"]) <= 4 and 0 <= vp["kept"] < len(vp["candidate_us_per_iteration"])
+    assert vp["search_ms"] < 3000
     pl = d["spmv_dia"]["placement"]
     assert 1 <= len(pl["candidate_us"]) <= 8 and 0 <= pl["kept"] < len(pl["candidate_us"])
     it = d["iter_dia"]         # SURVEY 8d's 264 B per DOF*iter, plain DIA, five launches, driver-timed (200 iterations)

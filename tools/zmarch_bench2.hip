@@ -264,6 +264,28 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(WPE))) void z
     acc[(int64_t)blockIdx.x * T + t] = acc0 + acc1 + acc2;
 }
 
+// One stream in, one out, z-march, planes walked upwards (DIR = +1) or downwards (-1): does a kernel that walks DOWN find the
+// planes the kernel before it wrote LAST (walking up) in the 256 MiB Infinity Cache?  (1 GiB per vector at 512^3.)
+template <int DIR, bool NTST>
+__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4))) void zcopy(Geo g, const double *__restrict__ in,
+                                                                                    double *__restrict__ out, double *__restrict__ acc)
+{
+    int64_t r0;
+    int p0, p1;
+    if (!place(g, r0, p0, p1)) return;
+    double sum = 0.0;
+    for (int k = 0; k < p1 - p0; ++k) {
+        const int p = DIR > 0 ? p0 + k : p1 - 1 - k;
+        const int64_t row = r0 + (int64_t)p * g.kdz;
+        const d2 v = ld(in + row);
+        const d2 w = d2{v.x * 1.0000001, v.y * 0.9999999};
+        if (NTST) stnt(out + row, w);
+        else *reinterpret_cast<d2 *>(out + row) = w;
+        sum += w.x + w.y;
+    }
+    acc[(int64_t)blockIdx.x * T + threadIdx.x] = sum;
+}
+
 __global__ void fill(double *r, double *ap, int64_t n)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -330,7 +352,40 @@ int main()
         snprintf(nm, sizeof nm, "lin U=2 G=%d", G);
         run(nm, [&] { lin<2><<<G, T>>>(n / (2 * T), 0.3, v[0], v[1], v[2], acc); });
     }
-    for (int nseg : {1, 2, 1, 2}) {
+    {
+        g.pps = N / 2;
+        const int G = (g.ncol + 7) / 8 * 8 * 2;
+        // a -> b by one launch, b -> c by the next: both walking up, or the second walking down; 16 B per row and launch
+        auto pair = [&](const char *name, auto second) {
+            run(name, [&] {
+                zcopy<1, true><<<G, T>>>(g, v[0], v[1], acc);
+                second();
+            });
+        };
+        pair("pair: up (nt stores) then up     [2 launches]", [&] { zcopy<1, true><<<G, T>>>(g, v[1], v[2], acc); });
+        pair("pair: up (nt stores) then DOWN   [2 launches]", [&] { zcopy<-1, true><<<G, T>>>(g, v[1], v[2], acc); });
+        run("pair: up (plain stores) then up   [2 launches]", [&] {
+            zcopy<1, false><<<G, T>>>(g, v[0], v[1], acc);
+            zcopy<1, false><<<G, T>>>(g, v[1], v[2], acc);
+        });
+        run("pair: up (plain stores) then DOWN [2 launches]", [&] {
+            zcopy<1, false><<<G, T>>>(g, v[0], v[1], acc);
+            zcopy<-1, false><<<G, T>>>(g, v[1], v[2], acc);
+        });
+        run("alternating up / DOWN over a <-> b, plain stores [2 launches]", [&] {
+            zcopy<1, false><<<G, T>>>(g, v[0], v[1], acc);
+            zcopy<-1, false><<<G, T>>>(g, v[1], v[0], acc);
+        });
+        run("alternating up / DOWN over a <-> b, nt stores [2 launches]", [&] {
+            zcopy<1, true><<<G, T>>>(g, v[0], v[1], acc);
+            zcopy<-1, true><<<G, T>>>(g, v[1], v[0], acc);
+        });
+        run("up / up over a <-> b, nt stores [2 launches]", [&] {
+            zcopy<1, true><<<G, T>>>(g, v[0], v[1], acc);
+            zcopy<1, true><<<G, T>>>(g, v[1], v[0], acc);
+        });
+    }
+    for (int nseg : {2}) {
         g.pps = (N + nseg - 1) / nseg;
         const int G = (g.ncol + 7) / 8 * 8 * nseg;
         snprintf(nm, sizeof nm, "zreg nseg=%d G=%d", nseg, G);
