@@ -959,7 +959,7 @@ def main():
                 "search_ms": round(vplace[2], 1),
                 "note": "where the driver puts the work vectors is worth 2-3 % of the iteration at this size (each allocation "
                         "runs at its own time for as long as it lives), so at set-up -- outside the timed region -- the "
-                        "library iterates a right-hand side of ones on up to EC3D_PLACE_VEC (4) allocations and keeps the "
+                        "library iterates a right-hand side of ones on up to EC3D_PLACE_VEC (6) allocations and keeps the "
                         "fastest (ec3d_get_vector_placement; profiles/r06_vector_placement.log)"}
         if x_every > 1:
             out["config"]["x_update_every"] = x_every

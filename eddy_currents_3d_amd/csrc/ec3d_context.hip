@@ -1080,7 +1080,7 @@ int ec3d_prepare_vectors(ec3d_ctx *c)
         int rc = place_bands(c);
         if (rc) return rc;
     }
-    int cand = 4;
+    int cand = 6;
     if (const char *e = getenv("EC3D_PLACE_VEC")) cand = atoi(e);
     return place_vectors(c, cand, false);
 }
@@ -1091,8 +1091,9 @@ int ec3d_prepare_vectors(ec3d_ctx *c)
 // -- the physical pages, which a caller cannot ask for but can look at, as place_bands does for the plain band streams.  From
 // 32 Mi rows, on a handle that runs the three-launch iteration, owns its vectors and is no z-slab: a second set of vectors + rings is allocated while the first
 // is held, a right-hand side of ones is iterated on each (one group of X updates to warm up, one timed, exits disabled) and
-// the faster set kept, until one is 2.5 % faster than the slowest seen, EC3D_PLACE_VEC candidates (default 4; 0 or 1: no
-// probe) have been tried or 0.3 s are gone.  Once per handle and vector length: ec3d_prepare_vectors keeps the chosen
+// the faster set kept, until one is 3.5 % faster than the slowest seen (the two levels lie 3-4 % apart; allocations in between
+// occur), EC3D_PLACE_VEC candidates (default 6; 0 or 1: no probe) have been tried or 0.3 s are gone -- of six searches with four
+// candidates one had found no allocation on the fast level.  Once per handle and vector length: ec3d_prepare_vectors keeps the chosen
 // allocation for the next matrix of that size.  Everything the probe wrote is zeroed again; the state reads "never set up".
 // (force: ec3d_place_vectors -- at any size, and again on a handle that has chosen before)
 static int place_vectors(ec3d_ctx *c, int cand, bool force)
@@ -1146,7 +1147,7 @@ static int place_vectors(ec3d_ctx *c, int cand, bool force)
     c->vplace_kept = 0;
     if (verbose) fprintf(stderr, "libec3d_hip: vector placement 0: %.1f us per iteration\n", 1e3 * best);
     double *best_v = c->vec_base, *best_p = c->pp_base;
-    for (int k = 1; k < cand && !rc && best > 0.975f * worst; ++k) {
+    for (int k = 1; k < cand && !rc && best > 0.965f * worst; ++k) {
         if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count() > budget_ms) break;
         size_t fr = 0, tot = 0;
         if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < vec_bytes + pp_bytes + ((size_t)2 << 30)) break;

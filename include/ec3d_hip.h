@@ -389,7 +389,7 @@ int ec3d_get_matrix_info(ec3d_handle h, ec3d_matrix_info *info);
 int ec3d_get_band_placement(ec3d_handle h, int32_t cap, double *candidate_us, int32_t *tried, int32_t *kept);
 
 /* Work vectors of >= 32 Mi rows under the three-launch iteration (a handle that owns them and is no z-slab): the physical pages they land on are worth
- * 2-3 % of the iteration at 512^3, so the library looks at up to EC3D_PLACE_VEC (default 4) allocations of vectors + rings
+ * 2-3 % of the iteration at 512^3, so the library looks at up to EC3D_PLACE_VEC (default 6) allocations of vectors + rings
  * when such a matrix is first set on a handle -- a right-hand side of ones iterated on each, at most ~0.3 s, once per handle
  * and size (the chosen allocation is kept for the next matrix of that size) -- and keeps the fastest; vectors and state
  * are left as if nothing had run.  This reports what it saw: *tried candidates, their times per iteration in microseconds

@@ -83,7 +83,7 @@ def test_headline_line_carries_the_av_and_256_sub_records():
     assert d["kernels"]["k4"]["bytes_per_row"] == 45.0 and d["kernels"]["k4"]["survey_bytes_per_row"] == 56
     assert d["kernels"]["k3"]["bytes_per_row"] == 25 and d["config"]["bytes_per_dof_iter"]["this_format"] == 119.0
     vp = d["config"]["vector_placement"]    # the work vectors' placement search ran at set-up and says what it saw and cost
-    assert 2 <= len(vp["candidate_us_per_iteration"]) <= 4 and 0 <= vp["kept"] < len(vp["candidate_us_per_iteration"])
+    assert 2 <= len(vp["candidate_us_per_iteration"]) <= 6 and 0 <= vp["kept"] < len(vp["candidate_us_per_iteration"])
     assert vp["search_ms"] < 3000
     pl = d["spmv_dia"]["placement"]
     assert 1 <= len(pl["candidate_us"]) <= 8 and 0 <= pl["kept"] < len(pl["candidate_us"])
