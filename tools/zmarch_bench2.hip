@@ -5,6 +5,8 @@
 //   zreg     z-march over 128x4 patches, plane above into registers, no LDS, no barrier
 //   zbar     + the centre plane through LDS with one barrier per step and the rim rows from memory (patch_pair's shape)
 //   zbar2    the same, two planes per trip (both planes' loads requested together)
+//   lin_st   the linear sweep with nontemporal loads and the store's cache policy spelled out; wr_only / rd_only
+//   zcopy    two launches in a row walking up / down (Infinity Cache)
 //   zfull<PF> the whole step of K2-in-K3 (classes, table, shuffles, edge lanes, rim rows, dots), requests PF steps ahead
 // (an LDS-DMA ring of P+2 plane slots was timed too, 577-617 us with sums that were never verified: removed)
 // Build+run on the GPU box:  hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/zmarch_bench2.hip -o /tmp/zb2 && /tmp/zb2
@@ -43,6 +45,51 @@ __global__ __launch_bounds__(T) void lin(int64_t ntiles, double alpha, const dou
             stnt(s + row, v);
             sum += v.x * v.y;
         }
+    }
+    acc[(int64_t)blockIdx.x * T + threadIdx.x] = sum;
+}
+
+// the linear sweep with the store's cache policy spelled out (gfx950: nt / sc0 / sc1 bits of global_store_dwordx4)
+template <int POL>
+__global__ __launch_bounds__(T) void lin_st(int64_t ntiles, double alpha, const double *__restrict__ r,
+                                            const double *__restrict__ ap, double *__restrict__ s, double *__restrict__ acc)
+{
+    double sum = 0.0;
+    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int64_t row = t * 2 * T + 2 * threadIdx.x;
+        const d2 a = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(ap + row));
+        const d2 q = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(r + row));
+        const d2 v = form(q, a, alpha);
+        double *p = s + row;
+        if constexpr (POL == 0) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+        if constexpr (POL == 1) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+        if constexpr (POL == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+        if constexpr (POL == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+        if constexpr (POL == 4) asm volatile("global_store_dwordx4 %0, %1, off sc0" ::"v"(p), "v"(v) : "memory");
+        if constexpr (POL == 5) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory");
+        if constexpr (POL == 6) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(v) : "memory");
+        sum += v.x * v.y;
+    }
+    acc[(int64_t)blockIdx.x * T + threadIdx.x] = sum;
+}
+// write only / read only: what the part gives either way
+template <int POL>
+__global__ __launch_bounds__(T) void wr_only(int64_t ntiles, double *__restrict__ s)
+{
+    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        double *p = s + t * 2 * T + 2 * threadIdx.x;
+        const d2 v = d2{(double)t, 1.0};
+        if constexpr (POL == 0) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+        if constexpr (POL == 1) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+        if constexpr (POL == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+    }
+}
+__global__ __launch_bounds__(T) void rd_only(int64_t ntiles, const double *__restrict__ r, double *__restrict__ acc)
+{
+    double sum = 0.0;
+    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const d2 q = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(r + t * 2 * T + 2 * threadIdx.x));
+        sum += q.x + q.y;
     }
     acc[(int64_t)blockIdx.x * T + threadIdx.x] = sum;
 }
@@ -351,6 +398,23 @@ int main()
         run(nm, [&] { lin<1><<<G, T>>>(n / (2 * T), 0.3, v[0], v[1], v[2], acc); });
         snprintf(nm, sizeof nm, "lin U=2 G=%d", G);
         run(nm, [&] { lin<2><<<G, T>>>(n / (2 * T), 0.3, v[0], v[1], v[2], acc); });
+    }
+    {
+        const int64_t nt_ = n / (2 * T);
+        for (int G : {512, 1024}) {
+#define LST(P_, NAME_)                                                                                                 \
+    snprintf(nm, sizeof nm, "lin (nt loads) stores " NAME_ " G=%d", G);                                                \
+    run(nm, [&] { lin_st<P_><<<G, T>>>(nt_, 0.3, v[0], v[1], v[2], acc); });
+            LST(0, "plain") LST(1, "nt") LST(2, "sc1") LST(3, "sc0 sc1") LST(4, "sc0") LST(5, "sc1 nt") LST(6, "sc0 sc1 nt")
+            snprintf(nm, sizeof nm, "write only (8 B/row; rate column x3) plain G=%d", G);
+            run(nm, [&] { wr_only<0><<<G, T>>>(nt_, v[2]); });
+            snprintf(nm, sizeof nm, "write only (8 B/row; rate column x3) nt G=%d", G);
+            run(nm, [&] { wr_only<1><<<G, T>>>(nt_, v[2]); });
+            snprintf(nm, sizeof nm, "write only (8 B/row; rate column x3) sc0 sc1 G=%d", G);
+            run(nm, [&] { wr_only<3><<<G, T>>>(nt_, v[2]); });
+            snprintf(nm, sizeof nm, "read only (8 B/row; rate column x3) G=%d", G);
+            run(nm, [&] { rd_only<<<G, T>>>(nt_, v[0], acc); });
+        }
     }
     {
         g.pps = N / 2;
