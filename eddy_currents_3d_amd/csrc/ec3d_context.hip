@@ -1092,8 +1092,9 @@ int ec3d_prepare_vectors(ec3d_ctx *c)
 // 32 Mi rows, on a handle that runs the three-launch iteration, owns its vectors and is no z-slab: a second set of vectors + rings is allocated while the first
 // is held, a right-hand side of ones is iterated on each (one group of X updates to warm up, one timed, exits disabled) and
 // the faster set kept, until one is 3.5 % faster than the slowest seen (the two levels lie 3-4 % apart; allocations in between
-// occur), EC3D_PLACE_VEC candidates (default 6; 0 or 1: no probe) have been tried or 0.3 s are gone -- of six searches with four
-// candidates one had found no allocation on the fast level.  Once per handle and vector length: ec3d_prepare_vectors keeps the chosen
+// occur), EC3D_PLACE_VEC candidates (default 6; 0 or 1: no probe) have been tried, the candidates besides the first add up to
+// 96 GiB, or 0.3 s are gone.  The sets that lose are freed together when the search is over (see below).  Once per handle and
+// vector length: ec3d_prepare_vectors keeps the chosen
 // allocation for the next matrix of that size.  Everything the probe wrote is zeroed again; the state reads "never set up".
 // (force: ec3d_place_vectors -- at any size, and again on a handle that has chosen before)
 static int place_vectors(ec3d_ctx *c, int cand, bool force)
@@ -1147,11 +1148,17 @@ static int place_vectors(ec3d_ctx *c, int cand, bool force)
     c->vplace_kept = 0;
     if (verbose) fprintf(stderr, "libec3d_hip: vector placement 0: %.1f us per iteration\n", 1e3 * best);
     double *best_v = c->vec_base, *best_p = c->pp_base;
+    // Candidates that lose are held until the search is over and freed together: hipMalloc, 0.5 ms as a rule, took 1.4-2 s when
+    // it came behind the frees of earlier candidates (the fifth of 15 GiB at 512^3, the second of 30 / 51 GiB at 640^3 / 768^3:
+    // profiles/r06_vector_placement.log) -- so what the search holds at once is capped: 96 GiB besides the first set.
+    std::vector<std::pair<double *, double *>> losers;
     for (int k = 1; k < cand && !rc && best > 0.965f * worst; ++k) {
         if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count() > budget_ms) break;
         size_t fr = 0, tot = 0;
-        if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < vec_bytes + pp_bytes + ((size_t)2 << 30)) break;
+        if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < vec_bytes + pp_bytes + ((size_t)8 << 30)) break;
+        if (!force && (size_t)k * (vec_bytes + pp_bytes) > ((size_t)96 << 30)) break;
         double *nv = nullptr, *np = nullptr;
+        const auto t_alloc = std::chrono::steady_clock::now();
         if (hipMalloc(&nv, vec_bytes) != hipSuccess) {
             (void)hipGetLastError();
             break;
@@ -1166,28 +1173,31 @@ static int place_vectors(ec3d_ctx *c, int cand, bool force)
             rc = 100;
         }
         if (!rc) rc = repoint(nv, np);
+        const double alloc_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_alloc).count();
         float ms = 0.f;
         if (!rc) rc = time_it(ms);
         if (rc) { // back to the best so far; the candidate goes
             (void)repoint(best_v, best_p);
-            (void)hipFree(nv);
-            if (np) (void)hipFree(np);
+            losers.emplace_back(nv, np);
             break;
         }
-        if (verbose) fprintf(stderr, "libec3d_hip: vector placement %d: %.1f us per iteration\n", k, 1e3 * ms);
+        if (verbose)
+            fprintf(stderr, "libec3d_hip: vector placement %d: %.1f us per iteration (allocated in %.1f ms)\n", k, 1e3 * ms, alloc_ms);
         c->vplace_us.push_back(1e3f * ms);
         worst = std::max(worst, ms);
         if (ms < best) {
             best = ms;
             c->vplace_kept = k;
-            (void)hipFree(best_v);
-            if (best_p) (void)hipFree(best_p);
+            losers.emplace_back(best_v, best_p);
             best_v = nv;
             best_p = np;
         } else {
-            (void)hipFree(nv);
-            if (np) (void)hipFree(np);
+            losers.emplace_back(nv, np);
         }
+    }
+    for (auto &l : losers) {
+        (void)hipFree(l.first);
+        if (l.second) (void)hipFree(l.second);
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);

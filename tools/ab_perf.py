@@ -53,4 +53,6 @@ with E.EC3DSolver(dictionary=not wl.startswith("dia")) as s:
     s.time_iterations(20)
     itr = min(s.time_iterations(200), s.time_iterations(200)) / 200
     print(f"{wl:8s} {label:28s} " + " ".join(f"{k}={1e3 * min(ms[k], ms2[k]):7.1f}" for k in ("k1", "k2", "k3", "k4", "k5")) +
-          f" sum={1e3 * tot:7.1f} iter={1e3 * itr:7.1f} spmv={1e3 * sp:7.1f} us  wg={s.geometry(0).nblk}/{s.geometry(1).nblk}", flush=True)
+          f" sum={1e3 * tot:7.1f} iter={1e3 * itr:7.1f} spmv={1e3 * sp:7.1f} us  wg={s.geometry(0).nblk}/{s.geometry(1).nblk}"
+          + (f"  search {s.vector_placement()[2]:.0f} ms, kept {s.vector_placement()[1]} of {len(s.vector_placement()[0])}"
+             if hasattr(s, "vector_placement") and s.vector_placement()[0] else ""), flush=True)
