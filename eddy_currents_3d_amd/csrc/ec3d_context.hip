@@ -713,9 +713,16 @@ static int choose_sweep(ec3d_ctx *c)
                 // With K4 as an SpMV kernel (k4s_x_r_spmv, below) and X every fourth iteration the three launches move 117 B
                 // per row instead of 154 and pay from 32 Mi rows (profiles/r04_k4s_threshold.log, five launches / three):
                 // 256^3 400 / 448 us, 512 x 512 x 96 604 / 643, 512 x 512 x 128 813 / 745, 384^3 1433 / 1353-1390, 512^3 -7.7 %.
+                // Round 6 (the z-march step without its serial round trips, the X groups as launches of their own; five / three
+                // launches on one box, us per iteration, profiles/r06_three_launch_threshold.log): 256^3 395-396 / 392-399,
+                // 512 x 512 x 64 388-391 / 381-385, 384 x 384 x 128 449 / 447, 512 x 512 x 72 438-441 / 427-432, 512 x 512 x 80
+                // 494 / 477, 512 x 512 x 96 597-598 / 570-571, 384 x 384 x 192 689-690 / 667, 512 x 512 x 112 705-706 / 658-660:
+                // from 20 Mi rows on an undivided handle (z-slabs keep 32 Mi: their three-launch plans exchange AP and R).
                 int k4s = 1;
                 if (const char *e = getenv("EC3D_K4S")) k4s = atoi(e);
-                const bool fuse_big = c->A.n_pad >= ((int64_t)1 << (k4s != 0 && A.ncls > 0 ? 25 : 26));
+                const bool undivided = c->halo == 0 && !c->dist && c->nranks <= 1;
+                const int64_t fuse_rows = !(k4s != 0 && A.ncls > 0) ? (int64_t)1 << 26 : undivided ? (int64_t)20 << 20 : (int64_t)1 << 25;
+                const bool fuse_big = c->A.n_pad >= fuse_rows;
                 int fuse = 1;
                 if (const char *e = getenv("EC3D_FUSE23")) fuse = atoi(e);
                 c->fuse23_ok = fuse == 2 || (fuse == 1 && fuse_big);

@@ -462,7 +462,7 @@ int ec3d_get_x_interval(ec3d_handle h, int32_t *iterations);
  * and gathered sums (EC3D_XASYNC=1; off by default: one card shows 0 ... 2 %).  groups_launched:
  * such launches since the last solve / ec3d_iterate_begin started (tests).
  * second_stream = 2: the same launches on the iteration's OWN stream, each behind the K4 of its group's last iteration
- * (rings of one group): the default of an undivided handle on the three-launch iteration (from 32 Mi rows), where every K4
+ * (rings of one group): the default of an undivided handle on the three-launch iteration (from 20 Mi rows), where every K4
  * is then the light launch of the SpMV form; EC3D_XASYNC=0 keeps the K4 that applies the group itself. */
 int ec3d_get_x_groups(ec3d_handle h, int32_t *second_stream, int32_t *groups_launched);
 /* 1: K4 runs as an SpMV kernel that computes AS = A*S again from the S it reads anyway (k4s_x_r_spmv) and K2-in-K3 no

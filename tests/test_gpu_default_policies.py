@@ -2,7 +2,7 @@
 GPU-order twin, bit for bit.
 
 choose_sweep (csrc/ec3d_context.hip) switches by size: nontemporal streams and the X update every fourth iteration from
-4.5 Mi rows, the next kernel's operand kept cacheable up to 32 Mi rows, and from 32 Mi rows on 2-D tiles the three-launch iteration (K2 inside K3, K5 inside
+4.5 Mi rows, the next kernel's operand kept cacheable up to 32 Mi rows, and from 20 Mi rows (undivided handle; z-slabs: 32 Mi) on 2-D tiles the three-launch iteration (K2 inside K3, K5 inside
 the next K1, P / AP in alternating buffers, K4 as an SpMV kernel that computes A S again) with the X update applied
 every fourth iteration (six iterations = one whole group and the itmax exit's partial one).  The small
 parity cases force those instances through EC3D_NT / EC3D_KEEP / EC3D_FUSE* (tests/test_gpu_parity.py); here NOTHING is
@@ -30,16 +30,17 @@ def no_knobs(monkeypatch):
         monkeypatch.delenv(k, raising=False)
 
 
-@pytest.mark.parametrize("dims, fused, iters", [((256, 256, 80), False, 8), ((512, 512, 96), False, 6),
+@pytest.mark.parametrize("dims, fused, iters", [((256, 256, 80), False, 8), ((512, 512, 72), False, 6), ((512, 512, 80), True, 6),
                                                 ((512, 512, 128), True, 6), ((512, 512, 256), True, 6)],
-                         ids=["5Mi-rows-nt-keep", "24Mi-rows-five-launches", "32Mi-rows-three-launches",
+                         ids=["5Mi-rows-nt-keep", "18Mi-rows-five-launches", "20Mi-rows-three-launches", "32Mi-rows-three-launches",
                               "64Mi-rows-three-launches"])
 def test_cube_at_the_default_policy_bitwise(E, oracle, dims, fused, iters, monkeypatch):
     """Single-component operator (BASELINE configs 2 / 4 family).  256 x 256 x 80 = 5.2 M rows: nontemporal streams,
-    AP / S / R kept cacheable, 2-D tiles, five launches.  512 x 512 x 96 = 24 Mi rows: the largest five-launch size
-    class.  512 x 512 x 128 = 2^25 rows: the size from which K2 runs inside K3, K5 inside the next K1, K4 as an SpMV
-    kernel that computes A S again (k4s_x_r_spmv) and X is updated every fourth iteration, all by themselves -- the
-    configuration of the headline 512^3 run; 512 x 512 x 256 the same on twice the planes."""
+    AP / S / R kept cacheable, 2-D tiles, five launches.  512 x 512 x 72 = 18 Mi rows: the largest five-launch size
+    class.  512 x 512 x 80 = 20 Mi rows: the size from which, on an undivided handle, K2 runs inside K3, K5 inside the next
+    K1, K4 as an SpMV kernel that computes A S again (k4s_x_r_spmv) and X is updated every fourth iteration by a launch of
+    its own, all by themselves (32 Mi rows until round 6) -- the configuration of the headline 512^3 run; 512 x 512 x 128 (from
+    where the work vectors' placement is searched too) and 512 x 512 x 256 the same on more planes."""
     no_knobs(monkeypatch)
     sdx, sdy, sdz = dims
     n = sdx * sdy * sdz

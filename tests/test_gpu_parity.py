@@ -368,7 +368,7 @@ def test_two_dimensional_tiles_bitwise(E, oracle, grid, fuse, policy, monkeypatc
     residual history -- with the thread -> cell assignment the library reports (ec3d_geom::patch_x), and the same
     system on 512-consecutive-cell tiles (EC3D_PATCH=0) gives the same A*x bit for bit and the same solution to
     rounding growth.  Grids: two patch rows of 4 / one patch column; a 256-wide grid (two patch columns); 12 rows.
-    fuse = 2: K2 inside K3 (k23_s_spmv_dots, the default from 32 Mi rows, forced here): S.S is then summed in the SpMV
+    fuse = 2: K2 inside K3 (k23_s_spmv_dots, the default from 20 Mi rows -- z-slabs 32 Mi --, forced here): S.S is then summed in the SpMV
     kernels' order, which the library reports as geometry 2 -- the twin must still match bit for bit."""
     monkeypatch.setenv("EC3D_FUSE23", fuse)
     monkeypatch.setenv("EC3D_FUSE51", fuse)      # and K5 inside the next K1 (k51_p_spmv_dot), P / AP alternating buffers
@@ -424,7 +424,7 @@ def test_deferred_x_update_bitwise(E, oracle, depth, fuse, grid, monkeypatch):
 @pytest.mark.parametrize("grid", [(256, 8, 9), (128, 12, 10)], ids=lambda g: "x".join(map(str, g)))
 @pytest.mark.parametrize("depth", [2, 3, 4])
 def test_deferred_x_update_as_launches_of_the_iterations_stream_bitwise(E, oracle, depth, grid, monkeypatch):
-    """The default of an undivided handle on the three-launch iteration with K4 in SpMV form (from 32 Mi rows; forced on a
+    """The default of an undivided handle on the three-launch iteration with K4 in SpMV form (from 20 Mi rows; forced on a
     small grid here, no EC3D_XASYNC in the environment): no K4 touches X, every group of `depth` updates is applied by a
     launch of its own (k_x_group) on the iteration's OWN stream behind the K4 of the group's last iteration, P and S in
     rings of ONE group -- every exit at every position of a group, the itmax exit, bench-style calls: the twin's bits."""
